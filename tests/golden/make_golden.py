@@ -1,0 +1,395 @@
+#!/usr/bin/env python3
+"""Pin the oracle against the imported reference and emit golden fixtures.
+
+Runs ONLY in the build container (needs /root/reference).  Usage:
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+It (1) asserts ``oracle/kokoro_oracle.py`` ≡ reference for outputs, 6 losses, all
+gradients, the param-group partition, the pre-clip classes, one full optimizer step
+(pre-clip → clip → AdamW → EMA → weight-norm) and the LR sequence; (2) writes small
+``.npz`` fixtures next to this file.  The fixtures are data only: inputs and the
+reference's outputs.
+"""
+import os
+import sys
+import types
+import json
+from unittest import mock
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/src")
+
+import numpy as np
+import torch
+
+# --- stubs for modules absent from this image -----------------------------
+tb = types.ModuleType("torch.utils.tensorboard")
+
+
+class _SW:  # no-op SummaryWriter
+    def __init__(self, *a, **k): pass
+    def __getattr__(self, n): return lambda *a, **k: None
+
+
+tb.SummaryWriter = _SW
+sys.modules["torch.utils.tensorboard"] = tb
+for name in ("torchaudio", "torchaudio.transforms", "torchaudio.functional"):
+    sys.modules[name] = mock.MagicMock()
+
+from kokoro.model.model import KokoroModel                      # noqa: E402
+from kokoro.training.losses import calculate_training_losses    # noqa: E402
+from kokoro.training.config import TrainingConfig               # noqa: E402
+from kokoro.training.trainer import KokoroTrainer               # noqa: E402
+from kokoro.training.runtime_policies import RuntimeStepPolicy  # noqa: E402
+from kokoro.utils.lengths import vectorized_expand_tokens       # noqa: E402
+import logging                                                  # noqa: E402
+
+from oracle import kokoro_oracle as O                           # noqa: E402
+
+torch.manual_seed(0)
+logging.disable(logging.CRITICAL)
+WN_CEIL = 5.0
+
+
+def ref_model(d: O.ModelDims) -> KokoroModel:
+    m = KokoroModel(d.vocab, d.mel, d.hidden, n_encoder_layers=d.enc_layers, n_heads=d.heads,
+                    encoder_ff_dim=d.enc_ff, encoder_dropout=0.0, decoder_dropout=0.0,
+                    decoder_input_dropout=0.0, n_decoder_layers=d.dec_layers, decoder_ff_dim=d.dec_ff,
+                    max_decoder_seq_len=d.max_len, variance_filter_size=d.var_filter,
+                    variance_kernel_size=d.var_kernel, variance_dropout=0.0, n_variance_bins=d.var_bins,
+                    pitch_min=0.0, pitch_max=1.0, energy_min=0.0, energy_max=1.0,
+                    use_stochastic_depth=False, qk_norm=True, ffn_output_norm=True)
+    m.train()
+    return m
+
+
+def make_trainer(model, cfg) -> KokoroTrainer:
+    t = KokoroTrainer.__new__(KokoroTrainer)
+    t.config = cfg
+    t.model = model
+    t.device = torch.device("cpu")
+    t.device_type = "cpu"
+    t.use_mixed_precision = False
+    t.scaler = None
+    t.mixed_precision_stats = {}
+    return t
+
+
+def ref_losses(model, cfg, out, batch):
+    import torch.nn as nn
+    return calculate_training_losses(
+        device=torch.device("cpu"), config=cfg, model=model,
+        criterion_mel=nn.L1Loss(reduction="none"),
+        criterion_duration=nn.HuberLoss(reduction="none", delta=1.0),
+        criterion_stop_token=nn.BCEWithLogitsLoss(reduction="none",
+                                                  pos_weight=torch.tensor([cfg.stop_token_pos_weight])),
+        criterion_pitch=nn.HuberLoss(reduction="none", delta=cfg.pitch_huber_delta),
+        criterion_energy=nn.HuberLoss(reduction="none", delta=cfg.energy_huber_delta),
+        average_by_duration=None, logger=logging.getLogger("x"),
+        predicted_mel=out[0], predicted_log_durations=out[1], predicted_stop_logits=out[2],
+        mel_specs=batch["mel_specs"], phoneme_durations=batch["phoneme_durations"],
+        stop_token_targets=batch["stop_token_targets"], mel_lengths=batch["mel_lengths"],
+        phoneme_lengths=batch["phoneme_lengths"], predicted_pitch=out[3], predicted_energy=out[4],
+        pitch_targets=batch["pitches"], energy_targets=batch["energies"])
+
+
+def run_ref(model, cfg, batch):
+    out = model(batch["phoneme_indices"], batch["mel_specs"], batch["phoneme_durations"],
+                batch["stop_token_targets"], pitch_targets=batch["pitches"],
+                energy_targets=batch["energies"], stress_indices=batch["stress_indices"])
+    ls = ref_losses(model, cfg, out, batch)
+    return out, ls
+
+
+def check(name, a, b, atol, rtol=0.0):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    err = float((a - b).abs().max()) if a.numel() else 0.0
+    tol = atol + rtol * float(b.abs().max() if b.numel() else 0)
+    status = "ok " if err <= tol else "FAIL"
+    print(f"  [{status}] {name:48s} max|Δ|={err:.3e} (tol {tol:.1e})")
+    assert err <= tol, name
+
+
+def randomise(model, seed):
+    """Push every parameter off its init so gains/biases are not 1/0 (tests scale/shift paths)."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn(p.shape, generator=g) * 0.1)
+
+
+def seeded_params(d: O.ModelDims, seed: int):
+    """RNG-free-on-disk weights: both sides regenerate them from the seed (CPU generator)."""
+    P = O.init_params(d, seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    for n, p in P.items():
+        if p.dim() == 1:
+            p.add_(torch.randn(p.shape, generator=g) * 0.1)
+    return P
+
+
+def section_model(tag: str, d: O.ModelDims, B, T, Pn, seed, ragged, save_step: bool, seeded: bool = False):
+    print(f"== {tag}: dims={d} batch=({B},{T},{Pn}) ragged={ragged} seeded={seeded}")
+    cfg = TrainingConfig()
+    hp = O.StepHyper()
+    model = ref_model(d)
+    if seeded:
+        missing, unexpected = model.load_state_dict(seeded_params(d, seed), strict=False)
+        assert not unexpected and all("bins" in m or m.endswith(".pe") for m in missing), (missing, unexpected)
+    else:
+        randomise(model, seed)
+    names = [n for n, _ in model.named_parameters()]
+    assert names == list(O.param_shapes(d).keys()), "parameter name order differs"
+    for n, p in model.named_parameters():
+        assert tuple(p.shape) == O.param_shapes(d)[n], n
+    assert list(model.state_dict().keys()) == O.state_dict_order(d), "state_dict order differs"
+    Bf = O.make_buffers(d)
+    for k, v in Bf.items():
+        check(f"buffer {k}", v, model.state_dict()[k], 0.0)
+
+    batch = O.synthetic_batch(B, T, Pn, d, seed=seed, ragged=ragged)
+    if ragged:
+        # make id 0 ("comma" quirk) appear inside a real sequence too
+        batch["phoneme_indices"][0, 2] = 0
+    P = {n: p.detach().clone() for n, p in model.named_parameters()}
+
+    out_r, ls_r = run_ref(model, cfg, batch)
+    model.zero_grad()
+    ls_r[0].backward()
+    G_r = {n: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p))
+           for n, p in model.named_parameters()}
+    none_grads = [n for n, p in model.named_parameters() if p.grad is None]
+    print(f"  reference params with grad None: {none_grads}")
+
+    G_o, ls_o, out_o = O.grads_of(P, Bf, batch, d, hp)
+    for k, r in zip(("mel", "log_dur", "stop", "pitch", "energy"), out_r):
+        check(f"out.{k}", out_o[k], r.detach(), 2e-5)
+    for k, a, b in zip(("total", "mel", "dur", "stop", "pitch", "energy"), ls_o, ls_r):
+        check(f"loss.{k}", a, b.detach(), 1e-5)
+    worst = 0.0
+    for n in names:
+        e = float((G_o[n] - G_r[n]).abs().max())
+        s = float(G_r[n].abs().max()) + 1e-12
+        worst = max(worst, e / max(s, 1e-6))
+        assert e <= 2e-6 + 2e-4 * s, (n, e, s)
+    print(f"  [ok ] all {len(names)} gradients; worst relative max-err {worst:.2e}")
+
+    fx = {"dims": np.array([d.vocab, d.mel, d.hidden, d.heads, d.enc_layers, d.dec_layers, d.enc_ff,
+                            d.dec_ff, d.var_filter, d.var_kernel, d.var_bins, d.max_len])}
+    for k, v in batch.items():
+        fx[f"batch/{k}"] = v.numpy()
+    for k, r in zip(("mel", "log_dur", "stop", "pitch", "energy"), out_r):
+        fx[f"out/{k}"] = r.detach().numpy()
+    fx["losses"] = np.array([float(x) for x in ls_r], dtype=np.float64)
+    if seeded:
+        fx["seed"] = np.array(seed)
+        fx["grad_norms"] = np.array([float(G_r[n].double().norm()) for n in names])
+        fx["grad_sums"] = np.array([float(G_r[n].double().sum()) for n in names])
+        for n in names:
+            if G_r[n].dim() == 1:
+                fx[f"grad/{n}"] = G_r[n].numpy()
+    else:
+        for n in names:
+            fx[f"param/{n}"] = P[n].numpy()
+            fx[f"grad/{n}"] = G_r[n].numpy()
+
+    # ---- one full optimizer step through the reference's own step-driver code -------
+    if save_step:
+        tr = make_trainer(model, cfg)
+        tr._setup_optimizer()
+        groups = tr.optimizer.param_groups
+        id2name = {id(p): n for n, p in model.named_parameters()}
+        table = O.group_lr_mult_wd(hp)
+        assert len(groups) == 10
+        for gi, g in enumerate(groups):
+            assert g["group_type"] == O.GROUP_TYPES[gi]
+            assert abs(g["lr"] - cfg.learning_rate * table[gi][0]) < 1e-15
+            assert abs(g["weight_decay"] - table[gi][1]) < 1e-15
+            for p in g["params"]:
+                assert O.param_group_of(id2name[id(p)]) == gi, id2name[id(p)]
+        print("  [ok ] 10 param groups: membership, lr multipliers, weight decay")
+        tr._setup_grad_explosion_tracker()
+        # scale grads up so that pre-clip and global clip both actually fire
+        with torch.no_grad():
+            for p in model.parameters():
+                if p.grad is not None:
+                    p.grad.mul_(40.0)
+        G_big = {n: G_r[n] * 40.0 for n in names}
+        clipped = tr._preclip_projection_spikes()
+        print(f"  reference pre-clipped {len(clipped)} tensors")
+        import copy
+        tr.use_ema, tr.ema_update_every, tr.ema_updates = True, 1, 0
+        tr.ema_decay = hp.ema_decay
+        tr.ema_model = copy.deepcopy(model)
+        tr._setup_weight_norm_constraints()
+        cfg.dec_ffn_max_weight_norm = WN_CEIL     # low ceiling so projection fires on tiny dims
+        ok, post = RuntimeStepPolicy(logging.getLogger("x")).optimizer_step_with_clipping(
+            model=model, optimizer=tr.optimizer, use_mixed_precision=False, device_type="cpu",
+            scaler=None, mixed_precision_stats={}, clip_norm=cfg.max_grad_norm, step_scheduler=False,
+            scheduler_per_batch=True, step_scheduler_fn=lambda: None, update_ema=True,
+            update_ema_fn=tr._update_ema)
+        assert ok
+        tr._apply_weight_norm_constraints()
+
+        hp2 = O.StepHyper(dec_ffn_max_weight_norm=WN_CEIL)
+        P2 = {n: P[n].clone() for n in names}
+        G2 = {n: G_big[n].clone() for n in names}
+        ema = {n: P[n].clone() for n in names}
+        ema.update({k: v.clone() for k, v in Bf.items()})
+        st = O.OptState()
+        info = O.optimizer_step(P2, G2, st, hp2, cfg.learning_rate, cfg.max_grad_norm, ema, Bf)
+        n_proj = sum(1 for n in names if O.is_weight_norm_target(n)
+                     and float(P2[n].norm()) > WN_CEIL - 1e-3)
+        print(f"  oracle: grad_norm={info['grad_norm']:.4f} clip_coef={info['clip_coef']:.5f} "
+              f"post_clip(ref)={post:.4f}; weight-norm projected {n_proj} matrices")
+        sd, esd = model.state_dict(), tr.ema_model.state_dict()
+        for n in names:
+            e = float((P2[n] - sd[n]).abs().max())
+            assert e <= 1e-7 + 1e-6 * float(sd[n].abs().max()), (n, e)
+            e = float((ema[n] - esd[n]).abs().max())
+            assert e <= 1e-7 + 1e-6 * float(esd[n].abs().max()), ("ema", n, e)
+        for k in Bf:
+            check(f"ema buffer {k}", ema[k], esd[k], 1e-6)
+        print("  [ok ] params + EMA after one optimizer step (pre-clip, clip, AdamW, EMA, weight-norm)")
+        fx["step/grad_scale"] = np.array(40.0)
+        fx["step/max_weight_norm"] = np.array(WN_CEIL)
+        fx["step/grad_norm"] = np.array(info["grad_norm"])
+        for n in names:
+            fx[f"step_param/{n}"] = sd[n].numpy()
+            fx[f"step_ema/{n}"] = esd[n].numpy()
+        fx["step/preclipped"] = np.array(sorted(clipped.keys()))
+    np.savez_compressed(os.path.join(HERE, f"{tag}.npz"), **fx)
+    print(f"  wrote {tag}.npz")
+
+
+def section_tables():
+    print("== tables at default dims")
+    d = O.ModelDims()
+    model = ref_model(d)
+    cfg = TrainingConfig()
+    tr = make_trainer(model, cfg)
+    tr._setup_optimizer()
+    tr._setup_grad_explosion_tracker()
+    id2name = {id(p): n for n, p in model.named_parameters()}
+    rows = []
+    hp = O.StepHyper()
+    for p in model.parameters():
+        p.grad = torch.ones_like(p) * 1e3          # large → every class clips
+    clipped = tr._preclip_projection_spikes()
+    for gi, g in enumerate(tr.optimizer.param_groups):
+        for p in g["params"]:
+            n = id2name[id(p)]
+            assert O.param_group_of(n) == gi, n
+    for n, p in model.named_parameters():
+        mx = O.preclip_max_norm(n, hp)
+        assert (n in clipped) == (mx is not None), n
+        if mx is not None:
+            assert abs(clipped[n][1] - mx) < 1e-12, n
+        rows.append({"name": n, "shape": list(p.shape), "group": O.param_group_of(n),
+                     "preclip": mx, "weight_norm": O.is_weight_norm_target(n)})
+    tr._setup_weight_norm_constraints()
+    wn = {id(w) for w in tr._dec_ff_weights + tr._enc_ff_weights}
+    assert {id(p) for n, p in model.named_parameters() if O.is_weight_norm_target(n)} == wn
+    print(f"  [ok ] {len(rows)} params; {len(clipped)} pre-clip members; {len(wn)} weight-norm targets; "
+          f"total {sum(int(np.prod(r['shape'])) for r in rows)} elements")
+    with open(os.path.join(HERE, "param_table.json"), "w") as f:
+        json.dump({"state_dict_order": list(model.state_dict().keys()), "params": rows}, f, indent=0)
+
+    # LR sequence: drive the reference scheduler exactly as train_epoch does
+    for total_steps, warm in ((60, 20), (3000, 1200), (5, 1200)):
+        cfg = TrainingConfig(); cfg.warmup_steps = warm
+        tr = make_trainer(model, cfg)
+        tr._setup_optimizer()
+
+        class _DL:
+            def __len__(self): return total_steps
+        tr.dataloader = _DL(); cfg.num_epochs = 1; cfg.gradient_accumulation_steps = 1
+        tr._setup_scheduler()
+        hp = O.StepHyper(warmup_steps=warm)
+        sch = O.LRSchedule(hp, total_steps)
+        table = O.group_lr_mult_wd(hp)
+        seq = []
+        for k in range(total_steps + 3):
+            lrs = [g["lr"] for g in tr.optimizer.param_groups]
+            seq.append(lrs)
+            for gi, lr in enumerate(lrs):
+                want = sch.base_lr(k) * table[gi][0]
+                assert abs(lr - want) <= 1e-12 + 1e-9 * abs(want), (total_steps, k, gi, lr, want)
+            tr.optimizer.step()
+            tr._step_scheduler_with_warmup()
+        print(f"  [ok ] LR sequence total_steps={total_steps} warmup={warm} ({len(seq)} steps × 10 groups)")
+        np.save(os.path.join(HERE, f"lr_seq_{total_steps}_{warm}.npy"), np.array(seq))
+
+
+def section_lengths():
+    print("== length regulator")
+    cases = []
+    g = torch.Generator().manual_seed(7)
+
+    def add(tokens, dur, max_len):
+        ref = vectorized_expand_tokens(tokens, dur, max_len=max_len)
+        got = O.length_regulate(tokens, dur, max_len)
+        assert ref.shape == got.shape, (ref.shape, got.shape)
+        assert torch.equal(ref, got)
+        idx, lens, L = O.length_regulate_index(dur.numpy(), max_len)
+        cases.append({"tokens": tokens.numpy(), "dur": dur.numpy(), "max_len": -1 if max_len is None else max_len,
+                      "out": ref.numpy(), "idx": idx, "lens": lens})
+    # the reference's own known answers (tests/unit/test_utils_lengths.py:9-41)
+    add(torch.tensor([[1, 2, 3], [4, 5, 6]]), torch.tensor([[1, 2, 0], [0, 1, 2]]), None)
+    add(torch.tensor([[1, 2, 3], [4, 5, 6]]), torch.tensor([[1, 2, 0], [0, 1, 2]]), 2)
+    add(torch.tensor([[[1.0], [2.0]], [[3.0], [4.0]]]), torch.tensor([[0, 0], [0, 0]]), None)
+    add(torch.tensor([[1, 2]]), torch.tensor([[1, 1]]), 4)
+    add(torch.tensor([[1, 2], [3, 4]]), torch.tensor([[1, 2], [0, 1]]), None)
+    add(torch.tensor([[[1.0], [2.0]]]), torch.tensor([[0, 0]]), 5)
+    for B, Pn, H, mx, ml in ((3, 7, 4, 6, None), (4, 33, 8, 9, 100), (2, 128, 4, 12, 700), (5, 16, 2, 3, 10)):
+        tok = torch.randn(B, Pn, H, generator=g)
+        dur = torch.randint(0, mx, (B, Pn), generator=g)
+        dur[0, Pn // 2:] = 0
+        add(tok, dur, ml)
+        add(tok, dur.float() + 0.7, ml)              # float durations truncate (lengths.py:31)
+        add(tok, dur - 1, ml)                         # negatives clamp to 0
+    fx = {}
+    for i, c in enumerate(cases):
+        for k, v in c.items():
+            fx[f"{i}/{k}"] = np.asarray(v)
+    fx["n"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(HERE, "length_regulator.npz"), **fx)
+    print(f"  [ok ] {len(cases)} cases bit-exact; wrote length_regulator.npz")
+
+
+def section_loss_known_answers():
+    print("== loss known answers")
+    # reference's own: tests/unit/test_trainer_loss_stability.py:35-72 (total = ln 2)
+    d = O.ModelDims()
+    hp = O.StepHyper(duration_loss_weight=0.0, stop_token_loss_weight=1.0, stop_token_pos_weight=1.0,
+                     pitch_loss_weight=0.0, energy_loss_weight=0.0)
+    batch = {"mel_specs": torch.zeros(1, 2, 80), "phoneme_durations": torch.ones(1, 2, dtype=torch.long),
+             "stop_token_targets": torch.zeros(1, 2), "mel_lengths": torch.tensor([1]),
+             "phoneme_lengths": torch.tensor([2]), "pitches": torch.zeros(1, 2), "energies": torch.zeros(1, 2)}
+    mel_pred = torch.zeros(1, 2, 80); mel_pred[0, 1, 0] = float("nan")
+    out = {"mel": mel_pred, "log_dur": torch.log(torch.tensor([[2.0, 2.0]])), "stop": torch.zeros(1, 2),
+           "pitch": torch.zeros(1, 2), "energy": torch.zeros(1, 2)}
+    ls = O.losses(out, batch, hp)
+    assert abs(float(ls[0]) - 0.6931472) < 1e-6, float(ls[0])
+    print("  [ok ] total = ln 2 with NaN in a padded frame")
+
+
+if __name__ == "__main__":
+    tiny = O.ModelDims(vocab=59, mel=20, hidden=64, heads=2, enc_layers=2, dec_layers=2, enc_ff=96,
+                       dec_ff=96, var_filter=32, var_kernel=3, var_bins=16, max_len=700)
+    section_lengths()
+    section_loss_known_answers()
+    section_model("tiny_full", tiny, B=2, T=40, Pn=6, seed=11, ragged=False, save_step=False)
+    section_model("tiny_ragged", tiny, B=3, T=37, Pn=9, seed=12, ragged=True, save_step=True)
+    # chunk boundary of the variance predictors (T > 512 ⇒ two GroupNorm chunks), head_dim 64
+    mid = O.ModelDims(vocab=59, mel=80, hidden=128, heads=2, enc_layers=1, dec_layers=1, enc_ff=192,
+                      dec_ff=192, var_filter=64, var_kernel=3, var_bins=256, max_len=700)
+    section_model("mid_chunked", mid, B=2, T=600, Pn=40, seed=13, ragged=True, save_step=False, seeded=True)
+    # default dims (49.4 M params), small ragged batch: weights regenerated from the seed on both sides
+    section_model("full_dims", O.ModelDims(), B=2, T=96, Pn=12, seed=14, ragged=True, save_step=False, seeded=True)
+    section_tables()
+    print("ALL REFERENCE CHECKS PASSED")
