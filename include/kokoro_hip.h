@@ -1,0 +1,217 @@
+/* libkokoro_hip.so — C ABI of the MI355X (gfx950) kernels for the Kokoro acoustic-model train step.
+ *
+ * The reference (igorshmukler/kokoro-ruslan) is pure PyTorch and has no FFI; every entry point
+ * below therefore replaces an ATen call site of the reference's hot path (cited per function as
+ * `file:line` relative to /root/reference/src/kokoro).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer owned by the caller and must
+ *    stay alive until `stream` has passed the call; kernels never allocate and never synchronise;
+ *  - every function enqueues on `stream` (a hipStream_t passed as void*) and returns 0 on success,
+ *    a negative KK_E* code or a positive hipError_t otherwise; `kk_last_error()` holds the message;
+ *  - all float tensors are fp32 row-major; `math` selects the MFMA arithmetic of matmul-class
+ *    kernels: KK_MATH_F32 (v_mfma_f32_32x32x2_f32, exact fp32 — the parity mode) or KK_MATH_BF16
+ *    (operands rounded to bf16 at LDS staging, v_mfma_f32_32x32x16_bf16, fp32 accumulate);
+ *  - parameter-gradient outputs ACCUMULATE (+=) into their destination: the caller zeroes the
+ *    gradient arena once per accumulation cycle (reference: optimizer.zero_grad, trainer.py:2258).
+ */
+#ifndef KOKORO_HIP_H
+#define KOKORO_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KK_ABI_VERSION 1
+#define KK_MATH_F32 0
+#define KK_MATH_BF16 1
+#define KK_EINVAL (-22)
+#define KK_ENOTSUP (-95)
+#define KK_SEG_ALIGN 1024 /* arena segments start on multiples of this many elements */
+
+int kk_abi_version(void);
+const char *kk_last_error(void);
+
+/* ---- GEMM family (nn.Linear fwd/dgrad/wgrad: transformers.py:131-136,90-91; model.py:173,190) ----
+ * C[M,N] = alpha * op(A)·op(B) (+bias[n]) (+residual[(m % res_mod), n]) (+ beta*C).
+ * ta=0: A stored [M,K] (lda, K contiguous); ta=1: A stored [K,M] (M contiguous).
+ * tb=0: B stored [N,K] (nn.Linear weight layout);  tb=1: B stored [K,N].
+ * split_k>1 partitions K over blockIdx.z and accumulates with fp32 atomics (requires beta==1 or a
+ * contiguous C that the call zero-fills when beta==0; bias/residual are added by slice 0). */
+int kk_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, const float *A, int64_t lda,
+            const float *B, int64_t ldb, float beta, float *C, int64_t ldc, const float *bias,
+            const float *residual, int64_t ldr, int64_t res_mod, int split_k, int math, void *stream);
+/* out[n] += sum_m X[m,n]  (bias gradients). */
+int kk_colsum_acc(const float *X, int64_t ldx, int64_t M, int64_t N, float *out, void *stream);
+
+/* ---- attention (F.scaled_dot_product_attention, transformers.py:393-398; masks :299-316) ----
+ * Token-major operands: element (b, s, head, d) of X lives at X[(b*S + s)*ldx + head*64 + d]; head_dim is 64.
+ * key_mask: optional uint8 [B,Sk], non-zero = key masked (−inf); causal: key > query masked.
+ * LSE [B,heads,Sq] = log-sum-exp of the scaled scores (saved for backward). */
+int kk_attn_fwd(const float *Q, const float *K, const float *V, float *O, float *LSE, int B, int heads,
+                int Sq, int Sk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                const uint8_t *key_mask, int causal, float scale, int math, void *stream);
+/* Delta[b,head,q] = sum_d dO·O (first step of the backward). */
+int kk_attn_delta(const float *O, const float *dO, float *Delta, int B, int heads, int Sq, int64_t ldo,
+                  int64_t lddo, void *stream);
+int kk_attn_bwd_dq(const float *Q, const float *K, const float *V, const float *dO, const float *LSE,
+                   const float *Delta, float *dQ, int B, int heads, int Sq, int Sk, int64_t ldq, int64_t ldk,
+                   int64_t ldv, int64_t lddo, int64_t lddq, const uint8_t *key_mask, int causal, float scale,
+                   int math, void *stream);
+int kk_attn_bwd_dkv(const float *Q, const float *K, const float *V, const float *dO, const float *LSE,
+                    const float *Delta, float *dK, float *dV, int B, int heads, int Sq, int Sk, int64_t ldq,
+                    int64_t ldk, int64_t ldv, int64_t lddo, int64_t lddk, int64_t lddv,
+                    const uint8_t *key_mask, int causal, float scale, int math, void *stream);
+
+/* ---- norms ----
+ * LayerNorm (nn.LayerNorm eps 1e-5; transformers.py:461-462,518-520,612; model.py:122). */
+int kk_layernorm_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean,
+                     float *rstd, int64_t rows, int H, void *stream);
+int kk_layernorm_bwd(const float *dy, const float *x, const float *gamma, const float *mean,
+                     const float *rstd, float *dx, int dx_accumulate, float *dgamma, float *dbeta,
+                     int64_t rows, int H, void *stream);
+/* RMSNorm over the full row, eps = FLT_EPSILON (GLU output_norm, transformers.py:94,109-110), fused with the
+ * residual add of the block: y = (residual? residual : 0) + x*rstd*gain. */
+int kk_rmsnorm_fwd(const float *x, const float *gain, const float *residual, float *y, float *rstd,
+                   int64_t rows, int H, void *stream);
+int kk_rmsnorm_bwd(const float *dy, const float *x, const float *gain, const float *rstd, float *dx,
+                   float *dgain, int64_t rows, int H, void *stream);
+/* Per-head (64-wide) RMSNorm + optional RoPE rotate-half (transformers.py:260-277;
+ * positional_encoding.py:196-209).  x/y element (row, head, d) at [row*ld + head*64 + d];
+ * position = row % S; cos/sin tables are [>=S, 64]. */
+int kk_headnorm_rope_fwd(const float *x, int64_t ldx, const float *gain, float *y, int64_t ldy, int64_t rows,
+                         int heads, int S, const float *cos_t, const float *sin_t, void *stream);
+int kk_headnorm_rope_bwd(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *gain,
+                         float *dx, int64_t lddx, float *dgain, int64_t rows, int heads, int S,
+                         const float *cos_t, const float *sin_t, void *stream);
+
+/* ---- GLU feed-forward gate (transformers.py:107-108; exact-erf GELU): g = gelu(h[:, :F]) * h[:, F:] ---- */
+int kk_glu_fwd(const float *h, float *g, int64_t rows, int F, void *stream);
+int kk_glu_bwd(const float *dg, const float *h, float *dh, int64_t rows, int F, void *stream);
+
+/* ---- embeddings + sinusoid PE (model.py:375-378; positional_encoding.py:66-74) ---- */
+int kk_embed_fwd(const int64_t *ids, const int64_t *stress, const float *emb, const float *stress_emb,
+                 const float *pe, float *out, int B, int P, int H, float scale, void *stream);
+int kk_embed_bwd(const int64_t *ids, const int64_t *stress, const float *dout, float *demb,
+                 float *dstress_emb, int B, int P, int H, float scale, void *stream);
+
+/* ---- length regulator (utils/lengths.py:16-96): integer index expansion + payload gather ----
+ * idx[b,f] = #{j : cumsum(max(dur_b,0))[j] <= f} for f < min(sum dur_b, L), else -1; lens[b] = min(sum, L);
+ * total[b] = sum dur_b (un-clipped).  Bit-exact contract. */
+int kk_length_regulate_index(const int64_t *dur, int64_t *idx, int64_t *lens, int64_t *total, int B, int P,
+                             int L, void *stream);
+int kk_length_regulate_gather(const float *x, const int64_t *idx, float *out, int B, int P, int L, int H,
+                              void *stream);
+/* max over a non-negative int64 vector (trainer.py:2224 reads phoneme_durations.max()). */
+int kk_max_i64(const int64_t *x, int64_t n, int64_t *out, void *stream);
+
+/* ---- variance adaptor pieces (variance_predictor.py:89-115, 363-437) ---- */
+/* col[(b,l), c*3+k] = x[b, l+k-1, c] inside the 512-frame chunk of l, else 0. */
+int kk_im2col3_fwd(const float *x, float *col, int B, int L, int C, int chunk, void *stream);
+int kk_im2col3_bwd(const float *dcol, float *dx, int B, int L, int C, int chunk, void *stream);
+/* GroupNorm(1,C) over (C x chunk frames) per sample per chunk + ReLU; chunks with < 2 frames yield zeros.
+ * stats [B*nchunks, 2] = (mean, rstd). */
+int kk_groupnorm_relu_fwd(const float *x, const float *gamma, const float *beta, float *y, float *stats,
+                          double *scratch, int B, int L, int C, int chunk, void *stream);
+int kk_groupnorm_relu_bwd(const float *dy, const float *x, const float *y, const float *gamma,
+                          const float *stats, float *dx, float *dgamma, float *dbeta, double *scratch, int B,
+                          int L, int C, int chunk, void *stream);
+/* out[r] = mask[r] ? 0 : dot(x[r,:], w) + b  (Linear(C->1) + masked_fill; also the stop head, model.py:562). */
+int kk_rowdot_fwd(const float *x, const float *w, const float *b, const uint8_t *mask, float *out,
+                  int64_t rows, int C, int L, int chunk, void *stream);
+int kk_rowdot_bwd(const float *dout, const float *x, const float *w, const uint8_t *mask, float *dx,
+                  float *dw, float *db, int64_t rows, int C, int L, int chunk, void *stream);
+/* frame_mask[b,f] = f >= lens[b]; bucketize(right=False) + two embedding adds + masked_fill. */
+int kk_bucket_embed_add_fwd(const float *x, const float *pitch, const float *energy, const float *pbins,
+                            const float *ebins, const float *pemb, const float *eemb, const int64_t *lens,
+                            float *out, int32_t *pidx, int32_t *eidx, uint8_t *frame_mask, int B, int T,
+                            int H, int nbins, void *stream);
+int kk_bucket_embed_add_bwd(const float *dout, const int32_t *pidx, const int32_t *eidx,
+                            const uint8_t *frame_mask, float *dpemb, float *deemb, int B, int T, int H,
+                            void *stream);
+/* text key mask: mask[i] = (ids[i] == 0)  (model.py:586-587). */
+int kk_ids_eq_zero(const int64_t *ids, uint8_t *mask, int64_t n, void *stream);
+/* decoder input shift-right (model.py:519): out[b,0,:]=0, out[b,t,:]=mel[b,t-1,:]. */
+int kk_shift_right(const float *mel, float *out, int B, int T, int M, void *stream);
+
+/* ---- losses (training/losses.py:9-216) ----
+ * acc: 10 doubles (5 sums, 5 counts) zeroed by the call.  losses: 6 floats (total, mel, dur, stop, pitch, energy).
+ * coef: 5 floats = d(total*loss_scale)/d(per-element loss) for the backward kernel. */
+typedef struct KkLossCfg {
+    float w_dur, w_stop, w_pitch, w_energy;
+    float delta_dur, delta_pitch, delta_energy, pos_weight;
+    float loss_scale;             /* 1/accumulation divisor (trainer.py:2284-2294) */
+    int adaptive;                 /* 1: also apply the batch-shape loss scale of trainer.py:2218-2242 on device */
+} KkLossCfg;
+int kk_losses_fwd(const float *mel_pred, const float *mel_tgt, const float *dur_pred, const int64_t *dur,
+                  const float *stop_logit, const float *stop_tgt, const float *pitch_pred,
+                  const float *pitch_tgt, const float *energy_pred, const float *energy_tgt,
+                  const int64_t *mel_len, const int64_t *ph_len, int B, int T, int P, int M,
+                  const KkLossCfg *cfg, const int64_t *max_dur /* device scalar or null */, double *acc,
+                  float *losses, float *coef, void *stream);
+int kk_losses_bwd(const float *mel_pred, const float *mel_tgt, const float *dur_pred, const int64_t *dur,
+                  const float *stop_logit, const float *stop_tgt, const float *pitch_pred,
+                  const float *pitch_tgt, const float *energy_pred, const float *energy_tgt,
+                  const int64_t *mel_len, const int64_t *ph_len, int B, int T, int P, int M,
+                  const KkLossCfg *cfg, const float *coef, float *dmel, float *ddur, float *dstop,
+                  float *dpitch, float *denergy, void *stream);
+
+/* ---- optimizer pass over the flat arena (trainer.py:1332-1407,2355-2405; runtime_policies.py:14-87;
+ *      torch AdamW; trainer.py:1491-1517,882-912) ---- */
+typedef struct KkOptCfg {
+    /* schedule (trainer.py:691-772,1519-1575) */
+    double learning_rate, max_lr, warmup_start_lr, warmup_target_lr, pct_start, div_factor, final_div_factor;
+    int64_t warmup_steps, onecycle_steps;
+    int use_warmup;
+    /* AdamW */
+    double beta1, beta2, eps;
+    /* clipping */
+    double max_grad_norm;
+    int64_t mel_length;           /* batch mel length for the adaptive clip (trainer.py:2218-2242) */
+    /* explosion tracker (trainer.py:1315-1330,2367-2405) */
+    double expl_alpha, expl_abs_floor, expl_multiplier, expl_warmup_floor;
+    int64_t expl_warmup_steps, expl_min_ema_steps;
+    /* EMA + weight-norm */
+    double ema_decay;
+    double max_weight_norm;
+} KkOptCfg;
+/* device-resident optimizer state (doubles): see kk_opt_state_* indices */
+#define KK_OS_SKIPPED 0      /* boundaries skipped for non-finite grads */
+#define KK_OS_EXPL_EMA 1
+#define KK_OS_EXPL_EMA_STEPS 2
+#define KK_OS_EXPL_STREAK 3
+#define KK_OS_LAST_GRAD_NORM 4
+#define KK_OS_LAST_CLIP_COEF 5
+#define KK_OS_LAST_SKIP 6
+#define KK_OS_LAST_BASE_LR 7
+#define KK_OS_LAST_CLIP_NORM 8
+#define KK_OS_EXPL_EMA_VALID 9
+#define KK_OS_ATTEMPT 10      /* optimizer-step boundaries reached so far (successful = ATTEMPT - SKIPPED) */
+#define KK_OS_SIZE 16
+/* sumsq[seg] (double, zeroed by the call) = sum of squares of each arena segment of `buf`. */
+int kk_seg_sumsq(const float *buf, const int32_t *block_seg, int64_t nblocks, double *sumsq, int nseg,
+                 void *stream);
+/* One-thread-block kernel: per-parameter pre-clip, total norm, non-finite check, explosion tracker,
+ * adaptive + global clip, LR schedule -> per-segment gradient scale / lr / step-size constants. */
+int kk_opt_prepare(const double *grad_sumsq, const float *seg_preclip, const float *seg_lr_mult,
+                   const float *seg_wd, int nseg, const int64_t *max_dur, const KkOptCfg *cfg,
+                   double *opt_state, float *seg_gscale, float *seg_decay, float *seg_stepsize,
+                   float *step_consts /* [4]: skip, sqrt(1-beta2^t), eps, base_lr */, void *stream);
+/* Fused single pass: p,g,m,v,(ema) -> p,m,v,(ema).  seg_flags bit0: AdamW-updated, bit1: EMA-tracked,
+ * bit2: weight-norm target (its post-step sum of squares is accumulated into p_sumsq, zeroed by the call). */
+int kk_adamw_ema(float *p, const float *g, float *m, float *v, float *ema, const int32_t *block_seg,
+                 int64_t nblocks, const float *seg_gscale, const float *seg_decay, const float *seg_stepsize,
+                 const int32_t *seg_flags, const float *step_consts, float beta1, float beta2,
+                 float ema_decay, double *p_sumsq, int nseg, void *stream);
+/* FFN weight-norm projection: for flagged segments with ||W|| > max: W *= max/||W||. */
+int kk_weight_norm_project(float *p, const int32_t *block_seg, int64_t nblocks, const double *p_sumsq,
+                           const int32_t *seg_flags, const float *step_consts, double max_norm, void *stream);
+
+/* ---- misc ---- */
+int kk_axpby(float a, const float *x, float b, float *y, int64_t n, void *stream); /* y = a*x + b*y */
+int kk_mfma_probe(float *out_f32 /*32*32*/, float *out_bf16 /*32*32*/, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,442 @@
+// Fused (flash-style) multi-head attention, forward and backward, head_dim 64, for gfx950.
+//
+// Replaces F.scaled_dot_product_attention(Q,K,V, attn_mask=additive -inf bias) and its autograd backward
+// (reference model/transformers.py:393-398; masks built at :299-316; causal mask model/model.py:434-437).
+// The reference's SDPA math path materialises [B,h,Sq,Sk] scores/probabilities (268 MB per tensor at 8x1024);
+// here nothing of size Sq x Sk ever leaves the CU.
+//
+// Work decomposition: one 256-thread workgroup per (batch, head, 128-row block); each of its 4 waves owns
+// 32 rows.  K/V (or Q/dO in the dK/dV kernel) stream through LDS in 64-row tiles shared by the 4 waves.
+//
+// MFMA orientation ("swapped QK^T"): scores are computed TRANSPOSED, S^T[key][q] = K.Q^T, with the 32x32
+// MFMA (C/D map: col = lane&31, row = (r&3)+8(r>>2)+4(lane>>5)).  A lane then owns one query column and 16 of
+// the 32 keys of a sub-tile, so the softmax row reduction is 16 in-lane operations + one lane^32 exchange,
+// and the probabilities are already laid out as the B operand of the second MFMA (O^T[d][q] = V^T.P^T) with
+// no cross-lane traffic: the k-slots of that MFMA are bound to keys in the order the accumulator registers
+// hold them, and the A operand (V^T) is read from a transposed LDS tile in that same order.
+//
+// KK_MATH_F32 runs the identical structure on v_mfma_f32_32x32x2_f32 (exact fp32) — the parity mode;
+// KK_MATH_BF16 rounds Q/K/V/P/dS/dO to bf16 for the MFMAs and keeps scores, softmax and accumulators in fp32.
+#include "kk_common.h"
+#include <math.h>
+
+namespace {
+
+template <bool BF16> struct ACfg;
+template <> struct ACfg<true> { typedef __bf16 elem; static constexpr int LR = 72; };    // 144-byte rows
+template <> struct ACfg<false> { typedef float elem; static constexpr int LR = 65; };
+
+struct AttnArgs {
+    const float *Q, *K, *V, *O, *dO, *LSE, *Delta;
+    float *Out, *Out2, *LSEo;
+    const uint8_t *key_mask;
+    int B, heads, Sq, Sk, causal;
+    int64_t ldq, ldk, ldv, ldo, lddo, ldout, ldout2;
+    float scale;
+};
+
+__device__ __forceinline__ float f4g(const float4 &v, int c) { return reinterpret_cast<const float *>(&v)[c]; }
+
+// One row (this lane's row, lane&31) of a [32][64] fp32 matrix, held as an MFMA operand with k = d.
+template <bool BF16> struct RowFrag;
+template <> struct RowFrag<true> { bf16x8 v[4]; };    // v[ks][j] = X[row][16 ks + 8 half + j]
+template <> struct RowFrag<false> { float v[32]; };   // v[ks]    = X[row][2 ks + half]
+
+template <bool BF16>
+__device__ __forceinline__ void load_rowfrag(RowFrag<BF16> &f, const float *rowptr, int half) {
+    if constexpr (BF16) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+            if (rowptr) { a = ld4(rowptr + ks * 16 + half * 8); b = ld4(rowptr + ks * 16 + half * 8 + 4); }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { f.v[ks][e] = (__bf16)f4g(a, e); f.v[ks][4 + e] = (__bf16)f4g(b, e); }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rowptr) a = ld4(rowptr + 4 * j);
+            f.v[2 * j] = half ? a.y : a.x;
+            f.v[2 * j + 1] = half ? a.w : a.z;
+        }
+    }
+}
+
+// Stage a [64][64] fp32 tile (row r at src + r*ld; rows >= nvalid are zero) into LDS row-major S[64][LR].
+template <bool BF16>
+__device__ __forceinline__ void stage_rows(typename ACfg<BF16>::elem *S, const float *src, int64_t ld, int nvalid) {
+    constexpr int LR = ACfg<BF16>::LR;
+    const int t = threadIdx.x, row = t >> 2, seg = (t & 3) * 16;
+    float4 r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = row < nvalid ? ld4(src + (int64_t)row * ld + seg + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (BF16) {
+        bf16x8 lo, hi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            lo[e] = (__bf16)f4g(r[0], e); lo[4 + e] = (__bf16)f4g(r[1], e);
+            hi[e] = (__bf16)f4g(r[2], e); hi[4 + e] = (__bf16)f4g(r[3], e);
+        }
+        *reinterpret_cast<bf16x8 *>(&S[row * LR + seg]) = lo;
+        *reinterpret_cast<bf16x8 *>(&S[row * LR + seg + 8]) = hi;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) S[row * LR + seg + 4 * i + e] = f4g(r[i], e);
+    }
+}
+
+// bf16 only: stage the same tile TRANSPOSED, St[d][row] (row contiguous).
+__device__ __forceinline__ void stage_rows_T(__bf16 *St, const float *src, int64_t ld, int nvalid) {
+    constexpr int LR = ACfg<true>::LR;
+    const int t = threadIdx.x, rg = (t & 15) * 4, dg = (t >> 4) * 4;
+    float4 r[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r[c] = (rg + c) < nvalid ? ld4(src + (int64_t)(rg + c) * ld + dg) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        bf16x4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = (__bf16)f4g(r[c], e);
+        *reinterpret_cast<bf16x4 *>(&St[(dg + e) * LR + rg]) = v;
+    }
+}
+
+// acc[row][col] += sum_d T[r0 + row][d] * F_col[d]: A operand = 32 rows of the LDS tile, B operand = RowFrag.
+template <bool BF16>
+__device__ __forceinline__ void mma_tile_x_frag(f32x16 &acc, const typename ACfg<BF16>::elem *T, int r0,
+                                                const RowFrag<BF16> &f, int l31, int half) {
+    constexpr int LR = ACfg<BF16>::LR;
+    if constexpr (BF16) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&T[(r0 + l31) * LR + ks * 16 + half * 8]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, f.v[ks], acc, 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(T[(r0 + l31) * LR + 2 * ks + half], f.v[ks], acc, 0, 0, 0);
+    }
+}
+
+// out[db][d_local][col] += sum_{rows of sub-tile} X[row][db*32 + d_local] * p[row][col], where p[16] are this
+// lane's accumulator-layout values (row_local = frag_row(r, half), col = lane&31).  bf16: Tx is the TRANSPOSED
+// tile [d][row]; fp32: Tx is the row-major tile [row][d].
+template <bool BF16>
+__device__ __forceinline__ void mma_T_x_p(f32x16 (&out)[2], const typename ACfg<BF16>::elem *Tx, int sub0,
+                                          const float (&p)[16], int l31, int half) {
+    constexpr int LR = ACfg<BF16>::LR;
+    if constexpr (BF16) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 b;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) b[j] = (__bf16)p[8 * s2 + j];
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const __bf16 *base = &Tx[(db * 32 + l31) * LR + sub0 + 16 * s2 + 4 * half];
+                const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(base);
+                const bf16x4 hi = *reinterpret_cast<const bf16x4 *>(base + 8);
+                bf16x8 a;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a[e] = lo[e]; a[4 + e] = hi[e]; }
+                out[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, out[db], 0, 0, 0);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = sub0 + frag_row(r, half);
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+                out[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(Tx[row * LR + db * 32 + l31], p[r], out[db], 0, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ void zero_acc(f32x16 &a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
+
+// Store a transposed accumulator pair acc[db][r] (row = d, col = this lane's matrix row) to dst_row[0..63].
+__device__ __forceinline__ void store_row(float *dst_row, const f32x16 (&acc)[2], float mul, int half) {
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            st4(dst_row + db * 32 + 8 * g + 4 * half,
+                make_float4(acc[db][4 * g] * mul, acc[db][4 * g + 1] * mul, acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul));
+}
+
+// ------------------------------------------------------------------ forward
+template <bool BF16>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+    using elem = typename ACfg<BF16>::elem;
+    constexpr int LR = ACfg<BF16>::LR;
+    __shared__ __attribute__((aligned(16))) elem smem[2 * 64 * LR];
+    elem *Ks = smem, *Vx = smem + 64 * LR;
+    const int b = blockIdx.y / a.heads, hh = blockIdx.y % a.heads;
+    const int qblk = blockIdx.x * 128;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, l31 = lane & 31;
+    const int q = qblk + wave * 32 + l31;
+    const bool qvalid = q < a.Sq;
+    RowFrag<BF16> qf;
+    load_rowfrag<BF16>(qf, qvalid ? a.Q + ((int64_t)b * a.Sq + q) * a.ldq + hh * 64 : nullptr, half);
+    f32x16 o[2];
+    zero_acc(o[0]); zero_acc(o[1]);
+    float m = -1e30f, l = 0.f;
+    const uint8_t *km = a.key_mask ? a.key_mask + (int64_t)b * a.Sk : nullptr;
+    int kend = a.Sk;
+    if (a.causal && qblk + 128 < kend) kend = qblk + 128;
+    for (int k0 = 0; k0 < kend; k0 += 64) {
+        __syncthreads();
+        const int nvalid = a.Sk - k0 < 64 ? a.Sk - k0 : 64;
+        stage_rows<BF16>(Ks, a.K + ((int64_t)b * a.Sk + k0) * a.ldk + hh * 64, a.ldk, nvalid);
+        if constexpr (BF16) stage_rows_T(Vx, a.V + ((int64_t)b * a.Sk + k0) * a.ldv + hh * 64, a.ldv, nvalid);
+        else stage_rows<false>(Vx, a.V + ((int64_t)b * a.Sk + k0) * a.ldv + hh * 64, a.ldv, nvalid);
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int kb = k0 + sub * 32;
+            if (kb >= kend) continue;
+            if (a.causal && kb > qblk + wave * 32 + 31) continue;
+            f32x16 s;
+            zero_acc(s);
+            mma_tile_x_frag<BF16>(s, Ks, sub * 32, qf, l31, half);
+            float p[16];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb + frag_row(r, half);
+                const bool ok = key < a.Sk && !(a.causal && key > q) && !(km && km[key]);
+                p[r] = ok ? s[r] * a.scale : -INFINITY;
+                mx = fmaxf(mx, p[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(m, mx);
+            const float alpha = expf(m - mn);
+            float rs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { p[r] = expf(p[r] - mn); rs += p[r]; }
+            rs += __shfl_xor(rs, 32, 64);
+            l = l * alpha + rs;
+            m = mn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+            mma_T_x_p<BF16>(o, Vx, sub * 32, p, l31, half);
+        }
+    }
+    if (qvalid) {
+        const float inv = l > 0.f ? 1.f / l : 0.f;
+        store_row(a.Out + ((int64_t)b * a.Sq + q) * a.ldout + hh * 64, o, inv, half);
+        if (half == 0) a.LSEo[((int64_t)b * a.heads + hh) * a.Sq + q] = l > 0.f ? m + logf(l) : INFINITY;
+    }
+}
+
+// ------------------------------------------------------------------ backward: dQ
+template <bool BF16>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+    using elem = typename ACfg<BF16>::elem;
+    constexpr int LR = ACfg<BF16>::LR;
+    __shared__ __attribute__((aligned(16))) elem smem[(BF16 ? 3 : 2) * 64 * LR];
+    elem *Ks = smem, *Vs = smem + 64 * LR, *Kt = BF16 ? smem + 2 * 64 * LR : smem;
+    const int b = blockIdx.y / a.heads, hh = blockIdx.y % a.heads;
+    const int qblk = blockIdx.x * 128;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, l31 = lane & 31;
+    const int q = qblk + wave * 32 + l31;
+    const bool qvalid = q < a.Sq;
+    RowFrag<BF16> qf, dof;
+    load_rowfrag<BF16>(qf, qvalid ? a.Q + ((int64_t)b * a.Sq + q) * a.ldq + hh * 64 : nullptr, half);
+    load_rowfrag<BF16>(dof, qvalid ? a.dO + ((int64_t)b * a.Sq + q) * a.lddo + hh * 64 : nullptr, half);
+    const float lse = qvalid ? a.LSE[((int64_t)b * a.heads + hh) * a.Sq + q] : INFINITY;
+    const float dlt = qvalid ? a.Delta[((int64_t)b * a.heads + hh) * a.Sq + q] : 0.f;
+    f32x16 dq[2];
+    zero_acc(dq[0]); zero_acc(dq[1]);
+    const uint8_t *km = a.key_mask ? a.key_mask + (int64_t)b * a.Sk : nullptr;
+    int kend = a.Sk;
+    if (a.causal && qblk + 128 < kend) kend = qblk + 128;
+    for (int k0 = 0; k0 < kend; k0 += 64) {
+        __syncthreads();
+        const int nvalid = a.Sk - k0 < 64 ? a.Sk - k0 : 64;
+        const float *kp = a.K + ((int64_t)b * a.Sk + k0) * a.ldk + hh * 64;
+        stage_rows<BF16>(Ks, kp, a.ldk, nvalid);
+        stage_rows<BF16>(Vs, a.V + ((int64_t)b * a.Sk + k0) * a.ldv + hh * 64, a.ldv, nvalid);
+        if constexpr (BF16) stage_rows_T(Kt, kp, a.ldk, nvalid);
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int kb = k0 + sub * 32;
+            if (kb >= kend) continue;
+            if (a.causal && kb > qblk + wave * 32 + 31) continue;
+            f32x16 s, dp;
+            zero_acc(s); zero_acc(dp);
+            mma_tile_x_frag<BF16>(s, Ks, sub * 32, qf, l31, half);
+            mma_tile_x_frag<BF16>(dp, Vs, sub * 32, dof, l31, half);
+            float ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb + frag_row(r, half);
+                const bool ok = key < a.Sk && !(a.causal && key > q) && !(km && km[key]);
+                const float pv = ok ? expf(s[r] * a.scale - lse) : 0.f;
+                ds[r] = pv * (dp[r] - dlt) * a.scale;
+            }
+            mma_T_x_p<BF16>(dq, BF16 ? Kt : Ks, sub * 32, ds, l31, half);
+        }
+    }
+    if (qvalid) store_row(a.Out + ((int64_t)b * a.Sq + q) * a.ldout + hh * 64, dq, 1.f, half);
+}
+
+// ------------------------------------------------------------------ backward: dK, dV
+template <bool BF16>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+    using elem = typename ACfg<BF16>::elem;
+    constexpr int LR = ACfg<BF16>::LR;
+    __shared__ __attribute__((aligned(16))) elem smem[(BF16 ? 4 : 2) * 64 * LR];
+    __shared__ float lse_s[64], dlt_s[64];
+    elem *Qs = smem, *dOs = smem + 64 * LR;
+    elem *Qt = BF16 ? smem + 2 * 64 * LR : Qs, *dOt = BF16 ? smem + 3 * 64 * LR : dOs;
+    const int b = blockIdx.y / a.heads, hh = blockIdx.y % a.heads;
+    const int kblk = blockIdx.x * 128;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, l31 = lane & 31;
+    const int key = kblk + wave * 32 + l31;
+    const bool kvalid = key < a.Sk;
+    const bool kalive = kvalid && !(a.key_mask && a.key_mask[(int64_t)b * a.Sk + key]);
+    RowFrag<BF16> kf, vf;
+    load_rowfrag<BF16>(kf, kvalid ? a.K + ((int64_t)b * a.Sk + key) * a.ldk + hh * 64 : nullptr, half);
+    load_rowfrag<BF16>(vf, kvalid ? a.V + ((int64_t)b * a.Sk + key) * a.ldv + hh * 64 : nullptr, half);
+    f32x16 dk[2], dv[2];
+    zero_acc(dk[0]); zero_acc(dk[1]); zero_acc(dv[0]); zero_acc(dv[1]);
+    const int qstart = a.causal ? (kblk / 64) * 64 : 0;
+    for (int q0 = qstart; q0 < a.Sq; q0 += 64) {
+        __syncthreads();
+        const int nvalid = a.Sq - q0 < 64 ? a.Sq - q0 : 64;
+        const float *qp = a.Q + ((int64_t)b * a.Sq + q0) * a.ldq + hh * 64;
+        const float *dop = a.dO + ((int64_t)b * a.Sq + q0) * a.lddo + hh * 64;
+        stage_rows<BF16>(Qs, qp, a.ldq, nvalid);
+        stage_rows<BF16>(dOs, dop, a.lddo, nvalid);
+        if constexpr (BF16) { stage_rows_T(Qt, qp, a.ldq, nvalid); stage_rows_T(dOt, dop, a.lddo, nvalid); }
+        if (threadIdx.x < 64) {
+            const int qq = q0 + threadIdx.x;
+            const int64_t o = ((int64_t)b * a.heads + hh) * a.Sq + qq;
+            lse_s[threadIdx.x] = qq < a.Sq ? a.LSE[o] : INFINITY;
+            dlt_s[threadIdx.x] = qq < a.Sq ? a.Delta[o] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int qb = q0 + sub * 32;
+            if (qb >= a.Sq) continue;
+            if (a.causal && qb + 31 < kblk + wave * 32) continue;
+            f32x16 s, dp;
+            zero_acc(s); zero_acc(dp);
+            mma_tile_x_frag<BF16>(s, Qs, sub * 32, kf, l31, half);
+            mma_tile_x_frag<BF16>(dp, dOs, sub * 32, vf, l31, half);
+            float p[16], ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ql = sub * 32 + frag_row(r, half);
+                const int qq = q0 + ql;
+                const bool ok = kalive && qq < a.Sq && !(a.causal && key > qq);
+                p[r] = ok ? expf(s[r] * a.scale - lse_s[ql]) : 0.f;
+                ds[r] = p[r] * (dp[r] - dlt_s[ql]) * a.scale;
+            }
+            mma_T_x_p<BF16>(dv, dOt, sub * 32, p, l31, half);
+            mma_T_x_p<BF16>(dk, Qt, sub * 32, ds, l31, half);
+        }
+    }
+    if (kvalid) {
+        store_row(a.Out + ((int64_t)b * a.Sk + key) * a.ldout + hh * 64, dk, 1.f, half);
+        store_row(a.Out2 + ((int64_t)b * a.Sk + key) * a.ldout2 + hh * 64, dv, 1.f, half);
+    }
+}
+
+// Delta[b,h,q] = sum_d dO*O : one wave per (row, head).
+__global__ __launch_bounds__(256) void attn_delta_kernel(const float *__restrict__ O, const float *__restrict__ dO,
+                                                         float *__restrict__ Delta, int64_t npairs, int heads, int Sq,
+                                                         int64_t ldo, int64_t lddo) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t pr = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); pr < npairs; pr += (int64_t)gridDim.x * 4) {
+        const int64_t row = pr / heads;
+        const int hd = (int)(pr - row * heads);
+        const float v = wave_sum(O[row * ldo + hd * 64 + lane] * dO[row * lddo + hd * 64 + lane]);
+        if (lane == 0) {
+            const int64_t b = row / Sq, q = row - b * Sq;
+            Delta[(b * heads + hd) * Sq + q] = v;
+        }
+    }
+}
+
+int check_common(const char *name, int B, int heads, int Sq, int Sk, int math, const int64_t *lds, int nld) {
+    KK_REQUIRE(B > 0 && heads > 0 && Sq > 0 && Sk > 0, "%s: bad shape B=%d heads=%d Sq=%d Sk=%d", name, B, heads, Sq, Sk);
+    KK_REQUIRE(math == KK_MATH_F32 || math == KK_MATH_BF16, "%s: bad math mode", name);
+    for (int i = 0; i < nld; ++i) KK_REQUIRE(lds[i] % 4 == 0 && lds[i] >= 64 * heads, "%s: row stride %ld unsupported", name, (long)lds[i]);
+    KK_REQUIRE((int64_t)B * heads < 65536, "%s: B*heads too large", name);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int kk_attn_fwd(const float *Q, const float *K, const float *V, float *O, float *LSE, int B, int heads,
+                           int Sq, int Sk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                           const uint8_t *key_mask, int causal, float scale, int math, void *stream) {
+    const int64_t lds[4] = {ldq, ldk, ldv, ldo};
+    if (int rc = check_common("kk_attn_fwd", B, heads, Sq, Sk, math, lds, 4)) return rc;
+    AttnArgs a = {};
+    a.Q = Q; a.K = K; a.V = V; a.Out = O; a.LSEo = LSE; a.key_mask = key_mask;
+    a.B = B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.causal = causal;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldout = ldo; a.scale = scale;
+    dim3 grid(kk_cdiv(Sq, 128), B * heads);
+    if (math == KK_MATH_BF16) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    KK_LAUNCH_CHECK("kk_attn_fwd");
+    return 0;
+}
+
+extern "C" int kk_attn_delta(const float *O, const float *dO, float *Delta, int B, int heads, int Sq, int64_t ldo,
+                             int64_t lddo, void *stream) {
+    KK_REQUIRE(B > 0 && heads > 0 && Sq > 0, "kk_attn_delta: bad shape");
+    const int64_t npairs = (int64_t)B * Sq * heads;
+    int blocks = kk_cdiv(npairs, 4);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, O, dO, Delta, npairs, heads, Sq, ldo, lddo);
+    KK_LAUNCH_CHECK("kk_attn_delta");
+    return 0;
+}
+
+extern "C" int kk_attn_bwd_dq(const float *Q, const float *K, const float *V, const float *dO, const float *LSE,
+                              const float *Delta, float *dQ, int B, int heads, int Sq, int Sk, int64_t ldq,
+                              int64_t ldk, int64_t ldv, int64_t lddo, int64_t lddq, const uint8_t *key_mask,
+                              int causal, float scale, int math, void *stream) {
+    const int64_t lds[5] = {ldq, ldk, ldv, lddo, lddq};
+    if (int rc = check_common("kk_attn_bwd_dq", B, heads, Sq, Sk, math, lds, 5)) return rc;
+    AttnArgs a = {};
+    a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.LSE = LSE; a.Delta = Delta; a.Out = dQ; a.key_mask = key_mask;
+    a.B = B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.causal = causal;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.lddo = lddo; a.ldout = lddq; a.scale = scale;
+    dim3 grid(kk_cdiv(Sq, 128), B * heads);
+    if (math == KK_MATH_BF16) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    KK_LAUNCH_CHECK("kk_attn_bwd_dq");
+    return 0;
+}
+
+extern "C" int kk_attn_bwd_dkv(const float *Q, const float *K, const float *V, const float *dO, const float *LSE,
+                               const float *Delta, float *dK, float *dV, int B, int heads, int Sq, int Sk,
+                               int64_t ldq, int64_t ldk, int64_t ldv, int64_t lddo, int64_t lddk, int64_t lddv,
+                               const uint8_t *key_mask, int causal, float scale, int math, void *stream) {
+    const int64_t lds[6] = {ldq, ldk, ldv, lddo, lddk, lddv};
+    if (int rc = check_common("kk_attn_bwd_dkv", B, heads, Sq, Sk, math, lds, 6)) return rc;
+    AttnArgs a = {};
+    a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.LSE = LSE; a.Delta = Delta; a.Out = dK; a.Out2 = dV; a.key_mask = key_mask;
+    a.B = B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.causal = causal;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.lddo = lddo; a.ldout = lddk; a.ldout2 = lddv; a.scale = scale;
+    dim3 grid(kk_cdiv(Sk, 128), B * heads);
+    if (math == KK_MATH_BF16) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    KK_LAUNCH_CHECK("kk_attn_bwd_dkv");
+    return 0;
+}

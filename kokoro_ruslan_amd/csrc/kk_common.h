@@ -1,0 +1,67 @@
+// Shared helpers for the gfx950 kernels (wave = 64 lanes; MFMA 32x32 tiles).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include "../../include/kokoro_hip.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+int kk_fail(int code, const char *fmt, ...);
+
+#define KK_REQUIRE(cond, ...)                                   \
+    do {                                                        \
+        if (!(cond)) return kk_fail(KK_EINVAL, __VA_ARGS__);    \
+    } while (0)
+
+#define KK_LAUNCH_CHECK(name)                                                              \
+    do {                                                                                   \
+        hipError_t e__ = hipGetLastError();                                                \
+        if (e__ != hipSuccess) return kk_fail((int)e__, "%s: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+static inline int kk_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide sum for blockDim.x == 256 (4 waves). `red` is >= 4 floats of LDS. Result valid in every thread.
+__device__ __forceinline__ float block_sum_256(float v, float *red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ double block_sum_256_d(double v, double *red) {
+    v = wave_sum_d(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+
+// C/D fragment of a 32x32 MFMA tile: register r of lane l holds element
+//   row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5),  col = l & 31.
+__device__ __forceinline__ int frag_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }

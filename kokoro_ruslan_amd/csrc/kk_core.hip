@@ -1,0 +1,65 @@
+// Error plumbing, ABI version and an MFMA fragment-layout probe.
+#include "kk_common.h"
+
+static thread_local char g_err[512] = "";
+
+int kk_fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" const char *kk_last_error(void) { return g_err; }
+extern "C" int kk_abi_version(void) { return KK_ABI_VERSION; }
+
+namespace {
+// One wave computes C[32x32] = A[32x16] * B[16x32] with A[i][k] = i + 0.25*k - 3, B[k][j] = 0.5*k - 0.125*j + 1
+// (asymmetric, exactly representable in bf16 products' fp32 sums), through both MFMA flavours, using the
+// operand/result lane maps every kernel in this library assumes.
+__global__ void probe_kernel(float *out_f32, float *out_bf16) {
+    const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
+    f32x16 c0, c1;
+    for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+    for (int ks = 0; ks < 8; ++ks) {
+        const int k = ks * 2 + half;
+        const float a = (float)l31 + 0.25f * k - 3.f;      // A[row=l31][k]
+        const float b = 0.5f * k - 0.125f * l31 + 1.f;     // B[k][col=l31]
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c0, 0, 0, 0);
+    }
+    bf16x8 av, bv;
+    for (int j = 0; j < 8; ++j) {
+        const int k = half * 8 + j;
+        av[j] = (__bf16)((float)l31 + 0.25f * k - 3.f);
+        bv[j] = (__bf16)(0.5f * k - 0.125f * l31 + 1.f);
+    }
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, c1, 0, 0, 0);
+    for (int r = 0; r < 16; ++r) {
+        const int row = frag_row(r, half);
+        out_f32[row * 32 + l31] = c0[r];
+        out_bf16[row * 32 + l31] = c1[r];
+    }
+}
+
+__global__ void axpby_kernel(float a, const float *__restrict__ x, float b, float *__restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = a * x[i] + (b == 0.f ? 0.f : b * y[i]);
+}
+}  // namespace
+
+extern "C" int kk_mfma_probe(float *out_f32, float *out_bf16, void *stream) {
+    hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out_f32, out_bf16);
+    KK_LAUNCH_CHECK("kk_mfma_probe");
+    return 0;
+}
+
+extern "C" int kk_axpby(float a, const float *x, float b, float *y, int64_t n, void *stream) {
+    KK_REQUIRE(n >= 0 && x && y, "kk_axpby: bad args");
+    if (n == 0) return 0;
+    int blocks = kk_cdiv(n, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(axpby_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, x, b, y, n);
+    KK_LAUNCH_CHECK("kk_axpby");
+    return 0;
+}

@@ -1,0 +1,420 @@
+// Gather / elementwise kernels of the Kokoro train step (HBM-bound integer + fp32 work).
+//
+//  GLU gate                      model/transformers.py:107-108 (exact-erf nn.GELU, :51)
+//  text+stress embedding, PE     model/model.py:375-378; model/positional_encoding.py:66-74
+//  length regulator              utils/lengths.py:16-96 (index expansion is integer-exact)
+//  variance-adaptor pieces       model/variance_predictor.py:89-115 (conv k=3 as im2col+GEMM, Linear(C->1)+mask),
+//                                :363-368 (frame mask), :181-218,430-437 (bucketize + embedding adds + masked_fill)
+//  decoder-input shift           model/model.py:519
+#include "kk_common.h"
+
+namespace {
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+}
+
+// ------------------------------------------------------------------ GLU
+__global__ __launch_bounds__(256) void glu_fwd_kernel(const float *__restrict__ h, float *__restrict__ g, int64_t total4, int F) {
+    const int F4 = F / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / F4;
+        const int c = (int)(i - row * F4) * 4;
+        const float4 a = ld4(h + row * 2 * F + c), b = ld4(h + row * 2 * F + F + c);
+        st4(g + row * F + c, make_float4(gelu_f(a.x) * b.x, gelu_f(a.y) * b.y, gelu_f(a.z) * b.z, gelu_f(a.w) * b.w));
+    }
+}
+
+__global__ __launch_bounds__(256) void glu_bwd_kernel(const float *__restrict__ dg, const float *__restrict__ h,
+                                                      float *__restrict__ dh, int64_t total4, int F) {
+    const int F4 = F / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / F4;
+        const int c = (int)(i - row * F4) * 4;
+        const float4 a = ld4(h + row * 2 * F + c), b = ld4(h + row * 2 * F + F + c), d = ld4(dg + row * F + c);
+        st4(dh + row * 2 * F + c, make_float4(d.x * b.x * gelu_grad_f(a.x), d.y * b.y * gelu_grad_f(a.y),
+                                              d.z * b.z * gelu_grad_f(a.z), d.w * b.w * gelu_grad_f(a.w)));
+        st4(dh + row * 2 * F + F + c, make_float4(d.x * gelu_f(a.x), d.y * gelu_f(a.y), d.z * gelu_f(a.z), d.w * gelu_f(a.w)));
+    }
+}
+
+// ------------------------------------------------------------------ embedding + PE
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t *__restrict__ ids, const int64_t *__restrict__ stress,
+                                                        const float *__restrict__ emb, const float *__restrict__ semb,
+                                                        const float *__restrict__ pe, float *__restrict__ out, int64_t total4,
+                                                        int P, int H, float scale) {
+    const int H4 = H / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int64_t tok = i / H4;
+        const int c = (int)(i - tok * H4) * 4;
+        const int p = (int)(tok % P);
+        const float4 e = ld4(emb + ids[tok] * H + c), pv = ld4(pe + (int64_t)p * H + c);
+        float4 o = make_float4(e.x * scale, e.y * scale, e.z * scale, e.w * scale);
+        if (stress) { const float4 s = ld4(semb + stress[tok] * H + c); o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w; }
+        o.x += pv.x; o.y += pv.y; o.z += pv.z; o.w += pv.w;
+        st4(out + tok * H + c, o);
+    }
+}
+
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t *__restrict__ ids, const int64_t *__restrict__ stress,
+                                                        const float *__restrict__ dout, float *__restrict__ demb,
+                                                        float *__restrict__ dsemb, int64_t total, int H, float scale) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t tok = i / H;
+        const int c = (int)(i - tok * H);
+        const float d = dout[i];
+        atomicAdd(&demb[ids[tok] * H + c], d * scale);
+        if (stress) { const int64_t s = stress[tok]; if (s != 0) atomicAdd(&dsemb[s * H + c], d); }   // padding_idx=0 (model.py:93)
+    }
+}
+
+// ------------------------------------------------------------------ length regulator
+// One workgroup per batch row: inclusive scan of max(dur,0) into LDS, then a per-frame upper_bound.
+constexpr int LR_MAXP = 4096;
+__global__ __launch_bounds__(256) void lr_index_kernel(const int64_t *__restrict__ dur, int64_t *__restrict__ idx,
+                                                       int64_t *__restrict__ lens, int64_t *__restrict__ total, int P, int L) {
+    __shared__ int64_t cum[LR_MAXP];
+    __shared__ int64_t wtot[4];
+    __shared__ int64_t carry;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < P; base += 256) {
+        const int j = base + t;
+        int64_t v = 0;
+        if (j < P) { v = dur[(int64_t)b * P + j]; v = v > 0 ? v : 0; }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {            // wave inclusive scan
+            const int64_t n = __shfl_up(v, o, 64);
+            if (lane >= o) v += n;
+        }
+        if (lane == 63) wtot[w] = v;
+        __syncthreads();
+        int64_t off = carry;
+        for (int k = 0; k < w; ++k) off += wtot[k];
+        if (j < P) cum[j] = v + off;
+        __syncthreads();
+        if (t == 0) carry += wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        __syncthreads();
+    }
+    const int64_t tot = carry;
+    const int64_t len = tot < L ? tot : L;
+    if (t == 0) { lens[b] = len; total[b] = tot; }
+    for (int f = t; f < L; f += 256) {
+        int64_t r = -1;
+        if (f < len) {
+            int lo = 0, hi = P;                       // first j with cum[j] > f  ==  #{j : cum[j] <= f}
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (cum[mid] <= f) lo = mid + 1; else hi = mid; }
+            r = lo;
+        }
+        idx[(int64_t)b * L + f] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void lr_gather_kernel(const float *__restrict__ x, const int64_t *__restrict__ idx,
+                                                        float *__restrict__ out, int64_t total4, int P, int L, int H) {
+    const int H4 = H / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int64_t fr = i / H4;
+        const int c = (int)(i - fr * H4) * 4;
+        const int64_t b = fr / L, j = idx[fr];
+        st4(out + fr * H + c, j >= 0 ? ld4(x + (b * P + j) * H + c) : make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+}
+
+__global__ __launch_bounds__(256) void max_i64_kernel(const int64_t *__restrict__ x, int64_t n, int64_t *__restrict__ out) {
+    __shared__ int64_t red[256];
+    int64_t m = 0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) m = x[i] > m ? x[i] : m;
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] = red[threadIdx.x + s] > red[threadIdx.x] ? red[threadIdx.x + s] : red[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = red[0];
+}
+
+// ------------------------------------------------------------------ conv k=3 as im2col (per 512-frame chunk)
+__global__ __launch_bounds__(256) void im2col3_fwd_kernel(const float *__restrict__ x, float *__restrict__ col, int64_t total,
+                                                          int L, int C, int chunk) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t fr = i / C;
+        const int c = (int)(i - fr * C);
+        const int l = (int)(fr % L);
+        const int cb = (l / chunk) * chunk, ce = cb + chunk < L ? cb + chunk : L;
+        float *o = col + fr * 3 * C + c * 3;
+        o[0] = (l - 1 >= cb) ? x[i - C] : 0.f;
+        o[1] = x[i];
+        o[2] = (l + 1 < ce) ? x[i + C] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void im2col3_bwd_kernel(const float *__restrict__ dcol, float *__restrict__ dx, int64_t total,
+                                                          int L, int C, int chunk) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t fr = i / C;
+        const int c = (int)(i - fr * C);
+        const int l = (int)(fr % L);
+        const int cb = (l / chunk) * chunk, ce = cb + chunk < L ? cb + chunk : L;
+        const float *d = dcol + fr * 3 * C + c * 3;
+        float v = d[1];
+        if (l + 1 < ce) v += d[3 * C + 0];            // row l+1, tap k=0 read x[l]
+        if (l - 1 >= cb) v += d[-3 * C + 2];          // row l-1, tap k=2 read x[l]
+        dx[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------ Linear(C->1) + masked_fill  (wave per row)
+__device__ __forceinline__ bool row_dead(const uint8_t *mask, int64_t r, int L, int chunk) {
+    if (mask && mask[r]) return true;
+    if (chunk > 0) {
+        const int l = (int)(r % L), cb = (l / chunk) * chunk;
+        if ((L - cb < chunk ? L - cb : chunk) < 2) return true;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(256) void rowdot_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                         const float *__restrict__ b, const uint8_t *__restrict__ mask,
+                                                         float *__restrict__ out, int64_t rows, int C, int L, int chunk) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+        float s = 0.f;
+        for (int c = lane * 4; c < C; c += 256) {
+            const float4 xv = ld4(x + r * C + c), wv = ld4(w + c);
+            s += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+        }
+        s = wave_sum(s);
+        if (lane == 0) out[r] = row_dead(mask, r, L, chunk) ? 0.f : s + b[0];
+    }
+}
+
+__global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float *__restrict__ dout, const float *__restrict__ x,
+                                                         const float *__restrict__ w, const uint8_t *__restrict__ mask,
+                                                         float *__restrict__ dx, float *__restrict__ dw, float *__restrict__ db,
+                                                         int64_t rows, int C, int L, int chunk, int rows_per_block) {
+    // thread t owns columns t, t+256, ... (C <= 1024); block walks a slab of rows.
+    const int64_t rbeg = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t rend = rbeg + rows_per_block < rows ? rbeg + rows_per_block : rows;
+    float aw[4] = {0.f, 0.f, 0.f, 0.f};
+    float ab = 0.f;
+    for (int64_t r = rbeg; r < rend; ++r) {
+        const float d = row_dead(mask, r, L, chunk) ? 0.f : dout[r];
+        if (threadIdx.x == 0) ab += d;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = threadIdx.x + 256 * k;
+            if (c < C) {
+                aw[k] += d * x[r * C + c];
+                if (dx) dx[r * C + c] = d * w[c];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = threadIdx.x + 256 * k;
+        if (c < C) atomicAdd(&dw[c], aw[k]);
+    }
+    if (threadIdx.x == 0) atomicAdd(db, ab);
+}
+
+// ------------------------------------------------------------------ bucketize + embedding adds + frame mask (wave per frame)
+__device__ __forceinline__ int bucketize_left(const float *__restrict__ bins, int n, float v) {
+    int lo = 0, hi = n;                                  // #{i : bins[i] < v}   (torch.bucketize right=False)
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (bins[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void bucket_embed_add_fwd_kernel(
+    const float *__restrict__ x, const float *__restrict__ pitch, const float *__restrict__ energy,
+    const float *__restrict__ pbins, const float *__restrict__ ebins, const float *__restrict__ pemb,
+    const float *__restrict__ eemb, const int64_t *__restrict__ lens, float *__restrict__ out, int32_t *__restrict__ pidx,
+    int32_t *__restrict__ eidx, uint8_t *__restrict__ fmask, int64_t rows, int T, int H, int nbins) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+        const int b = (int)(r / T), f = (int)(r - (int64_t)b * T);
+        const bool masked = f >= lens[b];
+        const int pi = bucketize_left(pbins, nbins - 1, pitch[r]);
+        const int ei = bucketize_left(ebins, nbins - 1, energy[r]);
+        if (lane == 0) { pidx[r] = pi; eidx[r] = ei; fmask[r] = masked ? 1 : 0; }
+        for (int c = lane * 4; c < H; c += 256) {
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!masked) {
+                const float4 a = ld4(x + r * H + c), p = ld4(pemb + (int64_t)pi * H + c), e = ld4(eemb + (int64_t)ei * H + c);
+                o = make_float4(a.x + p.x + e.x, a.y + p.y + e.y, a.z + p.z + e.z, a.w + p.w + e.w);
+            }
+            st4(out + r * H + c, o);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bucket_embed_add_bwd_kernel(const float *__restrict__ dout, const int32_t *__restrict__ pidx,
+                                                                   const int32_t *__restrict__ eidx, const uint8_t *__restrict__ fmask,
+                                                                   float *__restrict__ dpemb, float *__restrict__ deemb, int64_t rows, int H) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+        if (fmask[r]) continue;
+        const int64_t po = (int64_t)pidx[r] * H, eo = (int64_t)eidx[r] * H;
+        for (int c = lane; c < H; c += 64) {
+            const float d = dout[r * H + c];
+            atomicAdd(&dpemb[po + c], d);
+            atomicAdd(&deemb[eo + c], d);
+        }
+    }
+}
+
+__global__ void ids_eq_zero_kernel(const int64_t *__restrict__ ids, uint8_t *__restrict__ mask, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        mask[i] = ids[i] == 0 ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void shift_right_kernel(const float *__restrict__ mel, float *__restrict__ out, int64_t total,
+                                                          int T, int M) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t fr = i / M;
+        out[i] = (fr % T) == 0 ? 0.f : mel[i - M];
+    }
+}
+
+inline int grid_for(int64_t n, int cap = 4096) {
+    int b = kk_cdiv(n, 256);
+    return b > cap ? cap : (b < 1 ? 1 : b);
+}
+
+}  // namespace
+
+extern "C" int kk_glu_fwd(const float *h, float *g, int64_t rows, int F, void *stream) {
+    KK_REQUIRE(rows > 0 && F > 0 && F % 4 == 0, "kk_glu_fwd: bad shape rows=%ld F=%d", (long)rows, F);
+    const int64_t total4 = rows * F / 4;
+    hipLaunchKernelGGL(glu_fwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, h, g, total4, F);
+    KK_LAUNCH_CHECK("kk_glu_fwd");
+    return 0;
+}
+extern "C" int kk_glu_bwd(const float *dg, const float *h, float *dh, int64_t rows, int F, void *stream) {
+    KK_REQUIRE(rows > 0 && F > 0 && F % 4 == 0, "kk_glu_bwd: bad shape");
+    const int64_t total4 = rows * F / 4;
+    hipLaunchKernelGGL(glu_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, dg, h, dh, total4, F);
+    KK_LAUNCH_CHECK("kk_glu_bwd");
+    return 0;
+}
+
+extern "C" int kk_embed_fwd(const int64_t *ids, const int64_t *stress, const float *emb, const float *stress_emb,
+                            const float *pe, float *out, int B, int P, int H, float scale, void *stream) {
+    KK_REQUIRE(B > 0 && P > 0 && H > 0 && H % 4 == 0, "kk_embed_fwd: bad shape");
+    const int64_t total4 = (int64_t)B * P * H / 4;
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, ids, stress, emb,
+                       stress_emb, pe, out, total4, P, H, scale);
+    KK_LAUNCH_CHECK("kk_embed_fwd");
+    return 0;
+}
+extern "C" int kk_embed_bwd(const int64_t *ids, const int64_t *stress, const float *dout, float *demb,
+                            float *dstress_emb, int B, int P, int H, float scale, void *stream) {
+    KK_REQUIRE(B > 0 && P > 0 && H > 0, "kk_embed_bwd: bad shape");
+    const int64_t total = (int64_t)B * P * H;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, ids, stress, dout, demb,
+                       dstress_emb, total, H, scale);
+    KK_LAUNCH_CHECK("kk_embed_bwd");
+    return 0;
+}
+
+extern "C" int kk_length_regulate_index(const int64_t *dur, int64_t *idx, int64_t *lens, int64_t *total, int B,
+                                        int P, int L, void *stream) {
+    KK_REQUIRE(B > 0 && P > 0 && L > 0, "kk_length_regulate_index: bad shape B=%d P=%d L=%d", B, P, L);
+    KK_REQUIRE(P <= LR_MAXP, "kk_length_regulate_index: P=%d exceeds %d", P, LR_MAXP);
+    hipLaunchKernelGGL(lr_index_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dur, idx, lens, total, P, L);
+    KK_LAUNCH_CHECK("kk_length_regulate_index");
+    return 0;
+}
+extern "C" int kk_length_regulate_gather(const float *x, const int64_t *idx, float *out, int B, int P, int L, int H,
+                                         void *stream) {
+    KK_REQUIRE(B > 0 && P > 0 && L > 0 && H > 0 && H % 4 == 0, "kk_length_regulate_gather: bad shape");
+    const int64_t total4 = (int64_t)B * L * H / 4;
+    hipLaunchKernelGGL(lr_gather_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, idx, out, total4, P, L, H);
+    KK_LAUNCH_CHECK("kk_length_regulate_gather");
+    return 0;
+}
+extern "C" int kk_max_i64(const int64_t *x, int64_t n, int64_t *out, void *stream) {
+    KK_REQUIRE(n > 0, "kk_max_i64: empty");
+    hipLaunchKernelGGL(max_i64_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, n, out);
+    KK_LAUNCH_CHECK("kk_max_i64");
+    return 0;
+}
+
+extern "C" int kk_im2col3_fwd(const float *x, float *col, int B, int L, int C, int chunk, void *stream) {
+    KK_REQUIRE(B > 0 && L > 0 && C > 0 && chunk > 0, "kk_im2col3_fwd: bad shape");
+    const int64_t total = (int64_t)B * L * C;
+    hipLaunchKernelGGL(im2col3_fwd_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, x, col, total, L, C, chunk);
+    KK_LAUNCH_CHECK("kk_im2col3_fwd");
+    return 0;
+}
+extern "C" int kk_im2col3_bwd(const float *dcol, float *dx, int B, int L, int C, int chunk, void *stream) {
+    KK_REQUIRE(B > 0 && L > 0 && C > 0 && chunk > 0, "kk_im2col3_bwd: bad shape");
+    const int64_t total = (int64_t)B * L * C;
+    hipLaunchKernelGGL(im2col3_bwd_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, dcol, dx, total, L, C, chunk);
+    KK_LAUNCH_CHECK("kk_im2col3_bwd");
+    return 0;
+}
+
+extern "C" int kk_rowdot_fwd(const float *x, const float *w, const float *b, const uint8_t *mask, float *out,
+                             int64_t rows, int C, int L, int chunk, void *stream) {
+    KK_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && L > 0, "kk_rowdot_fwd: bad shape");
+    int blocks = kk_cdiv(rows, 4);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(rowdot_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, w, b, mask, out, rows, C, L, chunk);
+    KK_LAUNCH_CHECK("kk_rowdot_fwd");
+    return 0;
+}
+extern "C" int kk_rowdot_bwd(const float *dout, const float *x, const float *w, const uint8_t *mask, float *dx,
+                             float *dw, float *db, int64_t rows, int C, int L, int chunk, void *stream) {
+    KK_REQUIRE(rows > 0 && C > 0 && C <= 1024 && L > 0, "kk_rowdot_bwd: bad shape (C <= 1024)");
+    int blocks = kk_cdiv(rows, 16);
+    if (blocks > 1024) blocks = 1024;
+    const int rpb = kk_cdiv(rows, blocks);
+    blocks = kk_cdiv(rows, rpb);
+    hipLaunchKernelGGL(rowdot_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, x, w, mask, dx, dw, db, rows,
+                       C, L, chunk, rpb);
+    KK_LAUNCH_CHECK("kk_rowdot_bwd");
+    return 0;
+}
+
+extern "C" int kk_bucket_embed_add_fwd(const float *x, const float *pitch, const float *energy, const float *pbins,
+                                       const float *ebins, const float *pemb, const float *eemb, const int64_t *lens,
+                                       float *out, int32_t *pidx, int32_t *eidx, uint8_t *frame_mask, int B, int T,
+                                       int H, int nbins, void *stream) {
+    KK_REQUIRE(B > 0 && T > 0 && H > 0 && H % 4 == 0 && nbins > 1, "kk_bucket_embed_add_fwd: bad shape");
+    const int64_t rows = (int64_t)B * T;
+    int blocks = kk_cdiv(rows, 4);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bucket_embed_add_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, pitch, energy, pbins,
+                       ebins, pemb, eemb, lens, out, pidx, eidx, frame_mask, rows, T, H, nbins);
+    KK_LAUNCH_CHECK("kk_bucket_embed_add_fwd");
+    return 0;
+}
+extern "C" int kk_bucket_embed_add_bwd(const float *dout, const int32_t *pidx, const int32_t *eidx,
+                                       const uint8_t *frame_mask, float *dpemb, float *deemb, int B, int T, int H,
+                                       void *stream) {
+    KK_REQUIRE(B > 0 && T > 0 && H > 0, "kk_bucket_embed_add_bwd: bad shape");
+    const int64_t rows = (int64_t)B * T;
+    int blocks = kk_cdiv(rows, 4);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bucket_embed_add_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, pidx, eidx,
+                       frame_mask, dpemb, deemb, rows, H);
+    KK_LAUNCH_CHECK("kk_bucket_embed_add_bwd");
+    return 0;
+}
+
+extern "C" int kk_ids_eq_zero(const int64_t *ids, uint8_t *mask, int64_t n, void *stream) {
+    KK_REQUIRE(n > 0, "kk_ids_eq_zero: empty");
+    hipLaunchKernelGGL(ids_eq_zero_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, ids, mask, n);
+    KK_LAUNCH_CHECK("kk_ids_eq_zero");
+    return 0;
+}
+extern "C" int kk_shift_right(const float *mel, float *out, int B, int T, int M, void *stream) {
+    KK_REQUIRE(B > 0 && T > 0 && M > 0, "kk_shift_right: bad shape");
+    const int64_t total = (int64_t)B * T * M;
+    hipLaunchKernelGGL(shift_right_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, mel, out, total, T, M);
+    KK_LAUNCH_CHECK("kk_shift_right");
+    return 0;
+}

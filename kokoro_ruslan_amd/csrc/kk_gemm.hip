@@ -1,0 +1,308 @@
+// MFMA GEMM for the Linear layers of the Kokoro train step (forward, dgrad, wgrad).
+//
+// Replaces the nn.Linear / F.linear call sites of the reference: attention projections
+// (model/transformers.py:131-136,228,258-259,434), GLU feed-forward (transformers.py:90-91,106-108),
+// mel projections and heads (model/model.py:173,190,523,561), conv-as-GEMM of the variance predictors
+// (model/variance_predictor.py:46-51 via kk_im2col3_*), and their autograd backward.
+//
+// Design (gfx950): 128x128 output tile per 256-thread workgroup, 4 waves in a 2x2 grid, each wave owns
+// 64x64 = 2x2 MFMA tiles of 32x32 (4 x 16 accumulator registers).  Operands are fp32 in HBM; they are
+// staged global -> registers -> LDS with 16-byte loads along whichever dimension is contiguous in memory,
+// so the three layouts a Linear needs (X.W^T, dY.W, dY^T.X) share one kernel: a k-strided operand is
+// transposed for free while it is being converted/written to LDS.  LDS rows are padded (80 B for bf16,
+// 68 B for fp32) so fragment reads spread over the banks.  Two LDS buffers, the next tile's global loads
+// are in flight while the current tile is multiplied.  KK_MATH_BF16 rounds operands to bf16 at staging
+// and uses v_mfma_f32_32x32x16_bf16; KK_MATH_F32 keeps fp32 and uses v_mfma_f32_32x32x2_f32 (bit-exact
+// fp32 FMA chain) — the parity mode.  Short-M/N problems (weight gradients) split K over blockIdx.z and
+// combine with fp32 atomics.
+#include "kk_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+
+template <bool BF16> struct GemmCfg;
+template <> struct GemmCfg<true> {
+    static constexpr int BK = 32, LR = 40, NV = 4;   // LR: LDS row stride in elements (80 bytes)
+    typedef __bf16 elem;
+};
+template <> struct GemmCfg<false> {
+    static constexpr int BK = 16, LR = 17, NV = 2;
+    typedef float elem;
+};
+
+struct GemmArgs {
+    int M, N, K;
+    float alpha, beta;
+    const float *A, *B, *bias, *residual;
+    float *C;
+    int64_t lda, ldb, ldc, ldr, res_mod;
+    int k_per_split, atomic;
+};
+
+__device__ __forceinline__ float f4c(const float4 &v, int c) { return reinterpret_cast<const float *>(&v)[c]; }
+
+// Global -> registers for one 128 x BK operand tile.  KS=false: element (row,k) at X[row*ld + k];
+// KS=true: element (row,k) at X[k*ld + row].
+template <bool BF16, bool KS>
+__device__ __forceinline__ void g2r(const float *__restrict__ X, int64_t ld, int rows_total, int r0, int k0,
+                                    int kend, float4 (&reg)[GemmCfg<BF16>::NV]) {
+    constexpr int NV = GemmCfg<BF16>::NV;
+    const int t = threadIdx.x;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!KS) {
+        const int row = r0 + (t >> 1);
+        const int kb = k0 + (t & 1) * (NV * 4);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int k = kb + 4 * i;
+            reg[i] = (row < rows_total && k < kend) ? ld4(X + (int64_t)row * ld + k) : z;
+        }
+    } else {
+        const int row = r0 + (t & 31) * 4;
+        const int kb = k0 + (t >> 5) * NV;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int k = kb + i;
+            reg[i] = (row < rows_total && k < kend) ? ld4(X + (int64_t)k * ld + row) : z;
+        }
+    }
+}
+
+// Registers -> LDS tile S[128][LR] (k contiguous), converting to bf16 when BF16.
+template <bool BF16, bool KS>
+__device__ __forceinline__ void r2s(typename GemmCfg<BF16>::elem *S, const float4 (&reg)[GemmCfg<BF16>::NV]) {
+    constexpr int LR = GemmCfg<BF16>::LR;
+    const int t = threadIdx.x;
+    if constexpr (BF16) {
+        if (!KS) {
+            const int row = t >> 1, kofs = (t & 1) * 16;
+            bf16x8 lo, hi;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                lo[e] = (__bf16)f4c(reg[0], e);
+                lo[4 + e] = (__bf16)f4c(reg[1], e);
+                hi[e] = (__bf16)f4c(reg[2], e);
+                hi[4 + e] = (__bf16)f4c(reg[3], e);
+            }
+            *reinterpret_cast<bf16x8 *>(&S[row * LR + kofs]) = lo;
+            *reinterpret_cast<bf16x8 *>(&S[row * LR + kofs + 8]) = hi;
+        } else {
+            const int rowb = (t & 31) * 4, kofs = (t >> 5) * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                bf16x4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = (__bf16)f4c(reg[i], c);
+                *reinterpret_cast<bf16x4 *>(&S[(rowb + c) * LR + kofs]) = v;
+            }
+        }
+    } else {
+        if (!KS) {
+            const int row = t >> 1, kofs = (t & 1) * 8;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) S[row * LR + kofs + 4 * i + e] = f4c(reg[i], e);
+        } else {
+            const int rowb = (t & 31) * 4, kofs = (t >> 5) * 2;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) S[(rowb + c) * LR + kofs + i] = f4c(reg[i], c);
+        }
+    }
+}
+
+template <bool TA, bool TB, bool BF16>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
+    using Cfg = GemmCfg<BF16>;
+    using elem = typename Cfg::elem;
+    constexpr int BK = Cfg::BK, LR = Cfg::LR, NV = Cfg::NV;
+    constexpr int TILE = BM * LR;
+    __shared__ __attribute__((aligned(16))) elem smem[4 * TILE];   // A0 A1 B0 B1
+    elem *As = smem, *Bs = smem + 2 * TILE;
+
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * a.k_per_split;
+    const int kend = min(a.K, kbeg + a.k_per_split);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1, half = lane >> 5, l31 = lane & 31;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[NV], rb[NV];
+    if (nk > 0) {
+        g2r<BF16, TA>(a.A, a.lda, a.M, m0, kbeg, kend, ra);
+        g2r<BF16, TB>(a.B, a.ldb, a.N, n0, kbeg, kend, rb);
+        r2s<BF16, TA>(As, ra);
+        r2s<BF16, TB>(Bs, rb);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            g2r<BF16, TA>(a.A, a.lda, a.M, m0, kbeg + (kt + 1) * BK, kend, ra);
+            g2r<BF16, TB>(a.B, a.ldb, a.N, n0, kbeg + (kt + 1) * BK, kend, rb);
+        }
+        const elem *Ac = As + cur * TILE + (wr * 64 + l31) * LR;
+        const elem *Bc = Bs + cur * TILE + (wc * 64 + l31) * LR;
+        if constexpr (BF16) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 af[2], bf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[i] = *reinterpret_cast<const bf16x8 *>(Ac + i * 32 * LR + ks * 16 + half * 8);
+                    bf[i] = *reinterpret_cast<const bf16x8 *>(Bc + i * 32 * LR + ks * 16 + half * 8);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                float af[2], bf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[i] = Ac[i * 32 * LR + ks * 2 + half];
+                    bf[i] = Bc[i * 32 * LR + ks * 2 + half];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (more) {
+            r2s<BF16, TA>(As + (cur ^ 1) * TILE, ra);
+            r2s<BF16, TB>(Bs + (cur ^ 1) * TILE, rb);
+        }
+        __syncthreads();
+    }
+    if (nk <= 0) return;
+
+    const bool lead = (blockIdx.z == 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wc * 64 + j * 32 + l31;
+            if (col >= a.N) continue;
+            const float bv = (a.bias != nullptr && lead) ? a.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * 64 + i * 32 + frag_row(r, half);
+                if (row >= a.M) continue;
+                float v = a.alpha * acc[i][j][r] + bv;
+                if (a.residual != nullptr && lead) {
+                    const int64_t rr = a.res_mod > 0 ? (int64_t)row % a.res_mod : (int64_t)row;
+                    v += a.residual[rr * a.ldr + col];
+                }
+                float *dst = a.C + (int64_t)row * a.ldc + col;
+                if (a.atomic) {
+                    atomicAdd(dst, v);
+                } else {
+                    if (a.beta != 0.f) v += a.beta * (*dst);
+                    *dst = v;
+                }
+            }
+        }
+}
+
+template <bool BF16>
+int launch(int ta, int tb, const GemmArgs &a, dim3 grid, hipStream_t s) {
+    if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<false, false, BF16>), grid, dim3(256), 0, s, a);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<false, true, BF16>), grid, dim3(256), 0, s, a);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<true, false, BF16>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gemm_kernel<true, true, BF16>), grid, dim3(256), 0, s, a);
+    KK_LAUNCH_CHECK("kk_gemm");
+    return 0;
+}
+
+// ---- column sums (bias gradients): out[n] += sum_m X[m,n] -------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ X, int64_t ldx, int64_t M, int N,
+                                                     float *__restrict__ out, int rows_per_block) {
+    // block = 64 columns x 4 row-lanes; grid.x = column groups, grid.y = row slabs
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const int64_t rbeg = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t rend = rbeg + rows_per_block < M ? rbeg + rows_per_block : M;
+    float s = 0.f;
+    if (c < N)
+        for (int64_t r = rbeg + rl; r < rend; r += 4) s += X[r * ldx + c];
+    red[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < N) atomicAdd(&out[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+}  // namespace
+
+extern "C" int kk_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, const float *A, int64_t lda,
+                       const float *B, int64_t ldb, float beta, float *C, int64_t ldc, const float *bias,
+                       const float *residual, int64_t ldr, int64_t res_mod, int split_k, int math, void *stream) {
+    KK_REQUIRE(M > 0 && N > 0 && K > 0, "kk_gemm: empty problem M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
+    KK_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "kk_gemm: dimension overflow");
+    KK_REQUIRE(A && B && C, "kk_gemm: null operand");
+    KK_REQUIRE(lda % 4 == 0 && ldb % 4 == 0, "kk_gemm: lda/ldb must be multiples of 4 (16-byte loads)");
+    KK_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "kk_gemm: A/B must be 16-byte aligned");
+    if (!ta || !tb) KK_REQUIRE(K % 4 == 0, "kk_gemm: K=%ld must be a multiple of 4 for a k-contiguous operand", (long)K);
+    if (ta) KK_REQUIRE(M % 4 == 0, "kk_gemm: M=%ld must be a multiple of 4 when A is stored [K,M]", (long)M);
+    if (tb) KK_REQUIRE(N % 4 == 0, "kk_gemm: N=%ld must be a multiple of 4 when B is stored [K,N]", (long)N);
+    KK_REQUIRE(math == KK_MATH_F32 || math == KK_MATH_BF16, "kk_gemm: bad math mode %d", math);
+    hipStream_t s = (hipStream_t)stream;
+    const int BK = math == KK_MATH_BF16 ? 32 : 16;
+    const int tiles = kk_cdiv(M, BM) * kk_cdiv(N, BN);
+    const int ktiles = kk_cdiv(K, BK);
+    int splits = split_k;
+    if (splits <= 0) {   // auto: fill ~2 workgroups per CU, keep >= 4 k-tiles per slice
+        splits = 1;
+        if (tiles < 256) {
+            splits = kk_cdiv(512, tiles);
+            const int cap = ktiles / 4 > 0 ? ktiles / 4 : 1;
+            if (splits > cap) splits = cap;
+        }
+    }
+    if (splits > ktiles) splits = ktiles;
+    if (splits > 1 && !(beta == 1.f || (beta == 0.f && ldc == N))) splits = 1;
+    int k_per_split = kk_cdiv(ktiles, splits) * BK;
+    splits = kk_cdiv(K, k_per_split);
+    GemmArgs a;
+    a.M = (int)M; a.N = (int)N; a.K = (int)K;
+    a.alpha = alpha; a.beta = beta;
+    a.A = A; a.B = B; a.bias = bias; a.residual = residual; a.C = C;
+    a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.res_mod = res_mod;
+    a.k_per_split = k_per_split;
+    a.atomic = splits > 1 ? 1 : 0;
+    if (splits > 1 && beta == 0.f) {
+        hipError_t e = hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), s);
+        if (e != hipSuccess) return kk_fail((int)e, "kk_gemm: memset: %s", hipGetErrorString(e));
+    }
+    dim3 grid(kk_cdiv(N, BN), kk_cdiv(M, BM), splits);
+    return math == KK_MATH_BF16 ? launch<true>(ta, tb, a, grid, s) : launch<false>(ta, tb, a, grid, s);
+}
+
+extern "C" int kk_colsum_acc(const float *X, int64_t ldx, int64_t M, int64_t N, float *out, void *stream) {
+    KK_REQUIRE(M > 0 && N > 0 && X && out, "kk_colsum_acc: bad args");
+    int slabs = kk_cdiv(M, 256);
+    if (slabs > 512) slabs = 512;
+    const int rows_per_block = kk_cdiv(M, slabs);
+    slabs = kk_cdiv(M, rows_per_block);
+    hipLaunchKernelGGL(colsum_kernel, dim3(kk_cdiv(N, 64), slabs), dim3(256), 0, (hipStream_t)stream, X, ldx, M,
+                       (int)N, out, rows_per_block);
+    KK_LAUNCH_CHECK("kk_colsum_acc");
+    return 0;
+}

@@ -1,0 +1,490 @@
+// Normalisation kernels of the Kokoro train step — all HBM-bound, one wavefront per row.
+//
+//  LayerNorm      nn.LayerNorm(H), eps 1e-5           model/transformers.py:461-462,518-520,612; model.py:122
+//  RMSNorm        nn.RMSNorm(H), eps = FLT_EPSILON    transformers.py:94,109-110 (GLU output_norm) + block residual
+//  head-norm+RoPE nn.RMSNorm(64) per head + rotate-half  transformers.py:145-148,260-277; positional_encoding.py:196-209
+//  GroupNorm(1,C) over (C x chunk frames) + ReLU      model/variance_predictor.py:55,77-87,102-106
+//
+// Rows are processed by a 64-lane wave holding the row in registers (float4 per lane per 256 columns), so a
+// row is read once and written once; statistics are two-pass in registers (mean, then centred variance).
+// Parameter gradients (gamma/beta/gain) are accumulated per workgroup in LDS and added to HBM with one
+// atomic per column per workgroup.
+#include "kk_common.h"
+#include <float.h>
+
+namespace {
+
+constexpr int MAXV = 8;   // float4 per lane -> H <= 2048
+
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// ------------------------------------------------------------------ LayerNorm
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, float *__restrict__ y,
+                                                            float *__restrict__ mean_o, float *__restrict__ rstd_o,
+                                                            int64_t rows, int H) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *xr = x + row * H;
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        v[i] = c < H ? ld4(xr + c) : f4zero();
+        s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+    const float mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < H) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            q += a * a + b * b + cc * cc + d * d;
+        }
+    }
+    const float rstd = 1.f / sqrtf(wave_sum(q) / (float)H + 1e-5f);
+    float *yr = y + row * H;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < H) {
+            const float4 g = ld4(gamma + c), b = ld4(beta + c);
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * g.x + b.x;
+            o.y = (v[i].y - mean) * rstd * g.y + b.y;
+            o.z = (v[i].z - mean) * rstd * g.z + b.z;
+            o.w = (v[i].w - mean) * rstd * g.w + b.w;
+            st4(yr + c, o);
+        }
+    }
+    if (lane == 0) {
+        mean_o[row] = mean;
+        rstd_o[row] = rstd;
+    }
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                            const float *__restrict__ gamma, const float *__restrict__ mean,
+                                                            const float *__restrict__ rstd, float *__restrict__ dx,
+                                                            int dx_acc, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                            int64_t rows, int H) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [2][H]
+    float *sg = sm, *sb = sm + H;
+    for (int c = threadIdx.x; c < 2 * H; c += 256) sm[c] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    float4 ag[MAXV], ab[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) { ag[i] = f4zero(); ab[i] = f4zero(); }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float4 xh[MAXV], dg[MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane * 4 + 256 * i;
+            if (c < H) {
+                const float4 xv = ld4(x + row * H + c), d = ld4(dy + row * H + c), g = ld4(gamma + c);
+                xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                dg[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+                s1 += dg[i].x + dg[i].y + dg[i].z + dg[i].w;
+                s2 += dg[i].x * xh[i].x + dg[i].y * xh[i].y + dg[i].z * xh[i].z + dg[i].w * xh[i].w;
+                ag[i].x += d.x * xh[i].x; ag[i].y += d.y * xh[i].y; ag[i].z += d.z * xh[i].z; ag[i].w += d.w * xh[i].w;
+                ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+            } else { xh[i] = f4zero(); dg[i] = f4zero(); }
+        }
+        s1 = wave_sum(s1) / (float)H;
+        s2 = wave_sum(s2) / (float)H;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane * 4 + 256 * i;
+            if (c < H) {
+                float4 o;
+                o.x = rs * (dg[i].x - s1 - xh[i].x * s2);
+                o.y = rs * (dg[i].y - s1 - xh[i].y * s2);
+                o.z = rs * (dg[i].z - s1 - xh[i].z * s2);
+                o.w = rs * (dg[i].w - s1 - xh[i].w * s2);
+                float *p = dx + row * H + c;
+                if (dx_acc) { const float4 old = ld4(p); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+                st4(p, o);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < H) {
+            atomicAdd(&sg[c], ag[i].x); atomicAdd(&sg[c + 1], ag[i].y); atomicAdd(&sg[c + 2], ag[i].z); atomicAdd(&sg[c + 3], ag[i].w);
+            atomicAdd(&sb[c], ab[i].x); atomicAdd(&sb[c + 1], ab[i].y); atomicAdd(&sb[c + 2], ab[i].z); atomicAdd(&sb[c + 3], ab[i].w);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += 256) {
+        atomicAdd(&dgamma[c], sg[c]);
+        atomicAdd(&dbeta[c], sb[c]);
+    }
+}
+
+// ------------------------------------------------------------------ RMSNorm (+ residual)
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gain,
+                                                          const float *__restrict__ residual, float *__restrict__ y,
+                                                          float *__restrict__ rstd_o, int64_t rows, int H) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float4 v[MAXV];
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        v[i] = c < H ? ld4(x + row * H + c) : f4zero();
+        q += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+    }
+    const float rs = 1.f / sqrtf(wave_sum(q) / (float)H + FLT_EPSILON);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < H) {
+            const float4 g = ld4(gain + c);
+            float4 o = make_float4(v[i].x * rs * g.x, v[i].y * rs * g.y, v[i].z * rs * g.z, v[i].w * rs * g.w);
+            if (residual) { const float4 r = ld4(residual + row * H + c); o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+            st4(y + row * H + c, o);
+        }
+    }
+    if (lane == 0) rstd_o[row] = rs;
+}
+
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                          const float *__restrict__ gain, const float *__restrict__ rstd,
+                                                          float *__restrict__ dx, float *__restrict__ dgain, int64_t rows, int H) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [H]
+    for (int c = threadIdx.x; c < H; c += 256) sm[c] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    float4 ag[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) ag[i] = f4zero();
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+        const float rs = rstd[row];
+        float4 xv[MAXV], dg[MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane * 4 + 256 * i;
+            if (c < H) {
+                xv[i] = ld4(x + row * H + c);
+                const float4 d = ld4(dy + row * H + c), g = ld4(gain + c);
+                dg[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+                s += dg[i].x * xv[i].x + dg[i].y * xv[i].y + dg[i].z * xv[i].z + dg[i].w * xv[i].w;
+                ag[i].x += d.x * xv[i].x * rs; ag[i].y += d.y * xv[i].y * rs; ag[i].z += d.z * xv[i].z * rs; ag[i].w += d.w * xv[i].w * rs;
+            } else { xv[i] = f4zero(); dg[i] = f4zero(); }
+        }
+        const float k = wave_sum(s) / (float)H * rs * rs * rs;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = lane * 4 + 256 * i;
+            if (c < H)
+                st4(dx + row * H + c, make_float4(rs * dg[i].x - xv[i].x * k, rs * dg[i].y - xv[i].y * k,
+                                                   rs * dg[i].z - xv[i].z * k, rs * dg[i].w - xv[i].w * k));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < H) { atomicAdd(&sm[c], ag[i].x); atomicAdd(&sm[c + 1], ag[i].y); atomicAdd(&sm[c + 2], ag[i].z); atomicAdd(&sm[c + 3], ag[i].w); }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += 256) atomicAdd(&dgain[c], sm[c]);
+}
+
+// ------------------------------------------------------------------ per-head RMSNorm(64) + RoPE
+// One wave per (row, head); lane = d.  rotate_half(n)[d] = -n[d+32] (d<32), n[d-32] (d>=32).
+__global__ __launch_bounds__(256) void headnorm_rope_fwd_kernel(const float *__restrict__ x, int64_t ldx,
+                                                                const float *__restrict__ gain, float *__restrict__ y,
+                                                                int64_t ldy, int64_t npairs, int heads, int S,
+                                                                const float *__restrict__ cos_t, const float *__restrict__ sin_t) {
+    const int lane = threadIdx.x & 63;
+    const float g = gain[lane];
+    for (int64_t pr = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); pr < npairs; pr += (int64_t)gridDim.x * 4) {
+        const int64_t row = pr / heads;
+        const int hd = (int)(pr - row * heads);
+        const float v = x[row * ldx + hd * 64 + lane];
+        const float rs = 1.f / sqrtf(wave_sum(v * v) * (1.f / 64.f) + FLT_EPSILON);
+        float n = v * rs * g;
+        if (cos_t) {
+            const int pos = (int)(row % S);
+            const float other = __shfl_xor(n, 32, 64);
+            const float rot = lane < 32 ? -other : other;
+            n = n * cos_t[pos * 64 + lane] + rot * sin_t[pos * 64 + lane];
+        }
+        y[row * ldy + hd * 64 + lane] = n;
+    }
+}
+
+__global__ __launch_bounds__(256) void headnorm_rope_bwd_kernel(const float *__restrict__ dy, int64_t lddy,
+                                                                const float *__restrict__ x, int64_t ldx,
+                                                                const float *__restrict__ gain, float *__restrict__ dx,
+                                                                int64_t lddx, float *__restrict__ dgain, int64_t npairs,
+                                                                int heads, int S, const float *__restrict__ cos_t,
+                                                                const float *__restrict__ sin_t) {
+    const int lane = threadIdx.x & 63;
+    const float g = gain[lane];
+    float acc_g = 0.f;
+    for (int64_t pr = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); pr < npairs; pr += (int64_t)gridDim.x * 4) {
+        const int64_t row = pr / heads;
+        const int hd = (int)(pr - row * heads);
+        const float v = x[row * ldx + hd * 64 + lane];
+        const float rs = 1.f / sqrtf(wave_sum(v * v) * (1.f / 64.f) + FLT_EPSILON);
+        float dn = dy[row * lddy + hd * 64 + lane];
+        if (cos_t) {
+            const int pos = (int)(row % S);
+            const float c = cos_t[pos * 64 + lane], sn = sin_t[pos * 64 + lane];
+            const float ds = dn * sn;                         // dy[e]*sin[e]
+            const float other = __shfl_xor(ds, 32, 64);       // dy[d^32]*sin[d^32]
+            dn = dn * c + (lane < 32 ? other : -other);
+        }
+        acc_g += dn * v * rs;
+        const float dgv = dn * g;
+        const float k = wave_sum(dgv * v) * (1.f / 64.f) * rs * rs * rs;
+        dx[row * lddx + hd * 64 + lane] = rs * dgv - v * k;
+    }
+    atomicAdd(&dgain[lane], acc_g);
+}
+
+// ------------------------------------------------------------------ GroupNorm(1,C) per 512-frame chunk + ReLU
+__device__ __forceinline__ int chunk_frames(int L, int chunk, int ci) {
+    const int beg = ci * chunk;
+    return (L - beg) < chunk ? (L - beg) : chunk;
+}
+
+// scratch[(b*nch+ci)*2 + {0,1}] += (sum, sumsq) of slice `blockIdx.x` of the chunk (contiguous frames*C floats).
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float *__restrict__ x, double *__restrict__ scratch, int L,
+                                                         int C, int chunk, int nch, int slices) {
+    __shared__ double red[4];
+    const int bc = blockIdx.y, b = bc / nch, ci = bc % nch;
+    const int64_t n = (int64_t)chunk_frames(L, chunk, ci) * C;
+    const float *base = x + ((int64_t)b * L + (int64_t)ci * chunk) * C;
+    const int64_t per = ((n / 4 + slices - 1) / slices) * 4;
+    const int64_t beg = (int64_t)blockIdx.x * per, end = beg + per < n ? beg + per : n;
+    float s = 0.f, q = 0.f;
+    for (int64_t i = beg + threadIdx.x * 4; i < end; i += 1024) {
+        const float4 v = ld4(base + i);
+        s += v.x + v.y + v.z + v.w;
+        q += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    const double ds = block_sum_256_d((double)s, red);
+    const double dq = block_sum_256_d((double)q, red);
+    if (threadIdx.x == 0 && beg < end) {
+        atomicAdd(&scratch[bc * 2], ds);
+        atomicAdd(&scratch[bc * 2 + 1], dq);
+    }
+}
+
+__global__ void gn_finalize_kernel(const double *__restrict__ scratch, float *__restrict__ stats, int L, int C, int chunk,
+                                   int nch, int total) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const double n = (double)chunk_frames(L, chunk, i % nch) * C;
+    const double mean = scratch[i * 2] / n;
+    double var = scratch[i * 2 + 1] / n - mean * mean;
+    if (var < 0) var = 0;
+    stats[i * 2] = (float)mean;
+    stats[i * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
+}
+
+__global__ __launch_bounds__(256) void gn_apply_relu_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, const float *__restrict__ stats,
+                                                            float *__restrict__ y, int64_t total4, int L, int C, int chunk, int nch) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int64_t e = i * 4;
+        const int c = (int)(e % C);
+        const int64_t fr = e / C;
+        const int l = (int)(fr % L), b = (int)(fr / L), ci = l / chunk;
+        float4 o = f4zero();
+        if (chunk_frames(L, chunk, ci) >= 2) {
+            const float mu = stats[(b * nch + ci) * 2], rs = stats[(b * nch + ci) * 2 + 1];
+            const float4 v = ld4(x + e), g = ld4(gamma + c), bt = ld4(beta + c);
+            o.x = fmaxf((v.x - mu) * rs * g.x + bt.x, 0.f);
+            o.y = fmaxf((v.y - mu) * rs * g.y + bt.y, 0.f);
+            o.z = fmaxf((v.z - mu) * rs * g.z + bt.z, 0.f);
+            o.w = fmaxf((v.w - mu) * rs * g.w + bt.w, 0.f);
+        }
+        st4(y + e, o);
+    }
+}
+
+// Backward pass 1: per (b,chunk) sums of dxhat and dxhat*xhat (double scratch) + dgamma/dbeta column sums.
+// Block = 256 threads arranged as (256/C) frame-lanes x C columns; blockIdx.x = frame slab, blockIdx.y = (b,chunk).
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                             const float *__restrict__ y, const float *__restrict__ gamma,
+                                                             const float *__restrict__ stats, double *__restrict__ scratch,
+                                                             float *__restrict__ dgamma, float *__restrict__ dbeta, int L, int C,
+                                                             int chunk, int nch, int slabs) {
+    __shared__ double red[4];
+    const int bc = blockIdx.y, b = bc / nch, ci = bc % nch;
+    const int nf = chunk_frames(L, chunk, ci);
+    const int lanes = 256 / C, c = threadIdx.x % C, fl = threadIdx.x / C;
+    const int per = (nf + slabs - 1) / slabs;
+    const int fbeg = blockIdx.x * per, fend = fbeg + per < nf ? fbeg + per : nf;
+    const float mu = stats[bc * 2], rs = stats[bc * 2 + 1], g = gamma[c];
+    const int64_t base = ((int64_t)b * L + (int64_t)ci * chunk) * C;
+    float ag = 0.f, ab = 0.f, s1 = 0.f, s2 = 0.f;
+    if (nf >= 2)
+        for (int f = fbeg + fl; f < fend; f += lanes) {
+            const int64_t o = base + (int64_t)f * C + c;
+            const float d = y[o] > 0.f ? dy[o] : 0.f;
+            const float xh = (x[o] - mu) * rs;
+            ag += d * xh; ab += d;
+            s1 += d * g; s2 += d * g * xh;
+        }
+    if (ag != 0.f || ab != 0.f) { atomicAdd(&dgamma[c], ag); atomicAdd(&dbeta[c], ab); }
+    const double d1 = block_sum_256_d((double)s1, red);
+    const double d2 = block_sum_256_d((double)s2, red);
+    if (threadIdx.x == 0 && fbeg < fend) {
+        atomicAdd(&scratch[bc * 2], d1);
+        atomicAdd(&scratch[bc * 2 + 1], d2);
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                           const float *__restrict__ y, const float *__restrict__ gamma,
+                                                           const float *__restrict__ stats, const double *__restrict__ scratch,
+                                                           float *__restrict__ dx, int64_t total4, int L, int C, int chunk, int nch) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int64_t e = i * 4;
+        const int c = (int)(e % C);
+        const int64_t fr = e / C;
+        const int l = (int)(fr % L), b = (int)(fr / L), ci = l / chunk, bc = b * nch + ci;
+        const int nf = chunk_frames(L, chunk, ci);
+        float4 o = f4zero();
+        if (nf >= 2) {
+            const double n = (double)nf * C;
+            const float m1 = (float)(scratch[bc * 2] / n), m2 = (float)(scratch[bc * 2 + 1] / n);
+            const float mu = stats[bc * 2], rs = stats[bc * 2 + 1];
+            const float4 d = ld4(dy + e), xv = ld4(x + e), yv = ld4(y + e), g = ld4(gamma + c);
+            o.x = rs * ((yv.x > 0.f ? d.x * g.x : 0.f) - m1 - (xv.x - mu) * rs * m2);
+            o.y = rs * ((yv.y > 0.f ? d.y * g.y : 0.f) - m1 - (xv.y - mu) * rs * m2);
+            o.z = rs * ((yv.z > 0.f ? d.z * g.z : 0.f) - m1 - (xv.z - mu) * rs * m2);
+            o.w = rs * ((yv.w > 0.f ? d.w * g.w : 0.f) - m1 - (xv.w - mu) * rs * m2);
+        }
+        st4(dx + e, o);
+    }
+}
+
+inline int row_blocks(int64_t rows) { return kk_cdiv(rows, 4); }
+
+}  // namespace
+
+#define KK_CHECK_H(name)                                                                                  \
+    KK_REQUIRE(rows > 0 && H > 0 && H % 4 == 0 && H <= 256 * MAXV, name ": unsupported rows=%ld H=%d", \
+               (long)rows, H)
+
+extern "C" int kk_layernorm_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean,
+                                float *rstd, int64_t rows, int H, void *stream) {
+    KK_CHECK_H("kk_layernorm_fwd");
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(row_blocks(rows)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
+                       y, mean, rstd, rows, H);
+    KK_LAUNCH_CHECK("kk_layernorm_fwd");
+    return 0;
+}
+
+extern "C" int kk_layernorm_bwd(const float *dy, const float *x, const float *gamma, const float *mean,
+                                const float *rstd, float *dx, int dx_accumulate, float *dgamma, float *dbeta,
+                                int64_t rows, int H, void *stream) {
+    KK_CHECK_H("kk_layernorm_bwd");
+    int blocks = row_blocks(rows);
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 2 * H * sizeof(float), (hipStream_t)stream, dy, x,
+                       gamma, mean, rstd, dx, dx_accumulate, dgamma, dbeta, rows, H);
+    KK_LAUNCH_CHECK("kk_layernorm_bwd");
+    return 0;
+}
+
+extern "C" int kk_rmsnorm_fwd(const float *x, const float *gain, const float *residual, float *y, float *rstd,
+                              int64_t rows, int H, void *stream) {
+    KK_CHECK_H("kk_rmsnorm_fwd");
+    hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(row_blocks(rows)), dim3(256), 0, (hipStream_t)stream, x, gain, residual,
+                       y, rstd, rows, H);
+    KK_LAUNCH_CHECK("kk_rmsnorm_fwd");
+    return 0;
+}
+
+extern "C" int kk_rmsnorm_bwd(const float *dy, const float *x, const float *gain, const float *rstd, float *dx,
+                              float *dgain, int64_t rows, int H, void *stream) {
+    KK_CHECK_H("kk_rmsnorm_bwd");
+    int blocks = row_blocks(rows);
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(blocks), dim3(256), H * sizeof(float), (hipStream_t)stream, dy, x, gain,
+                       rstd, dx, dgain, rows, H);
+    KK_LAUNCH_CHECK("kk_rmsnorm_bwd");
+    return 0;
+}
+
+extern "C" int kk_headnorm_rope_fwd(const float *x, int64_t ldx, const float *gain, float *y, int64_t ldy,
+                                    int64_t rows, int heads, int S, const float *cos_t, const float *sin_t,
+                                    void *stream) {
+    KK_REQUIRE(rows > 0 && heads > 0 && S > 0, "kk_headnorm_rope_fwd: bad shape");
+    KK_REQUIRE((cos_t == nullptr) == (sin_t == nullptr), "kk_headnorm_rope_fwd: cos/sin must both be set or null");
+    const int64_t npairs = rows * heads;
+    int blocks = kk_cdiv(npairs, 4);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(headnorm_rope_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, gain, y, ldy,
+                       npairs, heads, S, cos_t, sin_t);
+    KK_LAUNCH_CHECK("kk_headnorm_rope_fwd");
+    return 0;
+}
+
+extern "C" int kk_headnorm_rope_bwd(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *gain,
+                                    float *dx, int64_t lddx, float *dgain, int64_t rows, int heads, int S,
+                                    const float *cos_t, const float *sin_t, void *stream) {
+    KK_REQUIRE(rows > 0 && heads > 0 && S > 0, "kk_headnorm_rope_bwd: bad shape");
+    const int64_t npairs = rows * heads;
+    int blocks = kk_cdiv(npairs, 4);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(headnorm_rope_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, lddy, x, ldx, gain,
+                       dx, lddx, dgain, npairs, heads, S, cos_t, sin_t);
+    KK_LAUNCH_CHECK("kk_headnorm_rope_bwd");
+    return 0;
+}
+
+extern "C" int kk_groupnorm_relu_fwd(const float *x, const float *gamma, const float *beta, float *y, float *stats,
+                                     double *scratch, int B, int L, int C, int chunk, void *stream) {
+    KK_REQUIRE(B > 0 && L > 0 && C > 0 && C % 4 == 0 && chunk > 0, "kk_groupnorm_relu_fwd: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const int nch = kk_cdiv(L, chunk), total = B * nch;
+    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * 2 * total, s);
+    if (e != hipSuccess) return kk_fail((int)e, "kk_groupnorm_relu_fwd: memset failed");
+    const int slices = 32;
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(slices, total), dim3(256), 0, s, x, scratch, L, C, chunk, nch, slices);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(kk_cdiv(total, 64)), dim3(64), 0, s, scratch, stats, L, C, chunk, nch, total);
+    const int64_t total4 = (int64_t)B * L * C / 4;
+    int blocks = kk_cdiv(total4, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gn_apply_relu_kernel, dim3(blocks), dim3(256), 0, s, x, gamma, beta, stats, y, total4, L, C, chunk, nch);
+    KK_LAUNCH_CHECK("kk_groupnorm_relu_fwd");
+    return 0;
+}
+
+extern "C" int kk_groupnorm_relu_bwd(const float *dy, const float *x, const float *y, const float *gamma,
+                                     const float *stats, float *dx, float *dgamma, float *dbeta, double *scratch,
+                                     int B, int L, int C, int chunk, void *stream) {
+    KK_REQUIRE(B > 0 && L > 0 && C > 0 && C % 4 == 0 && chunk > 0, "kk_groupnorm_relu_bwd: bad shape");
+    KK_REQUIRE(C <= 256 && 256 % C == 0, "kk_groupnorm_relu_bwd: C=%d must divide 256", C);
+    hipStream_t s = (hipStream_t)stream;
+    const int nch = kk_cdiv(L, chunk), total = B * nch;
+    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * 2 * total, s);
+    if (e != hipSuccess) return kk_fail((int)e, "kk_groupnorm_relu_bwd: memset failed");
+    const int slabs = 16;
+    hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(slabs, total), dim3(256), 0, s, dy, x, y, gamma, stats, scratch, dgamma,
+                       dbeta, L, C, chunk, nch, slabs);
+    const int64_t total4 = (int64_t)B * L * C / 4;
+    int blocks = kk_cdiv(total4, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, s, dy, x, y, gamma, stats, scratch, dx, total4, L, C,
+                       chunk, nch);
+    KK_LAUNCH_CHECK("kk_groupnorm_relu_bwd");
+    return 0;
+}

@@ -1,0 +1,124 @@
+"""ctypes binding of libkokoro_hip.so (declared in include/kokoro_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a call fails, a
+RuntimeError carrying ``kk_last_error()`` is raised (same convention as the reference, which
+raises from Python — SURVEY §8b "Error conventions").
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Any, Dict, List
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libkokoro_hip.so")
+
+KK_MATH_F32, KK_MATH_BF16 = 0, 1
+KK_SEG_ALIGN = 1024
+OS = dict(SKIPPED=0, EXPL_EMA=1, EXPL_EMA_STEPS=2, EXPL_STREAK=3, LAST_GRAD_NORM=4, LAST_CLIP_COEF=5,
+          LAST_SKIP=6, LAST_BASE_LR=7, LAST_CLIP_NORM=8, EXPL_EMA_VALID=9, ATTEMPT=10, SIZE=16)
+
+
+class KkLossCfg(C.Structure):
+    _fields_ = [("w_dur", C.c_float), ("w_stop", C.c_float), ("w_pitch", C.c_float), ("w_energy", C.c_float),
+                ("delta_dur", C.c_float), ("delta_pitch", C.c_float), ("delta_energy", C.c_float),
+                ("pos_weight", C.c_float), ("loss_scale", C.c_float), ("adaptive", C.c_int)]
+
+
+class KkOptCfg(C.Structure):
+    _fields_ = [("learning_rate", C.c_double), ("max_lr", C.c_double), ("warmup_start_lr", C.c_double),
+                ("warmup_target_lr", C.c_double), ("pct_start", C.c_double), ("div_factor", C.c_double),
+                ("final_div_factor", C.c_double), ("warmup_steps", C.c_int64), ("onecycle_steps", C.c_int64),
+                ("use_warmup", C.c_int), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+                ("max_grad_norm", C.c_double), ("mel_length", C.c_int64), ("expl_alpha", C.c_double),
+                ("expl_abs_floor", C.c_double), ("expl_multiplier", C.c_double), ("expl_warmup_floor", C.c_double),
+                ("expl_warmup_steps", C.c_int64), ("expl_min_ema_steps", C.c_int64), ("ema_decay", C.c_double),
+                ("max_weight_norm", C.c_double)]
+
+
+_P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
+
+# name -> argtypes, in header order (tests/test_abi.py cross-checks arity against include/kokoro_hip.h)
+SIGNATURES: Dict[str, List[Any]] = {
+    "kk_gemm": [_I, _I, _L, _L, _L, _F, _P, _L, _P, _L, _F, _P, _L, _P, _P, _L, _L, _I, _I, _P],
+    "kk_colsum_acc": [_P, _L, _L, _L, _P, _P],
+    "kk_attn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _F, _I, _P],
+    "kk_attn_delta": [_P, _P, _P, _I, _I, _I, _L, _L, _P],
+    "kk_attn_bwd_dq": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _P, _I, _F, _I, _P],
+    "kk_attn_bwd_dkv": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _P, _I, _F, _I, _P],
+    "kk_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _P],
+    "kk_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _I, _P],
+    "kk_rmsnorm_fwd": [_P, _P, _P, _P, _P, _L, _I, _P],
+    "kk_rmsnorm_bwd": [_P, _P, _P, _P, _P, _P, _L, _I, _P],
+    "kk_headnorm_rope_fwd": [_P, _L, _P, _P, _L, _L, _I, _I, _P, _P, _P],
+    "kk_headnorm_rope_bwd": [_P, _L, _P, _L, _P, _P, _L, _P, _L, _I, _I, _P, _P, _P],
+    "kk_glu_fwd": [_P, _P, _L, _I, _P],
+    "kk_glu_bwd": [_P, _P, _P, _L, _I, _P],
+    "kk_embed_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
+    "kk_embed_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
+    "kk_length_regulate_index": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "kk_length_regulate_gather": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "kk_max_i64": [_P, _L, _P, _P],
+    "kk_im2col3_fwd": [_P, _P, _I, _I, _I, _I, _P],
+    "kk_im2col3_bwd": [_P, _P, _I, _I, _I, _I, _P],
+    "kk_groupnorm_relu_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "kk_groupnorm_relu_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "kk_rowdot_fwd": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
+    "kk_rowdot_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
+    "kk_bucket_embed_add_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "kk_bucket_embed_add_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "kk_ids_eq_zero": [_P, _P, _L, _P],
+    "kk_shift_right": [_P, _P, _I, _I, _I, _P],
+    "kk_losses_fwd": [_P] * 12 + [_I, _I, _I, _I, C.POINTER(KkLossCfg), _P, _P, _P, _P, _P],
+    "kk_losses_bwd": [_P] * 12 + [_I, _I, _I, _I, C.POINTER(KkLossCfg), _P, _P, _P, _P, _P, _P, _P],
+    "kk_seg_sumsq": [_P, _P, _L, _P, _I, _P],
+    "kk_opt_prepare": [_P, _P, _P, _P, _I, _P, C.POINTER(KkOptCfg), _P, _P, _P, _P, _P, _P],
+    "kk_adamw_ema": [_P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _F, _F, _F, _P, _I, _P],
+    "kk_weight_norm_project": [_P, _P, _L, _P, _P, _P, _D, _P],
+    "kk_axpby": [_F, _P, _F, _P, _L, _P],
+    "kk_mfma_probe": [_P, _P, _P],
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once).  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -m kokoro_ruslan_amd.build` "
+                           "(the MI355X engine has no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    lib.kk_last_error.restype = C.c_char_p
+    lib.kk_abi_version.restype = C.c_int
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    if lib.kk_abi_version() != 1:
+        raise RuntimeError("libkokoro_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _conv(a):
+    if a is None:
+        return None
+    if hasattr(a, "data_ptr"):
+        return a.data_ptr()
+    if isinstance(a, C.Structure):
+        return C.byref(a)
+    return a
+
+
+def call(name: str, *args) -> None:
+    """Invoke ``name`` with torch tensors (→ device pointers), scalars and cfg structs; the current
+    torch stream is appended as the trailing ``stream`` argument."""
+    import torch
+    lib = load()
+    stream = torch.cuda.current_stream().cuda_stream
+    rc = getattr(lib, name)(*[_conv(a) for a in args], stream)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (code {rc}): {lib.kk_last_error().decode(errors='replace')}")
