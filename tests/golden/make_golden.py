@@ -51,7 +51,7 @@ from oracle import kokoro_oracle as O                           # noqa: E402
 
 torch.manual_seed(0)
 logging.disable(logging.CRITICAL)
-WN_CEIL = 5.0
+WN_CEIL = 6.0
 
 
 def ref_model(d: O.ModelDims) -> KokoroModel:
@@ -132,7 +132,7 @@ def seeded_params(d: O.ModelDims, seed: int):
     return P
 
 
-def section_model(tag: str, d: O.ModelDims, B, T, Pn, seed, ragged, save_step: bool, seeded: bool = False):
+def section_model(tag: str, d: O.ModelDims, B, T, Pn, seed, ragged, save_step: bool, seeded: bool = True):
     print(f"== {tag}: dims={d} batch=({B},{T},{Pn}) ragged={ragged} seeded={seeded}")
     cfg = TrainingConfig()
     hp = O.StepHyper()
@@ -258,9 +258,15 @@ def section_model(tag: str, d: O.ModelDims, B, T, Pn, seed, ragged, save_step: b
         fx["step/grad_scale"] = np.array(40.0)
         fx["step/max_weight_norm"] = np.array(WN_CEIL)
         fx["step/grad_norm"] = np.array(info["grad_norm"])
+        fx["step/clip_coef"] = np.array(info["clip_coef"])
+        fx["step/param_norms"] = np.array([float(sd[n].double().norm()) for n in names])
+        fx["step/param_sums"] = np.array([float(sd[n].double().sum()) for n in names])
+        fx["step/delta_norms"] = np.array([float((sd[n].double() - P[n].double()).norm()) for n in names])
+        fx["step/ema_delta_norms"] = np.array([float((esd[n].double() - P[n].double()).norm()) for n in names])
         for n in names:
-            fx[f"step_param/{n}"] = sd[n].numpy()
-            fx[f"step_ema/{n}"] = esd[n].numpy()
+            if sd[n].dim() == 1:
+                fx[f"step_param/{n}"] = sd[n].numpy()
+                fx[f"step_ema/{n}"] = esd[n].numpy()
         fx["step/preclipped"] = np.array(sorted(clipped.keys()))
     np.savez_compressed(os.path.join(HERE, f"{tag}.npz"), **fx)
     print(f"  wrote {tag}.npz")
@@ -379,7 +385,7 @@ def section_loss_known_answers():
 
 
 if __name__ == "__main__":
-    tiny = O.ModelDims(vocab=59, mel=20, hidden=64, heads=2, enc_layers=2, dec_layers=2, enc_ff=96,
+    tiny = O.ModelDims(vocab=59, mel=20, hidden=128, heads=2, enc_layers=2, dec_layers=2, enc_ff=96,
                        dec_ff=96, var_filter=32, var_kernel=3, var_bins=16, max_len=700)
     section_lengths()
     section_loss_known_answers()

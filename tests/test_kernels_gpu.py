@@ -1,0 +1,432 @@
+"""GPU suite, kernel level: every C-ABI entry point against a plain fp32 PyTorch/NumPy restatement on the same
+seeded inputs (the oracle's pieces), called through the C ABI (kokoro_ruslan_amd.lib.call)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import kokoro_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def kk():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from kokoro_ruslan_amd import lib
+    lib.load()
+    return lib
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def close(got, ref, atol, rtol, what=""):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    assert not bool(bad.any()), (f"{what}: {int(bad.sum())}/{bad.numel()} off; max|err|={float(err.max()):.3e} "
+                                 f"max|ref|={float(ref.abs().max()):.3e}")
+
+
+TOL = {0: (2e-5, 2e-5), 1: (3e-2, 3e-2)}   # math mode -> (atol, rtol) for O(1) data
+
+
+def test_mfma_fragment_layout(kk):
+    o32, o16 = torch.zeros(32, 32, device="cuda"), torch.zeros(32, 32, device="cuda")
+    kk.call("kk_mfma_probe", o32, o16)
+    i = torch.arange(32.0)[:, None]
+    k = torch.arange(16.0)
+    A = i + 0.25 * k[None, :] - 3.0
+    Bm = 0.5 * k[:, None] - 0.125 * torch.arange(32.0)[None, :] + 1.0
+    ref = A @ Bm
+    close(o32, ref, 1e-4, 1e-6, "f32 mfma 32x32x2")
+    close(o16, A.bfloat16().float() @ Bm.bfloat16().float(), 1e-3, 1e-6, "bf16 mfma 32x32x16")
+
+
+@pytest.mark.parametrize("math_mode", [0, 1])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 80, 80), (517, 1536, 512), (64, 512, 1544)])
+def test_gemm_layouts(kk, math_mode, ta, tb, M, N, K):
+    if ta and M % 4:
+        M += 4 - M % 4
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + ta * 2 + tb)
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    Bm = torch.randn((K, N) if tb else (N, K), generator=g)
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(50, N, generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    Aop = A.t() if ta else A
+    Bop = Bm if tb else Bm.t()
+    if math_mode:
+        Aop, Bop = Aop.bfloat16().float(), Bop.bfloat16().float()
+    ref = 0.5 * (Aop.double() @ Bop.double()).float() + bias + res[torch.arange(M) % 50] + 2.0 * C0
+    Cd = dev(C0)
+    kk.call("kk_gemm", ta, tb, M, N, K, 0.5, dev(A), A.shape[1], dev(Bm), Bm.shape[1], 2.0, Cd, N, dev(bias), dev(res),
+            N, 50, 1, math_mode)
+    atol, rtol = (2e-4, 2e-5) if math_mode == 0 else (5e-2, 1e-3)
+    close(Cd, ref, atol * math.sqrt(K / 64), rtol, f"gemm ta={ta} tb={tb} {M}x{N}x{K} math={math_mode}")
+
+
+@pytest.mark.parametrize("math_mode", [0, 1])
+def test_gemm_splitk_wgrad(kk, math_mode):
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 512, 256, 4096              # dW[M=512 out rows, N=256] = dY^T[K=4096 rows] . X
+    dY, X = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
+    acc0 = torch.randn(M, N, generator=g)
+    a, b = (dY.bfloat16().float(), X.bfloat16().float()) if math_mode else (dY, X)
+    ref = (a.t().double() @ b.double()).float()
+    for beta, split in ((1.0, 0), (0.0, 0), (1.0, 8), (0.0, 1)):
+        Cd = dev(acc0)
+        kk.call("kk_gemm", 1, 1, M, N, K, 1.0, dev(dY), M, dev(X), N, beta, Cd, N, None, None, 0, 0, split, math_mode)
+        close(Cd, ref + beta * acc0, 2e-3 if math_mode == 0 else 0.3, 1e-3, f"split-k beta={beta} split={split}")
+
+
+def test_colsum(kk):
+    X = torch.randn(777, 200)
+    out = dev(torch.ones(200))
+    kk.call("kk_colsum_acc", dev(X), 200, 777, 200, out)
+    close(out, 1 + X.sum(0), 1e-3, 1e-5, "colsum")
+
+
+def _attn_ref(q, k, v, causal, key_mask, scale):
+    # q,k,v [B,h,S,d] double
+    s = q @ k.transpose(-1, -2) * scale
+    if causal:
+        s = s + torch.triu(torch.full(s.shape[-2:], float("-inf"), dtype=s.dtype), 1)
+    if key_mask is not None:
+        s = s.masked_fill(key_mask.bool()[:, None, None, :], float("-inf"))
+    return torch.softmax(s, -1) @ v
+
+
+@pytest.mark.parametrize("math_mode", [0, 1])
+@pytest.mark.parametrize("B,h,Sq,Sk,causal,masked", [(2, 2, 64, 64, 0, 1), (1, 2, 200, 200, 1, 0),
+                                                      (2, 1, 37, 150, 0, 1), (1, 8, 300, 300, 1, 0),
+                                                      (2, 2, 130, 70, 0, 0)])
+def test_attention_fwd_bwd(kk, math_mode, B, h, Sq, Sk, causal, masked):
+    g = torch.Generator().manual_seed(Sq * 3 + Sk + causal)
+    H = h * 64
+    Q, K, V = (torch.randn(B, S, H, generator=g) for S in (Sq, Sk, Sk))
+    dO = torch.randn(B, Sq, H, generator=g)
+    km = None
+    if masked:
+        km = torch.rand(B, Sk, generator=g) < 0.3
+        km[:, 0] = False
+    scale = 1 / 8.0
+
+    def heads(x, S):
+        return x.view(B, S, h, 64).transpose(1, 2)
+    Qr, Kr, Vr = (t.clone().double().requires_grad_(True) for t in (Q, K, V))
+    if math_mode:
+        Qr, Kr, Vr = (t.detach().bfloat16().double().requires_grad_(True) for t in (Q, K, V))
+    ref = _attn_ref(heads(Qr, Sq), heads(Kr, Sk), heads(Vr, Sk), causal, km, scale).transpose(1, 2).reshape(B, Sq, H)
+    ref.backward(dO.double())
+    Qd, Kd, Vd, dOd = dev(Q), dev(K), dev(V), dev(dO)
+    Od = torch.zeros(B, Sq, H, device="cuda")
+    lse = torch.zeros(B, h, Sq, device="cuda")
+    kmd = dev(km.to(torch.uint8)) if km is not None else None
+    kk.call("kk_attn_fwd", Qd, Kd, Vd, Od, lse, B, h, Sq, Sk, H, H, H, H, kmd, causal, scale, math_mode)
+    atol, rtol = (2e-5, 1e-4) if math_mode == 0 else (3e-2, 3e-2)
+    close(Od, ref, atol, rtol, "attn fwd")
+    delta = torch.zeros(B, h, Sq, device="cuda")
+    kk.call("kk_attn_delta", Od, dOd, delta, B, h, Sq, H, H)
+    dQ, dK, dV = (torch.zeros_like(t) for t in (Qd, Kd, Vd))
+    kk.call("kk_attn_bwd_dq", Qd, Kd, Vd, dOd, lse, delta, dQ, B, h, Sq, Sk, H, H, H, H, H, kmd, causal, scale, math_mode)
+    kk.call("kk_attn_bwd_dkv", Qd, Kd, Vd, dOd, lse, delta, dK, dV, B, h, Sq, Sk, H, H, H, H, H, H, kmd, causal, scale,
+            math_mode)
+    atol, rtol = (1e-4, 1e-3) if math_mode == 0 else (8e-2, 5e-2)
+    close(dQ, Qr.grad, atol, rtol, "attn dQ")
+    close(dK, Kr.grad, atol, rtol, "attn dK")
+    close(dV, Vr.grad, atol, rtol, "attn dV")
+
+
+def test_attention_strided_fused_qkv(kk):
+    """Operands living inside a fused [rows, 3H] projection buffer (row stride 3H)."""
+    B, h, S = 2, 2, 96
+    H = h * 64
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.randn(B, S, 3 * H, generator=g)
+    ref = _attn_ref(*(qkv[..., i * H:(i + 1) * H].double().view(B, S, h, 64).transpose(1, 2) for i in range(3)), 1, None,
+                    0.125).transpose(1, 2).reshape(B, S, H)
+    d = dev(qkv)
+    O_ = torch.zeros(B, S, H, device="cuda")
+    lse = torch.zeros(B, h, S, device="cuda")
+    kk.call("kk_attn_fwd", d, d[..., H:], d[..., 2 * H:], O_, lse, B, h, S, S, 3 * H, 3 * H, 3 * H, H, None, 1, 0.125, 0)
+    close(O_, ref, 2e-5, 1e-4, "attn fused-qkv strides")
+
+
+@pytest.mark.parametrize("rows,H", [(37, 64), (1000, 512), (5, 2048), (129, 128)])
+def test_layernorm(kk, rows, H):
+    g = torch.Generator().manual_seed(rows + H)
+    x = torch.randn(rows, H, generator=g) * 2 + 0.5
+    gam, bet = torch.randn(H, generator=g), torch.randn(H, generator=g)
+    dy = torch.randn(rows, H, generator=g)
+    xr, gr, br = (t.clone().requires_grad_(True) for t in (x, gam, bet))
+    y = F.layer_norm(xr, (H,), gr, br, 1e-5)
+    y.backward(dy)
+    yd, mean, rstd = torch.empty(rows, H, device="cuda"), torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    kk.call("kk_layernorm_fwd", dev(x), dev(gam), dev(bet), yd, mean, rstd, rows, H)
+    close(yd, y, 2e-5, 2e-5, "ln fwd")
+    dx0 = torch.randn(rows, H, generator=g)
+    dx, dg, db = dev(dx0), torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")
+    kk.call("kk_layernorm_bwd", dev(dy), dev(x), dev(gam), mean, rstd, dx, 1, dg, db, rows, H)
+    close(dx, xr.grad + dx0, 1e-4, 1e-4, "ln dx (accumulate)")
+    close(dg, gr.grad, 1e-3, 1e-4, "ln dgamma")
+    close(db, br.grad, 1e-3, 1e-4, "ln dbeta")
+
+
+@pytest.mark.parametrize("rows,H", [(33, 64), (700, 512)])
+def test_rmsnorm_residual(kk, rows, H):
+    g = torch.Generator().manual_seed(rows)
+    x, res = torch.randn(rows, H, generator=g), torch.randn(rows, H, generator=g)
+    gain, dy = torch.randn(H, generator=g), torch.randn(rows, H, generator=g)
+    xr, gr = x.clone().requires_grad_(True), gain.clone().requires_grad_(True)
+    y = res + O._rms_norm(xr, gr)
+    y.backward(dy)
+    yd, rstd = torch.empty(rows, H, device="cuda"), torch.empty(rows, device="cuda")
+    kk.call("kk_rmsnorm_fwd", dev(x), dev(gain), dev(res), yd, rstd, rows, H)
+    close(yd, y, 2e-5, 2e-5, "rms fwd")
+    dx, dg = torch.empty(rows, H, device="cuda"), torch.zeros(H, device="cuda")
+    kk.call("kk_rmsnorm_bwd", dev(dy), dev(x), dev(gain), rstd, dx, dg, rows, H)
+    close(dx, xr.grad, 1e-4, 1e-4, "rms dx")
+    close(dg, gr.grad, 1e-3, 1e-4, "rms dgain")
+
+
+@pytest.mark.parametrize("rope", [0, 1])
+def test_headnorm_rope(kk, rope):
+    B, S, h = 2, 50, 3
+    H = h * 64
+    g = torch.Generator().manual_seed(9 + rope)
+    x = torch.randn(B * S, 3 * H, generator=g)                 # operate on the middle third (ld = 3H)
+    gain, dy = torch.rand(64, generator=g) + 0.5, torch.randn(B * S, H, generator=g)
+    cos, sin = O.rope_tables(S, 64)
+    xr, gr = x.clone().requires_grad_(True), gain.clone().requires_grad_(True)
+    n = O._rms_norm(xr[:, H:2 * H].view(B, S, h, 64), gr)
+    if rope:
+        n = n * cos[None, :, None, :] + O._rotate_half(n) * sin[None, :, None, :]
+    n = n.reshape(B * S, H)
+    n.backward(dy)
+    xd = dev(x)
+    y = torch.empty(B * S, H, device="cuda")
+    ct, st_ = (dev(cos), dev(sin)) if rope else (None, None)
+    kk.call("kk_headnorm_rope_fwd", xd[:, H:], 3 * H, dev(gain), y, H, B * S, h, S, ct, st_)
+    close(y, n, 2e-5, 2e-5, "headnorm fwd")
+    dx, dg = torch.zeros(B * S, 3 * H, device="cuda"), torch.zeros(64, device="cuda")
+    kk.call("kk_headnorm_rope_bwd", dev(dy), H, xd[:, H:], 3 * H, dev(gain), dx[:, H:], 3 * H, dg, B * S, h, S, ct, st_)
+    close(dx, xr.grad, 1e-4, 1e-4, "headnorm dx")
+    close(dg, gr.grad, 1e-3, 1e-4, "headnorm dgain")
+
+
+def test_glu(kk):
+    rows, Fd = 123, 96
+    h = torch.randn(rows, 2 * Fd) * 2
+    dg = torch.randn(rows, Fd)
+    hr = h.clone().requires_grad_(True)
+    gate, lin = hr.chunk(2, -1)
+    y = F.gelu(gate) * lin
+    y.backward(dg)
+    out = torch.empty(rows, Fd, device="cuda")
+    kk.call("kk_glu_fwd", dev(h), out, rows, Fd)
+    close(out, y, 1e-5, 1e-5, "glu fwd")
+    dh = torch.empty(rows, 2 * Fd, device="cuda")
+    kk.call("kk_glu_bwd", dev(dg), dev(h), dh, rows, Fd)
+    close(dh, hr.grad, 1e-5, 1e-5, "glu bwd")
+
+
+def test_embed(kk):
+    B, P, H, V = 3, 17, 64, 59
+    g = torch.Generator().manual_seed(2)
+    ids, stress = torch.randint(0, V, (B, P), generator=g), torch.randint(0, 3, (B, P), generator=g)
+    emb, semb, pe = torch.randn(V, H, generator=g), torch.randn(3, H, generator=g), torch.randn(40, H, generator=g)
+    dout = torch.randn(B, P, H, generator=g)
+    er, sr = emb.clone().requires_grad_(True), semb.clone().requires_grad_(True)
+    y = F.embedding(ids, er) * 8.0 + F.embedding(stress, sr, padding_idx=0) + pe[:P]
+    y.backward(dout)
+    out = torch.empty(B, P, H, device="cuda")
+    kk.call("kk_embed_fwd", dev(ids), dev(stress), dev(emb), dev(semb), dev(pe), out, B, P, H, 8.0)
+    close(out, y, 1e-6, 1e-6, "embed fwd")
+    de, ds = torch.zeros(V, H, device="cuda"), torch.zeros(3, H, device="cuda")
+    kk.call("kk_embed_bwd", dev(ids), dev(stress), dev(dout), de, ds, B, P, H, 8.0)
+    close(de, er.grad, 1e-4, 1e-5, "embed demb")
+    close(ds, sr.grad, 1e-4, 1e-5, "embed dstress")
+
+
+def test_length_regulator_golden_bit_exact(kk, golden_dir):
+    fx = np.load(os.path.join(golden_dir, "length_regulator.npz"))
+    for i in range(int(fx["n"])):
+        c = {k: fx[f"{i}/{k}"] for k in ("tokens", "dur", "max_len", "out", "idx", "lens")}
+        dur = c["dur"]
+        dur = np.trunc(dur).astype(np.int64) if dur.dtype.kind == "f" else dur.astype(np.int64)   # lengths.py:31 .long()
+        B, P = dur.shape
+        L = c["idx"].shape[1]
+        idx, lens, tot = (torch.full((B, L), -9, dtype=torch.int64, device="cuda"),
+                          torch.zeros(B, dtype=torch.int64, device="cuda"), torch.zeros(B, dtype=torch.int64, device="cuda"))
+        kk.call("kk_length_regulate_index", dev(torch.from_numpy(dur)), idx, lens, tot, B, P, L)
+        assert np.array_equal(idx.cpu().numpy(), c["idx"]), f"case {i}: idx differs"
+        assert np.array_equal(lens.cpu().numpy(), c["lens"]), f"case {i}: lens differs"
+        tok = torch.from_numpy(c["tokens"]).float()
+        if tok.dim() == 3 and tok.shape[2] % 4 == 0:
+            out = torch.empty(B, L, tok.shape[2], device="cuda")
+            kk.call("kk_length_regulate_gather", dev(tok), idx, out, B, P, L, tok.shape[2])
+            assert np.array_equal(out.cpu().numpy(), c["out"].astype(np.float32)), f"case {i}: payload differs"
+
+
+def test_length_regulator_full_size_properties(kk):
+    """BASELINE sizes (8x1024 frames, P=128, H=512): bit-exact vs the oracle + size-independent properties."""
+    d = O.ModelDims()
+    b = O.synthetic_batch(8, 1024, 128, d, ragged=True)
+    B, P, L, H = 8, 128, 1024, 512
+    dur = b["phoneme_durations"]
+    idx, lens, tot = (torch.empty(B, L, dtype=torch.int64, device="cuda"), torch.empty(B, dtype=torch.int64, device="cuda"),
+                      torch.empty(B, dtype=torch.int64, device="cuda"))
+    kk.call("kk_length_regulate_index", dev(dur), idx, lens, tot, B, P, L)
+    ref_idx, ref_lens, _ = O.length_regulate_index(dur.numpy(), L)
+    assert np.array_equal(idx.cpu().numpy(), ref_idx) and np.array_equal(lens.cpu().numpy(), ref_lens)
+    i = idx.cpu()
+    assert (tot.cpu() == dur.clamp(min=0).sum(1)).all()
+    valid = i >= 0
+    assert (valid.sum(1) == lens.cpu()).all()                                   # exactly len_b expanded frames
+    assert ((i[:, 1:] >= i[:, :-1]) | ~valid[:, 1:]).all()                      # sortedness
+    counts = torch.stack([torch.bincount(i[bb][valid[bb]], minlength=P) for bb in range(B)])
+    assert (counts == dur.clamp(min=0)).all()                                   # each token repeated dur times
+    x = torch.randn(B, P, H)
+    out = torch.empty(B, L, H, device="cuda")
+    kk.call("kk_length_regulate_gather", dev(x), idx, out, B, P, L, H)
+    assert torch.equal(out.cpu(), O.length_regulate(x, dur, L))
+    mx = torch.zeros(1, dtype=torch.int64, device="cuda")
+    kk.call("kk_max_i64", dev(dur), dur.numel(), mx)
+    assert int(mx) == int(dur.max())
+
+
+@pytest.mark.parametrize("L", [40, 600, 513])
+def test_variance_predictor_chain(kk, L):
+    """im2col+GEMM conv, chunked GroupNorm(1,C)+ReLU, Linear(C->1)+mask: forward and backward vs the oracle."""
+    B, H, Fv = 2, 64, 32
+    g = torch.Generator().manual_seed(L)
+    names = O._varpred_names("vp", H, Fv, 3)
+    P = {n: torch.randn(s, generator=g) * (0.2 if len(s) > 1 else 0.5) for n, s in names}
+    x = torch.randn(B, L, H, generator=g)
+    mask = torch.zeros(B, L, dtype=torch.bool)
+    mask[1, L - 7:] = True
+    dout = torch.randn(B, L, generator=g)
+    Pr = {n: p.clone().requires_grad_(True) for n, p in P.items()}
+    xr = x.clone().requires_grad_(True)
+    ref = O.variance_predictor(Pr, "vp", xr, mask)
+    ref.backward(dout)
+    Pd = {n: dev(p) for n, p in P.items()}
+    Gd = {n: torch.zeros_like(p) for n, p in Pd.items()}
+    xd, rows, nch = dev(x), B * L, (L + 511) // 512
+    scratch = torch.zeros(2 * B * nch, dtype=torch.float64, device="cuda")
+    acts, cin, inp = [], H, xd
+    for li in range(2):
+        col = torch.empty(rows, 3 * cin, device="cuda")
+        kk.call("kk_im2col3_fwd", inp, col, B, L, cin, 512)
+        c = torch.empty(rows, Fv, device="cuda")
+        kk.call("kk_gemm", 0, 0, rows, Fv, 3 * cin, 1.0, col, 3 * cin, Pd[f"vp.conv_layers.{li}.weight"], 3 * cin, 0.0, c, Fv,
+                Pd[f"vp.conv_layers.{li}.bias"], None, 0, 0, 1, 0)
+        y, stats = torch.empty(rows, Fv, device="cuda"), torch.empty(B * nch, 2, device="cuda")
+        kk.call("kk_groupnorm_relu_fwd", c, Pd[f"vp.norms.{li}.weight"], Pd[f"vp.norms.{li}.bias"], y, stats, scratch, B, L, Fv, 512)
+        acts.append((col, c, y, stats, cin))
+        inp, cin = y, Fv
+    md = dev(mask.to(torch.uint8))
+    out = torch.empty(rows, device="cuda")
+    kk.call("kk_rowdot_fwd", inp, Pd["vp.linear.weight"], Pd["vp.linear.bias"], md, out, rows, Fv, L, 512)
+    close(out.view(B, L), ref, 2e-4, 2e-4, "varpred fwd")
+    dy = torch.empty(rows, Fv, device="cuda")
+    kk.call("kk_rowdot_bwd", dev(dout), inp, Pd["vp.linear.weight"], md, dy, Gd["vp.linear.weight"], Gd["vp.linear.bias"],
+            rows, Fv, L, 512)
+    for li in (1, 0):
+        col, c, y, stats, cin = acts[li]
+        dc = torch.empty(rows, Fv, device="cuda")
+        kk.call("kk_groupnorm_relu_bwd", dy, c, y, Pd[f"vp.norms.{li}.weight"], stats, dc, Gd[f"vp.norms.{li}.weight"],
+                Gd[f"vp.norms.{li}.bias"], scratch, B, L, Fv, 512)
+        kk.call("kk_gemm", 1, 1, Fv, 3 * cin, rows, 1.0, dc, Fv, col, 3 * cin, 1.0, Gd[f"vp.conv_layers.{li}.weight"], 3 * cin,
+                None, None, 0, 0, 0, 0)
+        kk.call("kk_colsum_acc", dc, Fv, rows, Fv, Gd[f"vp.conv_layers.{li}.bias"])
+        dcol = torch.empty(rows, 3 * cin, device="cuda")
+        kk.call("kk_gemm", 0, 1, rows, 3 * cin, Fv, 1.0, dc, Fv, Pd[f"vp.conv_layers.{li}.weight"], 3 * cin, 0.0, dcol, 3 * cin,
+                None, None, 0, 0, 1, 0)
+        dy = torch.empty(rows, cin, device="cuda")
+        kk.call("kk_im2col3_bwd", dcol, dy, B, L, cin, 512)
+    close(dy.view(B, L, H), xr.grad, 2e-4, 1e-3, "varpred dx")
+    for n in P:
+        close(Gd[n].view(P[n].shape), Pr[n].grad, 5e-4, 2e-3, f"varpred grad {n}")
+
+
+def test_bucket_embed_add(kk):
+    B, T, H, nb = 2, 33, 64, 256
+    g = torch.Generator().manual_seed(4)
+    x, pemb, eemb = torch.randn(B, T, H, generator=g), torch.randn(nb, H, generator=g), torch.randn(nb, H, generator=g)
+    pitch, energy = torch.rand(B, T, generator=g), torch.rand(B, T, generator=g)
+    bins = torch.linspace(0, 1, nb - 1)
+    pitch[0, :5] = torch.tensor([0.0, 1.0, float(bins[7]), float(bins[100]), 0.5])     # boundary values
+    lens = torch.tensor([T, 20])
+    dout = torch.randn(B, T, H, generator=g)
+    pr, er = pemb.clone().requires_grad_(True), eemb.clone().requires_grad_(True)
+    fm = torch.arange(T)[None] >= lens[:, None]
+    ref = (x + F.embedding(torch.bucketize(pitch, bins), pr) + F.embedding(torch.bucketize(energy, bins), er)
+           ).masked_fill(fm[..., None], 0.0)
+    ref.backward(dout)
+    out = torch.empty(B, T, H, device="cuda")
+    pi, ei = torch.empty(B, T, dtype=torch.int32, device="cuda"), torch.empty(B, T, dtype=torch.int32, device="cuda")
+    fmd = torch.empty(B, T, dtype=torch.uint8, device="cuda")
+    kk.call("kk_bucket_embed_add_fwd", dev(x), dev(pitch), dev(energy), dev(bins), dev(bins), dev(pemb), dev(eemb), dev(lens),
+            out, pi, ei, fmd, B, T, H, nb)
+    assert torch.equal(pi.cpu().long(), torch.bucketize(pitch, bins)), "bucketize must be bit-exact"
+    assert torch.equal(fmd.cpu().bool(), fm)
+    close(out, ref, 1e-6, 1e-6, "bucket-embed fwd")
+    dp, de = torch.zeros(nb, H, device="cuda"), torch.zeros(nb, H, device="cuda")
+    kk.call("kk_bucket_embed_add_bwd", dev(dout), pi, ei, fmd, dp, de, B, T, H)
+    close(dp, pr.grad, 1e-4, 1e-5, "bucket-embed dpitch_emb")
+    close(de, er.grad, 1e-4, 1e-5, "bucket-embed denergy_emb")
+
+
+def test_small_helpers(kk):
+    ids = torch.tensor([[0, 3, 0, 5]])
+    m = torch.empty(1, 4, dtype=torch.uint8, device="cuda")
+    kk.call("kk_ids_eq_zero", dev(ids), m, 4)
+    assert m.cpu().tolist() == [[1, 0, 1, 0]]
+    mel = torch.randn(2, 5, 8)
+    out = torch.empty(2, 5, 8, device="cuda")
+    kk.call("kk_shift_right", dev(mel), out, 2, 5, 8)
+    assert torch.equal(out.cpu(), F.pad(mel[:, :-1], (0, 0, 1, 0)))
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_losses_fwd_bwd(kk, ragged):
+    from kokoro_ruslan_amd.lib import KkLossCfg
+    d = O.ModelDims()
+    B, T, Pn = 3, 50, 9
+    b = O.synthetic_batch(B, T, Pn, d, seed=5, ragged=ragged)
+    g = torch.Generator().manual_seed(1)
+    out = {"mel": torch.randn(B, T, 80, generator=g) - 5, "log_dur": torch.randn(B, Pn, generator=g) + 1.5,
+           "stop": torch.randn(B, T, generator=g) * 3, "pitch": torch.rand(B, T, generator=g),
+           "energy": torch.rand(B, T, generator=g)}
+    if ragged:
+        out["mel"][0, 3, 4] = float("nan")            # non-finite element inside a valid frame is filtered
+        out["mel"][1, T - 1, 0] = float("inf")        # padded frame
+    outr = {k: v.clone().requires_grad_(True) for k, v in out.items()}
+    hp = O.StepHyper()
+    ls = O.losses(outr, b, hp)
+    (ls[0] * 0.5).backward()
+    cfg = KkLossCfg(hp.duration_loss_weight, hp.stop_token_loss_weight, hp.pitch_loss_weight, hp.energy_loss_weight,
+                    hp.duration_huber_delta, hp.pitch_huber_delta, hp.energy_huber_delta, hp.stop_token_pos_weight, 0.5, 0)
+    acc = torch.zeros(10, dtype=torch.float64, device="cuda")
+    losses, coef = torch.zeros(6, device="cuda"), torch.zeros(5, device="cuda")
+    dv = {k: dev(v) for k, v in out.items()}
+    bd = {k: dev(v) for k, v in b.items()}
+    args = (dv["mel"], bd["mel_specs"], dv["log_dur"], bd["phoneme_durations"], dv["stop"], bd["stop_token_targets"], dv["pitch"],
+            bd["pitches"], dv["energy"], bd["energies"], bd["mel_lengths"], bd["phoneme_lengths"], B, T, Pn, 80, cfg)
+    kk.call("kk_losses_fwd", *args, None, acc, losses, coef)
+    close(losses, torch.stack([x.detach() for x in ls]), 1e-5, 1e-5, "losses")
+    grads = [torch.empty_like(dv[k]) for k in ("mel", "log_dur", "stop", "pitch", "energy")]
+    kk.call("kk_losses_bwd", *args, coef, *grads)
+    for k, gd in zip(("mel", "log_dur", "stop", "pitch", "energy"), grads):
+        ref = torch.nan_to_num(outr[k].grad, nan=0.0, posinf=0.0, neginf=0.0)
+        close(gd, ref, 1e-7, 1e-4, f"loss grad {k}")
