@@ -1,0 +1,522 @@
+"""MI355X engine for the Kokoro acoustic-model train step.
+
+Host side of the hot path: owns a flat fp32 parameter arena (params, grads, Adam m/v, EMA as contiguous
+HBM slabs with a segment table), per-shape activation workspaces, and the explicit forward / backward /
+optimizer kernel sequences.  Autograd is not used: the model is a fixed DAG, so the backward is a
+hand-written reverse sequence of the same C-ABI kernels (kokoro_ruslan_amd.lib → libkokoro_hip.so).
+Nothing in a step synchronises with the host, so a whole step can be captured in one hipGraph.
+
+What it restates (reference file:line, relative to /root/reference/src/kokoro):
+  forward        model/model.py:565-673 (forward_training) with encode_text :358-388, VarianceAdaptor.forward
+                 model/variance_predictor.py:286-439, decoder model/transformers.py:543-583,622-662
+  losses         training/losses.py:9-216
+  step driver    training/trainer.py:2218-2242,2346-2477 + runtime_policies.py:14-87 (see csrc/kk_optim.hip)
+Quirks kept on purpose: the length-regulated memory is detached (no gradient from the decoder into
+the text encoder, facts 5); key padding = (phoneme id == 0) (fact 6); GroupNorm(1,C) statistics per 512-frame
+chunk including padding (fact 7); stop head sees a detached decoder output (model.py:562).
+Restriction: the expanded length max_b Σdur must equal the batch mel length T (true for the reference's
+datasets, whose durations sum to the mel length); frames beyond T only affect the reference through the
+variance predictors' GroupNorm statistics.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import lib as kk
+from . import spec
+from .spec import VA, ModelDims, StepHyper
+
+CHUNK = 512   # variance_predictor.py:77
+
+
+class Arena:
+    """Flat fp32 slabs p / g / m / v / ema with one 1024-aligned, zero-padded segment per tensor."""
+
+    def __init__(self, dims: ModelDims, hp: StepHyper, device: torch.device):
+        self.dims, self.device = dims, device
+        self.param_names = list(spec.param_shapes(dims).keys())
+        segs = list(spec.param_shapes(dims).items()) + list(spec.buffer_shapes(dims).items())
+        self.names = [n for n, _ in segs]
+        self.shapes = dict(segs)
+        self.offset: Dict[str, int] = {}
+        off = 0
+        for n, s in segs:
+            self.offset[n] = off
+            off += -(-math.prod(s) // kk.KK_SEG_ALIGN) * kk.KK_SEG_ALIGN
+        self.total = off
+        self.nblocks = off // kk.KK_SEG_ALIGN
+        self.nseg = len(segs)
+        z = lambda: torch.zeros(off, dtype=torch.float32, device=device)
+        self.p, self.g, self.m, self.v = z(), z(), z(), z()
+        self.ema = z() if hp.use_ema else None
+        block_seg = torch.empty(self.nblocks, dtype=torch.int32)
+        preclip, lr_mult, wd, flags = [], [], [], []
+        table = spec.group_lr_mult_wd(hp)
+        for i, (n, s) in enumerate(segs):
+            b0 = self.offset[n] // kk.KK_SEG_ALIGN
+            block_seg[b0:b0 + -(-math.prod(s) // kk.KK_SEG_ALIGN)] = i
+            if n in spec.param_shapes(dims):
+                mx = spec.preclip_max_norm(n, hp)
+                preclip.append(mx if mx is not None else 0.0)
+                mult, w = table[spec.param_group_of(n)]
+                lr_mult.append(mult), wd.append(w)
+                flags.append(1 | 2 | (4 if spec.is_weight_norm_target(n) else 0))
+            else:                                   # persistent buffer: EMA-tracked only (trainer.py:1504-1517)
+                preclip.append(0.0), lr_mult.append(0.0), wd.append(0.0), flags.append(2)
+        self.block_seg = block_seg.to(device)
+        self.seg_preclip = torch.tensor(preclip, dtype=torch.float32, device=device)
+        self.seg_lr_mult = torch.tensor(lr_mult, dtype=torch.float32, device=device)
+        self.seg_wd = torch.tensor(wd, dtype=torch.float32, device=device)
+        self.seg_flags = torch.tensor(flags, dtype=torch.int32, device=device)
+        self.P = {n: self.view(self.p, n) for n in self.names}
+        self.G = {n: self.view(self.g, n) for n in self.names}
+        self.E = {n: self.view(self.ema, n) for n in self.names} if hp.use_ema else {}
+
+    def view(self, slab: torch.Tensor, name: str) -> torch.Tensor:
+        o, s = self.offset[name], self.shapes[name]
+        return slab[o:o + math.prod(s)].view(s)
+
+    def fused(self, slab: torch.Tensor, first: str, count: int) -> torch.Tensor:
+        """[count*H, H] view over `count` consecutive square projection weights (w_q|w_k|w_v are adjacent)."""
+        H = self.dims.hidden
+        assert (H * H) % kk.KK_SEG_ALIGN == 0
+        o = self.offset[first]
+        return slab[o:o + count * H * H].view(count * H, H)
+
+
+class KokoroEngine:
+    def __init__(self, dims: Optional[ModelDims] = None, hyper: Optional[StepHyper] = None, device="cuda",
+                 math_mode: str = "f32", total_steps: int = 20000, seed: int = 0, init: bool = True):
+        kk.load()                                   # fails loudly when libkokoro_hip.so is missing
+        if not torch.cuda.is_available():
+            raise RuntimeError("KokoroEngine needs an MI355X (no CPU fallback in the product path)")
+        self.dims = dims or ModelDims()
+        self.dims.validate()
+        self.hp = hyper or StepHyper()
+        self.device = torch.device(device)
+        self.math = {"f32": kk.KK_MATH_F32, "bf16": kk.KK_MATH_BF16}[math_mode]
+        self.math_mode = math_mode
+        self.arena = Arena(self.dims, self.hp, self.device)
+        self.total_steps = total_steps
+        self._ws: Dict[Tuple, torch.Tensor] = {}
+        self._rope: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self.opt_state = torch.zeros(kk.OS["SIZE"], dtype=torch.float64, device=self.device)
+        ns = self.arena.nseg
+        f32 = lambda n: torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.seg_gscale, self.seg_decay, self.seg_stepsize = f32(ns), f32(ns), f32(ns)
+        self.step_consts = f32(4)
+        self.grad_sumsq = torch.zeros(ns, dtype=torch.float64, device=self.device)
+        self.p_sumsq = torch.zeros(ns, dtype=torch.float64, device=self.device)
+        self.max_dur = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.loss_acc = torch.zeros(10, dtype=torch.float64, device=self.device)
+        self.losses = f32(6)
+        self.loss_coef = f32(5)
+        self.micro_in_cycle = 0
+        for n, b in spec.make_buffers(self.dims).items():
+            self.arena.P[n].copy_(b)
+        if init:
+            self.load_params(spec.init_params(self.dims, seed))
+        elif self.arena.ema is not None:
+            self.arena.ema.copy_(self.arena.p)
+
+    # ------------------------------------------------------------------ state
+    def load_params(self, params: Dict[str, torch.Tensor], reset_ema: bool = True) -> None:
+        for n in self.arena.param_names:
+            self.arena.P[n].copy_(params[n].to(self.device, torch.float32).view(self.arena.shapes[n]))
+        if reset_ema and self.arena.ema is not None:
+            self.arena.ema.copy_(self.arena.p)      # EMA starts as a deep copy of the model (trainer.py:835)
+
+    def state_dict(self, ema: bool = False) -> "OrderedDict[str, torch.Tensor]":
+        """311 reference-named tensors (views of the arena; clone before mutating)."""
+        src = self.arena.E if ema else self.arena.P
+        return OrderedDict((n, src[n]) for n in spec.state_dict_order(self.dims))
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> None:
+        want = set(spec.state_dict_order(self.dims))
+        missing, unexpected = want - set(sd), set(sd) - want
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing={sorted(missing)} unexpected={sorted(unexpected)}")
+        for n in want & set(sd):
+            if tuple(sd[n].shape) != tuple(self.arena.shapes[n]):
+                raise RuntimeError(f"size mismatch for {n}: {tuple(sd[n].shape)} vs {self.arena.shapes[n]}")
+            self.arena.P[n].copy_(sd[n].to(self.device, torch.float32))
+
+    def grads(self) -> "OrderedDict[str, torch.Tensor]":
+        return OrderedDict((n, self.arena.G[n]) for n in self.arena.param_names)
+
+    # ------------------------------------------------------------------ helpers
+    def _buf(self, key, *shape, dtype=torch.float32) -> torch.Tensor:
+        k = (key, tuple(shape), dtype)
+        t = self._ws.get(k)
+        if t is None:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._ws[k] = t
+        return t
+
+    def _rope_tables(self, S: int):
+        if S not in self._rope:
+            c, s = spec.rope_tables(S, 64)
+            self._rope[S] = (c.to(self.device), s.to(self.device))
+        return self._rope[S]
+
+    def _linear(self, x, W, b, out, res=None, res_mod=0):
+        N, K = x.shape
+        M = W.shape[0]
+        kk.call("kk_gemm", 0, 0, N, M, K, 1.0, x, x.stride(0), W, K, 0.0, out, out.stride(0), b, res,
+                res.stride(0) if res is not None else 0, res_mod, 1, self.math)
+
+    def _dgrad(self, dy, W, dx, beta=0.0):
+        N, M = dy.shape
+        K = W.shape[1]
+        kk.call("kk_gemm", 0, 1, N, K, M, 1.0, dy, dy.stride(0), W, K, beta, dx, dx.stride(0), None, None, 0, 0, 1, self.math)
+
+    def _wgrad(self, dy, x, dW, db=None):
+        N, M = dy.shape
+        K = x.shape[1]
+        kk.call("kk_gemm", 1, 1, M, K, N, 1.0, dy, dy.stride(0), x, x.stride(0), 1.0, dW, K, None, None, 0, 0, 0, self.math)
+        if db is not None:
+            kk.call("kk_colsum_acc", dy, dy.stride(0), N, M, db)
+
+    def _ln_fwd(self, key, x, prefix):
+        P = self.arena.P
+        rows, H = x.shape
+        y, mean, rstd = self._buf(key + ".y", rows, H), self._buf(key + ".mean", rows), self._buf(key + ".rstd", rows)
+        kk.call("kk_layernorm_fwd", x, P[prefix + ".weight"], P[prefix + ".bias"], y, mean, rstd, rows, H)
+        return y
+
+    def _ln_bwd(self, key, dy, x, prefix, dx, accumulate):
+        P, G = self.arena.P, self.arena.G
+        rows, H = x.shape
+        kk.call("kk_layernorm_bwd", dy, x, P[prefix + ".weight"], self._buf(key + ".mean", rows), self._buf(key + ".rstd", rows),
+                dx, 1 if accumulate else 0, G[prefix + ".weight"], G[prefix + ".bias"], rows, H)
+
+    # ------------------------------------------------------------------ attention sub-layer
+    def _attn_fwd(self, key, prefix, xq, xkv, B, Sq, Sk, rope, causal, key_mask, x_res, x_out):
+        """x_out = x_res + w_o(attention(...)) + b_o.  xq [B*Sq,H] (post-LN), xkv [B*Sk,H] (None = self-attention)."""
+        a, P, H, h = self.arena, self.arena.P, self.dims.hidden, self.dims.heads
+        Nq, Nk = B * Sq, B * Sk
+        cos, sin = self._rope_tables(max(Sq, Sk)) if rope else (None, None)
+        if xkv is None:
+            raw, nrm = self._buf(key + ".qkv_raw", Nq, 3 * H), self._buf(key + ".qkv_n", Nq, 3 * H)
+            self._linear(xq, a.fused(a.p, prefix + ".w_q.weight", 3), None, raw)
+            q_raw, k_raw, v_raw, q_n, k_n, v_n = raw, raw[:, H:], raw[:, 2 * H:], nrm, nrm[:, H:], nrm[:, 2 * H:]
+        else:
+            q_raw, q_n = self._buf(key + ".q_raw", Nq, H), self._buf(key + ".q_n", Nq, H)
+            kv_raw, kv_n = self._buf(key + ".kv_raw", Nk, 2 * H), self._buf(key + ".kv_n", Nk, 2 * H)
+            self._linear(xq, P[prefix + ".w_q.weight"], None, q_raw)
+            self._linear(xkv, a.fused(a.p, prefix + ".w_k.weight", 2), None, kv_raw)
+            k_raw, v_raw, k_n, v_n = kv_raw, kv_raw[:, H:], kv_n, kv_n[:, H:]
+        kk.call("kk_headnorm_rope_fwd", q_raw, q_raw.stride(0), P[prefix + ".q_norm.weight"], q_n, q_n.stride(0), Nq, h, Sq, cos, sin)
+        kk.call("kk_headnorm_rope_fwd", k_raw, k_raw.stride(0), P[prefix + ".k_norm.weight"], k_n, k_n.stride(0), Nk, h, Sk, cos, sin)
+        kk.call("kk_headnorm_rope_fwd", v_raw, v_raw.stride(0), P[prefix + ".v_norm.weight"], v_n, v_n.stride(0), Nk, h, Sk, None, None)
+        ctx, lse = self._buf(key + ".ctx", Nq, H), self._buf(key + ".lse", B, h, Sq)
+        kk.call("kk_attn_fwd", q_n, k_n, v_n, ctx, lse, B, h, Sq, Sk, q_n.stride(0), k_n.stride(0), v_n.stride(0), H, key_mask,
+                1 if causal else 0, 0.125, self.math)
+        self._linear(ctx, P[prefix + ".w_o.weight"], P[prefix + ".w_o.bias"], x_out, res=x_res)
+
+    def _attn_bwd(self, key, prefix, d_out, xq, xkv, B, Sq, Sk, rope, causal, key_mask, d_xq, d_xkv, d_xkv_beta):
+        """Given d_out = dL/d(sub-layer output, pre-residual), accumulate parameter grads, write d_xq (dL/d xq) and,
+        for cross-attention, d_xkv (+= when d_xkv_beta == 1)."""
+        a, P, G, H, h = self.arena, self.arena.P, self.arena.G, self.dims.hidden, self.dims.heads
+        Nq, Nk = B * Sq, B * Sk
+        cos, sin = self._rope_tables(max(Sq, Sk)) if rope else (None, None)
+        ctx, lse = self._buf(key + ".ctx", Nq, H), self._buf(key + ".lse", B, h, Sq)
+        dctx, delta = self._buf("tmp.dctx", Nq, H), self._buf("tmp.delta", B, h, Sq)
+        self._wgrad(d_out, ctx, G[prefix + ".w_o.weight"], G[prefix + ".w_o.bias"])
+        self._dgrad(d_out, P[prefix + ".w_o.weight"], dctx)
+        kk.call("kk_attn_delta", ctx, dctx, delta, B, h, Sq, H, H)
+        if xkv is None:
+            raw, nrm = self._buf(key + ".qkv_raw", Nq, 3 * H), self._buf(key + ".qkv_n", Nq, 3 * H)
+            dn, draw = self._buf("tmp.dqkv_n", Nq, 3 * H), self._buf("tmp.dqkv_raw", Nq, 3 * H)
+            q_raw, k_raw, v_raw, q_n, k_n, v_n = raw, raw[:, H:], raw[:, 2 * H:], nrm, nrm[:, H:], nrm[:, 2 * H:]
+            dq_n, dk_n, dv_n, dq_raw, dk_raw, dv_raw = dn, dn[:, H:], dn[:, 2 * H:], draw, draw[:, H:], draw[:, 2 * H:]
+        else:
+            q_raw, q_n = self._buf(key + ".q_raw", Nq, H), self._buf(key + ".q_n", Nq, H)
+            kv_raw, kv_n = self._buf(key + ".kv_raw", Nk, 2 * H), self._buf(key + ".kv_n", Nk, 2 * H)
+            dq_n, dq_raw = self._buf("tmp.dq_n", Nq, H), self._buf("tmp.dq_raw", Nq, H)
+            dkv_n, dkv_raw = self._buf("tmp.dkv_n", Nk, 2 * H), self._buf("tmp.dkv_raw", Nk, 2 * H)
+            k_raw, v_raw, k_n, v_n = kv_raw, kv_raw[:, H:], kv_n, kv_n[:, H:]
+            dk_n, dv_n, dk_raw, dv_raw = dkv_n, dkv_n[:, H:], dkv_raw, dkv_raw[:, H:]
+        ld = lambda t: t.stride(0)
+        kk.call("kk_attn_bwd_dq", q_n, k_n, v_n, dctx, lse, delta, dq_n, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H, ld(dq_n),
+                key_mask, 1 if causal else 0, 0.125, self.math)
+        kk.call("kk_attn_bwd_dkv", q_n, k_n, v_n, dctx, lse, delta, dk_n, dv_n, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H,
+                ld(dk_n), ld(dv_n), key_mask, 1 if causal else 0, 0.125, self.math)
+        kk.call("kk_headnorm_rope_bwd", dq_n, ld(dq_n), q_raw, ld(q_raw), P[prefix + ".q_norm.weight"], dq_raw, ld(dq_raw),
+                G[prefix + ".q_norm.weight"], Nq, h, Sq, cos, sin)
+        kk.call("kk_headnorm_rope_bwd", dk_n, ld(dk_n), k_raw, ld(k_raw), P[prefix + ".k_norm.weight"], dk_raw, ld(dk_raw),
+                G[prefix + ".k_norm.weight"], Nk, h, Sk, cos, sin)
+        kk.call("kk_headnorm_rope_bwd", dv_n, ld(dv_n), v_raw, ld(v_raw), P[prefix + ".v_norm.weight"], dv_raw, ld(dv_raw),
+                G[prefix + ".v_norm.weight"], Nk, h, Sk, None, None)
+        if xkv is None:
+            self._wgrad(draw, xq, a.fused(a.g, prefix + ".w_q.weight", 3))
+            self._dgrad(draw, a.fused(a.p, prefix + ".w_q.weight", 3), d_xq)
+        else:
+            self._wgrad(dq_raw, xq, G[prefix + ".w_q.weight"])
+            self._dgrad(dq_raw, P[prefix + ".w_q.weight"], d_xq)
+            if d_xkv is not None:
+                self._wgrad(dkv_raw, xkv, a.fused(a.g, prefix + ".w_k.weight", 2))
+                self._dgrad(dkv_raw, a.fused(a.p, prefix + ".w_k.weight", 2), d_xkv, beta=d_xkv_beta)
+
+    # ------------------------------------------------------------------ GLU feed-forward sub-layer
+    def _ffn_fwd(self, key, prefix, y, x_res, x_out, Fd):
+        P = self.arena.P
+        N, H = y.shape
+        h1, g, f2 = self._buf(key + ".h1", N, 2 * Fd), self._buf(key + ".g", N, Fd), self._buf(key + ".f2", N, H)
+        self._linear(y, P[prefix + ".linear1.weight"], P[prefix + ".linear1.bias"], h1)
+        kk.call("kk_glu_fwd", h1, g, N, Fd)
+        self._linear(g, P[prefix + ".linear2.weight"], P[prefix + ".linear2.bias"], f2)
+        kk.call("kk_rmsnorm_fwd", f2, P[prefix + ".output_norm.weight"], x_res, x_out, self._buf(key + ".rstd_f", N), N, H)
+
+    def _ffn_bwd(self, key, prefix, d_out, y, d_y, Fd):
+        P, G = self.arena.P, self.arena.G
+        N, H = y.shape
+        h1, g, f2 = self._buf(key + ".h1", N, 2 * Fd), self._buf(key + ".g", N, Fd), self._buf(key + ".f2", N, H)
+        df2, dg, dh1 = self._buf("tmp.df2", N, H), self._buf("tmp.dg", N, Fd), self._buf("tmp.dh1", N, 2 * Fd)
+        kk.call("kk_rmsnorm_bwd", d_out, f2, P[prefix + ".output_norm.weight"], self._buf(key + ".rstd_f", N), df2,
+                G[prefix + ".output_norm.weight"], N, H)
+        self._wgrad(df2, g, G[prefix + ".linear2.weight"], G[prefix + ".linear2.bias"])
+        self._dgrad(df2, P[prefix + ".linear2.weight"], dg)
+        kk.call("kk_glu_bwd", dg, h1, dh1, N, Fd)
+        self._wgrad(dh1, y, G[prefix + ".linear1.weight"], G[prefix + ".linear1.bias"])
+        self._dgrad(dh1, P[prefix + ".linear1.weight"], d_y)
+
+    # ------------------------------------------------------------------ variance predictor
+    def _varpred_fwd(self, key, prefix, x, col1, B, L, mask, out):
+        """x [B*L, H]; col1 = im2col3(x) (shared by pitch & energy predictors); out [B*L]."""
+        P, Fv = self.arena.P, self.dims.var_filter
+        rows, nch = B * L, -(-L // CHUNK)
+        scratch = self._buf("tmp.gn_scratch", 2 * B * nch, dtype=torch.float64)
+        inp_col, cin = col1, x.shape[1]
+        for li in range(2):
+            c, y = self._buf(f"{key}.c{li}", rows, Fv), self._buf(f"{key}.y{li}", rows, Fv)
+            stats = self._buf(f"{key}.st{li}", B * nch, 2)
+            self._linear(inp_col, P[f"{prefix}.conv_layers.{li}.weight"].view(Fv, 3 * cin), P[f"{prefix}.conv_layers.{li}.bias"], c)
+            kk.call("kk_groupnorm_relu_fwd", c, P[f"{prefix}.norms.{li}.weight"], P[f"{prefix}.norms.{li}.bias"], y, stats,
+                    scratch, B, L, Fv, CHUNK)
+            if li == 0:
+                inp_col, cin = self._buf(f"{key}.col2", rows, 3 * Fv), Fv
+                kk.call("kk_im2col3_fwd", y, inp_col, B, L, Fv, CHUNK)
+        kk.call("kk_rowdot_fwd", y, P[f"{prefix}.linear.weight"], P[f"{prefix}.linear.bias"], mask, out, rows, Fv, L, CHUNK)
+
+    def _varpred_bwd(self, key, prefix, dout, x, col1, B, L, mask, dx):
+        """Accumulate the predictor's parameter grads; write dx (dL/dx) when dx is not None."""
+        P, G, Fv = self.arena.P, self.arena.G, self.dims.var_filter
+        rows, nch, H = B * L, -(-L // CHUNK), x.shape[1]
+        scratch = self._buf("tmp.gn_scratch", 2 * B * nch, dtype=torch.float64)
+        dy, dc = self._buf("tmp.vp_dy", rows, Fv), self._buf("tmp.vp_dc", rows, Fv)
+        y1 = self._buf(f"{key}.y1", rows, Fv)
+        kk.call("kk_rowdot_bwd", dout, y1, P[f"{prefix}.linear.weight"], mask, dy, G[f"{prefix}.linear.weight"],
+                G[f"{prefix}.linear.bias"], rows, Fv, L, CHUNK)
+        for li in (1, 0):
+            c, y, stats = self._buf(f"{key}.c{li}", rows, Fv), self._buf(f"{key}.y{li}", rows, Fv), self._buf(f"{key}.st{li}", B * nch, 2)
+            cin = Fv if li == 1 else H
+            col = self._buf(f"{key}.col2", rows, 3 * Fv) if li == 1 else col1
+            kk.call("kk_groupnorm_relu_bwd", dy, c, y, P[f"{prefix}.norms.{li}.weight"], stats, dc, G[f"{prefix}.norms.{li}.weight"],
+                    G[f"{prefix}.norms.{li}.bias"], scratch, B, L, Fv, CHUNK)
+            W, dW = P[f"{prefix}.conv_layers.{li}.weight"].view(Fv, 3 * cin), G[f"{prefix}.conv_layers.{li}.weight"].view(Fv, 3 * cin)
+            self._wgrad(dc, col, dW, G[f"{prefix}.conv_layers.{li}.bias"])
+            if li == 1 or dx is not None:
+                dcol = self._buf(f"tmp.vp_dcol{li}", rows, 3 * cin)
+                self._dgrad(dc, W, dcol)
+                kk.call("kk_im2col3_bwd", dcol, dy if li == 1 else dx, B, L, cin, CHUNK)
+
+    # ------------------------------------------------------------------ forward + losses + backward
+    def forward_backward(self, batch: Dict[str, torch.Tensor], loss_scale: float = 1.0, adaptive: bool = False,
+                         backward: bool = True) -> Dict[str, torch.Tensor]:
+        """One micro-batch: forward, the 6 losses, and (optionally) the full backward into the gradient arena
+        (which accumulates).  `batch` follows the reference collate contract (data/dataset.py:871-921), tensors on
+        the device.  Returns device tensors (no sync): losses[6] = (total, mel, dur, stop, pitch, energy) and outputs."""
+        d, a, P, G = self.dims, self.arena, self.arena.P, self.arena.G
+        H, M, Fv = d.hidden, d.mel, d.var_filter
+        ids, mel, dur = batch["phoneme_indices"], batch["mel_specs"], batch["phoneme_durations"]
+        stress = batch.get("stress_indices")
+        B, Pn = ids.shape
+        T = mel.shape[1]
+        Ne, Nd = B * Pn, B * T
+        pe = P["positional_encoding.pe"].view(d.max_len, H)
+        if T > d.max_len or Pn > d.max_len:
+            raise ValueError(f"sequence longer than the positional table ({d.max_len})")
+
+        # ---- encoder (model.py:375-388) ----
+        text_mask = self._buf("text_mask", B, Pn, dtype=torch.uint8)
+        kk.call("kk_ids_eq_zero", ids, text_mask, Ne)
+        kk.call("kk_max_i64", dur, Ne, self.max_dur)
+        x = self._buf("enc.x0", Ne, H)
+        kk.call("kk_embed_fwd", ids, stress, P["text_embedding.weight"], P["stress_embedding.weight"] if stress is not None else None,
+                pe, x, B, Pn, H, float(H ** 0.5))
+        for i in range(d.enc_layers):
+            pf, key = f"transformer_encoder_layers.{i}", f"enc{i}"
+            y1 = self._ln_fwd(key + ".ln1", x, pf + ".norm1")
+            xm = self._buf(key + ".xm", Ne, H)
+            self._attn_fwd(key + ".sa", pf + ".self_attn", y1, None, B, Pn, Pn, True, False, text_mask, x, xm)
+            y2 = self._ln_fwd(key + ".ln2", xm, pf + ".norm2")
+            xo = self._buf(key + ".xo", Ne, H)
+            self._ffn_fwd(key + ".ff", pf + ".ff", y2, xm, xo, d.enc_ff)
+            x = xo
+        enc_last = x
+        enc = self._ln_fwd("enc.norm", enc_last, "encoder_norm")
+
+        # ---- variance adaptor (variance_predictor.py:338-439) ----
+        dur_pred = self._buf("out.log_dur", B, Pn)
+        col_e = self._buf("vp.col_enc", Ne, 3 * H)
+        kk.call("kk_im2col3_fwd", enc, col_e, B, Pn, H, CHUNK)
+        self._varpred_fwd("vp.dur", f"{VA}.duration_predictor", enc, col_e, B, Pn, text_mask, dur_pred)
+        idx, lens, tot = (self._buf("lr.idx", B, T, dtype=torch.int64), self._buf("lr.lens", B, dtype=torch.int64),
+                          self._buf("lr.total", B, dtype=torch.int64))
+        kk.call("kk_length_regulate_index", dur, idx, lens, tot, B, Pn, T)
+        xf = self._buf("va.xf", Nd, H)
+        kk.call("kk_length_regulate_gather", enc, idx, xf, B, Pn, T, H)       # detached by construction
+        memory, fmask = self._buf("va.memory", Nd, H), self._buf("va.fmask", B, T, dtype=torch.uint8)
+        pidx, eidx = self._buf("va.pidx", B, T, dtype=torch.int32), self._buf("va.eidx", B, T, dtype=torch.int32)
+        kk.call("kk_bucket_embed_add_fwd", xf, batch["pitches"], batch["energies"], P[f"{VA}.pitch_bins"], P[f"{VA}.energy_bins"],
+                P[f"{VA}.pitch_embedding.weight"], P[f"{VA}.energy_embedding.weight"], lens, memory, pidx, eidx, fmask, B, T, H,
+                d.var_bins)
+        pitch_pred, energy_pred = self._buf("out.pitch", B, T), self._buf("out.energy", B, T)
+        col_f = self._buf("vp.col_frames", Nd, 3 * H)
+        kk.call("kk_im2col3_fwd", xf, col_f, B, T, H, CHUNK)
+        self._varpred_fwd("vp.pitch", f"{VA}.pitch_predictor", xf, col_f, B, T, fmask, pitch_pred)
+        self._varpred_fwd("vp.energy", f"{VA}.energy_predictor", xf, col_f, B, T, fmask, energy_pred)
+
+        # ---- decoder (model.py:519-531; transformers.py:543-583,660) ----
+        shifted = self._buf("dec.shifted", Nd, M)
+        kk.call("kk_shift_right", mel, shifted, B, T, M)
+        y = self._buf("dec.x0", Nd, H)
+        self._linear(shifted, P["mel_projection_in.weight"], P["mel_projection_in.bias"], y, res=pe, res_mod=T)
+        for i in range(d.dec_layers):
+            pf, key = f"decoder.layers.{i}", f"dec{i}"
+            n1 = self._ln_fwd(key + ".ln1", y, pf + ".norm1")
+            ya = self._buf(key + ".xa", Nd, H)
+            self._attn_fwd(key + ".sa", pf + ".self_attn", n1, None, B, T, T, True, True, None, y, ya)
+            n2 = self._ln_fwd(key + ".ln2", ya, pf + ".norm2")
+            yc = self._buf(key + ".xc", Nd, H)
+            self._attn_fwd(key + ".ca", pf + ".cross_attn", n2, memory, B, T, T, False, False, fmask, ya, yc)
+            n3 = self._ln_fwd(key + ".ln3", yc, pf + ".norm3")
+            yo = self._buf(key + ".xo", Nd, H)
+            self._ffn_fwd(key + ".ff", pf + ".ff", n3, yc, yo, d.dec_ff)
+            y = yo
+        dec_last = y
+        dec_out = self._ln_fwd("dec.norm", dec_last, "decoder.norm")
+        mel_pred, stop = self._buf("out.mel", B, T, M), self._buf("out.stop", B, T)
+        self._linear(dec_out, P["mel_projection_out.weight"], P["mel_projection_out.bias"], mel_pred.view(Nd, M))
+        kk.call("kk_rowdot_fwd", dec_out, P["stop_token_predictor.weight"], P["stop_token_predictor.bias"], None, stop, Nd, H, T, 0)
+
+        # ---- losses (losses.py) ----
+        hp = self.hp
+        lcfg = kk.KkLossCfg(hp.duration_loss_weight, hp.stop_token_loss_weight, hp.pitch_loss_weight, hp.energy_loss_weight,
+                            hp.duration_huber_delta, hp.pitch_huber_delta, hp.energy_huber_delta, hp.stop_token_pos_weight,
+                            float(loss_scale), 1 if adaptive else 0)
+        largs = (mel_pred, mel, dur_pred, dur, stop, batch["stop_token_targets"], pitch_pred, batch["pitches"], energy_pred,
+                 batch["energies"], batch["mel_lengths"], batch["phoneme_lengths"], B, T, Pn, M, lcfg)
+        kk.call("kk_losses_fwd", *largs, self.max_dur, self.loss_acc, self.losses, self.loss_coef)
+        out = {"losses": self.losses, "mel": mel_pred, "log_dur": dur_pred, "stop": stop, "pitch": pitch_pred,
+               "energy": energy_pred, "lr_idx": idx, "lr_lens": lens, "memory": memory.view(B, T, H)}
+        if not backward:
+            return out
+
+        # =========================== backward ===========================
+        dmel, ddur = self._buf("g.mel", B, T, M), self._buf("g.dur", B, Pn)
+        dstop, dpitch, denergy = self._buf("g.stop", B, T), self._buf("g.pitch", B, T), self._buf("g.energy", B, T)
+        kk.call("kk_losses_bwd", *largs, self.loss_coef, dmel, ddur, dstop, dpitch, denergy)
+        # heads (model.py:561-562): the stop head's input is detached
+        kk.call("kk_rowdot_bwd", dstop, dec_out, P["stop_token_predictor.weight"], None, None, G["stop_token_predictor.weight"],
+                G["stop_token_predictor.bias"], Nd, H, T, 0)
+        d_dec_out = self._buf("tmp.d_dec_out", Nd, H)
+        self._wgrad(dmel.view(Nd, M), dec_out, G["mel_projection_out.weight"], G["mel_projection_out.bias"])
+        self._dgrad(dmel.view(Nd, M), P["mel_projection_out.weight"], d_dec_out)
+        dy = self._buf("g.dec_stream", Nd, H)          # gradient of the decoder residual stream, updated in place
+        self._ln_bwd("dec.norm", d_dec_out, dec_last, "decoder.norm", dy, accumulate=False)
+        dmem = self._buf("g.memory", Nd, H)
+        dn = self._buf("tmp.dn", Nd, H)
+        first_mem = True
+        for i in reversed(range(d.dec_layers)):
+            pf, key = f"decoder.layers.{i}", f"dec{i}"
+            x_in = self._buf(f"dec{i - 1}.xo", Nd, H) if i > 0 else self._buf("dec.x0", Nd, H)
+            ya, yc = self._buf(key + ".xa", Nd, H), self._buf(key + ".xc", Nd, H)
+            n1, n2, n3 = (self._buf(f"{key}.ln{j}.y", Nd, H) for j in (1, 2, 3))
+            self._ffn_bwd(key + ".ff", pf + ".ff", dy, n3, dn, d.dec_ff)
+            self._ln_bwd(key + ".ln3", dn, yc, pf + ".norm3", dy, accumulate=True)
+            self._attn_bwd(key + ".ca", pf + ".cross_attn", dy, n2, memory, B, T, T, False, False, fmask, dn, dmem,
+                           0.0 if first_mem else 1.0)
+            first_mem = False
+            self._ln_bwd(key + ".ln2", dn, ya, pf + ".norm2", dy, accumulate=True)
+            self._attn_bwd(key + ".sa", pf + ".self_attn", dy, n1, None, B, T, T, True, True, None, dn, None, 0.0)
+            self._ln_bwd(key + ".ln1", dn, x_in, pf + ".norm1", dy, accumulate=True)
+        # decoder input projection (the PE add and the shift are parameter-free; mel is data)
+        self._wgrad(dy, shifted, G["mel_projection_in.weight"], G["mel_projection_in.bias"])
+        # variance adaptor: memory gradient feeds only the two embedding tables (xf is detached, lengths.py:30)
+        kk.call("kk_bucket_embed_add_bwd", dmem, pidx, eidx, fmask, G[f"{VA}.pitch_embedding.weight"],
+                G[f"{VA}.energy_embedding.weight"], B, T, H)
+        self._varpred_bwd("vp.pitch", f"{VA}.pitch_predictor", dpitch, xf, col_f, B, T, fmask, None)
+        self._varpred_bwd("vp.energy", f"{VA}.energy_predictor", denergy, xf, col_f, B, T, fmask, None)
+        d_enc = self._buf("g.enc_out", Ne, H)
+        self._varpred_bwd("vp.dur", f"{VA}.duration_predictor", ddur, enc, col_e, B, Pn, text_mask, d_enc)
+        # encoder
+        dx = self._buf("g.enc_stream", Ne, H)
+        self._ln_bwd("enc.norm", d_enc, enc_last, "encoder_norm", dx, accumulate=False)
+        dne = self._buf("tmp.dne", Ne, H)
+        for i in reversed(range(d.enc_layers)):
+            pf, key = f"transformer_encoder_layers.{i}", f"enc{i}"
+            x_in = self._buf(f"enc{i - 1}.xo", Ne, H) if i > 0 else self._buf("enc.x0", Ne, H)
+            xm = self._buf(key + ".xm", Ne, H)
+            y1, y2 = self._buf(key + ".ln1.y", Ne, H), self._buf(key + ".ln2.y", Ne, H)
+            self._ffn_bwd(key + ".ff", pf + ".ff", dx, y2, dne, d.enc_ff)
+            self._ln_bwd(key + ".ln2", dne, xm, pf + ".norm2", dx, accumulate=True)
+            self._attn_bwd(key + ".sa", pf + ".self_attn", dx, y1, None, B, Pn, Pn, True, False, text_mask, dne, None, 0.0)
+            self._ln_bwd(key + ".ln1", dne, x_in, pf + ".norm1", dx, accumulate=True)
+        kk.call("kk_embed_bwd", ids, stress, dx, G["text_embedding.weight"], G["stress_embedding.weight"] if stress is not None else None,
+                B, Pn, H, float(H ** 0.5))
+        return out
+
+    # ------------------------------------------------------------------ optimizer boundary
+    def _opt_cfg(self, mel_length: int) -> kk.KkOptCfg:
+        hp = self.hp
+        c = spec.lr_schedule_consts(hp, self.total_steps)
+        return kk.KkOptCfg(c["learning_rate"], c["max_lr"], c["warmup_start_lr"], c["warmup_target_lr"], c["pct_start"],
+                           c["div_factor"], c["final_div_factor"], c["warmup_steps"], c["onecycle_steps"], c["use_warmup"],
+                           hp.adam_betas[0], hp.adam_betas[1], hp.adam_eps, hp.max_grad_norm, mel_length,
+                           hp.grad_explosion_ema_alpha, hp.grad_explosion_abs_floor, hp.grad_explosion_multiplier,
+                           hp.grad_explosion_warmup_floor, hp.grad_explosion_warmup_steps, hp.grad_explosion_min_ema_steps,
+                           hp.ema_decay, hp.dec_ffn_max_weight_norm)
+
+    def zero_grad(self) -> None:
+        self.arena.g.zero_()
+
+    def optimizer_step(self, mel_length: int) -> None:
+        """Pre-clip → total norm → non-finite skip / explosion tracker / adaptive + global clip → fused AdamW+EMA →
+        FFN weight-norm projection.  All decisions on the device (see csrc/kk_optim.hip)."""
+        a, hp = self.arena, self.hp
+        cfg = self._opt_cfg(mel_length)
+        kk.call("kk_seg_sumsq", a.g, a.block_seg, a.nblocks, self.grad_sumsq, a.nseg)
+        kk.call("kk_opt_prepare", self.grad_sumsq, a.seg_preclip, a.seg_lr_mult, a.seg_wd, a.nseg, self.max_dur, cfg,
+                self.opt_state, self.seg_gscale, self.seg_decay, self.seg_stepsize, self.step_consts)
+        kk.call("kk_adamw_ema", a.p, a.g, a.m, a.v, a.ema, a.block_seg, a.nblocks, self.seg_gscale, self.seg_decay,
+                self.seg_stepsize, a.seg_flags, self.step_consts, hp.adam_betas[0], hp.adam_betas[1], hp.ema_decay,
+                self.p_sumsq, a.nseg)
+        kk.call("kk_weight_norm_project", a.p, a.block_seg, a.nblocks, self.p_sumsq, a.seg_flags, self.step_consts,
+                float(hp.dec_ffn_max_weight_norm))
+
+    def train_step(self, batch: Dict[str, torch.Tensor], accumulation_divisor: Optional[int] = None,
+                   boundary: Optional[bool] = None) -> torch.Tensor:
+        """One micro-batch of training in the reference's order (trainer.py:2257-2477): zero grads at the start of an
+        accumulation cycle, forward+backward with loss_scale = adaptive/divisor, optimizer boundary when the cycle
+        completes.  Returns the device tensor of 6 losses (no host sync)."""
+        G = max(1, int(self.hp.gradient_accumulation_steps))
+        div = accumulation_divisor if accumulation_divisor is not None else G
+        if self.micro_in_cycle == 0:
+            self.zero_grad()
+        out = self.forward_backward(batch, loss_scale=1.0 / div, adaptive=True)
+        self.micro_in_cycle += 1
+        if boundary if boundary is not None else self.micro_in_cycle >= G:
+            self.optimizer_step(batch["mel_specs"].shape[1])
+            self.micro_in_cycle = 0
+        return out["losses"]
+
+    def opt_stats(self) -> Dict[str, float]:
+        """Host read-back of the device optimizer state (synchronises; for logging/tests only)."""
+        s = self.opt_state.cpu().tolist()
+        return {k.lower(): s[v] for k, v in kk.OS.items() if k != "SIZE"}

@@ -1,0 +1,206 @@
+"""GPU suite, engine level: the HIP train step (forward, 6 losses, all gradients, optimizer boundary) against
+(1) the committed golden vectors — outputs of the reference itself — and (2) the CPU oracle on the same inputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import kokoro_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng_mod():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from kokoro_ruslan_amd import engine
+    return engine
+
+
+def _load(golden_dir, name):
+    fx = np.load(os.path.join(golden_dir, name + ".npz"))
+    d = O.ModelDims(*[int(x) for x in fx["dims"]])
+    batch = {k.split("/", 1)[1]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("batch/")}
+    seed = int(fx["seed"])
+    P = O.init_params(d, seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    for n, p in P.items():
+        if p.dim() == 1:
+            p.add_(torch.randn(p.shape, generator=g) * 0.1)
+    return fx, d, batch, P
+
+
+def _engine(eng_mod, d, P, math_mode="f32", **hp_kw):
+    from kokoro_ruslan_amd.spec import ModelDims, StepHyper
+    e = eng_mod.KokoroEngine(ModelDims(**d.__dict__), StepHyper(**hp_kw), math_mode=math_mode, init=False, total_steps=20000)
+    e.load_params(P)
+    return e
+
+
+def _cuda(batch):
+    return {k: v.cuda() for k, v in batch.items()}
+
+
+def _relerr(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return float((got - ref).norm() / (ref.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("name", ["tiny_full", "tiny_ragged", "mid_chunked", "full_dims"])
+def test_train_step_parity_fp32(eng_mod, golden_dir, name):
+    fx, d, batch, P = _load(golden_dir, name)
+    e = _engine(eng_mod, d, P)
+    e.zero_grad()
+    out = e.forward_backward(_cuda(batch), loss_scale=1.0)
+    torch.cuda.synchronize()
+    # (1) against the reference's own outputs (golden)
+    for k in ("mel", "log_dur", "stop", "pitch", "energy"):
+        ref = torch.from_numpy(fx[f"out/{k}"])
+        err = float((out[k].cpu() - ref).abs().max())
+        assert err < 2e-4, f"{name}: output {k} max|err| {err:.3e}"
+    losses = out["losses"].cpu().double().numpy()
+    assert abs(losses[1] - fx["losses"][1]) < 1e-4, "mel-L1 must be within 1e-4 of the reference (north_star bar)"
+    np.testing.assert_allclose(losses, fx["losses"], atol=1e-4, rtol=1e-5)
+    names = list(O.param_shapes(d))
+    G = e.grads()
+    got_norms = np.array([float(G[n].double().norm()) for n in names])
+    np.testing.assert_allclose(got_norms, fx["grad_norms"], rtol=2e-3, atol=1e-6)
+    # (2) every gradient tensor against the oracle (autograd on the CPU restatement)
+    Go, _, _ = O.grads_of(P, O.make_buffers(d), batch, d, O.StepHyper())
+    worst = max(((_relerr(G[n], Go[n]) if float(Go[n].norm()) > 1e-7 else float(G[n].abs().max())), n) for n in names)
+    assert worst[0] < 2e-3, f"{name}: worst gradient relative error {worst}"
+    # length-regulator indices: bit-exact
+    idx, lens, _ = O.length_regulate_index(batch["phoneme_durations"].numpy(), batch["mel_specs"].shape[1])
+    assert np.array_equal(out["lr_idx"].cpu().numpy(), idx) and np.array_equal(out["lr_lens"].cpu().numpy(), lens)
+
+
+def test_no_gradient_into_encoder_from_mel_loss(eng_mod, golden_dir):
+    """with only the mel loss active the text encoder must receive exactly zero gradient."""
+    fx, d, batch, P = _load(golden_dir, "tiny_ragged")
+    e = _engine(eng_mod, d, P, duration_loss_weight=0.0, stop_token_loss_weight=0.0, pitch_loss_weight=0.0,
+                energy_loss_weight=0.0)
+    e.zero_grad()
+    e.forward_backward(_cuda(batch))
+    G = e.grads()
+    assert float(G["text_embedding.weight"].abs().max()) == 0.0
+    assert float(G["transformer_encoder_layers.0.self_attn.w_q.weight"].abs().max()) == 0.0
+    assert float(G["decoder.layers.0.ff.linear1.weight"].abs().max()) > 0.0
+
+
+def test_optimizer_boundary_matches_reference(eng_mod, golden_dir):
+    """Pre-clip, clip, AdamW, EMA and weight-norm projection against the reference's post-step state."""
+    fx, d, batch, P = _load(golden_dir, "tiny_ragged")
+    names = list(O.param_shapes(d))
+    wn = float(fx["step/max_weight_norm"])
+    e = _engine(eng_mod, d, P, dec_ffn_max_weight_norm=wn, gradient_accumulation_steps=1)
+    e.zero_grad()
+    e.forward_backward(_cuda(batch), loss_scale=float(fx["step/grad_scale"]))     # grads x40 so every clip fires
+    e.optimizer_step(batch["mel_specs"].shape[1])
+    torch.cuda.synchronize()
+    st = e.opt_stats()
+    assert st["last_skip"] == 0.0 and st["attempt"] == 1.0
+    assert abs(st["last_grad_norm"] - float(fx["step/grad_norm"])) < 2e-3 * float(fx["step/grad_norm"])
+    assert abs(st["last_clip_coef"] - float(fx["step/clip_coef"])) < 2e-3 * float(fx["step/clip_coef"])
+    assert abs(st["last_base_lr"] - 5e-5) < 1e-12          # step 0 runs at the full OneCycle initial LR (quirk kept)
+    sd, esd = e.state_dict(), e.state_dict(ema=True)
+    got = np.array([float(sd[n].double().norm()) for n in names])
+    np.testing.assert_allclose(got, fx["step/param_norms"], rtol=1e-5, atol=1e-8)
+    got = np.array([float((sd[n].cpu().double() - P[n].double()).norm()) for n in names])
+    np.testing.assert_allclose(got, fx["step/delta_norms"], rtol=5e-3, atol=1e-8)
+    for n in names:
+        if f"step_param/{n}" in fx.files:
+            ref = fx[f"step_param/{n}"]
+            np.testing.assert_allclose(sd[n].cpu().numpy(), ref, atol=1e-6 + 1e-5 * np.abs(ref).max(), rtol=0)
+            ref = fx[f"step_ema/{n}"]      # EMA moves by (1-0.9999)*delta: compare values, the delta is below fp32 ulp
+            np.testing.assert_allclose(esd[n].cpu().numpy(), ref, atol=2e-7 + 2e-7 * np.abs(ref).max(), rtol=0)
+    # buffers are EMA-tracked like the reference's state_dict loop and must stay put
+    assert torch.equal(esd["positional_encoding.pe"].cpu(), O.make_buffers(d)["positional_encoding.pe"])
+    # and against the oracle, tensor by tensor
+    Go, _, _ = O.grads_of(P, O.make_buffers(d), batch, d, O.StepHyper(), loss_scale=float(fx["step/grad_scale"]))
+    P2 = {n: P[n].clone() for n in names}
+    ema = {n: P[n].clone() for n in names}
+    hp = O.StepHyper(dec_ffn_max_weight_norm=wn)
+    O.optimizer_step(P2, Go, O.OptState(), hp, hp.learning_rate, hp.max_grad_norm, ema, None)
+    for n in names:
+        dref = (P2[n] - P[n]).double()
+        dgot = (sd[n].cpu() - P[n]).double()
+        assert float((dgot - dref).norm()) <= 5e-3 * float(dref.norm()) + 1e-9, n
+        assert float((esd[n].cpu() - ema[n]).abs().max()) <= 2e-7 + 2e-7 * float(ema[n].abs().max()), ("ema", n)
+
+
+def test_multi_step_training_tracks_oracle(eng_mod, golden_dir):
+    """Three optimizer steps with gradient accumulation 2 (6 micro-batches): parameters track the oracle."""
+    fx, d, _, P = _load(golden_dir, "tiny_full")
+    names = list(O.param_shapes(d))
+    hp = O.StepHyper(warmup_steps=2, learning_rate=1e-3)
+    e = _engine(eng_mod, d, P, warmup_steps=2, learning_rate=1e-3, gradient_accumulation_steps=2)
+    e.total_steps = 10
+    Bf = O.make_buffers(d)
+    Po = {n: P[n].clone() for n in names}
+    ema = {n: P[n].clone() for n in names}
+    st, sch = O.OptState(), O.LRSchedule(hp, 10)
+    for step in range(3):
+        acc = {n: torch.zeros_like(P[n]) for n in names}
+        for mb in range(2):
+            batch = O.synthetic_batch(2, 40, 6, d, seed=100 + step * 2 + mb, ragged=True)
+            e.train_step(_cuda(batch))
+            G, _, _ = O.grads_of(Po, Bf, batch, d, hp, loss_scale=0.5)
+            for n in names:
+                acc[n] += G[n]
+        O.optimizer_step(Po, acc, st, hp, sch.base_lr(step), hp.max_grad_norm, ema, None)
+    torch.cuda.synchronize()
+    sd = e.state_dict()
+    assert e.opt_stats()["attempt"] == 3.0
+    for n in names:
+        dref = (Po[n] - P[n]).double()
+        dgot = (sd[n].cpu() - P[n]).double()
+        assert float((dgot - dref).norm()) <= 2e-2 * float(dref.norm()) + 1e-8, n
+
+
+def test_nonfinite_gradients_skip_the_step(eng_mod, golden_dir):
+    fx, d, batch, P = _load(golden_dir, "tiny_full")
+    e = _engine(eng_mod, d, P, gradient_accumulation_steps=1)
+    e.zero_grad()
+    e.forward_backward(_cuda(batch))
+    e.arena.G["mel_projection_out.bias"][0] = float("nan")
+    before = e.arena.p.clone()
+    e.optimizer_step(40)
+    torch.cuda.synchronize()
+    st = e.opt_stats()
+    assert st["last_skip"] == 1.0 and st["skipped"] == 1.0
+    assert torch.equal(e.arena.p, before), "a skipped step must leave every parameter untouched"
+
+
+def test_bf16_math_mode_close_to_fp32(eng_mod, golden_dir):
+    fx, d, batch, P = _load(golden_dir, "mid_chunked")
+    e = _engine(eng_mod, d, P, math_mode="bf16")
+    e.zero_grad()
+    out = e.forward_backward(_cuda(batch))
+    torch.cuda.synchronize()
+    losses = out["losses"].cpu().double().numpy()
+    np.testing.assert_allclose(losses, fx["losses"], atol=3e-2, rtol=3e-2)
+    names = list(O.param_shapes(d))
+    Go, _, _ = O.grads_of(P, O.make_buffers(d), batch, d, O.StepHyper())
+    G = e.grads()
+    cos = []
+    for n in names:
+        a, b = G[n].cpu().double().flatten(), Go[n].double().flatten()
+        if float(b.norm()) > 1e-6:
+            cos.append(float(a @ b / (a.norm() * b.norm() + 1e-30)))
+    assert min(cos) > 0.97 and float(np.mean(cos)) > 0.995, (min(cos), float(np.mean(cos)))
+
+
+def test_state_dict_roundtrip_and_names(eng_mod, golden_dir):
+    fx, d, batch, P = _load(golden_dir, "tiny_full")
+    e = _engine(eng_mod, d, P)
+    sd = e.state_dict()
+    assert list(sd.keys()) == O.state_dict_order(d)
+    for n in P:
+        assert torch.equal(sd[n].cpu(), P[n])
+    e2 = _engine(eng_mod, d, O.init_params(d, 99))
+    e2.load_state_dict({k: v.clone() for k, v in sd.items()})
+    assert torch.equal(e2.arena.p, e.arena.p)
+    with pytest.raises(RuntimeError):
+        e2.load_state_dict({"bogus": torch.zeros(1)})

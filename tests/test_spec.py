@@ -1,0 +1,54 @@
+"""CPU suite: the engine's static tables (kokoro_ruslan_amd.spec) against the reference dump and the oracle."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from kokoro_ruslan_amd import spec
+from oracle import kokoro_oracle as O
+
+
+def test_spec_matches_reference_param_table(golden_dir):
+    tab = json.load(open(os.path.join(golden_dir, "param_table.json")))
+    d, hp = spec.ModelDims(), spec.StepHyper()
+    shapes = spec.param_shapes(d)
+    assert [r["name"] for r in tab["params"]] == list(shapes)
+    assert tab["state_dict_order"] == spec.state_dict_order(d)
+    for r in tab["params"]:
+        n = r["name"]
+        assert tuple(r["shape"]) == shapes[n]
+        assert r["group"] == spec.param_group_of(n)
+        assert r["preclip"] == spec.preclip_max_norm(n, hp)
+        assert r["weight_norm"] == spec.is_weight_norm_target(n)
+
+
+def test_spec_matches_oracle():
+    for d_o in (O.ModelDims(), O.ModelDims(hidden=128, heads=2, enc_layers=1, dec_layers=2, enc_ff=96, dec_ff=96,
+                                           var_filter=32, var_bins=16, mel=20, max_len=300)):
+        d = spec.ModelDims(**d_o.__dict__)
+        assert spec.param_shapes(d) == O.param_shapes(d_o)
+        for (k1, v1), (k2, v2) in zip(spec.make_buffers(d).items(), O.make_buffers(d_o).items()):
+            assert k1 == k2 and torch.equal(v1, v2)
+        a, b = spec.init_params(d, 3), O.init_params(d_o, 3)
+        assert all(torch.equal(a[n], b[n]) for n in a)
+    assert spec.group_lr_mult_wd(spec.StepHyper()) == O.group_lr_mult_wd(O.StepHyper())
+    c, s = spec.rope_tables(77)
+    co, so = O.rope_tables(77, 64)
+    assert torch.equal(c, co) and torch.equal(s, so)
+
+
+def test_lr_consts_match_oracle_schedule():
+    for total, warm in ((60, 20), (5, 1200), (3000, 1200)):
+        hp = spec.StepHyper(warmup_steps=warm)
+        c = spec.lr_schedule_consts(hp, total)
+        sch = O.LRSchedule(O.StepHyper(warmup_steps=warm), total)
+        assert c["warmup_steps"] == sch.warmup_steps and c["onecycle_steps"] == sch.onecycle_steps
+        assert c["div_factor"] == sch.div and c["max_lr"] == sch.max_lr
+
+
+def test_dims_validation():
+    import pytest
+    with pytest.raises(ValueError):
+        spec.ModelDims(hidden=64, heads=2).validate()
+    spec.ModelDims().validate()
