@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Headline benchmark: mel-frames/s of the full Kokoro train step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one synthetic padded batch already resident in HBM: forward, 6 losses,
+full backward, (N>1: gradient SUM all-reduce over RCCL), pre-clip + global clip, fused AdamW + EMA, weight-norm
+projection.  Workload at every N: BASELINE.json configs[1]'s shape per GPU (8 x 512 mel frames, 64 phonemes,
+default 49.4 M-parameter model, bf16 MFMA arithmetic with fp32 accumulate/master weights) — weak scaling.
+Rank 0 prints ONE JSON line (contract in the task description) with `roofline` and `cpu_baseline` objects.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+# Algorithmic train-step FLOPs per mel frame (SURVEY §8d / BASELINE.md §4: 3 x forward, causal = lower triangle)
+FLOP_PER_FRAME = {(8, 512, 64): 212.4e6, (8, 1024, 128): 241.0e6}
+
+GEMM_SYMBOL = {(0, 0): "gemm_kernel<false,false,{b}> (X.W^T fwd)", (0, 1): "gemm_kernel<false,true,{b}> (dY.W dgrad)",
+               (1, 1): "gemm_kernel<true,true,{b}> (dY^T.X wgrad)", (1, 0): "gemm_kernel<true,false,{b}>"}
+
+
+def kernel_table(records, math_bf16: bool):
+    """Aggregate per-launch event timings into {kernel: {launches, ms, flops, bytes}}."""
+    agg = {}
+    for name, sc, ms in records:
+        flops = byts = 0.0
+        key = name
+        if name == "kk_gemm":
+            ta, tb, M, N, K = (int(x) for x in sc[:5])
+            key = GEMM_SYMBOL[(ta, tb)].format(b="true" if math_bf16 else "false")
+            flops = 2.0 * M * N * K
+            byts = 4.0 * (M * K + N * K + M * N)
+        elif name in ("kk_attn_fwd", "kk_attn_bwd_dq", "kk_attn_bwd_dkv"):
+            B, h, Sq, Sk = (int(x) for x in sc[:4])
+            causal = int(sc[-3])
+            mm = {"kk_attn_fwd": 2, "kk_attn_bwd_dq": 3, "kk_attn_bwd_dkv": 4}[name]   # matmuls of Sq x Sk x 64
+            flops = mm * 2.0 * B * h * Sq * Sk * 64 * (0.5 if causal else 1.0)
+            byts = 4.0 * B * h * 64 * (2 * Sq + 2 * Sk)
+        a = agg.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        a["launches"] += 1
+        a["ms"] += ms
+        a["flops"] += flops
+        a["bytes"] += byts
+    return agg
+
+
+def cpu_baseline(B, T, P, steps=2):
+    """The oracle (CPU restatement of the reference, proven equal to it) timed on this box's host cores: forward +
+    losses + backward + pre-clip/clip/AdamW/EMA, fp32, dropout off, no recompute.  Reported baseline, not the target."""
+    from oracle import kokoro_oracle as O
+    d, hp = O.ModelDims(), O.StepHyper()
+    Pm, Bf = O.init_params(d, 0), O.make_buffers(d)
+    ema = {n: p.clone() for n, p in Pm.items()}
+    st = O.OptState()
+    batch = O.synthetic_batch(B, T, P, d, seed=1234)
+    best = float("inf")
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        G, _, _ = O.grads_of(Pm, Bf, batch, d, hp)
+        O.optimizer_step(Pm, G, st, hp, hp.learning_rate, hp.max_grad_norm, ema, None)
+        best = min(best, time.perf_counter() - t0)
+    return {"value": round(B * T / best, 1), "unit": "mel-frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} full train steps of the {B}x{T} batch (P={P}), fp32, best of {steps}; "
+                      f"{best:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--frames", type=int, default=512)
+    ap.add_argument("--phonemes", type=int, default=64)
+    ap.add_argument("--math", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-table", default="")
+    args = ap.parse_args()
+
+    from kokoro_ruslan_amd import dp, lib as kk
+    from kokoro_ruslan_amd.engine import KokoroEngine
+    from kokoro_ruslan_amd.spec import ModelDims, StepHyper
+    from kokoro_ruslan_amd.synthetic import synthetic_batch
+
+    rank, world, local = dp.init()
+    if world != max(1, args.gpus) and rank == 0:
+        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    torch.cuda.set_device(local)
+    B, T, P = args.batch, args.frames, args.phonemes
+    hp = StepHyper(gradient_accumulation_steps=1)
+    eng = KokoroEngine(ModelDims(), hp, math_mode=args.math, total_steps=20000, seed=0)   # same seed ⇒ identical replicas
+    sync = dp.GradSync(world)
+    eng.dp_loss_scale = sync.loss_scale
+    batch = {k: v.cuda() for k, v in synthetic_batch(B, T, P, seed=1234 + rank).items()}
+    step = (lambda: eng.train_step(batch)) if args.no_graph else (lambda: eng.train_step_graphed(batch, sync if world > 1 else None))
+    if args.no_graph and world > 1:
+        def step():   # noqa: F811
+            eng.zero_grad()
+            eng.forward_backward(batch, loss_scale=eng.dp_loss_scale, adaptive=True)
+            sync(eng.arena.g)
+            eng.optimizer_step(T)
+
+    for _ in range(max(args.warmup, 2)):       # >= 2: first call allocates workspaces, second captures the graphs
+        step()
+    dp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dp.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    dp.all_max(dt)
+    dt = float(dt)
+    losses = eng.losses.cpu().tolist()
+    stats = eng.opt_stats()
+
+    roof, table = None, {}
+    if rank == 0:
+        # Roofline leg: the same step, eager, every launch bracketed by events on the launch stream.
+        kk.profile_start()
+        for _ in range(2):
+            eng.zero_grad()
+            eng.forward_backward(batch, loss_scale=eng.dp_loss_scale, adaptive=True)
+            eng.optimizer_step(T)
+        table = kernel_table(kk.profile_stop(), args.math == "bf16")
+        mfma = {k: v for k, v in table.items() if v["flops"] > 0}
+        dom = max(mfma, key=lambda k: mfma[k]["ms"])
+        v = mfma[dom]
+        peak = PEAK_BF16_TFLOPS if args.math == "bf16" else PEAK_F32_TFLOPS
+        ach = v["flops"] / (v["ms"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": v["launches"] // 2,
+                "avg_launch_us": round(v["ms"] * 1e3 / v["launches"], 2),
+                "algorithmic_gflop_per_launch": round(v["flops"] / v["launches"] / 1e9, 3)}
+        if args.kernel_table:
+            tot = sum(x["ms"] for x in table.values())
+            rows = sorted(table.items(), key=lambda kv: -kv[1]["ms"])
+            with open(args.kernel_table, "w") as f:
+                json.dump({"total_ms_2_steps": tot, "kernels": {k: v for k, v in rows}}, f, indent=1)
+    dp.barrier()
+    if rank != 0:
+        return
+    frames = world * B * T * args.steps
+    fpf = FLOP_PER_FRAME.get((B, T, P))
+    out = {"metric": "mel-frames/sec (full train step)", "value": round(frames / dt, 1), "unit": "mel-frames/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.math, "data": "synthetic",
+           "per_gpu": round(frames / dt / world, 1),
+           "config": {"workload": f"kokoro acoustic-model train step, {B}x{T} mel frames x {P} phonemes per GPU "
+                                  f"(BASELINE configs[1]), 49.4M params, fwd+loss+bwd+clip+AdamW+EMA every step",
+                      "global_batch": world * B, "frames": T, "phonemes": P, "parallelism": f"dp{world}",
+                      "grad_accumulation": 1, "dropout": "off (p=0 parity configuration)",
+                      "hipgraph": not args.no_graph},
+           "final_losses": [round(x, 5) for x in losses], "optimizer_steps": stats["attempt"], "skipped": stats["skipped"],
+           "roofline": roof}
+    if fpf:
+        out["model_tflops"] = round(frames / dt * fpf / 1e12, 2)
+        out["model_mfma_frac"] = round(frames / dt * fpf / 1e12 / world / (PEAK_BF16_TFLOPS if args.math == "bf16" else PEAK_F32_TFLOPS), 4)
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(B, T, P)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

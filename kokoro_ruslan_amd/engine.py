@@ -103,6 +103,7 @@ class KokoroEngine:
         self.arena = Arena(self.dims, self.hp, self.device)
         self.total_steps = total_steps
         self._ws: Dict[Tuple, torch.Tensor] = {}
+        self._graphs: Dict[Tuple, Dict] = {}
         self._rope: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
         self.opt_state = torch.zeros(kk.OS["SIZE"], dtype=torch.float64, device=self.device)
         ns = self.arena.nseg
@@ -116,6 +117,7 @@ class KokoroEngine:
         self.losses = f32(6)
         self.loss_coef = f32(5)
         self.micro_in_cycle = 0
+        self.dp_loss_scale = 1.0                    # 1/world in data-parallel runs (dp.GradSync.loss_scale)
         for n, b in spec.make_buffers(self.dims).items():
             self.arena.P[n].copy_(b)
         if init:
@@ -509,12 +511,47 @@ class KokoroEngine:
         div = accumulation_divisor if accumulation_divisor is not None else G
         if self.micro_in_cycle == 0:
             self.zero_grad()
-        out = self.forward_backward(batch, loss_scale=1.0 / div, adaptive=True)
+        out = self.forward_backward(batch, loss_scale=self.dp_loss_scale / div, adaptive=True)
         self.micro_in_cycle += 1
         if boundary if boundary is not None else self.micro_in_cycle >= G:
             self.optimizer_step(batch["mel_specs"].shape[1])
             self.micro_in_cycle = 0
         return out["losses"]
+
+    # ------------------------------------------------------------------ hipGraph replay of a whole step
+    def train_step_graphed(self, batch: Dict[str, torch.Tensor], grad_sync=None) -> torch.Tensor:
+        """Same semantics as train_step with gradient_accumulation_steps == 1, but the kernel sequence of a step is
+        captured once per batch shape into hipGraphs and replayed (a step is ~700 launches; eager launch overhead
+        would dominate).  `grad_sync` (data parallel) runs between the backward graph and the optimizer graph."""
+        B, T = batch["mel_specs"].shape[:2]
+        key = (B, T, batch["phoneme_indices"].shape[1])
+        ent = self._graphs.get(key)
+        if ent is None:                               # first sight of a shape: eager (allocates the workspaces)
+            static = {k: v.clone() for k, v in batch.items()}
+            self._graphs[key] = {"static": static, "fb": None, "opt": None}
+            self.zero_grad()
+            out = self.forward_backward(static, loss_scale=self.dp_loss_scale, adaptive=True)
+            if grad_sync is not None:
+                grad_sync(self.arena.g)
+            self.optimizer_step(T)
+            return out["losses"]
+        static = ent["static"]
+        for k, v in batch.items():
+            if v.data_ptr() != static[k].data_ptr():
+                static[k].copy_(v, non_blocking=True)
+        if ent["fb"] is None:
+            torch.cuda.synchronize()
+            ent["fb"], ent["opt"] = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ent["fb"]):
+                self.zero_grad()
+                self.forward_backward(static, loss_scale=self.dp_loss_scale, adaptive=True)
+            with torch.cuda.graph(ent["opt"]):
+                self.optimizer_step(T)
+        ent["fb"].replay()
+        if grad_sync is not None:
+            grad_sync(self.arena.g)
+        ent["opt"].replay()
+        return self.losses
 
     def opt_stats(self) -> Dict[str, float]:
         """Host read-back of the device optimizer state (synchronises; for logging/tests only)."""

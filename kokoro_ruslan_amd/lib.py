@@ -80,6 +80,21 @@ SIGNATURES: Dict[str, List[Any]] = {
 }
 
 _lib = None
+_prof = None   # when a list: call() brackets every launch with events on the launch stream (bench.py roofline leg)
+
+
+def profile_start() -> None:
+    global _prof
+    _prof = []
+
+
+def profile_stop():
+    """Returns [(name, args, ms)] for every call since profile_start() (synchronises)."""
+    global _prof
+    import torch
+    rec, _prof = _prof or [], None
+    torch.cuda.synchronize()
+    return [(n, a, s.elapsed_time(e)) for n, a, s, e in rec]
 
 
 def load() -> C.CDLL:
@@ -119,6 +134,13 @@ def call(name: str, *args) -> None:
     import torch
     lib = load()
     stream = torch.cuda.current_stream().cuda_stream
-    rc = getattr(lib, name)(*[_conv(a) for a in args], stream)
+    if _prof is not None:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = getattr(lib, name)(*[_conv(a) for a in args], stream)
+        e.record()
+        _prof.append((name, tuple(a for a in args if isinstance(a, (int, float))), s, e))
+    else:
+        rc = getattr(lib, name)(*[_conv(a) for a in args], stream)
     if rc != 0:
         raise RuntimeError(f"{name} failed (code {rc}): {lib.kk_last_error().decode(errors='replace')}")
