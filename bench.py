@@ -30,8 +30,8 @@ PEAK_HBM_GBS = 8000.0
 # Algorithmic train-step FLOPs per mel frame (SURVEY §8d / BASELINE.md §4: 3 x forward, causal = lower triangle)
 FLOP_PER_FRAME = {(8, 512, 64): 212.4e6, (8, 1024, 128): 241.0e6}
 
-GEMM_SYMBOL = {(0, 0): "gemm_kernel<false,false,{b}> (X.W^T fwd)", (0, 1): "gemm_kernel<false,true,{b}> (dY.W dgrad)",
-               (1, 1): "gemm_kernel<true,true,{b}> (dY^T.X wgrad)", (1, 0): "gemm_kernel<true,false,{b}>"}
+GEMM_SYMBOL = {(0, 0): "gemm_kernel<false,false,{b},{t}> (X.W^T fwd)", (0, 1): "gemm_kernel<false,true,{b},{t}> (dY.W dgrad)",
+               (1, 1): "gemm_kernel<true,true,{b},{t}> (dY^T.X wgrad)", (1, 0): "gemm_kernel<true,false,{b},{t}>"}
 
 
 def kernel_table(records, math_bf16: bool):
@@ -42,7 +42,8 @@ def kernel_table(records, math_bf16: bool):
         key = name
         if name == "kk_gemm":
             ta, tb, M, N, K = (int(x) for x in sc[:5])
-            key = GEMM_SYMBOL[(ta, tb)].format(b="true" if math_bf16 else "false")
+            tile = 128 if -(-M // 128) * -(-N // 128) >= 512 else 64          # same rule as kk_gemm
+            key = GEMM_SYMBOL[(ta, tb)].format(b="true" if math_bf16 else "false", t=tile)
             flops = 2.0 * M * N * K
             byts = 4.0 * (M * K + N * K + M * N)
         elif name in ("kk_attn_fwd", "kk_attn_bwd_dq", "kk_attn_bwd_dkv"):

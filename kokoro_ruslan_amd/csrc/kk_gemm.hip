@@ -19,17 +19,15 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128;
-
-template <bool BF16> struct GemmCfg;
-template <> struct GemmCfg<true> {
-    static constexpr int BK = 32, LR = 40, NV = 4;   // LR: LDS row stride in elements (80 bytes)
-    typedef __bf16 elem;
-};
-template <> struct GemmCfg<false> {
-    static constexpr int BK = 16, LR = 17, NV = 2;
-    typedef float elem;
-};
+// Tile configurations: TM x TM output tile, BK reduction slab.  Both stage 4096 (bf16) / 2048 (fp32) operand
+// elements per tile, i.e. the same 16 / 8 floats per thread.  The 64-tile (BK twice as deep) is used when the
+// 128-tile grid would leave most of the 256 CUs idle — the Linear layers here have M = B*T = 4096..8192 rows and
+// N = 512..3072, i.e. only 128..768 128x128 tiles.
+template <bool BF16, int TM> struct GemmCfg;
+template <> struct GemmCfg<true, 128> { static constexpr int BK = 32, LR = 40, NV = 4; typedef __bf16 elem; };   // 80-byte rows
+template <> struct GemmCfg<true, 64> { static constexpr int BK = 64, LR = 72, NV = 4; typedef __bf16 elem; };    // 144-byte rows
+template <> struct GemmCfg<false, 128> { static constexpr int BK = 16, LR = 17, NV = 2; typedef float elem; };
+template <> struct GemmCfg<false, 64> { static constexpr int BK = 32, LR = 33, NV = 2; typedef float elem; };
 
 struct GemmArgs {
     int M, N, K;
@@ -44,23 +42,25 @@ __device__ __forceinline__ float f4c(const float4 &v, int c) { return reinterpre
 
 // Global -> registers for one 128 x BK operand tile.  KS=false: element (row,k) at X[row*ld + k];
 // KS=true: element (row,k) at X[k*ld + row].
-template <bool BF16, bool KS>
+template <bool BF16, int TM, bool KS>
 __device__ __forceinline__ void g2r(const float *__restrict__ X, int64_t ld, int rows_total, int r0, int k0,
-                                    int kend, float4 (&reg)[GemmCfg<BF16>::NV]) {
-    constexpr int NV = GemmCfg<BF16>::NV;
+                                    int kend, float4 (&reg)[GemmCfg<BF16, TM>::NV]) {
+    constexpr int NV = GemmCfg<BF16, TM>::NV;
+    constexpr int TPR = GemmCfg<BF16, TM>::BK / (NV * 4);   // threads per tile row (k-contiguous operand)
+    constexpr int RG = TM / 4;                               // 4-row groups per tile (k-strided operand)
     const int t = threadIdx.x;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!KS) {
-        const int row = r0 + (t >> 1);
-        const int kb = k0 + (t & 1) * (NV * 4);
+        const int row = r0 + t / TPR;
+        const int kb = k0 + (t % TPR) * (NV * 4);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int k = kb + 4 * i;
             reg[i] = (row < rows_total && k < kend) ? ld4(X + (int64_t)row * ld + k) : z;
         }
     } else {
-        const int row = r0 + (t & 31) * 4;
-        const int kb = k0 + (t >> 5) * NV;
+        const int row = r0 + (t % RG) * 4;
+        const int kb = k0 + (t / RG) * NV;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int k = kb + i;
@@ -70,13 +70,14 @@ __device__ __forceinline__ void g2r(const float *__restrict__ X, int64_t ld, int
 }
 
 // Registers -> LDS tile S[128][LR] (k contiguous), converting to bf16 when BF16.
-template <bool BF16, bool KS>
-__device__ __forceinline__ void r2s(typename GemmCfg<BF16>::elem *S, const float4 (&reg)[GemmCfg<BF16>::NV]) {
-    constexpr int LR = GemmCfg<BF16>::LR;
+template <bool BF16, int TM, bool KS>
+__device__ __forceinline__ void r2s(typename GemmCfg<BF16, TM>::elem *S, const float4 (&reg)[GemmCfg<BF16, TM>::NV]) {
+    constexpr int LR = GemmCfg<BF16, TM>::LR, NV = GemmCfg<BF16, TM>::NV;
+    constexpr int TPR = GemmCfg<BF16, TM>::BK / (NV * 4), RG = TM / 4;
     const int t = threadIdx.x;
     if constexpr (BF16) {
         if (!KS) {
-            const int row = t >> 1, kofs = (t & 1) * 16;
+            const int row = t / TPR, kofs = (t % TPR) * 16;
             bf16x8 lo, hi;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -88,7 +89,7 @@ __device__ __forceinline__ void r2s(typename GemmCfg<BF16>::elem *S, const float
             *reinterpret_cast<bf16x8 *>(&S[row * LR + kofs]) = lo;
             *reinterpret_cast<bf16x8 *>(&S[row * LR + kofs + 8]) = hi;
         } else {
-            const int rowb = (t & 31) * 4, kofs = (t >> 5) * 4;
+            const int rowb = (t % RG) * 4, kofs = (t / RG) * 4;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 bf16x4 v;
@@ -99,13 +100,13 @@ __device__ __forceinline__ void r2s(typename GemmCfg<BF16>::elem *S, const float
         }
     } else {
         if (!KS) {
-            const int row = t >> 1, kofs = (t & 1) * 8;
+            const int row = t / TPR, kofs = (t % TPR) * 8;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) S[row * LR + kofs + 4 * i + e] = f4c(reg[i], e);
         } else {
-            const int rowb = (t & 31) * 4, kofs = (t >> 5) * 2;
+            const int rowb = (t % RG) * 4, kofs = (t / RG) * 2;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -114,11 +115,12 @@ __device__ __forceinline__ void r2s(typename GemmCfg<BF16>::elem *S, const float
     }
 }
 
-template <bool TA, bool TB, bool BF16>
+template <bool TA, bool TB, bool BF16, int TM>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
-    using Cfg = GemmCfg<BF16>;
+    using Cfg = GemmCfg<BF16, TM>;
     using elem = typename Cfg::elem;
     constexpr int BK = Cfg::BK, LR = Cfg::LR, NV = Cfg::NV;
+    constexpr int BM = TM, BN = TM, WT = TM / 2, MI = WT / 32;   // wave tile WT x WT = MI x MI MFMA tiles
     constexpr int TILE = BM * LR;
     __shared__ __attribute__((aligned(16))) elem smem[4 * TILE];   // A0 A1 B0 B1
     elem *As = smem, *Bs = smem + 2 * TILE;
@@ -130,65 +132,65 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1, half = lane >> 5, l31 = lane & 31;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][MI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < MI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[NV], rb[NV];
     if (nk > 0) {
-        g2r<BF16, TA>(a.A, a.lda, a.M, m0, kbeg, kend, ra);
-        g2r<BF16, TB>(a.B, a.ldb, a.N, n0, kbeg, kend, rb);
-        r2s<BF16, TA>(As, ra);
-        r2s<BF16, TB>(Bs, rb);
+        g2r<BF16, TM, TA>(a.A, a.lda, a.M, m0, kbeg, kend, ra);
+        g2r<BF16, TM, TB>(a.B, a.ldb, a.N, n0, kbeg, kend, rb);
+        r2s<BF16, TM, TA>(As, ra);
+        r2s<BF16, TM, TB>(Bs, rb);
     }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool more = kt + 1 < nk;
         if (more) {
-            g2r<BF16, TA>(a.A, a.lda, a.M, m0, kbeg + (kt + 1) * BK, kend, ra);
-            g2r<BF16, TB>(a.B, a.ldb, a.N, n0, kbeg + (kt + 1) * BK, kend, rb);
+            g2r<BF16, TM, TA>(a.A, a.lda, a.M, m0, kbeg + (kt + 1) * BK, kend, ra);
+            g2r<BF16, TM, TB>(a.B, a.ldb, a.N, n0, kbeg + (kt + 1) * BK, kend, rb);
         }
-        const elem *Ac = As + cur * TILE + (wr * 64 + l31) * LR;
-        const elem *Bc = Bs + cur * TILE + (wc * 64 + l31) * LR;
+        const elem *Ac = As + cur * TILE + (wr * WT + l31) * LR;
+        const elem *Bc = Bs + cur * TILE + (wc * WT + l31) * LR;
         if constexpr (BF16) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 af[2], bf[2];
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 af[MI], bf[MI];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < MI; ++i) {
                     af[i] = *reinterpret_cast<const bf16x8 *>(Ac + i * 32 * LR + ks * 16 + half * 8);
                     bf[i] = *reinterpret_cast<const bf16x8 *>(Bc + i * 32 * LR + ks * 16 + half * 8);
                 }
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < MI; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
             }
         } else {
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                float af[2], bf[2];
+            for (int ks = 0; ks < BK / 2; ++ks) {
+                float af[MI], bf[MI];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < MI; ++i) {
                     af[i] = Ac[i * 32 * LR + ks * 2 + half];
                     bf[i] = Bc[i * 32 * LR + ks * 2 + half];
                 }
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < MI; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
             }
         }
         if (more) {
-            r2s<BF16, TA>(As + (cur ^ 1) * TILE, ra);
-            r2s<BF16, TB>(Bs + (cur ^ 1) * TILE, rb);
+            r2s<BF16, TM, TA>(As + (cur ^ 1) * TILE, ra);
+            r2s<BF16, TM, TB>(Bs + (cur ^ 1) * TILE, rb);
         }
         __syncthreads();
     }
@@ -196,15 +198,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 
     const bool lead = (blockIdx.z == 0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wc * 64 + j * 32 + l31;
+        for (int j = 0; j < MI; ++j) {
+            const int col = n0 + wc * WT + j * 32 + l31;
             if (col >= a.N) continue;
             const float bv = (a.bias != nullptr && lead) ? a.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wr * 64 + i * 32 + frag_row(r, half);
+                const int row = m0 + wr * WT + i * 32 + frag_row(r, half);
                 if (row >= a.M) continue;
                 float v = a.alpha * acc[i][j][r] + bv;
                 if (a.residual != nullptr && lead) {
@@ -222,12 +224,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
         }
 }
 
-template <bool BF16>
+template <bool BF16, int TM>
 int launch(int ta, int tb, const GemmArgs &a, dim3 grid, hipStream_t s) {
-    if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<false, false, BF16>), grid, dim3(256), 0, s, a);
-    else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<false, true, BF16>), grid, dim3(256), 0, s, a);
-    else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<true, false, BF16>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((gemm_kernel<true, true, BF16>), grid, dim3(256), 0, s, a);
+    if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<false, false, BF16, TM>), grid, dim3(256), 0, s, a);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<false, true, BF16, TM>), grid, dim3(256), 0, s, a);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<true, false, BF16, TM>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gemm_kernel<true, true, BF16, TM>), grid, dim3(256), 0, s, a);
     KK_LAUNCH_CHECK("kk_gemm");
     return 0;
 }
@@ -243,8 +245,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ X
     const int64_t rend = rbeg + rows_per_block < M ? rbeg + rows_per_block : M;
     float s = 0.f;
     if (c < N)
+#pragma unroll 8
         for (int64_t r = rbeg + rl; r < rend; r += 4) s += X[r * ldx + c];
-    red[rl][threadIdx.x & 63] = s;
+    red[rl][threadIdx.x & 63] = s;   // (loads above are independent: the compiler keeps several in flight)
     __syncthreads();
     if (rl == 0 && c < N) atomicAdd(&out[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
@@ -264,8 +267,9 @@ extern "C" int kk_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, float al
     if (tb) KK_REQUIRE(N % 4 == 0, "kk_gemm: N=%ld must be a multiple of 4 when B is stored [K,N]", (long)N);
     KK_REQUIRE(math == KK_MATH_F32 || math == KK_MATH_BF16, "kk_gemm: bad math mode %d", math);
     hipStream_t s = (hipStream_t)stream;
-    const int BK = math == KK_MATH_BF16 ? 32 : 16;
-    const int tiles = kk_cdiv(M, BM) * kk_cdiv(N, BN);
+    const int TM = (int64_t)kk_cdiv(M, 128) * kk_cdiv(N, 128) >= 512 ? 128 : 64;
+    const int BK = (math == KK_MATH_BF16 ? 32 : 16) * (TM == 128 ? 1 : 2);
+    const int tiles = kk_cdiv(M, TM) * kk_cdiv(N, TM);
     const int ktiles = kk_cdiv(K, BK);
     int splits = split_k;
     if (splits <= 0) {   // auto: fill ~2 workgroups per CU, keep >= 4 k-tiles per slice
@@ -291,13 +295,14 @@ extern "C" int kk_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, float al
         hipError_t e = hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), s);
         if (e != hipSuccess) return kk_fail((int)e, "kk_gemm: memset: %s", hipGetErrorString(e));
     }
-    dim3 grid(kk_cdiv(N, BN), kk_cdiv(M, BM), splits);
-    return math == KK_MATH_BF16 ? launch<true>(ta, tb, a, grid, s) : launch<false>(ta, tb, a, grid, s);
+    dim3 grid(kk_cdiv(N, TM), kk_cdiv(M, TM), splits);
+    if (TM == 128) return math == KK_MATH_BF16 ? launch<true, 128>(ta, tb, a, grid, s) : launch<false, 128>(ta, tb, a, grid, s);
+    return math == KK_MATH_BF16 ? launch<true, 64>(ta, tb, a, grid, s) : launch<false, 64>(ta, tb, a, grid, s);
 }
 
 extern "C" int kk_colsum_acc(const float *X, int64_t ldx, int64_t M, int64_t N, float *out, void *stream) {
     KK_REQUIRE(M > 0 && N > 0 && X && out, "kk_colsum_acc: bad args");
-    int slabs = kk_cdiv(M, 256);
+    int slabs = kk_cdiv(M, 64);
     if (slabs > 512) slabs = 512;
     const int rows_per_block = kk_cdiv(M, slabs);
     slabs = kk_cdiv(M, rows_per_block);

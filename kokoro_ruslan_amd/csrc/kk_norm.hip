@@ -251,7 +251,11 @@ __global__ __launch_bounds__(256) void headnorm_rope_bwd_kernel(const float *__r
         const float k = wave_sum(dgv * v) * (1.f / 64.f) * rs * rs * rs;
         dx[row * lddx + hd * 64 + lane] = rs * dgv - v * k;
     }
-    atomicAdd(&dgain[lane], acc_g);
+    // one atomic per column per WORKGROUP (4096 waves hammering 64 addresses cost 100 us; see profiles/r01)
+    __shared__ float red[4][64];
+    red[threadIdx.x >> 6][lane] = acc_g;
+    __syncthreads();
+    if (threadIdx.x < 64) atomicAdd(&dgain[lane], red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
 }
 
 // ------------------------------------------------------------------ GroupNorm(1,C) per 512-frame chunk + ReLU
@@ -395,8 +399,9 @@ extern "C" int kk_layernorm_bwd(const float *dy, const float *x, const float *ga
                                 const float *rstd, float *dx, int dx_accumulate, float *dgamma, float *dbeta,
                                 int64_t rows, int H, void *stream) {
     KK_CHECK_H("kk_layernorm_bwd");
-    int blocks = row_blocks(rows);
-    if (blocks > 512) blocks = 512;
+    int blocks = kk_cdiv(rows, 16);
+    if (blocks > 256) blocks = 256;
+    if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 2 * H * sizeof(float), (hipStream_t)stream, dy, x,
                        gamma, mean, rstd, dx, dx_accumulate, dgamma, dbeta, rows, H);
     KK_LAUNCH_CHECK("kk_layernorm_bwd");
@@ -415,8 +420,9 @@ extern "C" int kk_rmsnorm_fwd(const float *x, const float *gain, const float *re
 extern "C" int kk_rmsnorm_bwd(const float *dy, const float *x, const float *gain, const float *rstd, float *dx,
                               float *dgain, int64_t rows, int H, void *stream) {
     KK_CHECK_H("kk_rmsnorm_bwd");
-    int blocks = row_blocks(rows);
-    if (blocks > 512) blocks = 512;
+    int blocks = kk_cdiv(rows, 16);
+    if (blocks > 256) blocks = 256;
+    if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(blocks), dim3(256), H * sizeof(float), (hipStream_t)stream, dy, x, gain,
                        rstd, dx, dgain, rows, H);
     KK_LAUNCH_CHECK("kk_rmsnorm_bwd");
@@ -442,8 +448,9 @@ extern "C" int kk_headnorm_rope_bwd(const float *dy, int64_t lddy, const float *
                                     const float *cos_t, const float *sin_t, void *stream) {
     KK_REQUIRE(rows > 0 && heads > 0 && S > 0, "kk_headnorm_rope_bwd: bad shape");
     const int64_t npairs = rows * heads;
-    int blocks = kk_cdiv(npairs, 4);
-    if (blocks > 1024) blocks = 1024;
+    int blocks = kk_cdiv(npairs, 16);
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(headnorm_rope_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, lddy, x, ldx, gain,
                        dx, lddx, dgain, npairs, heads, S, cos_t, sin_t);
     KK_LAUNCH_CHECK("kk_headnorm_rope_bwd");

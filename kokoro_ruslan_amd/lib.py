@@ -10,6 +10,9 @@ import ctypes as C
 import os
 from typing import Any, Dict, List
 
+import torch  # noqa: F401  -- must be imported BEFORE the .so is dlopen'ed: torch ships its own libamdhip64 and the
+#                              HIP runtime our kernels launch through has to be the one torch initialised
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libkokoro_hip.so")
 
@@ -91,7 +94,6 @@ def profile_start() -> None:
 def profile_stop():
     """Returns [(name, args, ms)] for every call since profile_start() (synchronises)."""
     global _prof
-    import torch
     rec, _prof = _prof or [], None
     torch.cuda.synchronize()
     return [(n, a, s.elapsed_time(e)) for n, a, s, e in rec]
@@ -131,7 +133,6 @@ def _conv(a):
 def call(name: str, *args) -> None:
     """Invoke ``name`` with torch tensors (→ device pointers), scalars and cfg structs; the current
     torch stream is appended as the trailing ``stream`` argument."""
-    import torch
     lib = load()
     stream = torch.cuda.current_stream().cuda_stream
     if _prof is not None:

@@ -52,7 +52,8 @@ def test_mfma_fragment_layout(kk):
 
 @pytest.mark.parametrize("math_mode", [0, 1])
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 80, 80), (517, 1536, 512), (64, 512, 1544)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 80, 80), (517, 1536, 512), (64, 512, 1544),
+                                   (4096, 2048, 136)])   # the last one takes the 128x128-tile path
 def test_gemm_layouts(kk, math_mode, ta, tb, M, N, K):
     if ta and M % 4:
         M += 4 - M % 4
