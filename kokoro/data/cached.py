@@ -1,0 +1,145 @@
+"""Cached-feature reader, collate and batch samplers.
+
+Reads the per-utterance `.pt` files the reference's `kokoro-precompute` writes under `{corpus}/.feature_cache/`
+(schema v7, reference data/dataset.py:849-862: mel_spec [80,T] f32, phoneme_indices/stress_indices/phoneme_durations
+[P] i64, stop_token_targets/pitch/energy [T] f32, mel_length, phoneme_length, text, audio_file, _cache_version).
+The audio front-end, MFA alignment and the phonemizer that PRODUCE these files stay on the reference (out of scope).
+`collate_fn` reproduces the reference's zero-padded batch dict (data/dataset.py:871-921).  The frame-budget sampler
+uses the reference's cost heuristic batch_size * max_frames_in_batch <= max_frames (dataset.py:924-1010) on a
+length-sorted order; the reference's quantile bucketing / heavy-batch spreading refinements are not reproduced.
+"""
+from __future__ import annotations
+
+import random
+from pathlib import Path
+from typing import Dict, Iterator, List, Optional, Sequence
+
+import torch
+
+FEATURE_CACHE_VERSION = 7
+_TENSOR_KEYS = ("mel_spec", "phoneme_indices", "stress_indices", "phoneme_durations", "stop_token_targets", "pitch", "energy")
+
+
+class CachedFeatureDataset:
+    def __init__(self, cache_dir: str, indices: Optional[Sequence[int]] = None, max_seq_length: int = 1800,
+                 memory_cache: bool = True):
+        self.dir = Path(cache_dir)
+        files = sorted(self.dir.glob("*.pt"))
+        if not files:
+            raise FileNotFoundError(f"no cached features (*.pt) under {self.dir}; run the reference's kokoro-precompute")
+        metas = []
+        for f in files:
+            it = torch.load(f, map_location="cpu", weights_only=False)
+            ver = it.get("_cache_version")
+            if ver != FEATURE_CACHE_VERSION:
+                raise RuntimeError(f"{f.name}: feature cache version {ver}, expected {FEATURE_CACHE_VERSION}")
+            metas.append({"file": f, "audio_length": int(it["mel_length"])})
+        metas.sort(key=lambda m: m["audio_length"])               # dataset.py:398 (sorted by length)
+        if indices is not None:
+            metas = [metas[i] for i in indices if i < len(metas)]  # dataset.py:403-405
+        self.samples = metas
+        self.max_seq_length = max_seq_length
+        self._mem: Optional[Dict[int, Dict]] = {} if memory_cache else None
+
+    def __len__(self) -> int:
+        return len(self.samples)
+
+    def __getitem__(self, i: int) -> Dict:
+        if self._mem is not None and i in self._mem:
+            return self._mem[i]
+        it = torch.load(self.samples[i]["file"], map_location="cpu", weights_only=False)
+        for k in _TENSOR_KEYS:
+            if k not in it:
+                raise KeyError(f"{self.samples[i]['file'].name}: missing field {k}")
+        T = min(int(it["mel_length"]), self.max_seq_length)
+        if it["mel_spec"].shape[1] != T:                           # clip over-long utterances (dataset.py:704-707)
+            it = dict(it)
+            it["mel_spec"] = it["mel_spec"][:, :T]
+            for k in ("stop_token_targets", "pitch", "energy"):
+                it[k] = it[k][:T]
+            it["mel_length"] = T
+        if self._mem is not None:
+            self._mem[i] = it
+        return it
+
+
+def collate_fn(batch: List[Dict]) -> Dict[str, torch.Tensor]:
+    B = len(batch)
+    mel_len = [int(it["mel_length"]) for it in batch]
+    ph_len = [int(it["phoneme_length"]) for it in batch]
+    T, P, M = max(mel_len), max(ph_len), batch[0]["mel_spec"].shape[0]
+    out = {"mel_specs": torch.zeros(B, T, M), "pitches": torch.zeros(B, T), "energies": torch.zeros(B, T),
+           "stop_token_targets": torch.zeros(B, T), "phoneme_indices": torch.zeros(B, P, dtype=torch.long),
+           "phoneme_durations": torch.zeros(B, P, dtype=torch.long), "stress_indices": torch.zeros(B, P, dtype=torch.long)}
+    for i, it in enumerate(batch):
+        t, p = mel_len[i], ph_len[i]
+        out["mel_specs"][i, :t] = it["mel_spec"].T[:t]
+        out["pitches"][i, :t] = it["pitch"][:t]
+        out["energies"][i, :t] = it["energy"][:t]
+        out["stop_token_targets"][i, :t] = it["stop_token_targets"][:t]
+        out["phoneme_indices"][i, :p] = it["phoneme_indices"][:p]
+        out["phoneme_durations"][i, :p] = it["phoneme_durations"][:p]
+        out["stress_indices"][i, :p] = it["stress_indices"][:p]
+    out["mel_lengths"] = torch.tensor(mel_len, dtype=torch.long)
+    out["phoneme_lengths"] = torch.tensor(ph_len, dtype=torch.long)
+    return out
+
+
+def split_indices(n: int, val_split: float):
+    """90/10 split exactly as the reference draws it (training/trainer.py:284-296)."""
+    idx = list(range(n))
+    if val_split <= 0:
+        return idx, []
+    random.seed(42)
+    random.shuffle(idx)
+    k = int(n * (1 - val_split))
+    return idx[:k], idx[k:]
+
+
+class FixedBatchSampler:
+    def __init__(self, n: int, batch_size: int, shuffle: bool = True, rank: int = 0, world: int = 1, seed: int = 0):
+        self.n, self.bs, self.shuffle, self.rank, self.world, self.seed, self.epoch = n, batch_size, shuffle, rank, world, seed, 0
+
+    def batches(self) -> List[List[int]]:
+        order = list(range(self.n))
+        if self.shuffle:
+            random.Random(self.seed + self.epoch).shuffle(order)
+        bl = [order[i:i + self.bs] for i in range(0, self.n, self.bs)]
+        return bl[self.rank::self.world] if self.world > 1 else bl
+
+    def __len__(self) -> int:
+        return len(self.batches())
+
+    def __iter__(self) -> Iterator[List[int]]:
+        yield from self.batches()
+
+
+class FrameBudgetBatchSampler:
+    """batch_size * longest_sample_frames <= max_frames, min/max batch size, rank-sharded round-robin."""
+
+    def __init__(self, dataset: CachedFeatureDataset, max_frames: int, min_batch_size: int = 4, max_batch_size: int = 32,
+                 shuffle: bool = True, rank: int = 0, world: int = 1, seed: int = 0):
+        self.ds, self.max_frames, self.min_bs, self.max_bs = dataset, max_frames, min_batch_size, max_batch_size
+        self.shuffle, self.rank, self.world, self.seed, self.epoch = shuffle, rank, world, seed, 0
+
+    def batches(self) -> List[List[int]]:
+        order = sorted(range(len(self.ds)), key=lambda i: self.ds.samples[i]["audio_length"])
+        out: List[List[int]] = []
+        cur: List[int] = []
+        for i in order:
+            longest = self.ds.samples[i]["audio_length"]           # sorted ⇒ the new sample is the longest
+            if cur and ((len(cur) + 1) * longest > self.max_frames or len(cur) >= self.max_bs):
+                out.append(cur)
+                cur = []
+            cur.append(i)
+        if cur:
+            out.append(cur)
+        if self.shuffle:
+            random.Random(self.seed + self.epoch).shuffle(out)
+        return out[self.rank::self.world] if self.world > 1 else out
+
+    def __len__(self) -> int:
+        return len(self.batches())
+
+    def __iter__(self) -> Iterator[List[int]]:
+        yield from self.batches()

@@ -1,0 +1,154 @@
+"""Checkpoint files in the reference's layout, so its inference / vocoder tooling loads what this engine trains.
+
+Reference: save_checkpoint_with_scaler (training/trainer.py:1987-2036), build_model_metadata / find_latest_checkpoint /
+save_final_model (training/checkpoint_manager.py:178-241, 898-925).  File names `checkpoint_epoch_{N}.pth`,
+`kokoro_russian_final.pth`; state-dict keys are the reference's un-prefixed parameter names; `optimizer_state_dict`
+has torch.optim.AdamW's structure with the reference's 10 param groups (each tagged `group_type`).
+"""
+from __future__ import annotations
+
+import os
+from pathlib import Path
+from typing import Any, Dict, Optional
+
+import torch
+
+from kokoro_ruslan_amd import lib as kk
+from kokoro_ruslan_amd import spec
+
+
+def build_model_metadata(config, dims: spec.ModelDims) -> Dict[str, Any]:
+    g = lambda k, d: getattr(config, k, d)
+    return {
+        "schema_version": 2,
+        "architecture": {
+            "mel_dim": int(dims.mel), "hidden_dim": int(dims.hidden), "n_encoder_layers": int(dims.enc_layers),
+            "n_decoder_layers": int(dims.dec_layers), "n_heads": int(dims.heads), "encoder_ff_dim": int(dims.enc_ff),
+            "decoder_ff_dim": int(dims.dec_ff), "encoder_dropout": float(g("encoder_dropout", 0.1)),
+            "max_decoder_seq_len": int(dims.max_len), "use_variance_predictor": True,
+            "variance_filter_size": int(dims.var_filter), "variance_kernel_size": int(dims.var_kernel),
+            "variance_dropout": float(g("variance_dropout", 0.1)), "n_variance_bins": int(dims.var_bins),
+            "pitch_min": float(g("pitch_min", 0.0)), "pitch_max": float(g("pitch_max", 1.0)),
+            "energy_min": float(g("energy_min", 0.0)), "energy_max": float(g("energy_max", 1.0)),
+            "use_stochastic_depth": bool(g("use_stochastic_depth", True)),
+            "stochastic_depth_rate": float(g("stochastic_depth_rate", 0.1)), "qk_norm": True, "ffn_output_norm": True,
+            "vocab_size": int(dims.vocab),
+        },
+        "inference_controls": {
+            "max_len": int(g("inference_max_len", 1200)), "stop_threshold": float(g("inference_stop_threshold", 0.45)),
+            "min_len_ratio": float(g("inference_min_len_ratio", 0.7)), "min_len_floor": int(g("inference_min_len_floor", 12)),
+        },
+    }
+
+
+def optimizer_state_dict(engine) -> Dict[str, Any]:
+    """torch.optim.AdamW-shaped state: params numbered consecutively through the 10 groups."""
+    a, hp = engine.arena, engine.hp
+    st = engine.opt_stats()
+    steps = float(st["attempt"] - st["skipped"])
+    table = spec.group_lr_mult_wd(hp)
+    groups = [[] for _ in range(10)]
+    for n in a.param_names:
+        groups[spec.param_group_of(n)].append(n)
+    state, pgs, idx = {}, [], 0
+    for gi, names in enumerate(groups):
+        ids = []
+        for n in names:
+            if steps > 0:
+                state[idx] = {"step": torch.tensor(steps), "exp_avg": a.view(a.m, n).detach().cpu().clone(),
+                              "exp_avg_sq": a.view(a.v, n).detach().cpu().clone()}
+            ids.append(idx)
+            idx += 1
+        pgs.append({"lr": st["last_base_lr"] * table[gi][0] if steps > 0 else hp.learning_rate * table[gi][0],
+                    "betas": tuple(hp.adam_betas), "eps": hp.adam_eps, "weight_decay": table[gi][1], "amsgrad": False,
+                    "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": True,
+                    "group_type": spec.GROUP_TYPES[gi], "params": ids})
+    return {"state": state, "param_groups": pgs}
+
+
+def load_optimizer_state_dict(engine, osd: Dict[str, Any]) -> None:
+    a = engine.arena
+    groups = [[] for _ in range(10)]
+    for n in a.param_names:
+        groups[spec.param_group_of(n)].append(n)
+    order = [n for g in groups for n in g]
+    steps = 0.0
+    for idx, n in enumerate(order):
+        s = osd["state"].get(idx)
+        if s is None:
+            continue
+        a.view(a.m, n).copy_(s["exp_avg"])
+        a.view(a.v, n).copy_(s["exp_avg_sq"])
+        steps = max(steps, float(s["step"]))
+    engine.opt_state[kk.OS["ATTEMPT"]] = steps
+    engine.opt_state[kk.OS["SKIPPED"]] = 0.0
+
+
+def save_checkpoint(engine, config, epoch: int, loss: float, output_dir: str, val: Optional[Dict[str, float]] = None,
+                    best_val_loss: Optional[float] = None, best_val_epoch: int = -1) -> str:
+    val = val or {}
+    st = engine.opt_stats()
+    done = int(st["attempt"] - st["skipped"])
+    c = spec.lr_schedule_consts(engine.hp, engine.total_steps)
+    ckpt = {
+        "epoch": epoch, "global_step": done,
+        "model_state_dict": {k: v.detach().cpu().clone() for k, v in engine.state_dict().items()},
+        "optimizer_state_dict": optimizer_state_dict(engine),
+        "scheduler_state_dict": {"last_epoch": max(0, done - c["warmup_steps"]), "total_steps": c["onecycle_steps"]},
+        "current_optimizer_step": done, "optimizer_steps_completed": done,
+        "loss": loss, "train_loss": loss, "val_loss": val.get("total"), "val_mel_loss": val.get("mel"),
+        "val_stop_loss": val.get("stop"), "val_dur_loss": val.get("dur"),
+        "best_val_loss": best_val_loss if best_val_loss is not None else val.get("total"), "best_val_epoch": best_val_epoch,
+        "config": config, "model_metadata": build_model_metadata(config, engine.dims),
+        "scheduler_config": {"onecycle_steps": c["onecycle_steps"], "max_lr": c["max_lr"], "pct_start": c["pct_start"],
+                             "div_factor": c["div_factor"], "warmup_steps": c["warmup_steps"]},
+        "engine_opt_state": engine.opt_state.detach().cpu().clone(),       # new key: device-side step-driver state
+    }
+    if engine.arena.ema is not None:
+        ckpt["ema_model_state_dict"] = {k: v.detach().cpu().clone() for k, v in engine.state_dict(ema=True).items()}
+        ckpt["ema_updates"] = done
+    os.makedirs(output_dir, exist_ok=True)
+    path = os.path.join(output_dir, f"checkpoint_epoch_{epoch + 1}.pth")
+    torch.save(ckpt, path)
+    return path
+
+
+def find_latest_checkpoint(output_dir: str) -> Optional[str]:
+    files = list(Path(output_dir).glob("checkpoint_epoch_*.pth")) if Path(output_dir).exists() else []
+    if not files:
+        return None
+    files.sort(key=lambda p: int(p.stem.split("_")[-1]))
+    return str(files[-1])
+
+
+def load_checkpoint(engine, path: str) -> Dict[str, Any]:
+    """Strict resume: validates the architecture metadata like the reference (checkpoint_manager.py:309-358)."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    arch = (ckpt.get("model_metadata") or {}).get("architecture") or {}
+    required = ["mel_dim", "hidden_dim", "n_encoder_layers", "n_decoder_layers", "max_decoder_seq_len", "use_variance_predictor"]
+    missing = [k for k in required if k not in arch]
+    if missing:
+        raise RuntimeError(f"Checkpoint metadata is incomplete. Missing fields: {missing}.")
+    d = engine.dims
+    cur = {"mel_dim": d.mel, "hidden_dim": d.hidden, "n_encoder_layers": d.enc_layers, "n_decoder_layers": d.dec_layers,
+           "max_decoder_seq_len": d.max_len, "use_variance_predictor": True, "vocab_size": d.vocab}
+    bad = {k: (arch[k], v) for k, v in cur.items() if k in arch and arch[k] != v}
+    if bad:
+        raise RuntimeError(f"Checkpoint architecture mismatch (checkpoint, current): {bad}")
+    engine.load_state_dict(ckpt["model_state_dict"], strict=True)
+    if "ema_model_state_dict" in ckpt and engine.arena.ema is not None:
+        for n, t in ckpt["ema_model_state_dict"].items():
+            engine.arena.E[n].copy_(t)
+    if "optimizer_state_dict" in ckpt:
+        load_optimizer_state_dict(engine, ckpt["optimizer_state_dict"])
+    if "engine_opt_state" in ckpt:
+        engine.opt_state.copy_(ckpt["engine_opt_state"])
+    return ckpt
+
+
+def save_final_model(engine, config, output_dir: str) -> str:
+    os.makedirs(output_dir, exist_ok=True)
+    path = os.path.join(output_dir, "kokoro_russian_final.pth")
+    torch.save({"model_state_dict": {k: v.detach().cpu().clone() for k, v in engine.state_dict().items()},
+                "config": config, "model_metadata": build_model_metadata(config, engine.dims)}, path)
+    return path

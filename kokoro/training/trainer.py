@@ -1,0 +1,162 @@
+"""Host training loop around the MI355X engine, with the reference trainer's control flow for the hot path:
+epoch loop → micro-batches with exact accumulation divisor (reference training/trainer.py:3344-3362) → optimizer
+boundary (all decisions on the device, see kokoro_ruslan_amd/csrc/kk_optim.hip) → validation on the EMA weights
+(trainer.py:1771-1985, forward + losses only) → checkpoints in the reference layout (kokoro.training.checkpoint).
+
+Input data are the reference's cached features (kokoro.data.cached); the audio front-end / MFA / phonemizer stay on
+the reference.  TensorBoard, profilers and MPS memory management of the reference trainer are out of scope.
+"""
+from __future__ import annotations
+
+import logging
+import math
+import os
+from typing import Dict, Optional
+
+import torch
+
+from kokoro.data.cached import (CachedFeatureDataset, FixedBatchSampler, FrameBudgetBatchSampler, collate_fn, split_indices)
+from kokoro.training import checkpoint as ckpt
+from kokoro_ruslan_amd import dp, lib as kk
+from kokoro_ruslan_amd.spec import ModelDims, StepHyper
+
+logger = logging.getLogger(__name__)
+
+
+def recommended_ema_decay(steps_per_epoch: int, half_life_epochs: float) -> float:
+    """exp(-ln2 / (steps_per_epoch * k)) clipped to [0.9, 0.9999] (reference utils/ema.py:6-27)."""
+    hl = steps_per_epoch * half_life_epochs
+    if steps_per_epoch <= 0 or hl <= 0:
+        return 0.9999
+    return max(0.9, min(math.exp(-math.log(2) / hl), 0.9999))
+
+
+def effective_accumulation_divisor(G: int, accumulated_step: int, batch_idx: int, num_batches: int) -> int:
+    """trainer.py:3344-3362."""
+    return max(1, min(max(1, int(G)), max(0, int(accumulated_step)) + max(1, int(num_batches) - int(batch_idx))))
+
+
+def cap_batch(batch: Dict[str, torch.Tensor], max_mel: int = 2000, max_ph: int = 2000) -> Dict[str, torch.Tensor]:
+    """_cap_batch_sequence_dimensions (trainer.py:3364-3411)."""
+    b = dict(batch)
+    if b["mel_specs"].size(1) > max_mel:
+        for k in ("mel_specs", "stop_token_targets", "pitches", "energies"):
+            b[k] = b[k][:, :max_mel].contiguous()
+        b["mel_lengths"] = b["mel_lengths"].clamp(max=max_mel)
+    if b["phoneme_indices"].size(1) > max_ph:
+        for k in ("phoneme_indices", "phoneme_durations", "stress_indices"):
+            b[k] = b[k][:, :max_ph].contiguous()
+        b["phoneme_lengths"] = b["phoneme_lengths"].clamp(max=max_ph)
+    return b
+
+
+class KokoroTrainer:
+    def __init__(self, config, vocab_size: int = 59):
+        from kokoro_ruslan_amd.engine import KokoroEngine
+        self.config = config
+        self.rank, self.world, self.local = dp.init()
+        if torch.cuda.is_available():
+            torch.cuda.set_device(self.local)
+        n_all = len(CachedFeatureDataset(config.feature_cache_dir, memory_cache=False))
+        tr_idx, va_idx = split_indices(n_all, config.validation_split)
+        self.dataset = CachedFeatureDataset(config.feature_cache_dir, tr_idx, config.max_seq_length, config.use_memory_cache)
+        self.val_dataset = CachedFeatureDataset(config.feature_cache_dir, va_idx, config.max_seq_length, config.use_memory_cache) if va_idx else None
+        if config.use_dynamic_batching:
+            self.sampler = FrameBudgetBatchSampler(self.dataset, config.max_frames_per_batch, config.min_batch_size,
+                                                   config.max_batch_size, True, self.rank, self.world)
+        else:
+            self.sampler = FixedBatchSampler(len(self.dataset), config.batch_size, True, self.rank, self.world)
+        G = max(1, config.gradient_accumulation_steps)
+        steps_per_epoch = max(1, -(-len(self.sampler) // G))
+        hp = StepHyper.from_config(config)
+        if config.ema_decay is None:
+            hp.ema_decay = recommended_ema_decay(steps_per_epoch, config.ema_half_life_epochs)   # trainer.py:808-827
+        dims = ModelDims(vocab=vocab_size, mel=config.n_mels, hidden=config.hidden_dim, heads=config.n_heads,
+                         enc_layers=config.n_encoder_layers, dec_layers=config.n_decoder_layers, enc_ff=config.encoder_ff_dim,
+                         dec_ff=config.decoder_ff_dim, var_filter=config.variance_filter_size,
+                         var_kernel=config.variance_kernel_size, var_bins=config.n_variance_bins,
+                         max_len=config.max_decoder_seq_len)
+        math_mode = "bf16" if (config.use_mixed_precision and config.mixed_precision_dtype == "bfloat16") else "f32"
+        self.engine = KokoroEngine(dims, hp, math_mode=math_mode, total_steps=config.num_epochs * steps_per_epoch, seed=0)
+        self.sync = dp.GradSync(self.world)
+        self.engine.dp_loss_scale = self.sync.loss_scale
+        self.start_epoch, self.best_val, self.best_epoch = 0, float("inf"), -1
+        logger.info("engine ready: %d params, %s math, %d train / %d val utterances, %d batches/epoch, world %d",
+                    sum(math.prod(s) for s in self.engine.arena.shapes.values()), math_mode, len(self.dataset),
+                    len(self.val_dataset) if self.val_dataset else 0, len(self.sampler), self.world)
+
+    # ------------------------------------------------------------------
+    def _to_device(self, batch):
+        return {k: v.to(self.engine.device, non_blocking=True) for k, v in batch.items()}
+
+    def train_epoch(self, epoch: int) -> float:
+        cfg, G = self.config, max(1, self.config.gradient_accumulation_steps)
+        self.sampler.epoch = epoch
+        batches = self.sampler.batches()
+        acc, losses, n = 0, torch.zeros(6, device=self.engine.device), 0
+        for bi, idxs in enumerate(batches):
+            batch = cap_batch(self._to_device(collate_fn([self.dataset[i] for i in idxs])))
+            div = effective_accumulation_divisor(G, acc, bi, len(batches))
+            boundary = (acc + 1 >= G) or (bi == len(batches) - 1)
+            self.engine.micro_in_cycle = acc
+            losses += self.engine.train_step(batch, div, boundary, self.sync if self.world > 1 else None)
+            acc = 0 if boundary else acc + 1
+            n += 1
+        avg = (losses / max(n, 1)).cpu().tolist()          # the only host sync of the epoch
+        if n == 0:
+            logger.warning("epoch %d: no training batches", epoch + 1)
+        logger.info("epoch %d train: total %.4f mel %.4f dur %.4f stop %.4f pitch %.4f energy %.4f", epoch + 1, *avg)
+        return avg[0]
+
+    @torch.no_grad()
+    def validate_epoch(self) -> Optional[Dict[str, float]]:
+        if not self.val_dataset or len(self.val_dataset) == 0:
+            return None
+        e = self.engine
+        saved_math, saved_p = e.math, None
+        e.math = kk.KK_MATH_F32                              # validation runs without autocast (trainer.py:1821-1834)
+        if e.arena.ema is not None:
+            saved_p = e.arena.p.clone()
+            e.arena.p.copy_(e.arena.ema)                     # evaluate the EMA replica
+        tot, n = torch.zeros(6, device=e.device), 0
+        bs = max(1, self.config.batch_size)
+        for i in range(0, len(self.val_dataset), bs):
+            batch = cap_batch(self._to_device(collate_fn([self.val_dataset[j] for j in range(i, min(i + bs, len(self.val_dataset)))])))
+            tot += e.forward_backward(batch, backward=False)["losses"]
+            n += 1
+        if saved_p is not None:
+            e.arena.p.copy_(saved_p)
+        e.math = saved_math
+        v = (tot / n).cpu().tolist()
+        return dict(zip(("total", "mel", "dur", "stop", "pitch", "energy"), v))
+
+    def train(self) -> None:
+        cfg = self.config
+        os.makedirs(cfg.output_dir, exist_ok=True)
+        resume = cfg.resume_checkpoint
+        path = ckpt.find_latest_checkpoint(cfg.output_dir) if resume == "auto" else resume
+        if path and os.path.exists(path):
+            c = ckpt.load_checkpoint(self.engine, path)
+            self.start_epoch = int(c["epoch"]) + 1
+            self.best_val = c.get("best_val_loss") or float("inf")
+            self.best_epoch = c.get("best_val_epoch", -1)
+            logger.info("resumed from %s at epoch %d", path, self.start_epoch)
+        patience = 0
+        for epoch in range(self.start_epoch, cfg.num_epochs):
+            loss = self.train_epoch(epoch)
+            val = self.validate_epoch() if (epoch + 1) % max(1, cfg.validation_interval) == 0 else None
+            improved = False
+            if val is not None:
+                logger.info("epoch %d val: total %.4f mel %.4f dur %.4f stop %.4f", epoch + 1, val["total"], val["mel"], val["dur"], val["stop"])
+                if val["total"] < self.best_val - cfg.early_stopping_min_delta:
+                    self.best_val, self.best_epoch, improved, patience = val["total"], epoch, True, 0
+                else:
+                    patience += 1
+            if self.rank == 0 and (improved or (epoch + 1) % max(1, cfg.save_every) == 0 or epoch + 1 == cfg.num_epochs):
+                p = ckpt.save_checkpoint(self.engine, cfg, epoch, loss, cfg.output_dir, val, self.best_val, self.best_epoch)
+                logger.info("checkpoint saved: %s", p)
+            if val is not None and patience >= cfg.early_stopping_patience:
+                logger.info("early stopping at epoch %d", epoch + 1)
+                break
+        if self.rank == 0:
+            logger.info("final model saved: %s", ckpt.save_final_model(self.engine, cfg, cfg.output_dir))

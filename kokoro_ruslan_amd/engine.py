@@ -503,7 +503,7 @@ class KokoroEngine:
                 float(hp.dec_ffn_max_weight_norm))
 
     def train_step(self, batch: Dict[str, torch.Tensor], accumulation_divisor: Optional[int] = None,
-                   boundary: Optional[bool] = None) -> torch.Tensor:
+                   boundary: Optional[bool] = None, grad_sync=None) -> torch.Tensor:
         """One micro-batch of training in the reference's order (trainer.py:2257-2477): zero grads at the start of an
         accumulation cycle, forward+backward with loss_scale = adaptive/divisor, optimizer boundary when the cycle
         completes.  Returns the device tensor of 6 losses (no host sync)."""
@@ -514,6 +514,8 @@ class KokoroEngine:
         out = self.forward_backward(batch, loss_scale=self.dp_loss_scale / div, adaptive=True)
         self.micro_in_cycle += 1
         if boundary if boundary is not None else self.micro_in_cycle >= G:
+            if grad_sync is not None:
+                grad_sync(self.arena.g)              # data parallel: SUM over ranks (dp.GradSync)
             self.optimizer_step(batch["mel_specs"].shape[1])
             self.micro_in_cycle = 0
         return out["losses"]

@@ -331,6 +331,40 @@ def section_tables():
         np.save(os.path.join(HERE, f"lr_seq_{total_steps}_{warm}.npy"), np.array(seq))
 
 
+def section_surface():
+    """Dump the reference's Python surface for the drop-in tests: TrainingConfig fields and kokoro-train flags."""
+    print("== drop-in surface")
+    import argparse
+    import dataclasses
+    import kokoro.cli.cli as rcli
+    fields = [{"name": f.name, "default": repr(f.default)} for f in dataclasses.fields(TrainingConfig) if f.name != "device"]
+    cap = {}
+    orig = argparse.ArgumentParser.parse_args
+
+    def fake(self, args=None, namespace=None):
+        cap["p"] = self
+        return orig(self, [])
+    argparse.ArgumentParser.parse_args = fake
+    try:
+        ns = rcli.parse_arguments()
+    finally:
+        argparse.ArgumentParser.parse_args = orig
+    flags = [{"flags": sorted(a.option_strings), "dest": a.dest, "default": repr(a.default), "action": type(a).__name__,
+              "type": getattr(a.type, "__name__", None)} for a in cap["p"]._actions if a.dest != "help"]
+    cfg = rcli.create_config_from_args(ns)
+    mapped = {f.name: repr(getattr(cfg, f.name)) for f in dataclasses.fields(TrainingConfig) if f.name != "device"}
+    with open(os.path.join(HERE, "surface.json"), "w") as f:
+        json.dump({"config_fields": fields, "cli_flags": flags, "config_from_default_args": mapped}, f, indent=0)
+    print(f"  wrote surface.json ({len(fields)} config fields, {len(flags)} flags)")
+    # the reference model strictly loads a state dict built from this repo's tables
+    d = O.ModelDims()
+    m = ref_model(d)
+    sd = dict(O.init_params(d, 1))
+    sd.update(O.make_buffers(d))
+    m.load_state_dict(sd, strict=True)
+    print("  [ok ] reference KokoroModel.load_state_dict(strict=True) accepts our 311-entry state dict")
+
+
 def section_lengths():
     print("== length regulator")
     cases = []
@@ -387,6 +421,7 @@ def section_loss_known_answers():
 if __name__ == "__main__":
     tiny = O.ModelDims(vocab=59, mel=20, hidden=128, heads=2, enc_layers=2, dec_layers=2, enc_ff=96,
                        dec_ff=96, var_filter=32, var_kernel=3, var_bins=16, max_len=700)
+    section_surface()
     section_lengths()
     section_loss_known_answers()
     section_model("tiny_full", tiny, B=2, T=40, Pn=6, seed=11, ragged=False, save_step=False)
