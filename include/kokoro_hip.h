@@ -41,6 +41,8 @@ const char *kk_last_error(void);
 int kk_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, const float *A, int64_t lda,
             const float *B, int64_t ldb, float beta, float *C, int64_t ldc, const float *bias,
             const float *residual, int64_t ldr, int64_t res_mod, int split_k, int math, void *stream);
+/* tuning hook for benchmarks: 128x128-tile threshold (tile count) and XCD-aware tile order on/off */
+int kk_gemm_tune(int tm_threshold, int xcd_swizzle);
 /* out[n] += sum_m X[m,n]  (bias gradients). */
 int kk_colsum_acc(const float *X, int64_t ldx, int64_t M, int64_t N, float *out, void *stream);
 

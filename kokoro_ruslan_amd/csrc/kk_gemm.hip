@@ -36,6 +36,7 @@ struct GemmArgs {
     float *C;
     int64_t lda, ldb, ldc, ldr, res_mod;
     int k_per_split, atomic;
+    int tiles_m, tiles_n, xcd_swizzle;
 };
 
 __device__ __forceinline__ float f4c(const float4 &v, int c) { return reinterpret_cast<const float *>(&v)[c]; }
@@ -125,8 +126,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     __shared__ __attribute__((aligned(16))) elem smem[4 * TILE];   // A0 A1 B0 B1
     elem *As = smem, *Bs = smem + 2 * TILE;
 
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * a.k_per_split;
+    // XCD-aware tile order: the dispatcher places workgroup i on XCD i % 8 (each XCD has a private 4 MiB L2).  Remap
+    // so every XCD sweeps a CONTIGUOUS run of tiles (n fastest): the A row panel and the whole weight matrix then
+    // stay in that XCD's L2 instead of being fetched by all eight.  Bijective for any tile count.
+    int tid_lin = blockIdx.x;
+    if (a.xcd_swizzle) {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = tid_lin & 7, in = tid_lin >> 3;
+        tid_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + in;
+    }
+    const int m0 = (tid_lin / a.tiles_n) * BM, n0 = (tid_lin % a.tiles_n) * BN;
+    const int kbeg = blockIdx.y * a.k_per_split;
     const int kend = min(a.K, kbeg + a.k_per_split);
     const int nk = (kend - kbeg + BK - 1) / BK;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -196,7 +205,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     }
     if (nk <= 0) return;
 
-    const bool lead = (blockIdx.z == 0);
+    const bool lead = (blockIdx.y == 0);
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -252,7 +261,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ X
     if (rl == 0 && c < N) atomicAdd(&out[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+int g_tm_threshold = 512;   // use 128x128 tiles when they number at least this many
+int g_xcd_swizzle = 1;
+
 }  // namespace
+
+// Test/tuning hook (not part of the product path): tile-selection threshold and XCD swizzle on/off.
+extern "C" int kk_gemm_tune(int tm_threshold, int xcd_swizzle) {
+    g_tm_threshold = tm_threshold;
+    g_xcd_swizzle = xcd_swizzle;
+    return 0;
+}
 
 extern "C" int kk_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, const float *A, int64_t lda,
                        const float *B, int64_t ldb, float beta, float *C, int64_t ldc, const float *bias,
@@ -267,7 +286,7 @@ extern "C" int kk_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, float al
     if (tb) KK_REQUIRE(N % 4 == 0, "kk_gemm: N=%ld must be a multiple of 4 when B is stored [K,N]", (long)N);
     KK_REQUIRE(math == KK_MATH_F32 || math == KK_MATH_BF16, "kk_gemm: bad math mode %d", math);
     hipStream_t s = (hipStream_t)stream;
-    const int TM = (int64_t)kk_cdiv(M, 128) * kk_cdiv(N, 128) >= 512 ? 128 : 64;
+    const int TM = (int64_t)kk_cdiv(M, 128) * kk_cdiv(N, 128) >= g_tm_threshold ? 128 : 64;
     const int BK = (math == KK_MATH_BF16 ? 32 : 16) * (TM == 128 ? 1 : 2);
     const int tiles = kk_cdiv(M, TM) * kk_cdiv(N, TM);
     const int ktiles = kk_cdiv(K, BK);
@@ -295,7 +314,10 @@ extern "C" int kk_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, float al
         hipError_t e = hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), s);
         if (e != hipSuccess) return kk_fail((int)e, "kk_gemm: memset: %s", hipGetErrorString(e));
     }
-    dim3 grid(kk_cdiv(N, TM), kk_cdiv(M, TM), splits);
+    a.tiles_m = kk_cdiv(M, TM);
+    a.tiles_n = kk_cdiv(N, TM);
+    a.xcd_swizzle = g_xcd_swizzle;
+    dim3 grid(a.tiles_m * a.tiles_n, splits);
     if (TM == 128) return math == KK_MATH_BF16 ? launch<true, 128>(ta, tb, a, grid, s) : launch<false, 128>(ta, tb, a, grid, s);
     return math == KK_MATH_BF16 ? launch<true, 64>(ta, tb, a, grid, s) : launch<false, 64>(ta, tb, a, grid, s);
 }

@@ -44,6 +44,7 @@ _P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 # name -> argtypes, in header order (tests/test_abi.py cross-checks arity against include/kokoro_hip.h)
 SIGNATURES: Dict[str, List[Any]] = {
     "kk_gemm": [_I, _I, _L, _L, _L, _F, _P, _L, _P, _L, _F, _P, _L, _P, _P, _L, _L, _I, _I, _P],
+    "kk_gemm_tune": [_I, _I],
     "kk_colsum_acc": [_P, _L, _L, _L, _P, _P],
     "kk_attn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _F, _I, _P],
     "kk_attn_delta": [_P, _P, _P, _I, _I, _I, _L, _L, _P],
@@ -128,6 +129,10 @@ def _conv(a):
     if isinstance(a, C.Structure):
         return C.byref(a)
     return a
+
+
+def gemm_tune(tm_threshold: int = 512, xcd_swizzle: int = 1) -> None:
+    load().kk_gemm_tune(tm_threshold, xcd_swizzle)
 
 
 def call(name: str, *args) -> None:
