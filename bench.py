@@ -48,7 +48,7 @@ def kernel_table(records, math_bf16: bool):
             byts = 4.0 * (M * K + N * K + M * N)
         elif name in ("kk_attn_fwd", "kk_attn_bwd_dq", "kk_attn_bwd_dkv"):
             B, h, Sq, Sk = (int(x) for x in sc[:4])
-            causal = int(sc[-3])
+            causal = int(sc[-5])           # (..., causal, scale, site, p_drop, math)
             mm = {"kk_attn_fwd": 2, "kk_attn_bwd_dq": 3, "kk_attn_bwd_dkv": 4}[name]   # matmuls of Sq x Sk x 64
             flops = mm * 2.0 * B * h * Sq * Sk * 64 * (0.5 if causal else 1.0)
             byts = 4.0 * B * h * 64 * (2 * Sq + 2 * Sk)
@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--phonemes", type=int, default=64)
     ap.add_argument("--math", choices=["bf16", "f32"], default="bf16")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-dropout", action="store_true", help="parity configuration (p = 0 everywhere)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-table", default="")
     args = ap.parse_args()
@@ -106,6 +107,7 @@ def main():
     B, T, P = args.batch, args.frames, args.phonemes
     hp = StepHyper(gradient_accumulation_steps=1)
     eng = KokoroEngine(ModelDims(), hp, math_mode=args.math, total_steps=20000, seed=0)   # same seed ⇒ identical replicas
+    eng.train_dropout = not args.no_dropout          # reference-faithful: dropout, stochastic depth, SpecAugment on
     sync = dp.GradSync(world)
     eng.dp_loss_scale = sync.loss_scale
     batch = {k: v.cuda() for k, v in synthetic_batch(B, T, P, seed=1234 + rank).items()}
@@ -167,7 +169,9 @@ def main():
            "config": {"workload": f"kokoro acoustic-model train step, {B}x{T} mel frames x {P} phonemes per GPU "
                                   f"(BASELINE configs[1]), 49.4M params, fwd+loss+bwd+clip+AdamW+EMA every step",
                       "global_batch": world * B, "frames": T, "phonemes": P, "parallelism": f"dp{world}",
-                      "grad_accumulation": 1, "dropout": "off (p=0 parity configuration)",
+                      "grad_accumulation": 1,
+                      "dropout": ("off (p=0 parity configuration)" if args.no_dropout else
+                                  "on: enc 0.15 / dec 0.20 / dec-input 0.15 / variance 0.10, stochastic depth 0.1, SpecAugment (config.py defaults)"),
                       "hipgraph": not args.no_graph},
            "final_losses": [round(x, 5) for x in losses], "optimizer_steps": stats["attempt"], "skipped": stats["skipped"],
            "roofline": roof}

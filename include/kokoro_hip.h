@@ -49,21 +49,25 @@ int kk_colsum_acc(const float *X, int64_t ldx, int64_t M, int64_t N, float *out,
 /* ---- attention (F.scaled_dot_product_attention, transformers.py:393-398; masks :299-316) ----
  * Token-major operands: element (b, s, head, d) of X lives at X[(b*S + s)*ldx + head*64 + d]; head_dim is 64.
  * key_mask: optional uint8 [B,Sk], non-zero = key masked (−inf); causal: key > query masked.
- * LSE [B,heads,Sq] = log-sum-exp of the scaled scores (saved for backward). */
+ * LSE [B,heads,Sq] = log-sum-exp of the scaled scores (saved for backward).
+ * Dropout on the probabilities (p_drop > 0): the keep mask is a pure function of (*seed, site, b, head, q, key), so
+ * the two backward kernels regenerate it — pass them the same seed pointer, site and p_drop. */
 int kk_attn_fwd(const float *Q, const float *K, const float *V, float *O, float *LSE, int B, int heads,
                 int Sq, int Sk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
-                const uint8_t *key_mask, int causal, float scale, int math, void *stream);
+                const uint8_t *key_mask, int causal, float scale, const uint32_t *seed, uint32_t site,
+                float p_drop, int math, void *stream);
 /* Delta[b,head,q] = sum_d dO·O (first step of the backward). */
 int kk_attn_delta(const float *O, const float *dO, float *Delta, int B, int heads, int Sq, int64_t ldo,
                   int64_t lddo, void *stream);
 int kk_attn_bwd_dq(const float *Q, const float *K, const float *V, const float *dO, const float *LSE,
                    const float *Delta, float *dQ, int B, int heads, int Sq, int Sk, int64_t ldq, int64_t ldk,
                    int64_t ldv, int64_t lddo, int64_t lddq, const uint8_t *key_mask, int causal, float scale,
-                   int math, void *stream);
+                   const uint32_t *seed, uint32_t site, float p_drop, int math, void *stream);
 int kk_attn_bwd_dkv(const float *Q, const float *K, const float *V, const float *dO, const float *LSE,
                     const float *Delta, float *dK, float *dV, int B, int heads, int Sq, int Sk, int64_t ldq,
                     int64_t ldk, int64_t ldv, int64_t lddo, int64_t lddk, int64_t lddv,
-                    const uint8_t *key_mask, int causal, float scale, int math, void *stream);
+                    const uint8_t *key_mask, int causal, float scale, const uint32_t *seed, uint32_t site,
+                    float p_drop, int math, void *stream);
 
 /* ---- norms ----
  * LayerNorm (nn.LayerNorm eps 1e-5; transformers.py:461-462,518-520,612; model.py:122). */
@@ -88,14 +92,18 @@ int kk_headnorm_rope_bwd(const float *dy, int64_t lddy, const float *x, int64_t 
                          const float *cos_t, const float *sin_t, void *stream);
 
 /* ---- GLU feed-forward gate (transformers.py:107-108; exact-erf GELU): g = gelu(h[:, :F]) * h[:, F:] ---- */
-int kk_glu_fwd(const float *h, float *g, int64_t rows, int F, void *stream);
-int kk_glu_bwd(const float *dg, const float *h, float *dh, int64_t rows, int F, void *stream);
+int kk_glu_fwd(const float *h, float *g, int64_t rows, int F, const uint32_t *seed, uint32_t site, float p,
+               void *stream);
+int kk_glu_bwd(const float *dg, const float *h, float *dh, int64_t rows, int F, const uint32_t *seed, uint32_t site,
+               float p, void *stream);
 
 /* ---- embeddings + sinusoid PE (model.py:375-378; positional_encoding.py:66-74) ---- */
 int kk_embed_fwd(const int64_t *ids, const int64_t *stress, const float *emb, const float *stress_emb,
-                 const float *pe, float *out, int B, int P, int H, float scale, void *stream);
+                 const float *pe, float *out, int B, int P, int H, float scale, const uint32_t *seed,
+                 uint32_t site, float p, void *stream);
 int kk_embed_bwd(const int64_t *ids, const int64_t *stress, const float *dout, float *demb,
-                 float *dstress_emb, int B, int P, int H, float scale, void *stream);
+                 float *dstress_emb, int B, int P, int H, float scale, const uint32_t *seed, uint32_t site, float p,
+                 void *stream);
 
 /* ---- length regulator (utils/lengths.py:16-96): integer index expansion + payload gather ----
  * idx[b,f] = #{j : cumsum(max(dur_b,0))[j] <= f} for f < min(sum dur_b, L), else -1; lens[b] = min(sum, L);
@@ -114,10 +122,11 @@ int kk_im2col3_bwd(const float *dcol, float *dx, int B, int L, int C, int chunk,
 /* GroupNorm(1,C) over (C x chunk frames) per sample per chunk + ReLU; chunks with < 2 frames yield zeros.
  * stats [B*nchunks, 2] = (mean, rstd). */
 int kk_groupnorm_relu_fwd(const float *x, const float *gamma, const float *beta, float *y, float *stats,
-                          double *scratch, int B, int L, int C, int chunk, void *stream);
+                          double *scratch, int B, int L, int C, int chunk, const uint32_t *seed, uint32_t site,
+                          float p, void *stream);
 int kk_groupnorm_relu_bwd(const float *dy, const float *x, const float *y, const float *gamma,
                           const float *stats, float *dx, float *dgamma, float *dbeta, double *scratch, int B,
-                          int L, int C, int chunk, void *stream);
+                          int L, int C, int chunk, float p, void *stream);
 /* out[r] = mask[r] ? 0 : dot(x[r,:], w) + b  (Linear(C->1) + masked_fill; also the stop head, model.py:562). */
 int kk_rowdot_fwd(const float *x, const float *w, const float *b, const uint8_t *mask, float *out,
                   int64_t rows, int C, int L, int chunk, void *stream);
@@ -135,6 +144,18 @@ int kk_bucket_embed_add_bwd(const float *dout, const int32_t *pidx, const int32_
 int kk_ids_eq_zero(const int64_t *ids, uint8_t *mask, int64_t n, void *stream);
 /* decoder input shift-right (model.py:519): out[b,0,:]=0, out[b,t,:]=mel[b,t-1,:]. */
 int kk_shift_right(const float *mel, float *out, int B, int T, int M, void *stream);
+
+/* ---- dropout / DropPath / SpecAugment (p > 0 training paths; masks from an in-kernel counter RNG) ----
+ * out = (res ? res[row % res_mod (0: row)] : 0) + x * m1 * m2 * droppath(sample(row)), m_i in {0, 1/(1-p_i)}
+ * (transformers.py:16-40,482-487,569-581; the FFN has two dropouts in series, :111).  *seed is read on the device. */
+int kk_dropout_fwd(const float *x, const float *res, int64_t res_mod, float *out, int64_t rows, int H, int S,
+                   const uint32_t *seed, uint32_t site1, float p1, uint32_t site2, float p2, uint32_t site_dp,
+                   float dp_rate, void *stream);
+int kk_dropout_bwd(const float *dy, float *dx, int64_t rows, int H, int S, const uint32_t *seed, uint32_t site1,
+                   float p1, uint32_t site2, float p2, uint32_t site_dp, float dp_rate, void *stream);
+/* SpecAugment on the cross-attention memory, in place (trainer.py:1577-1604); call again on the memory gradient. */
+int kk_specaug(float *x, int B, int T, int H, const uint32_t *seed, uint32_t site, int time_mask_max,
+               int feat_mask_max, int n_time, int n_feat, void *stream);
 
 /* ---- losses (training/losses.py:9-216) ----
  * acc: 10 doubles (5 sums, 5 counts) zeroed by the call.  losses: 6 floats (total, mel, dur, stop, pitch, energy).

@@ -33,6 +33,29 @@ struct AttnArgs {
     int B, heads, Sq, Sk, causal;
     int64_t ldq, ldk, ldv, ldo, lddo, ldout, ldout2;
     float scale;
+    // dropout on the attention probabilities (SDPA dropout_p, transformers.py:396): mask = f(seed, site, element)
+    const uint32_t *seed;
+    uint32_t site;
+    float p_drop;
+};
+
+// mask multiplier of probability element (b, head, q, key): 0 or 1/(1-p); identical in forward and both backward kernels
+struct ProbDrop {
+    uint32_t seed, thr, site;
+    float inv_keep;
+    uint64_t base;   // (b*heads + head) * Sq
+    int Sk;
+    __device__ __forceinline__ void init(const AttnArgs &a, int b, int hh) {
+        thr = a.seed ? kk_drop_threshold(a.p_drop) : 0u;
+        seed = thr ? *a.seed : 0u;
+        site = a.site;
+        inv_keep = thr ? 1.f / (1.f - a.p_drop) : 1.f;
+        base = ((uint64_t)b * a.heads + hh) * (uint64_t)a.Sq;
+        Sk = a.Sk;
+    }
+    __device__ __forceinline__ float mul(int q, int key) const {
+        return thr == 0u ? 1.f : kk_drop_mul(seed, site, (base + (uint64_t)q) * (uint64_t)Sk + (uint64_t)key, thr, inv_keep);
+    }
 };
 
 __device__ __forceinline__ float f4g(const float4 &v, int c) { return reinterpret_cast<const float *>(&v)[c]; }
@@ -189,6 +212,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     f32x16 o[2];
     zero_acc(o[0]); zero_acc(o[1]);
     float m = -1e30f, l = 0.f;
+    ProbDrop pd;
+    pd.init(a, b, hh);
     const uint8_t *km = a.key_mask ? a.key_mask + (int64_t)b * a.Sk : nullptr;
     int kend = a.Sk;
     if (a.causal && qblk + 128 < kend) kend = qblk + 128;
@@ -227,6 +252,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
             m = mn;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+            if (pd.thr) {                                  // the row sum l stays un-dropped: softmax first, dropout after
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p[r] *= pd.mul(q, kb + frag_row(r, half));
+            }
             mma_T_x_p<BF16>(o, Vx, sub * 32, p, l31, half);
         }
     }
@@ -256,6 +285,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     const float dlt = qvalid ? a.Delta[((int64_t)b * a.heads + hh) * a.Sq + q] : 0.f;
     f32x16 dq[2];
     zero_acc(dq[0]); zero_acc(dq[1]);
+    ProbDrop pd;
+    pd.init(a, b, hh);
     const uint8_t *km = a.key_mask ? a.key_mask + (int64_t)b * a.Sk : nullptr;
     int kend = a.Sk;
     if (a.causal && qblk + 128 < kend) kend = qblk + 128;
@@ -282,7 +313,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
                 const int key = kb + frag_row(r, half);
                 const bool ok = key < a.Sk && !(a.causal && key > q) && !(km && km[key]);
                 const float pv = ok ? expf(s[r] * a.scale - lse) : 0.f;
-                ds[r] = pv * (dp[r] - dlt) * a.scale;
+                ds[r] = pv * (dp[r] * pd.mul(q, key) - dlt) * a.scale;
             }
             mma_T_x_p<BF16>(dq, BF16 ? Kt : Ks, sub * 32, ds, l31, half);
         }
@@ -310,6 +341,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     load_rowfrag<BF16>(vf, kvalid ? a.V + ((int64_t)b * a.Sk + key) * a.ldv + hh * 64 : nullptr, half);
     f32x16 dk[2], dv[2];
     zero_acc(dk[0]); zero_acc(dk[1]); zero_acc(dv[0]); zero_acc(dv[1]);
+    ProbDrop pd;
+    pd.init(a, b, hh);
     const int qstart = a.causal ? (kblk / 64) * 64 : 0;
     for (int q0 = qstart; q0 < a.Sq; q0 += 64) {
         __syncthreads();
@@ -341,8 +374,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
                 const int ql = sub * 32 + frag_row(r, half);
                 const int qq = q0 + ql;
                 const bool ok = kalive && qq < a.Sq && !(a.causal && key > qq);
-                p[r] = ok ? expf(s[r] * a.scale - lse_s[ql]) : 0.f;
-                ds[r] = p[r] * (dp[r] - dlt_s[ql]) * a.scale;
+                const float pv = ok ? expf(s[r] * a.scale - lse_s[ql]) : 0.f;
+                const float dm = pd.mul(qq, key);
+                p[r] = pv * dm;                                       // dropped probabilities feed dV
+                ds[r] = pv * (dp[r] * dm - dlt_s[ql]) * a.scale;
             }
             mma_T_x_p<BF16>(dv, dOt, sub * 32, p, l31, half);
             mma_T_x_p<BF16>(dk, Qt, sub * 32, ds, l31, half);
@@ -382,13 +417,16 @@ int check_common(const char *name, int B, int heads, int Sq, int Sk, int math, c
 
 extern "C" int kk_attn_fwd(const float *Q, const float *K, const float *V, float *O, float *LSE, int B, int heads,
                            int Sq, int Sk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
-                           const uint8_t *key_mask, int causal, float scale, int math, void *stream) {
+                           const uint8_t *key_mask, int causal, float scale, const uint32_t *seed, uint32_t site,
+                           float p_drop, int math, void *stream) {
+    KK_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "kk_attn_fwd: dropout probability must be in [0,1)");
     const int64_t lds[4] = {ldq, ldk, ldv, ldo};
     if (int rc = check_common("kk_attn_fwd", B, heads, Sq, Sk, math, lds, 4)) return rc;
     AttnArgs a = {};
     a.Q = Q; a.K = K; a.V = V; a.Out = O; a.LSEo = LSE; a.key_mask = key_mask;
     a.B = B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.causal = causal;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldout = ldo; a.scale = scale;
+    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop;
     dim3 grid(kk_cdiv(Sq, 128), B * heads);
     if (math == KK_MATH_BF16) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
@@ -410,13 +448,15 @@ extern "C" int kk_attn_delta(const float *O, const float *dO, float *Delta, int 
 extern "C" int kk_attn_bwd_dq(const float *Q, const float *K, const float *V, const float *dO, const float *LSE,
                               const float *Delta, float *dQ, int B, int heads, int Sq, int Sk, int64_t ldq,
                               int64_t ldk, int64_t ldv, int64_t lddo, int64_t lddq, const uint8_t *key_mask,
-                              int causal, float scale, int math, void *stream) {
+                              int causal, float scale, const uint32_t *seed, uint32_t site, float p_drop, int math,
+                              void *stream) {
     const int64_t lds[5] = {ldq, ldk, ldv, lddo, lddq};
     if (int rc = check_common("kk_attn_bwd_dq", B, heads, Sq, Sk, math, lds, 5)) return rc;
     AttnArgs a = {};
     a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.LSE = LSE; a.Delta = Delta; a.Out = dQ; a.key_mask = key_mask;
     a.B = B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.causal = causal;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.lddo = lddo; a.ldout = lddq; a.scale = scale;
+    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop;
     dim3 grid(kk_cdiv(Sq, 128), B * heads);
     if (math == KK_MATH_BF16) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
@@ -427,13 +467,15 @@ extern "C" int kk_attn_bwd_dq(const float *Q, const float *K, const float *V, co
 extern "C" int kk_attn_bwd_dkv(const float *Q, const float *K, const float *V, const float *dO, const float *LSE,
                                const float *Delta, float *dK, float *dV, int B, int heads, int Sq, int Sk,
                                int64_t ldq, int64_t ldk, int64_t ldv, int64_t lddo, int64_t lddk, int64_t lddv,
-                               const uint8_t *key_mask, int causal, float scale, int math, void *stream) {
+                               const uint8_t *key_mask, int causal, float scale, const uint32_t *seed, uint32_t site,
+                               float p_drop, int math, void *stream) {
     const int64_t lds[6] = {ldq, ldk, ldv, lddo, lddk, lddv};
     if (int rc = check_common("kk_attn_bwd_dkv", B, heads, Sq, Sk, math, lds, 6)) return rc;
     AttnArgs a = {};
     a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.LSE = LSE; a.Delta = Delta; a.Out = dK; a.Out2 = dV; a.key_mask = key_mask;
     a.B = B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.causal = causal;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.lddo = lddo; a.ldout = lddk; a.ldout2 = lddv; a.scale = scale;
+    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop;
     dim3 grid(kk_cdiv(Sk, 128), B * heads);
     if (math == KK_MATH_BF16) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);

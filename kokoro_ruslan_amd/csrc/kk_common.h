@@ -65,3 +65,21 @@ __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<floa
 // C/D fragment of a 32x32 MFMA tile: register r of lane l holds element
 //   row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5),  col = l & 31.
 __device__ __forceinline__ int frag_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// ---- counter-based RNG for dropout / DropPath / SpecAugment -------------------------------------------------------
+// A mask bit is a pure function of (step seed read from device memory, call-site id, element index), so the backward
+// kernels regenerate exactly the forward's masks and nothing mask-sized is ever stored.  The seed lives in HBM (not
+// in a kernel argument) so that a captured hipGraph draws fresh masks on every replay.
+__device__ __forceinline__ uint32_t kk_hash(uint32_t seed, uint32_t site, uint64_t idx) {
+    uint32_t x = (uint32_t)idx ^ (seed * 0x9E3779B9u + site * 0x85EBCA6Bu + (uint32_t)(idx >> 32) * 0xC2B2AE35u);
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;      // "lowbias32" finaliser
+    x ^= seed; x *= 0x9E3779B1u; x ^= x >> 15;
+    return x;
+}
+__device__ __forceinline__ uint32_t kk_drop_threshold(float p) {       // drop iff hash < threshold
+    return p <= 0.f ? 0u : (p >= 1.f ? 0xFFFFFFFFu : (uint32_t)((double)p * 4294967296.0));
+}
+// multiplicative mask value: 0 when dropped, 1/(1-p) when kept (p == 0 -> always 1)
+__device__ __forceinline__ float kk_drop_mul(uint32_t seed, uint32_t site, uint64_t idx, uint32_t thr, float inv_keep) {
+    return (thr != 0u && kk_hash(seed, site, idx) < thr) ? 0.f : inv_keep;
+}

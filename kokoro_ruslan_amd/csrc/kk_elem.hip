@@ -16,23 +16,39 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 }
 
 // ------------------------------------------------------------------ GLU
-__global__ __launch_bounds__(256) void glu_fwd_kernel(const float *__restrict__ h, float *__restrict__ g, int64_t total4, int F) {
+// Dropout on the gated product (transformers.py:108) is fused: mask = f(seed, site, row*F + col).
+struct Drop1 { const uint32_t *seed; uint32_t site; float p; };
+__device__ __forceinline__ float4 drop4(const Drop1 &d, uint32_t seed, uint32_t thr, float ik, uint64_t idx0) {
+    if (thr == 0u) return make_float4(1.f, 1.f, 1.f, 1.f);
+    return make_float4(kk_drop_mul(seed, d.site, idx0, thr, ik), kk_drop_mul(seed, d.site, idx0 + 1, thr, ik),
+                       kk_drop_mul(seed, d.site, idx0 + 2, thr, ik), kk_drop_mul(seed, d.site, idx0 + 3, thr, ik));
+}
+
+__global__ __launch_bounds__(256) void glu_fwd_kernel(const float *__restrict__ h, float *__restrict__ g, int64_t total4, int F, Drop1 d) {
     const int F4 = F / 4;
+    const uint32_t thr = d.seed ? kk_drop_threshold(d.p) : 0u, seed = thr ? *d.seed : 0u;
+    const float ik = thr ? 1.f / (1.f - d.p) : 1.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
         const int64_t row = i / F4;
         const int c = (int)(i - row * F4) * 4;
         const float4 a = ld4(h + row * 2 * F + c), b = ld4(h + row * 2 * F + F + c);
-        st4(g + row * F + c, make_float4(gelu_f(a.x) * b.x, gelu_f(a.y) * b.y, gelu_f(a.z) * b.z, gelu_f(a.w) * b.w));
+        const float4 m = drop4(d, seed, thr, ik, (uint64_t)row * F + c);
+        st4(g + row * F + c, make_float4(gelu_f(a.x) * b.x * m.x, gelu_f(a.y) * b.y * m.y, gelu_f(a.z) * b.z * m.z, gelu_f(a.w) * b.w * m.w));
     }
 }
 
 __global__ __launch_bounds__(256) void glu_bwd_kernel(const float *__restrict__ dg, const float *__restrict__ h,
-                                                      float *__restrict__ dh, int64_t total4, int F) {
+                                                      float *__restrict__ dh, int64_t total4, int F, Drop1 dr) {
     const int F4 = F / 4;
+    const uint32_t thr = dr.seed ? kk_drop_threshold(dr.p) : 0u, seed = thr ? *dr.seed : 0u;
+    const float ik = thr ? 1.f / (1.f - dr.p) : 1.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
         const int64_t row = i / F4;
         const int c = (int)(i - row * F4) * 4;
-        const float4 a = ld4(h + row * 2 * F + c), b = ld4(h + row * 2 * F + F + c), d = ld4(dg + row * F + c);
+        const float4 a = ld4(h + row * 2 * F + c), b = ld4(h + row * 2 * F + F + c);
+        float4 d = ld4(dg + row * F + c);
+        const float4 m = drop4(dr, seed, thr, ik, (uint64_t)row * F + c);
+        d.x *= m.x; d.y *= m.y; d.z *= m.z; d.w *= m.w;
         st4(dh + row * 2 * F + c, make_float4(d.x * b.x * gelu_grad_f(a.x), d.y * b.y * gelu_grad_f(a.y),
                                               d.z * b.z * gelu_grad_f(a.z), d.w * b.w * gelu_grad_f(a.w)));
         st4(dh + row * 2 * F + F + c, make_float4(d.x * gelu_f(a.x), d.y * gelu_f(a.y), d.z * gelu_f(a.z), d.w * gelu_f(a.w)));
@@ -43,8 +59,10 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const float *__restrict__ 
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t *__restrict__ ids, const int64_t *__restrict__ stress,
                                                         const float *__restrict__ emb, const float *__restrict__ semb,
                                                         const float *__restrict__ pe, float *__restrict__ out, int64_t total4,
-                                                        int P, int H, float scale) {
+                                                        int P, int H, float scale, Drop1 d) {
     const int H4 = H / 4;
+    const uint32_t thr = d.seed ? kk_drop_threshold(d.p) : 0u, seed = thr ? *d.seed : 0u;
+    const float ik = thr ? 1.f / (1.f - d.p) : 1.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
         const int64_t tok = i / H4;
         const int c = (int)(i - tok * H4) * 4;
@@ -53,17 +71,21 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t *__restric
         float4 o = make_float4(e.x * scale, e.y * scale, e.z * scale, e.w * scale);
         if (stress) { const float4 s = ld4(semb + stress[tok] * H + c); o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w; }
         o.x += pv.x; o.y += pv.y; o.z += pv.z; o.w += pv.w;
+        const float4 m = drop4(d, seed, thr, ik, (uint64_t)tok * H + c);     // PE dropout (positional_encoding.py:74)
+        o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w;
         st4(out + tok * H + c, o);
     }
 }
 
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t *__restrict__ ids, const int64_t *__restrict__ stress,
                                                         const float *__restrict__ dout, float *__restrict__ demb,
-                                                        float *__restrict__ dsemb, int64_t total, int H, float scale) {
+                                                        float *__restrict__ dsemb, int64_t total, int H, float scale, Drop1 dr) {
+    const uint32_t thr = dr.seed ? kk_drop_threshold(dr.p) : 0u, seed = thr ? *dr.seed : 0u;
+    const float ik = thr ? 1.f / (1.f - dr.p) : 1.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t tok = i / H;
         const int c = (int)(i - tok * H);
-        const float d = dout[i];
+        const float d = dout[i] * kk_drop_mul(seed, dr.site, (uint64_t)i, thr, ik);
         atomicAdd(&demb[ids[tok] * H + c], d * scale);
         if (stress) { const int64_t s = stress[tok]; if (s != 0) atomicAdd(&dsemb[s * H + c], d); }   // padding_idx=0 (model.py:93)
     }
@@ -285,36 +307,44 @@ inline int grid_for(int64_t n, int cap = 4096) {
 
 }  // namespace
 
-extern "C" int kk_glu_fwd(const float *h, float *g, int64_t rows, int F, void *stream) {
-    KK_REQUIRE(rows > 0 && F > 0 && F % 4 == 0, "kk_glu_fwd: bad shape rows=%ld F=%d", (long)rows, F);
+extern "C" int kk_glu_fwd(const float *h, float *g, int64_t rows, int F, const uint32_t *seed, uint32_t site, float p,
+                          void *stream) {
+    KK_REQUIRE(rows > 0 && F > 0 && F % 4 == 0 && p >= 0.f && p < 1.f, "kk_glu_fwd: bad shape rows=%ld F=%d", (long)rows, F);
     const int64_t total4 = rows * F / 4;
-    hipLaunchKernelGGL(glu_fwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, h, g, total4, F);
+    Drop1 d = {p > 0.f ? seed : nullptr, site, p};
+    hipLaunchKernelGGL(glu_fwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, h, g, total4, F, d);
     KK_LAUNCH_CHECK("kk_glu_fwd");
     return 0;
 }
-extern "C" int kk_glu_bwd(const float *dg, const float *h, float *dh, int64_t rows, int F, void *stream) {
-    KK_REQUIRE(rows > 0 && F > 0 && F % 4 == 0, "kk_glu_bwd: bad shape");
+extern "C" int kk_glu_bwd(const float *dg, const float *h, float *dh, int64_t rows, int F, const uint32_t *seed, uint32_t site,
+                          float p, void *stream) {
+    KK_REQUIRE(rows > 0 && F > 0 && F % 4 == 0 && p >= 0.f && p < 1.f, "kk_glu_bwd: bad shape");
     const int64_t total4 = rows * F / 4;
-    hipLaunchKernelGGL(glu_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, dg, h, dh, total4, F);
+    Drop1 d = {p > 0.f ? seed : nullptr, site, p};
+    hipLaunchKernelGGL(glu_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, dg, h, dh, total4, F, d);
     KK_LAUNCH_CHECK("kk_glu_bwd");
     return 0;
 }
 
 extern "C" int kk_embed_fwd(const int64_t *ids, const int64_t *stress, const float *emb, const float *stress_emb,
-                            const float *pe, float *out, int B, int P, int H, float scale, void *stream) {
-    KK_REQUIRE(B > 0 && P > 0 && H > 0 && H % 4 == 0, "kk_embed_fwd: bad shape");
+                            const float *pe, float *out, int B, int P, int H, float scale, const uint32_t *seed,
+                            uint32_t site, float p, void *stream) {
+    KK_REQUIRE(B > 0 && P > 0 && H > 0 && H % 4 == 0 && p >= 0.f && p < 1.f, "kk_embed_fwd: bad shape");
     const int64_t total4 = (int64_t)B * P * H / 4;
+    Drop1 d = {p > 0.f ? seed : nullptr, site, p};
     hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, ids, stress, emb,
-                       stress_emb, pe, out, total4, P, H, scale);
+                       stress_emb, pe, out, total4, P, H, scale, d);
     KK_LAUNCH_CHECK("kk_embed_fwd");
     return 0;
 }
 extern "C" int kk_embed_bwd(const int64_t *ids, const int64_t *stress, const float *dout, float *demb,
-                            float *dstress_emb, int B, int P, int H, float scale, void *stream) {
-    KK_REQUIRE(B > 0 && P > 0 && H > 0, "kk_embed_bwd: bad shape");
+                            float *dstress_emb, int B, int P, int H, float scale, const uint32_t *seed, uint32_t site,
+                            float p, void *stream) {
+    KK_REQUIRE(B > 0 && P > 0 && H > 0 && p >= 0.f && p < 1.f, "kk_embed_bwd: bad shape");
     const int64_t total = (int64_t)B * P * H;
+    Drop1 d = {p > 0.f ? seed : nullptr, site, p};
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, ids, stress, dout, demb,
-                       dstress_emb, total, H, scale);
+                       dstress_emb, total, H, scale, d);
     KK_LAUNCH_CHECK("kk_embed_bwd");
     return 0;
 }

@@ -301,7 +301,11 @@ __global__ void gn_finalize_kernel(const double *__restrict__ scratch, float *__
 
 __global__ __launch_bounds__(256) void gn_apply_relu_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                             const float *__restrict__ beta, const float *__restrict__ stats,
-                                                            float *__restrict__ y, int64_t total4, int L, int C, int chunk, int nch) {
+                                                            float *__restrict__ y, int64_t total4, int L, int C, int chunk, int nch,
+                                                            const uint32_t *__restrict__ seedp, uint32_t site, float p) {
+    // dropout after the ReLU (variance_predictor.py:106) is fused: dropped elements are stored as 0, kept ones scaled
+    const uint32_t thr = seedp ? kk_drop_threshold(p) : 0u, seed = thr ? *seedp : 0u;
+    const float ik = thr ? 1.f / (1.f - p) : 1.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
         const int64_t e = i * 4;
         const int c = (int)(e % C);
@@ -315,6 +319,10 @@ __global__ __launch_bounds__(256) void gn_apply_relu_kernel(const float *__restr
             o.y = fmaxf((v.y - mu) * rs * g.y + bt.y, 0.f);
             o.z = fmaxf((v.z - mu) * rs * g.z + bt.z, 0.f);
             o.w = fmaxf((v.w - mu) * rs * g.w + bt.w, 0.f);
+            if (thr) {
+                o.x *= kk_drop_mul(seed, site, (uint64_t)e, thr, ik); o.y *= kk_drop_mul(seed, site, (uint64_t)e + 1, thr, ik);
+                o.z *= kk_drop_mul(seed, site, (uint64_t)e + 2, thr, ik); o.w *= kk_drop_mul(seed, site, (uint64_t)e + 3, thr, ik);
+            }
         }
         st4(y + e, o);
     }
@@ -326,7 +334,7 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float *__rest
                                                              const float *__restrict__ y, const float *__restrict__ gamma,
                                                              const float *__restrict__ stats, double *__restrict__ scratch,
                                                              float *__restrict__ dgamma, float *__restrict__ dbeta, int L, int C,
-                                                             int chunk, int nch, int slabs) {
+                                                             int chunk, int nch, int slabs, float inv_keep) {
     __shared__ double red[4];
     const int bc = blockIdx.y, b = bc / nch, ci = bc % nch;
     const int nf = chunk_frames(L, chunk, ci);
@@ -339,7 +347,7 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float *__rest
     if (nf >= 2)
         for (int f = fbeg + fl; f < fend; f += lanes) {
             const int64_t o = base + (int64_t)f * C + c;
-            const float d = y[o] > 0.f ? dy[o] : 0.f;
+            const float d = y[o] > 0.f ? dy[o] * inv_keep : 0.f;   // y == 0 also where dropout removed the element
             const float xh = (x[o] - mu) * rs;
             ag += d * xh; ab += d;
             s1 += d * g; s2 += d * g * xh;
@@ -356,7 +364,8 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float *__rest
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                            const float *__restrict__ y, const float *__restrict__ gamma,
                                                            const float *__restrict__ stats, const double *__restrict__ scratch,
-                                                           float *__restrict__ dx, int64_t total4, int L, int C, int chunk, int nch) {
+                                                           float *__restrict__ dx, int64_t total4, int L, int C, int chunk, int nch,
+                                                           float inv_keep) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
         const int64_t e = i * 4;
         const int c = (int)(e % C);
@@ -368,7 +377,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float *__restri
             const double n = (double)nf * C;
             const float m1 = (float)(scratch[bc * 2] / n), m2 = (float)(scratch[bc * 2 + 1] / n);
             const float mu = stats[bc * 2], rs = stats[bc * 2 + 1];
-            const float4 d = ld4(dy + e), xv = ld4(x + e), yv = ld4(y + e), g = ld4(gamma + c);
+            float4 d = ld4(dy + e);
+            d.x *= inv_keep; d.y *= inv_keep; d.z *= inv_keep; d.w *= inv_keep;
+            const float4 xv = ld4(x + e), yv = ld4(y + e), g = ld4(gamma + c);
             o.x = rs * ((yv.x > 0.f ? d.x * g.x : 0.f) - m1 - (xv.x - mu) * rs * m2);
             o.y = rs * ((yv.y > 0.f ? d.y * g.y : 0.f) - m1 - (xv.y - mu) * rs * m2);
             o.z = rs * ((yv.z > 0.f ? d.z * g.z : 0.f) - m1 - (xv.z - mu) * rs * m2);
@@ -458,8 +469,9 @@ extern "C" int kk_headnorm_rope_bwd(const float *dy, int64_t lddy, const float *
 }
 
 extern "C" int kk_groupnorm_relu_fwd(const float *x, const float *gamma, const float *beta, float *y, float *stats,
-                                     double *scratch, int B, int L, int C, int chunk, void *stream) {
-    KK_REQUIRE(B > 0 && L > 0 && C > 0 && C % 4 == 0 && chunk > 0, "kk_groupnorm_relu_fwd: bad shape");
+                                     double *scratch, int B, int L, int C, int chunk, const uint32_t *seed, uint32_t site,
+                                     float p, void *stream) {
+    KK_REQUIRE(B > 0 && L > 0 && C > 0 && C % 4 == 0 && chunk > 0 && p >= 0.f && p < 1.f, "kk_groupnorm_relu_fwd: bad shape");
     hipStream_t s = (hipStream_t)stream;
     const int nch = kk_cdiv(L, chunk), total = B * nch;
     hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * 2 * total, s);
@@ -470,15 +482,17 @@ extern "C" int kk_groupnorm_relu_fwd(const float *x, const float *gamma, const f
     const int64_t total4 = (int64_t)B * L * C / 4;
     int blocks = kk_cdiv(total4, 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(gn_apply_relu_kernel, dim3(blocks), dim3(256), 0, s, x, gamma, beta, stats, y, total4, L, C, chunk, nch);
+    hipLaunchKernelGGL(gn_apply_relu_kernel, dim3(blocks), dim3(256), 0, s, x, gamma, beta, stats, y, total4, L, C, chunk, nch,
+                       p > 0.f ? seed : nullptr, site, p);
     KK_LAUNCH_CHECK("kk_groupnorm_relu_fwd");
     return 0;
 }
 
 extern "C" int kk_groupnorm_relu_bwd(const float *dy, const float *x, const float *y, const float *gamma,
                                      const float *stats, float *dx, float *dgamma, float *dbeta, double *scratch,
-                                     int B, int L, int C, int chunk, void *stream) {
-    KK_REQUIRE(B > 0 && L > 0 && C > 0 && C % 4 == 0 && chunk > 0, "kk_groupnorm_relu_bwd: bad shape");
+                                     int B, int L, int C, int chunk, float p, void *stream) {
+    KK_REQUIRE(B > 0 && L > 0 && C > 0 && C % 4 == 0 && chunk > 0 && p >= 0.f && p < 1.f, "kk_groupnorm_relu_bwd: bad shape");
+    const float inv_keep = 1.f / (1.f - p);
     KK_REQUIRE(C <= 256 && 256 % C == 0, "kk_groupnorm_relu_bwd: C=%d must divide 256", C);
     hipStream_t s = (hipStream_t)stream;
     const int nch = kk_cdiv(L, chunk), total = B * nch;
@@ -486,12 +500,12 @@ extern "C" int kk_groupnorm_relu_bwd(const float *dy, const float *x, const floa
     if (e != hipSuccess) return kk_fail((int)e, "kk_groupnorm_relu_bwd: memset failed");
     const int slabs = 16;
     hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(slabs, total), dim3(256), 0, s, dy, x, y, gamma, stats, scratch, dgamma,
-                       dbeta, L, C, chunk, nch, slabs);
+                       dbeta, L, C, chunk, nch, slabs, inv_keep);
     const int64_t total4 = (int64_t)B * L * C / 4;
     int blocks = kk_cdiv(total4, 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, s, dy, x, y, gamma, stats, scratch, dx, total4, L, C,
-                       chunk, nch);
+                       chunk, nch, inv_keep);
     KK_LAUNCH_CHECK("kk_groupnorm_relu_bwd");
     return 0;
 }

@@ -118,6 +118,10 @@ class KokoroEngine:
         self.loss_coef = f32(5)
         self.micro_in_cycle = 0
         self.dp_loss_scale = 1.0                    # 1/world in data-parallel runs (dp.GradSync.loss_scale)
+        # dropout / DropPath / SpecAugment: off = the parity configuration (reference with p = 0)
+        self.train_dropout = False
+        self.spec_augment_active = True             # the trainer clears it for epochs < spec_augment_start_epoch
+        self.rng = torch.full((1,), int(seed) & 0x7FFFFFFF, dtype=torch.int32, device=self.device)   # step seed, read on device
         for n, b in spec.make_buffers(self.dims).items():
             self.arena.P[n].copy_(b)
         if init:
@@ -196,8 +200,25 @@ class KokoroEngine:
         kk.call("kk_layernorm_bwd", dy, x, P[prefix + ".weight"], self._buf(key + ".mean", rows), self._buf(key + ".rstd", rows),
                 dx, 1 if accumulate else 0, G[prefix + ".weight"], G[prefix + ".bias"], rows, H)
 
+    # ------------------------------------------------------------------ dropout plumbing
+    def _p(self, rate: float) -> float:
+        return float(rate) if self.train_dropout else 0.0
+
+    def _dpr(self, i: int, n: int) -> float:
+        """Stochastic-depth rate of layer i of n (model.py:100-107)."""
+        if not (self.train_dropout and self.hp.use_stochastic_depth):
+            return 0.0
+        return (i / max(n - 1, 1)) * self.hp.stochastic_depth_rate
+
+    def _residual(self, y, x_res, x_out, S, site, p, dpr, p2=0.0):
+        """x_out = x_res + dropout_p(dropout_p2(drop_path(y))) through the mask kernel (p > 0 path)."""
+        kk.call("kk_dropout_fwd", y, x_res, 0, x_out, y.shape[0], y.shape[1], S, self.rng, site, p, site + 1, p2, site + 2, dpr)
+
+    def _residual_bwd(self, dy, dx, S, site, p, dpr, p2=0.0):
+        kk.call("kk_dropout_bwd", dy, dx, dy.shape[0], dy.shape[1], S, self.rng, site, p, site + 1, p2, site + 2, dpr)
+
     # ------------------------------------------------------------------ attention sub-layer
-    def _attn_fwd(self, key, prefix, xq, xkv, B, Sq, Sk, rope, causal, key_mask, x_res, x_out):
+    def _attn_fwd(self, key, prefix, xq, xkv, B, Sq, Sk, rope, causal, key_mask, x_res, x_out, site=0, p=0.0, dpr=0.0):
         """x_out = x_res + w_o(attention(...)) + b_o.  xq [B*Sq,H] (post-LN), xkv [B*Sk,H] (None = self-attention)."""
         a, P, H, h = self.arena, self.arena.P, self.dims.hidden, self.dims.heads
         Nq, Nk = B * Sq, B * Sk
@@ -217,10 +238,16 @@ class KokoroEngine:
         kk.call("kk_headnorm_rope_fwd", v_raw, v_raw.stride(0), P[prefix + ".v_norm.weight"], v_n, v_n.stride(0), Nk, h, Sk, None, None)
         ctx, lse = self._buf(key + ".ctx", Nq, H), self._buf(key + ".lse", B, h, Sq)
         kk.call("kk_attn_fwd", q_n, k_n, v_n, ctx, lse, B, h, Sq, Sk, q_n.stride(0), k_n.stride(0), v_n.stride(0), H, key_mask,
-                1 if causal else 0, 0.125, self.math)
-        self._linear(ctx, P[prefix + ".w_o.weight"], P[prefix + ".w_o.bias"], x_out, res=x_res)
+                1 if causal else 0, 0.125, self.rng, site + 3, p, self.math)
+        if p > 0.0 or dpr > 0.0:
+            proj = self._buf("tmp.attn_proj", Nq, H)
+            self._linear(ctx, P[prefix + ".w_o.weight"], P[prefix + ".w_o.bias"], proj)
+            self._residual(proj, x_res, x_out, Sq, site, p, dpr)
+        else:
+            self._linear(ctx, P[prefix + ".w_o.weight"], P[prefix + ".w_o.bias"], x_out, res=x_res)
 
-    def _attn_bwd(self, key, prefix, d_out, xq, xkv, B, Sq, Sk, rope, causal, key_mask, d_xq, d_xkv, d_xkv_beta):
+    def _attn_bwd(self, key, prefix, d_out, xq, xkv, B, Sq, Sk, rope, causal, key_mask, d_xq, d_xkv, d_xkv_beta,
+                  site=0, p=0.0, dpr=0.0):
         """Given d_out = dL/d(sub-layer output, pre-residual), accumulate parameter grads, write d_xq (dL/d xq) and,
         for cross-attention, d_xkv (+= when d_xkv_beta == 1)."""
         a, P, G, H, h = self.arena, self.arena.P, self.arena.G, self.dims.hidden, self.dims.heads
@@ -228,6 +255,10 @@ class KokoroEngine:
         cos, sin = self._rope_tables(max(Sq, Sk)) if rope else (None, None)
         ctx, lse = self._buf(key + ".ctx", Nq, H), self._buf(key + ".lse", B, h, Sq)
         dctx, delta = self._buf("tmp.dctx", Nq, H), self._buf("tmp.delta", B, h, Sq)
+        if p > 0.0 or dpr > 0.0:
+            masked = self._buf("tmp.d_attn_proj", Nq, H)
+            self._residual_bwd(d_out, masked, Sq, site, p, dpr)
+            d_out = masked
         self._wgrad(d_out, ctx, G[prefix + ".w_o.weight"], G[prefix + ".w_o.bias"])
         self._dgrad(d_out, P[prefix + ".w_o.weight"], dctx)
         kk.call("kk_attn_delta", ctx, dctx, delta, B, h, Sq, H, H)
@@ -245,9 +276,9 @@ class KokoroEngine:
             dk_n, dv_n, dk_raw, dv_raw = dkv_n, dkv_n[:, H:], dkv_raw, dkv_raw[:, H:]
         ld = lambda t: t.stride(0)
         kk.call("kk_attn_bwd_dq", q_n, k_n, v_n, dctx, lse, delta, dq_n, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H, ld(dq_n),
-                key_mask, 1 if causal else 0, 0.125, self.math)
+                key_mask, 1 if causal else 0, 0.125, self.rng, site + 3, p, self.math)
         kk.call("kk_attn_bwd_dkv", q_n, k_n, v_n, dctx, lse, delta, dk_n, dv_n, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H,
-                ld(dk_n), ld(dv_n), key_mask, 1 if causal else 0, 0.125, self.math)
+                ld(dk_n), ld(dv_n), key_mask, 1 if causal else 0, 0.125, self.rng, site + 3, p, self.math)
         kk.call("kk_headnorm_rope_bwd", dq_n, ld(dq_n), q_raw, ld(q_raw), P[prefix + ".q_norm.weight"], dq_raw, ld(dq_raw),
                 G[prefix + ".q_norm.weight"], Nq, h, Sq, cos, sin)
         kk.call("kk_headnorm_rope_bwd", dk_n, ld(dk_n), k_raw, ld(k_raw), P[prefix + ".k_norm.weight"], dk_raw, ld(dk_raw),
@@ -265,30 +296,39 @@ class KokoroEngine:
                 self._dgrad(dkv_raw, a.fused(a.p, prefix + ".w_k.weight", 2), d_xkv, beta=d_xkv_beta)
 
     # ------------------------------------------------------------------ GLU feed-forward sub-layer
-    def _ffn_fwd(self, key, prefix, y, x_res, x_out, Fd):
+    def _ffn_fwd(self, key, prefix, y, x_res, x_out, Fd, S=1, site=0, p=0.0, dpr=0.0):
         P = self.arena.P
         N, H = y.shape
         h1, g, f2 = self._buf(key + ".h1", N, 2 * Fd), self._buf(key + ".g", N, Fd), self._buf(key + ".f2", N, H)
         self._linear(y, P[prefix + ".linear1.weight"], P[prefix + ".linear1.bias"], h1)
-        kk.call("kk_glu_fwd", h1, g, N, Fd)
+        kk.call("kk_glu_fwd", h1, g, N, Fd, self.rng, site + 4, p)
         self._linear(g, P[prefix + ".linear2.weight"], P[prefix + ".linear2.bias"], f2)
-        kk.call("kk_rmsnorm_fwd", f2, P[prefix + ".output_norm.weight"], x_res, x_out, self._buf(key + ".rstd_f", N), N, H)
+        if p > 0.0 or dpr > 0.0:      # rmsnorm -> FFN dropout (:111) -> drop_path -> residual dropout
+            nrm = self._buf("tmp.ffn_norm", N, H)
+            kk.call("kk_rmsnorm_fwd", f2, P[prefix + ".output_norm.weight"], None, nrm, self._buf(key + ".rstd_f", N), N, H)
+            self._residual(nrm, x_res, x_out, S, site, p, dpr, p2=p)
+        else:
+            kk.call("kk_rmsnorm_fwd", f2, P[prefix + ".output_norm.weight"], x_res, x_out, self._buf(key + ".rstd_f", N), N, H)
 
-    def _ffn_bwd(self, key, prefix, d_out, y, d_y, Fd):
+    def _ffn_bwd(self, key, prefix, d_out, y, d_y, Fd, S=1, site=0, p=0.0, dpr=0.0):
         P, G = self.arena.P, self.arena.G
         N, H = y.shape
         h1, g, f2 = self._buf(key + ".h1", N, 2 * Fd), self._buf(key + ".g", N, Fd), self._buf(key + ".f2", N, H)
         df2, dg, dh1 = self._buf("tmp.df2", N, H), self._buf("tmp.dg", N, Fd), self._buf("tmp.dh1", N, 2 * Fd)
+        if p > 0.0 or dpr > 0.0:
+            masked = self._buf("tmp.d_ffn_norm", N, H)
+            self._residual_bwd(d_out, masked, S, site, p, dpr, p2=p)
+            d_out = masked
         kk.call("kk_rmsnorm_bwd", d_out, f2, P[prefix + ".output_norm.weight"], self._buf(key + ".rstd_f", N), df2,
                 G[prefix + ".output_norm.weight"], N, H)
         self._wgrad(df2, g, G[prefix + ".linear2.weight"], G[prefix + ".linear2.bias"])
         self._dgrad(df2, P[prefix + ".linear2.weight"], dg)
-        kk.call("kk_glu_bwd", dg, h1, dh1, N, Fd)
+        kk.call("kk_glu_bwd", dg, h1, dh1, N, Fd, self.rng, site + 4, p)
         self._wgrad(dh1, y, G[prefix + ".linear1.weight"], G[prefix + ".linear1.bias"])
         self._dgrad(dh1, P[prefix + ".linear1.weight"], d_y)
 
     # ------------------------------------------------------------------ variance predictor
-    def _varpred_fwd(self, key, prefix, x, col1, B, L, mask, out):
+    def _varpred_fwd(self, key, prefix, x, col1, B, L, mask, out, site=0, p=0.0):
         """x [B*L, H]; col1 = im2col3(x) (shared by pitch & energy predictors); out [B*L]."""
         P, Fv = self.arena.P, self.dims.var_filter
         rows, nch = B * L, -(-L // CHUNK)
@@ -299,13 +339,13 @@ class KokoroEngine:
             stats = self._buf(f"{key}.st{li}", B * nch, 2)
             self._linear(inp_col, P[f"{prefix}.conv_layers.{li}.weight"].view(Fv, 3 * cin), P[f"{prefix}.conv_layers.{li}.bias"], c)
             kk.call("kk_groupnorm_relu_fwd", c, P[f"{prefix}.norms.{li}.weight"], P[f"{prefix}.norms.{li}.bias"], y, stats,
-                    scratch, B, L, Fv, CHUNK)
+                    scratch, B, L, Fv, CHUNK, self.rng, site + li, p)
             if li == 0:
                 inp_col, cin = self._buf(f"{key}.col2", rows, 3 * Fv), Fv
                 kk.call("kk_im2col3_fwd", y, inp_col, B, L, Fv, CHUNK)
         kk.call("kk_rowdot_fwd", y, P[f"{prefix}.linear.weight"], P[f"{prefix}.linear.bias"], mask, out, rows, Fv, L, CHUNK)
 
-    def _varpred_bwd(self, key, prefix, dout, x, col1, B, L, mask, dx):
+    def _varpred_bwd(self, key, prefix, dout, x, col1, B, L, mask, dx, p=0.0):
         """Accumulate the predictor's parameter grads; write dx (dL/dx) when dx is not None."""
         P, G, Fv = self.arena.P, self.arena.G, self.dims.var_filter
         rows, nch, H = B * L, -(-L // CHUNK), x.shape[1]
@@ -319,7 +359,7 @@ class KokoroEngine:
             cin = Fv if li == 1 else H
             col = self._buf(f"{key}.col2", rows, 3 * Fv) if li == 1 else col1
             kk.call("kk_groupnorm_relu_bwd", dy, c, y, P[f"{prefix}.norms.{li}.weight"], stats, dc, G[f"{prefix}.norms.{li}.weight"],
-                    G[f"{prefix}.norms.{li}.bias"], scratch, B, L, Fv, CHUNK)
+                    G[f"{prefix}.norms.{li}.bias"], scratch, B, L, Fv, CHUNK, p)
             W, dW = P[f"{prefix}.conv_layers.{li}.weight"].view(Fv, 3 * cin), G[f"{prefix}.conv_layers.{li}.weight"].view(Fv, 3 * cin)
             self._wgrad(dc, col, dW, G[f"{prefix}.conv_layers.{li}.bias"])
             if li == 1 or dx is not None:
@@ -349,16 +389,21 @@ class KokoroEngine:
         kk.call("kk_ids_eq_zero", ids, text_mask, Ne)
         kk.call("kk_max_i64", dur, Ne, self.max_dur)
         x = self._buf("enc.x0", Ne, H)
+        hp = self.hp
+        if self.train_dropout:
+            self.rng.add_(1)                              # fresh masks every micro-batch (captured in the hipGraph)
+        pe_drop, p_enc, p_dec, p_var = self._p(hp.encoder_dropout), self._p(hp.encoder_dropout), self._p(hp.decoder_dropout), self._p(hp.variance_dropout)
         kk.call("kk_embed_fwd", ids, stress, P["text_embedding.weight"], P["stress_embedding.weight"] if stress is not None else None,
-                pe, x, B, Pn, H, float(H ** 0.5))
+                pe, x, B, Pn, H, float(H ** 0.5), self.rng, 1, pe_drop)
         for i in range(d.enc_layers):
-            pf, key = f"transformer_encoder_layers.{i}", f"enc{i}"
+            pf, key, st = f"transformer_encoder_layers.{i}", f"enc{i}", 1000 + 32 * i
+            dpr = self._dpr(i, d.enc_layers)
             y1 = self._ln_fwd(key + ".ln1", x, pf + ".norm1")
             xm = self._buf(key + ".xm", Ne, H)
-            self._attn_fwd(key + ".sa", pf + ".self_attn", y1, None, B, Pn, Pn, True, False, text_mask, x, xm)
+            self._attn_fwd(key + ".sa", pf + ".self_attn", y1, None, B, Pn, Pn, True, False, text_mask, x, xm, st, p_enc, dpr)
             y2 = self._ln_fwd(key + ".ln2", xm, pf + ".norm2")
             xo = self._buf(key + ".xo", Ne, H)
-            self._ffn_fwd(key + ".ff", pf + ".ff", y2, xm, xo, d.enc_ff)
+            self._ffn_fwd(key + ".ff", pf + ".ff", y2, xm, xo, d.enc_ff, Pn, st + 8, p_enc, dpr)
             x = xo
         enc_last = x
         enc = self._ln_fwd("enc.norm", enc_last, "encoder_norm")
@@ -367,7 +412,7 @@ class KokoroEngine:
         dur_pred = self._buf("out.log_dur", B, Pn)
         col_e = self._buf("vp.col_enc", Ne, 3 * H)
         kk.call("kk_im2col3_fwd", enc, col_e, B, Pn, H, CHUNK)
-        self._varpred_fwd("vp.dur", f"{VA}.duration_predictor", enc, col_e, B, Pn, text_mask, dur_pred)
+        self._varpred_fwd("vp.dur", f"{VA}.duration_predictor", enc, col_e, B, Pn, text_mask, dur_pred, 10, p_var)
         idx, lens, tot = (self._buf("lr.idx", B, T, dtype=torch.int64), self._buf("lr.lens", B, dtype=torch.int64),
                           self._buf("lr.total", B, dtype=torch.int64))
         kk.call("kk_length_regulate_index", dur, idx, lens, tot, B, Pn, T)
@@ -381,25 +426,37 @@ class KokoroEngine:
         pitch_pred, energy_pred = self._buf("out.pitch", B, T), self._buf("out.energy", B, T)
         col_f = self._buf("vp.col_frames", Nd, 3 * H)
         kk.call("kk_im2col3_fwd", xf, col_f, B, T, H, CHUNK)
-        self._varpred_fwd("vp.pitch", f"{VA}.pitch_predictor", xf, col_f, B, T, fmask, pitch_pred)
-        self._varpred_fwd("vp.energy", f"{VA}.energy_predictor", xf, col_f, B, T, fmask, energy_pred)
+        self._varpred_fwd("vp.pitch", f"{VA}.pitch_predictor", xf, col_f, B, T, fmask, pitch_pred, 12, p_var)
+        self._varpred_fwd("vp.energy", f"{VA}.energy_predictor", xf, col_f, B, T, fmask, energy_pred, 14, p_var)
+        spec_aug = self.train_dropout and hp.use_spec_augment and self.spec_augment_active
+        if spec_aug:                                      # on the cross-attention memory only (model.py:636-639)
+            kk.call("kk_specaug", memory, B, T, H, self.rng, 20, hp.spec_augment_time_mask_max, hp.spec_augment_freq_mask_max,
+                    hp.spec_augment_num_time_masks, hp.spec_augment_num_freq_masks)
 
         # ---- decoder (model.py:519-531; transformers.py:543-583,660) ----
         shifted = self._buf("dec.shifted", Nd, M)
         kk.call("kk_shift_right", mel, shifted, B, T, M)
         y = self._buf("dec.x0", Nd, H)
-        self._linear(shifted, P["mel_projection_in.weight"], P["mel_projection_in.bias"], y, res=pe, res_mod=T)
+        p_din = self._p(hp.decoder_input_dropout)
+        if self.train_dropout and (p_din > 0.0 or pe_drop > 0.0):    # dropout(proj) + pe, then the PE module's dropout
+            lin, t1 = self._buf("tmp.dec_lin", Nd, H), self._buf("tmp.dec_t1", Nd, H)
+            self._linear(shifted, P["mel_projection_in.weight"], P["mel_projection_in.bias"], lin)
+            kk.call("kk_dropout_fwd", lin, pe, T, t1, Nd, H, T, self.rng, 30, p_din, 0, 0.0, 0, 0.0)
+            kk.call("kk_dropout_fwd", t1, None, 0, y, Nd, H, T, self.rng, 31, pe_drop, 0, 0.0, 0, 0.0)
+        else:
+            self._linear(shifted, P["mel_projection_in.weight"], P["mel_projection_in.bias"], y, res=pe, res_mod=T)
         for i in range(d.dec_layers):
-            pf, key = f"decoder.layers.{i}", f"dec{i}"
+            pf, key, st = f"decoder.layers.{i}", f"dec{i}", 2000 + 32 * i
+            dpr = self._dpr(i, d.dec_layers)
             n1 = self._ln_fwd(key + ".ln1", y, pf + ".norm1")
             ya = self._buf(key + ".xa", Nd, H)
-            self._attn_fwd(key + ".sa", pf + ".self_attn", n1, None, B, T, T, True, True, None, y, ya)
+            self._attn_fwd(key + ".sa", pf + ".self_attn", n1, None, B, T, T, True, True, None, y, ya, st, p_dec, dpr)
             n2 = self._ln_fwd(key + ".ln2", ya, pf + ".norm2")
             yc = self._buf(key + ".xc", Nd, H)
-            self._attn_fwd(key + ".ca", pf + ".cross_attn", n2, memory, B, T, T, False, False, fmask, ya, yc)
+            self._attn_fwd(key + ".ca", pf + ".cross_attn", n2, memory, B, T, T, False, False, fmask, ya, yc, st + 8, p_dec, dpr)
             n3 = self._ln_fwd(key + ".ln3", yc, pf + ".norm3")
             yo = self._buf(key + ".xo", Nd, H)
-            self._ffn_fwd(key + ".ff", pf + ".ff", n3, yc, yo, d.dec_ff)
+            self._ffn_fwd(key + ".ff", pf + ".ff", n3, yc, yo, d.dec_ff, T, st + 16, p_dec, dpr)
             y = yo
         dec_last = y
         dec_out = self._ln_fwd("dec.norm", dec_last, "decoder.norm")
@@ -408,7 +465,6 @@ class KokoroEngine:
         kk.call("kk_rowdot_fwd", dec_out, P["stop_token_predictor.weight"], P["stop_token_predictor.bias"], None, stop, Nd, H, T, 0)
 
         # ---- losses (losses.py) ----
-        hp = self.hp
         lcfg = kk.KkLossCfg(hp.duration_loss_weight, hp.stop_token_loss_weight, hp.pitch_loss_weight, hp.energy_loss_weight,
                             hp.duration_huber_delta, hp.pitch_huber_delta, hp.energy_huber_delta, hp.stop_token_pos_weight,
                             float(loss_scale), 1 if adaptive else 0)
@@ -436,42 +492,54 @@ class KokoroEngine:
         dn = self._buf("tmp.dn", Nd, H)
         first_mem = True
         for i in reversed(range(d.dec_layers)):
-            pf, key = f"decoder.layers.{i}", f"dec{i}"
+            pf, key, st = f"decoder.layers.{i}", f"dec{i}", 2000 + 32 * i
+            dpr = self._dpr(i, d.dec_layers)
             x_in = self._buf(f"dec{i - 1}.xo", Nd, H) if i > 0 else self._buf("dec.x0", Nd, H)
             ya, yc = self._buf(key + ".xa", Nd, H), self._buf(key + ".xc", Nd, H)
             n1, n2, n3 = (self._buf(f"{key}.ln{j}.y", Nd, H) for j in (1, 2, 3))
-            self._ffn_bwd(key + ".ff", pf + ".ff", dy, n3, dn, d.dec_ff)
+            self._ffn_bwd(key + ".ff", pf + ".ff", dy, n3, dn, d.dec_ff, T, st + 16, p_dec, dpr)
             self._ln_bwd(key + ".ln3", dn, yc, pf + ".norm3", dy, accumulate=True)
             self._attn_bwd(key + ".ca", pf + ".cross_attn", dy, n2, memory, B, T, T, False, False, fmask, dn, dmem,
-                           0.0 if first_mem else 1.0)
+                           0.0 if first_mem else 1.0, st + 8, p_dec, dpr)
             first_mem = False
             self._ln_bwd(key + ".ln2", dn, ya, pf + ".norm2", dy, accumulate=True)
-            self._attn_bwd(key + ".sa", pf + ".self_attn", dy, n1, None, B, T, T, True, True, None, dn, None, 0.0)
+            self._attn_bwd(key + ".sa", pf + ".self_attn", dy, n1, None, B, T, T, True, True, None, dn, None, 0.0, st, p_dec, dpr)
             self._ln_bwd(key + ".ln1", dn, x_in, pf + ".norm1", dy, accumulate=True)
         # decoder input projection (the PE add and the shift are parameter-free; mel is data)
-        self._wgrad(dy, shifted, G["mel_projection_in.weight"], G["mel_projection_in.bias"])
+        if self.train_dropout and (p_din > 0.0 or pe_drop > 0.0):
+            t1, dlin = self._buf("tmp.d_dec_t1", Nd, H), self._buf("tmp.d_dec_lin", Nd, H)
+            kk.call("kk_dropout_bwd", dy, t1, Nd, H, T, self.rng, 31, pe_drop, 0, 0.0, 0, 0.0)
+            kk.call("kk_dropout_bwd", t1, dlin, Nd, H, T, self.rng, 30, p_din, 0, 0.0, 0, 0.0)
+            self._wgrad(dlin, shifted, G["mel_projection_in.weight"], G["mel_projection_in.bias"])
+        else:
+            self._wgrad(dy, shifted, G["mel_projection_in.weight"], G["mel_projection_in.bias"])
         # variance adaptor: memory gradient feeds only the two embedding tables (xf is detached, lengths.py:30)
+        if spec_aug:
+            kk.call("kk_specaug", dmem, B, T, H, self.rng, 20, hp.spec_augment_time_mask_max, hp.spec_augment_freq_mask_max,
+                    hp.spec_augment_num_time_masks, hp.spec_augment_num_freq_masks)
         kk.call("kk_bucket_embed_add_bwd", dmem, pidx, eidx, fmask, G[f"{VA}.pitch_embedding.weight"],
                 G[f"{VA}.energy_embedding.weight"], B, T, H)
-        self._varpred_bwd("vp.pitch", f"{VA}.pitch_predictor", dpitch, xf, col_f, B, T, fmask, None)
-        self._varpred_bwd("vp.energy", f"{VA}.energy_predictor", denergy, xf, col_f, B, T, fmask, None)
+        self._varpred_bwd("vp.pitch", f"{VA}.pitch_predictor", dpitch, xf, col_f, B, T, fmask, None, p_var)
+        self._varpred_bwd("vp.energy", f"{VA}.energy_predictor", denergy, xf, col_f, B, T, fmask, None, p_var)
         d_enc = self._buf("g.enc_out", Ne, H)
-        self._varpred_bwd("vp.dur", f"{VA}.duration_predictor", ddur, enc, col_e, B, Pn, text_mask, d_enc)
+        self._varpred_bwd("vp.dur", f"{VA}.duration_predictor", ddur, enc, col_e, B, Pn, text_mask, d_enc, p_var)
         # encoder
         dx = self._buf("g.enc_stream", Ne, H)
         self._ln_bwd("enc.norm", d_enc, enc_last, "encoder_norm", dx, accumulate=False)
         dne = self._buf("tmp.dne", Ne, H)
         for i in reversed(range(d.enc_layers)):
-            pf, key = f"transformer_encoder_layers.{i}", f"enc{i}"
+            pf, key, st = f"transformer_encoder_layers.{i}", f"enc{i}", 1000 + 32 * i
+            dpr = self._dpr(i, d.enc_layers)
             x_in = self._buf(f"enc{i - 1}.xo", Ne, H) if i > 0 else self._buf("enc.x0", Ne, H)
             xm = self._buf(key + ".xm", Ne, H)
             y1, y2 = self._buf(key + ".ln1.y", Ne, H), self._buf(key + ".ln2.y", Ne, H)
-            self._ffn_bwd(key + ".ff", pf + ".ff", dx, y2, dne, d.enc_ff)
+            self._ffn_bwd(key + ".ff", pf + ".ff", dx, y2, dne, d.enc_ff, Pn, st + 8, p_enc, dpr)
             self._ln_bwd(key + ".ln2", dne, xm, pf + ".norm2", dx, accumulate=True)
-            self._attn_bwd(key + ".sa", pf + ".self_attn", dx, y1, None, B, Pn, Pn, True, False, text_mask, dne, None, 0.0)
+            self._attn_bwd(key + ".sa", pf + ".self_attn", dx, y1, None, B, Pn, Pn, True, False, text_mask, dne, None, 0.0,
+                           st, p_enc, dpr)
             self._ln_bwd(key + ".ln1", dne, x_in, pf + ".norm1", dx, accumulate=True)
         kk.call("kk_embed_bwd", ids, stress, dx, G["text_embedding.weight"], G["stress_embedding.weight"] if stress is not None else None,
-                B, Pn, H, float(H ** 0.5))
+                B, Pn, H, float(H ** 0.5), self.rng, 1, pe_drop)
         return out
 
     # ------------------------------------------------------------------ optimizer boundary

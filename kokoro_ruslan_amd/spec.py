@@ -100,6 +100,19 @@ class StepHyper:
     grad_explosion_warmup_floor: float = 8000.0
     grad_explosion_min_ema_steps: int = 100
     gradient_accumulation_steps: int = 2
+    # regularisation (config.py:108-121,156-161,195); active only when the engine's `train_dropout` flag is on
+    encoder_dropout: float = 0.15
+    decoder_dropout: float = 0.20
+    decoder_input_dropout: float = 0.15
+    variance_dropout: float = 0.1
+    use_stochastic_depth: bool = True
+    stochastic_depth_rate: float = 0.1
+    use_spec_augment: bool = True
+    spec_augment_time_mask_max: int = 5
+    spec_augment_freq_mask_max: int = 3
+    spec_augment_num_time_masks: int = 1
+    spec_augment_num_freq_masks: int = 2
+    spec_augment_start_epoch: int = 1
 
     @classmethod
     def from_config(cls, cfg) -> "StepHyper":

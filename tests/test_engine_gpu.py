@@ -204,3 +204,51 @@ def test_state_dict_roundtrip_and_names(eng_mod, golden_dir):
     assert torch.equal(e2.arena.p, e.arena.p)
     with pytest.raises(RuntimeError):
         e2.load_state_dict({"bogus": torch.zeros(1)})
+
+
+def test_training_dropout_is_deterministic_per_seed_and_gradients_are_consistent(eng_mod, golden_dir):
+    """With dropout / DropPath / SpecAugment on: same seed ⇒ identical losses and gradients, a new seed changes them,
+    and the analytic gradient agrees with a central finite difference taken under the SAME masks — i.e. the backward
+    kernels regenerate the forward masks at every site."""
+    fx, d, batch, P = _load(golden_dir, "tiny_ragged")
+    names = list(O.param_shapes(d))
+
+    def run(seed, params=None, backward=True):
+        e = run.e
+        if params is not None:
+            e.load_params(params, reset_ema=False)
+        e.rng.fill_(seed)
+        e.zero_grad()
+        out = e.forward_backward(_cuda(batch), backward=backward)
+        torch.cuda.synchronize()
+        return float(out["losses"][0]), {n: g.clone() for n, g in e.grads().items()}
+    run.e = _engine(eng_mod, d, P)
+    run.e.train_dropout = True
+    l1, g1 = run(100)
+    l2, g2 = run(100)
+    l3, g3 = run(101)
+    assert l1 == l2                                      # identical masks => identical forward
+    for n in names:                                      # gradient sums use fp32 atomics: equal up to summation order
+        assert float((g1[n] - g2[n]).abs().max()) <= 1e-5 + 1e-4 * float(g1[n].abs().max()), n
+    assert l1 != l3
+    run.e.train_dropout = False
+    l0, _ = run(100)
+    assert abs(l1 - l0) > 1e-4, "dropout must change the loss"
+    run.e.train_dropout = True
+    # directional derivative along a random direction restricted to a few tensors of every kind
+    gen = torch.Generator().manual_seed(0)
+    # (decoder-side and predictor tensors only: a finite difference on ENCODER weights also moves the detached
+    #  length-regulated memory, which the analytic gradient deliberately excludes — SURVEY §0 fact 5)
+    pick = [n for n in names if any(k in n for k in ("decoder.layers.0.ff.linear1.weight", "decoder.layers.1.cross_attn.w_k.weight",
+            "decoder.layers.0.self_attn.w_q.weight", "pitch_predictor.conv_layers.0.weight", "mel_projection_in.weight",
+            "decoder.layers.0.norm2.weight", "pitch_embedding.weight", "decoder.layers.1.ff.linear2.weight"))]
+    report = []
+    for n in pick:
+        Vn = torch.randn(P[n].shape, generator=gen)
+        analytic = float((g1[n].cpu().double() * Vn.double()).sum())
+        eps = 1e-3
+        lp, _ = run(100, {**P, n: P[n] + eps * Vn}, backward=False)    # same seed argument => the masks of g1
+        lm, _ = run(100, {**P, n: P[n] - eps * Vn}, backward=False)
+        report.append((n, analytic, (lp - lm) / (2 * eps)))
+    bad = [(n, a_, f_) for n, a_, f_ in report if abs(f_ - a_) > 0.1 * abs(a_) + 0.02]
+    assert not bad, report
