@@ -52,11 +52,17 @@ def kernel_table(records, math_bf16: bool):
             mm = {"kk_attn_fwd": 2, "kk_attn_bwd_dq": 3, "kk_attn_bwd_dkv": 4}[name]   # matmuls of Sq x Sk x 64
             flops = mm * 2.0 * B * h * Sq * Sk * 64 * (0.5 if causal else 1.0)
             byts = 4.0 * B * h * 64 * (2 * Sq + 2 * Sk)
-        a = agg.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
-        a["launches"] += 1
-        a["ms"] += ms
-        a["flops"] += flops
-        a["bytes"] += byts
+        keys = [key]
+        if name == "kk_gemm":
+            keys.append(f"  shape ta={ta} tb={tb} M={M} N={N} K={K}")
+        elif name.startswith("kk_attn_") and name != "kk_attn_delta":
+            keys.append(f"  shape {name} B={B} h={h} Sq={Sq} Sk={Sk} causal={causal}")
+        for kq in keys:
+            a = agg.setdefault(kq, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            a["launches"] += 1
+            a["ms"] += ms
+            a["flops"] += flops
+            a["bytes"] += byts
     return agg
 
 
@@ -143,6 +149,8 @@ def main():
             eng.forward_backward(batch, loss_scale=eng.dp_loss_scale, adaptive=True)
             eng.optimizer_step(T)
         table = kernel_table(kk.profile_stop(), args.math == "bf16")
+        shapes = {k: v for k, v in table.items() if k.startswith("  shape")}
+        table = {k: v for k, v in table.items() if not k.startswith("  shape")}
         mfma = {k: v for k, v in table.items() if v["flops"] > 0}
         dom = max(mfma, key=lambda k: mfma[k]["ms"])
         v = mfma[dom]
@@ -156,7 +164,8 @@ def main():
             tot = sum(x["ms"] for x in table.values())
             rows = sorted(table.items(), key=lambda kv: -kv[1]["ms"])
             with open(args.kernel_table, "w") as f:
-                json.dump({"total_ms_2_steps": tot, "kernels": {k: v for k, v in rows}}, f, indent=1)
+                srows = sorted(shapes.items(), key=lambda kv: -kv[1]["ms"])
+                json.dump({"total_ms_2_steps": tot, "kernels": {k: v for k, v in rows}, "shapes": {k: v for k, v in srows}}, f, indent=1)
     dp.barrier()
     if rank != 0:
         return

@@ -82,13 +82,16 @@ int kk_rmsnorm_fwd(const float *x, const float *gain, const float *residual, flo
                    int64_t rows, int H, void *stream);
 int kk_rmsnorm_bwd(const float *dy, const float *x, const float *gain, const float *rstd, float *dx,
                    float *dgain, int64_t rows, int H, void *stream);
-/* Per-head (64-wide) RMSNorm + optional RoPE rotate-half (transformers.py:260-277;
- * positional_encoding.py:196-209).  x/y element (row, head, d) at [row*ld + head*64 + d];
- * position = row % S; cos/sin tables are [>=S, 64]. */
-int kk_headnorm_rope_fwd(const float *x, int64_t ldx, const float *gain, float *y, int64_t ldy, int64_t rows,
-                         int heads, int S, const float *cos_t, const float *sin_t, void *stream);
-int kk_headnorm_rope_bwd(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *gain,
-                         float *dx, int64_t lddx, float *dgain, int64_t rows, int heads, int S,
+/* Per-head (64-wide) RMSNorm + optional RoPE rotate-half (transformers.py:260-277; positional_encoding.py:196-209)
+ * over up to three column groups ("parts", e.g. q|k|v of a fused projection): element (row, part, head, d) at
+ * [row*ld + part*heads*64 + head*64 + d]; gain_j / dgain_j belong to part j; bit j of rope_mask enables RoPE for
+ * part j; position = row % S; cos/sin tables are [>=S, 64].  dgain_j accumulate (+=). */
+int kk_headnorm_rope_fwd(const float *x, int64_t ldx, float *y, int64_t ldy, int64_t rows, int heads, int S,
+                         int parts, const float *gain0, const float *gain1, const float *gain2, int rope_mask,
+                         const float *cos_t, const float *sin_t, void *stream);
+int kk_headnorm_rope_bwd(const float *dy, int64_t lddy, const float *x, int64_t ldx, float *dx, int64_t lddx,
+                         int64_t rows, int heads, int S, int parts, const float *gain0, const float *gain1,
+                         const float *gain2, float *dgain0, float *dgain1, float *dgain2, int rope_mask,
                          const float *cos_t, const float *sin_t, void *stream);
 
 /* ---- GLU feed-forward gate (transformers.py:107-108; exact-erf GELU): g = gelu(h[:, :F]) * h[:, F:] ---- */

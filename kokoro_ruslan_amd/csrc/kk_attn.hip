@@ -86,20 +86,28 @@ __device__ __forceinline__ void load_rowfrag(RowFrag<BF16> &f, const float *rowp
     }
 }
 
-// Stage a [64][64] fp32 tile (row r at src + r*ld; rows >= nvalid are zero) into LDS row-major S[64][LR].
-template <bool BF16>
-__device__ __forceinline__ void stage_rows(typename ACfg<BF16>::elem *S, const float *src, int64_t ld, int nvalid) {
-    constexpr int LR = ACfg<BF16>::LR;
-    const int t = threadIdx.x, row = t >> 2, seg = (t & 3) * 16;
-    float4 r[4];
+// Staging of a [64][64] fp32 tile (row r at src + r*ld; rows >= nvalid read as zero) is split in two halves so the
+// global loads of tile t+1 can be in flight while tile t is being multiplied: load_* fills 4 float4 registers,
+// store_* converts and writes them to LDS.  "rows": LDS row-major S[64][LR];  "rows_T" (bf16 only): transposed
+// St[d][row] (row contiguous), needed where the MFMA reduction runs over the tile's rows.
+struct TileRegs { float4 r[4]; };
+
+__device__ __forceinline__ void load_rows(TileRegs &t, const float *src, int64_t ld, int nvalid) {
+    const int row = threadIdx.x >> 2, seg = (threadIdx.x & 3) * 16;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = row < nvalid ? ld4(src + (int64_t)row * ld + seg + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < 4; ++i) t.r[i] = row < nvalid ? ld4(src + (int64_t)row * ld + seg + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+template <bool BF16>
+__device__ __forceinline__ void store_rows(typename ACfg<BF16>::elem *S, const TileRegs &t) {
+    constexpr int LR = ACfg<BF16>::LR;
+    const int row = threadIdx.x >> 2, seg = (threadIdx.x & 3) * 16;
     if constexpr (BF16) {
         bf16x8 lo, hi;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            lo[e] = (__bf16)f4g(r[0], e); lo[4 + e] = (__bf16)f4g(r[1], e);
-            hi[e] = (__bf16)f4g(r[2], e); hi[4 + e] = (__bf16)f4g(r[3], e);
+            lo[e] = (__bf16)f4g(t.r[0], e); lo[4 + e] = (__bf16)f4g(t.r[1], e);
+            hi[e] = (__bf16)f4g(t.r[2], e); hi[4 + e] = (__bf16)f4g(t.r[3], e);
         }
         *reinterpret_cast<bf16x8 *>(&S[row * LR + seg]) = lo;
         *reinterpret_cast<bf16x8 *>(&S[row * LR + seg + 8]) = hi;
@@ -107,22 +115,24 @@ __device__ __forceinline__ void stage_rows(typename ACfg<BF16>::elem *S, const f
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) S[row * LR + seg + 4 * i + e] = f4g(r[i], e);
+            for (int e = 0; e < 4; ++e) S[row * LR + seg + 4 * i + e] = f4g(t.r[i], e);
     }
 }
 
-// bf16 only: stage the same tile TRANSPOSED, St[d][row] (row contiguous).
-__device__ __forceinline__ void stage_rows_T(__bf16 *St, const float *src, int64_t ld, int nvalid) {
-    constexpr int LR = ACfg<true>::LR;
-    const int t = threadIdx.x, rg = (t & 15) * 4, dg = (t >> 4) * 4;
-    float4 r[4];
+__device__ __forceinline__ void load_rows_T(TileRegs &t, const float *src, int64_t ld, int nvalid) {
+    const int rg = (threadIdx.x & 15) * 4, dg = (threadIdx.x >> 4) * 4;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) r[c] = (rg + c) < nvalid ? ld4(src + (int64_t)(rg + c) * ld + dg) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < 4; ++c) t.r[c] = (rg + c) < nvalid ? ld4(src + (int64_t)(rg + c) * ld + dg) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__device__ __forceinline__ void store_rows_T(__bf16 *St, const TileRegs &t) {
+    constexpr int LR = ACfg<true>::LR;
+    const int rg = (threadIdx.x & 15) * 4, dg = (threadIdx.x >> 4) * 4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         bf16x4 v;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = (__bf16)f4g(r[c], e);
+        for (int c = 0; c < 4; ++c) v[c] = (__bf16)f4g(t.r[c], e);
         *reinterpret_cast<bf16x4 *>(&St[(dg + e) * LR + rg]) = v;
     }
 }
@@ -199,9 +209,8 @@ __device__ __forceinline__ void store_row(float *dst_row, const f32x16 (&acc)[2]
 template <bool BF16>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     using elem = typename ACfg<BF16>::elem;
-    constexpr int LR = ACfg<BF16>::LR;
-    __shared__ __attribute__((aligned(16))) elem smem[2 * 64 * LR];
-    elem *Ks = smem, *Vx = smem + 64 * LR;
+    constexpr int LR = ACfg<BF16>::LR, TILE = 64 * LR;
+    __shared__ __attribute__((aligned(16))) elem smem[2 * 2 * TILE];      // [buffer][K | V]
     const int b = blockIdx.y / a.heads, hh = blockIdx.y % a.heads;
     const int qblk = blockIdx.x * 128;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, l31 = lane & 31;
@@ -217,13 +226,27 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     const uint8_t *km = a.key_mask ? a.key_mask + (int64_t)b * a.Sk : nullptr;
     int kend = a.Sk;
     if (a.causal && qblk + 128 < kend) kend = qblk + 128;
-    for (int k0 = 0; k0 < kend; k0 += 64) {
-        __syncthreads();
+    const float *Kb = a.K + (int64_t)b * a.Sk * a.ldk + hh * 64, *Vb = a.V + (int64_t)b * a.Sk * a.ldv + hh * 64;
+    TileRegs rk, rv;
+    auto issue = [&](int k0) {
         const int nvalid = a.Sk - k0 < 64 ? a.Sk - k0 : 64;
-        stage_rows<BF16>(Ks, a.K + ((int64_t)b * a.Sk + k0) * a.ldk + hh * 64, a.ldk, nvalid);
-        if constexpr (BF16) stage_rows_T(Vx, a.V + ((int64_t)b * a.Sk + k0) * a.ldv + hh * 64, a.ldv, nvalid);
-        else stage_rows<false>(Vx, a.V + ((int64_t)b * a.Sk + k0) * a.ldv + hh * 64, a.ldv, nvalid);
-        __syncthreads();
+        load_rows(rk, Kb + (int64_t)k0 * a.ldk, a.ldk, nvalid);
+        if constexpr (BF16) load_rows_T(rv, Vb + (int64_t)k0 * a.ldv, a.ldv, nvalid);
+        else load_rows(rv, Vb + (int64_t)k0 * a.ldv, a.ldv, nvalid);
+    };
+    auto commit = [&](int buf) {
+        store_rows<BF16>(smem + buf * 2 * TILE, rk);
+        if constexpr (BF16) store_rows_T(smem + buf * 2 * TILE + TILE, rv);
+        else store_rows<false>(smem + buf * 2 * TILE + TILE, rv);
+    };
+    issue(0);
+    commit(0);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = 0; k0 < kend; k0 += 64, cur ^= 1) {
+        const bool more = k0 + 64 < kend;
+        if (more) issue(k0 + 64);                       // next tile's global loads fly during this tile's MFMAs
+        const elem *Ks = smem + cur * 2 * TILE, *Vx = Ks + TILE;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int kb = k0 + sub * 32;
@@ -258,6 +281,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
             }
             mma_T_x_p<BF16>(o, Vx, sub * 32, p, l31, half);
         }
+        if (more) commit(cur ^ 1);
+        __syncthreads();
     }
     if (qvalid) {
         const float inv = l > 0.f ? 1.f / l : 0.f;
@@ -270,9 +295,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 template <bool BF16>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     using elem = typename ACfg<BF16>::elem;
-    constexpr int LR = ACfg<BF16>::LR;
-    __shared__ __attribute__((aligned(16))) elem smem[(BF16 ? 3 : 2) * 64 * LR];
-    elem *Ks = smem, *Vs = smem + 64 * LR, *Kt = BF16 ? smem + 2 * 64 * LR : smem;
+    constexpr int LR = ACfg<BF16>::LR, TILE = 64 * LR, NT = BF16 ? 3 : 2;   // K, V (+ K transposed for bf16)
+    __shared__ __attribute__((aligned(16))) elem smem[2 * NT * TILE];
     const int b = blockIdx.y / a.heads, hh = blockIdx.y % a.heads;
     const int qblk = blockIdx.x * 128;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, l31 = lane & 31;
@@ -290,14 +314,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     const uint8_t *km = a.key_mask ? a.key_mask + (int64_t)b * a.Sk : nullptr;
     int kend = a.Sk;
     if (a.causal && qblk + 128 < kend) kend = qblk + 128;
-    for (int k0 = 0; k0 < kend; k0 += 64) {
-        __syncthreads();
+    const float *Kb = a.K + (int64_t)b * a.Sk * a.ldk + hh * 64, *Vb = a.V + (int64_t)b * a.Sk * a.ldv + hh * 64;
+    TileRegs rk, rv, rkt;
+    auto issue = [&](int k0) {
         const int nvalid = a.Sk - k0 < 64 ? a.Sk - k0 : 64;
-        const float *kp = a.K + ((int64_t)b * a.Sk + k0) * a.ldk + hh * 64;
-        stage_rows<BF16>(Ks, kp, a.ldk, nvalid);
-        stage_rows<BF16>(Vs, a.V + ((int64_t)b * a.Sk + k0) * a.ldv + hh * 64, a.ldv, nvalid);
-        if constexpr (BF16) stage_rows_T(Kt, kp, a.ldk, nvalid);
-        __syncthreads();
+        load_rows(rk, Kb + (int64_t)k0 * a.ldk, a.ldk, nvalid);
+        load_rows(rv, Vb + (int64_t)k0 * a.ldv, a.ldv, nvalid);
+        if constexpr (BF16) load_rows_T(rkt, Kb + (int64_t)k0 * a.ldk, a.ldk, nvalid);
+    };
+    auto commit = [&](int buf) {
+        store_rows<BF16>(smem + buf * NT * TILE, rk);
+        store_rows<BF16>(smem + buf * NT * TILE + TILE, rv);
+        if constexpr (BF16) store_rows_T(smem + buf * NT * TILE + 2 * TILE, rkt);
+    };
+    issue(0);
+    commit(0);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = 0; k0 < kend; k0 += 64, cur ^= 1) {
+        const bool more = k0 + 64 < kend;
+        if (more) issue(k0 + 64);
+        const elem *Ks = smem + cur * NT * TILE, *Vs = Ks + TILE, *Kt = BF16 ? Ks + 2 * TILE : Ks;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int kb = k0 + sub * 32;
@@ -315,8 +352,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
                 const float pv = ok ? expf(s[r] * a.scale - lse) : 0.f;
                 ds[r] = pv * (dp[r] * pd.mul(q, key) - dlt) * a.scale;
             }
-            mma_T_x_p<BF16>(dq, BF16 ? Kt : Ks, sub * 32, ds, l31, half);
+            mma_T_x_p<BF16>(dq, Kt, sub * 32, ds, l31, half);
         }
+        if (more) commit(cur ^ 1);
+        __syncthreads();
     }
     if (qvalid) store_row(a.Out + ((int64_t)b * a.Sq + q) * a.ldout + hh * 64, dq, 1.f, half);
 }
@@ -325,11 +364,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 template <bool BF16>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     using elem = typename ACfg<BF16>::elem;
-    constexpr int LR = ACfg<BF16>::LR;
-    __shared__ __attribute__((aligned(16))) elem smem[(BF16 ? 4 : 2) * 64 * LR];
-    __shared__ float lse_s[64], dlt_s[64];
-    elem *Qs = smem, *dOs = smem + 64 * LR;
-    elem *Qt = BF16 ? smem + 2 * 64 * LR : Qs, *dOt = BF16 ? smem + 3 * 64 * LR : dOs;
+    constexpr int LR = ACfg<BF16>::LR, TILE = 64 * LR, NT = BF16 ? 4 : 2;   // Q, dO (+ both transposed for bf16)
+    __shared__ __attribute__((aligned(16))) elem smem[2 * NT * TILE];
+    __shared__ float lse_s[2][64], dlt_s[2][64];
     const int b = blockIdx.y / a.heads, hh = blockIdx.y % a.heads;
     const int kblk = blockIdx.x * 128;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, l31 = lane & 31;
@@ -344,21 +381,44 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     ProbDrop pd;
     pd.init(a, b, hh);
     const int qstart = a.causal ? (kblk / 64) * 64 : 0;
-    for (int q0 = qstart; q0 < a.Sq; q0 += 64) {
-        __syncthreads();
+    const float *Qb = a.Q + (int64_t)b * a.Sq * a.ldq + hh * 64, *dOb = a.dO + (int64_t)b * a.Sq * a.lddo + hh * 64;
+    const float *LSEb = a.LSE + ((int64_t)b * a.heads + hh) * a.Sq, *DLb = a.Delta + ((int64_t)b * a.heads + hh) * a.Sq;
+    TileRegs rq, rdo, rqt, rdot;
+    float r_lse = INFINITY, r_dlt = 0.f;
+    auto issue = [&](int q0) {
         const int nvalid = a.Sq - q0 < 64 ? a.Sq - q0 : 64;
-        const float *qp = a.Q + ((int64_t)b * a.Sq + q0) * a.ldq + hh * 64;
-        const float *dop = a.dO + ((int64_t)b * a.Sq + q0) * a.lddo + hh * 64;
-        stage_rows<BF16>(Qs, qp, a.ldq, nvalid);
-        stage_rows<BF16>(dOs, dop, a.lddo, nvalid);
-        if constexpr (BF16) { stage_rows_T(Qt, qp, a.ldq, nvalid); stage_rows_T(dOt, dop, a.lddo, nvalid); }
+        load_rows(rq, Qb + (int64_t)q0 * a.ldq, a.ldq, nvalid);
+        load_rows(rdo, dOb + (int64_t)q0 * a.lddo, a.lddo, nvalid);
+        if constexpr (BF16) {
+            load_rows_T(rqt, Qb + (int64_t)q0 * a.ldq, a.ldq, nvalid);
+            load_rows_T(rdot, dOb + (int64_t)q0 * a.lddo, a.lddo, nvalid);
+        }
         if (threadIdx.x < 64) {
             const int qq = q0 + threadIdx.x;
-            const int64_t o = ((int64_t)b * a.heads + hh) * a.Sq + qq;
-            lse_s[threadIdx.x] = qq < a.Sq ? a.LSE[o] : INFINITY;
-            dlt_s[threadIdx.x] = qq < a.Sq ? a.Delta[o] : 0.f;
+            r_lse = qq < a.Sq ? LSEb[qq] : INFINITY;
+            r_dlt = qq < a.Sq ? DLb[qq] : 0.f;
         }
-        __syncthreads();
+    };
+    auto commit = [&](int buf) {
+        store_rows<BF16>(smem + buf * NT * TILE, rq);
+        store_rows<BF16>(smem + buf * NT * TILE + TILE, rdo);
+        if constexpr (BF16) {
+            store_rows_T(smem + buf * NT * TILE + 2 * TILE, rqt);
+            store_rows_T(smem + buf * NT * TILE + 3 * TILE, rdot);
+        }
+        if (threadIdx.x < 64) { lse_s[buf][threadIdx.x] = r_lse; dlt_s[buf][threadIdx.x] = r_dlt; }
+    };
+    if (qstart < a.Sq) {
+        issue(qstart);
+        commit(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int q0 = qstart; q0 < a.Sq; q0 += 64, cur ^= 1) {
+        const bool more = q0 + 64 < a.Sq;
+        if (more) issue(q0 + 64);
+        const elem *Qs = smem + cur * NT * TILE, *dOs = Qs + TILE;
+        const elem *Qt = BF16 ? Qs + 2 * TILE : Qs, *dOt = BF16 ? Qs + 3 * TILE : dOs;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int qb = q0 + sub * 32;
@@ -374,14 +434,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
                 const int ql = sub * 32 + frag_row(r, half);
                 const int qq = q0 + ql;
                 const bool ok = kalive && qq < a.Sq && !(a.causal && key > qq);
-                const float pv = ok ? expf(s[r] * a.scale - lse_s[ql]) : 0.f;
+                const float pv = ok ? expf(s[r] * a.scale - lse_s[cur][ql]) : 0.f;
                 const float dm = pd.mul(qq, key);
                 p[r] = pv * dm;                                       // dropped probabilities feed dV
-                ds[r] = pv * (dp[r] * dm - dlt_s[ql]) * a.scale;
+                ds[r] = pv * (dp[r] * dm - dlt_s[cur][ql]) * a.scale;
             }
             mma_T_x_p<BF16>(dv, dOt, sub * 32, p, l31, half);
             mma_T_x_p<BF16>(dk, Qt, sub * 32, ds, l31, half);
         }
+        if (more) commit(cur ^ 1);
+        __syncthreads();
     }
     if (kvalid) {
         store_row(a.Out + ((int64_t)b * a.Sk + key) * a.ldout + hh * 64, dk, 1.f, half);

@@ -47,16 +47,18 @@ template <bool BF16, int TM, bool KS>
 __device__ __forceinline__ void g2r(const float *__restrict__ X, int64_t ld, int rows_total, int r0, int k0,
                                     int kend, float4 (&reg)[GemmCfg<BF16, TM>::NV]) {
     constexpr int NV = GemmCfg<BF16, TM>::NV;
-    constexpr int TPR = GemmCfg<BF16, TM>::BK / (NV * 4);   // threads per tile row (k-contiguous operand)
+    constexpr int CPR = GemmCfg<BF16, TM>::BK / 4;          // 16-byte chunks per tile row (k-contiguous operand)
+    constexpr int RPI = 256 / CPR;                           // tile rows covered by one load instruction
     constexpr int RG = TM / 4;                               // 4-row groups per tile (k-strided operand)
     const int t = threadIdx.x;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!KS) {
-        const int row = r0 + t / TPR;
-        const int kb = k0 + (t % TPR) * (NV * 4);
+        // every load instruction reads whole contiguous rows (CPR lanes x 16 B): a wave touches 64/CPR full row
+        // segments instead of 64 scattered 16-byte pieces (measured: the scattered form ran at ~11 B/clk/CU)
+        const int k = k0 + (t % CPR) * 4;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int k = kb + 4 * i;
+            const int row = r0 + t / CPR + i * RPI;
             reg[i] = (row < rows_total && k < kend) ? ld4(X + (int64_t)row * ld + k) : z;
         }
     } else {
@@ -74,21 +76,18 @@ __device__ __forceinline__ void g2r(const float *__restrict__ X, int64_t ld, int
 template <bool BF16, int TM, bool KS>
 __device__ __forceinline__ void r2s(typename GemmCfg<BF16, TM>::elem *S, const float4 (&reg)[GemmCfg<BF16, TM>::NV]) {
     constexpr int LR = GemmCfg<BF16, TM>::LR, NV = GemmCfg<BF16, TM>::NV;
-    constexpr int TPR = GemmCfg<BF16, TM>::BK / (NV * 4), RG = TM / 4;
+    constexpr int CPR = GemmCfg<BF16, TM>::BK / 4, RPI = 256 / CPR, RG = TM / 4;
     const int t = threadIdx.x;
     if constexpr (BF16) {
         if (!KS) {
-            const int row = t / TPR, kofs = (t % TPR) * 16;
-            bf16x8 lo, hi;
+            const int kofs = (t % CPR) * 4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                lo[e] = (__bf16)f4c(reg[0], e);
-                lo[4 + e] = (__bf16)f4c(reg[1], e);
-                hi[e] = (__bf16)f4c(reg[2], e);
-                hi[4 + e] = (__bf16)f4c(reg[3], e);
+            for (int i = 0; i < NV; ++i) {
+                bf16x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (__bf16)f4c(reg[i], e);
+                *reinterpret_cast<bf16x4 *>(&S[(t / CPR + i * RPI) * LR + kofs]) = v;
             }
-            *reinterpret_cast<bf16x8 *>(&S[row * LR + kofs]) = lo;
-            *reinterpret_cast<bf16x8 *>(&S[row * LR + kofs + 8]) = hi;
         } else {
             const int rowb = (t % RG) * 4, kofs = (t / RG) * 4;
 #pragma unroll
@@ -101,11 +100,11 @@ __device__ __forceinline__ void r2s(typename GemmCfg<BF16, TM>::elem *S, const f
         }
     } else {
         if (!KS) {
-            const int row = t / TPR, kofs = (t % TPR) * 8;
+            const int kofs = (t % CPR) * 4;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) S[row * LR + kofs + 4 * i + e] = f4c(reg[i], e);
+                for (int e = 0; e < 4; ++e) S[(t / CPR + i * RPI) * LR + kofs + e] = f4c(reg[i], e);
         } else {
             const int rowb = (t % RG) * 4, kofs = (t / RG) * 2;
 #pragma unroll
@@ -291,11 +290,11 @@ extern "C" int kk_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, float al
     const int tiles = kk_cdiv(M, TM) * kk_cdiv(N, TM);
     const int ktiles = kk_cdiv(K, BK);
     int splits = split_k;
-    if (splits <= 0) {   // auto: fill ~2 workgroups per CU, keep >= 4 k-tiles per slice
+    if (splits <= 0) {   // auto: aim at ~2 workgroups per CU, keep >= 2 k-tiles per slice
         splits = 1;
-        if (tiles < 256) {
+        if (tiles < 384) {
             splits = kk_cdiv(512, tiles);
-            const int cap = ktiles / 4 > 0 ? ktiles / 4 : 1;
+            const int cap = ktiles / 2 > 0 ? ktiles / 2 : 1;
             if (splits > cap) splits = cap;
         }
     }

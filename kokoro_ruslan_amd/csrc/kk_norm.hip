@@ -201,61 +201,81 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float *__restric
 }
 
 // ------------------------------------------------------------------ per-head RMSNorm(64) + RoPE
-// One wave per (row, head); lane = d.  rotate_half(n)[d] = -n[d+32] (d<32), n[d-32] (d>=32).
-__global__ __launch_bounds__(256) void headnorm_rope_fwd_kernel(const float *__restrict__ x, int64_t ldx,
-                                                                const float *__restrict__ gain, float *__restrict__ y,
-                                                                int64_t ldy, int64_t npairs, int heads, int S,
-                                                                const float *__restrict__ cos_t, const float *__restrict__ sin_t) {
-    const int lane = threadIdx.x & 63;
-    const float g = gain[lane];
-    for (int64_t pr = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); pr < npairs; pr += (int64_t)gridDim.x * 4) {
-        const int64_t row = pr / heads;
-        const int hd = (int)(pr - row * heads);
-        const float v = x[row * ldx + hd * 64 + lane];
-        const float rs = 1.f / sqrtf(wave_sum(v * v) * (1.f / 64.f) + FLT_EPSILON);
-        float n = v * rs * g;
-        if (cos_t) {
-            const int pos = (int)(row % S);
-            const float other = __shfl_xor(n, 32, 64);
-            const float rot = lane < 32 ? -other : other;
-            n = n * cos_t[pos * 64 + lane] + rot * sin_t[pos * 64 + lane];
+// 16 lanes per (row, head) 64-vector, one float4 each (4 vectors per wave, 16 per workgroup); the sum of squares is
+// a 4-step xor-shuffle inside the 16-lane group and rotate_half's partner element d^32 lives in lane^8.
+// One launch covers up to three column groups ("parts": q|k|v of a fused projection) with their own gains and a
+// per-part RoPE flag; blockIdx.y = part, so a thread's gain-gradient accumulator belongs to one gain vector.
+// rotate_half(n)[d] = -n[d+32] (d<32), n[d-32] (d>=32)   (positional_encoding.py:152-157)
+struct HeadNormArgs {
+    const float *x, *dy, *cos_t, *sin_t;
+    float *y, *dx;
+    const float *gain[3];
+    float *dgain[3];
+    int64_t ldx, ldy, lddy, lddx, npairs;   // npairs = rows * heads (per part)
+    int heads, S, rope_mask;
+};
+
+__device__ __forceinline__ float sum16(float v) {
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    return v;
+}
+__device__ __forceinline__ float4 shfl8(const float4 &v) {
+    return make_float4(__shfl_xor(v.x, 8, 64), __shfl_xor(v.y, 8, 64), __shfl_xor(v.z, 8, 64), __shfl_xor(v.w, 8, 64));
+}
+
+__global__ __launch_bounds__(256) void headnorm_rope_fwd_kernel(HeadNormArgs a) {
+    const int part = blockIdx.y, sub = threadIdx.x & 15, H = a.heads * 64;
+    const bool rope = (a.rope_mask >> part) & 1;
+    const float4 g = ld4(a.gain[part] + sub * 4);
+    for (int64_t pr = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); pr < a.npairs; pr += (int64_t)gridDim.x * 16) {
+        const int64_t row = pr / a.heads;
+        const int col = part * H + (int)(pr - row * a.heads) * 64 + sub * 4;
+        const float4 v = ld4(a.x + row * a.ldx + col);
+        const float rs = 1.f / sqrtf(sum16(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w) * (1.f / 64.f) + FLT_EPSILON);
+        float4 n = make_float4(v.x * rs * g.x, v.y * rs * g.y, v.z * rs * g.z, v.w * rs * g.w);
+        if (rope) {
+            const int pos = (int)(row % a.S);
+            const float4 o = shfl8(n), c = ld4(a.cos_t + pos * 64 + sub * 4), sn = ld4(a.sin_t + pos * 64 + sub * 4);
+            const float sg = sub < 8 ? -1.f : 1.f;
+            n = make_float4(n.x * c.x + sg * o.x * sn.x, n.y * c.y + sg * o.y * sn.y, n.z * c.z + sg * o.z * sn.z,
+                            n.w * c.w + sg * o.w * sn.w);
         }
-        y[row * ldy + hd * 64 + lane] = n;
+        st4(a.y + row * a.ldy + col, n);
     }
 }
 
-__global__ __launch_bounds__(256) void headnorm_rope_bwd_kernel(const float *__restrict__ dy, int64_t lddy,
-                                                                const float *__restrict__ x, int64_t ldx,
-                                                                const float *__restrict__ gain, float *__restrict__ dx,
-                                                                int64_t lddx, float *__restrict__ dgain, int64_t npairs,
-                                                                int heads, int S, const float *__restrict__ cos_t,
-                                                                const float *__restrict__ sin_t) {
-    const int lane = threadIdx.x & 63;
-    const float g = gain[lane];
-    float acc_g = 0.f;
-    for (int64_t pr = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); pr < npairs; pr += (int64_t)gridDim.x * 4) {
-        const int64_t row = pr / heads;
-        const int hd = (int)(pr - row * heads);
-        const float v = x[row * ldx + hd * 64 + lane];
-        const float rs = 1.f / sqrtf(wave_sum(v * v) * (1.f / 64.f) + FLT_EPSILON);
-        float dn = dy[row * lddy + hd * 64 + lane];
-        if (cos_t) {
-            const int pos = (int)(row % S);
-            const float c = cos_t[pos * 64 + lane], sn = sin_t[pos * 64 + lane];
-            const float ds = dn * sn;                         // dy[e]*sin[e]
-            const float other = __shfl_xor(ds, 32, 64);       // dy[d^32]*sin[d^32]
-            dn = dn * c + (lane < 32 ? other : -other);
+__global__ __launch_bounds__(256) void headnorm_rope_bwd_kernel(HeadNormArgs a) {
+    __shared__ float red[16][64];
+    const int part = blockIdx.y, sub = threadIdx.x & 15, H = a.heads * 64;
+    const bool rope = (a.rope_mask >> part) & 1;
+    const float4 g = ld4(a.gain[part] + sub * 4);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t pr = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); pr < a.npairs; pr += (int64_t)gridDim.x * 16) {
+        const int64_t row = pr / a.heads;
+        const int col = part * H + (int)(pr - row * a.heads) * 64 + sub * 4;
+        const float4 v = ld4(a.x + row * a.ldx + col);
+        float4 dn = ld4(a.dy + row * a.lddy + col);
+        const float rs = 1.f / sqrtf(sum16(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w) * (1.f / 64.f) + FLT_EPSILON);
+        if (rope) {     // dn[d] = dy[d] cos[d] + (d < 32 ? dy[d+32] sin[d+32] : -dy[d-32] sin[d-32])
+            const int pos = (int)(row % a.S);
+            const float4 c = ld4(a.cos_t + pos * 64 + sub * 4), sn = ld4(a.sin_t + pos * 64 + sub * 4);
+            const float4 o = shfl8(make_float4(dn.x * sn.x, dn.y * sn.y, dn.z * sn.z, dn.w * sn.w));
+            const float sg = sub < 8 ? 1.f : -1.f;
+            dn = make_float4(dn.x * c.x + sg * o.x, dn.y * c.y + sg * o.y, dn.z * c.z + sg * o.z, dn.w * c.w + sg * o.w);
         }
-        acc_g += dn * v * rs;
-        const float dgv = dn * g;
-        const float k = wave_sum(dgv * v) * (1.f / 64.f) * rs * rs * rs;
-        dx[row * lddx + hd * 64 + lane] = rs * dgv - v * k;
+        acc.x += dn.x * v.x * rs; acc.y += dn.y * v.y * rs; acc.z += dn.z * v.z * rs; acc.w += dn.w * v.w * rs;
+        const float4 dg = make_float4(dn.x * g.x, dn.y * g.y, dn.z * g.z, dn.w * g.w);
+        const float k = sum16(dg.x * v.x + dg.y * v.y + dg.z * v.z + dg.w * v.w) * (1.f / 64.f) * rs * rs * rs;
+        st4(a.dx + row * a.lddx + col, make_float4(rs * dg.x - v.x * k, rs * dg.y - v.y * k, rs * dg.z - v.z * k, rs * dg.w - v.w * k));
     }
-    // one atomic per column per WORKGROUP (4096 waves hammering 64 addresses cost 100 us; see profiles/r01)
-    __shared__ float red[4][64];
-    red[threadIdx.x >> 6][lane] = acc_g;
+    st4(&red[threadIdx.x >> 4][sub * 4], acc);
     __syncthreads();
-    if (threadIdx.x < 64) atomicAdd(&dgain[lane], red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+    if (threadIdx.x < 64) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += red[i][threadIdx.x];
+        atomicAdd(&a.dgain[part][threadIdx.x], s);
+    }
 }
 
 // ------------------------------------------------------------------ GroupNorm(1,C) per 512-frame chunk + ReLU
@@ -440,30 +460,36 @@ extern "C" int kk_rmsnorm_bwd(const float *dy, const float *x, const float *gain
     return 0;
 }
 
-extern "C" int kk_headnorm_rope_fwd(const float *x, int64_t ldx, const float *gain, float *y, int64_t ldy,
-                                    int64_t rows, int heads, int S, const float *cos_t, const float *sin_t,
-                                    void *stream) {
-    KK_REQUIRE(rows > 0 && heads > 0 && S > 0, "kk_headnorm_rope_fwd: bad shape");
-    KK_REQUIRE((cos_t == nullptr) == (sin_t == nullptr), "kk_headnorm_rope_fwd: cos/sin must both be set or null");
-    const int64_t npairs = rows * heads;
-    int blocks = kk_cdiv(npairs, 4);
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(headnorm_rope_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, gain, y, ldy,
-                       npairs, heads, S, cos_t, sin_t);
+extern "C" int kk_headnorm_rope_fwd(const float *x, int64_t ldx, float *y, int64_t ldy, int64_t rows, int heads, int S,
+                                    int parts, const float *gain0, const float *gain1, const float *gain2, int rope_mask,
+                                    const float *cos_t, const float *sin_t, void *stream) {
+    KK_REQUIRE(rows > 0 && heads > 0 && S > 0 && parts >= 1 && parts <= 3 && gain0, "kk_headnorm_rope_fwd: bad shape");
+    KK_REQUIRE(rope_mask == 0 || (cos_t && sin_t), "kk_headnorm_rope_fwd: RoPE needs cos/sin tables");
+    KK_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "kk_headnorm_rope_fwd: strides must be multiples of 4");
+    HeadNormArgs a = {};
+    a.x = x; a.y = y; a.cos_t = cos_t; a.sin_t = sin_t; a.gain[0] = gain0; a.gain[1] = gain1; a.gain[2] = gain2;
+    a.ldx = ldx; a.ldy = ldy; a.npairs = rows * heads; a.heads = heads; a.S = S; a.rope_mask = rope_mask;
+    int blocks = kk_cdiv(a.npairs, 16 * 2);
+    blocks = blocks > 2048 ? 2048 : (blocks < 1 ? 1 : blocks);
+    hipLaunchKernelGGL(headnorm_rope_fwd_kernel, dim3(blocks, parts), dim3(256), 0, (hipStream_t)stream, a);
     KK_LAUNCH_CHECK("kk_headnorm_rope_fwd");
     return 0;
 }
 
-extern "C" int kk_headnorm_rope_bwd(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *gain,
-                                    float *dx, int64_t lddx, float *dgain, int64_t rows, int heads, int S,
+extern "C" int kk_headnorm_rope_bwd(const float *dy, int64_t lddy, const float *x, int64_t ldx, float *dx, int64_t lddx,
+                                    int64_t rows, int heads, int S, int parts, const float *gain0, const float *gain1,
+                                    const float *gain2, float *dgain0, float *dgain1, float *dgain2, int rope_mask,
                                     const float *cos_t, const float *sin_t, void *stream) {
-    KK_REQUIRE(rows > 0 && heads > 0 && S > 0, "kk_headnorm_rope_bwd: bad shape");
-    const int64_t npairs = rows * heads;
-    int blocks = kk_cdiv(npairs, 16);
-    if (blocks > 512) blocks = 512;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(headnorm_rope_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, lddy, x, ldx, gain,
-                       dx, lddx, dgain, npairs, heads, S, cos_t, sin_t);
+    KK_REQUIRE(rows > 0 && heads > 0 && S > 0 && parts >= 1 && parts <= 3 && gain0 && dgain0, "kk_headnorm_rope_bwd: bad shape");
+    KK_REQUIRE(rope_mask == 0 || (cos_t && sin_t), "kk_headnorm_rope_bwd: RoPE needs cos/sin tables");
+    KK_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "kk_headnorm_rope_bwd: strides must be multiples of 4");
+    HeadNormArgs a = {};
+    a.x = x; a.dy = dy; a.dx = dx; a.cos_t = cos_t; a.sin_t = sin_t;
+    a.gain[0] = gain0; a.gain[1] = gain1; a.gain[2] = gain2; a.dgain[0] = dgain0; a.dgain[1] = dgain1; a.dgain[2] = dgain2;
+    a.ldx = ldx; a.lddy = lddy; a.lddx = lddx; a.npairs = rows * heads; a.heads = heads; a.S = S; a.rope_mask = rope_mask;
+    int blocks = kk_cdiv(a.npairs, 16 * 8);
+    blocks = blocks > 512 ? 512 : (blocks < 1 ? 1 : blocks);
+    hipLaunchKernelGGL(headnorm_rope_bwd_kernel, dim3(blocks, parts), dim3(256), 0, (hipStream_t)stream, a);
     KK_LAUNCH_CHECK("kk_headnorm_rope_bwd");
     return 0;
 }

@@ -172,13 +172,14 @@ class KokoroEngine:
     def _linear(self, x, W, b, out, res=None, res_mod=0):
         N, K = x.shape
         M = W.shape[0]
+        # split_k = 0: kk_gemm splits K (fp32 atomics) by itself when the tile grid is too small to fill the chip
         kk.call("kk_gemm", 0, 0, N, M, K, 1.0, x, x.stride(0), W, K, 0.0, out, out.stride(0), b, res,
-                res.stride(0) if res is not None else 0, res_mod, 1, self.math)
+                res.stride(0) if res is not None else 0, res_mod, 0, self.math)
 
     def _dgrad(self, dy, W, dx, beta=0.0):
         N, M = dy.shape
         K = W.shape[1]
-        kk.call("kk_gemm", 0, 1, N, K, M, 1.0, dy, dy.stride(0), W, K, beta, dx, dx.stride(0), None, None, 0, 0, 1, self.math)
+        kk.call("kk_gemm", 0, 1, N, K, M, 1.0, dy, dy.stride(0), W, K, beta, dx, dx.stride(0), None, None, 0, 0, 0, self.math)
 
     def _wgrad(self, dy, x, dW, db=None):
         N, M = dy.shape
@@ -233,9 +234,12 @@ class KokoroEngine:
             self._linear(xq, P[prefix + ".w_q.weight"], None, q_raw)
             self._linear(xkv, a.fused(a.p, prefix + ".w_k.weight", 2), None, kv_raw)
             k_raw, v_raw, k_n, v_n = kv_raw, kv_raw[:, H:], kv_n, kv_n[:, H:]
-        kk.call("kk_headnorm_rope_fwd", q_raw, q_raw.stride(0), P[prefix + ".q_norm.weight"], q_n, q_n.stride(0), Nq, h, Sq, cos, sin)
-        kk.call("kk_headnorm_rope_fwd", k_raw, k_raw.stride(0), P[prefix + ".k_norm.weight"], k_n, k_n.stride(0), Nk, h, Sk, cos, sin)
-        kk.call("kk_headnorm_rope_fwd", v_raw, v_raw.stride(0), P[prefix + ".v_norm.weight"], v_n, v_n.stride(0), Nk, h, Sk, None, None)
+        gq, gk, gv = P[prefix + ".q_norm.weight"], P[prefix + ".k_norm.weight"], P[prefix + ".v_norm.weight"]
+        if xkv is None:       # q|k|v in one launch over the fused projection; RoPE on q and k only
+            kk.call("kk_headnorm_rope_fwd", raw, 3 * H, nrm, 3 * H, Nq, h, Sq, 3, gq, gk, gv, 3 if rope else 0, cos, sin)
+        else:
+            kk.call("kk_headnorm_rope_fwd", q_raw, H, q_n, H, Nq, h, Sq, 1, gq, None, None, 0, None, None)
+            kk.call("kk_headnorm_rope_fwd", kv_raw, 2 * H, kv_n, 2 * H, Nk, h, Sk, 2, gk, gv, None, 0, None, None)
         ctx, lse = self._buf(key + ".ctx", Nq, H), self._buf(key + ".lse", B, h, Sq)
         kk.call("kk_attn_fwd", q_n, k_n, v_n, ctx, lse, B, h, Sq, Sk, q_n.stride(0), k_n.stride(0), v_n.stride(0), H, key_mask,
                 1 if causal else 0, 0.125, self.rng, site + 3, p, self.math)
@@ -279,12 +283,15 @@ class KokoroEngine:
                 key_mask, 1 if causal else 0, 0.125, self.rng, site + 3, p, self.math)
         kk.call("kk_attn_bwd_dkv", q_n, k_n, v_n, dctx, lse, delta, dk_n, dv_n, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H,
                 ld(dk_n), ld(dv_n), key_mask, 1 if causal else 0, 0.125, self.rng, site + 3, p, self.math)
-        kk.call("kk_headnorm_rope_bwd", dq_n, ld(dq_n), q_raw, ld(q_raw), P[prefix + ".q_norm.weight"], dq_raw, ld(dq_raw),
-                G[prefix + ".q_norm.weight"], Nq, h, Sq, cos, sin)
-        kk.call("kk_headnorm_rope_bwd", dk_n, ld(dk_n), k_raw, ld(k_raw), P[prefix + ".k_norm.weight"], dk_raw, ld(dk_raw),
-                G[prefix + ".k_norm.weight"], Nk, h, Sk, cos, sin)
-        kk.call("kk_headnorm_rope_bwd", dv_n, ld(dv_n), v_raw, ld(v_raw), P[prefix + ".v_norm.weight"], dv_raw, ld(dv_raw),
-                G[prefix + ".v_norm.weight"], Nk, h, Sk, None, None)
+        gq, gk, gv = P[prefix + ".q_norm.weight"], P[prefix + ".k_norm.weight"], P[prefix + ".v_norm.weight"]
+        dgq, dgk, dgv = G[prefix + ".q_norm.weight"], G[prefix + ".k_norm.weight"], G[prefix + ".v_norm.weight"]
+        if xkv is None:
+            kk.call("kk_headnorm_rope_bwd", dn, 3 * H, raw, 3 * H, draw, 3 * H, Nq, h, Sq, 3, gq, gk, gv, dgq, dgk, dgv,
+                    3 if rope else 0, cos, sin)
+        else:
+            kk.call("kk_headnorm_rope_bwd", dq_n, H, q_raw, H, dq_raw, H, Nq, h, Sq, 1, gq, None, None, dgq, None, None, 0, None, None)
+            kk.call("kk_headnorm_rope_bwd", dkv_n, 2 * H, kv_raw, 2 * H, dkv_raw, 2 * H, Nk, h, Sk, 2, gk, gv, None, dgk, dgv, None,
+                    0, None, None)
         if xkv is None:
             self._wgrad(draw, xq, a.fused(a.g, prefix + ".w_q.weight", 3))
             self._dgrad(draw, a.fused(a.p, prefix + ".w_q.weight", 3), d_xq)

@@ -200,28 +200,40 @@ def test_rmsnorm_residual(kk, rows, H):
 
 
 @pytest.mark.parametrize("rope", [0, 1])
-def test_headnorm_rope(kk, rope):
+def test_headnorm_rope_fused_qkv(kk, rope):
+    """q|k|v thirds of a fused [rows, 3H] projection in one launch: own gains, RoPE on q and k only."""
     B, S, h = 2, 50, 3
     H = h * 64
     g = torch.Generator().manual_seed(9 + rope)
-    x = torch.randn(B * S, 3 * H, generator=g)                 # operate on the middle third (ld = 3H)
-    gain, dy = torch.rand(64, generator=g) + 0.5, torch.randn(B * S, H, generator=g)
+    x = torch.randn(B * S, 3 * H, generator=g)
+    gains = [torch.rand(64, generator=g) + 0.5 for _ in range(3)]
+    dy = torch.randn(B * S, 3 * H, generator=g)
     cos, sin = O.rope_tables(S, 64)
-    xr, gr = x.clone().requires_grad_(True), gain.clone().requires_grad_(True)
-    n = O._rms_norm(xr[:, H:2 * H].view(B, S, h, 64), gr)
-    if rope:
-        n = n * cos[None, :, None, :] + O._rotate_half(n) * sin[None, :, None, :]
-    n = n.reshape(B * S, H)
-    n.backward(dy)
-    xd = dev(x)
-    y = torch.empty(B * S, H, device="cuda")
-    ct, st_ = (dev(cos), dev(sin)) if rope else (None, None)
-    kk.call("kk_headnorm_rope_fwd", xd[:, H:], 3 * H, dev(gain), y, H, B * S, h, S, ct, st_)
-    close(y, n, 2e-5, 2e-5, "headnorm fwd")
-    dx, dg = torch.zeros(B * S, 3 * H, device="cuda"), torch.zeros(64, device="cuda")
-    kk.call("kk_headnorm_rope_bwd", dev(dy), H, xd[:, H:], 3 * H, dev(gain), dx[:, H:], 3 * H, dg, B * S, h, S, ct, st_)
+    xr = x.clone().requires_grad_(True)
+    gr = [t.clone().requires_grad_(True) for t in gains]
+    outs = []
+    for j in range(3):
+        n = O._rms_norm(xr[:, j * H:(j + 1) * H].view(B, S, h, 64), gr[j])
+        if rope and j < 2:
+            n = n * cos[None, :, None, :] + O._rotate_half(n) * sin[None, :, None, :]
+        outs.append(n.reshape(B * S, H))
+    ref = torch.cat(outs, 1)
+    ref.backward(dy)
+    xd, y = dev(x), torch.empty(B * S, 3 * H, device="cuda")
+    gd = [dev(t) for t in gains]
+    ct, st_ = dev(cos), dev(sin)
+    kk.call("kk_headnorm_rope_fwd", xd, 3 * H, y, 3 * H, B * S, h, S, 3, gd[0], gd[1], gd[2], 3 if rope else 0, ct, st_)
+    close(y, ref, 2e-5, 2e-5, "headnorm fwd")
+    dx, dg = torch.zeros(B * S, 3 * H, device="cuda"), [torch.zeros(64, device="cuda") for _ in range(3)]
+    kk.call("kk_headnorm_rope_bwd", dev(dy), 3 * H, xd, 3 * H, dx, 3 * H, B * S, h, S, 3, gd[0], gd[1], gd[2], dg[0], dg[1], dg[2],
+            3 if rope else 0, ct, st_)
     close(dx, xr.grad, 1e-4, 1e-4, "headnorm dx")
-    close(dg, gr.grad, 1e-3, 1e-4, "headnorm dgain")
+    for j in range(3):
+        close(dg[j], gr[j].grad, 1e-3, 1e-4, f"headnorm dgain{j}")
+    # single part with a row stride (cross-attention q) and the 2-part k|v form
+    y1 = torch.empty(B * S, H, device="cuda")
+    kk.call("kk_headnorm_rope_fwd", xd[:, H:], 3 * H, y1, H, B * S, h, S, 1, gd[1], None, None, 1 if rope else 0, ct, st_)
+    close(y1, ref[:, H:2 * H], 2e-5, 2e-5, "headnorm single part, strided")
 
 
 def test_glu(kk):
