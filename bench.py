@@ -45,13 +45,14 @@ def kernel_table(records, math_bf16: bool):
             tile = 128 if -(-M // 128) * -(-N // 128) >= 512 else 64          # same rule as kk_gemm
             key = GEMM_SYMBOL[(ta, tb)].format(b="true" if math_bf16 else "false", t=tile)
             flops = 2.0 * M * N * K
-            byts = 4.0 * (M * K + N * K + M * N)
+            dt = int(sc[-1])               # storage bits: A, B, C bf16
+            byts = (2.0 if dt & 1 else 4.0) * M * K + (2.0 if dt & 2 else 4.0) * N * K + (2.0 if dt & 4 else 4.0) * M * N
         elif name in ("kk_attn_fwd", "kk_attn_bwd_dq", "kk_attn_bwd_dkv"):
             B, h, Sq, Sk = (int(x) for x in sc[:4])
-            causal = int(sc[-5])           # (..., causal, scale, site, p_drop, math)
+            causal = int(sc[-6])           # (..., causal, scale, site, p_drop, math, io_bf16)
             mm = {"kk_attn_fwd": 2, "kk_attn_bwd_dq": 3, "kk_attn_bwd_dkv": 4}[name]   # matmuls of Sq x Sk x 64
             flops = mm * 2.0 * B * h * Sq * Sk * 64 * (0.5 if causal else 1.0)
-            byts = 4.0 * B * h * 64 * (2 * Sq + 2 * Sk)
+            byts = (2.0 if int(sc[-1]) else 4.0) * B * h * 64 * (2 * Sq + 2 * Sk)
         keys = [key]
         if name == "kk_gemm":
             keys.append(f"  shape ta={ta} tb={tb} M={M} N={N} K={K}")
@@ -95,6 +96,8 @@ def main():
     ap.add_argument("--frames", type=int, default=512)
     ap.add_argument("--phonemes", type=int, default=64)
     ap.add_argument("--math", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--storage", choices=["auto", "f32", "bf16", "bf16-dec"], default="auto",
+                    help="GEMM/attention operand storage in HBM (auto: bf16 in the bf16 mode)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="parity configuration (p = 0 everywhere)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -112,7 +115,8 @@ def main():
     torch.cuda.set_device(local)
     B, T, P = args.batch, args.frames, args.phonemes
     hp = StepHyper(gradient_accumulation_steps=1)
-    eng = KokoroEngine(ModelDims(), hp, math_mode=args.math, total_steps=20000, seed=0)   # same seed ⇒ identical replicas
+    eng = KokoroEngine(ModelDims(), hp, math_mode=args.math, total_steps=20000, seed=0,
+                       storage=args.storage)                           # same seed ⇒ identical replicas
     eng.train_dropout = not args.no_dropout          # reference-faithful: dropout, stochastic depth, SpecAugment on
     sync = dp.GradSync(world)
     eng.dp_loss_scale = sync.loss_scale
@@ -174,6 +178,7 @@ def main():
     out = {"metric": "mel-frames/sec (full train step)", "value": round(frames / dt, 1), "unit": "mel-frames/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.math, "data": "synthetic",
+           "storage": eng.storage,
            "per_gpu": round(frames / dt / world, 1),
            "config": {"workload": f"kokoro acoustic-model train step, {B}x{T} mel frames x {P} phonemes per GPU "
                                   f"(BASELINE configs[1]), 49.4M params, fwd+loss+bwd+clip+AdamW+EMA every step",

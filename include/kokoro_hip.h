@@ -36,15 +36,25 @@ const char *kk_last_error(void);
  * C[M,N] = alpha * op(A)·op(B) (+bias[n]) (+residual[(m % res_mod), n]) (+ beta*C).
  * ta=0: A stored [M,K] (lda, K contiguous); ta=1: A stored [K,M] (M contiguous).
  * tb=0: B stored [N,K] (nn.Linear weight layout);  tb=1: B stored [K,N].
- * split_k>1 partitions K over blockIdx.z and accumulates with fp32 atomics (requires beta==1 or a
+ * dtypes (KK_MATH_BF16 only): bit0 = A is stored as bf16, bit1 = B is bf16, bit2 = C is written as bf16
+ * (pointers are then bf16 arrays passed through the float* parameters; lda/ldb/ldc stay in elements).
+ * split_k>1 partitions K over blockIdx.y and accumulates with fp32 atomics (requires beta==1 or a
  * contiguous C that the call zero-fills when beta==0; bias/residual are added by slice 0). */
 int kk_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, const float *A, int64_t lda,
             const float *B, int64_t ldb, float beta, float *C, int64_t ldc, const float *bias,
-            const float *residual, int64_t ldr, int64_t res_mod, int split_k, int math, void *stream);
+            const float *residual, int64_t ldr, int64_t res_mod, int split_k, int math, int dtypes,
+            void *stream);
 /* tuning hook for benchmarks: 128x128-tile threshold (tile count) and XCD-aware tile order on/off */
 int kk_gemm_tune(int tm_threshold, int xcd_swizzle);
 /* out[n] += sum_m X[m,n]  (bias gradients). */
-int kk_colsum_acc(const float *X, int64_t ldx, int64_t M, int64_t N, float *out, void *stream);
+int kk_colsum_acc(const float *X, int64_t ldx, int64_t M, int64_t N, float *out, int x_bf16, void *stream);
+
+/* ---- activation storage ----
+ * Tensors are fp32 unless a trailing `*_bf16` flag of the entry point says otherwise.  A non-zero flag means the
+ * named operands (x / y / io = every activation operand of the call) are bf16 in HBM (2 bytes per element, same
+ * strides counted in elements); statistics, gains, parameter gradients and index tensors stay fp32 / integer.
+ * The fp32 parity mode passes 0 everywhere; the bf16 mode stores GEMM and attention operands as bf16 so that the
+ * MFMA kernels load their fragments without conversion and every activation round trip moves half the bytes. */
 
 /* ---- attention (F.scaled_dot_product_attention, transformers.py:393-398; masks :299-316) ----
  * Token-major operands: element (b, s, head, d) of X lives at X[(b*S + s)*ldx + head*64 + d]; head_dim is 64.
@@ -55,50 +65,50 @@ int kk_colsum_acc(const float *X, int64_t ldx, int64_t M, int64_t N, float *out,
 int kk_attn_fwd(const float *Q, const float *K, const float *V, float *O, float *LSE, int B, int heads,
                 int Sq, int Sk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                 const uint8_t *key_mask, int causal, float scale, const uint32_t *seed, uint32_t site,
-                float p_drop, int math, void *stream);
+                float p_drop, int math, int io_bf16, void *stream);
 /* Delta[b,head,q] = sum_d dO·O (first step of the backward). */
 int kk_attn_delta(const float *O, const float *dO, float *Delta, int B, int heads, int Sq, int64_t ldo,
-                  int64_t lddo, void *stream);
+                  int64_t lddo, int io_bf16, void *stream);
 int kk_attn_bwd_dq(const float *Q, const float *K, const float *V, const float *dO, const float *LSE,
                    const float *Delta, float *dQ, int B, int heads, int Sq, int Sk, int64_t ldq, int64_t ldk,
                    int64_t ldv, int64_t lddo, int64_t lddq, const uint8_t *key_mask, int causal, float scale,
-                   const uint32_t *seed, uint32_t site, float p_drop, int math, void *stream);
+                   const uint32_t *seed, uint32_t site, float p_drop, int math, int io_bf16, void *stream);
 int kk_attn_bwd_dkv(const float *Q, const float *K, const float *V, const float *dO, const float *LSE,
                     const float *Delta, float *dK, float *dV, int B, int heads, int Sq, int Sk, int64_t ldq,
                     int64_t ldk, int64_t ldv, int64_t lddo, int64_t lddk, int64_t lddv,
                     const uint8_t *key_mask, int causal, float scale, const uint32_t *seed, uint32_t site,
-                    float p_drop, int math, void *stream);
+                    float p_drop, int math, int io_bf16, void *stream);
 
 /* ---- norms ----
  * LayerNorm (nn.LayerNorm eps 1e-5; transformers.py:461-462,518-520,612; model.py:122). */
 int kk_layernorm_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean,
-                     float *rstd, int64_t rows, int H, void *stream);
+                     float *rstd, int64_t rows, int H, int y_bf16, void *stream);
 int kk_layernorm_bwd(const float *dy, const float *x, const float *gamma, const float *mean,
                      const float *rstd, float *dx, int dx_accumulate, float *dgamma, float *dbeta,
-                     int64_t rows, int H, void *stream);
+                     int64_t rows, int H, int dy_bf16, void *stream);
 /* RMSNorm over the full row, eps = FLT_EPSILON (GLU output_norm, transformers.py:94,109-110), fused with the
  * residual add of the block: y = (residual? residual : 0) + x*rstd*gain. */
 int kk_rmsnorm_fwd(const float *x, const float *gain, const float *residual, float *y, float *rstd,
-                   int64_t rows, int H, void *stream);
+                   int64_t rows, int H, int x_bf16, void *stream);
 int kk_rmsnorm_bwd(const float *dy, const float *x, const float *gain, const float *rstd, float *dx,
-                   float *dgain, int64_t rows, int H, void *stream);
+                   float *dgain, int64_t rows, int H, int x_bf16, void *stream);
 /* Per-head (64-wide) RMSNorm + optional RoPE rotate-half (transformers.py:260-277; positional_encoding.py:196-209)
  * over up to three column groups ("parts", e.g. q|k|v of a fused projection): element (row, part, head, d) at
  * [row*ld + part*heads*64 + head*64 + d]; gain_j / dgain_j belong to part j; bit j of rope_mask enables RoPE for
  * part j; position = row % S; cos/sin tables are [>=S, 64].  dgain_j accumulate (+=). */
 int kk_headnorm_rope_fwd(const float *x, int64_t ldx, float *y, int64_t ldy, int64_t rows, int heads, int S,
                          int parts, const float *gain0, const float *gain1, const float *gain2, int rope_mask,
-                         const float *cos_t, const float *sin_t, void *stream);
+                         const float *cos_t, const float *sin_t, int io_bf16, void *stream);
 int kk_headnorm_rope_bwd(const float *dy, int64_t lddy, const float *x, int64_t ldx, float *dx, int64_t lddx,
                          int64_t rows, int heads, int S, int parts, const float *gain0, const float *gain1,
                          const float *gain2, float *dgain0, float *dgain1, float *dgain2, int rope_mask,
-                         const float *cos_t, const float *sin_t, void *stream);
+                         const float *cos_t, const float *sin_t, int io_bf16, void *stream);
 
 /* ---- GLU feed-forward gate (transformers.py:107-108; exact-erf GELU): g = gelu(h[:, :F]) * h[:, F:] ---- */
 int kk_glu_fwd(const float *h, float *g, int64_t rows, int F, const uint32_t *seed, uint32_t site, float p,
-               void *stream);
+               int io_bf16, void *stream);
 int kk_glu_bwd(const float *dg, const float *h, float *dh, int64_t rows, int F, const uint32_t *seed, uint32_t site,
-               float p, void *stream);
+               float p, int io_bf16, void *stream);
 
 /* ---- embeddings + sinusoid PE (model.py:375-378; positional_encoding.py:66-74) ---- */
 int kk_embed_fwd(const int64_t *ids, const int64_t *stress, const float *emb, const float *stress_emb,
@@ -120,8 +130,8 @@ int kk_max_i64(const int64_t *x, int64_t n, int64_t *out, void *stream);
 
 /* ---- variance adaptor pieces (variance_predictor.py:89-115, 363-437) ---- */
 /* col[(b,l), c*3+k] = x[b, l+k-1, c] inside the 512-frame chunk of l, else 0. */
-int kk_im2col3_fwd(const float *x, float *col, int B, int L, int C, int chunk, void *stream);
-int kk_im2col3_bwd(const float *dcol, float *dx, int B, int L, int C, int chunk, void *stream);
+int kk_im2col3_fwd(const float *x, float *col, int B, int L, int C, int chunk, int col_bf16, void *stream);
+int kk_im2col3_bwd(const float *dcol, float *dx, int B, int L, int C, int chunk, int dcol_bf16, void *stream);
 /* GroupNorm(1,C) over (C x chunk frames) per sample per chunk + ReLU; chunks with < 2 frames yield zeros.
  * stats [B*nchunks, 2] = (mean, rstd). */
 int kk_groupnorm_relu_fwd(const float *x, const float *gamma, const float *beta, float *y, float *stats,
@@ -132,14 +142,14 @@ int kk_groupnorm_relu_bwd(const float *dy, const float *x, const float *y, const
                           int L, int C, int chunk, float p, void *stream);
 /* out[r] = mask[r] ? 0 : dot(x[r,:], w) + b  (Linear(C->1) + masked_fill; also the stop head, model.py:562). */
 int kk_rowdot_fwd(const float *x, const float *w, const float *b, const uint8_t *mask, float *out,
-                  int64_t rows, int C, int L, int chunk, void *stream);
+                  int64_t rows, int C, int L, int chunk, int x_bf16, void *stream);
 int kk_rowdot_bwd(const float *dout, const float *x, const float *w, const uint8_t *mask, float *dx,
-                  float *dw, float *db, int64_t rows, int C, int L, int chunk, void *stream);
+                  float *dw, float *db, int64_t rows, int C, int L, int chunk, int x_bf16, void *stream);
 /* frame_mask[b,f] = f >= lens[b]; bucketize(right=False) + two embedding adds + masked_fill. */
 int kk_bucket_embed_add_fwd(const float *x, const float *pitch, const float *energy, const float *pbins,
                             const float *ebins, const float *pemb, const float *eemb, const int64_t *lens,
                             float *out, int32_t *pidx, int32_t *eidx, uint8_t *frame_mask, int B, int T,
-                            int H, int nbins, void *stream);
+                            int H, int nbins, int out_bf16, void *stream);
 int kk_bucket_embed_add_bwd(const float *dout, const int32_t *pidx, const int32_t *eidx,
                             const uint8_t *frame_mask, float *dpemb, float *deemb, int B, int T, int H,
                             void *stream);
@@ -158,7 +168,7 @@ int kk_dropout_bwd(const float *dy, float *dx, int64_t rows, int H, int S, const
                    float p1, uint32_t site2, float p2, uint32_t site_dp, float dp_rate, void *stream);
 /* SpecAugment on the cross-attention memory, in place (trainer.py:1577-1604); call again on the memory gradient. */
 int kk_specaug(float *x, int B, int T, int H, const uint32_t *seed, uint32_t site, int time_mask_max,
-               int feat_mask_max, int n_time, int n_feat, void *stream);
+               int feat_mask_max, int n_time, int n_feat, int x_bf16, void *stream);
 
 /* ---- losses (training/losses.py:9-216) ----
  * acc: 10 doubles (5 sums, 5 counts) zeroed by the call.  losses: 6 floats (total, mel, dur, stop, pitch, energy).
@@ -224,14 +234,19 @@ int kk_opt_prepare(const double *grad_sumsq, const float *seg_preclip, const flo
                    double *opt_state, float *seg_gscale, float *seg_decay, float *seg_stepsize,
                    float *step_consts /* [4]: skip, sqrt(1-beta2^t), eps, base_lr */, void *stream);
 /* Fused single pass: p,g,m,v,(ema) -> p,m,v,(ema).  seg_flags bit0: AdamW-updated, bit1: EMA-tracked,
- * bit2: weight-norm target (its post-step sum of squares is accumulated into p_sumsq, zeroed by the call). */
+ * bit2: weight-norm target (its post-step sum of squares is accumulated into p_sumsq, zeroed by the call).
+ * p_bf16 (optional): bf16 shadow of the arena, same element offsets, rewritten wherever p is (the bf16 mode's
+ * GEMMs read weights from it). */
 int kk_adamw_ema(float *p, const float *g, float *m, float *v, float *ema, const int32_t *block_seg,
                  int64_t nblocks, const float *seg_gscale, const float *seg_decay, const float *seg_stepsize,
                  const int32_t *seg_flags, const float *step_consts, float beta1, float beta2,
-                 float ema_decay, double *p_sumsq, int nseg, void *stream);
+                 float ema_decay, double *p_sumsq, int nseg, void *p_bf16, void *stream);
 /* FFN weight-norm projection: for flagged segments with ||W|| > max: W *= max/||W||. */
 int kk_weight_norm_project(float *p, const int32_t *block_seg, int64_t nblocks, const double *p_sumsq,
-                           const int32_t *seg_flags, const float *step_consts, double max_norm, void *stream);
+                           const int32_t *seg_flags, const float *step_consts, double max_norm, void *p_bf16,
+                           void *stream);
+/* dst (bf16) = src (fp32), n % 4 == 0: builds the weight shadow after a checkpoint load. */
+int kk_cast_f32_bf16(const float *src, void *dst, int64_t n, void *stream);
 
 /* ---- misc ---- */
 int kk_axpby(float a, const float *x, float b, float *y, int64_t n, void *stream); /* y = a*x + b*y */

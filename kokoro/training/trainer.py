@@ -113,20 +113,19 @@ class KokoroTrainer:
         if not self.val_dataset or len(self.val_dataset) == 0:
             return None
         e = self.engine
-        saved_math, saved_p = e.math, None
-        e.math = kk.KK_MATH_F32                              # validation runs without autocast (trainer.py:1821-1834)
+        saved_p = None
         if e.arena.ema is not None:
             saved_p = e.arena.p.clone()
             e.arena.p.copy_(e.arena.ema)                     # evaluate the EMA replica
         tot, n = torch.zeros(6, device=e.device), 0
         bs = max(1, self.config.batch_size)
-        for i in range(0, len(self.val_dataset), bs):
-            batch = cap_batch(self._to_device(collate_fn([self.val_dataset[j] for j in range(i, min(i + bs, len(self.val_dataset)))])))
-            tot += e.forward_backward(batch, backward=False)["losses"]
-            n += 1
+        with e.fp32_math():                                  # validation runs without autocast (trainer.py:1821-1834)
+            for i in range(0, len(self.val_dataset), bs):
+                batch = cap_batch(self._to_device(collate_fn([self.val_dataset[j] for j in range(i, min(i + bs, len(self.val_dataset)))])))
+                tot += e.forward_backward(batch, backward=False)["losses"]
+                n += 1
         if saved_p is not None:
-            e.arena.p.copy_(saved_p)
-        e.math = saved_math
+            e.arena.p.copy_(saved_p)                         # (the bf16 weight shadow was never touched)
         v = (tot / n).cpu().tolist()
         return dict(zip(("total", "mel", "dur", "stop", "pitch", "energy"), v))
 

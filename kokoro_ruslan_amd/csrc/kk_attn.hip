@@ -19,6 +19,7 @@
 // KK_MATH_BF16 rounds Q/K/V/P/dS/dO to bf16 for the MFMAs and keeps scores, softmax and accumulators in fp32.
 #include "kk_common.h"
 #include <math.h>
+#include <type_traits>
 
 namespace {
 
@@ -27,8 +28,10 @@ template <> struct ACfg<true> { typedef __bf16 elem; static constexpr int LR = 7
 template <> struct ACfg<false> { typedef float elem; static constexpr int LR = 65; };
 
 struct AttnArgs {
-    const float *Q, *K, *V, *O, *dO, *LSE, *Delta;
-    float *Out, *Out2, *LSEo;
+    const void *Q, *K, *V, *O, *dO;      // fp32, or bf16 when the kernel is instantiated with ST16 (bf16 storage)
+    const float *LSE, *Delta;
+    void *Out, *Out2;
+    float *LSEo;
     const uint8_t *key_mask;
     int B, heads, Sq, Sk, causal;
     int64_t ldq, ldk, ldv, ldo, lddo, ldout, ldout2;
@@ -65,21 +68,33 @@ template <bool BF16> struct RowFrag;
 template <> struct RowFrag<true> { bf16x8 v[4]; };    // v[ks][j] = X[row][16 ks + 8 half + j]
 template <> struct RowFrag<false> { float v[32]; };   // v[ks]    = X[row][2 ks + half]
 
-template <bool BF16>
-__device__ __forceinline__ void load_rowfrag(RowFrag<BF16> &f, const float *rowptr, int half) {
-    if constexpr (BF16) {
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+template <bool BF16, typename T>
+__device__ __forceinline__ void load_rowfrag(RowFrag<BF16> &f, const T *rowptr, int half) {
+    if constexpr (BF16 && sizeof(T) == 2) {            // bf16 storage: the fragment is a plain 16-byte load
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (rowptr) v = *reinterpret_cast<const u32x4 *>(rowptr + ks * 16 + half * 8);
+            f.v[ks] = __builtin_bit_cast(bf16x8, v);
+        }
+    } else if constexpr (BF16) {
+        const float *rp = reinterpret_cast<const float *>(rowptr);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-            if (rowptr) { a = ld4(rowptr + ks * 16 + half * 8); b = ld4(rowptr + ks * 16 + half * 8 + 4); }
+            if (rp) { a = ld4(rp + ks * 16 + half * 8); b = ld4(rp + ks * 16 + half * 8 + 4); }
 #pragma unroll
             for (int e = 0; e < 4; ++e) { f.v[ks][e] = (__bf16)f4g(a, e); f.v[ks][4 + e] = (__bf16)f4g(b, e); }
         }
     } else {
+        const float *rp = reinterpret_cast<const float *>(rowptr);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rowptr) a = ld4(rowptr + 4 * j);
+            if (rp) a = ld4(rp + 4 * j);
             f.v[2 * j] = half ? a.y : a.x;
             f.v[2 * j + 1] = half ? a.w : a.z;
         }
@@ -136,6 +151,57 @@ __device__ __forceinline__ void store_rows_T(__bf16 *St, const TileRegs &t) {
         *reinterpret_cast<bf16x4 *>(&St[(dg + e) * LR + rg]) = v;
     }
 }
+
+// The same two staging patterns for tiles that are ALREADY bf16 in HBM (bf16 storage): no conversion, half the bytes.
+struct TileRegs16 { u32x4 r[2]; };     // "rows" pattern: 16 contiguous bf16 of one row
+struct TileRegs16T { u32x2 r[4]; };    // "rows_T" pattern: 4 rows x 4 contiguous bf16
+
+__device__ __forceinline__ void load_rows(TileRegs16 &t, const __bf16 *src, int64_t ld, int nvalid) {
+    const int row = threadIdx.x >> 2, seg = (threadIdx.x & 3) * 16;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) t.r[i] = row < nvalid ? *reinterpret_cast<const u32x4 *>(src + (int64_t)row * ld + seg + 8 * i) : z;
+}
+__device__ __forceinline__ void store_rows16(__bf16 *S, const TileRegs16 &t) {
+    constexpr int LR = ACfg<true>::LR;
+    const int row = threadIdx.x >> 2, seg = (threadIdx.x & 3) * 16;
+    *reinterpret_cast<u32x4 *>(&S[row * LR + seg]) = t.r[0];
+    *reinterpret_cast<u32x4 *>(&S[row * LR + seg + 8]) = t.r[1];
+}
+__device__ __forceinline__ void load_rows_T(TileRegs16T &t, const __bf16 *src, int64_t ld, int nvalid) {
+    const int rg = (threadIdx.x & 15) * 4, dg = (threadIdx.x >> 4) * 4;
+    const u32x2 z = {0u, 0u};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) t.r[c] = (rg + c) < nvalid ? *reinterpret_cast<const u32x2 *>(src + (int64_t)(rg + c) * ld + dg) : z;
+}
+__device__ __forceinline__ void store_rows_T16(__bf16 *St, const TileRegs16T &t) {
+    constexpr int LR = ACfg<true>::LR;
+    const int rg = (threadIdx.x & 15) * 4, dg = (threadIdx.x >> 4) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {        // element e of rows 0..3 -> 4 contiguous bf16 of transposed row dg+e
+        const int w = e >> 1, sh = 16 * (e & 1);
+        u32x2 v;
+        v[0] = ((t.r[0][w] >> sh) & 0xFFFFu) | (((t.r[1][w] >> sh) & 0xFFFFu) << 16);
+        v[1] = ((t.r[2][w] >> sh) & 0xFFFFu) | (((t.r[3][w] >> sh) & 0xFFFFu) << 16);
+        *reinterpret_cast<u32x2 *>(&St[(dg + e) * LR + rg]) = v;
+    }
+}
+
+// Uniform front end: Stage<BF16, ST16> picks the register type and the load/store pair for a tile.
+template <bool BF16, bool ST16> struct Stage {
+    typedef TileRegs R;
+    typedef TileRegs RT;
+    typedef float T;
+    static __device__ __forceinline__ void st(typename ACfg<BF16>::elem *S, const R &r) { store_rows<BF16>(S, r); }
+    static __device__ __forceinline__ void stT(__bf16 *S, const RT &r) { store_rows_T(S, r); }
+};
+template <> struct Stage<true, true> {
+    typedef TileRegs16 R;
+    typedef TileRegs16T RT;
+    typedef __bf16 T;
+    static __device__ __forceinline__ void st(__bf16 *S, const R &r) { store_rows16(S, r); }
+    static __device__ __forceinline__ void stT(__bf16 *S, const RT &r) { store_rows_T16(S, r); }
+};
 
 // acc[row][col] += sum_d T[r0 + row][d] * F_col[d]: A operand = 32 rows of the LDS tile, B operand = RowFrag.
 template <bool BF16>
@@ -196,19 +262,22 @@ __device__ __forceinline__ void zero_acc(f32x16 &a) {
 }
 
 // Store a transposed accumulator pair acc[db][r] (row = d, col = this lane's matrix row) to dst_row[0..63].
-__device__ __forceinline__ void store_row(float *dst_row, const f32x16 (&acc)[2], float mul, int half) {
+template <typename T>
+__device__ __forceinline__ void store_row(T *dst_row, const f32x16 (&acc)[2], float mul, int half) {
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-            st4(dst_row + db * 32 + 8 * g + 4 * half,
+            stv4<T>(dst_row + db * 32 + 8 * g + 4 * half,
                 make_float4(acc[db][4 * g] * mul, acc[db][4 * g + 1] * mul, acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul));
 }
 
 // ------------------------------------------------------------------ forward
-template <bool BF16>
+template <bool BF16, bool ST16>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     using elem = typename ACfg<BF16>::elem;
+    using SG = Stage<BF16, ST16>;
+    using T = typename SG::T;
     constexpr int LR = ACfg<BF16>::LR, TILE = 64 * LR;
     __shared__ __attribute__((aligned(16))) elem smem[2 * 2 * TILE];      // [buffer][K | V]
     const int b = blockIdx.y / a.heads, hh = blockIdx.y % a.heads;
@@ -217,7 +286,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     const int q = qblk + wave * 32 + l31;
     const bool qvalid = q < a.Sq;
     RowFrag<BF16> qf;
-    load_rowfrag<BF16>(qf, qvalid ? a.Q + ((int64_t)b * a.Sq + q) * a.ldq + hh * 64 : nullptr, half);
+    load_rowfrag<BF16, T>(qf, qvalid ? static_cast<const T *>(a.Q) + ((int64_t)b * a.Sq + q) * a.ldq + hh * 64 : nullptr, half);
     f32x16 o[2];
     zero_acc(o[0]); zero_acc(o[1]);
     float m = -1e30f, l = 0.f;
@@ -226,8 +295,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     const uint8_t *km = a.key_mask ? a.key_mask + (int64_t)b * a.Sk : nullptr;
     int kend = a.Sk;
     if (a.causal && qblk + 128 < kend) kend = qblk + 128;
-    const float *Kb = a.K + (int64_t)b * a.Sk * a.ldk + hh * 64, *Vb = a.V + (int64_t)b * a.Sk * a.ldv + hh * 64;
-    TileRegs rk, rv;
+    const T *Kb = static_cast<const T *>(a.K) + (int64_t)b * a.Sk * a.ldk + hh * 64;
+    const T *Vb = static_cast<const T *>(a.V) + (int64_t)b * a.Sk * a.ldv + hh * 64;
+    typename SG::R rk;
+    typename std::conditional<BF16, typename SG::RT, typename SG::R>::type rv;
     auto issue = [&](int k0) {
         const int nvalid = a.Sk - k0 < 64 ? a.Sk - k0 : 64;
         load_rows(rk, Kb + (int64_t)k0 * a.ldk, a.ldk, nvalid);
@@ -235,9 +306,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         else load_rows(rv, Vb + (int64_t)k0 * a.ldv, a.ldv, nvalid);
     };
     auto commit = [&](int buf) {
-        store_rows<BF16>(smem + buf * 2 * TILE, rk);
-        if constexpr (BF16) store_rows_T(smem + buf * 2 * TILE + TILE, rv);
-        else store_rows<false>(smem + buf * 2 * TILE + TILE, rv);
+        SG::st(smem + buf * 2 * TILE, rk);
+        if constexpr (BF16) SG::stT(smem + buf * 2 * TILE + TILE, rv);
+        else SG::st(smem + buf * 2 * TILE + TILE, rv);
     };
     issue(0);
     commit(0);
@@ -286,15 +357,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     }
     if (qvalid) {
         const float inv = l > 0.f ? 1.f / l : 0.f;
-        store_row(a.Out + ((int64_t)b * a.Sq + q) * a.ldout + hh * 64, o, inv, half);
+        store_row<T>(static_cast<T *>(a.Out) + ((int64_t)b * a.Sq + q) * a.ldout + hh * 64, o, inv, half);
         if (half == 0) a.LSEo[((int64_t)b * a.heads + hh) * a.Sq + q] = l > 0.f ? m + logf(l) : INFINITY;
     }
 }
 
 // ------------------------------------------------------------------ backward: dQ
-template <bool BF16>
+template <bool BF16, bool ST16>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     using elem = typename ACfg<BF16>::elem;
+    using SG = Stage<BF16, ST16>;
+    using T = typename SG::T;
     constexpr int LR = ACfg<BF16>::LR, TILE = 64 * LR, NT = BF16 ? 3 : 2;   // K, V (+ K transposed for bf16)
     __shared__ __attribute__((aligned(16))) elem smem[2 * NT * TILE];
     const int b = blockIdx.y / a.heads, hh = blockIdx.y % a.heads;
@@ -303,8 +376,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     const int q = qblk + wave * 32 + l31;
     const bool qvalid = q < a.Sq;
     RowFrag<BF16> qf, dof;
-    load_rowfrag<BF16>(qf, qvalid ? a.Q + ((int64_t)b * a.Sq + q) * a.ldq + hh * 64 : nullptr, half);
-    load_rowfrag<BF16>(dof, qvalid ? a.dO + ((int64_t)b * a.Sq + q) * a.lddo + hh * 64 : nullptr, half);
+    load_rowfrag<BF16, T>(qf, qvalid ? static_cast<const T *>(a.Q) + ((int64_t)b * a.Sq + q) * a.ldq + hh * 64 : nullptr, half);
+    load_rowfrag<BF16, T>(dof, qvalid ? static_cast<const T *>(a.dO) + ((int64_t)b * a.Sq + q) * a.lddo + hh * 64 : nullptr, half);
     const float lse = qvalid ? a.LSE[((int64_t)b * a.heads + hh) * a.Sq + q] : INFINITY;
     const float dlt = qvalid ? a.Delta[((int64_t)b * a.heads + hh) * a.Sq + q] : 0.f;
     f32x16 dq[2];
@@ -314,8 +387,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     const uint8_t *km = a.key_mask ? a.key_mask + (int64_t)b * a.Sk : nullptr;
     int kend = a.Sk;
     if (a.causal && qblk + 128 < kend) kend = qblk + 128;
-    const float *Kb = a.K + (int64_t)b * a.Sk * a.ldk + hh * 64, *Vb = a.V + (int64_t)b * a.Sk * a.ldv + hh * 64;
-    TileRegs rk, rv, rkt;
+    const T *Kb = static_cast<const T *>(a.K) + (int64_t)b * a.Sk * a.ldk + hh * 64;
+    const T *Vb = static_cast<const T *>(a.V) + (int64_t)b * a.Sk * a.ldv + hh * 64;
+    typename SG::R rk, rv;
+    typename SG::RT rkt;
     auto issue = [&](int k0) {
         const int nvalid = a.Sk - k0 < 64 ? a.Sk - k0 : 64;
         load_rows(rk, Kb + (int64_t)k0 * a.ldk, a.ldk, nvalid);
@@ -323,9 +398,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
         if constexpr (BF16) load_rows_T(rkt, Kb + (int64_t)k0 * a.ldk, a.ldk, nvalid);
     };
     auto commit = [&](int buf) {
-        store_rows<BF16>(smem + buf * NT * TILE, rk);
-        store_rows<BF16>(smem + buf * NT * TILE + TILE, rv);
-        if constexpr (BF16) store_rows_T(smem + buf * NT * TILE + 2 * TILE, rkt);
+        SG::st(smem + buf * NT * TILE, rk);
+        SG::st(smem + buf * NT * TILE + TILE, rv);
+        if constexpr (BF16) SG::stT(smem + buf * NT * TILE + 2 * TILE, rkt);
     };
     issue(0);
     commit(0);
@@ -357,13 +432,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
         if (more) commit(cur ^ 1);
         __syncthreads();
     }
-    if (qvalid) store_row(a.Out + ((int64_t)b * a.Sq + q) * a.ldout + hh * 64, dq, 1.f, half);
+    if (qvalid) store_row<T>(static_cast<T *>(a.Out) + ((int64_t)b * a.Sq + q) * a.ldout + hh * 64, dq, 1.f, half);
 }
 
 // ------------------------------------------------------------------ backward: dK, dV
-template <bool BF16>
+template <bool BF16, bool ST16>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     using elem = typename ACfg<BF16>::elem;
+    using SG = Stage<BF16, ST16>;
+    using T = typename SG::T;
     constexpr int LR = ACfg<BF16>::LR, TILE = 64 * LR, NT = BF16 ? 4 : 2;   // Q, dO (+ both transposed for bf16)
     __shared__ __attribute__((aligned(16))) elem smem[2 * NT * TILE];
     __shared__ float lse_s[2][64], dlt_s[2][64];
@@ -374,16 +451,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     const bool kvalid = key < a.Sk;
     const bool kalive = kvalid && !(a.key_mask && a.key_mask[(int64_t)b * a.Sk + key]);
     RowFrag<BF16> kf, vf;
-    load_rowfrag<BF16>(kf, kvalid ? a.K + ((int64_t)b * a.Sk + key) * a.ldk + hh * 64 : nullptr, half);
-    load_rowfrag<BF16>(vf, kvalid ? a.V + ((int64_t)b * a.Sk + key) * a.ldv + hh * 64 : nullptr, half);
+    load_rowfrag<BF16, T>(kf, kvalid ? static_cast<const T *>(a.K) + ((int64_t)b * a.Sk + key) * a.ldk + hh * 64 : nullptr, half);
+    load_rowfrag<BF16, T>(vf, kvalid ? static_cast<const T *>(a.V) + ((int64_t)b * a.Sk + key) * a.ldv + hh * 64 : nullptr, half);
     f32x16 dk[2], dv[2];
     zero_acc(dk[0]); zero_acc(dk[1]); zero_acc(dv[0]); zero_acc(dv[1]);
     ProbDrop pd;
     pd.init(a, b, hh);
     const int qstart = a.causal ? (kblk / 64) * 64 : 0;
-    const float *Qb = a.Q + (int64_t)b * a.Sq * a.ldq + hh * 64, *dOb = a.dO + (int64_t)b * a.Sq * a.lddo + hh * 64;
+    const T *Qb = static_cast<const T *>(a.Q) + (int64_t)b * a.Sq * a.ldq + hh * 64;
+    const T *dOb = static_cast<const T *>(a.dO) + (int64_t)b * a.Sq * a.lddo + hh * 64;
     const float *LSEb = a.LSE + ((int64_t)b * a.heads + hh) * a.Sq, *DLb = a.Delta + ((int64_t)b * a.heads + hh) * a.Sq;
-    TileRegs rq, rdo, rqt, rdot;
+    typename SG::R rq, rdo;
+    typename SG::RT rqt, rdot;
     float r_lse = INFINITY, r_dlt = 0.f;
     auto issue = [&](int q0) {
         const int nvalid = a.Sq - q0 < 64 ? a.Sq - q0 : 64;
@@ -400,11 +479,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
         }
     };
     auto commit = [&](int buf) {
-        store_rows<BF16>(smem + buf * NT * TILE, rq);
-        store_rows<BF16>(smem + buf * NT * TILE + TILE, rdo);
+        SG::st(smem + buf * NT * TILE, rq);
+        SG::st(smem + buf * NT * TILE + TILE, rdo);
         if constexpr (BF16) {
-            store_rows_T(smem + buf * NT * TILE + 2 * TILE, rqt);
-            store_rows_T(smem + buf * NT * TILE + 3 * TILE, rdot);
+            SG::stT(smem + buf * NT * TILE + 2 * TILE, rqt);
+            SG::stT(smem + buf * NT * TILE + 3 * TILE, rdot);
         }
         if (threadIdx.x < 64) { lse_s[buf][threadIdx.x] = r_lse; dlt_s[buf][threadIdx.x] = r_dlt; }
     };
@@ -446,20 +525,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
         __syncthreads();
     }
     if (kvalid) {
-        store_row(a.Out + ((int64_t)b * a.Sk + key) * a.ldout + hh * 64, dk, 1.f, half);
-        store_row(a.Out2 + ((int64_t)b * a.Sk + key) * a.ldout2 + hh * 64, dv, 1.f, half);
+        store_row<T>(static_cast<T *>(a.Out) + ((int64_t)b * a.Sk + key) * a.ldout + hh * 64, dk, 1.f, half);
+        store_row<T>(static_cast<T *>(a.Out2) + ((int64_t)b * a.Sk + key) * a.ldout2 + hh * 64, dv, 1.f, half);
     }
 }
 
 // Delta[b,h,q] = sum_d dO*O : one wave per (row, head).
-__global__ __launch_bounds__(256) void attn_delta_kernel(const float *__restrict__ O, const float *__restrict__ dO,
+template <typename T>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const T *__restrict__ O, const T *__restrict__ dO,
                                                          float *__restrict__ Delta, int64_t npairs, int heads, int Sq,
                                                          int64_t ldo, int64_t lddo) {
     const int lane = threadIdx.x & 63;
     for (int64_t pr = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); pr < npairs; pr += (int64_t)gridDim.x * 4) {
         const int64_t row = pr / heads;
         const int hd = (int)(pr - row * heads);
-        const float v = wave_sum(O[row * ldo + hd * 64 + lane] * dO[row * lddo + hd * 64 + lane]);
+        const float v = wave_sum((float)O[row * ldo + hd * 64 + lane] * (float)dO[row * lddo + hd * 64 + lane]);
         if (lane == 0) {
             const int64_t b = row / Sq, q = row - b * Sq;
             Delta[(b * heads + hd) * Sq + q] = v;
@@ -470,7 +550,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float *__restrict
 int check_common(const char *name, int B, int heads, int Sq, int Sk, int math, const int64_t *lds, int nld) {
     KK_REQUIRE(B > 0 && heads > 0 && Sq > 0 && Sk > 0, "%s: bad shape B=%d heads=%d Sq=%d Sk=%d", name, B, heads, Sq, Sk);
     KK_REQUIRE(math == KK_MATH_F32 || math == KK_MATH_BF16, "%s: bad math mode", name);
-    for (int i = 0; i < nld; ++i) KK_REQUIRE(lds[i] % 4 == 0 && lds[i] >= 64 * heads, "%s: row stride %ld unsupported", name, (long)lds[i]);
+    for (int i = 0; i < nld; ++i) KK_REQUIRE(lds[i] % 8 == 0 && lds[i] >= 64 * heads, "%s: row stride %ld unsupported", name, (long)lds[i]);
     KK_REQUIRE((int64_t)B * heads < 65536, "%s: B*heads too large", name);
     return 0;
 }
@@ -480,8 +560,9 @@ int check_common(const char *name, int B, int heads, int Sq, int Sk, int math, c
 extern "C" int kk_attn_fwd(const float *Q, const float *K, const float *V, float *O, float *LSE, int B, int heads,
                            int Sq, int Sk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                            const uint8_t *key_mask, int causal, float scale, const uint32_t *seed, uint32_t site,
-                           float p_drop, int math, void *stream) {
+                           float p_drop, int math, int io_bf16, void *stream) {
     KK_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "kk_attn_fwd: dropout probability must be in [0,1)");
+    KK_REQUIRE(!io_bf16 || math == KK_MATH_BF16, "kk_attn_fwd: bf16 storage needs KK_MATH_BF16");
     const int64_t lds[4] = {ldq, ldk, ldv, ldo};
     if (int rc = check_common("kk_attn_fwd", B, heads, Sq, Sk, math, lds, 4)) return rc;
     AttnArgs a = {};
@@ -490,19 +571,24 @@ extern "C" int kk_attn_fwd(const float *Q, const float *K, const float *V, float
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldout = ldo; a.scale = scale;
     a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop;
     dim3 grid(kk_cdiv(Sq, 128), B * heads);
-    if (math == KK_MATH_BF16) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (io_bf16) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else if (math == KK_MATH_BF16) hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
     KK_LAUNCH_CHECK("kk_attn_fwd");
     return 0;
 }
 
 extern "C" int kk_attn_delta(const float *O, const float *dO, float *Delta, int B, int heads, int Sq, int64_t ldo,
-                             int64_t lddo, void *stream) {
+                             int64_t lddo, int io_bf16, void *stream) {
     KK_REQUIRE(B > 0 && heads > 0 && Sq > 0, "kk_attn_delta: bad shape");
     const int64_t npairs = (int64_t)B * Sq * heads;
     int blocks = kk_cdiv(npairs, 4);
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, O, dO, Delta, npairs, heads, Sq, ldo, lddo);
+    if (io_bf16)
+        hipLaunchKernelGGL(attn_delta_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const __bf16 *>(O),
+                           reinterpret_cast<const __bf16 *>(dO), Delta, npairs, heads, Sq, ldo, lddo);
+    else
+        hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, O, dO, Delta, npairs, heads, Sq, ldo, lddo);
     KK_LAUNCH_CHECK("kk_attn_delta");
     return 0;
 }
@@ -511,7 +597,8 @@ extern "C" int kk_attn_bwd_dq(const float *Q, const float *K, const float *V, co
                               const float *Delta, float *dQ, int B, int heads, int Sq, int Sk, int64_t ldq,
                               int64_t ldk, int64_t ldv, int64_t lddo, int64_t lddq, const uint8_t *key_mask,
                               int causal, float scale, const uint32_t *seed, uint32_t site, float p_drop, int math,
-                              void *stream) {
+                              int io_bf16, void *stream) {
+    KK_REQUIRE(!io_bf16 || math == KK_MATH_BF16, "kk_attn_bwd_dq: bf16 storage needs KK_MATH_BF16");
     const int64_t lds[5] = {ldq, ldk, ldv, lddo, lddq};
     if (int rc = check_common("kk_attn_bwd_dq", B, heads, Sq, Sk, math, lds, 5)) return rc;
     AttnArgs a = {};
@@ -520,8 +607,9 @@ extern "C" int kk_attn_bwd_dq(const float *Q, const float *K, const float *V, co
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.lddo = lddo; a.ldout = lddq; a.scale = scale;
     a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop;
     dim3 grid(kk_cdiv(Sq, 128), B * heads);
-    if (math == KK_MATH_BF16) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (io_bf16) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else if (math == KK_MATH_BF16) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
     KK_LAUNCH_CHECK("kk_attn_bwd_dq");
     return 0;
 }
@@ -530,7 +618,8 @@ extern "C" int kk_attn_bwd_dkv(const float *Q, const float *K, const float *V, c
                                const float *Delta, float *dK, float *dV, int B, int heads, int Sq, int Sk,
                                int64_t ldq, int64_t ldk, int64_t ldv, int64_t lddo, int64_t lddk, int64_t lddv,
                                const uint8_t *key_mask, int causal, float scale, const uint32_t *seed, uint32_t site,
-                               float p_drop, int math, void *stream) {
+                               float p_drop, int math, int io_bf16, void *stream) {
+    KK_REQUIRE(!io_bf16 || math == KK_MATH_BF16, "kk_attn_bwd_dkv: bf16 storage needs KK_MATH_BF16");
     const int64_t lds[6] = {ldq, ldk, ldv, lddo, lddk, lddv};
     if (int rc = check_common("kk_attn_bwd_dkv", B, heads, Sq, Sk, math, lds, 6)) return rc;
     AttnArgs a = {};
@@ -539,8 +628,9 @@ extern "C" int kk_attn_bwd_dkv(const float *Q, const float *K, const float *V, c
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.lddo = lddo; a.ldout = lddk; a.ldout2 = lddv; a.scale = scale;
     a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop;
     dim3 grid(kk_cdiv(Sk, 128), B * heads);
-    if (math == KK_MATH_BF16) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (io_bf16) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else if (math == KK_MATH_BF16) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
     KK_LAUNCH_CHECK("kk_attn_bwd_dkv");
     return 0;
 }

@@ -62,6 +62,23 @@ __device__ __forceinline__ double block_sum_256_d(double v, double *red) {
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 
+// Storage-type generic 4-element access: activations are fp32 in the parity mode and bf16 in the bf16 mode.
+template <typename T> __device__ __forceinline__ float4 ldv4(const T *p);
+template <> __device__ __forceinline__ float4 ldv4<float>(const float *p) { return ld4(p); }
+template <> __device__ __forceinline__ float4 ldv4<__bf16>(const __bf16 *p) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4 *>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+template <typename T> __device__ __forceinline__ void stv4(T *p, float4 v);
+template <> __device__ __forceinline__ void stv4<float>(float *p, float4 v) { st4(p, v); }
+template <> __device__ __forceinline__ void stv4<__bf16>(__bf16 *p, float4 v) {
+    bf16x4 o;
+    o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+    *reinterpret_cast<bf16x4 *>(p) = o;
+}
+template <typename T> __device__ __forceinline__ float ldv1(const T *p) { return (float)(*p); }
+template <typename T> __device__ __forceinline__ void stv1(T *p, float v) { *p = (T)v; }
+
 // C/D fragment of a 32x32 MFMA tile: register r of lane l holds element
 //   row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5),  col = l & 31.
 __device__ __forceinline__ int frag_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }

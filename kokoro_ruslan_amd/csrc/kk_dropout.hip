@@ -52,7 +52,8 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float *__restrict__ 
 
 // SpecAugment: per sample `nt` time masks of t in [0, time_limit) frames at t0 in [0, max(1, T - t)) and `nf`
 // feature masks of f in [0, max(1, fmax)) dims at f0 in [0, max(1, H - f)); masked positions are zeroed (in place).
-__global__ __launch_bounds__(256) void specaug_kernel(float *__restrict__ x, int64_t total4, int T, int H, const uint32_t *__restrict__ seedp,
+template <typename TX>
+__global__ __launch_bounds__(256) void specaug_kernel(TX *__restrict__ x, int64_t total4, int T, int H, const uint32_t *__restrict__ seedp,
                                                       uint32_t site, int tmax, int fmax, int nt, int nf) {
     const uint32_t seed = *seedp;
     const int time_limit = max(1, min(tmax, T / 4));
@@ -75,12 +76,12 @@ __global__ __launch_bounds__(256) void specaug_kernel(float *__restrict__ x, int
             for (int e = 0; e < 4; ++e) fm[e] |= (c + e >= f0 && c + e < f0 + len);
         }
         if (tm || fm[0] || fm[1] || fm[2] || fm[3]) {
-            float4 v = ld4(x + row * H + c);
+            float4 v = ldv4<TX>(x + row * H + c);
             if (tm || fm[0]) v.x = 0.f;
             if (tm || fm[1]) v.y = 0.f;
             if (tm || fm[2]) v.z = 0.f;
             if (tm || fm[3]) v.w = 0.f;
-            st4(x + row * H + c, v);
+            stv4<TX>(x + row * H + c, v);
         }
     }
 }
@@ -115,14 +116,18 @@ extern "C" int kk_dropout_bwd(const float *dy, float *dx, int64_t rows, int H, i
 }
 
 extern "C" int kk_specaug(float *x, int B, int T, int H, const uint32_t *seed, uint32_t site, int time_mask_max,
-                          int feat_mask_max, int n_time, int n_feat, void *stream) {
+                          int feat_mask_max, int n_time, int n_feat, int x_bf16, void *stream) {
     KK_REQUIRE(x && seed && B > 0 && T > 0 && H > 0 && H % 4 == 0, "kk_specaug: bad args");
     KK_REQUIRE(n_time >= 0 && n_time <= 16 && n_feat >= 0 && n_feat <= 16, "kk_specaug: at most 16 masks of each kind");
     const int64_t total4 = (int64_t)B * T * H / 4;
     int blocks = kk_cdiv(total4, 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(specaug_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, total4, T, H, seed, site, time_mask_max,
-                       feat_mask_max, n_time, n_feat);
+    if (x_bf16)
+        hipLaunchKernelGGL(specaug_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<__bf16 *>(x), total4,
+                           T, H, seed, site, time_mask_max, feat_mask_max, n_time, n_feat);
+    else
+        hipLaunchKernelGGL(specaug_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, total4, T, H, seed, site,
+                           time_mask_max, feat_mask_max, n_time, n_feat);
     KK_LAUNCH_CHECK("kk_specaug");
     return 0;
 }

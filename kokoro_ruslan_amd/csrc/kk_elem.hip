@@ -24,34 +24,36 @@ __device__ __forceinline__ float4 drop4(const Drop1 &d, uint32_t seed, uint32_t 
                        kk_drop_mul(seed, d.site, idx0 + 2, thr, ik), kk_drop_mul(seed, d.site, idx0 + 3, thr, ik));
 }
 
-__global__ __launch_bounds__(256) void glu_fwd_kernel(const float *__restrict__ h, float *__restrict__ g, int64_t total4, int F, Drop1 d) {
+template <typename T>
+__global__ __launch_bounds__(256) void glu_fwd_kernel(const T *__restrict__ h, T *__restrict__ g, int64_t total4, int F, Drop1 d) {
     const int F4 = F / 4;
     const uint32_t thr = d.seed ? kk_drop_threshold(d.p) : 0u, seed = thr ? *d.seed : 0u;
     const float ik = thr ? 1.f / (1.f - d.p) : 1.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
         const int64_t row = i / F4;
         const int c = (int)(i - row * F4) * 4;
-        const float4 a = ld4(h + row * 2 * F + c), b = ld4(h + row * 2 * F + F + c);
+        const float4 a = ldv4<T>(h + row * 2 * F + c), b = ldv4<T>(h + row * 2 * F + F + c);
         const float4 m = drop4(d, seed, thr, ik, (uint64_t)row * F + c);
-        st4(g + row * F + c, make_float4(gelu_f(a.x) * b.x * m.x, gelu_f(a.y) * b.y * m.y, gelu_f(a.z) * b.z * m.z, gelu_f(a.w) * b.w * m.w));
+        stv4<T>(g + row * F + c, make_float4(gelu_f(a.x) * b.x * m.x, gelu_f(a.y) * b.y * m.y, gelu_f(a.z) * b.z * m.z, gelu_f(a.w) * b.w * m.w));
     }
 }
 
-__global__ __launch_bounds__(256) void glu_bwd_kernel(const float *__restrict__ dg, const float *__restrict__ h,
-                                                      float *__restrict__ dh, int64_t total4, int F, Drop1 dr) {
+template <typename T>
+__global__ __launch_bounds__(256) void glu_bwd_kernel(const T *__restrict__ dg, const T *__restrict__ h,
+                                                      T *__restrict__ dh, int64_t total4, int F, Drop1 dr) {
     const int F4 = F / 4;
     const uint32_t thr = dr.seed ? kk_drop_threshold(dr.p) : 0u, seed = thr ? *dr.seed : 0u;
     const float ik = thr ? 1.f / (1.f - dr.p) : 1.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
         const int64_t row = i / F4;
         const int c = (int)(i - row * F4) * 4;
-        const float4 a = ld4(h + row * 2 * F + c), b = ld4(h + row * 2 * F + F + c);
-        float4 d = ld4(dg + row * F + c);
+        const float4 a = ldv4<T>(h + row * 2 * F + c), b = ldv4<T>(h + row * 2 * F + F + c);
+        float4 d = ldv4<T>(dg + row * F + c);
         const float4 m = drop4(dr, seed, thr, ik, (uint64_t)row * F + c);
         d.x *= m.x; d.y *= m.y; d.z *= m.z; d.w *= m.w;
-        st4(dh + row * 2 * F + c, make_float4(d.x * b.x * gelu_grad_f(a.x), d.y * b.y * gelu_grad_f(a.y),
+        stv4<T>(dh + row * 2 * F + c, make_float4(d.x * b.x * gelu_grad_f(a.x), d.y * b.y * gelu_grad_f(a.y),
                                               d.z * b.z * gelu_grad_f(a.z), d.w * b.w * gelu_grad_f(a.w)));
-        st4(dh + row * 2 * F + F + c, make_float4(d.x * gelu_f(a.x), d.y * gelu_f(a.y), d.z * gelu_f(a.z), d.w * gelu_f(a.w)));
+        stv4<T>(dh + row * 2 * F + F + c, make_float4(d.x * gelu_f(a.x), d.y * gelu_f(a.y), d.z * gelu_f(a.z), d.w * gelu_f(a.w)));
     }
 }
 
@@ -159,31 +161,33 @@ __global__ __launch_bounds__(256) void max_i64_kernel(const int64_t *__restrict_
 }
 
 // ------------------------------------------------------------------ conv k=3 as im2col (per 512-frame chunk)
-__global__ __launch_bounds__(256) void im2col3_fwd_kernel(const float *__restrict__ x, float *__restrict__ col, int64_t total,
+template <typename TO>
+__global__ __launch_bounds__(256) void im2col3_fwd_kernel(const float *__restrict__ x, TO *__restrict__ col, int64_t total,
                                                           int L, int C, int chunk) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t fr = i / C;
         const int c = (int)(i - fr * C);
         const int l = (int)(fr % L);
         const int cb = (l / chunk) * chunk, ce = cb + chunk < L ? cb + chunk : L;
-        float *o = col + fr * 3 * C + c * 3;
-        o[0] = (l - 1 >= cb) ? x[i - C] : 0.f;
-        o[1] = x[i];
-        o[2] = (l + 1 < ce) ? x[i + C] : 0.f;
+        TO *o = col + fr * 3 * C + c * 3;
+        o[0] = (TO)((l - 1 >= cb) ? x[i - C] : 0.f);
+        o[1] = (TO)x[i];
+        o[2] = (TO)((l + 1 < ce) ? x[i + C] : 0.f);
     }
 }
 
-__global__ __launch_bounds__(256) void im2col3_bwd_kernel(const float *__restrict__ dcol, float *__restrict__ dx, int64_t total,
+template <typename TI>
+__global__ __launch_bounds__(256) void im2col3_bwd_kernel(const TI *__restrict__ dcol, float *__restrict__ dx, int64_t total,
                                                           int L, int C, int chunk) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t fr = i / C;
         const int c = (int)(i - fr * C);
         const int l = (int)(fr % L);
         const int cb = (l / chunk) * chunk, ce = cb + chunk < L ? cb + chunk : L;
-        const float *d = dcol + fr * 3 * C + c * 3;
-        float v = d[1];
-        if (l + 1 < ce) v += d[3 * C + 0];            // row l+1, tap k=0 read x[l]
-        if (l - 1 >= cb) v += d[-3 * C + 2];          // row l-1, tap k=2 read x[l]
+        const TI *d = dcol + fr * 3 * C + c * 3;
+        float v = (float)d[1];
+        if (l + 1 < ce) v += (float)d[3 * C + 0];     // row l+1, tap k=0 read x[l]
+        if (l - 1 >= cb) v += (float)d[-3 * C + 2];   // row l-1, tap k=2 read x[l]
         dx[i] = v;
     }
 }
@@ -198,14 +202,15 @@ __device__ __forceinline__ bool row_dead(const uint8_t *mask, int64_t r, int L, 
     return false;
 }
 
-__global__ __launch_bounds__(256) void rowdot_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
+template <typename TX>
+__global__ __launch_bounds__(256) void rowdot_fwd_kernel(const TX *__restrict__ x, const float *__restrict__ w,
                                                          const float *__restrict__ b, const uint8_t *__restrict__ mask,
                                                          float *__restrict__ out, int64_t rows, int C, int L, int chunk) {
     const int lane = threadIdx.x & 63;
     for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
         float s = 0.f;
         for (int c = lane * 4; c < C; c += 256) {
-            const float4 xv = ld4(x + r * C + c), wv = ld4(w + c);
+            const float4 xv = ldv4<TX>(x + r * C + c), wv = ld4(w + c);
             s += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
         }
         s = wave_sum(s);
@@ -213,7 +218,8 @@ __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const float *__restrict
     }
 }
 
-__global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float *__restrict__ dout, const float *__restrict__ x,
+template <typename TX>
+__global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float *__restrict__ dout, const TX *__restrict__ x,
                                                          const float *__restrict__ w, const uint8_t *__restrict__ mask,
                                                          float *__restrict__ dx, float *__restrict__ dw, float *__restrict__ db,
                                                          int64_t rows, int C, int L, int chunk, int rows_per_block) {
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float *__restrict
         for (int k = 0; k < 4; ++k) {
             const int c = threadIdx.x + 256 * k;
             if (c < C) {
-                aw[k] += d * x[r * C + c];
+                aw[k] += d * (float)x[r * C + c];
                 if (dx) dx[r * C + c] = d * w[c];
             }
         }
@@ -249,10 +255,11 @@ __device__ __forceinline__ int bucketize_left(const float *__restrict__ bins, in
     return lo;
 }
 
+template <typename TO>
 __global__ __launch_bounds__(256) void bucket_embed_add_fwd_kernel(
     const float *__restrict__ x, const float *__restrict__ pitch, const float *__restrict__ energy,
     const float *__restrict__ pbins, const float *__restrict__ ebins, const float *__restrict__ pemb,
-    const float *__restrict__ eemb, const int64_t *__restrict__ lens, float *__restrict__ out, int32_t *__restrict__ pidx,
+    const float *__restrict__ eemb, const int64_t *__restrict__ lens, TO *__restrict__ out, int32_t *__restrict__ pidx,
     int32_t *__restrict__ eidx, uint8_t *__restrict__ fmask, int64_t rows, int T, int H, int nbins) {
     const int lane = threadIdx.x & 63;
     for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(256) void bucket_embed_add_fwd_kernel(
                 const float4 a = ld4(x + r * H + c), p = ld4(pemb + (int64_t)pi * H + c), e = ld4(eemb + (int64_t)ei * H + c);
                 o = make_float4(a.x + p.x + e.x, a.y + p.y + e.y, a.z + p.z + e.z, a.w + p.w + e.w);
             }
-            st4(out + r * H + c, o);
+            stv4<TO>(out + r * H + c, o);
         }
     }
 }
@@ -308,20 +315,28 @@ inline int grid_for(int64_t n, int cap = 4096) {
 }  // namespace
 
 extern "C" int kk_glu_fwd(const float *h, float *g, int64_t rows, int F, const uint32_t *seed, uint32_t site, float p,
-                          void *stream) {
+                          int io_bf16, void *stream) {
     KK_REQUIRE(rows > 0 && F > 0 && F % 4 == 0 && p >= 0.f && p < 1.f, "kk_glu_fwd: bad shape rows=%ld F=%d", (long)rows, F);
     const int64_t total4 = rows * F / 4;
     Drop1 d = {p > 0.f ? seed : nullptr, site, p};
-    hipLaunchKernelGGL(glu_fwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, h, g, total4, F, d);
+    if (io_bf16)
+        hipLaunchKernelGGL(glu_fwd_kernel<__bf16>, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const __bf16 *>(h), reinterpret_cast<__bf16 *>(g), total4, F, d);
+    else
+        hipLaunchKernelGGL(glu_fwd_kernel<float>, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, h, g, total4, F, d);
     KK_LAUNCH_CHECK("kk_glu_fwd");
     return 0;
 }
 extern "C" int kk_glu_bwd(const float *dg, const float *h, float *dh, int64_t rows, int F, const uint32_t *seed, uint32_t site,
-                          float p, void *stream) {
+                          float p, int io_bf16, void *stream) {
     KK_REQUIRE(rows > 0 && F > 0 && F % 4 == 0 && p >= 0.f && p < 1.f, "kk_glu_bwd: bad shape");
     const int64_t total4 = rows * F / 4;
     Drop1 d = {p > 0.f ? seed : nullptr, site, p};
-    hipLaunchKernelGGL(glu_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, dg, h, dh, total4, F, d);
+    if (io_bf16)
+        hipLaunchKernelGGL(glu_bwd_kernel<__bf16>, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const __bf16 *>(dg), reinterpret_cast<const __bf16 *>(h), reinterpret_cast<__bf16 *>(dh), total4, F, d);
+    else
+        hipLaunchKernelGGL(glu_bwd_kernel<float>, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, dg, h, dh, total4, F, d);
     KK_LAUNCH_CHECK("kk_glu_bwd");
     return 0;
 }
@@ -372,39 +387,55 @@ extern "C" int kk_max_i64(const int64_t *x, int64_t n, int64_t *out, void *strea
     return 0;
 }
 
-extern "C" int kk_im2col3_fwd(const float *x, float *col, int B, int L, int C, int chunk, void *stream) {
+extern "C" int kk_im2col3_fwd(const float *x, float *col, int B, int L, int C, int chunk, int col_bf16, void *stream) {
     KK_REQUIRE(B > 0 && L > 0 && C > 0 && chunk > 0, "kk_im2col3_fwd: bad shape");
     const int64_t total = (int64_t)B * L * C;
-    hipLaunchKernelGGL(im2col3_fwd_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, x, col, total, L, C, chunk);
+    if (col_bf16)
+        hipLaunchKernelGGL(im2col3_fwd_kernel<__bf16>, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, x,
+                           reinterpret_cast<__bf16 *>(col), total, L, C, chunk);
+    else
+        hipLaunchKernelGGL(im2col3_fwd_kernel<float>, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, x, col, total, L, C, chunk);
     KK_LAUNCH_CHECK("kk_im2col3_fwd");
     return 0;
 }
-extern "C" int kk_im2col3_bwd(const float *dcol, float *dx, int B, int L, int C, int chunk, void *stream) {
+extern "C" int kk_im2col3_bwd(const float *dcol, float *dx, int B, int L, int C, int chunk, int dcol_bf16, void *stream) {
     KK_REQUIRE(B > 0 && L > 0 && C > 0 && chunk > 0, "kk_im2col3_bwd: bad shape");
     const int64_t total = (int64_t)B * L * C;
-    hipLaunchKernelGGL(im2col3_bwd_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, dcol, dx, total, L, C, chunk);
+    if (dcol_bf16)
+        hipLaunchKernelGGL(im2col3_bwd_kernel<__bf16>, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const __bf16 *>(dcol), dx, total, L, C, chunk);
+    else
+        hipLaunchKernelGGL(im2col3_bwd_kernel<float>, dim3(grid_for(total, 8192)), dim3(256), 0, (hipStream_t)stream, dcol, dx, total, L, C, chunk);
     KK_LAUNCH_CHECK("kk_im2col3_bwd");
     return 0;
 }
 
 extern "C" int kk_rowdot_fwd(const float *x, const float *w, const float *b, const uint8_t *mask, float *out,
-                             int64_t rows, int C, int L, int chunk, void *stream) {
+                             int64_t rows, int C, int L, int chunk, int x_bf16, void *stream) {
     KK_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && L > 0, "kk_rowdot_fwd: bad shape");
     int blocks = kk_cdiv(rows, 4);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(rowdot_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, w, b, mask, out, rows, C, L, chunk);
+    if (x_bf16)
+        hipLaunchKernelGGL(rowdot_fwd_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const __bf16 *>(x), w, b, mask, out, rows, C, L, chunk);
+    else
+        hipLaunchKernelGGL(rowdot_fwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, w, b, mask, out, rows, C, L, chunk);
     KK_LAUNCH_CHECK("kk_rowdot_fwd");
     return 0;
 }
 extern "C" int kk_rowdot_bwd(const float *dout, const float *x, const float *w, const uint8_t *mask, float *dx,
-                             float *dw, float *db, int64_t rows, int C, int L, int chunk, void *stream) {
+                             float *dw, float *db, int64_t rows, int C, int L, int chunk, int x_bf16, void *stream) {
     KK_REQUIRE(rows > 0 && C > 0 && C <= 1024 && L > 0, "kk_rowdot_bwd: bad shape (C <= 1024)");
     int blocks = kk_cdiv(rows, 16);
     if (blocks > 1024) blocks = 1024;
     const int rpb = kk_cdiv(rows, blocks);
     blocks = kk_cdiv(rows, rpb);
-    hipLaunchKernelGGL(rowdot_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, x, w, mask, dx, dw, db, rows,
-                       C, L, chunk, rpb);
+    if (x_bf16)
+        hipLaunchKernelGGL(rowdot_bwd_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout,
+                           reinterpret_cast<const __bf16 *>(x), w, mask, dx, dw, db, rows, C, L, chunk, rpb);
+    else
+        hipLaunchKernelGGL(rowdot_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, x, w, mask, dx, dw, db, rows,
+                           C, L, chunk, rpb);
     KK_LAUNCH_CHECK("kk_rowdot_bwd");
     return 0;
 }
@@ -412,13 +443,17 @@ extern "C" int kk_rowdot_bwd(const float *dout, const float *x, const float *w, 
 extern "C" int kk_bucket_embed_add_fwd(const float *x, const float *pitch, const float *energy, const float *pbins,
                                        const float *ebins, const float *pemb, const float *eemb, const int64_t *lens,
                                        float *out, int32_t *pidx, int32_t *eidx, uint8_t *frame_mask, int B, int T,
-                                       int H, int nbins, void *stream) {
+                                       int H, int nbins, int out_bf16, void *stream) {
     KK_REQUIRE(B > 0 && T > 0 && H > 0 && H % 4 == 0 && nbins > 1, "kk_bucket_embed_add_fwd: bad shape");
     const int64_t rows = (int64_t)B * T;
     int blocks = kk_cdiv(rows, 4);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(bucket_embed_add_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, pitch, energy, pbins,
-                       ebins, pemb, eemb, lens, out, pidx, eidx, frame_mask, rows, T, H, nbins);
+    if (out_bf16)
+        hipLaunchKernelGGL(bucket_embed_add_fwd_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, pitch, energy,
+                           pbins, ebins, pemb, eemb, lens, reinterpret_cast<__bf16 *>(out), pidx, eidx, frame_mask, rows, T, H, nbins);
+    else
+        hipLaunchKernelGGL(bucket_embed_add_fwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, pitch, energy, pbins,
+                           ebins, pemb, eemb, lens, out, pidx, eidx, frame_mask, rows, T, H, nbins);
     KK_LAUNCH_CHECK("kk_bucket_embed_add_fwd");
     return 0;
 }

@@ -32,8 +32,10 @@ template <> struct GemmCfg<false, 64> { static constexpr int BK = 32, LR = 33, N
 struct GemmArgs {
     int M, N, K;
     float alpha, beta;
-    const float *A, *B, *bias, *residual;
-    float *C;
+    const void *A, *B;          // fp32, or bf16 when the kernel is instantiated with A16 / B16
+    const float *bias, *residual;
+    void *C;                    // fp32, or bf16 when c_bf16 (runtime flag; plain stores only)
+    int c_bf16;
     int64_t lda, ldb, ldc, ldr, res_mod;
     int k_per_split, atomic;
     int tiles_m, tiles_n, xcd_swizzle;
@@ -115,7 +117,56 @@ __device__ __forceinline__ void r2s(typename GemmCfg<BF16, TM>::elem *S, const f
     }
 }
 
-template <bool TA, bool TB, bool BF16, int TM>
+// ---- operands already stored as bf16 in HBM (bf16 mode: weights' shadow copy, bf16 activations) ----------------
+// No conversion and half the bytes: 16-byte loads carry 8 elements.  Two loads per thread per tile for both tile sizes.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in registers (HIP's uint4 struct did not)
+
+template <int TM, int BK, bool KS>
+__device__ __forceinline__ void g2r16(const __bf16 *__restrict__ X, int64_t ld, int rows_total, int r0, int k0, int kend,
+                                      u32x4 (&reg)[2]) {
+    const int t = threadIdx.x;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    if (!KS) {
+        constexpr int CPR = BK / 8, RPI = 256 / CPR;          // 16-byte chunks per row; rows per instruction
+        const int k = k0 + (t % CPR) * 8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = r0 + t / CPR + i * RPI;
+            reg[i] = (row < rows_total && k < kend) ? *reinterpret_cast<const u32x4 *>(X + (int64_t)row * ld + k) : z;
+        }
+    } else {
+        constexpr int RG = TM / 8;                             // 8-row groups; each thread takes 2 consecutive k
+        const int row = r0 + (t % RG) * 8;
+        const int kb = k0 + (t / RG) * 2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = kb + i;
+            reg[i] = (row < rows_total && k < kend) ? *reinterpret_cast<const u32x4 *>(X + (int64_t)k * ld + row) : z;
+        }
+    }
+}
+
+template <int TM, int BK, int LR, bool KS>
+__device__ __forceinline__ void r2s16(__bf16 *S, const u32x4 (&reg)[2]) {
+    const int t = threadIdx.x;
+    if (!KS) {
+        constexpr int CPR = BK / 8, RPI = 256 / CPR;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            *reinterpret_cast<u32x4 *>(&S[(t / CPR + i * RPI) * LR + (t % CPR) * 8]) = reg[i];
+    } else {
+        constexpr int RG = TM / 8;
+        const int rowb = (t % RG) * 8, kofs = (t / RG) * 2;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {    // (k, k+1) of row c packed into one 4-byte LDS store
+            const unsigned int lo = (reg[0][c >> 1] >> (16 * (c & 1))) & 0xFFFFu;
+            const unsigned int hi = (reg[1][c >> 1] >> (16 * (c & 1))) & 0xFFFFu;
+            *reinterpret_cast<unsigned int *>(&S[(rowb + c) * LR + kofs]) = lo | (hi << 16);
+        }
+    }
+}
+
+template <bool TA, bool TB, bool BF16, int TM, bool A16, bool B16>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
     using Cfg = GemmCfg<BF16, TM>;
     using elem = typename Cfg::elem;
@@ -148,20 +199,38 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    static_assert(BF16 || (!A16 && !B16), "bf16 storage only with bf16 arithmetic");
     float4 ra[NV], rb[NV];
+    u32x4 ra16[2], rb16[2];
+    auto loadA = [&](int k0) {
+        if constexpr (A16) g2r16<TM, BK, TA>(static_cast<const __bf16 *>(a.A), a.lda, a.M, m0, k0, kend, ra16);
+        else g2r<BF16, TM, TA>(static_cast<const float *>(a.A), a.lda, a.M, m0, k0, kend, ra);
+    };
+    auto loadB = [&](int k0) {
+        if constexpr (B16) g2r16<TM, BK, TB>(static_cast<const __bf16 *>(a.B), a.ldb, a.N, n0, k0, kend, rb16);
+        else g2r<BF16, TM, TB>(static_cast<const float *>(a.B), a.ldb, a.N, n0, k0, kend, rb);
+    };
+    auto storeA = [&](elem *S) {
+        if constexpr (A16) r2s16<TM, BK, LR, TA>(reinterpret_cast<__bf16 *>(S), ra16);
+        else r2s<BF16, TM, TA>(S, ra);
+    };
+    auto storeB = [&](elem *S) {
+        if constexpr (B16) r2s16<TM, BK, LR, TB>(reinterpret_cast<__bf16 *>(S), rb16);
+        else r2s<BF16, TM, TB>(S, rb);
+    };
     if (nk > 0) {
-        g2r<BF16, TM, TA>(a.A, a.lda, a.M, m0, kbeg, kend, ra);
-        g2r<BF16, TM, TB>(a.B, a.ldb, a.N, n0, kbeg, kend, rb);
-        r2s<BF16, TM, TA>(As, ra);
-        r2s<BF16, TM, TB>(Bs, rb);
+        loadA(kbeg);
+        loadB(kbeg);
+        storeA(As);
+        storeB(Bs);
     }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool more = kt + 1 < nk;
         if (more) {
-            g2r<BF16, TM, TA>(a.A, a.lda, a.M, m0, kbeg + (kt + 1) * BK, kend, ra);
-            g2r<BF16, TM, TB>(a.B, a.ldb, a.N, n0, kbeg + (kt + 1) * BK, kend, rb);
+            loadA(kbeg + (kt + 1) * BK);
+            loadB(kbeg + (kt + 1) * BK);
         }
         const elem *Ac = As + cur * TILE + (wr * WT + l31) * LR;
         const elem *Bc = Bs + cur * TILE + (wc * WT + l31) * LR;
@@ -197,8 +266,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
             }
         }
         if (more) {
-            r2s<BF16, TM, TA>(As + (cur ^ 1) * TILE, ra);
-            r2s<BF16, TM, TB>(Bs + (cur ^ 1) * TILE, rb);
+            storeA(As + (cur ^ 1) * TILE);
+            storeB(Bs + (cur ^ 1) * TILE);
         }
         __syncthreads();
     }
@@ -221,7 +290,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
                     const int64_t rr = a.res_mod > 0 ? (int64_t)row % a.res_mod : (int64_t)row;
                     v += a.residual[rr * a.ldr + col];
                 }
-                float *dst = a.C + (int64_t)row * a.ldc + col;
+                if (a.c_bf16) {          // bf16 activation output (never atomic, never accumulated)
+                    static_cast<__bf16 *>(a.C)[(int64_t)row * a.ldc + col] = (__bf16)v;
+                    continue;
+                }
+                float *dst = static_cast<float *>(a.C) + (int64_t)row * a.ldc + col;
                 if (a.atomic) {
                     atomicAdd(dst, v);
                 } else {
@@ -232,18 +305,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs a) {
         }
 }
 
-template <bool BF16, int TM>
-int launch(int ta, int tb, const GemmArgs &a, dim3 grid, hipStream_t s) {
-    if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<false, false, BF16, TM>), grid, dim3(256), 0, s, a);
-    else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<false, true, BF16, TM>), grid, dim3(256), 0, s, a);
-    else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<true, false, BF16, TM>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((gemm_kernel<true, true, BF16, TM>), grid, dim3(256), 0, s, a);
+template <bool BF16, int TM, bool A16, bool B16>
+int launch2(int ta, int tb, const GemmArgs &a, dim3 grid, hipStream_t s) {
+    if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<false, false, BF16, TM, A16, B16>), grid, dim3(256), 0, s, a);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<false, true, BF16, TM, A16, B16>), grid, dim3(256), 0, s, a);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<true, false, BF16, TM, A16, B16>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gemm_kernel<true, true, BF16, TM, A16, B16>), grid, dim3(256), 0, s, a);
     KK_LAUNCH_CHECK("kk_gemm");
     return 0;
 }
 
+template <bool BF16, int TM>
+int launch(int ta, int tb, int a16, int b16, const GemmArgs &a, dim3 grid, hipStream_t s) {
+    if constexpr (BF16) {
+        if (a16 && b16) return launch2<true, TM, true, true>(ta, tb, a, grid, s);
+        if (a16) return launch2<true, TM, true, false>(ta, tb, a, grid, s);
+        if (b16) return launch2<true, TM, false, true>(ta, tb, a, grid, s);
+    }
+    return launch2<BF16, TM, false, false>(ta, tb, a, grid, s);
+}
+
 // ---- column sums (bias gradients): out[n] += sum_m X[m,n] -------------------------------------------
-__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ X, int64_t ldx, int64_t M, int N,
+template <typename TX>
+__global__ __launch_bounds__(256) void colsum_kernel(const TX *__restrict__ X, int64_t ldx, int64_t M, int N,
                                                      float *__restrict__ out, int rows_per_block) {
     // block = 64 columns x 4 row-lanes; grid.x = column groups, grid.y = row slabs
     __shared__ float red[4][64];
@@ -254,7 +338,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ X
     float s = 0.f;
     if (c < N)
 #pragma unroll 8
-        for (int64_t r = rbeg + rl; r < rend; r += 4) s += X[r * ldx + c];
+        for (int64_t r = rbeg + rl; r < rend; r += 4) s += (float)X[r * ldx + c];
     red[rl][threadIdx.x & 63] = s;   // (loads above are independent: the compiler keeps several in flight)
     __syncthreads();
     if (rl == 0 && c < N) atomicAdd(&out[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
@@ -274,7 +358,13 @@ extern "C" int kk_gemm_tune(int tm_threshold, int xcd_swizzle) {
 
 extern "C" int kk_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, const float *A, int64_t lda,
                        const float *B, int64_t ldb, float beta, float *C, int64_t ldc, const float *bias,
-                       const float *residual, int64_t ldr, int64_t res_mod, int split_k, int math, void *stream) {
+                       const float *residual, int64_t ldr, int64_t res_mod, int split_k, int math, int dtypes,
+                       void *stream) {
+    const int a16 = dtypes & 1, b16 = (dtypes >> 1) & 1, c16 = (dtypes >> 2) & 1;
+    KK_REQUIRE(dtypes == 0 || math == KK_MATH_BF16, "kk_gemm: bf16 storage needs KK_MATH_BF16");
+    KK_REQUIRE(!c16 || beta == 0.f, "kk_gemm: a bf16 C cannot be accumulated into");
+    if (a16) KK_REQUIRE(lda % 8 == 0 && (ta ? M % 8 == 0 : K % 8 == 0), "kk_gemm: bf16 A needs lda and its contiguous extent to be multiples of 8");
+    if (b16) KK_REQUIRE(ldb % 8 == 0 && (tb ? N % 8 == 0 : K % 8 == 0), "kk_gemm: bf16 B needs ldb and its contiguous extent to be multiples of 8");
     KK_REQUIRE(M > 0 && N > 0 && K > 0, "kk_gemm: empty problem M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
     KK_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "kk_gemm: dimension overflow");
     KK_REQUIRE(A && B && C, "kk_gemm: null operand");
@@ -299,13 +389,13 @@ extern "C" int kk_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, float al
         }
     }
     if (splits > ktiles) splits = ktiles;
-    if (splits > 1 && !(beta == 1.f || (beta == 0.f && ldc == N))) splits = 1;
+    if (splits > 1 && (c16 || !(beta == 1.f || (beta == 0.f && ldc == N)))) splits = 1;
     int k_per_split = kk_cdiv(ktiles, splits) * BK;
     splits = kk_cdiv(K, k_per_split);
     GemmArgs a;
     a.M = (int)M; a.N = (int)N; a.K = (int)K;
     a.alpha = alpha; a.beta = beta;
-    a.A = A; a.B = B; a.bias = bias; a.residual = residual; a.C = C;
+    a.A = A; a.B = B; a.bias = bias; a.residual = residual; a.C = C; a.c_bf16 = c16;
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.res_mod = res_mod;
     a.k_per_split = k_per_split;
     a.atomic = splits > 1 ? 1 : 0;
@@ -317,18 +407,22 @@ extern "C" int kk_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, float al
     a.tiles_n = kk_cdiv(N, TM);
     a.xcd_swizzle = g_xcd_swizzle;
     dim3 grid(a.tiles_m * a.tiles_n, splits);
-    if (TM == 128) return math == KK_MATH_BF16 ? launch<true, 128>(ta, tb, a, grid, s) : launch<false, 128>(ta, tb, a, grid, s);
-    return math == KK_MATH_BF16 ? launch<true, 64>(ta, tb, a, grid, s) : launch<false, 64>(ta, tb, a, grid, s);
+    if (TM == 128) return math == KK_MATH_BF16 ? launch<true, 128>(ta, tb, a16, b16, a, grid, s) : launch<false, 128>(ta, tb, 0, 0, a, grid, s);
+    return math == KK_MATH_BF16 ? launch<true, 64>(ta, tb, a16, b16, a, grid, s) : launch<false, 64>(ta, tb, 0, 0, a, grid, s);
 }
 
-extern "C" int kk_colsum_acc(const float *X, int64_t ldx, int64_t M, int64_t N, float *out, void *stream) {
+extern "C" int kk_colsum_acc(const float *X, int64_t ldx, int64_t M, int64_t N, float *out, int x_bf16, void *stream) {
     KK_REQUIRE(M > 0 && N > 0 && X && out, "kk_colsum_acc: bad args");
     int slabs = kk_cdiv(M, 64);
     if (slabs > 512) slabs = 512;
     const int rows_per_block = kk_cdiv(M, slabs);
     slabs = kk_cdiv(M, rows_per_block);
-    hipLaunchKernelGGL(colsum_kernel, dim3(kk_cdiv(N, 64), slabs), dim3(256), 0, (hipStream_t)stream, X, ldx, M,
-                       (int)N, out, rows_per_block);
+    if (x_bf16)
+        hipLaunchKernelGGL(colsum_kernel<__bf16>, dim3(kk_cdiv(N, 64), slabs), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const __bf16 *>(X), ldx, M, (int)N, out, rows_per_block);
+    else
+        hipLaunchKernelGGL(colsum_kernel<float>, dim3(kk_cdiv(N, 64), slabs), dim3(256), 0, (hipStream_t)stream, X, ldx, M,
+                           (int)N, out, rows_per_block);
     KK_LAUNCH_CHECK("kk_colsum_acc");
     return 0;
 }

@@ -19,8 +19,9 @@ constexpr int MAXV = 8;   // float4 per lane -> H <= 2048
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
 // ------------------------------------------------------------------ LayerNorm
+template <typename TY>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
-                                                            const float *__restrict__ beta, float *__restrict__ y,
+                                                            const float *__restrict__ beta, TY *__restrict__ y,
                                                             float *__restrict__ mean_o, float *__restrict__ rstd_o,
                                                             int64_t rows, int H) {
     const int lane = threadIdx.x & 63;
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *__restr
         }
     }
     const float rstd = 1.f / sqrtf(wave_sum(q) / (float)H + 1e-5f);
-    float *yr = y + row * H;
+    TY *yr = y + row * H;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane * 4 + 256 * i;
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *__restr
             o.y = (v[i].y - mean) * rstd * g.y + b.y;
             o.z = (v[i].z - mean) * rstd * g.z + b.z;
             o.w = (v[i].w - mean) * rstd * g.w + b.w;
-            st4(yr + c, o);
+            stv4<TY>(yr + c, o);
         }
     }
     if (lane == 0) {
@@ -66,7 +67,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *__restr
     }
 }
 
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+template <typename TD>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TD *__restrict__ dy, const float *__restrict__ x,
                                                             const float *__restrict__ gamma, const float *__restrict__ mean,
                                                             const float *__restrict__ rstd, float *__restrict__ dx,
                                                             int dx_acc, float *__restrict__ dgamma, float *__restrict__ dbeta,
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restr
         for (int i = 0; i < MAXV; ++i) {
             const int c = lane * 4 + 256 * i;
             if (c < H) {
-                const float4 xv = ld4(x + row * H + c), d = ld4(dy + row * H + c), g = ld4(gamma + c);
+                const float4 xv = ld4(x + row * H + c), d = ldv4<TD>(dy + row * H + c), g = ld4(gamma + c);
                 xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
                 dg[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
                 s1 += dg[i].x + dg[i].y + dg[i].z + dg[i].w;
@@ -129,7 +131,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restr
 }
 
 // ------------------------------------------------------------------ RMSNorm (+ residual)
-__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gain,
+template <typename TX>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const TX *__restrict__ x, const float *__restrict__ gain,
                                                           const float *__restrict__ residual, float *__restrict__ y,
                                                           float *__restrict__ rstd_o, int64_t rows, int H) {
     const int lane = threadIdx.x & 63;
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float *__restric
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = lane * 4 + 256 * i;
-        v[i] = c < H ? ld4(x + row * H + c) : f4zero();
+        v[i] = c < H ? ldv4<TX>(x + row * H + c) : f4zero();
         q += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
     }
     const float rs = 1.f / sqrtf(wave_sum(q) / (float)H + FLT_EPSILON);
@@ -157,9 +160,10 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float *__restric
     if (lane == 0) rstd_o[row] = rs;
 }
 
-__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+template <typename TX>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float *__restrict__ dy, const TX *__restrict__ x,
                                                           const float *__restrict__ gain, const float *__restrict__ rstd,
-                                                          float *__restrict__ dx, float *__restrict__ dgain, int64_t rows, int H) {
+                                                          TX *__restrict__ dx, float *__restrict__ dgain, int64_t rows, int H) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [H]
     for (int c = threadIdx.x; c < H; c += 256) sm[c] = 0.f;
     __syncthreads();
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float *__restric
         for (int i = 0; i < MAXV; ++i) {
             const int c = lane * 4 + 256 * i;
             if (c < H) {
-                xv[i] = ld4(x + row * H + c);
+                xv[i] = ldv4<TX>(x + row * H + c);
                 const float4 d = ld4(dy + row * H + c), g = ld4(gain + c);
                 dg[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
                 s += dg[i].x * xv[i].x + dg[i].y * xv[i].y + dg[i].z * xv[i].z + dg[i].w * xv[i].w;
@@ -187,8 +191,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float *__restric
         for (int i = 0; i < MAXV; ++i) {
             const int c = lane * 4 + 256 * i;
             if (c < H)
-                st4(dx + row * H + c, make_float4(rs * dg[i].x - xv[i].x * k, rs * dg[i].y - xv[i].y * k,
-                                                   rs * dg[i].z - xv[i].z * k, rs * dg[i].w - xv[i].w * k));
+                stv4<TX>(dx + row * H + c, make_float4(rs * dg[i].x - xv[i].x * k, rs * dg[i].y - xv[i].y * k,
+                                                       rs * dg[i].z - xv[i].z * k, rs * dg[i].w - xv[i].w * k));
         }
     }
 #pragma unroll
@@ -207,8 +211,9 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float *__restric
 // per-part RoPE flag; blockIdx.y = part, so a thread's gain-gradient accumulator belongs to one gain vector.
 // rotate_half(n)[d] = -n[d+32] (d<32), n[d-32] (d>=32)   (positional_encoding.py:152-157)
 struct HeadNormArgs {
-    const float *x, *dy, *cos_t, *sin_t;
-    float *y, *dx;
+    const void *x, *dy;          // fp32 or bf16 (template parameter of the kernels)
+    const float *cos_t, *sin_t;
+    void *y, *dx;
     const float *gain[3];
     float *dgain[3];
     int64_t ldx, ldy, lddy, lddx, npairs;   // npairs = rows * heads (per part)
@@ -223,14 +228,17 @@ __device__ __forceinline__ float4 shfl8(const float4 &v) {
     return make_float4(__shfl_xor(v.x, 8, 64), __shfl_xor(v.y, 8, 64), __shfl_xor(v.z, 8, 64), __shfl_xor(v.w, 8, 64));
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void headnorm_rope_fwd_kernel(HeadNormArgs a) {
+    const T *x = static_cast<const T *>(a.x);
+    T *y = static_cast<T *>(a.y);
     const int part = blockIdx.y, sub = threadIdx.x & 15, H = a.heads * 64;
     const bool rope = (a.rope_mask >> part) & 1;
     const float4 g = ld4(a.gain[part] + sub * 4);
     for (int64_t pr = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); pr < a.npairs; pr += (int64_t)gridDim.x * 16) {
         const int64_t row = pr / a.heads;
         const int col = part * H + (int)(pr - row * a.heads) * 64 + sub * 4;
-        const float4 v = ld4(a.x + row * a.ldx + col);
+        const float4 v = ldv4<T>(x + row * a.ldx + col);
         const float rs = 1.f / sqrtf(sum16(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w) * (1.f / 64.f) + FLT_EPSILON);
         float4 n = make_float4(v.x * rs * g.x, v.y * rs * g.y, v.z * rs * g.z, v.w * rs * g.w);
         if (rope) {
@@ -240,12 +248,15 @@ __global__ __launch_bounds__(256) void headnorm_rope_fwd_kernel(HeadNormArgs a) 
             n = make_float4(n.x * c.x + sg * o.x * sn.x, n.y * c.y + sg * o.y * sn.y, n.z * c.z + sg * o.z * sn.z,
                             n.w * c.w + sg * o.w * sn.w);
         }
-        st4(a.y + row * a.ldy + col, n);
+        stv4<T>(y + row * a.ldy + col, n);
     }
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void headnorm_rope_bwd_kernel(HeadNormArgs a) {
     __shared__ float red[16][64];
+    const T *x = static_cast<const T *>(a.x), *dy = static_cast<const T *>(a.dy);
+    T *dx = static_cast<T *>(a.dx);
     const int part = blockIdx.y, sub = threadIdx.x & 15, H = a.heads * 64;
     const bool rope = (a.rope_mask >> part) & 1;
     const float4 g = ld4(a.gain[part] + sub * 4);
@@ -253,8 +264,8 @@ __global__ __launch_bounds__(256) void headnorm_rope_bwd_kernel(HeadNormArgs a) 
     for (int64_t pr = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); pr < a.npairs; pr += (int64_t)gridDim.x * 16) {
         const int64_t row = pr / a.heads;
         const int col = part * H + (int)(pr - row * a.heads) * 64 + sub * 4;
-        const float4 v = ld4(a.x + row * a.ldx + col);
-        float4 dn = ld4(a.dy + row * a.lddy + col);
+        const float4 v = ldv4<T>(x + row * a.ldx + col);
+        float4 dn = ldv4<T>(dy + row * a.lddy + col);
         const float rs = 1.f / sqrtf(sum16(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w) * (1.f / 64.f) + FLT_EPSILON);
         if (rope) {     // dn[d] = dy[d] cos[d] + (d < 32 ? dy[d+32] sin[d+32] : -dy[d-32] sin[d-32])
             const int pos = (int)(row % a.S);
@@ -266,7 +277,7 @@ __global__ __launch_bounds__(256) void headnorm_rope_bwd_kernel(HeadNormArgs a) 
         acc.x += dn.x * v.x * rs; acc.y += dn.y * v.y * rs; acc.z += dn.z * v.z * rs; acc.w += dn.w * v.w * rs;
         const float4 dg = make_float4(dn.x * g.x, dn.y * g.y, dn.z * g.z, dn.w * g.w);
         const float k = sum16(dg.x * v.x + dg.y * v.y + dg.z * v.z + dg.w * v.w) * (1.f / 64.f) * rs * rs * rs;
-        st4(a.dx + row * a.lddx + col, make_float4(rs * dg.x - v.x * k, rs * dg.y - v.y * k, rs * dg.z - v.z * k, rs * dg.w - v.w * k));
+        stv4<T>(dx + row * a.lddx + col, make_float4(rs * dg.x - v.x * k, rs * dg.y - v.y * k, rs * dg.z - v.z * k, rs * dg.w - v.w * k));
     }
     st4(&red[threadIdx.x >> 4][sub * 4], acc);
     __syncthreads();
@@ -418,51 +429,67 @@ inline int row_blocks(int64_t rows) { return kk_cdiv(rows, 4); }
                (long)rows, H)
 
 extern "C" int kk_layernorm_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean,
-                                float *rstd, int64_t rows, int H, void *stream) {
+                                float *rstd, int64_t rows, int H, int y_bf16, void *stream) {
     KK_CHECK_H("kk_layernorm_fwd");
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(row_blocks(rows)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
-                       y, mean, rstd, rows, H);
+    if (y_bf16)
+        hipLaunchKernelGGL(layernorm_fwd_kernel<__bf16>, dim3(row_blocks(rows)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
+                           reinterpret_cast<__bf16 *>(y), mean, rstd, rows, H);
+    else
+        hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(row_blocks(rows)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
+                           y, mean, rstd, rows, H);
     KK_LAUNCH_CHECK("kk_layernorm_fwd");
     return 0;
 }
 
 extern "C" int kk_layernorm_bwd(const float *dy, const float *x, const float *gamma, const float *mean,
                                 const float *rstd, float *dx, int dx_accumulate, float *dgamma, float *dbeta,
-                                int64_t rows, int H, void *stream) {
+                                int64_t rows, int H, int dy_bf16, void *stream) {
     KK_CHECK_H("kk_layernorm_bwd");
     int blocks = kk_cdiv(rows, 16);
     if (blocks > 256) blocks = 256;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 2 * H * sizeof(float), (hipStream_t)stream, dy, x,
-                       gamma, mean, rstd, dx, dx_accumulate, dgamma, dbeta, rows, H);
+    if (dy_bf16)
+        hipLaunchKernelGGL(layernorm_bwd_kernel<__bf16>, dim3(blocks), dim3(256), 2 * H * sizeof(float), (hipStream_t)stream,
+                           reinterpret_cast<const __bf16 *>(dy), x, gamma, mean, rstd, dx, dx_accumulate, dgamma, dbeta, rows, H);
+    else
+        hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(blocks), dim3(256), 2 * H * sizeof(float), (hipStream_t)stream, dy, x,
+                           gamma, mean, rstd, dx, dx_accumulate, dgamma, dbeta, rows, H);
     KK_LAUNCH_CHECK("kk_layernorm_bwd");
     return 0;
 }
 
 extern "C" int kk_rmsnorm_fwd(const float *x, const float *gain, const float *residual, float *y, float *rstd,
-                              int64_t rows, int H, void *stream) {
+                              int64_t rows, int H, int x_bf16, void *stream) {
     KK_CHECK_H("kk_rmsnorm_fwd");
-    hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(row_blocks(rows)), dim3(256), 0, (hipStream_t)stream, x, gain, residual,
-                       y, rstd, rows, H);
+    if (x_bf16)
+        hipLaunchKernelGGL(rmsnorm_fwd_kernel<__bf16>, dim3(row_blocks(rows)), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const __bf16 *>(x), gain, residual, y, rstd, rows, H);
+    else
+        hipLaunchKernelGGL(rmsnorm_fwd_kernel<float>, dim3(row_blocks(rows)), dim3(256), 0, (hipStream_t)stream, x, gain, residual,
+                           y, rstd, rows, H);
     KK_LAUNCH_CHECK("kk_rmsnorm_fwd");
     return 0;
 }
 
 extern "C" int kk_rmsnorm_bwd(const float *dy, const float *x, const float *gain, const float *rstd, float *dx,
-                              float *dgain, int64_t rows, int H, void *stream) {
+                              float *dgain, int64_t rows, int H, int x_bf16, void *stream) {
     KK_CHECK_H("kk_rmsnorm_bwd");
     int blocks = kk_cdiv(rows, 16);
     if (blocks > 256) blocks = 256;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(blocks), dim3(256), H * sizeof(float), (hipStream_t)stream, dy, x, gain,
-                       rstd, dx, dgain, rows, H);
+    if (x_bf16)
+        hipLaunchKernelGGL(rmsnorm_bwd_kernel<__bf16>, dim3(blocks), dim3(256), H * sizeof(float), (hipStream_t)stream, dy,
+                           reinterpret_cast<const __bf16 *>(x), gain, rstd, reinterpret_cast<__bf16 *>(dx), dgain, rows, H);
+    else
+        hipLaunchKernelGGL(rmsnorm_bwd_kernel<float>, dim3(blocks), dim3(256), H * sizeof(float), (hipStream_t)stream, dy, x, gain,
+                           rstd, dx, dgain, rows, H);
     KK_LAUNCH_CHECK("kk_rmsnorm_bwd");
     return 0;
 }
 
 extern "C" int kk_headnorm_rope_fwd(const float *x, int64_t ldx, float *y, int64_t ldy, int64_t rows, int heads, int S,
                                     int parts, const float *gain0, const float *gain1, const float *gain2, int rope_mask,
-                                    const float *cos_t, const float *sin_t, void *stream) {
+                                    const float *cos_t, const float *sin_t, int io_bf16, void *stream) {
     KK_REQUIRE(rows > 0 && heads > 0 && S > 0 && parts >= 1 && parts <= 3 && gain0, "kk_headnorm_rope_fwd: bad shape");
     KK_REQUIRE(rope_mask == 0 || (cos_t && sin_t), "kk_headnorm_rope_fwd: RoPE needs cos/sin tables");
     KK_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "kk_headnorm_rope_fwd: strides must be multiples of 4");
@@ -471,7 +498,8 @@ extern "C" int kk_headnorm_rope_fwd(const float *x, int64_t ldx, float *y, int64
     a.ldx = ldx; a.ldy = ldy; a.npairs = rows * heads; a.heads = heads; a.S = S; a.rope_mask = rope_mask;
     int blocks = kk_cdiv(a.npairs, 16 * 2);
     blocks = blocks > 2048 ? 2048 : (blocks < 1 ? 1 : blocks);
-    hipLaunchKernelGGL(headnorm_rope_fwd_kernel, dim3(blocks, parts), dim3(256), 0, (hipStream_t)stream, a);
+    if (io_bf16) hipLaunchKernelGGL(headnorm_rope_fwd_kernel<__bf16>, dim3(blocks, parts), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(headnorm_rope_fwd_kernel<float>, dim3(blocks, parts), dim3(256), 0, (hipStream_t)stream, a);
     KK_LAUNCH_CHECK("kk_headnorm_rope_fwd");
     return 0;
 }
@@ -479,7 +507,7 @@ extern "C" int kk_headnorm_rope_fwd(const float *x, int64_t ldx, float *y, int64
 extern "C" int kk_headnorm_rope_bwd(const float *dy, int64_t lddy, const float *x, int64_t ldx, float *dx, int64_t lddx,
                                     int64_t rows, int heads, int S, int parts, const float *gain0, const float *gain1,
                                     const float *gain2, float *dgain0, float *dgain1, float *dgain2, int rope_mask,
-                                    const float *cos_t, const float *sin_t, void *stream) {
+                                    const float *cos_t, const float *sin_t, int io_bf16, void *stream) {
     KK_REQUIRE(rows > 0 && heads > 0 && S > 0 && parts >= 1 && parts <= 3 && gain0 && dgain0, "kk_headnorm_rope_bwd: bad shape");
     KK_REQUIRE(rope_mask == 0 || (cos_t && sin_t), "kk_headnorm_rope_bwd: RoPE needs cos/sin tables");
     KK_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "kk_headnorm_rope_bwd: strides must be multiples of 4");
@@ -489,7 +517,8 @@ extern "C" int kk_headnorm_rope_bwd(const float *dy, int64_t lddy, const float *
     a.ldx = ldx; a.lddy = lddy; a.lddx = lddx; a.npairs = rows * heads; a.heads = heads; a.S = S; a.rope_mask = rope_mask;
     int blocks = kk_cdiv(a.npairs, 16 * 8);
     blocks = blocks > 512 ? 512 : (blocks < 1 ? 1 : blocks);
-    hipLaunchKernelGGL(headnorm_rope_bwd_kernel, dim3(blocks, parts), dim3(256), 0, (hipStream_t)stream, a);
+    if (io_bf16) hipLaunchKernelGGL(headnorm_rope_bwd_kernel<__bf16>, dim3(blocks, parts), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(headnorm_rope_bwd_kernel<float>, dim3(blocks, parts), dim3(256), 0, (hipStream_t)stream, a);
     KK_LAUNCH_CHECK("kk_headnorm_rope_bwd");
     return 0;
 }

@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float *__restrict__ p, c
                                                         const int32_t *__restrict__ block_seg, const float *__restrict__ seg_gscale,
                                                         const float *__restrict__ seg_decay, const float *__restrict__ seg_stepsize,
                                                         const int32_t *__restrict__ seg_flags, const float *__restrict__ step_consts,
-                                                        float beta1, float beta2, float ema_decay, double *__restrict__ p_sumsq) {
+                                                        float beta1, float beta2, float ema_decay, double *__restrict__ p_sumsq,
+                                                        __bf16 *__restrict__ p16) {
     __shared__ float red[4];
     if (step_consts[0] != 0.f) return;                // non-finite gradients: whole step skipped (trainer.py:2407-2463)
     const int64_t blk = blockIdx.x;
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float *__restrict__ p, c
         st4(p + o, pv);
         st4(m + o, mv);
         st4(v + o, vv);
+        if (p16) stv4<__bf16>(p16 + o, pv);          // bf16 shadow of the master weights: the GEMMs' B operand
     }
     if ((flags & 2) && ema) {
         float4 ev = ld4(ema + o);
@@ -197,7 +199,8 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float *__restrict__ p, c
 
 __global__ __launch_bounds__(256) void weight_norm_project_kernel(float *__restrict__ p, const int32_t *__restrict__ block_seg,
                                                                   const double *__restrict__ p_sumsq, const int32_t *__restrict__ seg_flags,
-                                                                  const float *__restrict__ step_consts, double max_norm) {
+                                                                  const float *__restrict__ step_consts, double max_norm,
+                                                                  __bf16 *__restrict__ p16) {
     if (step_consts[0] != 0.f) return;
     const int64_t blk = blockIdx.x;
     const int seg = block_seg[blk];
@@ -209,6 +212,11 @@ __global__ __launch_bounds__(256) void weight_norm_project_kernel(float *__restr
     float4 pv = ld4(p + o);
     pv.x *= sc; pv.y *= sc; pv.z *= sc; pv.w *= sc;
     st4(p + o, pv);
+    if (p16) stv4<__bf16>(p16 + o, pv);
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float *__restrict__ src, __bf16 *__restrict__ dst, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) stv4<__bf16>(dst + 4 * i, ld4(src + 4 * i));
 }
 
 }  // namespace
@@ -241,7 +249,8 @@ extern "C" int kk_opt_prepare(const double *grad_sumsq, const float *seg_preclip
 extern "C" int kk_adamw_ema(float *p, const float *g, float *m, float *v, float *ema, const int32_t *block_seg,
                             int64_t nblocks, const float *seg_gscale, const float *seg_decay,
                             const float *seg_stepsize, const int32_t *seg_flags, const float *step_consts,
-                            float beta1, float beta2, float ema_decay, double *p_sumsq, int nseg, void *stream) {
+                            float beta1, float beta2, float ema_decay, double *p_sumsq, int nseg, void *p_bf16,
+                            void *stream) {
     KK_REQUIRE(p && g && m && v && block_seg && nblocks > 0 && nblocks < (1ll << 31), "kk_adamw_ema: bad args");
     hipStream_t s = (hipStream_t)stream;
     if (p_sumsq) {
@@ -249,18 +258,27 @@ extern "C" int kk_adamw_ema(float *p, const float *g, float *m, float *v, float 
         if (e != hipSuccess) return kk_fail((int)e, "kk_adamw_ema: memset failed");
     }
     hipLaunchKernelGGL(adamw_ema_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, p, g, m, v, ema, block_seg, seg_gscale,
-                       seg_decay, seg_stepsize, seg_flags, step_consts, beta1, beta2, ema_decay, p_sumsq);
+                       seg_decay, seg_stepsize, seg_flags, step_consts, beta1, beta2, ema_decay, p_sumsq, reinterpret_cast<__bf16 *>(p_bf16));
     KK_LAUNCH_CHECK("kk_adamw_ema");
     return 0;
 }
 
 extern "C" int kk_weight_norm_project(float *p, const int32_t *block_seg, int64_t nblocks, const double *p_sumsq,
                                       const int32_t *seg_flags, const float *step_consts, double max_norm,
-                                      void *stream) {
+                                      void *p_bf16, void *stream) {
     KK_REQUIRE(p && block_seg && p_sumsq && seg_flags && nblocks > 0, "kk_weight_norm_project: bad args");
     if (!(max_norm > 0.0)) return 0;
     hipLaunchKernelGGL(weight_norm_project_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, p, block_seg,
-                       p_sumsq, seg_flags, step_consts, max_norm);
+                       p_sumsq, seg_flags, step_consts, max_norm, reinterpret_cast<__bf16 *>(p_bf16));
     KK_LAUNCH_CHECK("kk_weight_norm_project");
+    return 0;
+}
+
+extern "C" int kk_cast_f32_bf16(const float *src, void *dst, int64_t n, void *stream) {
+    KK_REQUIRE(src && dst && n > 0 && n % 4 == 0, "kk_cast_f32_bf16: n must be a positive multiple of 4");
+    int blocks = kk_cdiv(n / 4, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, reinterpret_cast<__bf16 *>(dst), n / 4);
+    KK_LAUNCH_CHECK("kk_cast_f32_bf16");
     return 0;
 }

@@ -20,6 +20,7 @@ variance predictors' GroupNorm statistics.
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from collections import OrderedDict
 from typing import Dict, Optional, Tuple
@@ -33,10 +34,15 @@ from .spec import VA, ModelDims, StepHyper
 CHUNK = 512   # variance_predictor.py:77
 
 
+def _b16(t) -> int:
+    """1 when the tensor is stored as bf16 (the C ABI's *_bf16 flags are derived from the tensors themselves)."""
+    return 1 if t is not None and t.dtype == torch.bfloat16 else 0
+
+
 class Arena:
     """Flat fp32 slabs p / g / m / v / ema with one 1024-aligned, zero-padded segment per tensor."""
 
-    def __init__(self, dims: ModelDims, hp: StepHyper, device: torch.device):
+    def __init__(self, dims: ModelDims, hp: StepHyper, device: torch.device, shadow_bf16: bool = False):
         self.dims, self.device = dims, device
         self.param_names = list(spec.param_shapes(dims).keys())
         segs = list(spec.param_shapes(dims).items()) + list(spec.buffer_shapes(dims).items())
@@ -53,6 +59,9 @@ class Arena:
         z = lambda: torch.zeros(off, dtype=torch.float32, device=device)
         self.p, self.g, self.m, self.v = z(), z(), z(), z()
         self.ema = z() if hp.use_ema else None
+        # bf16 mode: a bf16 copy of p at the same element offsets, rewritten by the optimizer kernels; the GEMMs read
+        # weights from it (half the bytes, no conversion in the k-loop).  fp32 p stays the master copy.
+        self.p16 = torch.zeros(off, dtype=torch.bfloat16, device=device) if shadow_bf16 else None
         block_seg = torch.empty(self.nblocks, dtype=torch.int32)
         preclip, lr_mult, wd, flags = [], [], [], []
         table = spec.group_lr_mult_wd(hp)
@@ -75,6 +84,7 @@ class Arena:
         self.P = {n: self.view(self.p, n) for n in self.names}
         self.G = {n: self.view(self.g, n) for n in self.names}
         self.E = {n: self.view(self.ema, n) for n in self.names} if hp.use_ema else {}
+        self.P16 = {n: self.view(self.p16, n) for n in self.names} if shadow_bf16 else {}
 
     def view(self, slab: torch.Tensor, name: str) -> torch.Tensor:
         o, s = self.offset[name], self.shapes[name]
@@ -90,7 +100,8 @@ class Arena:
 
 class KokoroEngine:
     def __init__(self, dims: Optional[ModelDims] = None, hyper: Optional[StepHyper] = None, device="cuda",
-                 math_mode: str = "f32", total_steps: int = 20000, seed: int = 0, init: bool = True):
+                 math_mode: str = "f32", total_steps: int = 20000, seed: int = 0, init: bool = True,
+                 storage: str = "auto"):
         kk.load()                                   # fails loudly when libkokoro_hip.so is missing
         if not torch.cuda.is_available():
             raise RuntimeError("KokoroEngine needs an MI355X (no CPU fallback in the product path)")
@@ -100,7 +111,19 @@ class KokoroEngine:
         self.device = torch.device(device)
         self.math = {"f32": kk.KK_MATH_F32, "bf16": kk.KK_MATH_BF16}[math_mode]
         self.math_mode = math_mode
-        self.arena = Arena(self.dims, self.hp, self.device)
+        # activation / weight-operand storage: "f32" everywhere (always in the parity mode), or bf16 for the GEMM and
+        # attention operands of the bf16 mode ("bf16": both stacks, "bf16-dec": decoder stack only).
+        if storage == "auto":      # encoder GEMMs (512 rows) need split-K with fp32 atomic outputs to fill the chip
+            storage = "bf16-dec" if math_mode == "bf16" else "f32"
+        if storage not in ("f32", "bf16", "bf16-dec") or (storage != "f32" and math_mode != "bf16"):
+            raise ValueError(f"storage={storage!r} is not available with math_mode={math_mode!r}")
+        if storage != "f32" and any(v % 8 for v in (self.dims.enc_ff, self.dims.dec_ff, self.dims.var_filter)):
+            raise ValueError("bf16 storage needs enc_ff, dec_ff and var_filter to be multiples of 8")
+        self.storage = storage
+        self.enc_dt = torch.bfloat16 if storage == "bf16" else torch.float32
+        self.dec_dt = torch.bfloat16 if storage in ("bf16", "bf16-dec") else torch.float32
+        self.arena = Arena(self.dims, self.hp, self.device, shadow_bf16=storage != "f32")
+        self.use_shadow = storage != "f32"
         self.total_steps = total_steps
         self._ws: Dict[Tuple, torch.Tensor] = {}
         self._graphs: Dict[Tuple, Dict] = {}
@@ -128,6 +151,7 @@ class KokoroEngine:
             self.load_params(spec.init_params(self.dims, seed))
         elif self.arena.ema is not None:
             self.arena.ema.copy_(self.arena.p)
+        self.sync_shadow()
 
     # ------------------------------------------------------------------ state
     def load_params(self, params: Dict[str, torch.Tensor], reset_ema: bool = True) -> None:
@@ -135,6 +159,24 @@ class KokoroEngine:
             self.arena.P[n].copy_(params[n].to(self.device, torch.float32).view(self.arena.shapes[n]))
         if reset_ema and self.arena.ema is not None:
             self.arena.ema.copy_(self.arena.p)      # EMA starts as a deep copy of the model (trainer.py:835)
+        self.sync_shadow()
+
+    @contextlib.contextmanager
+    def fp32_math(self):
+        """Run the enclosed calls in the fp32 parity mode (fp32 MFMA, fp32 storage, master weights) whatever the
+        engine's training precision is — the reference validates without autocast (trainer.py:1821-1834)."""
+        saved = (self.math, self.enc_dt, self.dec_dt, self.use_shadow)
+        self.math, self.enc_dt, self.dec_dt, self.use_shadow = kk.KK_MATH_F32, torch.float32, torch.float32, False
+        try:
+            yield self
+        finally:
+            self.math, self.enc_dt, self.dec_dt, self.use_shadow = saved
+
+    def sync_shadow(self) -> None:
+        """Rebuild the bf16 weight shadow from the fp32 master arena (after any write to arena.p from outside the
+        optimizer kernels)."""
+        if self.arena.p16 is not None:
+            kk.call("kk_cast_f32_bf16", self.arena.p, self.arena.p16, self.arena.total)
 
     def state_dict(self, ema: bool = False) -> "OrderedDict[str, torch.Tensor]":
         """311 reference-named tensors (views of the arena; clone before mutating)."""
@@ -150,6 +192,7 @@ class KokoroEngine:
             if tuple(sd[n].shape) != tuple(self.arena.shapes[n]):
                 raise RuntimeError(f"size mismatch for {n}: {tuple(sd[n].shape)} vs {self.arena.shapes[n]}")
             self.arena.P[n].copy_(sd[n].to(self.device, torch.float32))
+        self.sync_shadow()
 
     def grads(self) -> "OrderedDict[str, torch.Tensor]":
         return OrderedDict((n, self.arena.G[n]) for n in self.arena.param_names)
@@ -169,37 +212,49 @@ class KokoroEngine:
             self._rope[S] = (c.to(self.device), s.to(self.device))
         return self._rope[S]
 
+    def _W(self, name: str) -> torch.Tensor:
+        """GEMM weight operand: the bf16 shadow when there is one, else the fp32 master."""
+        if self.use_shadow and self.arena.shapes[name][-1] % 8 == 0:      # bf16 rows are fetched 8 elements at a time
+            return self.arena.P16[name]
+        return self.arena.P[name]
+
+    def _Wf(self, first: str, count: int) -> torch.Tensor:
+        a = self.arena
+        return a.fused(a.p16 if self.use_shadow else a.p, first, count)
+
     def _linear(self, x, W, b, out, res=None, res_mod=0):
         N, K = x.shape
         M = W.shape[0]
         # split_k = 0: kk_gemm splits K (fp32 atomics) by itself when the tile grid is too small to fill the chip
         kk.call("kk_gemm", 0, 0, N, M, K, 1.0, x, x.stride(0), W, K, 0.0, out, out.stride(0), b, res,
-                res.stride(0) if res is not None else 0, res_mod, 0, self.math)
+                res.stride(0) if res is not None else 0, res_mod, 0, self.math, _b16(x) | _b16(W) << 1 | _b16(out) << 2)
 
     def _dgrad(self, dy, W, dx, beta=0.0):
         N, M = dy.shape
         K = W.shape[1]
-        kk.call("kk_gemm", 0, 1, N, K, M, 1.0, dy, dy.stride(0), W, K, beta, dx, dx.stride(0), None, None, 0, 0, 0, self.math)
+        kk.call("kk_gemm", 0, 1, N, K, M, 1.0, dy, dy.stride(0), W, K, beta, dx, dx.stride(0), None, None, 0, 0, 0, self.math,
+                _b16(dy) | _b16(W) << 1 | _b16(dx) << 2)
 
     def _wgrad(self, dy, x, dW, db=None):
         N, M = dy.shape
         K = x.shape[1]
-        kk.call("kk_gemm", 1, 1, M, K, N, 1.0, dy, dy.stride(0), x, x.stride(0), 1.0, dW, K, None, None, 0, 0, 0, self.math)
+        kk.call("kk_gemm", 1, 1, M, K, N, 1.0, dy, dy.stride(0), x, x.stride(0), 1.0, dW, K, None, None, 0, 0, 0, self.math,
+                _b16(dy) | _b16(x) << 1)
         if db is not None:
-            kk.call("kk_colsum_acc", dy, dy.stride(0), N, M, db)
+            kk.call("kk_colsum_acc", dy, dy.stride(0), N, M, db, _b16(dy))
 
-    def _ln_fwd(self, key, x, prefix):
+    def _ln_fwd(self, key, x, prefix, dtype=torch.float32):
         P = self.arena.P
         rows, H = x.shape
-        y, mean, rstd = self._buf(key + ".y", rows, H), self._buf(key + ".mean", rows), self._buf(key + ".rstd", rows)
-        kk.call("kk_layernorm_fwd", x, P[prefix + ".weight"], P[prefix + ".bias"], y, mean, rstd, rows, H)
+        y, mean, rstd = self._buf(key + ".y", rows, H, dtype=dtype), self._buf(key + ".mean", rows), self._buf(key + ".rstd", rows)
+        kk.call("kk_layernorm_fwd", x, P[prefix + ".weight"], P[prefix + ".bias"], y, mean, rstd, rows, H, _b16(y))
         return y
 
     def _ln_bwd(self, key, dy, x, prefix, dx, accumulate):
         P, G = self.arena.P, self.arena.G
         rows, H = x.shape
         kk.call("kk_layernorm_bwd", dy, x, P[prefix + ".weight"], self._buf(key + ".mean", rows), self._buf(key + ".rstd", rows),
-                dx, 1 if accumulate else 0, G[prefix + ".weight"], G[prefix + ".bias"], rows, H)
+                dx, 1 if accumulate else 0, G[prefix + ".weight"], G[prefix + ".bias"], rows, H, _b16(dy))
 
     # ------------------------------------------------------------------ dropout plumbing
     def _p(self, rate: float) -> float:
@@ -221,34 +276,36 @@ class KokoroEngine:
     # ------------------------------------------------------------------ attention sub-layer
     def _attn_fwd(self, key, prefix, xq, xkv, B, Sq, Sk, rope, causal, key_mask, x_res, x_out, site=0, p=0.0, dpr=0.0):
         """x_out = x_res + w_o(attention(...)) + b_o.  xq [B*Sq,H] (post-LN), xkv [B*Sk,H] (None = self-attention)."""
-        a, P, H, h = self.arena, self.arena.P, self.dims.hidden, self.dims.heads
+        P, H, h = self.arena.P, self.dims.hidden, self.dims.heads
         Nq, Nk = B * Sq, B * Sk
+        dt = xq.dtype                                   # storage of every activation of the sub-layer
+        i16 = _b16(xq)
         cos, sin = self._rope_tables(max(Sq, Sk)) if rope else (None, None)
         if xkv is None:
-            raw, nrm = self._buf(key + ".qkv_raw", Nq, 3 * H), self._buf(key + ".qkv_n", Nq, 3 * H)
-            self._linear(xq, a.fused(a.p, prefix + ".w_q.weight", 3), None, raw)
+            raw, nrm = self._buf(key + ".qkv_raw", Nq, 3 * H, dtype=dt), self._buf(key + ".qkv_n", Nq, 3 * H, dtype=dt)
+            self._linear(xq, self._Wf(prefix + ".w_q.weight", 3), None, raw)
             q_raw, k_raw, v_raw, q_n, k_n, v_n = raw, raw[:, H:], raw[:, 2 * H:], nrm, nrm[:, H:], nrm[:, 2 * H:]
         else:
-            q_raw, q_n = self._buf(key + ".q_raw", Nq, H), self._buf(key + ".q_n", Nq, H)
-            kv_raw, kv_n = self._buf(key + ".kv_raw", Nk, 2 * H), self._buf(key + ".kv_n", Nk, 2 * H)
-            self._linear(xq, P[prefix + ".w_q.weight"], None, q_raw)
-            self._linear(xkv, a.fused(a.p, prefix + ".w_k.weight", 2), None, kv_raw)
+            q_raw, q_n = self._buf(key + ".q_raw", Nq, H, dtype=dt), self._buf(key + ".q_n", Nq, H, dtype=dt)
+            kv_raw, kv_n = self._buf(key + ".kv_raw", Nk, 2 * H, dtype=dt), self._buf(key + ".kv_n", Nk, 2 * H, dtype=dt)
+            self._linear(xq, self._W(prefix + ".w_q.weight"), None, q_raw)
+            self._linear(xkv, self._Wf(prefix + ".w_k.weight", 2), None, kv_raw)
             k_raw, v_raw, k_n, v_n = kv_raw, kv_raw[:, H:], kv_n, kv_n[:, H:]
         gq, gk, gv = P[prefix + ".q_norm.weight"], P[prefix + ".k_norm.weight"], P[prefix + ".v_norm.weight"]
         if xkv is None:       # q|k|v in one launch over the fused projection; RoPE on q and k only
-            kk.call("kk_headnorm_rope_fwd", raw, 3 * H, nrm, 3 * H, Nq, h, Sq, 3, gq, gk, gv, 3 if rope else 0, cos, sin)
+            kk.call("kk_headnorm_rope_fwd", raw, 3 * H, nrm, 3 * H, Nq, h, Sq, 3, gq, gk, gv, 3 if rope else 0, cos, sin, i16)
         else:
-            kk.call("kk_headnorm_rope_fwd", q_raw, H, q_n, H, Nq, h, Sq, 1, gq, None, None, 0, None, None)
-            kk.call("kk_headnorm_rope_fwd", kv_raw, 2 * H, kv_n, 2 * H, Nk, h, Sk, 2, gk, gv, None, 0, None, None)
-        ctx, lse = self._buf(key + ".ctx", Nq, H), self._buf(key + ".lse", B, h, Sq)
+            kk.call("kk_headnorm_rope_fwd", q_raw, H, q_n, H, Nq, h, Sq, 1, gq, None, None, 0, None, None, i16)
+            kk.call("kk_headnorm_rope_fwd", kv_raw, 2 * H, kv_n, 2 * H, Nk, h, Sk, 2, gk, gv, None, 0, None, None, i16)
+        ctx, lse = self._buf(key + ".ctx", Nq, H, dtype=dt), self._buf(key + ".lse", B, h, Sq)
         kk.call("kk_attn_fwd", q_n, k_n, v_n, ctx, lse, B, h, Sq, Sk, q_n.stride(0), k_n.stride(0), v_n.stride(0), H, key_mask,
-                1 if causal else 0, 0.125, self.rng, site + 3, p, self.math)
+                1 if causal else 0, 0.125, self.rng, site + 3, p, self.math, i16)
         if p > 0.0 or dpr > 0.0:
             proj = self._buf("tmp.attn_proj", Nq, H)
-            self._linear(ctx, P[prefix + ".w_o.weight"], P[prefix + ".w_o.bias"], proj)
+            self._linear(ctx, self._W(prefix + ".w_o.weight"), P[prefix + ".w_o.bias"], proj)
             self._residual(proj, x_res, x_out, Sq, site, p, dpr)
         else:
-            self._linear(ctx, P[prefix + ".w_o.weight"], P[prefix + ".w_o.bias"], x_out, res=x_res)
+            self._linear(ctx, self._W(prefix + ".w_o.weight"), P[prefix + ".w_o.bias"], x_out, res=x_res)
 
     def _attn_bwd(self, key, prefix, d_out, xq, xkv, B, Sq, Sk, rope, causal, key_mask, d_xq, d_xkv, d_xkv_beta,
                   site=0, p=0.0, dpr=0.0):
@@ -256,83 +313,90 @@ class KokoroEngine:
         for cross-attention, d_xkv (+= when d_xkv_beta == 1)."""
         a, P, G, H, h = self.arena, self.arena.P, self.arena.G, self.dims.hidden, self.dims.heads
         Nq, Nk = B * Sq, B * Sk
+        dt = xq.dtype
+        i16 = _b16(xq)
         cos, sin = self._rope_tables(max(Sq, Sk)) if rope else (None, None)
-        ctx, lse = self._buf(key + ".ctx", Nq, H), self._buf(key + ".lse", B, h, Sq)
-        dctx, delta = self._buf("tmp.dctx", Nq, H), self._buf("tmp.delta", B, h, Sq)
+        ctx, lse = self._buf(key + ".ctx", Nq, H, dtype=dt), self._buf(key + ".lse", B, h, Sq)
+        dctx, delta = self._buf("tmp.dctx", Nq, H, dtype=dt), self._buf("tmp.delta", B, h, Sq)
         if p > 0.0 or dpr > 0.0:
             masked = self._buf("tmp.d_attn_proj", Nq, H)
             self._residual_bwd(d_out, masked, Sq, site, p, dpr)
             d_out = masked
         self._wgrad(d_out, ctx, G[prefix + ".w_o.weight"], G[prefix + ".w_o.bias"])
-        self._dgrad(d_out, P[prefix + ".w_o.weight"], dctx)
-        kk.call("kk_attn_delta", ctx, dctx, delta, B, h, Sq, H, H)
+        self._dgrad(d_out, self._W(prefix + ".w_o.weight"), dctx)
+        kk.call("kk_attn_delta", ctx, dctx, delta, B, h, Sq, H, H, i16)
         if xkv is None:
-            raw, nrm = self._buf(key + ".qkv_raw", Nq, 3 * H), self._buf(key + ".qkv_n", Nq, 3 * H)
-            dn, draw = self._buf("tmp.dqkv_n", Nq, 3 * H), self._buf("tmp.dqkv_raw", Nq, 3 * H)
+            raw, nrm = self._buf(key + ".qkv_raw", Nq, 3 * H, dtype=dt), self._buf(key + ".qkv_n", Nq, 3 * H, dtype=dt)
+            dn, draw = self._buf("tmp.dqkv_n", Nq, 3 * H, dtype=dt), self._buf("tmp.dqkv_raw", Nq, 3 * H, dtype=dt)
             q_raw, k_raw, v_raw, q_n, k_n, v_n = raw, raw[:, H:], raw[:, 2 * H:], nrm, nrm[:, H:], nrm[:, 2 * H:]
             dq_n, dk_n, dv_n, dq_raw, dk_raw, dv_raw = dn, dn[:, H:], dn[:, 2 * H:], draw, draw[:, H:], draw[:, 2 * H:]
         else:
-            q_raw, q_n = self._buf(key + ".q_raw", Nq, H), self._buf(key + ".q_n", Nq, H)
-            kv_raw, kv_n = self._buf(key + ".kv_raw", Nk, 2 * H), self._buf(key + ".kv_n", Nk, 2 * H)
-            dq_n, dq_raw = self._buf("tmp.dq_n", Nq, H), self._buf("tmp.dq_raw", Nq, H)
-            dkv_n, dkv_raw = self._buf("tmp.dkv_n", Nk, 2 * H), self._buf("tmp.dkv_raw", Nk, 2 * H)
+            q_raw, q_n = self._buf(key + ".q_raw", Nq, H, dtype=dt), self._buf(key + ".q_n", Nq, H, dtype=dt)
+            kv_raw, kv_n = self._buf(key + ".kv_raw", Nk, 2 * H, dtype=dt), self._buf(key + ".kv_n", Nk, 2 * H, dtype=dt)
+            dq_n, dq_raw = self._buf("tmp.dq_n", Nq, H, dtype=dt), self._buf("tmp.dq_raw", Nq, H, dtype=dt)
+            dkv_n, dkv_raw = self._buf("tmp.dkv_n", Nk, 2 * H, dtype=dt), self._buf("tmp.dkv_raw", Nk, 2 * H, dtype=dt)
             k_raw, v_raw, k_n, v_n = kv_raw, kv_raw[:, H:], kv_n, kv_n[:, H:]
             dk_n, dv_n, dk_raw, dv_raw = dkv_n, dkv_n[:, H:], dkv_raw, dkv_raw[:, H:]
         ld = lambda t: t.stride(0)
         kk.call("kk_attn_bwd_dq", q_n, k_n, v_n, dctx, lse, delta, dq_n, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H, ld(dq_n),
-                key_mask, 1 if causal else 0, 0.125, self.rng, site + 3, p, self.math)
+                key_mask, 1 if causal else 0, 0.125, self.rng, site + 3, p, self.math, i16)
         kk.call("kk_attn_bwd_dkv", q_n, k_n, v_n, dctx, lse, delta, dk_n, dv_n, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H,
-                ld(dk_n), ld(dv_n), key_mask, 1 if causal else 0, 0.125, self.rng, site + 3, p, self.math)
+                ld(dk_n), ld(dv_n), key_mask, 1 if causal else 0, 0.125, self.rng, site + 3, p, self.math, i16)
         gq, gk, gv = P[prefix + ".q_norm.weight"], P[prefix + ".k_norm.weight"], P[prefix + ".v_norm.weight"]
         dgq, dgk, dgv = G[prefix + ".q_norm.weight"], G[prefix + ".k_norm.weight"], G[prefix + ".v_norm.weight"]
         if xkv is None:
             kk.call("kk_headnorm_rope_bwd", dn, 3 * H, raw, 3 * H, draw, 3 * H, Nq, h, Sq, 3, gq, gk, gv, dgq, dgk, dgv,
-                    3 if rope else 0, cos, sin)
+                    3 if rope else 0, cos, sin, i16)
         else:
-            kk.call("kk_headnorm_rope_bwd", dq_n, H, q_raw, H, dq_raw, H, Nq, h, Sq, 1, gq, None, None, dgq, None, None, 0, None, None)
+            kk.call("kk_headnorm_rope_bwd", dq_n, H, q_raw, H, dq_raw, H, Nq, h, Sq, 1, gq, None, None, dgq, None, None, 0, None, None, i16)
             kk.call("kk_headnorm_rope_bwd", dkv_n, 2 * H, kv_raw, 2 * H, dkv_raw, 2 * H, Nk, h, Sk, 2, gk, gv, None, dgk, dgv, None,
-                    0, None, None)
+                    0, None, None, i16)
         if xkv is None:
             self._wgrad(draw, xq, a.fused(a.g, prefix + ".w_q.weight", 3))
-            self._dgrad(draw, a.fused(a.p, prefix + ".w_q.weight", 3), d_xq)
+            self._dgrad(draw, self._Wf(prefix + ".w_q.weight", 3), d_xq)
         else:
             self._wgrad(dq_raw, xq, G[prefix + ".w_q.weight"])
-            self._dgrad(dq_raw, P[prefix + ".w_q.weight"], d_xq)
+            self._dgrad(dq_raw, self._W(prefix + ".w_q.weight"), d_xq)
             if d_xkv is not None:
                 self._wgrad(dkv_raw, xkv, a.fused(a.g, prefix + ".w_k.weight", 2))
-                self._dgrad(dkv_raw, a.fused(a.p, prefix + ".w_k.weight", 2), d_xkv, beta=d_xkv_beta)
+                self._dgrad(dkv_raw, self._Wf(prefix + ".w_k.weight", 2), d_xkv, beta=d_xkv_beta)
 
     # ------------------------------------------------------------------ GLU feed-forward sub-layer
     def _ffn_fwd(self, key, prefix, y, x_res, x_out, Fd, S=1, site=0, p=0.0, dpr=0.0):
         P = self.arena.P
         N, H = y.shape
-        h1, g, f2 = self._buf(key + ".h1", N, 2 * Fd), self._buf(key + ".g", N, Fd), self._buf(key + ".f2", N, H)
-        self._linear(y, P[prefix + ".linear1.weight"], P[prefix + ".linear1.bias"], h1)
-        kk.call("kk_glu_fwd", h1, g, N, Fd, self.rng, site + 4, p)
-        self._linear(g, P[prefix + ".linear2.weight"], P[prefix + ".linear2.bias"], f2)
+        dt, i16 = y.dtype, _b16(y)
+        h1, g, f2 = (self._buf(key + ".h1", N, 2 * Fd, dtype=dt), self._buf(key + ".g", N, Fd, dtype=dt),
+                     self._buf(key + ".f2", N, H, dtype=dt))
+        self._linear(y, self._W(prefix + ".linear1.weight"), P[prefix + ".linear1.bias"], h1)
+        kk.call("kk_glu_fwd", h1, g, N, Fd, self.rng, site + 4, p, i16)
+        self._linear(g, self._W(prefix + ".linear2.weight"), P[prefix + ".linear2.bias"], f2)
         if p > 0.0 or dpr > 0.0:      # rmsnorm -> FFN dropout (:111) -> drop_path -> residual dropout
             nrm = self._buf("tmp.ffn_norm", N, H)
-            kk.call("kk_rmsnorm_fwd", f2, P[prefix + ".output_norm.weight"], None, nrm, self._buf(key + ".rstd_f", N), N, H)
+            kk.call("kk_rmsnorm_fwd", f2, P[prefix + ".output_norm.weight"], None, nrm, self._buf(key + ".rstd_f", N), N, H, i16)
             self._residual(nrm, x_res, x_out, S, site, p, dpr, p2=p)
         else:
-            kk.call("kk_rmsnorm_fwd", f2, P[prefix + ".output_norm.weight"], x_res, x_out, self._buf(key + ".rstd_f", N), N, H)
+            kk.call("kk_rmsnorm_fwd", f2, P[prefix + ".output_norm.weight"], x_res, x_out, self._buf(key + ".rstd_f", N), N, H, i16)
 
     def _ffn_bwd(self, key, prefix, d_out, y, d_y, Fd, S=1, site=0, p=0.0, dpr=0.0):
         P, G = self.arena.P, self.arena.G
         N, H = y.shape
-        h1, g, f2 = self._buf(key + ".h1", N, 2 * Fd), self._buf(key + ".g", N, Fd), self._buf(key + ".f2", N, H)
-        df2, dg, dh1 = self._buf("tmp.df2", N, H), self._buf("tmp.dg", N, Fd), self._buf("tmp.dh1", N, 2 * Fd)
+        dt, i16 = y.dtype, _b16(y)
+        h1, g, f2 = (self._buf(key + ".h1", N, 2 * Fd, dtype=dt), self._buf(key + ".g", N, Fd, dtype=dt),
+                     self._buf(key + ".f2", N, H, dtype=dt))
+        df2, dg, dh1 = (self._buf("tmp.df2", N, H, dtype=dt), self._buf("tmp.dg", N, Fd, dtype=dt),
+                        self._buf("tmp.dh1", N, 2 * Fd, dtype=dt))
         if p > 0.0 or dpr > 0.0:
             masked = self._buf("tmp.d_ffn_norm", N, H)
             self._residual_bwd(d_out, masked, S, site, p, dpr, p2=p)
             d_out = masked
         kk.call("kk_rmsnorm_bwd", d_out, f2, P[prefix + ".output_norm.weight"], self._buf(key + ".rstd_f", N), df2,
-                G[prefix + ".output_norm.weight"], N, H)
+                G[prefix + ".output_norm.weight"], N, H, i16)
         self._wgrad(df2, g, G[prefix + ".linear2.weight"], G[prefix + ".linear2.bias"])
-        self._dgrad(df2, P[prefix + ".linear2.weight"], dg)
-        kk.call("kk_glu_bwd", dg, h1, dh1, N, Fd, self.rng, site + 4, p)
+        self._dgrad(df2, self._W(prefix + ".linear2.weight"), dg)
+        kk.call("kk_glu_bwd", dg, h1, dh1, N, Fd, self.rng, site + 4, p, i16)
         self._wgrad(dh1, y, G[prefix + ".linear1.weight"], G[prefix + ".linear1.bias"])
-        self._dgrad(dh1, P[prefix + ".linear1.weight"], d_y)
+        self._dgrad(dh1, self._W(prefix + ".linear1.weight"), d_y)
 
     # ------------------------------------------------------------------ variance predictor
     def _varpred_fwd(self, key, prefix, x, col1, B, L, mask, out, site=0, p=0.0):
@@ -344,13 +408,13 @@ class KokoroEngine:
         for li in range(2):
             c, y = self._buf(f"{key}.c{li}", rows, Fv), self._buf(f"{key}.y{li}", rows, Fv)
             stats = self._buf(f"{key}.st{li}", B * nch, 2)
-            self._linear(inp_col, P[f"{prefix}.conv_layers.{li}.weight"].view(Fv, 3 * cin), P[f"{prefix}.conv_layers.{li}.bias"], c)
+            self._linear(inp_col, self._W(f"{prefix}.conv_layers.{li}.weight").view(Fv, 3 * cin), P[f"{prefix}.conv_layers.{li}.bias"], c)
             kk.call("kk_groupnorm_relu_fwd", c, P[f"{prefix}.norms.{li}.weight"], P[f"{prefix}.norms.{li}.bias"], y, stats,
                     scratch, B, L, Fv, CHUNK, self.rng, site + li, p)
             if li == 0:
-                inp_col, cin = self._buf(f"{key}.col2", rows, 3 * Fv), Fv
-                kk.call("kk_im2col3_fwd", y, inp_col, B, L, Fv, CHUNK)
-        kk.call("kk_rowdot_fwd", y, P[f"{prefix}.linear.weight"], P[f"{prefix}.linear.bias"], mask, out, rows, Fv, L, CHUNK)
+                inp_col, cin = self._buf(f"{key}.col2", rows, 3 * Fv, dtype=col1.dtype), Fv
+                kk.call("kk_im2col3_fwd", y, inp_col, B, L, Fv, CHUNK, _b16(inp_col))
+        kk.call("kk_rowdot_fwd", y, P[f"{prefix}.linear.weight"], P[f"{prefix}.linear.bias"], mask, out, rows, Fv, L, CHUNK, 0)
 
     def _varpred_bwd(self, key, prefix, dout, x, col1, B, L, mask, dx, p=0.0):
         """Accumulate the predictor's parameter grads; write dx (dL/dx) when dx is not None."""
@@ -360,19 +424,19 @@ class KokoroEngine:
         dy, dc = self._buf("tmp.vp_dy", rows, Fv), self._buf("tmp.vp_dc", rows, Fv)
         y1 = self._buf(f"{key}.y1", rows, Fv)
         kk.call("kk_rowdot_bwd", dout, y1, P[f"{prefix}.linear.weight"], mask, dy, G[f"{prefix}.linear.weight"],
-                G[f"{prefix}.linear.bias"], rows, Fv, L, CHUNK)
+                G[f"{prefix}.linear.bias"], rows, Fv, L, CHUNK, 0)
         for li in (1, 0):
             c, y, stats = self._buf(f"{key}.c{li}", rows, Fv), self._buf(f"{key}.y{li}", rows, Fv), self._buf(f"{key}.st{li}", B * nch, 2)
             cin = Fv if li == 1 else H
-            col = self._buf(f"{key}.col2", rows, 3 * Fv) if li == 1 else col1
+            col = self._buf(f"{key}.col2", rows, 3 * Fv, dtype=col1.dtype) if li == 1 else col1
             kk.call("kk_groupnorm_relu_bwd", dy, c, y, P[f"{prefix}.norms.{li}.weight"], stats, dc, G[f"{prefix}.norms.{li}.weight"],
                     G[f"{prefix}.norms.{li}.bias"], scratch, B, L, Fv, CHUNK, p)
-            W, dW = P[f"{prefix}.conv_layers.{li}.weight"].view(Fv, 3 * cin), G[f"{prefix}.conv_layers.{li}.weight"].view(Fv, 3 * cin)
+            W, dW = self._W(f"{prefix}.conv_layers.{li}.weight").view(Fv, 3 * cin), G[f"{prefix}.conv_layers.{li}.weight"].view(Fv, 3 * cin)
             self._wgrad(dc, col, dW, G[f"{prefix}.conv_layers.{li}.bias"])
             if li == 1 or dx is not None:
-                dcol = self._buf(f"tmp.vp_dcol{li}", rows, 3 * cin)
+                dcol = self._buf(f"tmp.vp_dcol{li}", rows, 3 * cin, dtype=col1.dtype)
                 self._dgrad(dc, W, dcol)
-                kk.call("kk_im2col3_bwd", dcol, dy if li == 1 else dx, B, L, cin, CHUNK)
+                kk.call("kk_im2col3_bwd", dcol, dy if li == 1 else dx, B, L, cin, CHUNK, _b16(dcol))
 
     # ------------------------------------------------------------------ forward + losses + backward
     def forward_backward(self, batch: Dict[str, torch.Tensor], loss_scale: float = 1.0, adaptive: bool = False,
@@ -387,6 +451,7 @@ class KokoroEngine:
         B, Pn = ids.shape
         T = mel.shape[1]
         Ne, Nd = B * Pn, B * T
+        edt, ddt = self.enc_dt, self.dec_dt               # activation storage of the encoder / decoder stacks
         pe = P["positional_encoding.pe"].view(d.max_len, H)
         if T > d.max_len or Pn > d.max_len:
             raise ValueError(f"sequence longer than the positional table ({d.max_len})")
@@ -405,10 +470,10 @@ class KokoroEngine:
         for i in range(d.enc_layers):
             pf, key, st = f"transformer_encoder_layers.{i}", f"enc{i}", 1000 + 32 * i
             dpr = self._dpr(i, d.enc_layers)
-            y1 = self._ln_fwd(key + ".ln1", x, pf + ".norm1")
+            y1 = self._ln_fwd(key + ".ln1", x, pf + ".norm1", edt)
             xm = self._buf(key + ".xm", Ne, H)
             self._attn_fwd(key + ".sa", pf + ".self_attn", y1, None, B, Pn, Pn, True, False, text_mask, x, xm, st, p_enc, dpr)
-            y2 = self._ln_fwd(key + ".ln2", xm, pf + ".norm2")
+            y2 = self._ln_fwd(key + ".ln2", xm, pf + ".norm2", edt)
             xo = self._buf(key + ".xo", Ne, H)
             self._ffn_fwd(key + ".ff", pf + ".ff", y2, xm, xo, d.enc_ff, Pn, st + 8, p_enc, dpr)
             x = xo
@@ -417,28 +482,28 @@ class KokoroEngine:
 
         # ---- variance adaptor (variance_predictor.py:338-439) ----
         dur_pred = self._buf("out.log_dur", B, Pn)
-        col_e = self._buf("vp.col_enc", Ne, 3 * H)
-        kk.call("kk_im2col3_fwd", enc, col_e, B, Pn, H, CHUNK)
+        col_e = self._buf("vp.col_enc", Ne, 3 * H, dtype=edt)
+        kk.call("kk_im2col3_fwd", enc, col_e, B, Pn, H, CHUNK, _b16(col_e))
         self._varpred_fwd("vp.dur", f"{VA}.duration_predictor", enc, col_e, B, Pn, text_mask, dur_pred, 10, p_var)
         idx, lens, tot = (self._buf("lr.idx", B, T, dtype=torch.int64), self._buf("lr.lens", B, dtype=torch.int64),
                           self._buf("lr.total", B, dtype=torch.int64))
         kk.call("kk_length_regulate_index", dur, idx, lens, tot, B, Pn, T)
         xf = self._buf("va.xf", Nd, H)
         kk.call("kk_length_regulate_gather", enc, idx, xf, B, Pn, T, H)       # detached by construction
-        memory, fmask = self._buf("va.memory", Nd, H), self._buf("va.fmask", B, T, dtype=torch.uint8)
+        memory, fmask = self._buf("va.memory", Nd, H, dtype=ddt), self._buf("va.fmask", B, T, dtype=torch.uint8)
         pidx, eidx = self._buf("va.pidx", B, T, dtype=torch.int32), self._buf("va.eidx", B, T, dtype=torch.int32)
         kk.call("kk_bucket_embed_add_fwd", xf, batch["pitches"], batch["energies"], P[f"{VA}.pitch_bins"], P[f"{VA}.energy_bins"],
                 P[f"{VA}.pitch_embedding.weight"], P[f"{VA}.energy_embedding.weight"], lens, memory, pidx, eidx, fmask, B, T, H,
-                d.var_bins)
+                d.var_bins, _b16(memory))
         pitch_pred, energy_pred = self._buf("out.pitch", B, T), self._buf("out.energy", B, T)
-        col_f = self._buf("vp.col_frames", Nd, 3 * H)
-        kk.call("kk_im2col3_fwd", xf, col_f, B, T, H, CHUNK)
+        col_f = self._buf("vp.col_frames", Nd, 3 * H, dtype=ddt)
+        kk.call("kk_im2col3_fwd", xf, col_f, B, T, H, CHUNK, _b16(col_f))
         self._varpred_fwd("vp.pitch", f"{VA}.pitch_predictor", xf, col_f, B, T, fmask, pitch_pred, 12, p_var)
         self._varpred_fwd("vp.energy", f"{VA}.energy_predictor", xf, col_f, B, T, fmask, energy_pred, 14, p_var)
         spec_aug = self.train_dropout and hp.use_spec_augment and self.spec_augment_active
         if spec_aug:                                      # on the cross-attention memory only (model.py:636-639)
             kk.call("kk_specaug", memory, B, T, H, self.rng, 20, hp.spec_augment_time_mask_max, hp.spec_augment_freq_mask_max,
-                    hp.spec_augment_num_time_masks, hp.spec_augment_num_freq_masks)
+                    hp.spec_augment_num_time_masks, hp.spec_augment_num_freq_masks, _b16(memory))
 
         # ---- decoder (model.py:519-531; transformers.py:543-583,660) ----
         shifted = self._buf("dec.shifted", Nd, M)
@@ -447,29 +512,30 @@ class KokoroEngine:
         p_din = self._p(hp.decoder_input_dropout)
         if self.train_dropout and (p_din > 0.0 or pe_drop > 0.0):    # dropout(proj) + pe, then the PE module's dropout
             lin, t1 = self._buf("tmp.dec_lin", Nd, H), self._buf("tmp.dec_t1", Nd, H)
-            self._linear(shifted, P["mel_projection_in.weight"], P["mel_projection_in.bias"], lin)
+            self._linear(shifted, self._W("mel_projection_in.weight"), P["mel_projection_in.bias"], lin)
             kk.call("kk_dropout_fwd", lin, pe, T, t1, Nd, H, T, self.rng, 30, p_din, 0, 0.0, 0, 0.0)
             kk.call("kk_dropout_fwd", t1, None, 0, y, Nd, H, T, self.rng, 31, pe_drop, 0, 0.0, 0, 0.0)
         else:
-            self._linear(shifted, P["mel_projection_in.weight"], P["mel_projection_in.bias"], y, res=pe, res_mod=T)
+            self._linear(shifted, self._W("mel_projection_in.weight"), P["mel_projection_in.bias"], y, res=pe, res_mod=T)
         for i in range(d.dec_layers):
             pf, key, st = f"decoder.layers.{i}", f"dec{i}", 2000 + 32 * i
             dpr = self._dpr(i, d.dec_layers)
-            n1 = self._ln_fwd(key + ".ln1", y, pf + ".norm1")
+            n1 = self._ln_fwd(key + ".ln1", y, pf + ".norm1", ddt)
             ya = self._buf(key + ".xa", Nd, H)
             self._attn_fwd(key + ".sa", pf + ".self_attn", n1, None, B, T, T, True, True, None, y, ya, st, p_dec, dpr)
-            n2 = self._ln_fwd(key + ".ln2", ya, pf + ".norm2")
+            n2 = self._ln_fwd(key + ".ln2", ya, pf + ".norm2", ddt)
             yc = self._buf(key + ".xc", Nd, H)
             self._attn_fwd(key + ".ca", pf + ".cross_attn", n2, memory, B, T, T, False, False, fmask, ya, yc, st + 8, p_dec, dpr)
-            n3 = self._ln_fwd(key + ".ln3", yc, pf + ".norm3")
+            n3 = self._ln_fwd(key + ".ln3", yc, pf + ".norm3", ddt)
             yo = self._buf(key + ".xo", Nd, H)
             self._ffn_fwd(key + ".ff", pf + ".ff", n3, yc, yo, d.dec_ff, T, st + 16, p_dec, dpr)
             y = yo
         dec_last = y
-        dec_out = self._ln_fwd("dec.norm", dec_last, "decoder.norm")
+        dec_out = self._ln_fwd("dec.norm", dec_last, "decoder.norm", ddt)
         mel_pred, stop = self._buf("out.mel", B, T, M), self._buf("out.stop", B, T)
-        self._linear(dec_out, P["mel_projection_out.weight"], P["mel_projection_out.bias"], mel_pred.view(Nd, M))
-        kk.call("kk_rowdot_fwd", dec_out, P["stop_token_predictor.weight"], P["stop_token_predictor.bias"], None, stop, Nd, H, T, 0)
+        self._linear(dec_out, self._W("mel_projection_out.weight"), P["mel_projection_out.bias"], mel_pred.view(Nd, M))
+        kk.call("kk_rowdot_fwd", dec_out, P["stop_token_predictor.weight"], P["stop_token_predictor.bias"], None, stop, Nd, H, T, 0,
+                _b16(dec_out))
 
         # ---- losses (losses.py) ----
         lcfg = kk.KkLossCfg(hp.duration_loss_weight, hp.stop_token_loss_weight, hp.pitch_loss_weight, hp.energy_loss_weight,
@@ -489,21 +555,21 @@ class KokoroEngine:
         kk.call("kk_losses_bwd", *largs, self.loss_coef, dmel, ddur, dstop, dpitch, denergy)
         # heads (model.py:561-562): the stop head's input is detached
         kk.call("kk_rowdot_bwd", dstop, dec_out, P["stop_token_predictor.weight"], None, None, G["stop_token_predictor.weight"],
-                G["stop_token_predictor.bias"], Nd, H, T, 0)
-        d_dec_out = self._buf("tmp.d_dec_out", Nd, H)
+                G["stop_token_predictor.bias"], Nd, H, T, 0, _b16(dec_out))
+        d_dec_out = self._buf("tmp.d_dec_out", Nd, H, dtype=ddt)
         self._wgrad(dmel.view(Nd, M), dec_out, G["mel_projection_out.weight"], G["mel_projection_out.bias"])
-        self._dgrad(dmel.view(Nd, M), P["mel_projection_out.weight"], d_dec_out)
+        self._dgrad(dmel.view(Nd, M), self._W("mel_projection_out.weight"), d_dec_out)
         dy = self._buf("g.dec_stream", Nd, H)          # gradient of the decoder residual stream, updated in place
         self._ln_bwd("dec.norm", d_dec_out, dec_last, "decoder.norm", dy, accumulate=False)
         dmem = self._buf("g.memory", Nd, H)
-        dn = self._buf("tmp.dn", Nd, H)
+        dn = self._buf("tmp.dn", Nd, H, dtype=ddt)
         first_mem = True
         for i in reversed(range(d.dec_layers)):
             pf, key, st = f"decoder.layers.{i}", f"dec{i}", 2000 + 32 * i
             dpr = self._dpr(i, d.dec_layers)
             x_in = self._buf(f"dec{i - 1}.xo", Nd, H) if i > 0 else self._buf("dec.x0", Nd, H)
             ya, yc = self._buf(key + ".xa", Nd, H), self._buf(key + ".xc", Nd, H)
-            n1, n2, n3 = (self._buf(f"{key}.ln{j}.y", Nd, H) for j in (1, 2, 3))
+            n1, n2, n3 = (self._buf(f"{key}.ln{j}.y", Nd, H, dtype=ddt) for j in (1, 2, 3))
             self._ffn_bwd(key + ".ff", pf + ".ff", dy, n3, dn, d.dec_ff, T, st + 16, p_dec, dpr)
             self._ln_bwd(key + ".ln3", dn, yc, pf + ".norm3", dy, accumulate=True)
             self._attn_bwd(key + ".ca", pf + ".cross_attn", dy, n2, memory, B, T, T, False, False, fmask, dn, dmem,
@@ -523,7 +589,7 @@ class KokoroEngine:
         # variance adaptor: memory gradient feeds only the two embedding tables (xf is detached, lengths.py:30)
         if spec_aug:
             kk.call("kk_specaug", dmem, B, T, H, self.rng, 20, hp.spec_augment_time_mask_max, hp.spec_augment_freq_mask_max,
-                    hp.spec_augment_num_time_masks, hp.spec_augment_num_freq_masks)
+                    hp.spec_augment_num_time_masks, hp.spec_augment_num_freq_masks, 0)
         kk.call("kk_bucket_embed_add_bwd", dmem, pidx, eidx, fmask, G[f"{VA}.pitch_embedding.weight"],
                 G[f"{VA}.energy_embedding.weight"], B, T, H)
         self._varpred_bwd("vp.pitch", f"{VA}.pitch_predictor", dpitch, xf, col_f, B, T, fmask, None, p_var)
@@ -533,13 +599,13 @@ class KokoroEngine:
         # encoder
         dx = self._buf("g.enc_stream", Ne, H)
         self._ln_bwd("enc.norm", d_enc, enc_last, "encoder_norm", dx, accumulate=False)
-        dne = self._buf("tmp.dne", Ne, H)
+        dne = self._buf("tmp.dne", Ne, H, dtype=edt)
         for i in reversed(range(d.enc_layers)):
             pf, key, st = f"transformer_encoder_layers.{i}", f"enc{i}", 1000 + 32 * i
             dpr = self._dpr(i, d.enc_layers)
             x_in = self._buf(f"enc{i - 1}.xo", Ne, H) if i > 0 else self._buf("enc.x0", Ne, H)
             xm = self._buf(key + ".xm", Ne, H)
-            y1, y2 = self._buf(key + ".ln1.y", Ne, H), self._buf(key + ".ln2.y", Ne, H)
+            y1, y2 = self._buf(key + ".ln1.y", Ne, H, dtype=edt), self._buf(key + ".ln2.y", Ne, H, dtype=edt)
             self._ffn_bwd(key + ".ff", pf + ".ff", dx, y2, dne, d.enc_ff, Pn, st + 8, p_enc, dpr)
             self._ln_bwd(key + ".ln2", dne, xm, pf + ".norm2", dx, accumulate=True)
             self._attn_bwd(key + ".sa", pf + ".self_attn", dx, y1, None, B, Pn, Pn, True, False, text_mask, dne, None, 0.0,
@@ -573,9 +639,9 @@ class KokoroEngine:
                 self.opt_state, self.seg_gscale, self.seg_decay, self.seg_stepsize, self.step_consts)
         kk.call("kk_adamw_ema", a.p, a.g, a.m, a.v, a.ema, a.block_seg, a.nblocks, self.seg_gscale, self.seg_decay,
                 self.seg_stepsize, a.seg_flags, self.step_consts, hp.adam_betas[0], hp.adam_betas[1], hp.ema_decay,
-                self.p_sumsq, a.nseg)
+                self.p_sumsq, a.nseg, a.p16)
         kk.call("kk_weight_norm_project", a.p, a.block_seg, a.nblocks, self.p_sumsq, a.seg_flags, self.step_consts,
-                float(hp.dec_ffn_max_weight_norm))
+                float(hp.dec_ffn_max_weight_norm), a.p16)
 
     def train_step(self, batch: Dict[str, torch.Tensor], accumulation_divisor: Optional[int] = None,
                    boundary: Optional[bool] = None, grad_sync=None) -> torch.Tensor:

@@ -43,45 +43,46 @@ _P, _I, _L, _F, _D, _U = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, 
 
 # name -> argtypes, in header order (tests/test_abi.py cross-checks arity against include/kokoro_hip.h)
 SIGNATURES: Dict[str, List[Any]] = {
-    "kk_gemm": [_I, _I, _L, _L, _L, _F, _P, _L, _P, _L, _F, _P, _L, _P, _P, _L, _L, _I, _I, _P],
+    "kk_gemm": [_I, _I, _L, _L, _L, _F, _P, _L, _P, _L, _F, _P, _L, _P, _P, _L, _L, _I, _I, _I, _P],
     "kk_gemm_tune": [_I, _I],
-    "kk_colsum_acc": [_P, _L, _L, _L, _P, _P],
-    "kk_attn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _P],
-    "kk_attn_delta": [_P, _P, _P, _I, _I, _I, _L, _L, _P],
-    "kk_attn_bwd_dq": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _P],
-    "kk_attn_bwd_dkv": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _P],
-    "kk_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _P],
-    "kk_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _I, _P],
-    "kk_rmsnorm_fwd": [_P, _P, _P, _P, _P, _L, _I, _P],
-    "kk_rmsnorm_bwd": [_P, _P, _P, _P, _P, _P, _L, _I, _P],
-    "kk_headnorm_rope_fwd": [_P, _L, _P, _L, _L, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P],
-    "kk_headnorm_rope_bwd": [_P, _L, _P, _L, _P, _L, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P],
-    "kk_glu_fwd": [_P, _P, _L, _I, _P, _U, _F, _P],
-    "kk_glu_bwd": [_P, _P, _P, _L, _I, _P, _U, _F, _P],
+    "kk_colsum_acc": [_P, _L, _L, _L, _P, _I, _P],
+    "kk_attn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P],
+    "kk_attn_delta": [_P, _P, _P, _I, _I, _I, _L, _L, _I, _P],
+    "kk_attn_bwd_dq": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P],
+    "kk_attn_bwd_dkv": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P],
+    "kk_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "kk_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _I, _I, _P],
+    "kk_rmsnorm_fwd": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "kk_rmsnorm_bwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "kk_headnorm_rope_fwd": [_P, _L, _P, _L, _L, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P],
+    "kk_headnorm_rope_bwd": [_P, _L, _P, _L, _P, _L, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P],
+    "kk_glu_fwd": [_P, _P, _L, _I, _P, _U, _F, _I, _P],
+    "kk_glu_bwd": [_P, _P, _P, _L, _I, _P, _U, _F, _I, _P],
     "kk_embed_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _U, _F, _P],
     "kk_embed_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _U, _F, _P],
     "kk_length_regulate_index": [_P, _P, _P, _P, _I, _I, _I, _P],
     "kk_length_regulate_gather": [_P, _P, _P, _I, _I, _I, _I, _P],
     "kk_max_i64": [_P, _L, _P, _P],
-    "kk_im2col3_fwd": [_P, _P, _I, _I, _I, _I, _P],
-    "kk_im2col3_bwd": [_P, _P, _I, _I, _I, _I, _P],
+    "kk_im2col3_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "kk_im2col3_bwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "kk_groupnorm_relu_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _U, _F, _P],
     "kk_groupnorm_relu_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
-    "kk_rowdot_fwd": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
-    "kk_rowdot_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
-    "kk_bucket_embed_add_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "kk_rowdot_fwd": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
+    "kk_rowdot_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
+    "kk_bucket_embed_add_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "kk_bucket_embed_add_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "kk_dropout_fwd": [_P, _P, _L, _P, _L, _I, _I, _P, _U, _F, _U, _F, _U, _F, _P],
     "kk_dropout_bwd": [_P, _P, _L, _I, _I, _P, _U, _F, _U, _F, _U, _F, _P],
-    "kk_specaug": [_P, _I, _I, _I, _P, _U, _I, _I, _I, _I, _P],
+    "kk_specaug": [_P, _I, _I, _I, _P, _U, _I, _I, _I, _I, _I, _P],
     "kk_ids_eq_zero": [_P, _P, _L, _P],
     "kk_shift_right": [_P, _P, _I, _I, _I, _P],
     "kk_losses_fwd": [_P] * 12 + [_I, _I, _I, _I, C.POINTER(KkLossCfg), _P, _P, _P, _P, _P],
     "kk_losses_bwd": [_P] * 12 + [_I, _I, _I, _I, C.POINTER(KkLossCfg), _P, _P, _P, _P, _P, _P, _P],
     "kk_seg_sumsq": [_P, _P, _L, _P, _I, _P],
     "kk_opt_prepare": [_P, _P, _P, _P, _I, _P, C.POINTER(KkOptCfg), _P, _P, _P, _P, _P, _P],
-    "kk_adamw_ema": [_P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _F, _F, _F, _P, _I, _P],
-    "kk_weight_norm_project": [_P, _P, _L, _P, _P, _P, _D, _P],
+    "kk_adamw_ema": [_P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _F, _F, _F, _P, _I, _P, _P],
+    "kk_weight_norm_project": [_P, _P, _L, _P, _P, _P, _D, _P, _P],
+    "kk_cast_f32_bf16": [_P, _P, _L, _P],
     "kk_axpby": [_F, _P, _F, _P, _L, _P],
     "kk_mfma_probe": [_P, _P, _P],
 }

@@ -32,9 +32,10 @@ def _load(golden_dir, name):
     return fx, d, batch, P
 
 
-def _engine(eng_mod, d, P, math_mode="f32", **hp_kw):
+def _engine(eng_mod, d, P, math_mode="f32", storage="auto", **hp_kw):
     from kokoro_ruslan_amd.spec import ModelDims, StepHyper
-    e = eng_mod.KokoroEngine(ModelDims(**d.__dict__), StepHyper(**hp_kw), math_mode=math_mode, init=False, total_steps=20000)
+    e = eng_mod.KokoroEngine(ModelDims(**d.__dict__), StepHyper(**hp_kw), math_mode=math_mode, init=False, total_steps=20000,
+                             storage=storage)
     e.load_params(P)
     return e
 
@@ -173,9 +174,11 @@ def test_nonfinite_gradients_skip_the_step(eng_mod, golden_dir):
     assert torch.equal(e.arena.p, before), "a skipped step must leave every parameter untouched"
 
 
-def test_bf16_math_mode_close_to_fp32(eng_mod, golden_dir):
+@pytest.mark.parametrize("storage", ["f32", "bf16-dec", "bf16"])
+def test_bf16_math_mode_close_to_fp32(eng_mod, golden_dir, storage):
+    """bf16 MFMA arithmetic, with fp32 or bf16 operand storage: losses and gradient directions stay on the reference."""
     fx, d, batch, P = _load(golden_dir, "mid_chunked")
-    e = _engine(eng_mod, d, P, math_mode="bf16")
+    e = _engine(eng_mod, d, P, math_mode="bf16", storage=storage)
     e.zero_grad()
     out = e.forward_backward(_cuda(batch))
     torch.cuda.synchronize()
@@ -190,6 +193,27 @@ def test_bf16_math_mode_close_to_fp32(eng_mod, golden_dir):
         if float(b.norm()) > 1e-6:
             cos.append(float(a @ b / (a.norm() * b.norm() + 1e-30)))
     assert min(cos) > 0.97 and float(np.mean(cos)) > 0.995, (min(cos), float(np.mean(cos)))
+
+
+def test_bf16_weight_shadow_tracks_master(eng_mod, golden_dir):
+    """The bf16 copy of the weights (the GEMMs' B operand in the bf16 mode) is exactly round(master) after loads,
+    optimizer steps (incl. the weight-norm projection) and skipped steps; fp32_math() validates on the masters."""
+    fx, d, batch, P = _load(golden_dir, "tiny_full")
+    e = _engine(eng_mod, d, P, math_mode="bf16", dec_ffn_max_weight_norm=6.0, gradient_accumulation_steps=1)
+    assert e.arena.p16 is not None and torch.equal(e.arena.p16, e.arena.p.bfloat16())
+    b = _cuda(batch)
+    for _ in range(3):
+        e.train_step(b)
+    torch.cuda.synchronize()
+    assert e.opt_stats()["attempt"] == 3
+    assert torch.equal(e.arena.p16, e.arena.p.bfloat16())
+    ref = _engine(eng_mod, d, {n: e.arena.P[n].clone() for n in P})          # fp32 engine on the same weights
+    with e.fp32_math():
+        l16 = e.forward_backward(b, backward=False)["losses"].clone()
+    l32 = ref.forward_backward(b, backward=False)["losses"]
+    torch.testing.assert_close(l16, l32, rtol=1e-5, atol=1e-6)     # same kernels, same masters (split-K atomics reorder sums)
+    with pytest.raises(ValueError):
+        _engine(eng_mod, d, P, math_mode="f32", storage="bf16")
 
 
 def test_state_dict_roundtrip_and_names(eng_mod, golden_dir):

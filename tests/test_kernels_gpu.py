@@ -70,7 +70,7 @@ def test_gemm_layouts(kk, math_mode, ta, tb, M, N, K):
     ref = 0.5 * (Aop.double() @ Bop.double()).float() + bias + res[torch.arange(M) % 50] + 2.0 * C0
     Cd = dev(C0)
     kk.call("kk_gemm", ta, tb, M, N, K, 0.5, dev(A), A.shape[1], dev(Bm), Bm.shape[1], 2.0, Cd, N, dev(bias), dev(res),
-            N, 50, 1, math_mode)
+            N, 50, 1, math_mode, 0)
     atol, rtol = (2e-4, 2e-5) if math_mode == 0 else (5e-2, 1e-3)
     close(Cd, ref, atol * math.sqrt(K / 64), rtol, f"gemm ta={ta} tb={tb} {M}x{N}x{K} math={math_mode}")
 
@@ -85,14 +85,37 @@ def test_gemm_splitk_wgrad(kk, math_mode):
     ref = (a.t().double() @ b.double()).float()
     for beta, split in ((1.0, 0), (0.0, 0), (1.0, 8), (0.0, 1)):
         Cd = dev(acc0)
-        kk.call("kk_gemm", 1, 1, M, N, K, 1.0, dev(dY), M, dev(X), N, beta, Cd, N, None, None, 0, 0, split, math_mode)
+        kk.call("kk_gemm", 1, 1, M, N, K, 1.0, dev(dY), M, dev(X), N, beta, Cd, N, None, None, 0, 0, split, math_mode, 0)
         close(Cd, ref + beta * acc0, 2e-3 if math_mode == 0 else 0.3, 1e-3, f"split-k beta={beta} split={split}")
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("dtypes", [1, 2, 3, 7, 6])
+@pytest.mark.parametrize("M,N,K", [(136, 72, 200), (4096, 2048, 136), (520, 1536, 512)])
+def test_gemm_bf16_storage(kk, ta, tb, dtypes, M, N, K):
+    """A / B / C held as bf16 in HBM (bit0 / bit1 / bit2 of `dtypes`): same result as fp32 storage of the rounded values."""
+    g = torch.Generator().manual_seed(M + N + K + dtypes)
+    A = torch.randn((K, M) if ta else (M, K), generator=g).bfloat16()
+    Bm = torch.randn((K, N) if tb else (N, K), generator=g).bfloat16()
+    bias = torch.randn(N, generator=g)
+    ref = ((A.float().t() if ta else A.float()).double() @ (Bm.float() if tb else Bm.float().t()).double()).float() + bias
+    a16, b16, c16 = dtypes & 1, (dtypes >> 1) & 1, (dtypes >> 2) & 1
+    Ad = dev(A if a16 else A.float())
+    Bd = dev(Bm if b16 else Bm.float())
+    Cd = torch.empty(M, N, device="cuda", dtype=torch.bfloat16 if c16 else torch.float32)
+    kk.call("kk_gemm", ta, tb, M, N, K, 1.0, Ad, A.shape[1], Bd, Bm.shape[1], 0.0, Cd, N, dev(bias), None, 0, 0, 1, 1, dtypes)
+    close(Cd, ref, 2e-3 * math.sqrt(K / 64) + (0.1 if c16 else 0.0), 1e-2 if c16 else 1e-4, f"bf16-storage gemm dtypes={dtypes}")
+    if not c16 and ta and tb:      # weight-gradient form: split-K atomics accumulate into fp32
+        acc = torch.randn(M, N, generator=g)
+        Cd = dev(acc)
+        kk.call("kk_gemm", ta, tb, M, N, K, 1.0, Ad, A.shape[1], Bd, Bm.shape[1], 1.0, Cd, N, None, None, 0, 0, 4, 1, dtypes)
+        close(Cd, ref - bias + acc, 3e-3 * math.sqrt(K / 64), 1e-4, "bf16-storage split-k")
 
 
 def test_colsum(kk):
     X = torch.randn(777, 200)
     out = dev(torch.ones(200))
-    kk.call("kk_colsum_acc", dev(X), 200, 777, 200, out)
+    kk.call("kk_colsum_acc", dev(X), 200, 777, 200, out, 0)
     close(out, 1 + X.sum(0), 1e-3, 1e-5, "colsum")
 
 
@@ -132,15 +155,15 @@ def test_attention_fwd_bwd(kk, math_mode, B, h, Sq, Sk, causal, masked):
     Od = torch.zeros(B, Sq, H, device="cuda")
     lse = torch.zeros(B, h, Sq, device="cuda")
     kmd = dev(km.to(torch.uint8)) if km is not None else None
-    kk.call("kk_attn_fwd", Qd, Kd, Vd, Od, lse, B, h, Sq, Sk, H, H, H, H, kmd, causal, scale, None, 0, 0.0, math_mode)
+    kk.call("kk_attn_fwd", Qd, Kd, Vd, Od, lse, B, h, Sq, Sk, H, H, H, H, kmd, causal, scale, None, 0, 0.0, math_mode, 0)
     atol, rtol = (2e-5, 1e-4) if math_mode == 0 else (3e-2, 3e-2)
     close(Od, ref, atol, rtol, "attn fwd")
     delta = torch.zeros(B, h, Sq, device="cuda")
-    kk.call("kk_attn_delta", Od, dOd, delta, B, h, Sq, H, H)
+    kk.call("kk_attn_delta", Od, dOd, delta, B, h, Sq, H, H, 0)
     dQ, dK, dV = (torch.zeros_like(t) for t in (Qd, Kd, Vd))
-    kk.call("kk_attn_bwd_dq", Qd, Kd, Vd, dOd, lse, delta, dQ, B, h, Sq, Sk, H, H, H, H, H, kmd, causal, scale, None, 0, 0.0, math_mode)
+    kk.call("kk_attn_bwd_dq", Qd, Kd, Vd, dOd, lse, delta, dQ, B, h, Sq, Sk, H, H, H, H, H, kmd, causal, scale, None, 0, 0.0, math_mode, 0)
     kk.call("kk_attn_bwd_dkv", Qd, Kd, Vd, dOd, lse, delta, dK, dV, B, h, Sq, Sk, H, H, H, H, H, H, kmd, causal, scale,
-            None, 0, 0.0, math_mode)
+            None, 0, 0.0, math_mode, 0)
     atol, rtol = (1e-4, 1e-3) if math_mode == 0 else (8e-2, 5e-2)
     close(dQ, Qr.grad, atol, rtol, "attn dQ")
     close(dK, Kr.grad, atol, rtol, "attn dK")
@@ -158,7 +181,7 @@ def test_attention_strided_fused_qkv(kk):
     d = dev(qkv)
     O_ = torch.zeros(B, S, H, device="cuda")
     lse = torch.zeros(B, h, S, device="cuda")
-    kk.call("kk_attn_fwd", d, d[..., H:], d[..., 2 * H:], O_, lse, B, h, S, S, 3 * H, 3 * H, 3 * H, H, None, 1, 0.125, None, 0, 0.0, 0)
+    kk.call("kk_attn_fwd", d, d[..., H:], d[..., 2 * H:], O_, lse, B, h, S, S, 3 * H, 3 * H, 3 * H, H, None, 1, 0.125, None, 0, 0.0, 0, 0)
     close(O_, ref, 2e-5, 1e-4, "attn fused-qkv strides")
 
 
@@ -172,11 +195,11 @@ def test_layernorm(kk, rows, H):
     y = F.layer_norm(xr, (H,), gr, br, 1e-5)
     y.backward(dy)
     yd, mean, rstd = torch.empty(rows, H, device="cuda"), torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
-    kk.call("kk_layernorm_fwd", dev(x), dev(gam), dev(bet), yd, mean, rstd, rows, H)
+    kk.call("kk_layernorm_fwd", dev(x), dev(gam), dev(bet), yd, mean, rstd, rows, H, 0)
     close(yd, y, 2e-5, 2e-5, "ln fwd")
     dx0 = torch.randn(rows, H, generator=g)
     dx, dg, db = dev(dx0), torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")
-    kk.call("kk_layernorm_bwd", dev(dy), dev(x), dev(gam), mean, rstd, dx, 1, dg, db, rows, H)
+    kk.call("kk_layernorm_bwd", dev(dy), dev(x), dev(gam), mean, rstd, dx, 1, dg, db, rows, H, 0)
     close(dx, xr.grad + dx0, 1e-4, 1e-4, "ln dx (accumulate)")
     close(dg, gr.grad, 1e-3, 1e-4, "ln dgamma")
     close(db, br.grad, 1e-3, 1e-4, "ln dbeta")
@@ -191,10 +214,10 @@ def test_rmsnorm_residual(kk, rows, H):
     y = res + O._rms_norm(xr, gr)
     y.backward(dy)
     yd, rstd = torch.empty(rows, H, device="cuda"), torch.empty(rows, device="cuda")
-    kk.call("kk_rmsnorm_fwd", dev(x), dev(gain), dev(res), yd, rstd, rows, H)
+    kk.call("kk_rmsnorm_fwd", dev(x), dev(gain), dev(res), yd, rstd, rows, H, 0)
     close(yd, y, 2e-5, 2e-5, "rms fwd")
     dx, dg = torch.empty(rows, H, device="cuda"), torch.zeros(H, device="cuda")
-    kk.call("kk_rmsnorm_bwd", dev(dy), dev(x), dev(gain), rstd, dx, dg, rows, H)
+    kk.call("kk_rmsnorm_bwd", dev(dy), dev(x), dev(gain), rstd, dx, dg, rows, H, 0)
     close(dx, xr.grad, 1e-4, 1e-4, "rms dx")
     close(dg, gr.grad, 1e-3, 1e-4, "rms dgain")
 
@@ -222,17 +245,17 @@ def test_headnorm_rope_fused_qkv(kk, rope):
     xd, y = dev(x), torch.empty(B * S, 3 * H, device="cuda")
     gd = [dev(t) for t in gains]
     ct, st_ = dev(cos), dev(sin)
-    kk.call("kk_headnorm_rope_fwd", xd, 3 * H, y, 3 * H, B * S, h, S, 3, gd[0], gd[1], gd[2], 3 if rope else 0, ct, st_)
+    kk.call("kk_headnorm_rope_fwd", xd, 3 * H, y, 3 * H, B * S, h, S, 3, gd[0], gd[1], gd[2], 3 if rope else 0, ct, st_, 0)
     close(y, ref, 2e-5, 2e-5, "headnorm fwd")
     dx, dg = torch.zeros(B * S, 3 * H, device="cuda"), [torch.zeros(64, device="cuda") for _ in range(3)]
     kk.call("kk_headnorm_rope_bwd", dev(dy), 3 * H, xd, 3 * H, dx, 3 * H, B * S, h, S, 3, gd[0], gd[1], gd[2], dg[0], dg[1], dg[2],
-            3 if rope else 0, ct, st_)
+            3 if rope else 0, ct, st_, 0)
     close(dx, xr.grad, 1e-4, 1e-4, "headnorm dx")
     for j in range(3):
         close(dg[j], gr[j].grad, 1e-3, 1e-4, f"headnorm dgain{j}")
     # single part with a row stride (cross-attention q) and the 2-part k|v form
     y1 = torch.empty(B * S, H, device="cuda")
-    kk.call("kk_headnorm_rope_fwd", xd[:, H:], 3 * H, y1, H, B * S, h, S, 1, gd[1], None, None, 1 if rope else 0, ct, st_)
+    kk.call("kk_headnorm_rope_fwd", xd[:, H:], 3 * H, y1, H, B * S, h, S, 1, gd[1], None, None, 1 if rope else 0, ct, st_, 0)
     close(y1, ref[:, H:2 * H], 2e-5, 2e-5, "headnorm single part, strided")
 
 
@@ -245,10 +268,10 @@ def test_glu(kk):
     y = F.gelu(gate) * lin
     y.backward(dg)
     out = torch.empty(rows, Fd, device="cuda")
-    kk.call("kk_glu_fwd", dev(h), out, rows, Fd, None, 0, 0.0)
+    kk.call("kk_glu_fwd", dev(h), out, rows, Fd, None, 0, 0.0, 0)
     close(out, y, 1e-5, 1e-5, "glu fwd")
     dh = torch.empty(rows, 2 * Fd, device="cuda")
-    kk.call("kk_glu_bwd", dev(dg), dev(h), dh, rows, Fd, None, 0, 0.0)
+    kk.call("kk_glu_bwd", dev(dg), dev(h), dh, rows, Fd, None, 0, 0.0, 0)
     close(dh, hr.grad, 1e-5, 1e-5, "glu bwd")
 
 
@@ -339,34 +362,34 @@ def test_variance_predictor_chain(kk, L):
     acts, cin, inp = [], H, xd
     for li in range(2):
         col = torch.empty(rows, 3 * cin, device="cuda")
-        kk.call("kk_im2col3_fwd", inp, col, B, L, cin, 512)
+        kk.call("kk_im2col3_fwd", inp, col, B, L, cin, 512, 0)
         c = torch.empty(rows, Fv, device="cuda")
         kk.call("kk_gemm", 0, 0, rows, Fv, 3 * cin, 1.0, col, 3 * cin, Pd[f"vp.conv_layers.{li}.weight"], 3 * cin, 0.0, c, Fv,
-                Pd[f"vp.conv_layers.{li}.bias"], None, 0, 0, 1, 0)
+                Pd[f"vp.conv_layers.{li}.bias"], None, 0, 0, 1, 0, 0)
         y, stats = torch.empty(rows, Fv, device="cuda"), torch.empty(B * nch, 2, device="cuda")
         kk.call("kk_groupnorm_relu_fwd", c, Pd[f"vp.norms.{li}.weight"], Pd[f"vp.norms.{li}.bias"], y, stats, scratch, B, L, Fv, 512, None, 0, 0.0)
         acts.append((col, c, y, stats, cin))
         inp, cin = y, Fv
     md = dev(mask.to(torch.uint8))
     out = torch.empty(rows, device="cuda")
-    kk.call("kk_rowdot_fwd", inp, Pd["vp.linear.weight"], Pd["vp.linear.bias"], md, out, rows, Fv, L, 512)
+    kk.call("kk_rowdot_fwd", inp, Pd["vp.linear.weight"], Pd["vp.linear.bias"], md, out, rows, Fv, L, 512, 0)
     close(out.view(B, L), ref, 2e-4, 2e-4, "varpred fwd")
     dy = torch.empty(rows, Fv, device="cuda")
     kk.call("kk_rowdot_bwd", dev(dout), inp, Pd["vp.linear.weight"], md, dy, Gd["vp.linear.weight"], Gd["vp.linear.bias"],
-            rows, Fv, L, 512)
+            rows, Fv, L, 512, 0)
     for li in (1, 0):
         col, c, y, stats, cin = acts[li]
         dc = torch.empty(rows, Fv, device="cuda")
         kk.call("kk_groupnorm_relu_bwd", dy, c, y, Pd[f"vp.norms.{li}.weight"], stats, dc, Gd[f"vp.norms.{li}.weight"],
                 Gd[f"vp.norms.{li}.bias"], scratch, B, L, Fv, 512, 0.0)
         kk.call("kk_gemm", 1, 1, Fv, 3 * cin, rows, 1.0, dc, Fv, col, 3 * cin, 1.0, Gd[f"vp.conv_layers.{li}.weight"], 3 * cin,
-                None, None, 0, 0, 0, 0)
-        kk.call("kk_colsum_acc", dc, Fv, rows, Fv, Gd[f"vp.conv_layers.{li}.bias"])
+                None, None, 0, 0, 0, 0, 0)
+        kk.call("kk_colsum_acc", dc, Fv, rows, Fv, Gd[f"vp.conv_layers.{li}.bias"], 0)
         dcol = torch.empty(rows, 3 * cin, device="cuda")
         kk.call("kk_gemm", 0, 1, rows, 3 * cin, Fv, 1.0, dc, Fv, Pd[f"vp.conv_layers.{li}.weight"], 3 * cin, 0.0, dcol, 3 * cin,
-                None, None, 0, 0, 1, 0)
+                None, None, 0, 0, 1, 0, 0)
         dy = torch.empty(rows, cin, device="cuda")
-        kk.call("kk_im2col3_bwd", dcol, dy, B, L, cin, 512)
+        kk.call("kk_im2col3_bwd", dcol, dy, B, L, cin, 512, 0)
     close(dy.view(B, L, H), xr.grad, 2e-4, 1e-3, "varpred dx")
     for n in P:
         close(Gd[n].view(P[n].shape), Pr[n].grad, 5e-4, 2e-3, f"varpred grad {n}")
@@ -390,7 +413,7 @@ def test_bucket_embed_add(kk):
     pi, ei = torch.empty(B, T, dtype=torch.int32, device="cuda"), torch.empty(B, T, dtype=torch.int32, device="cuda")
     fmd = torch.empty(B, T, dtype=torch.uint8, device="cuda")
     kk.call("kk_bucket_embed_add_fwd", dev(x), dev(pitch), dev(energy), dev(bins), dev(bins), dev(pemb), dev(eemb), dev(lens),
-            out, pi, ei, fmd, B, T, H, nb)
+            out, pi, ei, fmd, B, T, H, nb, 0)
     assert torch.equal(pi.cpu().long(), torch.bucketize(pitch, bins)), "bucketize must be bit-exact"
     assert torch.equal(fmd.cpu().bool(), fm)
     close(out, ref, 1e-6, 1e-6, "bucket-embed fwd")
@@ -487,14 +510,14 @@ def test_fused_dropout_masks_match_between_forward_and_backward(kk):
     rows, Fd, p = 300, 96, 0.2
     h, dg = torch.randn(rows, 2 * Fd, generator=g) + 1.0, torch.randn(rows, Fd, generator=g)
     g0, g1 = torch.empty(rows, Fd, device="cuda"), torch.empty(rows, Fd, device="cuda")
-    kk.call("kk_glu_fwd", dev(h), g0, rows, Fd, None, 0, 0.0)
-    kk.call("kk_glu_fwd", dev(h), g1, rows, Fd, _seed(), 3, p)
+    kk.call("kk_glu_fwd", dev(h), g0, rows, Fd, None, 0, 0.0, 0)
+    kk.call("kk_glu_fwd", dev(h), g1, rows, Fd, _seed(), 3, p, 0)
     mask = torch.where(g0.abs() > 1e-6, g1 / g0, torch.ones_like(g0)).cpu()
     assert bool(((mask.abs() < 1e-5) | ((mask - 1 / (1 - p)).abs() < 1e-4)).all())
     assert abs(float((mask > 0).float().mean()) - (1 - p)) < 0.02
     d0, d1 = torch.empty(rows, 2 * Fd, device="cuda"), torch.empty(rows, 2 * Fd, device="cuda")
-    kk.call("kk_glu_bwd", dev(dg * mask), dev(h), d0, rows, Fd, None, 0, 0.0)       # explicit mask, no RNG
-    kk.call("kk_glu_bwd", dev(dg), dev(h), d1, rows, Fd, _seed(), 3, p)              # regenerated mask
+    kk.call("kk_glu_bwd", dev(dg * mask), dev(h), d0, rows, Fd, None, 0, 0.0, 0)       # explicit mask, no RNG
+    kk.call("kk_glu_bwd", dev(dg), dev(h), d1, rows, Fd, _seed(), 3, p, 0)              # regenerated mask
     close(d1, d0, 1e-6, 1e-5, "glu backward regenerates the forward mask")
     # embedding + PE dropout
     B, P, H, V = 4, 30, 64, 59
@@ -544,8 +567,8 @@ def test_attention_probability_dropout(kk, math_mode, causal):
     Qd, Kd, Vd = dev(Q), dev(K), dev(V)
     O0, O1 = torch.zeros(B, S, H, device="cuda"), torch.zeros(B, S, H, device="cuda")
     lse = torch.zeros(B, h, S, device="cuda")
-    kk.call("kk_attn_fwd", Qd, Kd, Vd, O0, lse, B, h, S, S, H, H, H, H, None, causal, 0.125, None, 0, 0.0, math_mode)
-    kk.call("kk_attn_fwd", Qd, Kd, Vd, O1, lse, B, h, S, S, H, H, H, H, None, causal, 0.125, _seed(5), 9, p, math_mode)
+    kk.call("kk_attn_fwd", Qd, Kd, Vd, O0, lse, B, h, S, S, H, H, H, H, None, causal, 0.125, None, 0, 0.0, math_mode, 0)
+    kk.call("kk_attn_fwd", Qd, Kd, Vd, O1, lse, B, h, S, S, H, H, H, H, None, causal, 0.125, _seed(5), 9, p, math_mode, 0)
     P0, P1 = O0.cpu().view(B, S, h, 64).transpose(1, 2), O1.cpu().view(B, S, h, 64).transpose(1, 2)     # [B,h,q,key]
     big = P0 > 1e-3
     ratio = (P1 / P0.clamp(min=1e-9))[big]
@@ -566,16 +589,16 @@ def test_attention_probability_dropout(kk, math_mode, causal):
     ref.backward(dO.double())
     V2d, dOd = dev(V2), dev(dO)
     O2 = torch.zeros(B, S, H, device="cuda")
-    kk.call("kk_attn_fwd", Qd, Kd, V2d, O2, lse, B, h, S, S, H, H, H, H, None, causal, 0.125, _seed(5), 9, p, math_mode)
+    kk.call("kk_attn_fwd", Qd, Kd, V2d, O2, lse, B, h, S, S, H, H, H, H, None, causal, 0.125, _seed(5), 9, p, math_mode, 0)
     small = big.sum() == big.numel()       # the recovered mask is exact only where P0 is not tiny
     atol, rtol = (1e-2, 3e-3) if math_mode == 0 else (8e-2, 5e-2)   # mask unknown where P0 < 1e-3: error <= 1e-3*|V|/(1-p)
     close(O2, ref, atol, rtol, "attn fwd with dropout")
     delta = torch.zeros(B, h, S, device="cuda")
-    kk.call("kk_attn_delta", O2, dOd, delta, B, h, S, H, H)
+    kk.call("kk_attn_delta", O2, dOd, delta, B, h, S, H, H, 0)
     dQ, dK, dV = torch.zeros_like(Qd), torch.zeros_like(Kd), torch.zeros_like(V2d)
-    kk.call("kk_attn_bwd_dq", Qd, Kd, V2d, dOd, lse, delta, dQ, B, h, S, S, H, H, H, H, H, None, causal, 0.125, _seed(5), 9, p, math_mode)
+    kk.call("kk_attn_bwd_dq", Qd, Kd, V2d, dOd, lse, delta, dQ, B, h, S, S, H, H, H, H, H, None, causal, 0.125, _seed(5), 9, p, math_mode, 0)
     kk.call("kk_attn_bwd_dkv", Qd, Kd, V2d, dOd, lse, delta, dK, dV, B, h, S, S, H, H, H, H, H, H, None, causal, 0.125,
-            _seed(5), 9, p, math_mode)
+            _seed(5), 9, p, math_mode, 0)
     atol, rtol = (2e-2, 1e-2) if math_mode == 0 else (0.15, 0.1)
     close(dV, Vr.grad, atol, rtol, "attn dV with dropout")
     close(dQ, Qr.grad, atol, rtol, "attn dQ with dropout")
@@ -585,7 +608,7 @@ def test_attention_probability_dropout(kk, math_mode, causal):
 def test_specaugment_mask_structure(kk):
     B, T, H = 16, 100, 128
     x = torch.ones(B, T, H, device="cuda")
-    kk.call("kk_specaug", x, B, T, H, _seed(3), 20, 5, 3, 1, 2)
+    kk.call("kk_specaug", x, B, T, H, _seed(3), 20, 5, 3, 1, 2, 0)
     z = (x.cpu() == 0)
     for b in range(B):
         rows = z[b].all(1)                              # fully masked frames = the time mask
@@ -596,5 +619,191 @@ def test_specaugment_mask_structure(kk):
         assert int(cols.sum()) <= 4                     # two feature masks of f in [0, 3) dims
     assert 0 < int(z.any(-1).any(-1).sum()), "some samples are masked"
     y = torch.ones(B, T, H, device="cuda")
-    kk.call("kk_specaug", y, B, T, H, _seed(3), 20, 5, 3, 1, 2)
+    kk.call("kk_specaug", y, B, T, H, _seed(3), 20, 5, 3, 1, 2, 0)
     assert torch.equal(x, y)                            # the gradient pass sees the same mask
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bf16 activation storage: every kernel that takes a *_bf16 flag must agree with its own fp32-storage instantiation
+# run on the same (bf16-representable) inputs, up to one bf16 rounding of the outputs.
+def _r16(t):
+    return t.bfloat16().float()
+
+
+BF = (2e-2, 1e-2)   # (atol, rtol): one bf16 rounding (2^-8 relative) of O(1) outputs, with slack for re-associated sums
+
+
+@pytest.mark.parametrize("B,h,Sq,Sk,causal,masked,strided", [(2, 2, 64, 64, 0, 1, 0), (1, 2, 200, 200, 1, 0, 1),
+                                                              (2, 1, 37, 150, 0, 1, 0), (1, 8, 300, 300, 1, 0, 1)])
+def test_attention_bf16_storage(kk, B, h, Sq, Sk, causal, masked, strided):
+    g = torch.Generator().manual_seed(Sq + 7 * Sk + causal)
+    H = h * 64
+    ld = 3 * H if strided else H          # fused-qkv row stride
+    big = [_r16(torch.randn(B, S, ld, generator=g)) for S in (Sq, Sk, Sk)]
+    Q, K, V = (dev(t)[..., :H] if not strided else dev(t)[..., i * H:(i + 1) * H] for i, t in enumerate(big))
+    if not strided:
+        Q, K, V = (t.contiguous() for t in (Q, K, V))
+    dO = dev(_r16(torch.randn(B, Sq, H, generator=g)))
+    kmd = None
+    if masked:
+        km = torch.rand(B, Sk, generator=g) < 0.3
+        km[:, 0] = False
+        kmd = dev(km.to(torch.uint8))
+    Q16, K16, V16 = (dev(t).bfloat16()[..., :H] if not strided else dev(t).bfloat16()[..., i * H:(i + 1) * H] for i, t in enumerate(big))
+    if not strided:
+        Q16, K16, V16 = (t.contiguous() for t in (Q16, K16, V16))
+    dO16 = dO.bfloat16()
+    seed = torch.tensor([11], dtype=torch.int32, device="cuda")
+    for p in (0.0, 0.2):
+        O32, O16 = torch.zeros(B, Sq, H, device="cuda"), torch.zeros(B, Sq, H, device="cuda", dtype=torch.bfloat16)
+        l32, l16 = torch.zeros(B, h, Sq, device="cuda"), torch.zeros(B, h, Sq, device="cuda")
+        kk.call("kk_attn_fwd", Q, K, V, O32, l32, B, h, Sq, Sk, ld, ld, ld, H, kmd, causal, 0.125, seed, 4, p, 1, 0)
+        kk.call("kk_attn_fwd", Q16, K16, V16, O16, l16, B, h, Sq, Sk, ld, ld, ld, H, kmd, causal, 0.125, seed, 4, p, 1, 1)
+        close(O16, O32, *BF, f"attn fwd bf16 storage p={p}")
+        close(l16, l32, 1e-5, 1e-5, "attn lse bf16 storage")
+        O32r = O16.float()                                 # backward from the same (rounded) forward output
+        d32, d16 = torch.zeros(B, h, Sq, device="cuda"), torch.zeros(B, h, Sq, device="cuda")
+        kk.call("kk_attn_delta", O32r, dO, d32, B, h, Sq, H, H, 0)
+        kk.call("kk_attn_delta", O16, dO16, d16, B, h, Sq, H, H, 1)
+        close(d16, d32, 1e-4, 1e-5, "attn delta bf16 storage")
+        g32 = [torch.zeros(B, S, H, device="cuda") for S in (Sq, Sk, Sk)]
+        g16 = [torch.zeros(B, S, H, device="cuda", dtype=torch.bfloat16) for S in (Sq, Sk, Sk)]
+        kk.call("kk_attn_bwd_dq", Q, K, V, dO, l32, d32, g32[0], B, h, Sq, Sk, ld, ld, ld, H, H, kmd, causal, 0.125, seed, 4, p, 1, 0)
+        kk.call("kk_attn_bwd_dq", Q16, K16, V16, dO16, l16, d16, g16[0], B, h, Sq, Sk, ld, ld, ld, H, H, kmd, causal, 0.125, seed, 4, p, 1, 1)
+        kk.call("kk_attn_bwd_dkv", Q, K, V, dO, l32, d32, g32[1], g32[2], B, h, Sq, Sk, ld, ld, ld, H, H, H, kmd, causal, 0.125,
+                seed, 4, p, 1, 0)
+        kk.call("kk_attn_bwd_dkv", Q16, K16, V16, dO16, l16, d16, g16[1], g16[2], B, h, Sq, Sk, ld, ld, ld, H, H, H, kmd, causal, 0.125,
+                seed, 4, p, 1, 1)
+        for a, b, n in zip(g16, g32, "QKV"):
+            close(a, b, 3e-2, 1e-2, f"attn d{n} bf16 storage p={p}")
+
+
+def test_norms_bf16_storage(kk):
+    g = torch.Generator().manual_seed(5)
+    rows, H = 333, 512
+    x, dy = dev(torch.randn(rows, H, generator=g)), dev(_r16(torch.randn(rows, H, generator=g)))
+    gam, bet = dev(1 + 0.1 * torch.randn(H, generator=g)), dev(0.1 * torch.randn(H, generator=g))
+    # LayerNorm: x fp32 (residual stream), y / dy in bf16
+    y32, y16 = torch.empty(rows, H, device="cuda"), torch.empty(rows, H, device="cuda", dtype=torch.bfloat16)
+    mean, rstd = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    kk.call("kk_layernorm_fwd", x, gam, bet, y32, mean, rstd, rows, H, 0)
+    kk.call("kk_layernorm_fwd", x, gam, bet, y16, mean, rstd, rows, H, 1)
+    assert torch.equal(y16, y32.bfloat16())
+    out = []
+    for flag, d in ((0, dy), (1, dy.bfloat16())):
+        dx, dg, db = torch.ones(rows, H, device="cuda"), torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")
+        kk.call("kk_layernorm_bwd", d, x, gam, mean, rstd, dx, 1, dg, db, rows, H, flag)
+        out.append((dx, dg, db))
+    for a, b, n in zip(out[1], out[0], ("dx", "dgamma", "dbeta")):
+        close(a, b, 1e-5, 1e-5, f"ln bwd {n} with bf16 dy")
+    # RMSNorm: x (and dx) bf16, y / dy fp32
+    xr = _r16(x)
+    gain, res = gam, dev(torch.randn(rows, H, generator=g))
+    ya, yb = torch.empty(rows, H, device="cuda"), torch.empty(rows, H, device="cuda")
+    ra, rb = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    kk.call("kk_rmsnorm_fwd", xr, gain, res, ya, ra, rows, H, 0)
+    kk.call("kk_rmsnorm_fwd", xr.bfloat16(), gain, res, yb, rb, rows, H, 1)
+    close(yb, ya, 1e-6, 1e-6, "rms fwd bf16 x")
+    dxa, dxb = torch.empty(rows, H, device="cuda"), torch.empty(rows, H, device="cuda", dtype=torch.bfloat16)
+    dga, dgb = torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")
+    kk.call("kk_rmsnorm_bwd", dy, xr, gain, ra, dxa, dga, rows, H, 0)
+    kk.call("kk_rmsnorm_bwd", dy, xr.bfloat16(), gain, rb, dxb, dgb, rows, H, 1)
+    close(dxb, dxa, *BF, "rms dx bf16")
+    close(dgb, dga, 1e-4, 1e-5, "rms dgain bf16 x")
+
+
+@pytest.mark.parametrize("rope", [0, 1])
+def test_headnorm_bf16_storage(kk, rope):
+    g = torch.Generator().manual_seed(9 + rope)
+    B, S, h = 2, 50, 4
+    H = h * 64
+    x, dy = dev(_r16(torch.randn(B * S, 3 * H, generator=g))), dev(_r16(torch.randn(B * S, 3 * H, generator=g)))
+    gains = [dev(1 + 0.1 * torch.randn(64, generator=g)) for _ in range(3)]
+    c, s_ = O.rope_tables(S, 64)
+    ct, st_ = dev(c), dev(s_)
+    y32, y16 = torch.empty_like(x), torch.empty_like(x, dtype=torch.bfloat16)
+    kk.call("kk_headnorm_rope_fwd", x, 3 * H, y32, 3 * H, B * S, h, S, 3, *gains, 3 if rope else 0, ct, st_, 0)
+    kk.call("kk_headnorm_rope_fwd", x.bfloat16(), 3 * H, y16, 3 * H, B * S, h, S, 3, *gains, 3 if rope else 0, ct, st_, 1)
+    close(y16, y32, *BF, "headnorm fwd bf16")
+    dx32, dx16 = torch.empty_like(x), torch.empty_like(x, dtype=torch.bfloat16)
+    dg32, dg16 = [torch.zeros(64, device="cuda") for _ in range(3)], [torch.zeros(64, device="cuda") for _ in range(3)]
+    kk.call("kk_headnorm_rope_bwd", dy, 3 * H, x, 3 * H, dx32, 3 * H, B * S, h, S, 3, *gains, *dg32, 3 if rope else 0, ct, st_, 0)
+    kk.call("kk_headnorm_rope_bwd", dy.bfloat16(), 3 * H, x.bfloat16(), 3 * H, dx16, 3 * H, B * S, h, S, 3, *gains, *dg16,
+            3 if rope else 0, ct, st_, 1)
+    close(dx16, dx32, *BF, "headnorm dx bf16")
+    for a, b in zip(dg16, dg32):
+        close(a, b, 1e-3, 1e-4, "headnorm dgain bf16")
+
+
+def test_elementwise_bf16_storage(kk):
+    g = torch.Generator().manual_seed(21)
+    rows, Fd = 300, 256
+    seed = torch.tensor([3], dtype=torch.int32, device="cuda")
+    hh, dg = dev(_r16(torch.randn(rows, 2 * Fd, generator=g))), dev(_r16(torch.randn(rows, Fd, generator=g)))
+    for p in (0.0, 0.1):
+        g32, g16 = torch.empty(rows, Fd, device="cuda"), torch.empty(rows, Fd, device="cuda", dtype=torch.bfloat16)
+        kk.call("kk_glu_fwd", hh, g32, rows, Fd, seed, 5, p, 0)
+        kk.call("kk_glu_fwd", hh.bfloat16(), g16, rows, Fd, seed, 5, p, 1)
+        assert torch.equal(g16, g32.bfloat16()), "glu fwd: bf16 storage = rounded fp32 result"
+        d32, d16 = torch.empty(rows, 2 * Fd, device="cuda"), torch.empty(rows, 2 * Fd, device="cuda", dtype=torch.bfloat16)
+        kk.call("kk_glu_bwd", dg, hh, d32, rows, Fd, seed, 5, p, 0)
+        kk.call("kk_glu_bwd", dg.bfloat16(), hh.bfloat16(), d16, rows, Fd, seed, 5, p, 1)
+        assert torch.equal(d16, d32.bfloat16())
+    # im2col3 (fp32 in, bf16 columns) and its transpose (bf16 columns in, fp32 out)
+    B, L, C = 2, 600, 64
+    x = dev(torch.randn(B * L, C, generator=g))
+    c32, c16 = torch.empty(B * L, 3 * C, device="cuda"), torch.empty(B * L, 3 * C, device="cuda", dtype=torch.bfloat16)
+    kk.call("kk_im2col3_fwd", x, c32, B, L, C, 512, 0)
+    kk.call("kk_im2col3_fwd", x, c16, B, L, C, 512, 1)
+    assert torch.equal(c16, c32.bfloat16())
+    dcol = dev(_r16(torch.randn(B * L, 3 * C, generator=g)))
+    a32, a16 = torch.empty(B * L, C, device="cuda"), torch.empty(B * L, C, device="cuda")
+    kk.call("kk_im2col3_bwd", dcol, a32, B, L, C, 512, 0)
+    kk.call("kk_im2col3_bwd", dcol.bfloat16(), a16, B, L, C, 512, 1)
+    assert torch.equal(a16, a32)
+    # rowdot with a bf16 x (stop head on the bf16 decoder output)
+    xr, w, b = dev(_r16(torch.randn(B * L, C, generator=g))), dev(torch.randn(C, generator=g)), dev(torch.randn(1, generator=g))
+    o32, o16 = torch.empty(B * L, device="cuda"), torch.empty(B * L, device="cuda")
+    kk.call("kk_rowdot_fwd", xr, w, b, None, o32, B * L, C, L, 0, 0)
+    kk.call("kk_rowdot_fwd", xr.bfloat16(), w, b, None, o16, B * L, C, L, 0, 1)
+    close(o16, o32, 1e-5, 1e-5, "rowdot fwd bf16 x")
+    dout = dev(torch.randn(B * L, generator=g))
+    dw32, dw16, db32, db16 = (torch.zeros(n, device="cuda") for n in (C, C, 1, 1))
+    kk.call("kk_rowdot_bwd", dout, xr, w, None, None, dw32, db32, B * L, C, L, 0, 0)
+    kk.call("kk_rowdot_bwd", dout, xr.bfloat16(), w, None, None, dw16, db16, B * L, C, L, 0, 1)
+    close(dw16, dw32, 1e-4, 1e-5, "rowdot dw bf16 x")
+    close(db16, db32, 1e-4, 1e-5, "rowdot db bf16 x")
+    # column sums of a bf16 matrix; fp32 -> bf16 cast
+    X = dev(_r16(torch.randn(777, 200, generator=g)))
+    s32, s16 = torch.zeros(200, device="cuda"), torch.zeros(200, device="cuda")
+    kk.call("kk_colsum_acc", X, 200, 777, 200, s32, 0)
+    kk.call("kk_colsum_acc", X.bfloat16(), 200, 777, 200, s16, 1)
+    close(s16, s32, 1e-4, 1e-5, "colsum bf16")
+    src = dev(torch.randn(4096 + 8, generator=g))
+    dst = torch.empty(4096 + 8, device="cuda", dtype=torch.bfloat16)
+    kk.call("kk_cast_f32_bf16", src, dst, src.numel())
+    assert torch.equal(dst, src.bfloat16()), "cast must round to nearest even like torch"
+
+
+def test_memory_path_bf16_storage(kk):
+    """bucket_embed_add writes the cross-attention memory, SpecAugment masks it in place: both in bf16 storage."""
+    g = torch.Generator().manual_seed(4)
+    B, T, H, nb = 2, 40, 64, 16
+    x, pitch, energy = torch.randn(B, T, H, generator=g), torch.rand(B, T, generator=g), torch.rand(B, T, generator=g)
+    bins = torch.linspace(0, 1, nb - 1)
+    pemb, eemb = torch.randn(nb, H, generator=g), torch.randn(nb, H, generator=g)
+    lens = torch.tensor([40, 25])
+    outs = []
+    for flag in (0, 1):
+        out = torch.empty(B, T, H, device="cuda", dtype=torch.bfloat16 if flag else torch.float32)
+        pi, ei = torch.empty(B, T, dtype=torch.int32, device="cuda"), torch.empty(B, T, dtype=torch.int32, device="cuda")
+        fm = torch.empty(B, T, dtype=torch.uint8, device="cuda")
+        kk.call("kk_bucket_embed_add_fwd", dev(x), dev(pitch), dev(energy), dev(bins), dev(bins), dev(pemb), dev(eemb), dev(lens),
+                out, pi, ei, fm, B, T, H, nb, flag)
+        outs.append(out)
+    assert torch.equal(outs[1], outs[0].bfloat16())
+    seed = torch.tensor([3], dtype=torch.int32, device="cuda")
+    a, b = outs[0].clone(), outs[1].clone()
+    kk.call("kk_specaug", a, B, T, H, seed, 20, 5, 3, 1, 2, 0)
+    kk.call("kk_specaug", b, B, T, H, seed, 20, 5, 3, 1, 2, 1)
+    assert torch.equal(b, a.bfloat16()) and bool((b == 0).any())

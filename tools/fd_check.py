@@ -27,8 +27,8 @@ for mode in ("off", "on", "attn_only", "resid_only", "glu_only", "droppath_only"
             a = list(a)
             def zero_p(i):
                 a[i] = 0.0
-            if name in ("kk_attn_fwd", "kk_attn_bwd_dq", "kk_attn_bwd_dkv") and _mode != "attn_only": zero_p(-2)
-            if name in ("kk_glu_fwd", "kk_glu_bwd") and _mode != "glu_only": zero_p(-1)
+            if name in ("kk_attn_fwd", "kk_attn_bwd_dq", "kk_attn_bwd_dkv") and _mode != "attn_only": zero_p(-3)
+            if name in ("kk_glu_fwd", "kk_glu_bwd") and _mode != "glu_only": zero_p(-2)
             if name in ("kk_embed_fwd", "kk_embed_bwd") and _mode != "input_only": zero_p(-1)
             if name == "kk_groupnorm_relu_fwd" and _mode != "var_only": zero_p(-1)
             if name == "kk_groupnorm_relu_bwd" and _mode != "var_only": zero_p(-1)
