@@ -42,23 +42,31 @@ struct AttnArgs {
     float p_drop;
 };
 
-// mask multiplier of probability element (b, head, q, key): 0 or 1/(1-p); identical in forward and both backward kernels
+// Dropout on the probabilities.  The keep decision of element (b, head, q, key) is a 16-bit field of a 32-bit hash of
+// (q, key >> 1), keyed by (seed, site, b, head): lanes that own a query get two decisions (key, key^1) per hash, and
+// all three kernels evaluate the same function, so the backward regenerates the forward's mask exactly.  p is
+// quantised to 1/65536 and 1/(1-p) is taken from the quantised value, so the mask stays unbiased.
 struct ProbDrop {
-    uint32_t seed, thr, site;
+    uint32_t thr, key, sk2;      // thr == 0: dropout off
     float inv_keep;
-    uint64_t base;   // (b*heads + head) * Sq
-    int Sk;
     __device__ __forceinline__ void init(const AttnArgs &a, int b, int hh) {
-        thr = a.seed ? kk_drop_threshold(a.p_drop) : 0u;
-        seed = thr ? *a.seed : 0u;
-        site = a.site;
-        inv_keep = thr ? 1.f / (1.f - a.p_drop) : 1.f;
-        base = ((uint64_t)b * a.heads + hh) * (uint64_t)a.Sq;
-        Sk = a.Sk;
+        thr = 0u;
+        if (a.seed && a.p_drop > 0.f) {
+            thr = (uint32_t)(a.p_drop * 65536.f + 0.5f);
+            thr = thr > 65535u ? 65535u : thr;
+        }
+        key = thr ? kk_hash(*a.seed, a.site, (uint64_t)(b * a.heads + hh)) : 0u;
+        inv_keep = thr ? 65536.f / (float)(65536u - thr) : 1.f;
+        sk2 = (uint32_t)(a.Sk + 1) >> 1;
     }
-    __device__ __forceinline__ float mul(int q, int key) const {
-        return thr == 0u ? 1.f : kk_drop_mul(seed, site, (base + (uint64_t)q) * (uint64_t)Sk + (uint64_t)key, thr, inv_keep);
+    __device__ __forceinline__ uint32_t row(int q, int key0) const { return (uint32_t)q * sk2 + ((uint32_t)key0 >> 1); }
+    __device__ __forceinline__ uint32_t hash(uint32_t x) const {        // "lowbias32"
+        x ^= key;
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        return x;
     }
+    __device__ __forceinline__ float lo(uint32_t h) const { return (h & 0xFFFFu) < thr ? 0.f : inv_keep; }   // even key
+    __device__ __forceinline__ float hi(uint32_t h) const { return (h >> 16) < thr ? 0.f : inv_keep; }       // odd key
 };
 
 __device__ __forceinline__ float f4g(const float4 &v, int c) { return reinterpret_cast<const float *>(&v)[c]; }
@@ -289,21 +297,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     load_rowfrag<BF16, T>(qf, qvalid ? static_cast<const T *>(a.Q) + ((int64_t)b * a.Sq + q) * a.ldq + hh * 64 : nullptr, half);
     f32x16 o[2];
     zero_acc(o[0]); zero_acc(o[1]);
-    float m = -1e30f, l = 0.f;
+    float m = -1e30f, l = 0.f;                            // running max in the log2 domain, running sum
+    const float c2 = a.scale * 1.4426950408889634f;       // exp(x*scale) = exp2(x*c2)
     ProbDrop pd;
     pd.init(a, b, hh);
     const uint8_t *km = a.key_mask ? a.key_mask + (int64_t)b * a.Sk : nullptr;
+    const int qmin = qblk + wave * 32;                    // smallest query of this wave
     int kend = a.Sk;
     if (a.causal && qblk + 128 < kend) kend = qblk + 128;
     const T *Kb = static_cast<const T *>(a.K) + (int64_t)b * a.Sk * a.ldk + hh * 64;
     const T *Vb = static_cast<const T *>(a.V) + (int64_t)b * a.Sk * a.ldv + hh * 64;
     typename SG::R rk;
     typename std::conditional<BF16, typename SG::RT, typename SG::R>::type rv;
+    uint32_t rkm = 0;                                     // key-mask byte of key (tile start + lane), prefetched with K/V
     auto issue = [&](int k0) {
         const int nvalid = a.Sk - k0 < 64 ? a.Sk - k0 : 64;
         load_rows(rk, Kb + (int64_t)k0 * a.ldk, a.ldk, nvalid);
         if constexpr (BF16) load_rows_T(rv, Vb + (int64_t)k0 * a.ldv, a.ldv, nvalid);
         else load_rows(rv, Vb + (int64_t)k0 * a.ldv, a.ldv, nvalid);
+        if (km) rkm = lane < nvalid ? km[k0 + lane] : 0u;
     };
     auto commit = [&](int buf) {
         SG::st(smem + buf * 2 * TILE, rk);
@@ -312,6 +324,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     };
     issue(0);
     commit(0);
+    uint64_t kmbits = __ballot(rkm != 0u), kmnext = 0;    // bit j: key (tile start + j) is masked (wave-uniform)
     __syncthreads();
     int cur = 0;
     for (int k0 = 0; k0 < kend; k0 += 64, cur ^= 1) {
@@ -322,43 +335,65 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         for (int sub = 0; sub < 2; ++sub) {
             const int kb = k0 + sub * 32;
             if (kb >= kend) continue;
-            if (a.causal && kb > qblk + wave * 32 + 31) continue;
+            if (a.causal && kb > qmin + 31) continue;
             f32x16 s;
             zero_acc(s);
             mma_tile_x_frag<BF16>(s, Ks, sub * 32, qf, l31, half);
+            const uint32_t kmsub = (uint32_t)(kmbits >> (sub * 32));
+            // masks are only evaluated on edge sub-tiles: ragged end, causal diagonal, or a masked key among the 32
+            const bool edge = kb + 32 > a.Sk || (a.causal && kb + 31 > qmin) || kmsub != 0u;
             float p[16];
-            float mx = -INFINITY;
+            if (edge) {
+                const uint32_t kml = kmsub >> (4 * half);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kb + frag_row(r, half);
-                const bool ok = key < a.Sk && !(a.causal && key > q) && !(km && km[key]);
-                p[r] = ok ? s[r] * a.scale : -INFINITY;
-                mx = fmaxf(mx, p[r]);
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb + frag_row(r, half);
+                    const bool ok = key < a.Sk && !(a.causal && key > q) && !((kml >> frag_row(r, 0)) & 1u);
+                    p[r] = ok ? s[r] * c2 : -INFINITY;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p[r] = s[r] * c2;
             }
+            float mx = p[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, p[r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float mn = fmaxf(m, mx);
-            const float alpha = expf(m - mn);
+            if (__ballot(mn > m) != 0ull) {               // rescale only when some row's maximum moved (wave-uniform)
+                const float alpha = __builtin_amdgcn_exp2f(m - mn);
+                l *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+                m = mn;
+            }
             float rs = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { p[r] = expf(p[r] - mn); rs += p[r]; }
+            for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(p[r] - m); rs += p[r]; }
             rs += __shfl_xor(rs, 32, 64);
-            l = l * alpha + rs;
-            m = mn;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+            l += rs;
             if (pd.thr) {                                  // the row sum l stays un-dropped: softmax first, dropout after
+                const uint32_t xb = pd.row(q, kb + 4 * half);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) p[r] *= pd.mul(q, kb + frag_row(r, half));
+                for (int r = 0; r < 16; r += 2) {
+                    const uint32_t hsh = pd.hash(xb + (uint32_t)(frag_row(r, 0) >> 1));
+                    p[r] *= pd.lo(hsh);
+                    p[r + 1] *= pd.hi(hsh);
+                }
             }
             mma_T_x_p<BF16>(o, Vx, sub * 32, p, l31, half);
         }
-        if (more) commit(cur ^ 1);
+        if (more) {
+            commit(cur ^ 1);
+            kmnext = __ballot(rkm != 0u);
+        }
+        kmbits = kmnext;
         __syncthreads();
     }
     if (qvalid) {
         const float inv = l > 0.f ? 1.f / l : 0.f;
         store_row<T>(static_cast<T *>(a.Out) + ((int64_t)b * a.Sq + q) * a.ldout + hh * 64, o, inv, half);
-        if (half == 0) a.LSEo[((int64_t)b * a.heads + hh) * a.Sq + q] = l > 0.f ? m + logf(l) : INFINITY;
+        if (half == 0) a.LSEo[((int64_t)b * a.heads + hh) * a.Sq + q] = l > 0.f ? (m + __builtin_amdgcn_logf(l)) * 0.6931471805599453f : INFINITY;
     }
 }
 
@@ -378,13 +413,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     RowFrag<BF16> qf, dof;
     load_rowfrag<BF16, T>(qf, qvalid ? static_cast<const T *>(a.Q) + ((int64_t)b * a.Sq + q) * a.ldq + hh * 64 : nullptr, half);
     load_rowfrag<BF16, T>(dof, qvalid ? static_cast<const T *>(a.dO) + ((int64_t)b * a.Sq + q) * a.lddo + hh * 64 : nullptr, half);
-    const float lse = qvalid ? a.LSE[((int64_t)b * a.heads + hh) * a.Sq + q] : INFINITY;
+    const float c2 = a.scale * 1.4426950408889634f;
+    const float lse2 = qvalid ? a.LSE[((int64_t)b * a.heads + hh) * a.Sq + q] * 1.4426950408889634f : INFINITY;   // log2 domain
     const float dlt = qvalid ? a.Delta[((int64_t)b * a.heads + hh) * a.Sq + q] : 0.f;
     f32x16 dq[2];
     zero_acc(dq[0]); zero_acc(dq[1]);
     ProbDrop pd;
     pd.init(a, b, hh);
     const uint8_t *km = a.key_mask ? a.key_mask + (int64_t)b * a.Sk : nullptr;
+    const int qmin = qblk + wave * 32;
+    uint32_t rkm = 0;
     int kend = a.Sk;
     if (a.causal && qblk + 128 < kend) kend = qblk + 128;
     const T *Kb = static_cast<const T *>(a.K) + (int64_t)b * a.Sk * a.ldk + hh * 64;
@@ -396,6 +434,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
         load_rows(rk, Kb + (int64_t)k0 * a.ldk, a.ldk, nvalid);
         load_rows(rv, Vb + (int64_t)k0 * a.ldv, a.ldv, nvalid);
         if constexpr (BF16) load_rows_T(rkt, Kb + (int64_t)k0 * a.ldk, a.ldk, nvalid);
+        if (km) rkm = lane < nvalid ? km[k0 + lane] : 0u;
     };
     auto commit = [&](int buf) {
         SG::st(smem + buf * NT * TILE, rk);
@@ -404,6 +443,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     };
     issue(0);
     commit(0);
+    uint64_t kmbits = __ballot(rkm != 0u), kmnext = 0;
     __syncthreads();
     int cur = 0;
     for (int k0 = 0; k0 < kend; k0 += 64, cur ^= 1) {
@@ -414,25 +454,47 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
         for (int sub = 0; sub < 2; ++sub) {
             const int kb = k0 + sub * 32;
             if (kb >= kend) continue;
-            if (a.causal && kb > qblk + wave * 32 + 31) continue;
+            if (a.causal && kb > qmin + 31) continue;
             f32x16 s, dp;
             zero_acc(s); zero_acc(dp);
             mma_tile_x_frag<BF16>(s, Ks, sub * 32, qf, l31, half);
             mma_tile_x_frag<BF16>(dp, Vs, sub * 32, dof, l31, half);
-            float ds[16];
+            const uint32_t kmsub = (uint32_t)(kmbits >> (sub * 32));
+            const bool edge = kb + 32 > a.Sk || (a.causal && kb + 31 > qmin) || kmsub != 0u;
+            float pv[16], ds[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kb + frag_row(r, half);
-                const bool ok = key < a.Sk && !(a.causal && key > q) && !(km && km[key]);
-                const float pv = ok ? expf(s[r] * a.scale - lse) : 0.f;
-                ds[r] = pv * (dp[r] * pd.mul(q, key) - dlt) * a.scale;
+            for (int r = 0; r < 16; ++r) pv[r] = __builtin_amdgcn_exp2f(s[r] * c2 - lse2);
+            if (edge) {
+                const uint32_t kml = kmsub >> (4 * half);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb + frag_row(r, half);
+                    const bool ok = key < a.Sk && !(a.causal && key > q) && !((kml >> frag_row(r, 0)) & 1u);
+                    pv[r] = ok ? pv[r] : 0.f;
+                }
             }
-            mma_T_x_p<BF16>(dq, Kt, sub * 32, ds, l31, half);
+            if (pd.thr) {
+                const uint32_t xb = pd.row(q, kb + 4 * half);
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const uint32_t hsh = pd.hash(xb + (uint32_t)(frag_row(r, 0) >> 1));
+                    ds[r] = pv[r] * (dp[r] * pd.lo(hsh) - dlt);
+                    ds[r + 1] = pv[r + 1] * (dp[r + 1] * pd.hi(hsh) - dlt);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ds[r] = pv[r] * (dp[r] - dlt);
+            }
+            mma_T_x_p<BF16>(dq, Kt, sub * 32, ds, l31, half);     // (the softmax scale is applied once, at the store)
         }
-        if (more) commit(cur ^ 1);
+        if (more) {
+            commit(cur ^ 1);
+            kmnext = __ballot(rkm != 0u);
+        }
+        kmbits = kmnext;
         __syncthreads();
     }
-    if (qvalid) store_row<T>(static_cast<T *>(a.Out) + ((int64_t)b * a.Sq + q) * a.ldout + hh * 64, dq, 1.f, half);
+    if (qvalid) store_row<T>(static_cast<T *>(a.Out) + ((int64_t)b * a.Sq + q) * a.ldout + hh * 64, dq, a.scale, half);
 }
 
 // ------------------------------------------------------------------ backward: dK, dV
@@ -457,6 +519,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     zero_acc(dk[0]); zero_acc(dk[1]); zero_acc(dv[0]); zero_acc(dv[1]);
     ProbDrop pd;
     pd.init(a, b, hh);
+    const float c2 = a.scale * 1.4426950408889634f;
+    const int kmaxw = kblk + wave * 32 + 31;                           // largest key of this wave
+    const bool anydead = __ballot(!kalive) != 0ull;                    // masked / out-of-range keys in this wave
     const int qstart = a.causal ? (kblk / 64) * 64 : 0;
     const T *Qb = static_cast<const T *>(a.Q) + (int64_t)b * a.Sq * a.ldq + hh * 64;
     const T *dOb = static_cast<const T *>(a.dO) + (int64_t)b * a.Sq * a.lddo + hh * 64;
@@ -474,7 +539,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
         }
         if (threadIdx.x < 64) {
             const int qq = q0 + threadIdx.x;
-            r_lse = qq < a.Sq ? LSEb[qq] : INFINITY;
+            r_lse = qq < a.Sq ? LSEb[qq] * 1.4426950408889634f : INFINITY;      // log2 domain
             r_dlt = qq < a.Sq ? DLb[qq] : 0.f;
         }
     };
@@ -507,16 +572,32 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
             zero_acc(s); zero_acc(dp);
             mma_tile_x_frag<BF16>(s, Qs, sub * 32, kf, l31, half);
             mma_tile_x_frag<BF16>(dp, dOs, sub * 32, vf, l31, half);
+            const bool edge = anydead || qb + 32 > a.Sq || (a.causal && kmaxw > qb);
             float p[16], ds[16];
+            const float *lse_r = &lse_s[cur][sub * 32 + 4 * half], *dlt_r = &dlt_s[cur][sub * 32 + 4 * half];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ql = sub * 32 + frag_row(r, half);
-                const int qq = q0 + ql;
-                const bool ok = kalive && qq < a.Sq && !(a.causal && key > qq);
-                const float pv = ok ? expf(s[r] * a.scale - lse_s[cur][ql]) : 0.f;
-                const float dm = pd.mul(qq, key);
-                p[r] = pv * dm;                                       // dropped probabilities feed dV
-                ds[r] = pv * (dp[r] * dm - dlt_s[cur][ql]) * a.scale;
+            for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(s[r] * c2 - lse_r[frag_row(r, 0)]);
+            if (edge) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qq = qb + frag_row(r, half);
+                    const bool ok = kalive && qq < a.Sq && !(a.causal && key > qq);
+                    p[r] = ok ? p[r] : 0.f;
+                }
+            }
+            if (pd.thr) {
+                const uint32_t xb = pd.row(qb + 4 * half, key);
+                const bool odd = key & 1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t hsh = pd.hash(xb + (uint32_t)frag_row(r, 0) * pd.sk2);
+                    const float dm = odd ? pd.hi(hsh) : pd.lo(hsh);
+                    ds[r] = p[r] * (dp[r] * dm - dlt_r[frag_row(r, 0)]);
+                    p[r] *= dm;                                       // dropped probabilities feed dV
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ds[r] = p[r] * (dp[r] - dlt_r[frag_row(r, 0)]);
             }
             mma_T_x_p<BF16>(dv, dOt, sub * 32, p, l31, half);
             mma_T_x_p<BF16>(dk, Qt, sub * 32, ds, l31, half);
@@ -525,7 +606,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
         __syncthreads();
     }
     if (kvalid) {
-        store_row<T>(static_cast<T *>(a.Out) + ((int64_t)b * a.Sk + key) * a.ldout + hh * 64, dk, 1.f, half);
+        store_row<T>(static_cast<T *>(a.Out) + ((int64_t)b * a.Sk + key) * a.ldout + hh * 64, dk, a.scale, half);
         store_row<T>(static_cast<T *>(a.Out2) + ((int64_t)b * a.Sk + key) * a.ldout2 + hh * 64, dv, 1.f, half);
     }
 }

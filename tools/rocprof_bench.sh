@@ -1,14 +1,10 @@
+# usage (on the GPU box): bash tools/rocprof_bench.sh <tag> [extra bench.py args]
+tag=${1:-run}; shift
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof1 -o r01 -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-graph > gpurun_out/prof1_bench.json 2> gpurun_out/prof1_err.log
-ls -R gpurun_out/prof1 | head -30
-python - <<'PY'
-import csv, glob
-fs = glob.glob('gpurun_out/prof1/**/*kernel_stats.csv', recursive=True)
-print(fs)
-if fs:
-    rows = list(csv.DictReader(open(fs[0])))
-    print(list(rows[0].keys()))
-    for r in rows[:30]:
-        print(r)
-PY
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o r -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" > gpurun_out/prof_${tag}_bench.json 2> gpurun_out/prof_${tag}_err.log
+db=$(find gpurun_out/prof_$tag -name '*.db' | head -1)
+python tools/rocpd_stats.py $db > gpurun_out/prof_${tag}_kernel_stats.txt
+python tools/rocpd_gaps.py $db 0.3 0.8 > gpurun_out/prof_${tag}_gaps.txt
+cat gpurun_out/prof_${tag}_gaps.txt; tail -1 gpurun_out/prof_${tag}_bench.json | cut -c1-200
+rm -rf gpurun_out/prof_$tag
