@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--no-dropout", action="store_true", help="parity configuration (p = 0 everywhere)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-table", default="")
+    ap.add_argument("--gemm16", default="", help="tuning sweep hook: enable,thr128,thr12864,split_target for the bf16 GEMM core")
     args = ap.parse_args()
 
     from kokoro_ruslan_amd import dp, lib as kk
@@ -109,6 +110,8 @@ def main():
     from kokoro_ruslan_amd.spec import ModelDims, StepHyper
     from kokoro_ruslan_amd.synthetic import synthetic_batch
 
+    if args.gemm16:
+        kk.gemm_tune16(*(int(v) for v in args.gemm16.split(",")))
     rank, world, local = dp.init()
     if world != max(1, args.gpus) and rank == 0:
         print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)

@@ -46,6 +46,7 @@ int kk_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, const 
             void *stream);
 /* tuning hook for benchmarks: 128x128-tile threshold (tile count) and XCD-aware tile order on/off */
 int kk_gemm_tune(int tm_threshold, int xcd_swizzle);
+int kk_gemm_tune16(int enable, int thr128, int thr12864, int split_target);   /* same, for the bf16 x bf16 DMA-staged core */
 /* out[n] += sum_m X[m,n]  (bias gradients). */
 int kk_colsum_acc(const float *X, int64_t ldx, int64_t M, int64_t N, float *out, int x_bf16, void *stream);
 

@@ -23,6 +23,13 @@ int kk_fail(int code, const char *fmt, ...);
         if (e__ != hipSuccess) return kk_fail((int)e__, "%s: %s", name, hipGetErrorString(e__)); \
     } while (0)
 
+// bf16-storage GEMM core (kk_gemm16.hip); kk_gemm routes to it when both operands are bf16 and it is eligible
+bool kk_gemm16_eligible(int ta, int tb, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, const void *B, int64_t ldb);
+int kk_gemm16_launch(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, const void *A, int64_t lda, const void *B,
+                     int64_t ldb, float beta, void *C, int64_t ldc, int c_bf16, const float *bias, const float *residual,
+                     int64_t ldr, int64_t res_mod, int split_k, int xcd_swizzle, hipStream_t s);
+void kk_gemm16_tune(int thr128, int thr12864, int split_target);
+
 static inline int kk_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 __device__ __forceinline__ float wave_sum(float v) {

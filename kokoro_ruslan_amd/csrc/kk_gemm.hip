@@ -346,6 +346,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const TX *__restrict__ X, i
 
 int g_tm_threshold = 512;   // use 128x128 tiles when they number at least this many
 int g_xcd_swizzle = 1;
+int g_use_gemm16 = 1;       // route bf16 x bf16 problems to the DMA-staged core (kk_gemm16.hip)
 
 }  // namespace
 
@@ -353,6 +354,11 @@ int g_xcd_swizzle = 1;
 extern "C" int kk_gemm_tune(int tm_threshold, int xcd_swizzle) {
     g_tm_threshold = tm_threshold;
     g_xcd_swizzle = xcd_swizzle;
+    return 0;
+}
+extern "C" int kk_gemm_tune16(int enable, int thr128, int thr12864, int split_target) {
+    g_use_gemm16 = enable;
+    if (thr128 > 0) kk_gemm16_tune(thr128, thr12864, split_target);
     return 0;
 }
 
@@ -375,6 +381,9 @@ extern "C" int kk_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, float al
     if (tb) KK_REQUIRE(N % 4 == 0, "kk_gemm: N=%ld must be a multiple of 4 when B is stored [K,N]", (long)N);
     KK_REQUIRE(math == KK_MATH_F32 || math == KK_MATH_BF16, "kk_gemm: bad math mode %d", math);
     hipStream_t s = (hipStream_t)stream;
+    if (a16 && b16 && g_use_gemm16 && kk_gemm16_eligible(ta, tb, M, N, K, A, lda, B, ldb))
+        return kk_gemm16_launch(ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, c16, bias, residual, ldr, res_mod, split_k,
+                                g_xcd_swizzle, s);
     const int TM = (int64_t)kk_cdiv(M, 128) * kk_cdiv(N, 128) >= g_tm_threshold ? 128 : 64;
     const int BK = (math == KK_MATH_BF16 ? 32 : 16) * (TM == 128 ? 1 : 2);
     const int tiles = kk_cdiv(M, TM) * kk_cdiv(N, TM);

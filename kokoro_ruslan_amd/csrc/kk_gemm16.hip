@@ -1,0 +1,349 @@
+// bf16-storage MFMA GEMM core for gfx950: operands already bf16 in HBM, fp32 accumulate, LDS filled by the
+// buffer-load-to-LDS DMA (16 bytes per lane, no VGPR staging, no ds_write pass).
+//
+// kk_gemm (kk_gemm.hip) routes to this core when both operands are stored as bf16 and the alignment rules below
+// hold; it serves the same three Linear layouts (reference call sites listed at the top of kk_gemm.hip):
+//   forward  Y = X.W^T        A k-contiguous, B k-contiguous
+//   dgrad    dX = dY.W        A k-contiguous, B k-strided
+//   wgrad    dW = dY^T.X      A k-strided,    B k-strided
+//
+// LDS images (BK = 64 reduction elements per stage, two stages):
+//   k-contiguous operand: [rows][64] bf16, 128-byte rows, 16-byte chunk index XOR-ed with (row>>1)&7.  The DMA
+//     writes LDS lane-linearly, so the XOR is applied to the GLOBAL source address (a permutation inside one
+//     128-byte line: still fully coalesced); MFMA fragments are conflict-free ds_read_b128.
+//   k-strided operand: [64 k][rows] bf16 exactly as it lies in memory (rows*2 bytes per k), 32-byte blocks XOR-ed
+//     with a function of k; fragments (8 consecutive k per lane) come from two ds_read_b64_tr_b16 — the hardware
+//     4x16 transpose read — so no software transpose exists anywhere.
+// Out-of-range rows (tile edges, the K tail of a k-strided operand) are zero-filled by the buffer bounds check.
+#include "kk_common.h"
+
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
+
+struct G16Args {
+    int M, N, K;
+    float alpha, beta;
+    const void *A, *B;
+    const float *bias, *residual;
+    void *C;
+    int c_bf16;
+    int64_t lda, ldb, ldc, ldr, res_mod;
+    int k_per_split, atomic;
+    int tiles_m, tiles_n, xcd_swizzle;
+    uint32_t a_bytes, b_bytes;
+};
+
+constexpr int BK = 64;
+
+// One operand tile of ROWS x 64: DMA issue + fragment reads.
+template <int ROWS, bool KS> struct Operand {
+    static constexpr int BYTES = ROWS * BK * 2;
+    static constexpr int NP = ROWS / 32;                       // 16-byte pieces per thread per tile (256 threads)
+    static constexpr int PITCH = KS ? ROWS * 2 : BK * 2;        // bytes per LDS row
+    uint32_t voff[NP];                                          // per-thread byte offset of each piece (tile 0)
+    uint32_t kstep;                                             // bytes to advance per k-tile
+    __amdgpu_buffer_rsrc_t rsrc;
+
+    __device__ __forceinline__ void init(const void *base, uint32_t bytes, int64_t ld, int r0) {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int p = t + 256 * j;
+            if constexpr (!KS) {
+                const int row = p >> 3, c = (p & 7) ^ ((row >> 1) & 7);
+                voff[j] = (uint32_t)(((int64_t)(r0 + row) * ld + c * 8) * 2);
+            } else {
+                constexpr int PPR = ROWS / 8;                   // pieces per k-row
+                const int k = p / PPR, q = p % PPR;
+                const int s = ROWS == 128 ? 2 * (k & 3) : 2 * ((k >> 1) & 1);
+                const int g = (((q >> 1) ^ s) << 1) | (q & 1);
+                voff[j] = (uint32_t)(((int64_t)k * ld + r0 + g * 8) * 2);
+            }
+        }
+        kstep = KS ? (uint32_t)(ld * BK * 2) : (uint32_t)(BK * 2);
+    }
+    // start the DMA of k-tile `kt` (absolute tile index) into the LDS image at `dst`
+    __device__ __forceinline__ void issue(char *dst, int kt, int wave) const {
+        const uint32_t so = (uint32_t)kt * kstep;
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(dst + (wave * 64 + 256 * j) * 16), 16, voff[j], so, 0, 0);
+    }
+};
+
+struct Frag {
+    bf16x8 v;            // k-contiguous operand
+    s16x4 lo, hi;        // k-strided operand: k 0..3 and 4..7 of this lane's eight
+};
+
+// per-lane constants of the fragment reads
+template <int ROWS, bool KS> struct FragAddr {
+    uint32_t base;          // byte offset inside the image
+    uint32_t x[4];          // KC: chunk offsets per ks;  KS: block offsets per 32-row block (ROWS/64 used... up to 4)
+    __device__ __forceinline__ void init(int lane, int wave_row0) {
+        const int l31 = lane & 31, half = lane >> 5;
+        if constexpr (!KS) {
+            const int swz = (l31 >> 1) & 7;
+            base = (uint32_t)((wave_row0 + l31) * (BK * 2));
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) x[ks] = (uint32_t)(((2 * ks + half) ^ swz) * 16);
+        } else {
+            const int L = lane & 15, gi = (lane >> 4) & 1, kq = L >> 2;
+            const int s = ROWS == 128 ? 2 * (kq & 3) : 2 * ((kq >> 1) & 1);
+            base = (uint32_t)((8 * half + kq) * (ROWS * 2) + 8 * (L & 3));
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) x[rb] = (uint32_t)((((wave_row0 >> 4) + 2 * rb + gi) ^ s) * 32);
+        }
+    }
+    // Fragment for 32-row block rb (relative to the wave's first row), k-slab ks (16 k).
+    // k-contiguous: one ds_read_b128 the compiler schedules and waits for.  k-strided: two transpose reads issued as
+    // inline asm — through the builtin, hipcc puts an s_waitcnt vmcnt(0) in front of every read while a DMA is in
+    // flight, which would serialise the pipeline; the caller retires them with wait_frags() before the MFMAs.
+    __device__ __forceinline__ void load(Frag &f, const char *img, int rb, int ks) const {
+        if constexpr (!KS) {
+            f.v = *reinterpret_cast<const bf16x8 *>(img + base + rb * 32 * (BK * 2) + x[ks]);
+        } else {
+            const uint32_t addr = (uint32_t)(uintptr_t)LDS_PTR(img) + base + x[rb] + ks * 16 * (ROWS * 2);
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(addr));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi) : "v"(addr), "n"(4 * ROWS * 2));
+        }
+    }
+};
+
+__device__ __forceinline__ bf16x8 frag_value(const Frag &f, bool ks) {
+    if (!ks) return f.v;
+    s16x8 v;
+    v[0] = f.lo[0]; v[1] = f.lo[1]; v[2] = f.lo[2]; v[3] = f.lo[3]; v[4] = f.hi[0]; v[5] = f.hi[1]; v[6] = f.hi[2]; v[7] = f.hi[3];
+    return __builtin_bit_cast(bf16x8, v);
+}
+// s_waitcnt lgkmcnt(0) that the asm reads' results are data-dependent on (so no consumer can be scheduled above it)
+__device__ __forceinline__ void wait_frag(Frag &f) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.lo), "+v"(f.hi)); }
+
+// NS LDS stages: NS-1 k-tiles are in flight while one is multiplied.  The DMA of a tile is waited for with a COUNTED
+// vmcnt (the younger tiles stay in flight across the barrier), and the barrier is a raw s_barrier: __syncthreads()
+// would drain vmcnt(0) because an LDS-DMA is a pending LDS write.
+template <bool TA, bool TB, int BM, int BN, int NS>
+__global__ __launch_bounds__(256) void gemm16_kernel(G16Args a) {
+    constexpr int MI = BM / 64, NI = BN / 64;                  // 32x32 MFMA tiles per wave (wave tile = BM/2 x BN/2)
+    using OA = Operand<BM, TA>;
+    using OB = Operand<BN, TB>;
+    constexpr int STAGE = OA::BYTES + OB::BYTES;
+    constexpr int NPT = OA::NP + OB::NP;                       // DMA instructions per thread per k-tile
+    __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
+
+    int tid_lin = blockIdx.x;
+    if (a.xcd_swizzle) {                                        // contiguous run of tiles per XCD (see kk_gemm.hip)
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = tid_lin & 7, in = tid_lin >> 3;
+        tid_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + in;
+    }
+    const int m0 = (tid_lin / a.tiles_n) * BM, n0 = (tid_lin % a.tiles_n) * BN;
+    const int kbeg = blockIdx.y * a.k_per_split;
+    const int kend = min(a.K, kbeg + a.k_per_split);
+    const int nk = (kend - kbeg + BK - 1) / BK, kt0 = kbeg / BK;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 1, wc = wave & 1, half = lane >> 5, l31 = lane & 31;
+
+    OA oa;
+    OB ob;
+    oa.init(a.A, a.a_bytes, a.lda, m0);
+    ob.init(a.B, a.b_bytes, a.ldb, n0);
+    FragAddr<BM, TA> fa;
+    FragAddr<BN, TB> fb;
+    fa.init(lane, wr * (BM / 2));
+    fb.init(lane, wc * (BN / 2));
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+        if (p < nk) {
+            oa.issue(smem + p * STAGE, kt0 + p, wave);
+            ob.issue(smem + p * STAGE + OA::BYTES, kt0 + p, wave);
+        }
+    int sc = 0, sn = NS - 1;                                    // stage being multiplied / stage being refilled
+    for (int kt = 0; kt < nk; ++kt) {
+        // this wave's pieces of tile kt have landed once at most the younger tiles' DMAs are outstanding
+        const int younger = min(nk - 1 - kt, NS - 2);
+        if (NS >= 4 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPT) : "memory");
+        else if (NS >= 3 && younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                           // everyone's pieces landed; everyone finished reading stage sn
+        asm volatile("" ::: "memory");
+        if (kt + NS - 1 < nk) {
+            oa.issue(smem + sn * STAGE, kt0 + kt + NS - 1, wave);
+            ob.issue(smem + sn * STAGE + OA::BYTES, kt0 + kt + NS - 1, wave);
+        }
+        const char *cur = smem + sc * STAGE;
+        sn = sc;
+        sc = sc + 1 == NS ? 0 : sc + 1;
+        const char *Ai = cur, *Bi = cur + OA::BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            Frag af[MI], bf[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa.load(af[i], Ai, i, ks);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) fb.load(bf[j], Bi, j, ks);
+            if constexpr (TA) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) wait_frag(af[i]);
+            }
+            if constexpr (TB) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) wait_frag(bf[j]);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_value(af[i], TA), frag_value(bf[j], TB), acc[i][j], 0, 0, 0);
+        }
+    }
+    if (nk <= 0) return;
+
+    const bool lead = (blockIdx.y == 0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int col = n0 + wc * (BN / 2) + j * 32 + l31;
+            if (col >= a.N) continue;
+            const float bv = (a.bias != nullptr && lead) ? a.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * (BM / 2) + i * 32 + frag_row(r, half);
+                if (row >= a.M) continue;
+                float v = a.alpha * acc[i][j][r] + bv;
+                if (a.residual != nullptr && lead) {
+                    const int64_t rr = a.res_mod > 0 ? (int64_t)row % a.res_mod : (int64_t)row;
+                    v += a.residual[rr * a.ldr + col];
+                }
+                if (a.c_bf16) {
+                    static_cast<__bf16 *>(a.C)[(int64_t)row * a.ldc + col] = (__bf16)v;
+                    continue;
+                }
+                float *dst = static_cast<float *>(a.C) + (int64_t)row * a.ldc + col;
+                if (a.atomic) {
+                    atomicAdd(dst, v);
+                } else {
+                    if (a.beta != 0.f) v += a.beta * (*dst);
+                    *dst = v;
+                }
+            }
+        }
+}
+
+// (explicit instantiations: the host stubs of kernels only named inside launch_tile's if/else chain were not emitted)
+
+template __global__ void gemm16_kernel<false, false, 128, 128, 2>(G16Args);
+template __global__ void gemm16_kernel<false, true, 128, 128, 2>(G16Args);
+template __global__ void gemm16_kernel<true, false, 128, 128, 2>(G16Args);
+template __global__ void gemm16_kernel<true, true, 128, 128, 2>(G16Args);
+template __global__ void gemm16_kernel<false, false, 128, 64, 2>(G16Args);
+template __global__ void gemm16_kernel<false, true, 128, 64, 2>(G16Args);
+template __global__ void gemm16_kernel<true, false, 128, 64, 2>(G16Args);
+template __global__ void gemm16_kernel<true, true, 128, 64, 2>(G16Args);
+template __global__ void gemm16_kernel<false, false, 128, 64, 3>(G16Args);
+template __global__ void gemm16_kernel<false, true, 128, 64, 3>(G16Args);
+template __global__ void gemm16_kernel<true, false, 128, 64, 3>(G16Args);
+template __global__ void gemm16_kernel<true, true, 128, 64, 3>(G16Args);
+template __global__ void gemm16_kernel<false, false, 64, 64, 2>(G16Args);
+template __global__ void gemm16_kernel<false, true, 64, 64, 2>(G16Args);
+template __global__ void gemm16_kernel<true, false, 64, 64, 2>(G16Args);
+template __global__ void gemm16_kernel<true, true, 64, 64, 2>(G16Args);
+template __global__ void gemm16_kernel<false, false, 64, 64, 3>(G16Args);
+template __global__ void gemm16_kernel<false, true, 64, 64, 3>(G16Args);
+template __global__ void gemm16_kernel<true, false, 64, 64, 3>(G16Args);
+template __global__ void gemm16_kernel<true, true, 64, 64, 3>(G16Args);
+template __global__ void gemm16_kernel<false, false, 64, 64, 4>(G16Args);
+template __global__ void gemm16_kernel<false, true, 64, 64, 4>(G16Args);
+template __global__ void gemm16_kernel<true, false, 64, 64, 4>(G16Args);
+template __global__ void gemm16_kernel<true, true, 64, 64, 4>(G16Args);
+
+template <int BM, int BN, int NS>
+void launch_tile(int ta, int tb, const G16Args &a, dim3 grid, hipStream_t s) {
+    if (!ta && !tb) hipLaunchKernelGGL((gemm16_kernel<false, false, BM, BN, NS>), grid, dim3(256), 0, s, a);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm16_kernel<false, true, BM, BN, NS>), grid, dim3(256), 0, s, a);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm16_kernel<true, false, BM, BN, NS>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gemm16_kernel<true, true, BM, BN, NS>), grid, dim3(256), 0, s, a);
+}
+
+// Tile choice (by tile count): at this model's sizes (4096..8192 rows x 512..3072 columns) the 64x64 tile wins on
+// every shape measured inside the train step — the launches are latency-bound, so more, smaller workgroups with more
+// DMAs in flight beat the larger tiles' better bytes-per-flop.
+int g16_thr128 = 4096, g16_thr12864 = 4096, g16_split_target = 768, g16_stages = 3;
+
+}  // namespace
+
+// Tuning hook used by tools/ (not part of the C ABI).
+void kk_gemm16_tune(int thr128, int thr12864, int split_target) {
+    g16_thr128 = thr128;
+    g16_thr12864 = thr12864;
+    g16_stages = split_target / 10000 ? split_target / 10000 : 3;        // tools encode stages*10000 + split target
+    g16_split_target = split_target % 10000;
+}
+
+// True when this core can run the problem (both operands bf16 assumed by the caller).
+bool kk_gemm16_eligible(int ta, int tb, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, const void *B, int64_t ldb) {
+    if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || lda % 8 || ldb % 8) return false;
+    if ((!ta || !tb) && K % BK) return false;                 // a k-contiguous operand has no zero-filled K tail
+    const int64_t a_el = ta ? (K - 1) * lda + M : (M - 1) * lda + K, b_el = tb ? (K - 1) * ldb + N : (N - 1) * ldb + K;
+    return a_el * 2 < (1ll << 31) && b_el * 2 < (1ll << 31);
+}
+
+int kk_gemm16_launch(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, const void *A, int64_t lda, const void *B,
+                     int64_t ldb, float beta, void *C, int64_t ldc, int c_bf16, const float *bias, const float *residual,
+                     int64_t ldr, int64_t res_mod, int split_k, int xcd_swizzle, hipStream_t s) {
+    auto cd = [](int64_t x, int64_t y) { return (int)((x + y - 1) / y); };
+    int BM = 64, BN = 64;
+    if (cd(M, 128) * cd(N, 128) >= g16_thr128) { BM = 128; BN = 128; }
+    else if (cd(M, 128) * cd(N, 64) >= g16_thr12864) { BM = 128; BN = 64; }
+    const int tiles = cd(M, BM) * cd(N, BN), ktiles = cd(K, BK);
+    int splits = split_k;
+    if (splits <= 0) {
+        splits = 1;
+        if (tiles * 2 <= g16_split_target) {
+            splits = cd(g16_split_target, tiles);
+            const int cap = ktiles / 2 > 0 ? ktiles / 2 : 1;
+            if (splits > cap) splits = cap;
+        }
+    }
+    if (splits > ktiles) splits = ktiles;
+    if (splits > 1 && (c_bf16 || !(beta == 1.f || (beta == 0.f && ldc == N)))) splits = 1;
+    const int k_per_split = cd(ktiles, splits) * BK;
+    splits = cd(K, k_per_split);
+    G16Args a;
+    a.M = (int)M; a.N = (int)N; a.K = (int)K;
+    a.alpha = alpha; a.beta = beta;
+    a.A = A; a.B = B; a.bias = bias; a.residual = residual; a.C = C; a.c_bf16 = c_bf16;
+    a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.res_mod = res_mod;
+    a.k_per_split = k_per_split;
+    a.atomic = splits > 1 ? 1 : 0;
+    a.tiles_m = cd(M, BM); a.tiles_n = cd(N, BN);
+    a.xcd_swizzle = xcd_swizzle;
+    a.a_bytes = (uint32_t)(((ta ? (K - 1) * lda + M : (M - 1) * lda + K)) * 2);
+    a.b_bytes = (uint32_t)(((tb ? (K - 1) * ldb + N : (N - 1) * ldb + K)) * 2);
+    if (splits > 1 && beta == 0.f) {
+        hipError_t e = hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), s);
+        if (e != hipSuccess) return kk_fail((int)e, "kk_gemm: memset: %s", hipGetErrorString(e));
+    }
+    dim3 grid(a.tiles_m * a.tiles_n, splits);
+    const int ns = ktiles / splits < 3 ? 2 : g16_stages;        // (a short reduction gains nothing from depth)
+    if (BM == 128 && BN == 128) launch_tile<128, 128, 2>(ta, tb, a, grid, s);
+    else if (BM == 128) { if (ns >= 3) launch_tile<128, 64, 3>(ta, tb, a, grid, s); else launch_tile<128, 64, 2>(ta, tb, a, grid, s); }
+    else if (ns >= 4) launch_tile<64, 64, 4>(ta, tb, a, grid, s);
+    else if (ns == 3) launch_tile<64, 64, 3>(ta, tb, a, grid, s);
+    else launch_tile<64, 64, 2>(ta, tb, a, grid, s);
+    KK_LAUNCH_CHECK("kk_gemm");
+    return 0;
+}

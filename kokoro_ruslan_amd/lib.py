@@ -45,6 +45,7 @@ _P, _I, _L, _F, _D, _U = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, 
 SIGNATURES: Dict[str, List[Any]] = {
     "kk_gemm": [_I, _I, _L, _L, _L, _F, _P, _L, _P, _L, _F, _P, _L, _P, _P, _L, _L, _I, _I, _I, _P],
     "kk_gemm_tune": [_I, _I],
+    "kk_gemm_tune16": [_I, _I, _I, _I],
     "kk_colsum_acc": [_P, _L, _L, _L, _P, _I, _P],
     "kk_attn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P],
     "kk_attn_delta": [_P, _P, _P, _I, _I, _I, _L, _L, _I, _P],
@@ -137,6 +138,11 @@ def _conv(a):
 
 def gemm_tune(tm_threshold: int = 512, xcd_swizzle: int = 1) -> None:
     load().kk_gemm_tune(tm_threshold, xcd_swizzle)
+
+
+def gemm_tune16(enable: int = 1, thr128: int = 0, thr12864: int = 0, split_target: int = 0) -> None:
+    """Benchmark hook for the bf16 x bf16 GEMM core: on/off, tile thresholds, split-K workgroup target (0 = keep)."""
+    load().kk_gemm_tune16(enable, thr128, thr12864, split_target)
 
 
 def call(name: str, *args) -> None:

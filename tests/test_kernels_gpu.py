@@ -89,6 +89,41 @@ def test_gemm_splitk_wgrad(kk, math_mode):
         close(Cd, ref + beta * acc0, 2e-3 if math_mode == 0 else 0.3, 1e-3, f"split-k beta={beta} split={split}")
 
 
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(128, 64, 64), (200, 136, 192), (520, 1536, 512), (4096, 512, 1536), (1000, 3072, 320),
+                                   (72, 264, 4096)])
+def test_gemm_bf16_dma_core(kk, ta, tb, M, N, K):
+    """bf16 x bf16 operands (the DMA-staged core, kk_gemm16.hip): strided operands and outputs, bias, residual with
+    a row period, alpha/beta, bf16 and fp32 outputs, ragged tiles; for k-strided operands also a K that is not a
+    multiple of the 64-deep stage (zero-filled by the buffer bounds check)."""
+    g = torch.Generator().manual_seed(M * 3 + N * 5 + K + 2 * ta + tb)
+    if ta and tb:
+        K += 40                                   # K tail: only legal when both operands are k-strided
+    pad_a, pad_b, pad_c = 16, 8, 24                # leading dimensions larger than the logical widths
+    A = torch.randn((K, M + pad_a) if ta else (M, K + pad_a), generator=g).bfloat16()
+    Bm = torch.randn((K, N + pad_b) if tb else (N, K + pad_b), generator=g).bfloat16()
+    Al = (A[:, :M].float().t() if ta else A[:, :K].float()).double()
+    Bl = (Bm[:, :N].float() if tb else Bm[:, :K].float().t()).double()
+    bias, res = torch.randn(N, generator=g), torch.randn(50, N + 8, generator=g)
+    rows = torch.arange(M) % 50
+    ref = (0.5 * (Al @ Bl)).float() + bias + res[rows][:, :N]
+    Ad, Bd = dev(A), dev(Bm)
+    for c16 in (0, 1):
+        Cd = torch.full((M, N + pad_c), 7.0, device="cuda", dtype=torch.bfloat16 if c16 else torch.float32)
+        kk.call("kk_gemm", ta, tb, M, N, K, 0.5, Ad, A.shape[1], Bd, Bm.shape[1], 0.0, Cd, N + pad_c, dev(bias), dev(res), N + 8, 50,
+                1, 1, 3 | (c16 << 2))
+        close(Cd[:, :N], ref, 2e-3 * math.sqrt(K / 64) + (0.1 if c16 else 0.0), 1e-2 if c16 else 1e-4, f"dma core c16={c16}")
+        assert bool((Cd[:, N:].float() == 7.0).all()), "columns beyond N must not be written"
+    acc = torch.randn(M, N, generator=g)
+    for split in (1, 0, 3):                        # beta = 1 accumulate: plain, auto split-K, forced split-K (fp32 atomics)
+        Cd = dev(acc)
+        kk.call("kk_gemm", ta, tb, M, N, K, 1.0, Ad, A.shape[1], Bd, Bm.shape[1], 1.0, Cd, N, None, None, 0, 0, split, 1, 3)
+        close(Cd, (Al @ Bl).float() + acc, 3e-3 * math.sqrt(K / 64), 1e-4, f"dma core accumulate split={split}")
+    Cd = torch.empty(M, N, device="cuda")           # beta = 0 with split-K (memset + atomics)
+    kk.call("kk_gemm", ta, tb, M, N, K, 1.0, Ad, A.shape[1], Bd, Bm.shape[1], 0.0, Cd, N, None, None, 0, 0, 2, 1, 3)
+    close(Cd, (Al @ Bl).float(), 3e-3 * math.sqrt(K / 64), 1e-4, "dma core beta=0 split")
+
+
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1)])
 @pytest.mark.parametrize("dtypes", [1, 2, 3, 7, 6])
 @pytest.mark.parametrize("M,N,K", [(136, 72, 200), (4096, 2048, 136), (520, 1536, 512)])
