@@ -143,6 +143,12 @@ class KokoroEngine:
         self.dp_loss_scale = 1.0                    # 1/world in data-parallel runs (dp.GradSync.loss_scale)
         # dropout / DropPath / SpecAugment: off = the parity configuration (reference with p = 0)
         self.train_dropout = False
+        # Second HIP stream: the parts of a step that do not depend on the decoder (pitch/energy predictors; after the
+        # loss, the predictors' and the whole text encoder's backward — the length-regulated memory is detached) run
+        # beside the decoder kernels instead of after them; they are small launches that cannot fill 256 CUs alone.
+        self.overlap = True
+        self._side = torch.cuda.Stream(device=self.device)
+        self._tmp_ns = ""
         self.spec_augment_active = True             # the trainer clears it for epochs < spec_augment_start_epoch
         self.rng = torch.full((1,), int(seed) & 0x7FFFFFFF, dtype=torch.int32, device=self.device)   # step seed, read on device
         for n, b in spec.make_buffers(self.dims).items():
@@ -198,7 +204,29 @@ class KokoroEngine:
         return OrderedDict((n, self.arena.G[n]) for n in self.arena.param_names)
 
     # ------------------------------------------------------------------ helpers
+    @contextlib.contextmanager
+    def _on_side_stream(self):
+        """Run the enclosed launches on the side stream, after everything already queued on the current stream; the
+        caller joins with _join_side().  Scratch ("tmp.*") buffers get their own namespace so the two streams never
+        share one.  With overlap off this is a no-op (same stream, same order)."""
+        if not self.overlap:
+            yield
+            return
+        self._side.wait_stream(torch.cuda.current_stream())
+        self._tmp_ns = "side."
+        try:
+            with torch.cuda.stream(self._side):
+                yield
+        finally:
+            self._tmp_ns = ""
+
+    def _join_side(self) -> None:
+        if self.overlap:
+            torch.cuda.current_stream().wait_stream(self._side)
+
     def _buf(self, key, *shape, dtype=torch.float32) -> torch.Tensor:
+        if key.startswith("tmp."):
+            key = self._tmp_ns + key
         k = (key, tuple(shape), dtype)
         t = self._ws.get(k)
         if t is None:
@@ -498,8 +526,9 @@ class KokoroEngine:
         pitch_pred, energy_pred = self._buf("out.pitch", B, T), self._buf("out.energy", B, T)
         col_f = self._buf("vp.col_frames", Nd, 3 * H, dtype=ddt)
         kk.call("kk_im2col3_fwd", xf, col_f, B, T, H, CHUNK, _b16(col_f))
-        self._varpred_fwd("vp.pitch", f"{VA}.pitch_predictor", xf, col_f, B, T, fmask, pitch_pred, 12, p_var)
-        self._varpred_fwd("vp.energy", f"{VA}.energy_predictor", xf, col_f, B, T, fmask, energy_pred, 14, p_var)
+        with self._on_side_stream():                      # joined before the losses
+            self._varpred_fwd("vp.pitch", f"{VA}.pitch_predictor", xf, col_f, B, T, fmask, pitch_pred, 12, p_var)
+            self._varpred_fwd("vp.energy", f"{VA}.energy_predictor", xf, col_f, B, T, fmask, energy_pred, 14, p_var)
         spec_aug = self.train_dropout and hp.use_spec_augment and self.spec_augment_active
         if spec_aug:                                      # on the cross-attention memory only (model.py:636-639)
             kk.call("kk_specaug", memory, B, T, H, self.rng, 20, hp.spec_augment_time_mask_max, hp.spec_augment_freq_mask_max,
@@ -538,6 +567,7 @@ class KokoroEngine:
                 _b16(dec_out))
 
         # ---- losses (losses.py) ----
+        self._join_side()
         lcfg = kk.KkLossCfg(hp.duration_loss_weight, hp.stop_token_loss_weight, hp.pitch_loss_weight, hp.energy_loss_weight,
                             hp.duration_huber_delta, hp.pitch_huber_delta, hp.energy_huber_delta, hp.stop_token_pos_weight,
                             float(loss_scale), 1 if adaptive else 0)
@@ -553,6 +583,27 @@ class KokoroEngine:
         dmel, ddur = self._buf("g.mel", B, T, M), self._buf("g.dur", B, Pn)
         dstop, dpitch, denergy = self._buf("g.stop", B, T), self._buf("g.pitch", B, T), self._buf("g.energy", B, T)
         kk.call("kk_losses_bwd", *largs, self.loss_coef, dmel, ddur, dstop, dpitch, denergy)
+        with self._on_side_stream():                      # independent of the decoder backward (disjoint gradient segments)
+            self._varpred_bwd("vp.pitch", f"{VA}.pitch_predictor", dpitch, xf, col_f, B, T, fmask, None, p_var)
+            self._varpred_bwd("vp.energy", f"{VA}.energy_predictor", denergy, xf, col_f, B, T, fmask, None, p_var)
+            d_enc = self._buf("g.enc_out", Ne, H)
+            self._varpred_bwd("vp.dur", f"{VA}.duration_predictor", ddur, enc, col_e, B, Pn, text_mask, d_enc, p_var)
+            dx = self._buf("g.enc_stream", Ne, H)
+            self._ln_bwd("enc.norm", d_enc, enc_last, "encoder_norm", dx, accumulate=False)
+            dne = self._buf("tmp.dne", Ne, H, dtype=edt)
+            for i in reversed(range(d.enc_layers)):
+                pf, key, st = f"transformer_encoder_layers.{i}", f"enc{i}", 1000 + 32 * i
+                dpr = self._dpr(i, d.enc_layers)
+                x_in = self._buf(f"enc{i - 1}.xo", Ne, H) if i > 0 else self._buf("enc.x0", Ne, H)
+                xm = self._buf(key + ".xm", Ne, H)
+                y1, y2 = self._buf(key + ".ln1.y", Ne, H, dtype=edt), self._buf(key + ".ln2.y", Ne, H, dtype=edt)
+                self._ffn_bwd(key + ".ff", pf + ".ff", dx, y2, dne, d.enc_ff, Pn, st + 8, p_enc, dpr)
+                self._ln_bwd(key + ".ln2", dne, xm, pf + ".norm2", dx, accumulate=True)
+                self._attn_bwd(key + ".sa", pf + ".self_attn", dx, y1, None, B, Pn, Pn, True, False, text_mask, dne, None, 0.0,
+                               st, p_enc, dpr)
+                self._ln_bwd(key + ".ln1", dne, x_in, pf + ".norm1", dx, accumulate=True)
+            kk.call("kk_embed_bwd", ids, stress, dx, G["text_embedding.weight"],
+                    G["stress_embedding.weight"] if stress is not None else None, B, Pn, H, float(H ** 0.5), self.rng, 1, pe_drop)
         # heads (model.py:561-562): the stop head's input is detached
         kk.call("kk_rowdot_bwd", dstop, dec_out, P["stop_token_predictor.weight"], None, None, G["stop_token_predictor.weight"],
                 G["stop_token_predictor.bias"], Nd, H, T, 0, _b16(dec_out))
@@ -592,27 +643,7 @@ class KokoroEngine:
                     hp.spec_augment_num_time_masks, hp.spec_augment_num_freq_masks, 0)
         kk.call("kk_bucket_embed_add_bwd", dmem, pidx, eidx, fmask, G[f"{VA}.pitch_embedding.weight"],
                 G[f"{VA}.energy_embedding.weight"], B, T, H)
-        self._varpred_bwd("vp.pitch", f"{VA}.pitch_predictor", dpitch, xf, col_f, B, T, fmask, None, p_var)
-        self._varpred_bwd("vp.energy", f"{VA}.energy_predictor", denergy, xf, col_f, B, T, fmask, None, p_var)
-        d_enc = self._buf("g.enc_out", Ne, H)
-        self._varpred_bwd("vp.dur", f"{VA}.duration_predictor", ddur, enc, col_e, B, Pn, text_mask, d_enc, p_var)
-        # encoder
-        dx = self._buf("g.enc_stream", Ne, H)
-        self._ln_bwd("enc.norm", d_enc, enc_last, "encoder_norm", dx, accumulate=False)
-        dne = self._buf("tmp.dne", Ne, H, dtype=edt)
-        for i in reversed(range(d.enc_layers)):
-            pf, key, st = f"transformer_encoder_layers.{i}", f"enc{i}", 1000 + 32 * i
-            dpr = self._dpr(i, d.enc_layers)
-            x_in = self._buf(f"enc{i - 1}.xo", Ne, H) if i > 0 else self._buf("enc.x0", Ne, H)
-            xm = self._buf(key + ".xm", Ne, H)
-            y1, y2 = self._buf(key + ".ln1.y", Ne, H, dtype=edt), self._buf(key + ".ln2.y", Ne, H, dtype=edt)
-            self._ffn_bwd(key + ".ff", pf + ".ff", dx, y2, dne, d.enc_ff, Pn, st + 8, p_enc, dpr)
-            self._ln_bwd(key + ".ln2", dne, xm, pf + ".norm2", dx, accumulate=True)
-            self._attn_bwd(key + ".sa", pf + ".self_attn", dx, y1, None, B, Pn, Pn, True, False, text_mask, dne, None, 0.0,
-                           st, p_enc, dpr)
-            self._ln_bwd(key + ".ln1", dne, x_in, pf + ".norm1", dx, accumulate=True)
-        kk.call("kk_embed_bwd", ids, stress, dx, G["text_embedding.weight"], G["stress_embedding.weight"] if stress is not None else None,
-                B, Pn, H, float(H ** 0.5), self.rng, 1, pe_drop)
+        self._join_side()
         return out
 
     # ------------------------------------------------------------------ optimizer boundary
