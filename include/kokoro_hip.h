@@ -166,7 +166,7 @@ int kk_dropout_fwd(const float *x, const float *res, int64_t res_mod, float *out
                    const uint32_t *seed, uint32_t site1, float p1, uint32_t site2, float p2, uint32_t site_dp,
                    float dp_rate, void *stream);
 int kk_dropout_bwd(const float *dy, float *dx, int64_t rows, int H, int S, const uint32_t *seed, uint32_t site1,
-                   float p1, uint32_t site2, float p2, uint32_t site_dp, float dp_rate, void *stream);
+                   float p1, uint32_t site2, float p2, uint32_t site_dp, float dp_rate, int dx_bf16, void *stream);
 /* SpecAugment on the cross-attention memory, in place (trainer.py:1577-1604); call again on the memory gradient. */
 int kk_specaug(float *x, int B, int T, int H, const uint32_t *seed, uint32_t site, int time_mask_max,
                int feat_mask_max, int n_time, int n_feat, int x_bf16, void *stream);

@@ -24,8 +24,9 @@ __device__ __forceinline__ float row_scale(const DropArgs &d, uint32_t seed, int
 
 // out = (res ? res[(row % res_mod)] : 0) + x * m1 * m2 * droppath(row)      (fwd)
 // dx  = dy * m1 * m2 * droppath(row)                                        (bwd: res == nullptr, x = dy)
+template <typename TO>
 __global__ __launch_bounds__(256) void dropout_kernel(const float *__restrict__ x, const float *__restrict__ res, int64_t res_mod,
-                                                      float *__restrict__ out, int64_t total4, int H, DropArgs d) {
+                                                      TO *__restrict__ out, int64_t total4, int H, DropArgs d) {
     const uint32_t seed = *d.seed;
     const uint32_t t1 = kk_drop_threshold(d.p1), t2 = kk_drop_threshold(d.p2);
     const float k1 = d.p1 > 0.f ? 1.f / (1.f - d.p1) : 1.f, k2 = d.p2 > 0.f ? 1.f / (1.f - d.p2) : 1.f;
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float *__restrict__ 
             const float4 r = ld4(res + rr * H + c);
             o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
         }
-        st4(out + row * H + c, make_float4(o[0], o[1], o[2], o[3]));
+        stv4<TO>(out + row * H + c, make_float4(o[0], o[1], o[2], o[3]));
     }
 }
 
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void specaug_kernel(TX *__restrict__ x, int64_
     }
 }
 
-int launch_dropout(const float *x, const float *res, int64_t res_mod, float *out, int64_t rows, int H, int S,
+int launch_dropout(const float *x, const float *res, int64_t res_mod, float *out, int out_bf16, int64_t rows, int H, int S,
                    const uint32_t *seed, uint32_t site1, float p1, uint32_t site2, float p2, uint32_t site_dp, float dp_rate,
                    hipStream_t s, const char *name) {
     KK_REQUIRE(rows > 0 && H > 0 && H % 4 == 0 && S > 0 && seed, "%s: bad args", name);
@@ -95,7 +96,8 @@ int launch_dropout(const float *x, const float *res, int64_t res_mod, float *out
     const int64_t total4 = rows * H / 4;
     int blocks = kk_cdiv(total4, 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(dropout_kernel, dim3(blocks), dim3(256), 0, s, x, res, res_mod, out, total4, H, d);
+    if (out_bf16) hipLaunchKernelGGL(dropout_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, x, res, res_mod, reinterpret_cast<__bf16 *>(out), total4, H, d);
+    else hipLaunchKernelGGL(dropout_kernel<float>, dim3(blocks), dim3(256), 0, s, x, res, res_mod, out, total4, H, d);
     KK_LAUNCH_CHECK(name);
     return 0;
 }
@@ -105,13 +107,13 @@ int launch_dropout(const float *x, const float *res, int64_t res_mod, float *out
 extern "C" int kk_dropout_fwd(const float *x, const float *res, int64_t res_mod, float *out, int64_t rows, int H, int S,
                               const uint32_t *seed, uint32_t site1, float p1, uint32_t site2, float p2, uint32_t site_dp,
                               float dp_rate, void *stream) {
-    return launch_dropout(x, res, res_mod, out, rows, H, S, seed, site1, p1, site2, p2, site_dp, dp_rate, (hipStream_t)stream,
+    return launch_dropout(x, res, res_mod, out, 0, rows, H, S, seed, site1, p1, site2, p2, site_dp, dp_rate, (hipStream_t)stream,
                           "kk_dropout_fwd");
 }
 
 extern "C" int kk_dropout_bwd(const float *dy, float *dx, int64_t rows, int H, int S, const uint32_t *seed, uint32_t site1,
-                              float p1, uint32_t site2, float p2, uint32_t site_dp, float dp_rate, void *stream) {
-    return launch_dropout(dy, nullptr, 0, dx, rows, H, S, seed, site1, p1, site2, p2, site_dp, dp_rate, (hipStream_t)stream,
+                              float p1, uint32_t site2, float p2, uint32_t site_dp, float dp_rate, int dx_bf16, void *stream) {
+    return launch_dropout(dy, nullptr, 0, dx, dx_bf16, rows, H, S, seed, site1, p1, site2, p2, site_dp, dp_rate, (hipStream_t)stream,
                           "kk_dropout_bwd");
 }
 

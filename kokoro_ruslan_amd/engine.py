@@ -113,8 +113,8 @@ class KokoroEngine:
         self.math_mode = math_mode
         # activation / weight-operand storage: "f32" everywhere (always in the parity mode), or bf16 for the GEMM and
         # attention operands of the bf16 mode ("bf16": both stacks, "bf16-dec": decoder stack only).
-        if storage == "auto":      # encoder GEMMs (512 rows) need split-K with fp32 atomic outputs to fill the chip
-            storage = "bf16-dec" if math_mode == "bf16" else "f32"
+        if storage == "auto":
+            storage = "bf16" if math_mode == "bf16" else "f32"
         if storage not in ("f32", "bf16", "bf16-dec") or (storage != "f32" and math_mode != "bf16"):
             raise ValueError(f"storage={storage!r} is not available with math_mode={math_mode!r}")
         if storage != "f32" and any(v % 8 for v in (self.dims.enc_ff, self.dims.dec_ff, self.dims.var_filter)):
@@ -149,6 +149,12 @@ class KokoroEngine:
         self.overlap = True
         self._side = torch.cuda.Stream(device=self.device)
         self._tmp_ns = ""
+        # Optional third stream for the decoder's weight-gradient GEMMs (leaves of the backward graph).  Measured on
+        # MI355X at 8x512: OFF is faster (7.47 ms vs 9.16 ms/step) — one fork/join per GEMM costs more in cross-stream
+        # graph edges than the overlap returns, the dgrad chain already fills the chip.  Kept for larger batches.
+        self.wgrad_aside = False
+        self._wg = torch.cuda.Stream(device=self.device)
+        self._wg_busy = False
         self.spec_augment_active = True             # the trainer clears it for epochs < spec_augment_start_epoch
         self.rng = torch.full((1,), int(seed) & 0x7FFFFFFF, dtype=torch.int32, device=self.device)   # step seed, read on device
         for n, b in spec.make_buffers(self.dims).items():
@@ -263,13 +269,26 @@ class KokoroEngine:
         kk.call("kk_gemm", 0, 1, N, K, M, 1.0, dy, dy.stride(0), W, K, beta, dx, dx.stride(0), None, None, 0, 0, 0, self.math,
                 _b16(dy) | _b16(W) << 1 | _b16(dx) << 2)
 
-    def _wgrad(self, dy, x, dW, db=None):
+    def _wgrad(self, dy, x, dW, db=None, aside=False):
+        """dW += dy^T x (and db += column sums of dy).  aside=True: launch on the weight-gradient stream; the caller
+        guarantees that dy and x stay untouched until the next _wg_sync()."""
         N, M = dy.shape
         K = x.shape[1]
-        kk.call("kk_gemm", 1, 1, M, K, N, 1.0, dy, dy.stride(0), x, x.stride(0), 1.0, dW, K, None, None, 0, 0, 0, self.math,
-                _b16(dy) | _b16(x) << 1)
-        if db is not None:
-            kk.call("kk_colsum_acc", dy, dy.stride(0), N, M, db, _b16(dy))
+        aside = aside and self.wgrad_aside and self.overlap and self._tmp_ns == ""
+        if aside:
+            self._wg.wait_stream(torch.cuda.current_stream())
+            self._wg_busy = True
+        with (torch.cuda.stream(self._wg) if aside else contextlib.nullcontext()):
+            kk.call("kk_gemm", 1, 1, M, K, N, 1.0, dy, dy.stride(0), x, x.stride(0), 1.0, dW, K, None, None, 0, 0, 0, self.math,
+                    _b16(dy) | _b16(x) << 1)
+            if db is not None:
+                kk.call("kk_colsum_acc", dy, dy.stride(0), N, M, db, _b16(dy))
+
+    def _wg_sync(self) -> None:
+        """The current stream waits for every weight-gradient launch queued so far (before their inputs are reused)."""
+        if self._wg_busy and self._tmp_ns == "":
+            torch.cuda.current_stream().wait_stream(self._wg)
+            self._wg_busy = False
 
     def _ln_fwd(self, key, x, prefix, dtype=torch.float32):
         P = self.arena.P
@@ -299,7 +318,7 @@ class KokoroEngine:
         kk.call("kk_dropout_fwd", y, x_res, 0, x_out, y.shape[0], y.shape[1], S, self.rng, site, p, site + 1, p2, site + 2, dpr)
 
     def _residual_bwd(self, dy, dx, S, site, p, dpr, p2=0.0):
-        kk.call("kk_dropout_bwd", dy, dx, dy.shape[0], dy.shape[1], S, self.rng, site, p, site + 1, p2, site + 2, dpr)
+        kk.call("kk_dropout_bwd", dy, dx, dy.shape[0], dy.shape[1], S, self.rng, site, p, site + 1, p2, site + 2, dpr, _b16(dx))
 
     # ------------------------------------------------------------------ attention sub-layer
     def _attn_fwd(self, key, prefix, xq, xkv, B, Sq, Sk, rope, causal, key_mask, x_res, x_out, site=0, p=0.0, dpr=0.0):
@@ -346,11 +365,13 @@ class KokoroEngine:
         cos, sin = self._rope_tables(max(Sq, Sk)) if rope else (None, None)
         ctx, lse = self._buf(key + ".ctx", Nq, H, dtype=dt), self._buf(key + ".lse", B, h, Sq)
         dctx, delta = self._buf("tmp.dctx", Nq, H, dtype=dt), self._buf("tmp.delta", B, h, Sq)
-        if p > 0.0 or dpr > 0.0:
-            masked = self._buf("tmp.d_attn_proj", Nq, H)
+        self._wg_sync()                                   # the previous sub-layer's weight gradients read these scratch buffers
+        own_dout = p > 0.0 or dpr > 0.0                   # else d_out is the residual-stream gradient, updated in place later
+        if own_dout:
+            masked = self._buf("tmp.d_attn_proj", Nq, H, dtype=dt)    # bf16 in the bf16 mode: operand of two GEMMs
             self._residual_bwd(d_out, masked, Sq, site, p, dpr)
             d_out = masked
-        self._wgrad(d_out, ctx, G[prefix + ".w_o.weight"], G[prefix + ".w_o.bias"])
+        self._wgrad(d_out, ctx, G[prefix + ".w_o.weight"], G[prefix + ".w_o.bias"], aside=own_dout)
         self._dgrad(d_out, self._W(prefix + ".w_o.weight"), dctx)
         kk.call("kk_attn_delta", ctx, dctx, delta, B, h, Sq, H, H, i16)
         if xkv is None:
@@ -380,13 +401,13 @@ class KokoroEngine:
             kk.call("kk_headnorm_rope_bwd", dkv_n, 2 * H, kv_raw, 2 * H, dkv_raw, 2 * H, Nk, h, Sk, 2, gk, gv, None, dgk, dgv, None,
                     0, None, None, i16)
         if xkv is None:
-            self._wgrad(draw, xq, a.fused(a.g, prefix + ".w_q.weight", 3))
+            self._wgrad(draw, xq, a.fused(a.g, prefix + ".w_q.weight", 3), aside=True)
             self._dgrad(draw, self._Wf(prefix + ".w_q.weight", 3), d_xq)
         else:
-            self._wgrad(dq_raw, xq, G[prefix + ".w_q.weight"])
+            self._wgrad(dq_raw, xq, G[prefix + ".w_q.weight"], aside=True)
             self._dgrad(dq_raw, self._W(prefix + ".w_q.weight"), d_xq)
             if d_xkv is not None:
-                self._wgrad(dkv_raw, xkv, a.fused(a.g, prefix + ".w_k.weight", 2))
+                self._wgrad(dkv_raw, xkv, a.fused(a.g, prefix + ".w_k.weight", 2), aside=True)
                 self._dgrad(dkv_raw, self._Wf(prefix + ".w_k.weight", 2), d_xkv, beta=d_xkv_beta)
 
     # ------------------------------------------------------------------ GLU feed-forward sub-layer
@@ -414,16 +435,17 @@ class KokoroEngine:
                      self._buf(key + ".f2", N, H, dtype=dt))
         df2, dg, dh1 = (self._buf("tmp.df2", N, H, dtype=dt), self._buf("tmp.dg", N, Fd, dtype=dt),
                         self._buf("tmp.dh1", N, 2 * Fd, dtype=dt))
+        self._wg_sync()
         if p > 0.0 or dpr > 0.0:
             masked = self._buf("tmp.d_ffn_norm", N, H)
             self._residual_bwd(d_out, masked, S, site, p, dpr, p2=p)
             d_out = masked
         kk.call("kk_rmsnorm_bwd", d_out, f2, P[prefix + ".output_norm.weight"], self._buf(key + ".rstd_f", N), df2,
                 G[prefix + ".output_norm.weight"], N, H, i16)
-        self._wgrad(df2, g, G[prefix + ".linear2.weight"], G[prefix + ".linear2.bias"])
+        self._wgrad(df2, g, G[prefix + ".linear2.weight"], G[prefix + ".linear2.bias"], aside=True)
         self._dgrad(df2, self._W(prefix + ".linear2.weight"), dg)
         kk.call("kk_glu_bwd", dg, h1, dh1, N, Fd, self.rng, site + 4, p, i16)
-        self._wgrad(dh1, y, G[prefix + ".linear1.weight"], G[prefix + ".linear1.bias"])
+        self._wgrad(dh1, y, G[prefix + ".linear1.weight"], G[prefix + ".linear1.bias"], aside=True)
         self._dgrad(dh1, self._W(prefix + ".linear1.weight"), d_y)
 
     # ------------------------------------------------------------------ variance predictor
@@ -608,7 +630,7 @@ class KokoroEngine:
         kk.call("kk_rowdot_bwd", dstop, dec_out, P["stop_token_predictor.weight"], None, None, G["stop_token_predictor.weight"],
                 G["stop_token_predictor.bias"], Nd, H, T, 0, _b16(dec_out))
         d_dec_out = self._buf("tmp.d_dec_out", Nd, H, dtype=ddt)
-        self._wgrad(dmel.view(Nd, M), dec_out, G["mel_projection_out.weight"], G["mel_projection_out.bias"])
+        self._wgrad(dmel.view(Nd, M), dec_out, G["mel_projection_out.weight"], G["mel_projection_out.bias"], aside=True)
         self._dgrad(dmel.view(Nd, M), self._W("mel_projection_out.weight"), d_dec_out)
         dy = self._buf("g.dec_stream", Nd, H)          # gradient of the decoder residual stream, updated in place
         self._ln_bwd("dec.norm", d_dec_out, dec_last, "decoder.norm", dy, accumulate=False)
@@ -632,8 +654,8 @@ class KokoroEngine:
         # decoder input projection (the PE add and the shift are parameter-free; mel is data)
         if self.train_dropout and (p_din > 0.0 or pe_drop > 0.0):
             t1, dlin = self._buf("tmp.d_dec_t1", Nd, H), self._buf("tmp.d_dec_lin", Nd, H)
-            kk.call("kk_dropout_bwd", dy, t1, Nd, H, T, self.rng, 31, pe_drop, 0, 0.0, 0, 0.0)
-            kk.call("kk_dropout_bwd", t1, dlin, Nd, H, T, self.rng, 30, p_din, 0, 0.0, 0, 0.0)
+            kk.call("kk_dropout_bwd", dy, t1, Nd, H, T, self.rng, 31, pe_drop, 0, 0.0, 0, 0.0, 0)
+            kk.call("kk_dropout_bwd", t1, dlin, Nd, H, T, self.rng, 30, p_din, 0, 0.0, 0, 0.0, 0)
             self._wgrad(dlin, shifted, G["mel_projection_in.weight"], G["mel_projection_in.bias"])
         else:
             self._wgrad(dy, shifted, G["mel_projection_in.weight"], G["mel_projection_in.bias"])
@@ -643,6 +665,7 @@ class KokoroEngine:
                     hp.spec_augment_num_time_masks, hp.spec_augment_num_freq_masks, 0)
         kk.call("kk_bucket_embed_add_bwd", dmem, pidx, eidx, fmask, G[f"{VA}.pitch_embedding.weight"],
                 G[f"{VA}.energy_embedding.weight"], B, T, H)
+        self._wg_sync()
         self._join_side()
         return out
 

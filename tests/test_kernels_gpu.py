@@ -527,7 +527,10 @@ def test_dropout_residual_droppath(kk):
     rate = float((kept > 0).float().mean())
     assert abs(rate - (1 - p1) * (1 - p2)) < 0.01, rate
     dx = torch.empty(rows, H, device="cuda")
-    kk.call("kk_dropout_bwd", xd, dx, rows, H, S, _seed(), 5, p1, 6, p2, 7, dp)
+    kk.call("kk_dropout_bwd", xd, dx, rows, H, S, _seed(), 5, p1, 6, p2, 7, dp, 0)
+    dx16 = torch.empty(rows, H, device="cuda", dtype=torch.bfloat16)
+    kk.call("kk_dropout_bwd", xd, dx16, rows, H, S, _seed(), 5, p1, 6, p2, 7, dp, 1)
+    assert torch.equal(dx16, dx.bfloat16()), "bf16 output = rounded fp32 output"
     assert torch.equal(dx.cpu(), (out - rd).cpu()) or float((dx.cpu() - (out.cpu() - res)).abs().max()) < 1e-5
     out2 = torch.empty_like(out)
     kk.call("kk_dropout_fwd", xd, rd, 0, out2, rows, H, S, _seed(), 5, p1, 6, p2, 7, dp)

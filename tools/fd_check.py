@@ -34,12 +34,14 @@ for mode in ("off", "on", "attn_only", "resid_only", "glu_only", "droppath_only"
             if name == "kk_groupnorm_relu_bwd" and _mode != "var_only": zero_p(-1)
             if name == "kk_specaug" and _mode != "specaug_only": return
             if name in ("kk_dropout_fwd", "kk_dropout_bwd"):
-                # (… seed, site1, p1, site2, p2, site_dp, dp_rate)
+                # (… seed, site1, p1, site2, p2, site_dp, dp_rate[, dx_bf16])
+                tail = [a.pop()] if name == "kk_dropout_bwd" else []
                 if _mode == "resid_only": a[-1] = 0.0
                 elif _mode == "droppath_only": a[-5] = 0.0; a[-3] = 0.0
                 elif _mode == "input_only":
                     if a[-6] not in (30, 31): a[-5] = 0.0; a[-3] = 0.0; a[-1] = 0.0
                 else: a[-5] = 0.0; a[-3] = 0.0; a[-1] = 0.0
+                a += tail
             return real_call(name, *a)
         import kokoro_ruslan_amd.engine as em
         em.kk.call = call
