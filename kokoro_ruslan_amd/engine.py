@@ -149,12 +149,15 @@ class KokoroEngine:
         self.overlap = True
         self._side = torch.cuda.Stream(device=self.device)
         self._tmp_ns = ""
-        # Optional third stream for the decoder's weight-gradient GEMMs (leaves of the backward graph).  Measured on
-        # MI355X at 8x512: OFF is faster (7.47 ms vs 9.16 ms/step) — one fork/join per GEMM costs more in cross-stream
-        # graph edges than the overlap returns, the dgrad chain already fills the chip.  Kept for larger batches.
-        self.wgrad_aside = False
-        self._wg = torch.cuda.Stream(device=self.device)
-        self._wg_busy = False
+        # Optional third stream for the key/value branch of the decoder's cross-attention (forward: the K/V projections
+        # of all layers depend only on the memory; backward: dK/dV, their head-norm backward, the K/V weight gradient
+        # and the memory gradient feed nothing on the residual chain).  Measured on MI355X at 8x512, both are OFF:
+        # forward aside is neutral (568K vs 572K frames/s), backward aside loses 9 % (519K) — one fork per layer of
+        # chip-filling kernels costs more in cross-stream graph edges than it overlaps.  A stream per weight-gradient
+        # GEMM was worse still (447K).  Only the long independent encoder/predictor branch pays (470K -> 548K).
+        self._kv = torch.cuda.Stream(device=self.device)
+        self.kv_fwd_aside = False
+        self.kv_bwd_aside = False
         self.spec_augment_active = True             # the trainer clears it for epochs < spec_augment_start_epoch
         self.rng = torch.full((1,), int(seed) & 0x7FFFFFFF, dtype=torch.int32, device=self.device)   # step seed, read on device
         for n, b in spec.make_buffers(self.dims).items():
@@ -211,24 +214,30 @@ class KokoroEngine:
 
     # ------------------------------------------------------------------ helpers
     @contextlib.contextmanager
-    def _on_side_stream(self):
-        """Run the enclosed launches on the side stream, after everything already queued on the current stream; the
-        caller joins with _join_side().  Scratch ("tmp.*") buffers get their own namespace so the two streams never
-        share one.  With overlap off this is a no-op (same stream, same order)."""
-        if not self.overlap:
+    def _on_stream(self, stream, ns, enable=True):
+        """Run the enclosed launches on `stream`, after everything already queued on the current stream; the caller
+        joins with _join(stream).  Scratch ("tmp.*") buffers get the namespace `ns` so that streams never share one.
+        With overlap off this is a no-op (same stream, same order)."""
+        if not (self.overlap and enable):
             yield
             return
-        self._side.wait_stream(torch.cuda.current_stream())
-        self._tmp_ns = "side."
+        stream.wait_stream(torch.cuda.current_stream())
+        saved, self._tmp_ns = self._tmp_ns, ns
         try:
-            with torch.cuda.stream(self._side):
+            with torch.cuda.stream(stream):
                 yield
         finally:
-            self._tmp_ns = ""
+            self._tmp_ns = saved
+
+    def _on_side_stream(self):
+        return self._on_stream(self._side, "side.")
+
+    def _join(self, stream) -> None:
+        if self.overlap:
+            torch.cuda.current_stream().wait_stream(stream)
 
     def _join_side(self) -> None:
-        if self.overlap:
-            torch.cuda.current_stream().wait_stream(self._side)
+        self._join(self._side)
 
     def _buf(self, key, *shape, dtype=torch.float32) -> torch.Tensor:
         if key.startswith("tmp."):
@@ -269,26 +278,13 @@ class KokoroEngine:
         kk.call("kk_gemm", 0, 1, N, K, M, 1.0, dy, dy.stride(0), W, K, beta, dx, dx.stride(0), None, None, 0, 0, 0, self.math,
                 _b16(dy) | _b16(W) << 1 | _b16(dx) << 2)
 
-    def _wgrad(self, dy, x, dW, db=None, aside=False):
-        """dW += dy^T x (and db += column sums of dy).  aside=True: launch on the weight-gradient stream; the caller
-        guarantees that dy and x stay untouched until the next _wg_sync()."""
+    def _wgrad(self, dy, x, dW, db=None):
         N, M = dy.shape
         K = x.shape[1]
-        aside = aside and self.wgrad_aside and self.overlap and self._tmp_ns == ""
-        if aside:
-            self._wg.wait_stream(torch.cuda.current_stream())
-            self._wg_busy = True
-        with (torch.cuda.stream(self._wg) if aside else contextlib.nullcontext()):
-            kk.call("kk_gemm", 1, 1, M, K, N, 1.0, dy, dy.stride(0), x, x.stride(0), 1.0, dW, K, None, None, 0, 0, 0, self.math,
-                    _b16(dy) | _b16(x) << 1)
-            if db is not None:
-                kk.call("kk_colsum_acc", dy, dy.stride(0), N, M, db, _b16(dy))
-
-    def _wg_sync(self) -> None:
-        """The current stream waits for every weight-gradient launch queued so far (before their inputs are reused)."""
-        if self._wg_busy and self._tmp_ns == "":
-            torch.cuda.current_stream().wait_stream(self._wg)
-            self._wg_busy = False
+        kk.call("kk_gemm", 1, 1, M, K, N, 1.0, dy, dy.stride(0), x, x.stride(0), 1.0, dW, K, None, None, 0, 0, 0, self.math,
+                _b16(dy) | _b16(x) << 1)
+        if db is not None:
+            kk.call("kk_colsum_acc", dy, dy.stride(0), N, M, db, _b16(dy))
 
     def _ln_fwd(self, key, x, prefix, dtype=torch.float32):
         P = self.arena.P
@@ -336,14 +332,12 @@ class KokoroEngine:
             q_raw, q_n = self._buf(key + ".q_raw", Nq, H, dtype=dt), self._buf(key + ".q_n", Nq, H, dtype=dt)
             kv_raw, kv_n = self._buf(key + ".kv_raw", Nk, 2 * H, dtype=dt), self._buf(key + ".kv_n", Nk, 2 * H, dtype=dt)
             self._linear(xq, self._W(prefix + ".w_q.weight"), None, q_raw)
-            self._linear(xkv, self._Wf(prefix + ".w_k.weight", 2), None, kv_raw)
-            k_raw, v_raw, k_n, v_n = kv_raw, kv_raw[:, H:], kv_n, kv_n[:, H:]
+            k_raw, v_raw, k_n, v_n = kv_raw, kv_raw[:, H:], kv_n, kv_n[:, H:]           # filled by _cross_kv_fwd
         gq, gk, gv = P[prefix + ".q_norm.weight"], P[prefix + ".k_norm.weight"], P[prefix + ".v_norm.weight"]
         if xkv is None:       # q|k|v in one launch over the fused projection; RoPE on q and k only
             kk.call("kk_headnorm_rope_fwd", raw, 3 * H, nrm, 3 * H, Nq, h, Sq, 3, gq, gk, gv, 3 if rope else 0, cos, sin, i16)
         else:
             kk.call("kk_headnorm_rope_fwd", q_raw, H, q_n, H, Nq, h, Sq, 1, gq, None, None, 0, None, None, i16)
-            kk.call("kk_headnorm_rope_fwd", kv_raw, 2 * H, kv_n, 2 * H, Nk, h, Sk, 2, gk, gv, None, 0, None, None, i16)
         ctx, lse = self._buf(key + ".ctx", Nq, H, dtype=dt), self._buf(key + ".lse", B, h, Sq)
         kk.call("kk_attn_fwd", q_n, k_n, v_n, ctx, lse, B, h, Sq, Sk, q_n.stride(0), k_n.stride(0), v_n.stride(0), H, key_mask,
                 1 if causal else 0, 0.125, self.rng, site + 3, p, self.math, i16)
@@ -353,6 +347,15 @@ class KokoroEngine:
             self._residual(proj, x_res, x_out, Sq, site, p, dpr)
         else:
             self._linear(ctx, self._W(prefix + ".w_o.weight"), P[prefix + ".w_o.bias"], x_out, res=x_res)
+
+    def _cross_kv_fwd(self, key, prefix, xkv, Nk, Sk, dt):
+        """K/V projection + per-head RMSNorm of one cross-attention layer (no RoPE: transformers.py:268-277 applies it
+        to self-attention only).  Depends on the memory alone."""
+        P, H, h = self.arena.P, self.dims.hidden, self.dims.heads
+        kv_raw, kv_n = self._buf(key + ".kv_raw", Nk, 2 * H, dtype=dt), self._buf(key + ".kv_n", Nk, 2 * H, dtype=dt)
+        self._linear(xkv, self._Wf(prefix + ".w_k.weight", 2), None, kv_raw)
+        kk.call("kk_headnorm_rope_fwd", kv_raw, 2 * H, kv_n, 2 * H, Nk, h, Sk, 2, P[prefix + ".k_norm.weight"],
+                P[prefix + ".v_norm.weight"], None, 0, None, None, _b16(kv_raw))
 
     def _attn_bwd(self, key, prefix, d_out, xq, xkv, B, Sq, Sk, rope, causal, key_mask, d_xq, d_xkv, d_xkv_beta,
                   site=0, p=0.0, dpr=0.0):
@@ -364,14 +367,14 @@ class KokoroEngine:
         i16 = _b16(xq)
         cos, sin = self._rope_tables(max(Sq, Sk)) if rope else (None, None)
         ctx, lse = self._buf(key + ".ctx", Nq, H, dtype=dt), self._buf(key + ".lse", B, h, Sq)
-        dctx, delta = self._buf("tmp.dctx", Nq, H, dtype=dt), self._buf("tmp.delta", B, h, Sq)
-        self._wg_sync()                                   # the previous sub-layer's weight gradients read these scratch buffers
-        own_dout = p > 0.0 or dpr > 0.0                   # else d_out is the residual-stream gradient, updated in place later
-        if own_dout:
+        # cross-attention: dctx / delta are read by the K/V branch on its own stream, so each layer keeps its own
+        ck = "tmp" if xkv is None else key
+        dctx, delta = self._buf(ck + ".dctx", Nq, H, dtype=dt), self._buf(ck + ".delta", B, h, Sq)
+        if p > 0.0 or dpr > 0.0:
             masked = self._buf("tmp.d_attn_proj", Nq, H, dtype=dt)    # bf16 in the bf16 mode: operand of two GEMMs
             self._residual_bwd(d_out, masked, Sq, site, p, dpr)
             d_out = masked
-        self._wgrad(d_out, ctx, G[prefix + ".w_o.weight"], G[prefix + ".w_o.bias"], aside=own_dout)
+        self._wgrad(d_out, ctx, G[prefix + ".w_o.weight"], G[prefix + ".w_o.bias"])
         self._dgrad(d_out, self._W(prefix + ".w_o.weight"), dctx)
         kk.call("kk_attn_delta", ctx, dctx, delta, B, h, Sq, H, H, i16)
         if xkv is None:
@@ -383,32 +386,35 @@ class KokoroEngine:
             q_raw, q_n = self._buf(key + ".q_raw", Nq, H, dtype=dt), self._buf(key + ".q_n", Nq, H, dtype=dt)
             kv_raw, kv_n = self._buf(key + ".kv_raw", Nk, 2 * H, dtype=dt), self._buf(key + ".kv_n", Nk, 2 * H, dtype=dt)
             dq_n, dq_raw = self._buf("tmp.dq_n", Nq, H, dtype=dt), self._buf("tmp.dq_raw", Nq, H, dtype=dt)
-            dkv_n, dkv_raw = self._buf("tmp.dkv_n", Nk, 2 * H, dtype=dt), self._buf("tmp.dkv_raw", Nk, 2 * H, dtype=dt)
             k_raw, v_raw, k_n, v_n = kv_raw, kv_raw[:, H:], kv_n, kv_n[:, H:]
-            dk_n, dv_n, dk_raw, dv_raw = dkv_n, dkv_n[:, H:], dkv_raw, dkv_raw[:, H:]
         ld = lambda t: t.stride(0)
-        kk.call("kk_attn_bwd_dq", q_n, k_n, v_n, dctx, lse, delta, dq_n, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H, ld(dq_n),
-                key_mask, 1 if causal else 0, 0.125, self.rng, site + 3, p, self.math, i16)
-        kk.call("kk_attn_bwd_dkv", q_n, k_n, v_n, dctx, lse, delta, dk_n, dv_n, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H,
-                ld(dk_n), ld(dv_n), key_mask, 1 if causal else 0, 0.125, self.rng, site + 3, p, self.math, i16)
         gq, gk, gv = P[prefix + ".q_norm.weight"], P[prefix + ".k_norm.weight"], P[prefix + ".v_norm.weight"]
         dgq, dgk, dgv = G[prefix + ".q_norm.weight"], G[prefix + ".k_norm.weight"], G[prefix + ".v_norm.weight"]
+        cz = 1 if causal else 0
         if xkv is None:
+            kk.call("kk_attn_bwd_dq", q_n, k_n, v_n, dctx, lse, delta, dq_n, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H, ld(dq_n),
+                    key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16)
+            kk.call("kk_attn_bwd_dkv", q_n, k_n, v_n, dctx, lse, delta, dk_n, dv_n, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H,
+                    ld(dk_n), ld(dv_n), key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16)
             kk.call("kk_headnorm_rope_bwd", dn, 3 * H, raw, 3 * H, draw, 3 * H, Nq, h, Sq, 3, gq, gk, gv, dgq, dgk, dgv,
                     3 if rope else 0, cos, sin, i16)
-        else:
-            kk.call("kk_headnorm_rope_bwd", dq_n, H, q_raw, H, dq_raw, H, Nq, h, Sq, 1, gq, None, None, dgq, None, None, 0, None, None, i16)
-            kk.call("kk_headnorm_rope_bwd", dkv_n, 2 * H, kv_raw, 2 * H, dkv_raw, 2 * H, Nk, h, Sk, 2, gk, gv, None, dgk, dgv, None,
-                    0, None, None, i16)
-        if xkv is None:
-            self._wgrad(draw, xq, a.fused(a.g, prefix + ".w_q.weight", 3), aside=True)
+            self._wgrad(draw, xq, a.fused(a.g, prefix + ".w_q.weight", 3))
             self._dgrad(draw, self._Wf(prefix + ".w_q.weight", 3), d_xq)
-        else:
-            self._wgrad(dq_raw, xq, G[prefix + ".w_q.weight"], aside=True)
-            self._dgrad(dq_raw, self._W(prefix + ".w_q.weight"), d_xq)
-            if d_xkv is not None:
-                self._wgrad(dkv_raw, xkv, a.fused(a.g, prefix + ".w_k.weight", 2), aside=True)
+            return
+        if d_xkv is not None:
+            with self._on_stream(self._kv, "kv.", self.kv_bwd_aside):          # the key/value branch: nothing on the residual chain reads it
+                dkv_n, dkv_raw = self._buf("tmp.dkv_n", Nk, 2 * H, dtype=dt), self._buf("tmp.dkv_raw", Nk, 2 * H, dtype=dt)
+                kk.call("kk_attn_bwd_dkv", q_n, k_n, v_n, dctx, lse, delta, dkv_n, dkv_n[:, H:], B, h, Sq, Sk, ld(q_n), ld(k_n),
+                        ld(v_n), H, 2 * H, 2 * H, key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16)
+                kk.call("kk_headnorm_rope_bwd", dkv_n, 2 * H, kv_raw, 2 * H, dkv_raw, 2 * H, Nk, h, Sk, 2, gk, gv, None, dgk, dgv,
+                        None, 0, None, None, i16)
+                self._wgrad(dkv_raw, xkv, a.fused(a.g, prefix + ".w_k.weight", 2))
                 self._dgrad(dkv_raw, self._Wf(prefix + ".w_k.weight", 2), d_xkv, beta=d_xkv_beta)
+        kk.call("kk_attn_bwd_dq", q_n, k_n, v_n, dctx, lse, delta, dq_n, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H, ld(dq_n),
+                key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16)
+        kk.call("kk_headnorm_rope_bwd", dq_n, H, q_raw, H, dq_raw, H, Nq, h, Sq, 1, gq, None, None, dgq, None, None, 0, None, None, i16)
+        self._wgrad(dq_raw, xq, G[prefix + ".w_q.weight"])
+        self._dgrad(dq_raw, self._W(prefix + ".w_q.weight"), d_xq)
 
     # ------------------------------------------------------------------ GLU feed-forward sub-layer
     def _ffn_fwd(self, key, prefix, y, x_res, x_out, Fd, S=1, site=0, p=0.0, dpr=0.0):
@@ -435,17 +441,16 @@ class KokoroEngine:
                      self._buf(key + ".f2", N, H, dtype=dt))
         df2, dg, dh1 = (self._buf("tmp.df2", N, H, dtype=dt), self._buf("tmp.dg", N, Fd, dtype=dt),
                         self._buf("tmp.dh1", N, 2 * Fd, dtype=dt))
-        self._wg_sync()
         if p > 0.0 or dpr > 0.0:
             masked = self._buf("tmp.d_ffn_norm", N, H)
             self._residual_bwd(d_out, masked, S, site, p, dpr, p2=p)
             d_out = masked
         kk.call("kk_rmsnorm_bwd", d_out, f2, P[prefix + ".output_norm.weight"], self._buf(key + ".rstd_f", N), df2,
                 G[prefix + ".output_norm.weight"], N, H, i16)
-        self._wgrad(df2, g, G[prefix + ".linear2.weight"], G[prefix + ".linear2.bias"], aside=True)
+        self._wgrad(df2, g, G[prefix + ".linear2.weight"], G[prefix + ".linear2.bias"])
         self._dgrad(df2, self._W(prefix + ".linear2.weight"), dg)
         kk.call("kk_glu_bwd", dg, h1, dh1, N, Fd, self.rng, site + 4, p, i16)
-        self._wgrad(dh1, y, G[prefix + ".linear1.weight"], G[prefix + ".linear1.bias"], aside=True)
+        self._wgrad(dh1, y, G[prefix + ".linear1.weight"], G[prefix + ".linear1.bias"])
         self._dgrad(dh1, self._W(prefix + ".linear1.weight"), d_y)
 
     # ------------------------------------------------------------------ variance predictor
@@ -557,6 +562,9 @@ class KokoroEngine:
                     hp.spec_augment_num_time_masks, hp.spec_augment_num_freq_masks, _b16(memory))
 
         # ---- decoder (model.py:519-531; transformers.py:543-583,660) ----
+        with self._on_stream(self._kv, "kv.", self.kv_fwd_aside):   # all cross-attention K/V projections, beside decoder layer 0
+            for i in range(d.dec_layers):
+                self._cross_kv_fwd(f"dec{i}.ca", f"decoder.layers.{i}.cross_attn", memory, Nd, T, ddt)
         shifted = self._buf("dec.shifted", Nd, M)
         kk.call("kk_shift_right", mel, shifted, B, T, M)
         y = self._buf("dec.x0", Nd, H)
@@ -575,6 +583,8 @@ class KokoroEngine:
             ya = self._buf(key + ".xa", Nd, H)
             self._attn_fwd(key + ".sa", pf + ".self_attn", n1, None, B, T, T, True, True, None, y, ya, st, p_dec, dpr)
             n2 = self._ln_fwd(key + ".ln2", ya, pf + ".norm2", ddt)
+            if i == 0:
+                self._join(self._kv)
             yc = self._buf(key + ".xc", Nd, H)
             self._attn_fwd(key + ".ca", pf + ".cross_attn", n2, memory, B, T, T, False, False, fmask, ya, yc, st + 8, p_dec, dpr)
             n3 = self._ln_fwd(key + ".ln3", yc, pf + ".norm3", ddt)
@@ -630,7 +640,7 @@ class KokoroEngine:
         kk.call("kk_rowdot_bwd", dstop, dec_out, P["stop_token_predictor.weight"], None, None, G["stop_token_predictor.weight"],
                 G["stop_token_predictor.bias"], Nd, H, T, 0, _b16(dec_out))
         d_dec_out = self._buf("tmp.d_dec_out", Nd, H, dtype=ddt)
-        self._wgrad(dmel.view(Nd, M), dec_out, G["mel_projection_out.weight"], G["mel_projection_out.bias"], aside=True)
+        self._wgrad(dmel.view(Nd, M), dec_out, G["mel_projection_out.weight"], G["mel_projection_out.bias"])
         self._dgrad(dmel.view(Nd, M), self._W("mel_projection_out.weight"), d_dec_out)
         dy = self._buf("g.dec_stream", Nd, H)          # gradient of the decoder residual stream, updated in place
         self._ln_bwd("dec.norm", d_dec_out, dec_last, "decoder.norm", dy, accumulate=False)
@@ -660,13 +670,13 @@ class KokoroEngine:
         else:
             self._wgrad(dy, shifted, G["mel_projection_in.weight"], G["mel_projection_in.bias"])
         # variance adaptor: memory gradient feeds only the two embedding tables (xf is detached, lengths.py:30)
+        self._join(self._kv)                              # dmem is accumulated by the K/V branch
         if spec_aug:
             kk.call("kk_specaug", dmem, B, T, H, self.rng, 20, hp.spec_augment_time_mask_max, hp.spec_augment_freq_mask_max,
                     hp.spec_augment_num_time_masks, hp.spec_augment_num_freq_masks, 0)
         kk.call("kk_bucket_embed_add_bwd", dmem, pidx, eidx, fmask, G[f"{VA}.pitch_embedding.weight"],
                 G[f"{VA}.energy_embedding.weight"], B, T, H)
-        self._wg_sync()
-        self._join_side()
+        self._join(self._side)
         return out
 
     # ------------------------------------------------------------------ optimizer boundary
