@@ -84,15 +84,27 @@ int kk_attn_bwd_dkv(const float *Q, const float *K, const float *V, const float 
  * LayerNorm (nn.LayerNorm eps 1e-5; transformers.py:461-462,518-520,612; model.py:122). */
 int kk_layernorm_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean,
                      float *rstd, int64_t rows, int H, int y_bf16, void *stream);
+/* Backward.  The column reductions (dgamma, dbeta / dgain) leave each workgroup either as device-scope atomics into
+ * the gradient vectors (partials == NULL) or as one row of partials[kk_norm_bwd_blocks(rows,H)][2H] ([..][H] for
+ * RMSNorm) with plain stores; kk_partials_reduce then adds the column sums of any number of such matrices to their
+ * gradient vectors in one launch (the engine does this once per step: the atomics were ~40 % of the kernel). */
+int kk_norm_bwd_blocks(int64_t rows, int H);
+typedef struct KkReduceDesc {
+    const float *src;   /* [nblocks][ncols] partial sums */
+    float *dst0;        /* columns [0, split) are added to dst0[c] */
+    float *dst1;        /* columns [split, ncols) to dst1[c - split] */
+    int nblocks, ncols, split;
+} KkReduceDesc;
+int kk_partials_reduce(const KkReduceDesc *descs /* device memory */, int n, int max_cols, void *stream);
 int kk_layernorm_bwd(const float *dy, const float *x, const float *gamma, const float *mean,
                      const float *rstd, float *dx, int dx_accumulate, float *dgamma, float *dbeta,
-                     int64_t rows, int H, int dy_bf16, void *stream);
+                     float *partials, int64_t rows, int H, int dy_bf16, void *stream);
 /* RMSNorm over the full row, eps = FLT_EPSILON (GLU output_norm, transformers.py:94,109-110), fused with the
  * residual add of the block: y = (residual? residual : 0) + x*rstd*gain. */
 int kk_rmsnorm_fwd(const float *x, const float *gain, const float *residual, float *y, float *rstd,
                    int64_t rows, int H, int x_bf16, void *stream);
 int kk_rmsnorm_bwd(const float *dy, const float *x, const float *gain, const float *rstd, float *dx,
-                   float *dgain, int64_t rows, int H, int x_bf16, void *stream);
+                   float *dgain, float *partials, int64_t rows, int H, int x_bf16, void *stream);
 /* Per-head (64-wide) RMSNorm + optional RoPE rotate-half (transformers.py:260-277; positional_encoding.py:196-209)
  * over up to three column groups ("parts", e.g. q|k|v of a fused projection): element (row, part, head, d) at
  * [row*ld + part*heads*64 + head*64 + d]; gain_j / dgain_j belong to part j; bit j of rope_mask enables RoPE for

@@ -67,56 +67,84 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *__restr
     }
 }
 
-template <typename TD>
+// Each wave takes LN_R rows per trip and issues all their loads before the first reduction, so a wave keeps
+// LN_R x (x, dy, dx) rows in flight instead of one (the kernel is pure latency at 4 waves per CU otherwise).
+// The per-column gain/bias gradients leave a workgroup either as 2H device-scope atomics (measured: ~29 ns per
+// workgroup, 40 % of this kernel at 256 workgroups) or, when `partials` is given, as one plain row of
+// partials[blockIdx.x][2H] that kk_partials_reduce sums later — once for all the norm layers of a step.
+template <typename TD, int NV, int LN_R>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TD *__restrict__ dy, const float *__restrict__ x,
                                                             const float *__restrict__ gamma, const float *__restrict__ mean,
                                                             const float *__restrict__ rstd, float *__restrict__ dx,
                                                             int dx_acc, float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                                            int64_t rows, int H) {
+                                                            float *__restrict__ partials, int64_t rows, int H) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [2][H]
     float *sg = sm, *sb = sm + H;
-    for (int c = threadIdx.x; c < 2 * H; c += 256) sm[c] = 0.f;
+    for (int c = threadIdx.x; c < 2 * H; c += blockDim.x) sm[c] = 0.f;
     __syncthreads();
-    const int lane = threadIdx.x & 63;
-    float4 ag[MAXV], ab[MAXV];
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    float4 ag[NV], ab[NV], gm[NV];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) { ag[i] = f4zero(); ab[i] = f4zero(); }
-    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
-        const float mu = mean[row], rs = rstd[row];
-        float4 xh[MAXV], dg[MAXV];
-        float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        ag[i] = f4zero(); ab[i] = f4zero();
+        gm[i] = c < H ? ld4(gamma + c) : f4zero();
+    }
+    const float invH = 1.f / (float)H;
+    for (int64_t row0 = ((int64_t)blockIdx.x * wpb + (threadIdx.x >> 6)) * LN_R; row0 < rows; row0 += (int64_t)gridDim.x * wpb * LN_R) {
+        float4 xv[LN_R][NV], dv[LN_R][NV], ov[LN_R][NV];
+        float mu[LN_R], rs[LN_R];
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int c = lane * 4 + 256 * i;
-            if (c < H) {
-                const float4 xv = ld4(x + row * H + c), d = ldv4<TD>(dy + row * H + c), g = ld4(gamma + c);
-                xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
-                dg[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
-                s1 += dg[i].x + dg[i].y + dg[i].z + dg[i].w;
-                s2 += dg[i].x * xh[i].x + dg[i].y * xh[i].y + dg[i].z * xh[i].z + dg[i].w * xh[i].w;
-                ag[i].x += d.x * xh[i].x; ag[i].y += d.y * xh[i].y; ag[i].z += d.z * xh[i].z; ag[i].w += d.w * xh[i].w;
-                ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
-            } else { xh[i] = f4zero(); dg[i] = f4zero(); }
+        for (int r = 0; r < LN_R; ++r) {
+            const int64_t row = row0 + r;
+            const bool rv = row < rows;
+            mu[r] = rv ? mean[row] : 0.f;
+            rs[r] = rv ? rstd[row] : 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = lane * 4 + 256 * i;
+                const bool ok = rv && c < H;
+                xv[r][i] = ok ? ld4(x + row * H + c) : f4zero();
+                dv[r][i] = ok ? ldv4<TD>(dy + row * H + c) : f4zero();
+                ov[r][i] = (ok && dx_acc) ? ld4(dx + row * H + c) : f4zero();
+            }
         }
-        s1 = wave_sum(s1) / (float)H;
-        s2 = wave_sum(s2) / (float)H;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int c = lane * 4 + 256 * i;
-            if (c < H) {
-                float4 o;
-                o.x = rs * (dg[i].x - s1 - xh[i].x * s2);
-                o.y = rs * (dg[i].y - s1 - xh[i].y * s2);
-                o.z = rs * (dg[i].z - s1 - xh[i].z * s2);
-                o.w = rs * (dg[i].w - s1 - xh[i].w * s2);
-                float *p = dx + row * H + c;
-                if (dx_acc) { const float4 old = ld4(p); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
-                st4(p, o);
+        for (int r = 0; r < LN_R; ++r) {
+            const int64_t row = row0 + r;
+            if (row >= rows) break;                        // wave-uniform
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const float4 d = dv[r][i];
+                float4 &xh = xv[r][i], &dg = dv[r][i];
+                xh = make_float4((xh.x - mu[r]) * rs[r], (xh.y - mu[r]) * rs[r], (xh.z - mu[r]) * rs[r], (xh.w - mu[r]) * rs[r]);
+                if (lane * 4 + 256 * i >= H) xh = f4zero();
+                ag[i].x += d.x * xh.x; ag[i].y += d.y * xh.y; ag[i].z += d.z * xh.z; ag[i].w += d.w * xh.w;
+                ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+                dg = make_float4(d.x * gm[i].x, d.y * gm[i].y, d.z * gm[i].z, d.w * gm[i].w);
+                s1 += dg.x + dg.y + dg.z + dg.w;
+                s2 += dg.x * xh.x + dg.y * xh.y + dg.z * xh.z + dg.w * xh.w;
+            }
+            s1 = wave_sum(s1) * invH;
+            s2 = wave_sum(s2) * invH;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = lane * 4 + 256 * i;
+                if (c < H) {
+                    const float4 xh = xv[r][i], dg = dv[r][i];
+                    float4 o = ov[r][i];
+                    o.x += rs[r] * (dg.x - s1 - xh.x * s2);
+                    o.y += rs[r] * (dg.y - s1 - xh.y * s2);
+                    o.z += rs[r] * (dg.z - s1 - xh.z * s2);
+                    o.w += rs[r] * (dg.w - s1 - xh.w * s2);
+                    st4(dx + row * H + c, o);
+                }
             }
         }
     }
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = lane * 4 + 256 * i;
         if (c < H) {
             atomicAdd(&sg[c], ag[i].x); atomicAdd(&sg[c + 1], ag[i].y); atomicAdd(&sg[c + 2], ag[i].z); atomicAdd(&sg[c + 3], ag[i].w);
@@ -124,7 +152,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TD *__restrict
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < H; c += 256) {
+    if (partials) {
+        for (int c = threadIdx.x; c < 2 * H; c += blockDim.x) partials[(int64_t)blockIdx.x * 2 * H + c] = sm[c];
+        return;
+    }
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
         atomicAdd(&dgamma[c], sg[c]);
         atomicAdd(&dbeta[c], sb[c]);
     }
@@ -160,48 +192,95 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const TX *__restrict__
     if (lane == 0) rstd_o[row] = rs;
 }
 
-template <typename TX>
+template <typename TX, int NV, int RR>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float *__restrict__ dy, const TX *__restrict__ x,
                                                           const float *__restrict__ gain, const float *__restrict__ rstd,
-                                                          TX *__restrict__ dx, float *__restrict__ dgain, int64_t rows, int H) {
+                                                          TX *__restrict__ dx, float *__restrict__ dgain, float *__restrict__ partials,
+                                                          int64_t rows, int H) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [H]
-    for (int c = threadIdx.x; c < H; c += 256) sm[c] = 0.f;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) sm[c] = 0.f;
     __syncthreads();
-    const int lane = threadIdx.x & 63;
-    float4 ag[MAXV];
+    const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+    float4 ag[NV], gm[NV];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) ag[i] = f4zero();
-    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
-        const float rs = rstd[row];
-        float4 xv[MAXV], dg[MAXV];
-        float s = 0.f;
+    for (int i = 0; i < NV; ++i) {
+        ag[i] = f4zero();
+        gm[i] = lane * 4 + 256 * i < H ? ld4(gain + lane * 4 + 256 * i) : f4zero();
+    }
+    const float invH = 1.f / (float)H;
+    // RR rows per wave per trip, all loads issued before the first reduction (see layernorm_bwd_kernel)
+    for (int64_t row0 = ((int64_t)blockIdx.x * wpb + (threadIdx.x >> 6)) * RR; row0 < rows; row0 += (int64_t)gridDim.x * wpb * RR) {
+        float4 xv[RR][NV], dv[RR][NV];
+        float rs[RR];
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int c = lane * 4 + 256 * i;
-            if (c < H) {
-                xv[i] = ldv4<TX>(x + row * H + c);
-                const float4 d = ld4(dy + row * H + c), g = ld4(gain + c);
-                dg[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
-                s += dg[i].x * xv[i].x + dg[i].y * xv[i].y + dg[i].z * xv[i].z + dg[i].w * xv[i].w;
-                ag[i].x += d.x * xv[i].x * rs; ag[i].y += d.y * xv[i].y * rs; ag[i].z += d.z * xv[i].z * rs; ag[i].w += d.w * xv[i].w * rs;
-            } else { xv[i] = f4zero(); dg[i] = f4zero(); }
+        for (int r = 0; r < RR; ++r) {
+            const int64_t row = row0 + r;
+            const bool rv = row < rows;
+            rs[r] = rv ? rstd[row] : 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = lane * 4 + 256 * i;
+                const bool ok = rv && c < H;
+                xv[r][i] = ok ? ldv4<TX>(x + row * H + c) : f4zero();
+                dv[r][i] = ok ? ld4(dy + row * H + c) : f4zero();
+            }
         }
-        const float k = wave_sum(s) / (float)H * rs * rs * rs;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int c = lane * 4 + 256 * i;
-            if (c < H)
-                stv4<TX>(dx + row * H + c, make_float4(rs * dg[i].x - xv[i].x * k, rs * dg[i].y - xv[i].y * k,
-                                                       rs * dg[i].z - xv[i].z * k, rs * dg[i].w - xv[i].w * k));
+        for (int r = 0; r < RR; ++r) {
+            const int64_t row = row0 + r;
+            if (row >= rows) break;
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const float4 d = dv[r][i], xx = xv[r][i];
+                float4 &dg = dv[r][i];
+                ag[i].x += d.x * xx.x * rs[r]; ag[i].y += d.y * xx.y * rs[r]; ag[i].z += d.z * xx.z * rs[r]; ag[i].w += d.w * xx.w * rs[r];
+                dg = make_float4(d.x * gm[i].x, d.y * gm[i].y, d.z * gm[i].z, d.w * gm[i].w);
+                s += dg.x * xx.x + dg.y * xx.y + dg.z * xx.z + dg.w * xx.w;
+            }
+            const float k = wave_sum(s) * invH * rs[r] * rs[r] * rs[r];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = lane * 4 + 256 * i;
+                const float4 dg = dv[r][i], xx = xv[r][i];
+                if (c < H)
+                    stv4<TX>(dx + row * H + c, make_float4(rs[r] * dg.x - xx.x * k, rs[r] * dg.y - xx.y * k,
+                                                           rs[r] * dg.z - xx.z * k, rs[r] * dg.w - xx.w * k));
+            }
         }
     }
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = lane * 4 + 256 * i;
         if (c < H) { atomicAdd(&sm[c], ag[i].x); atomicAdd(&sm[c + 1], ag[i].y); atomicAdd(&sm[c + 2], ag[i].z); atomicAdd(&sm[c + 3], ag[i].w); }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < H; c += 256) atomicAdd(&dgain[c], sm[c]);
+    if (partials) {
+        for (int c = threadIdx.x; c < H; c += blockDim.x) partials[(int64_t)blockIdx.x * H + c] = sm[c];
+        return;
+    }
+    for (int c = threadIdx.x; c < H; c += blockDim.x) atomicAdd(&dgain[c], sm[c]);
+}
+
+// dst[c] += sum over the nblocks rows of a [nblocks][ncols] partial-sum matrix; one launch serves a whole list.
+// grid (64-column slab, descriptor); 256 threads = 64 columns x 4 row groups.
+__global__ __launch_bounds__(256) void partials_reduce_kernel(const KkReduceDesc *__restrict__ descs) {
+    __shared__ float red[4][64];
+    const KkReduceDesc d = descs[blockIdx.y];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    if (blockIdx.x * 64 >= d.ncols) return;
+    float s = 0.f;
+    if (c < d.ncols) {
+        const float *p = d.src + c;
+#pragma unroll 8
+        for (int r = rg; r < d.nblocks; r += 4) s += p[(int64_t)r * d.ncols];
+    }
+    red[rg][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rg == 0 && c < d.ncols) {
+        float *dst = c < d.split ? d.dst0 + c : d.dst1 + (c - d.split);
+        *dst += red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    }
 }
 
 // ------------------------------------------------------------------ per-head RMSNorm(64) + RoPE
@@ -261,23 +340,43 @@ __global__ __launch_bounds__(256) void headnorm_rope_bwd_kernel(HeadNormArgs a) 
     const bool rope = (a.rope_mask >> part) & 1;
     const float4 g = ld4(a.gain[part] + sub * 4);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int64_t pr = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); pr < a.npairs; pr += (int64_t)gridDim.x * 16) {
-        const int64_t row = pr / a.heads;
-        const int col = part * H + (int)(pr - row * a.heads) * 64 + sub * 4;
-        const float4 v = ldv4<T>(x + row * a.ldx + col);
-        float4 dn = ldv4<T>(dy + row * a.lddy + col);
-        const float rs = 1.f / sqrtf(sum16(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w) * (1.f / 64.f) + FLT_EPSILON);
-        if (rope) {     // dn[d] = dy[d] cos[d] + (d < 32 ? dy[d+32] sin[d+32] : -dy[d-32] sin[d-32])
-            const int pos = (int)(row % a.S);
-            const float4 c = ld4(a.cos_t + pos * 64 + sub * 4), sn = ld4(a.sin_t + pos * 64 + sub * 4);
-            const float4 o = shfl8(make_float4(dn.x * sn.x, dn.y * sn.y, dn.z * sn.z, dn.w * sn.w));
-            const float sg = sub < 8 ? 1.f : -1.f;
-            dn = make_float4(dn.x * c.x + sg * o.x, dn.y * c.y + sg * o.y, dn.z * c.z + sg * o.z, dn.w * c.w + sg * o.w);
+    constexpr int U = 4;     // (row, head) vectors in flight per 16-lane group: all loads of a trip precede its reductions
+    for (int64_t pr0 = ((int64_t)blockIdx.x * 16 + (threadIdx.x >> 4)) * U; pr0 < a.npairs; pr0 += (int64_t)gridDim.x * 16 * U) {
+        float4 vv[U], dd[U], cc[U], ss[U];
+        int64_t off_x[U], off_o[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t pr = pr0 + u;
+            const bool ok = pr < a.npairs;
+            const int64_t row = ok ? pr / a.heads : 0;
+            const int col = part * H + (int)((ok ? pr : 0) - row * a.heads) * 64 + sub * 4;
+            off_x[u] = row * a.ldx + col;
+            off_o[u] = row * a.lddx + col;
+            vv[u] = ok ? ldv4<T>(x + off_x[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            dd[u] = ok ? ldv4<T>(dy + row * a.lddy + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rope) {
+                const int pos = (int)(row % a.S);
+                cc[u] = ld4(a.cos_t + pos * 64 + sub * 4);
+                ss[u] = ld4(a.sin_t + pos * 64 + sub * 4);
+            }
         }
-        acc.x += dn.x * v.x * rs; acc.y += dn.y * v.y * rs; acc.z += dn.z * v.z * rs; acc.w += dn.w * v.w * rs;
-        const float4 dg = make_float4(dn.x * g.x, dn.y * g.y, dn.z * g.z, dn.w * g.w);
-        const float k = sum16(dg.x * v.x + dg.y * v.y + dg.z * v.z + dg.w * v.w) * (1.f / 64.f) * rs * rs * rs;
-        stv4<T>(dx + row * a.lddx + col, make_float4(rs * dg.x - v.x * k, rs * dg.y - v.y * k, rs * dg.z - v.z * k, rs * dg.w - v.w * k));
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (pr0 + u >= a.npairs) break;                 // uniform across the 16-lane group
+            const float4 v = vv[u];
+            float4 dn = dd[u];
+            const float rs = 1.f / sqrtf(sum16(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w) * (1.f / 64.f) + FLT_EPSILON);
+            if (rope) {     // dn[d] = dy[d] cos[d] + (d < 32 ? dy[d+32] sin[d+32] : -dy[d-32] sin[d-32])
+                const float4 c = cc[u], sn = ss[u];
+                const float4 o = shfl8(make_float4(dn.x * sn.x, dn.y * sn.y, dn.z * sn.z, dn.w * sn.w));
+                const float sg = sub < 8 ? 1.f : -1.f;
+                dn = make_float4(dn.x * c.x + sg * o.x, dn.y * c.y + sg * o.y, dn.z * c.z + sg * o.z, dn.w * c.w + sg * o.w);
+            }
+            acc.x += dn.x * v.x * rs; acc.y += dn.y * v.y * rs; acc.z += dn.z * v.z * rs; acc.w += dn.w * v.w * rs;
+            const float4 dg = make_float4(dn.x * g.x, dn.y * g.y, dn.z * g.z, dn.w * g.w);
+            const float k = sum16(dg.x * v.x + dg.y * v.y + dg.z * v.z + dg.w * v.w) * (1.f / 64.f) * rs * rs * rs;
+            stv4<T>(dx + off_o[u], make_float4(rs * dg.x - v.x * k, rs * dg.y - v.y * k, rs * dg.z - v.z * k, rs * dg.w - v.w * k));
+        }
     }
     st4(&red[threadIdx.x >> 4][sub * 4], acc);
     __syncthreads();
@@ -441,19 +540,38 @@ extern "C" int kk_layernorm_fwd(const float *x, const float *gamma, const float 
     return 0;
 }
 
+// workgroups (= rows of `partials`) that kk_layernorm_bwd / kk_rmsnorm_bwd launch for this shape
+extern "C" int kk_norm_bwd_blocks(int64_t rows, int H) {
+    const int nv = kk_cdiv(H, 256), R = nv <= 2 ? 4 : (nv <= 4 ? 2 : 1);
+    int blocks = kk_cdiv(rows, 4 * R);
+    if (blocks > 256) blocks = 256;
+    return blocks < 1 ? 1 : blocks;
+}
+
+extern "C" int kk_partials_reduce(const KkReduceDesc *descs, int n, int max_cols, void *stream) {
+    KK_REQUIRE(descs && n > 0 && max_cols > 0, "kk_partials_reduce: bad args");
+    hipLaunchKernelGGL(partials_reduce_kernel, dim3(kk_cdiv(max_cols, 64), n), dim3(256), 0, (hipStream_t)stream, descs);
+    KK_LAUNCH_CHECK("kk_partials_reduce");
+    return 0;
+}
+
 extern "C" int kk_layernorm_bwd(const float *dy, const float *x, const float *gamma, const float *mean,
                                 const float *rstd, float *dx, int dx_accumulate, float *dgamma, float *dbeta,
-                                int64_t rows, int H, int dy_bf16, void *stream) {
+                                float *partials, int64_t rows, int H, int dy_bf16, void *stream) {
     KK_CHECK_H("kk_layernorm_bwd");
-    int blocks = kk_cdiv(rows, 16);
-    if (blocks > 256) blocks = 256;
-    if (blocks < 1) blocks = 1;
-    if (dy_bf16)
-        hipLaunchKernelGGL(layernorm_bwd_kernel<__bf16>, dim3(blocks), dim3(256), 2 * H * sizeof(float), (hipStream_t)stream,
-                           reinterpret_cast<const __bf16 *>(dy), x, gamma, mean, rstd, dx, dx_accumulate, dgamma, dbeta, rows, H);
-    else
-        hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(blocks), dim3(256), 2 * H * sizeof(float), (hipStream_t)stream, dy, x,
-                           gamma, mean, rstd, dx, dx_accumulate, dgamma, dbeta, rows, H);
+    const int nv = kk_cdiv(H, 256);
+    const int blocks = kk_norm_bwd_blocks(rows, H);            // (rows in flight per wave: 4 / 2 / 1 by register budget)
+    const size_t shm = 2 * H * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+#define KK_LN_BWD(TD, NV, R)                                                                                                  \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<TD, NV, R>), dim3(blocks), dim3(256), shm, st, reinterpret_cast<const TD *>(dy), x, gamma, \
+                       mean, rstd, dx, dx_accumulate, dgamma, dbeta, partials, rows, H)
+    if (dy_bf16) {
+        if (nv <= 1) KK_LN_BWD(__bf16, 1, 4); else if (nv <= 2) KK_LN_BWD(__bf16, 2, 4); else if (nv <= 4) KK_LN_BWD(__bf16, 4, 2); else KK_LN_BWD(__bf16, 8, 1);
+    } else {
+        if (nv <= 1) KK_LN_BWD(float, 1, 4); else if (nv <= 2) KK_LN_BWD(float, 2, 4); else if (nv <= 4) KK_LN_BWD(float, 4, 2); else KK_LN_BWD(float, 8, 1);
+    }
+#undef KK_LN_BWD
     KK_LAUNCH_CHECK("kk_layernorm_bwd");
     return 0;
 }
@@ -472,17 +590,20 @@ extern "C" int kk_rmsnorm_fwd(const float *x, const float *gain, const float *re
 }
 
 extern "C" int kk_rmsnorm_bwd(const float *dy, const float *x, const float *gain, const float *rstd, float *dx,
-                              float *dgain, int64_t rows, int H, int x_bf16, void *stream) {
+                              float *dgain, float *partials, int64_t rows, int H, int x_bf16, void *stream) {
     KK_CHECK_H("kk_rmsnorm_bwd");
-    int blocks = kk_cdiv(rows, 16);
-    if (blocks > 256) blocks = 256;
-    if (blocks < 1) blocks = 1;
-    if (x_bf16)
-        hipLaunchKernelGGL(rmsnorm_bwd_kernel<__bf16>, dim3(blocks), dim3(256), H * sizeof(float), (hipStream_t)stream, dy,
-                           reinterpret_cast<const __bf16 *>(x), gain, rstd, reinterpret_cast<__bf16 *>(dx), dgain, rows, H);
-    else
-        hipLaunchKernelGGL(rmsnorm_bwd_kernel<float>, dim3(blocks), dim3(256), H * sizeof(float), (hipStream_t)stream, dy, x, gain,
-                           rstd, dx, dgain, rows, H);
+    const int nv = kk_cdiv(H, 256);
+    const int blocks = kk_norm_bwd_blocks(rows, H);
+    hipStream_t st = (hipStream_t)stream;
+#define KK_RMS_BWD(TX, NV, R)                                                                                              \
+    hipLaunchKernelGGL((rmsnorm_bwd_kernel<TX, NV, R>), dim3(blocks), dim3(256), H * sizeof(float), st, dy, reinterpret_cast<const TX *>(x), \
+                       gain, rstd, reinterpret_cast<TX *>(dx), dgain, partials, rows, H)
+    if (x_bf16) {
+        if (nv <= 1) KK_RMS_BWD(__bf16, 1, 4); else if (nv <= 2) KK_RMS_BWD(__bf16, 2, 4); else if (nv <= 4) KK_RMS_BWD(__bf16, 4, 2); else KK_RMS_BWD(__bf16, 8, 1);
+    } else {
+        if (nv <= 1) KK_RMS_BWD(float, 1, 4); else if (nv <= 2) KK_RMS_BWD(float, 2, 4); else if (nv <= 4) KK_RMS_BWD(float, 4, 2); else KK_RMS_BWD(float, 8, 1);
+    }
+#undef KK_RMS_BWD
     KK_LAUNCH_CHECK("kk_rmsnorm_bwd");
     return 0;
 }
@@ -515,7 +636,7 @@ extern "C" int kk_headnorm_rope_bwd(const float *dy, int64_t lddy, const float *
     a.x = x; a.dy = dy; a.dx = dx; a.cos_t = cos_t; a.sin_t = sin_t;
     a.gain[0] = gain0; a.gain[1] = gain1; a.gain[2] = gain2; a.dgain[0] = dgain0; a.dgain[1] = dgain1; a.dgain[2] = dgain2;
     a.ldx = ldx; a.lddy = lddy; a.lddx = lddx; a.npairs = rows * heads; a.heads = heads; a.S = S; a.rope_mask = rope_mask;
-    int blocks = kk_cdiv(a.npairs, 16 * 8);
+    int blocks = kk_cdiv(a.npairs, 16 * 4 * 2);           // two trips of 4 vectors per 16-lane group
     blocks = blocks > 512 ? 512 : (blocks < 1 ? 1 : blocks);
     if (io_bf16) hipLaunchKernelGGL(headnorm_rope_bwd_kernel<__bf16>, dim3(blocks, parts), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(headnorm_rope_bwd_kernel<float>, dim3(blocks, parts), dim3(256), 0, (hipStream_t)stream, a);

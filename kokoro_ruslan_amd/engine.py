@@ -128,6 +128,7 @@ class KokoroEngine:
         self._ws: Dict[Tuple, torch.Tensor] = {}
         self._graphs: Dict[Tuple, Dict] = {}
         self._rope: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._reduce_list, self._reduce_tables = [], {}
         self.opt_state = torch.zeros(kk.OS["SIZE"], dtype=torch.float64, device=self.device)
         ns = self.arena.nseg
         f32 = lambda n: torch.zeros(n, dtype=torch.float32, device=self.device)
@@ -293,11 +294,31 @@ class KokoroEngine:
         kk.call("kk_layernorm_fwd", x, P[prefix + ".weight"], P[prefix + ".bias"], y, mean, rstd, rows, H, _b16(y))
         return y
 
+    def _partials(self, key, rows, H, ncols, dst0, dst1, split):
+        """Per-workgroup column partial sums of a norm backward, summed into the gradient vectors by the single
+        kk_partials_reduce launch at the end of the backward pass (instead of device-scope atomics per workgroup)."""
+        nb = kk.load().kk_norm_bwd_blocks(rows, H)
+        part = self._buf(key + ".part", nb, ncols)
+        self._reduce_list.append((part, dst0, dst1, nb, ncols, split))
+        return part
+
     def _ln_bwd(self, key, dy, x, prefix, dx, accumulate):
         P, G = self.arena.P, self.arena.G
         rows, H = x.shape
+        part = self._partials(key, rows, H, 2 * H, G[prefix + ".weight"], G[prefix + ".bias"], H)
         kk.call("kk_layernorm_bwd", dy, x, P[prefix + ".weight"], self._buf(key + ".mean", rows), self._buf(key + ".rstd", rows),
-                dx, 1 if accumulate else 0, G[prefix + ".weight"], G[prefix + ".bias"], rows, H, _b16(dy))
+                dx, 1 if accumulate else 0, G[prefix + ".weight"], G[prefix + ".bias"], part, rows, H, _b16(dy))
+
+    def _reduce_partials(self, shape_key) -> None:
+        if not self._reduce_list:
+            return
+        ent = self._reduce_tables.get(shape_key)
+        if ent is None:                               # workspace addresses are stable per batch shape: build the table once
+            ent = (kk.reduce_table(self._reduce_list, self.device), len(self._reduce_list), max(e[4] for e in self._reduce_list))
+            self._reduce_tables[shape_key] = ent
+        assert ent[1] == len(self._reduce_list)
+        kk.call("kk_partials_reduce", ent[0], ent[1], ent[2])
+        self._reduce_list = []
 
     # ------------------------------------------------------------------ dropout plumbing
     def _p(self, rate: float) -> float:
@@ -445,8 +466,9 @@ class KokoroEngine:
             masked = self._buf("tmp.d_ffn_norm", N, H)
             self._residual_bwd(d_out, masked, S, site, p, dpr, p2=p)
             d_out = masked
+        part = self._partials(key + ".on", N, H, H, G[prefix + ".output_norm.weight"], None, H)
         kk.call("kk_rmsnorm_bwd", d_out, f2, P[prefix + ".output_norm.weight"], self._buf(key + ".rstd_f", N), df2,
-                G[prefix + ".output_norm.weight"], N, H, i16)
+                G[prefix + ".output_norm.weight"], part, N, H, i16)
         self._wgrad(df2, g, G[prefix + ".linear2.weight"], G[prefix + ".linear2.bias"])
         self._dgrad(df2, self._W(prefix + ".linear2.weight"), dg)
         kk.call("kk_glu_bwd", dg, h1, dh1, N, Fd, self.rng, site + 4, p, i16)
@@ -612,6 +634,7 @@ class KokoroEngine:
             return out
 
         # =========================== backward ===========================
+        self._reduce_list = []
         dmel, ddur = self._buf("g.mel", B, T, M), self._buf("g.dur", B, Pn)
         dstop, dpitch, denergy = self._buf("g.stop", B, T), self._buf("g.pitch", B, T), self._buf("g.energy", B, T)
         kk.call("kk_losses_bwd", *largs, self.loss_coef, dmel, ddur, dstop, dpitch, denergy)
@@ -677,6 +700,7 @@ class KokoroEngine:
         kk.call("kk_bucket_embed_add_bwd", dmem, pidx, eidx, fmask, G[f"{VA}.pitch_embedding.weight"],
                 G[f"{VA}.energy_embedding.weight"], B, T, H)
         self._join(self._side)
+        self._reduce_partials((B, T, Pn))
         return out
 
     # ------------------------------------------------------------------ optimizer boundary

@@ -42,6 +42,20 @@ class KkOptCfg(C.Structure):
 _P, _I, _L, _F, _D, _U = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_uint32
 
 # name -> argtypes, in header order (tests/test_abi.py cross-checks arity against include/kokoro_hip.h)
+class KkReduceDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst0", C.c_void_p), ("dst1", C.c_void_p), ("nblocks", C.c_int), ("ncols", C.c_int),
+                ("split", C.c_int)]
+
+
+def reduce_table(entries, device) -> "torch.Tensor":
+    """Device copy of a KkReduceDesc array from [(src, dst0, dst1 | None, nblocks, ncols, split)] of tensors/ints."""
+    arr = (KkReduceDesc * len(entries))()
+    for d, (src, dst0, dst1, nb, nc, split) in zip(arr, entries):
+        d.src, d.dst0, d.dst1 = src.data_ptr(), dst0.data_ptr(), (dst1.data_ptr() if dst1 is not None else 0)
+        d.nblocks, d.ncols, d.split = nb, nc, split
+    return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+
+
 SIGNATURES: Dict[str, List[Any]] = {
     "kk_gemm": [_I, _I, _L, _L, _L, _F, _P, _L, _P, _L, _F, _P, _L, _P, _P, _L, _L, _I, _I, _I, _P],
     "kk_gemm_tune": [_I, _I],
@@ -52,9 +66,11 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_attn_bwd_dq": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P],
     "kk_attn_bwd_dkv": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P],
     "kk_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
-    "kk_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _I, _I, _P],
+    "kk_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _L, _I, _I, _P],
+    "kk_norm_bwd_blocks": [_L, _I],
+    "kk_partials_reduce": [_P, _I, _I, _P],
     "kk_rmsnorm_fwd": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
-    "kk_rmsnorm_bwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "kk_rmsnorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "kk_headnorm_rope_fwd": [_P, _L, _P, _L, _L, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P],
     "kk_headnorm_rope_bwd": [_P, _L, _P, _L, _P, _L, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P],
     "kk_glu_fwd": [_P, _P, _L, _I, _P, _U, _F, _I, _P],

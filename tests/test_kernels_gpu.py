@@ -234,7 +234,7 @@ def test_layernorm(kk, rows, H):
     close(yd, y, 2e-5, 2e-5, "ln fwd")
     dx0 = torch.randn(rows, H, generator=g)
     dx, dg, db = dev(dx0), torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")
-    kk.call("kk_layernorm_bwd", dev(dy), dev(x), dev(gam), mean, rstd, dx, 1, dg, db, rows, H, 0)
+    kk.call("kk_layernorm_bwd", dev(dy), dev(x), dev(gam), mean, rstd, dx, 1, dg, db, None, rows, H, 0)
     close(dx, xr.grad + dx0, 1e-4, 1e-4, "ln dx (accumulate)")
     close(dg, gr.grad, 1e-3, 1e-4, "ln dgamma")
     close(db, br.grad, 1e-3, 1e-4, "ln dbeta")
@@ -252,7 +252,7 @@ def test_rmsnorm_residual(kk, rows, H):
     kk.call("kk_rmsnorm_fwd", dev(x), dev(gain), dev(res), yd, rstd, rows, H, 0)
     close(yd, y, 2e-5, 2e-5, "rms fwd")
     dx, dg = torch.empty(rows, H, device="cuda"), torch.zeros(H, device="cuda")
-    kk.call("kk_rmsnorm_bwd", dev(dy), dev(x), dev(gain), rstd, dx, dg, rows, H, 0)
+    kk.call("kk_rmsnorm_bwd", dev(dy), dev(x), dev(gain), rstd, dx, dg, None, rows, H, 0)
     close(dx, xr.grad, 1e-4, 1e-4, "rms dx")
     close(dg, gr.grad, 1e-3, 1e-4, "rms dgain")
 
@@ -730,7 +730,7 @@ def test_norms_bf16_storage(kk):
     out = []
     for flag, d in ((0, dy), (1, dy.bfloat16())):
         dx, dg, db = torch.ones(rows, H, device="cuda"), torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")
-        kk.call("kk_layernorm_bwd", d, x, gam, mean, rstd, dx, 1, dg, db, rows, H, flag)
+        kk.call("kk_layernorm_bwd", d, x, gam, mean, rstd, dx, 1, dg, db, None, rows, H, flag)
         out.append((dx, dg, db))
     for a, b, n in zip(out[1], out[0], ("dx", "dgamma", "dbeta")):
         close(a, b, 1e-5, 1e-5, f"ln bwd {n} with bf16 dy")
@@ -744,8 +744,8 @@ def test_norms_bf16_storage(kk):
     close(yb, ya, 1e-6, 1e-6, "rms fwd bf16 x")
     dxa, dxb = torch.empty(rows, H, device="cuda"), torch.empty(rows, H, device="cuda", dtype=torch.bfloat16)
     dga, dgb = torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")
-    kk.call("kk_rmsnorm_bwd", dy, xr, gain, ra, dxa, dga, rows, H, 0)
-    kk.call("kk_rmsnorm_bwd", dy, xr.bfloat16(), gain, rb, dxb, dgb, rows, H, 1)
+    kk.call("kk_rmsnorm_bwd", dy, xr, gain, ra, dxa, dga, None, rows, H, 0)
+    kk.call("kk_rmsnorm_bwd", dy, xr.bfloat16(), gain, rb, dxb, dgb, None, rows, H, 1)
     close(dxb, dxa, *BF, "rms dx bf16")
     close(dgb, dga, 1e-4, 1e-5, "rms dgain bf16 x")
 
@@ -845,3 +845,29 @@ def test_memory_path_bf16_storage(kk):
     kk.call("kk_specaug", a, B, T, H, seed, 20, 5, 3, 1, 2, 0)
     kk.call("kk_specaug", b, B, T, H, seed, 20, 5, 3, 1, 2, 1)
     assert torch.equal(b, a.bfloat16()) and bool((b == 0).any())
+
+
+@pytest.mark.parametrize("rows,H", [(333, 512), (4096, 128), (40, 1024)])
+def test_norm_bwd_partials_and_reduce(kk, rows, H):
+    """Column reductions through per-workgroup partial rows + one kk_partials_reduce launch = the atomics path."""
+    g = torch.Generator().manual_seed(rows + H)
+    x, dy = dev(torch.randn(rows, H, generator=g)), dev(torch.randn(rows, H, generator=g))
+    gam, bet = dev(1 + 0.1 * torch.randn(H, generator=g)), dev(0.1 * torch.randn(H, generator=g))
+    y, mean, rstd = torch.empty(rows, H, device="cuda"), torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    kk.call("kk_layernorm_fwd", x, gam, bet, y, mean, rstd, rows, H, 0)
+    nb = kk.load().kk_norm_bwd_blocks(rows, H)
+    ref, got = [], []
+    for use_part in (0, 1):
+        dx = torch.zeros(rows, H, device="cuda")
+        dg, db, dgn = (torch.full((H,), 0.5, device="cuda") for _ in range(3))
+        p_ln, p_rms = torch.full((nb, 2 * H), 9.0, device="cuda"), torch.full((nb, H), 9.0, device="cuda")
+        kk.call("kk_layernorm_bwd", dy, x, gam, mean, rstd, dx, 0, dg, db, p_ln if use_part else None, rows, H, 0)
+        dxr = torch.empty(rows, H, device="cuda")
+        kk.call("kk_rmsnorm_bwd", dy, x, gam, rstd, dxr, dgn, p_rms if use_part else None, rows, H, 0)
+        if use_part:
+            assert float(dg[0]) == 0.5 and float(dgn[0]) == 0.5, "with partials the kernels must not touch the gradient vectors"
+            table = kk.reduce_table([(p_ln, dg, db, nb, 2 * H, H), (p_rms, dgn, None, nb, H, H)], "cuda")
+            kk.call("kk_partials_reduce", table, 2, 2 * H)
+        (got if use_part else ref).extend([dx, dxr, dg, db, dgn])
+    for a, b, n in zip(got, ref, ("ln dx", "rms dx", "dgamma", "dbeta", "dgain")):
+        close(a, b, 2e-4, 1e-4, n)
