@@ -30,8 +30,23 @@ PEAK_HBM_GBS = 8000.0
 # Algorithmic train-step FLOPs per mel frame (SURVEY §8d / BASELINE.md §4: 3 x forward, causal = lower triangle)
 FLOP_PER_FRAME = {(8, 512, 64): 212.4e6, (8, 1024, 128): 241.0e6}
 
-GEMM_SYMBOL = {(0, 0): "gemm_kernel<false,false,{b},{t}> (X.W^T fwd)", (0, 1): "gemm_kernel<false,true,{b},{t}> (dY.W dgrad)",
-               (1, 1): "gemm_kernel<true,true,{b},{t}> (dY^T.X wgrad)", (1, 0): "gemm_kernel<true,false,{b},{t}>"}
+GEMM_ROLE = {(0, 0): "X.W^T fwd", (0, 1): "dY.W dgrad", (1, 1): "dY^T.X wgrad", (1, 0): "X^T.W"}
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")      # written by tools/rocprof_pmc.sh (separate --pmc passes)
+
+
+def gemm_symbol(ta, tb, M, N, K, math_bf16, dtypes):
+    """Name of the kernel instantiation kk_gemm launches for this call (mirrors the dispatch in kk_gemm.hip / kk_gemm16.hip)."""
+    b = lambda v: "true" if v else "false"
+    if math_bf16 and (dtypes & 3) == 3 and (K % 64 == 0 or (ta and tb)):      # DMA-staged bf16 x bf16 core, 64x64 tiles here
+        cd = lambda x, y: -(-x // y)
+        tiles, ktiles = cd(M, 64) * cd(N, 64), cd(K, 64)
+        splits = 1
+        if tiles * 2 <= 768 and not (dtypes & 4):
+            splits = max(1, min(cd(768, tiles), max(ktiles // 2, 1)))
+        ns = 2 if ktiles // splits < 3 else 3
+        return f"gemm16_kernel<{b(ta)},{b(tb)},64,64,{ns}> ({GEMM_ROLE[(ta, tb)]})"
+    tile = 128 if -(-M // 128) * -(-N // 128) >= 512 else 64
+    return f"gemm_kernel<{b(ta)},{b(tb)},{b(math_bf16)},{tile}> ({GEMM_ROLE[(ta, tb)]})"
 
 
 def kernel_table(records, math_bf16: bool):
@@ -42,10 +57,9 @@ def kernel_table(records, math_bf16: bool):
         key = name
         if name == "kk_gemm":
             ta, tb, M, N, K = (int(x) for x in sc[:5])
-            tile = 128 if -(-M // 128) * -(-N // 128) >= 512 else 64          # same rule as kk_gemm
-            key = GEMM_SYMBOL[(ta, tb)].format(b="true" if math_bf16 else "false", t=tile)
-            flops = 2.0 * M * N * K
             dt = int(sc[-1])               # storage bits: A, B, C bf16
+            key = gemm_symbol(ta, tb, M, N, K, math_bf16, dt)
+            flops = 2.0 * M * N * K
             byts = (2.0 if dt & 1 else 4.0) * M * K + (2.0 if dt & 2 else 4.0) * N * K + (2.0 if dt & 4 else 4.0) * M * N
         elif name in ("kk_attn_fwd", "kk_attn_bwd_dq", "kk_attn_bwd_dkv"):
             B, h, Sq, Sk = (int(x) for x in sc[:4])
@@ -163,8 +177,16 @@ def main():
         v = mfma[dom]
         peak = PEAK_BF16_TFLOPS if args.math == "bf16" else PEAK_F32_TFLOPS
         ach = v["flops"] / (v["ms"] * 1e-3) / 1e12
+        traffic, traffic_note = None, None
+        if os.path.exists(PMC_FILE):                 # HBM bytes per launch of this kernel from the committed PMC passes
+            pmc = json.load(open(PMC_FILE))
+            ent = pmc.get("kernels", {}).get(dom.split(" (")[0])
+            if ent and pmc.get("workload") == [B, T, P, args.math]:
+                traffic = round(ent["fetch_bytes_per_launch"] + ent["write_bytes_per_launch"])
+                traffic_note = pmc.get("method")
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": v["launches"] // 2,
+                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_note,
+                "algorithmic_bytes_per_launch": round(v["bytes"] / v["launches"]), "launches_per_step": v["launches"] // 2,
                 "avg_launch_us": round(v["ms"] * 1e3 / v["launches"], 2),
                 "algorithmic_gflop_per_launch": round(v["flops"] / v["launches"] / 1e9, 3)}
         if args.kernel_table:

@@ -31,7 +31,7 @@ struct G16Args {
     void *C;
     int c_bf16;
     int64_t lda, ldb, ldc, ldr, res_mod;
-    int k_per_split, atomic;
+    int k_per_split, atomic, splits, split_major;
     int tiles_m, tiles_n, xcd_swizzle;
     uint32_t a_bytes, b_bytes;
 };
@@ -135,13 +135,27 @@ __global__ __launch_bounds__(256) void gemm16_kernel(G16Args a) {
     constexpr int NPT = OA::NP + OB::NP;                       // DMA instructions per thread per k-tile
     __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
 
-    int tid_lin = blockIdx.x;
-    if (a.xcd_swizzle) {                                        // contiguous run of tiles per XCD (see kk_gemm.hip)
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = tid_lin & 7, in = tid_lin >> 3;
-        tid_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + in;
+    // Workgroup -> (tile, k-slice).  The dispatcher places workgroup i on XCD i % 8 (private 4 MiB L2 each).
+    //  tile-major (default): every XCD sweeps a contiguous run of tiles (n fastest), all k-slices of a tile together;
+    //  split-major (option, split-K with a multiple of 8 slices): slice = i % splits, so XCD x owns the k-slices
+    //    = x (mod 8) of every tile and reads its part of A and B from HBM exactly once.  It cuts FETCH_SIZE of the
+    //    512x512x4096 weight gradients 4.5x, yet the train step is 2 % SLOWER with it (566K vs 579K frames/s): these
+    //    launches are latency-bound, not HBM-bound, and a tile's atomics then come from eight XCDs.  Left off.
+    int tid_lin, ksl;
+    if (a.split_major) {
+        ksl = blockIdx.x % a.splits;
+        tid_lin = blockIdx.x / a.splits;
+    } else {
+        const int ntiles = a.tiles_m * a.tiles_n;
+        tid_lin = blockIdx.x % ntiles;
+        ksl = blockIdx.x / ntiles;
+        if (a.xcd_swizzle) {                                    // bijective for any tile count (see kk_gemm.hip)
+            const int q = ntiles >> 3, r = ntiles & 7, xcd = tid_lin & 7, in = tid_lin >> 3;
+            tid_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + in;
+        }
     }
     const int m0 = (tid_lin / a.tiles_n) * BM, n0 = (tid_lin % a.tiles_n) * BN;
-    const int kbeg = blockIdx.y * a.k_per_split;
+    const int kbeg = ksl * a.k_per_split;
     const int kend = min(a.K, kbeg + a.k_per_split);
     const int nk = (kend - kbeg + BK - 1) / BK, kt0 = kbeg / BK;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -211,7 +225,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(G16Args a) {
     }
     if (nk <= 0) return;
 
-    const bool lead = (blockIdx.y == 0);
+    const bool lead = (ksl == 0);
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -281,7 +295,7 @@ void launch_tile(int ta, int tb, const G16Args &a, dim3 grid, hipStream_t s) {
 // Tile choice (by tile count): at this model's sizes (4096..8192 rows x 512..3072 columns) the 64x64 tile wins on
 // every shape measured inside the train step — the launches are latency-bound, so more, smaller workgroups with more
 // DMAs in flight beat the larger tiles' better bytes-per-flop.
-int g16_thr128 = 4096, g16_thr12864 = 4096, g16_split_target = 768, g16_stages = 3;
+int g16_thr128 = 4096, g16_thr12864 = 4096, g16_split_target = 768, g16_stages = 3, g16_split_major = 0;
 
 }  // namespace
 
@@ -289,7 +303,8 @@ int g16_thr128 = 4096, g16_thr12864 = 4096, g16_split_target = 768, g16_stages =
 void kk_gemm16_tune(int thr128, int thr12864, int split_target) {
     g16_thr128 = thr128;
     g16_thr12864 = thr12864;
-    g16_stages = split_target / 10000 ? split_target / 10000 : 3;        // tools encode stages*10000 + split target
+    g16_stages = (split_target / 10000) % 10 ? (split_target / 10000) % 10 : 3;   // tools encode flags*100000 + stages*10000 + split target
+    g16_split_major = split_target / 100000 ? 1 : 0;                     // 1xxxxx: split-major split-K (A/B comparison)
     g16_split_target = split_target % 10000;
 }
 
@@ -320,8 +335,14 @@ int kk_gemm16_launch(int ta, int tb, int64_t M, int64_t N, int64_t K, float alph
     }
     if (splits > ktiles) splits = ktiles;
     if (splits > 1 && (c_bf16 || !(beta == 1.f || (beta == 0.f && ldc == N)))) splits = 1;
-    const int k_per_split = cd(ktiles, splits) * BK;
+    if (split_k <= 0 && splits >= 6 && g16_split_major) {       // a multiple of 8 slices: one XCD per slice residue class
+        int s8 = ((splits + 4) / 8) * 8;
+        while (s8 > 8 && ktiles / s8 < 2) s8 -= 8;
+        if (ktiles / s8 >= 1) splits = s8;
+    }
+    int k_per_split = cd(ktiles, splits) * BK;
     splits = cd(K, k_per_split);
+    const int split_major = (g16_split_major && splits > 1 && splits % 8 == 0) ? 1 : 0;
     G16Args a;
     a.M = (int)M; a.N = (int)N; a.K = (int)K;
     a.alpha = alpha; a.beta = beta;
@@ -329,6 +350,7 @@ int kk_gemm16_launch(int ta, int tb, int64_t M, int64_t N, int64_t K, float alph
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.res_mod = res_mod;
     a.k_per_split = k_per_split;
     a.atomic = splits > 1 ? 1 : 0;
+    a.splits = splits; a.split_major = split_major;
     a.tiles_m = cd(M, BM); a.tiles_n = cd(N, BN);
     a.xcd_swizzle = xcd_swizzle;
     a.a_bytes = (uint32_t)(((ta ? (K - 1) * lda + M : (M - 1) * lda + K)) * 2);
@@ -337,7 +359,7 @@ int kk_gemm16_launch(int ta, int tb, int64_t M, int64_t N, int64_t K, float alph
         hipError_t e = hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), s);
         if (e != hipSuccess) return kk_fail((int)e, "kk_gemm: memset: %s", hipGetErrorString(e));
     }
-    dim3 grid(a.tiles_m * a.tiles_n, splits);
+    dim3 grid(a.tiles_m * a.tiles_n * splits);
     const int ns = ktiles / splits < 3 ? 2 : g16_stages;        // (a short reduction gains nothing from depth)
     if (BM == 128 && BN == 128) launch_tile<128, 128, 2>(ta, tb, a, grid, s);
     else if (BM == 128) { if (ns >= 3) launch_tile<128, 64, 3>(ta, tb, a, grid, s); else launch_tile<128, 64, 2>(ta, tb, a, grid, s); }

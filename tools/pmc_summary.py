@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""profiles/r01_pmc_hbm_traffic.json from the two rocprofv3 --pmc passes (tools/rocprof_pmc.sh).
+
+FETCH_SIZE and WRITE_SIZE are reported in KiB-like units of 1000 B by rocprofv3 on this image ("KB"); on gfx950 FETCH_SIZE
+counts 64 B per 128-B request and is doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is used as reported (it matches
+the AdamW kernel's algorithmic 0.89 GB of writes to 1 %).  Kernel names are written the way bench.py names them."""
+import json
+import re
+import sys
+
+raw = json.load(open(sys.argv[1]))
+B, T, P, math = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+out = {"workload": [B, T, P, math], "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on "
+       "`bench.py --no-graph --steps 2 --warmup 2`; FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request), units of 1000 B", "kernels": {}}
+for mangled, c in raw.items():
+    m = re.search(r"gemm16_kernelILb(\d)ELb(\d)ELi(\d+)ELi(\d+)ELi(\d+)E", mangled)
+    if m:
+        b = lambda v: "true" if v == "1" else "false"
+        name = f"gemm16_kernel<{b(m.group(1))},{b(m.group(2))},{m.group(3)},{m.group(4)},{m.group(5)}>"
+    else:
+        m = re.search(r"_GLOBAL__N_1\d+([a-z_0-9]+?)(I|E)", mangled)
+        name = m.group(1) if m else mangled
+        name = {"attn_fwd_kernel": "kk_attn_fwd", "attn_bwd_dq_kernel": "kk_attn_bwd_dq", "attn_bwd_dkv_kernel": "kk_attn_bwd_dkv"}.get(name, name)
+    f, w = c.get("FETCH_SIZE", [0, 0.0]), c.get("WRITE_SIZE", [0, 0.0])
+    n = max(f[0], w[0], 1)
+    e = out["kernels"].setdefault(name, {"dispatches": 0, "fetch": 0.0, "write": 0.0})
+    e["dispatches"] += n
+    e["fetch"] += 2.0 * f[1] * 1000.0
+    e["write"] += w[1] * 1000.0
+for e in out["kernels"].values():
+    e["fetch_bytes_per_launch"] = e.pop("fetch") / e["dispatches"]
+    e["write_bytes_per_launch"] = e.pop("write") / e["dispatches"]
+json.dump(out, open(sys.argv[6], "w"), indent=1)
+print(json.dumps({k: v for k, v in list(out["kernels"].items())[:4]}, indent=1))
