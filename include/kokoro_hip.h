@@ -198,6 +198,10 @@ int kk_losses_fwd(const float *mel_pred, const float *mel_tgt, const float *dur_
                   const int64_t *mel_len, const int64_t *ph_len, int B, int T, int P, int M,
                   const KkLossCfg *cfg, const int64_t *max_dur /* device scalar or null */, double *acc,
                   float *losses, float *coef, void *stream);
+/* Recompute losses[6] and coef[5] from acc (see kk_losses_fwd) — used by data-parallel runs after acc has been
+ * SUM-reduced and *max_dur MAX-reduced over the ranks: normalisers become the global valid-element counts. */
+int kk_losses_finalize(const double *acc, const KkLossCfg *cfg, const int64_t *max_dur, int T, float *losses,
+                       float *coef, void *stream);
 int kk_losses_bwd(const float *mel_pred, const float *mel_tgt, const float *dur_pred, const int64_t *dur,
                   const float *stop_logit, const float *stop_tgt, const float *pitch_pred,
                   const float *pitch_tgt, const float *energy_pred, const float *energy_tgt,

@@ -96,16 +96,35 @@ def split_indices(n: int, val_split: float):
     return idx[:k], idx[k:]
 
 
+def shard_steps(global_batches: List[List[int]], rank: int, world: int) -> List[List[int]]:
+    """Step s of a data-parallel run = batches [s*world, (s+1)*world) of the deterministic global list, rank r takes the
+    r-th.  The ragged tail (< world batches) is dropped so every rank runs the same number of steps —
+    a rank with one step fewer would leave the others waiting in the gradient all-reduce."""
+    if world <= 1:
+        return global_batches
+    n = len(global_batches) // world * world
+    return global_batches[:n][rank::world]
+
+
+def step_groups(global_batches: List[List[int]], world: int) -> List[List[List[int]]]:
+    """The `world` batches that make up each data-parallel step (every rank can enumerate them: no communication)."""
+    world = max(1, world)
+    n = len(global_batches) // world * world
+    return [global_batches[i:i + world] for i in range(0, n, world)]
+
+
 class FixedBatchSampler:
     def __init__(self, n: int, batch_size: int, shuffle: bool = True, rank: int = 0, world: int = 1, seed: int = 0):
         self.n, self.bs, self.shuffle, self.rank, self.world, self.seed, self.epoch = n, batch_size, shuffle, rank, world, seed, 0
 
-    def batches(self) -> List[List[int]]:
+    def global_batches(self) -> List[List[int]]:
         order = list(range(self.n))
         if self.shuffle:
             random.Random(self.seed + self.epoch).shuffle(order)
-        bl = [order[i:i + self.bs] for i in range(0, self.n, self.bs)]
-        return bl[self.rank::self.world] if self.world > 1 else bl
+        return [order[i:i + self.bs] for i in range(0, self.n, self.bs)]
+
+    def batches(self) -> List[List[int]]:
+        return shard_steps(self.global_batches(), self.rank, self.world)
 
     def __len__(self) -> int:
         return len(self.batches())
@@ -122,7 +141,7 @@ class FrameBudgetBatchSampler:
         self.ds, self.max_frames, self.min_bs, self.max_bs = dataset, max_frames, min_batch_size, max_batch_size
         self.shuffle, self.rank, self.world, self.seed, self.epoch = shuffle, rank, world, seed, 0
 
-    def batches(self) -> List[List[int]]:
+    def global_batches(self) -> List[List[int]]:
         order = sorted(range(len(self.ds)), key=lambda i: self.ds.samples[i]["audio_length"])
         out: List[List[int]] = []
         cur: List[int] = []
@@ -136,7 +155,10 @@ class FrameBudgetBatchSampler:
             out.append(cur)
         if self.shuffle:
             random.Random(self.seed + self.epoch).shuffle(out)
-        return out[self.rank::self.world] if self.world > 1 else out
+        return out
+
+    def batches(self) -> List[List[int]]:
+        return shard_steps(self.global_batches(), self.rank, self.world)
 
     def __len__(self) -> int:
         return len(self.batches())

@@ -15,7 +15,8 @@ from typing import Dict, Optional
 
 import torch
 
-from kokoro.data.cached import (CachedFeatureDataset, FixedBatchSampler, FrameBudgetBatchSampler, collate_fn, split_indices)
+from kokoro.data.cached import (CachedFeatureDataset, FixedBatchSampler, FrameBudgetBatchSampler, collate_fn, split_indices,
+                                step_groups)
 from kokoro.training import checkpoint as ckpt
 from kokoro_ruslan_amd import dp, lib as kk
 from kokoro_ruslan_amd.spec import ModelDims, StepHyper
@@ -79,7 +80,11 @@ class KokoroTrainer:
         math_mode = "bf16" if (config.use_mixed_precision and config.mixed_precision_dtype == "bfloat16") else "f32"
         self.engine = KokoroEngine(dims, hp, math_mode=math_mode, total_steps=config.num_epochs * steps_per_epoch, seed=0)
         self.sync = dp.GradSync(self.world)
-        self.engine.dp_loss_scale = self.sync.loss_scale
+        if self.world > 1:
+            # real data = ragged shards: normalise every loss by the GLOBAL valid-element counts (dp.LossSync) instead of
+            # pre-scaling per-rank means by 1/world, and feed the batch-shape heuristics the global-batch mel length
+            self.engine.loss_sync = dp.LossSync(self.world)
+            self.engine.dp_loss_scale = 1.0
         self.start_epoch, self.best_val, self.best_epoch = 0, float("inf"), -1
         logger.info("engine ready: %d params, %s math, %d train / %d val utterances, %d batches/epoch, world %d",
                     sum(math.prod(s) for s in self.engine.arena.shapes.values()), math_mode, len(self.dataset),
@@ -93,9 +98,13 @@ class KokoroTrainer:
         cfg, G = self.config, max(1, self.config.gradient_accumulation_steps)
         self.sampler.epoch = epoch
         batches = self.sampler.batches()
+        groups = step_groups(self.sampler.global_batches(), self.world) if self.world > 1 else None
         acc, losses, n = 0, torch.zeros(6, device=self.engine.device), 0
         for bi, idxs in enumerate(batches):
             batch = cap_batch(self._to_device(collate_fn([self.dataset[i] for i in idxs])))
+            if groups is not None:      # longest (capped) mel length among this step's batches on all ranks
+                self.engine.global_mel_length = min(2000, max(min(self.dataset.samples[i]["audio_length"], self.dataset.max_seq_length)
+                                                              for g in groups[bi] for i in g))
             div = effective_accumulation_divisor(G, acc, bi, len(batches))
             boundary = (acc + 1 >= G) or (bi == len(batches) - 1)
             self.engine.micro_in_cycle = acc

@@ -164,6 +164,17 @@ extern "C" int kk_losses_fwd(const float *mel_pred, const float *mel_tgt, const 
     return 0;
 }
 
+// Finish the scalars again from `acc` — data parallel: after the 5 sums + 5 counts have been SUM-all-reduced (and
+// max_dur MAX-all-reduced), every rank normalises by the GLOBAL valid-element counts, so the summed gradients are the
+// global-batch gradients also when the shards are ragged.  T = the global-batch mel length.
+extern "C" int kk_losses_finalize(const double *acc, const KkLossCfg *cfg, const int64_t *max_dur, int T, float *losses,
+                                  float *coef, void *stream) {
+    KK_REQUIRE(acc && cfg && losses && coef && T > 0, "kk_losses_finalize: bad args");
+    hipLaunchKernelGGL(losses_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, acc, *cfg, max_dur, T, losses, coef);
+    KK_LAUNCH_CHECK("kk_losses_finalize");
+    return 0;
+}
+
 extern "C" int kk_losses_bwd(const float *mel_pred, const float *mel_tgt, const float *dur_pred, const int64_t *dur,
                              const float *stop_logit, const float *stop_tgt, const float *pitch_pred,
                              const float *pitch_tgt, const float *energy_pred, const float *energy_tgt,

@@ -4,9 +4,11 @@ The reference has no distributed code; the contract here is 
 the global batch".  Each rank runs forward+backward on its shard with the loss scaled by 1/world, the flat
 gradient arena is SUM-all-reduced, and every rank then runs the identical optimizer pass on the identical reduced
 gradients (pre-clip, norm, clip, AdamW, EMA are deterministic functions of them), so replicas stay in step without
-any further collective.  Exact for batches whose ranks hold the same number of valid loss elements (the fixed-shape
-configurations); for ragged shards the per-loss valid counts differ per rank and the result is the mean of per-rank
-means (documented in DESIGN.md §multi-GPU; the count exchange is listed as next work).
+any further collective.  That is exact when every rank holds the same number of valid loss elements (the fixed-shape
+configurations, bench.py).  For ragged shards `LossSync` additionally SUM-reduces the 5 loss sums + 5 valid-element
+counts and MAX-reduces the batch's largest duration between the loss forward and the loss backward (80 + 8 bytes):
+every rank then normalises by the GLOBAL counts (and the loss is not pre-scaled by 1/world), so the summed gradients
+are the global-batch gradients, and the batch-shape heuristics of trainer.py:2218-2242 see the same inputs everywhere.
 
 The functions take plain tensors so the same code runs under `gloo` on CPU (tests) and `nccl` (= RCCL) on MI355X.
 """
@@ -67,6 +69,19 @@ class GradSync:
         n = flat_grad.numel()
         for o in range(0, n, self.bucket):
             dist.all_reduce(flat_grad[o:min(n, o + self.bucket)], op=dist.ReduceOp.SUM)
+
+
+class LossSync:
+    """engine.loss_sync hook: global loss normalisers for ragged data-parallel shards (collective (2))."""
+
+    def __init__(self, world: int):
+        self.world = world
+
+    def __call__(self, acc: torch.Tensor, max_dur: torch.Tensor) -> None:
+        if self.world == 1:
+            return
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)        # 5 numerators, 5 valid-element counts (fp64)
+        dist.all_reduce(max_dur, op=dist.ReduceOp.MAX)    # adaptive loss scale / clip heuristics: same inputs on every rank
 
 
 def all_max(x: torch.Tensor) -> torch.Tensor:

@@ -142,6 +142,11 @@ class KokoroEngine:
         self.loss_coef = f32(5)
         self.micro_in_cycle = 0
         self.dp_loss_scale = 1.0                    # 1/world in data-parallel runs (dp.GradSync.loss_scale)
+        # Data parallel with ragged shards: callable(acc[10] f64, max_dur[1] i64) that SUM / MAX all-reduces them in
+        # place between the loss forward and the loss backward (dp.LossSync); the losses are then re-finalised with the
+        # global valid-element counts and dp_loss_scale stays 1.  None = per-rank normalisers (exact for equal shards).
+        self.loss_sync = None
+        self.global_mel_length = None               # batch-max T over all ranks (adaptive loss scale / clip heuristics)
         # dropout / DropPath / SpecAugment: off = the parity configuration (reference with p = 0)
         self.train_dropout = False
         # Second HIP stream: the parts of a step that do not depend on the decoder (pitch/energy predictors; after the
@@ -628,6 +633,10 @@ class KokoroEngine:
         largs = (mel_pred, mel, dur_pred, dur, stop, batch["stop_token_targets"], pitch_pred, batch["pitches"], energy_pred,
                  batch["energies"], batch["mel_lengths"], batch["phoneme_lengths"], B, T, Pn, M, lcfg)
         kk.call("kk_losses_fwd", *largs, self.max_dur, self.loss_acc, self.losses, self.loss_coef)
+        if self.loss_sync is not None:
+            self.loss_sync(self.loss_acc, self.max_dur)
+            kk.call("kk_losses_finalize", self.loss_acc, lcfg, self.max_dur, int(self.global_mel_length or T), self.losses,
+                    self.loss_coef)
         out = {"losses": self.losses, "mel": mel_pred, "log_dur": dur_pred, "stop": stop, "pitch": pitch_pred,
                "energy": energy_pred, "lr_idx": idx, "lr_lens": lens, "memory": memory.view(B, T, H)}
         if not backward:
@@ -745,7 +754,7 @@ class KokoroEngine:
         if boundary if boundary is not None else self.micro_in_cycle >= G:
             if grad_sync is not None:
                 grad_sync(self.arena.g)              # data parallel: SUM over ranks (dp.GradSync)
-            self.optimizer_step(batch["mel_specs"].shape[1])
+            self.optimizer_step(int(self.global_mel_length or batch["mel_specs"].shape[1]))
             self.micro_in_cycle = 0
         return out["losses"]
 
@@ -757,6 +766,9 @@ class KokoroEngine:
         B, T = batch["mel_specs"].shape[:2]
         key = (B, T, batch["phoneme_indices"].shape[1])
         ent = self._graphs.get(key)
+        if self.loss_sync is not None:
+            raise RuntimeError("train_step_graphed: the loss-count exchange (loss_sync) runs between kernels of the step; "
+                               "use train_step for ragged data-parallel shards")
         if ent is None:                               # first sight of a shape: eager (allocates the workspaces)
             static = {k: v.clone() for k, v in batch.items()}
             self._graphs[key] = {"static": static, "fb": None, "opt": None}

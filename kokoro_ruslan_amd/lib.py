@@ -94,6 +94,7 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_ids_eq_zero": [_P, _P, _L, _P],
     "kk_shift_right": [_P, _P, _I, _I, _I, _P],
     "kk_losses_fwd": [_P] * 12 + [_I, _I, _I, _I, C.POINTER(KkLossCfg), _P, _P, _P, _P, _P],
+    "kk_losses_finalize": [_P, C.POINTER(KkLossCfg), _P, _I, _P, _P, _P],
     "kk_losses_bwd": [_P] * 12 + [_I, _I, _I, _I, C.POINTER(KkLossCfg), _P, _P, _P, _P, _P, _P, _P],
     "kk_seg_sumsq": [_P, _P, _L, _P, _I, _P],
     "kk_opt_prepare": [_P, _P, _P, _P, _I, _P, C.POINTER(KkOptCfg), _P, _P, _P, _P, _P, _P],

@@ -547,6 +547,38 @@ def _masked_mean(v: Tensor, m: Tensor) -> Tensor:
     return v[m].mean() if bool(m.any()) else torch.tensor(0.0)
 
 
+def loss_sums(out: Dict[str, Tensor], batch: Dict[str, Tensor], hp: StepHyper) -> Tuple[List[Tensor], List[Tensor]]:
+    """The five loss terms as (sum over valid elements, number of valid elements) in the order mel, dur, stop, pitch,
+    energy — each reference term is such a masked mean (losses.py:60-199).  Data-parallel runs reduce these over the
+    ranks and normalise by the global counts (kk_losses_finalize)."""
+    mel_t = batch["mel_specs"]
+    T, Pn = mel_t.size(1), batch["phoneme_durations"].size(1)
+    mel_mask = torch.arange(T).unsqueeze(0) < batch["mel_lengths"].unsqueeze(1)
+    ph_mask = torch.arange(Pn).unsqueeze(0) < batch["phoneme_lengths"].unsqueeze(1)
+    l1 = (out["mel"] - mel_t).abs()
+    m3 = mel_mask.unsqueeze(-1).expand_as(l1)
+    tgt_dur = torch.log(batch["phoneme_durations"].float() + 1.0)
+    ld = _huber(out["log_dur"], tgt_dur, hp.duration_huber_delta)
+    dv = ph_mask & (batch["phoneme_durations"] > 0)
+    z, y = out["stop"], batch["stop_token_targets"]
+    # BCEWithLogits(pos_weight): -(pw*y*logσ(z) + (1-y)*logσ(-z))
+    ls = -(hp.stop_token_pos_weight * y * F.logsigmoid(z) + (1 - y) * F.logsigmoid(-z))
+    lp = _huber(out["pitch"][:, :T], batch["pitches"][:, :T], hp.pitch_huber_delta)
+    le = _huber(out["energy"][:, :T], batch["energies"][:, :T], hp.energy_huber_delta)
+    terms = [(l1, m3), (ld, dv), (ls, mel_mask), (lp, mel_mask), (le, mel_mask)]
+    return [t[m].sum() for t, m in terms], [m.sum().to(torch.float64) for _, m in terms]
+
+
+def losses_from_sums(sums: List[Tensor], counts: List[Tensor], hp: StepHyper) -> Tuple[Tensor, ...]:
+    """(total, mel, dur, stop, pitch, energy) from (possibly globally reduced) sums and counts: clamps and weights of
+    losses.py:200-216."""
+    caps = (100.0, 100.0, 100.0, 10.0, 10.0)
+    w = (1.0, hp.duration_loss_weight, hp.stop_token_loss_weight, hp.pitch_loss_weight, hp.energy_loss_weight)
+    means = [(s / c.to(s.dtype) if float(c) > 0 else s * 0.0).clamp(max=cap) for s, c, cap in zip(sums, counts, caps)]
+    total = sum(m * wk for m, wk in zip(means, w))
+    return (total, *means)
+
+
 def losses(out: Dict[str, Tensor], batch: Dict[str, Tensor], hp: StepHyper
            ) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor, Tensor]:
     """(total, mel, dur, stop, pitch, energy)."""

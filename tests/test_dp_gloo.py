@@ -56,6 +56,78 @@ def test_dp_two_ranks_equal_global_batch():
     assert mx == 1.0
 
 
+def _ragged(batch, seed):
+    """Per-sample valid lengths (as real, padded batches have): different valid-element counts per shard."""
+    g = torch.Generator().manual_seed(seed)
+    b = {k: v.clone() for k, v in batch.items()}
+    B, T = b["mel_specs"].shape[:2]
+    P = b["phoneme_indices"].shape[1]
+    b["mel_lengths"] = torch.randint(T // 3, T + 1, (B,), generator=g)
+    b["phoneme_lengths"] = torch.randint(2, P + 1, (B,), generator=g)
+    b["mel_lengths"][0], b["phoneme_lengths"][0] = T, P
+    return b
+
+
+def _worker_ragged(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from kokoro_ruslan_amd import dp
+    from oracle import kokoro_oracle as O
+    dp.init("gloo")
+    d = O.ModelDims(vocab=59, mel=20, hidden=128, heads=2, enc_layers=1, dec_layers=1, enc_ff=96, dec_ff=96, var_filter=32,
+                    var_bins=16, max_len=300)
+    P, Bf, hp = O.init_params(d, 7), O.make_buffers(d), O.StepHyper()
+    glob = _ragged(O.synthetic_batch(4, 32, 6, d, seed=21), 5)
+    shard = dp.shard_batch(glob, rank, world)
+    Pg = {n: p.detach().clone().requires_grad_(True) for n, p in P.items()}
+    sums, counts = O.loss_sums(O.forward(Pg, Bf, shard, d, None), shard, hp)
+    acc = torch.stack([s.detach().double() for s in sums] + [c.double() for c in counts])        # the engine's loss_acc
+    local_counts = acc[5:].clone()
+    max_dur = shard["phoneme_durations"].max().reshape(1)
+    dp.LossSync(world)(acc, max_dur)                                    # global sums / counts, global max duration
+    total = O.losses_from_sums(sums, list(acc[5:]), hp)[0]              # local sums over GLOBAL counts, no 1/world
+    total.backward()
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in Pg.values()])
+    dp.GradSync(world)(flat)
+    if rank == 0:
+        Gf, lf, _ = O.grads_of(P, Bf, glob, d, hp)
+        ref = torch.cat([g.reshape(-1) for g in Gf.values()])
+        glob_losses = O.losses_from_sums([a for a in acc[:5].float()], list(acc[5:]), hp)
+        q.put((float((flat - ref).abs().max()), float(ref.abs().max()), [float(x) for x in glob_losses], [float(x) for x in lf],
+               bool((local_counts != acc[5:] / world).any()), int(max_dur), int(glob["phoneme_durations"].max())))
+    dist.destroy_process_group()
+
+
+def test_dp_ragged_shards_use_global_loss_normalisers():
+    """Ragged shards: SUM of (local sums / GLOBAL counts) gradients == global-batch gradients, and the reduced sums give
+    the global-batch losses (what kk_losses_finalize computes from the reduced accumulator on the GPU)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ragged, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    err, scale, gl, lf, ragged, md, md_ref = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ragged, "the shards must really have different valid counts"
+    assert err <= 2e-5 * max(scale, 1.0), (err, scale)
+    np.testing.assert_allclose(gl, lf, rtol=1e-5, atol=1e-6)
+    assert md == md_ref
+
+
+def test_sampler_steps_are_equal_across_ranks():
+    from kokoro.data.cached import FixedBatchSampler, step_groups
+    for world in (2, 3, 8):
+        per_rank = [FixedBatchSampler(103, 4, True, r, world, seed=1).batches() for r in range(world)]
+        assert len({len(b) for b in per_rank}) == 1, "every rank must run the same number of steps"
+        groups = step_groups(FixedBatchSampler(103, 4, True, 0, world, seed=1).global_batches(), world)
+        assert len(groups) == len(per_rank[0])
+        for s, g in enumerate(groups):
+            assert [per_rank[r][s] for r in range(world)] == g
+
+
 def test_shard_batch_and_env():
     from kokoro_ruslan_amd import dp
     b = {"mel_specs": torch.arange(8.0).view(8, 1, 1), "x": torch.arange(8)}

@@ -276,3 +276,42 @@ def test_training_dropout_is_deterministic_per_seed_and_gradients_are_consistent
         report.append((n, analytic, (lp - lm) / (2 * eps)))
     bad = [(n, a_, f_) for n, a_, f_ in report if abs(f_ - a_) > 0.1 * abs(a_) + 0.02]
     assert not bad, report
+
+
+def test_global_loss_normalisers_two_shards_on_one_gpu(eng_mod, golden_dir):
+    """Data parallel with ragged shards, emulated on one GPU: each shard's backward uses the GLOBAL loss sums/counts
+    (engine.loss_sync + kk_losses_finalize), gradients are summed — the result is the global-batch gradient."""
+    fx, d, _, P = _load(golden_dir, "tiny_full")
+    glob = O.synthetic_batch(4, 40, 6, d, seed=3)
+    g = torch.Generator().manual_seed(9)
+    glob["mel_lengths"] = torch.tensor([40, 17, 33, 25])
+    glob["phoneme_lengths"] = torch.tensor([6, 3, 5, 4])
+    shards = [{k: v[i:i + 2].contiguous() for k, v in glob.items()} for i in (0, 2)]
+    e = _engine(eng_mod, d, P)
+    accs, mds = [], []
+    for sh in shards:                                   # what the ranks' loss forward kernels accumulate
+        e.forward_backward(_cuda(sh), backward=False)
+        accs.append(e.loss_acc.clone())
+        mds.append(e.max_dur.clone())
+    assert not torch.equal(accs[0][5:], accs[1][5:]), "shards must have different valid counts"
+    g_acc, g_md = accs[0] + accs[1], torch.maximum(mds[0], mds[1])
+
+    def fake_all_reduce(acc, md):                      # stands in for dp.LossSync over 2 ranks
+        acc.copy_(g_acc)
+        md.copy_(g_md)
+    e.loss_sync, e.dp_loss_scale = fake_all_reduce, 1.0
+    e.zero_grad()
+    for sh in shards:
+        out = e.forward_backward(_cuda(sh))
+    summed = e.arena.g.clone()
+    global_losses = out["losses"].clone()               # re-finalised from the reduced accumulator = global-batch losses
+    e.loss_sync = None
+    e.zero_grad()
+    ref_out = e.forward_backward(_cuda(glob))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(global_losses, ref_out["losses"], rtol=2e-5, atol=1e-6)
+    ref = e.arena.g
+    assert float((summed - ref).abs().max()) <= 3e-5 * max(1.0, float(ref.abs().max()))
+    with pytest.raises(RuntimeError):
+        e.loss_sync = fake_all_reduce
+        e.train_step_graphed(_cuda(glob))
