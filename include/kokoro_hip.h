@@ -112,10 +112,13 @@ int kk_rmsnorm_bwd(const float *dy, const float *x, const float *gain, const flo
 int kk_headnorm_rope_fwd(const float *x, int64_t ldx, float *y, int64_t ldy, int64_t rows, int heads, int S,
                          int parts, const float *gain0, const float *gain1, const float *gain2, int rope_mask,
                          const float *cos_t, const float *sin_t, int io_bf16, void *stream);
+/* partials (optional): [parts][kk_headnorm_bwd_blocks(rows,heads)][64] partial gain gradients instead of atomics into
+ * dgain_j; sum them with kk_partials_reduce (one descriptor per part, ncols = 64). */
+int kk_headnorm_bwd_blocks(int64_t rows, int heads);
 int kk_headnorm_rope_bwd(const float *dy, int64_t lddy, const float *x, int64_t ldx, float *dx, int64_t lddx,
                          int64_t rows, int heads, int S, int parts, const float *gain0, const float *gain1,
-                         const float *gain2, float *dgain0, float *dgain1, float *dgain2, int rope_mask,
-                         const float *cos_t, const float *sin_t, int io_bf16, void *stream);
+                         const float *gain2, float *dgain0, float *dgain1, float *dgain2, float *partials,
+                         int rope_mask, const float *cos_t, const float *sin_t, int io_bf16, void *stream);
 
 /* ---- GLU feed-forward gate (transformers.py:107-108; exact-erf GELU): g = gelu(h[:, :F]) * h[:, F:] ---- */
 int kk_glu_fwd(const float *h, float *g, int64_t rows, int F, const uint32_t *seed, uint32_t site, float p,

@@ -295,6 +295,7 @@ struct HeadNormArgs {
     void *y, *dx;
     const float *gain[3];
     float *dgain[3];
+    float *partials;             // optional [parts][gridDim.x][64] partial gain gradients (see layernorm_bwd_kernel)
     int64_t ldx, ldy, lddy, lddx, npairs;   // npairs = rows * heads (per part)
     int heads, S, rope_mask;
 };
@@ -384,7 +385,8 @@ __global__ __launch_bounds__(256) void headnorm_rope_bwd_kernel(HeadNormArgs a) 
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) s += red[i][threadIdx.x];
-        atomicAdd(&a.dgain[part][threadIdx.x], s);
+        if (a.partials) a.partials[((int64_t)part * gridDim.x + blockIdx.x) * 64 + threadIdx.x] = s;
+        else atomicAdd(&a.dgain[part][threadIdx.x], s);
     }
 }
 
@@ -625,10 +627,16 @@ extern "C" int kk_headnorm_rope_fwd(const float *x, int64_t ldx, float *y, int64
     return 0;
 }
 
+// workgroups per part (= rows of each [blocks][64] partial matrix) that kk_headnorm_rope_bwd launches
+extern "C" int kk_headnorm_bwd_blocks(int64_t rows, int heads) {
+    int blocks = kk_cdiv(rows * heads, 16 * 4 * 2);       // two trips of 4 vectors per 16-lane group
+    return blocks > 512 ? 512 : (blocks < 1 ? 1 : blocks);
+}
+
 extern "C" int kk_headnorm_rope_bwd(const float *dy, int64_t lddy, const float *x, int64_t ldx, float *dx, int64_t lddx,
                                     int64_t rows, int heads, int S, int parts, const float *gain0, const float *gain1,
-                                    const float *gain2, float *dgain0, float *dgain1, float *dgain2, int rope_mask,
-                                    const float *cos_t, const float *sin_t, int io_bf16, void *stream) {
+                                    const float *gain2, float *dgain0, float *dgain1, float *dgain2, float *partials,
+                                    int rope_mask, const float *cos_t, const float *sin_t, int io_bf16, void *stream) {
     KK_REQUIRE(rows > 0 && heads > 0 && S > 0 && parts >= 1 && parts <= 3 && gain0 && dgain0, "kk_headnorm_rope_bwd: bad shape");
     KK_REQUIRE(rope_mask == 0 || (cos_t && sin_t), "kk_headnorm_rope_bwd: RoPE needs cos/sin tables");
     KK_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "kk_headnorm_rope_bwd: strides must be multiples of 4");
@@ -636,8 +644,8 @@ extern "C" int kk_headnorm_rope_bwd(const float *dy, int64_t lddy, const float *
     a.x = x; a.dy = dy; a.dx = dx; a.cos_t = cos_t; a.sin_t = sin_t;
     a.gain[0] = gain0; a.gain[1] = gain1; a.gain[2] = gain2; a.dgain[0] = dgain0; a.dgain[1] = dgain1; a.dgain[2] = dgain2;
     a.ldx = ldx; a.lddy = lddy; a.lddx = lddx; a.npairs = rows * heads; a.heads = heads; a.S = S; a.rope_mask = rope_mask;
-    int blocks = kk_cdiv(a.npairs, 16 * 4 * 2);           // two trips of 4 vectors per 16-lane group
-    blocks = blocks > 512 ? 512 : (blocks < 1 ? 1 : blocks);
+    a.partials = partials;
+    const int blocks = kk_headnorm_bwd_blocks(rows, heads);
     if (io_bf16) hipLaunchKernelGGL(headnorm_rope_bwd_kernel<__bf16>, dim3(blocks, parts), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(headnorm_rope_bwd_kernel<float>, dim3(blocks, parts), dim3(256), 0, (hipStream_t)stream, a);
     KK_LAUNCH_CHECK("kk_headnorm_rope_bwd");

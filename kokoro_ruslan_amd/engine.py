@@ -307,6 +307,14 @@ class KokoroEngine:
         self._reduce_list.append((part, dst0, dst1, nb, ncols, split))
         return part
 
+    def _headnorm_partials(self, key, rows, dgains):
+        """[parts][blocks][64] partial gain gradients of one head-norm backward launch, one reduce descriptor per part."""
+        nb = kk.load().kk_headnorm_bwd_blocks(rows, self.dims.heads)
+        part = self._buf(key + ".hpart", len(dgains), nb, 64)
+        for j, dg in enumerate(dgains):
+            self._reduce_list.append((part[j], dg, None, nb, 64, 64))
+        return part
+
     def _ln_bwd(self, key, dy, x, prefix, dx, accumulate):
         P, G = self.arena.P, self.arena.G
         rows, H = x.shape
@@ -423,7 +431,7 @@ class KokoroEngine:
             kk.call("kk_attn_bwd_dkv", q_n, k_n, v_n, dctx, lse, delta, dk_n, dv_n, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H,
                     ld(dk_n), ld(dv_n), key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16)
             kk.call("kk_headnorm_rope_bwd", dn, 3 * H, raw, 3 * H, draw, 3 * H, Nq, h, Sq, 3, gq, gk, gv, dgq, dgk, dgv,
-                    3 if rope else 0, cos, sin, i16)
+                    self._headnorm_partials(key, Nq, (dgq, dgk, dgv)), 3 if rope else 0, cos, sin, i16)
             self._wgrad(draw, xq, a.fused(a.g, prefix + ".w_q.weight", 3))
             self._dgrad(draw, self._Wf(prefix + ".w_q.weight", 3), d_xq)
             return
@@ -433,12 +441,13 @@ class KokoroEngine:
                 kk.call("kk_attn_bwd_dkv", q_n, k_n, v_n, dctx, lse, delta, dkv_n, dkv_n[:, H:], B, h, Sq, Sk, ld(q_n), ld(k_n),
                         ld(v_n), H, 2 * H, 2 * H, key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16)
                 kk.call("kk_headnorm_rope_bwd", dkv_n, 2 * H, kv_raw, 2 * H, dkv_raw, 2 * H, Nk, h, Sk, 2, gk, gv, None, dgk, dgv,
-                        None, 0, None, None, i16)
+                        None, self._headnorm_partials(key + ".kv", Nk, (dgk, dgv)), 0, None, None, i16)
                 self._wgrad(dkv_raw, xkv, a.fused(a.g, prefix + ".w_k.weight", 2))
                 self._dgrad(dkv_raw, self._Wf(prefix + ".w_k.weight", 2), d_xkv, beta=d_xkv_beta)
         kk.call("kk_attn_bwd_dq", q_n, k_n, v_n, dctx, lse, delta, dq_n, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H, ld(dq_n),
                 key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16)
-        kk.call("kk_headnorm_rope_bwd", dq_n, H, q_raw, H, dq_raw, H, Nq, h, Sq, 1, gq, None, None, dgq, None, None, 0, None, None, i16)
+        kk.call("kk_headnorm_rope_bwd", dq_n, H, q_raw, H, dq_raw, H, Nq, h, Sq, 1, gq, None, None, dgq, None, None,
+                self._headnorm_partials(key + ".q", Nq, (dgq,)), 0, None, None, i16)
         self._wgrad(dq_raw, xq, G[prefix + ".w_q.weight"])
         self._dgrad(dq_raw, self._W(prefix + ".w_q.weight"), d_xq)
 

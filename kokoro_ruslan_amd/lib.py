@@ -72,7 +72,8 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_rmsnorm_fwd": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
     "kk_rmsnorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "kk_headnorm_rope_fwd": [_P, _L, _P, _L, _L, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P],
-    "kk_headnorm_rope_bwd": [_P, _L, _P, _L, _P, _L, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P],
+    "kk_headnorm_rope_bwd": [_P, _L, _P, _L, _P, _L, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P],
+    "kk_headnorm_bwd_blocks": [_L, _I],
     "kk_glu_fwd": [_P, _P, _L, _I, _P, _U, _F, _I, _P],
     "kk_glu_bwd": [_P, _P, _P, _L, _I, _P, _U, _F, _I, _P],
     "kk_embed_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _U, _F, _P],

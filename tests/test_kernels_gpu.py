@@ -284,7 +284,7 @@ def test_headnorm_rope_fused_qkv(kk, rope):
     close(y, ref, 2e-5, 2e-5, "headnorm fwd")
     dx, dg = torch.zeros(B * S, 3 * H, device="cuda"), [torch.zeros(64, device="cuda") for _ in range(3)]
     kk.call("kk_headnorm_rope_bwd", dev(dy), 3 * H, xd, 3 * H, dx, 3 * H, B * S, h, S, 3, gd[0], gd[1], gd[2], dg[0], dg[1], dg[2],
-            3 if rope else 0, ct, st_, 0)
+            None, 3 if rope else 0, ct, st_, 0)
     close(dx, xr.grad, 1e-4, 1e-4, "headnorm dx")
     for j in range(3):
         close(dg[j], gr[j].grad, 1e-3, 1e-4, f"headnorm dgain{j}")
@@ -765,9 +765,12 @@ def test_headnorm_bf16_storage(kk, rope):
     close(y16, y32, *BF, "headnorm fwd bf16")
     dx32, dx16 = torch.empty_like(x), torch.empty_like(x, dtype=torch.bfloat16)
     dg32, dg16 = [torch.zeros(64, device="cuda") for _ in range(3)], [torch.zeros(64, device="cuda") for _ in range(3)]
-    kk.call("kk_headnorm_rope_bwd", dy, 3 * H, x, 3 * H, dx32, 3 * H, B * S, h, S, 3, *gains, *dg32, 3 if rope else 0, ct, st_, 0)
+    kk.call("kk_headnorm_rope_bwd", dy, 3 * H, x, 3 * H, dx32, 3 * H, B * S, h, S, 3, *gains, *dg32, None, 3 if rope else 0, ct, st_, 0)
+    nb = kk.load().kk_headnorm_bwd_blocks(B * S, h)
+    part = torch.full((3, nb, 64), 5.0, device="cuda")           # bf16 run: gain gradients through partial rows + reduce
     kk.call("kk_headnorm_rope_bwd", dy.bfloat16(), 3 * H, x.bfloat16(), 3 * H, dx16, 3 * H, B * S, h, S, 3, *gains, *dg16,
-            3 if rope else 0, ct, st_, 1)
+            part, 3 if rope else 0, ct, st_, 1)
+    kk.call("kk_partials_reduce", kk.reduce_table([(part[j], dg16[j], None, nb, 64, 64) for j in range(3)], "cuda"), 3, 64)
     close(dx16, dx32, *BF, "headnorm dx bf16")
     for a, b in zip(dg16, dg32):
         close(a, b, 1e-3, 1e-4, "headnorm dgain bf16")
