@@ -60,13 +60,18 @@ struct ProbDrop {
         sk2 = (uint32_t)(a.Sk + 1) >> 1;
     }
     __device__ __forceinline__ uint32_t row(int q, int key0) const { return (uint32_t)q * sk2 + ((uint32_t)key0 >> 1); }
-    __device__ __forceinline__ uint32_t hash(uint32_t x) const {        // "lowbias32"
+    // Two xorshift-multiply rounds with 24-bit multipliers: v_mul_u32_u24 is full rate, v_mul_lo_u32 quarter rate, and
+    // the hash is a third of the softmax VALU work.  On the (q, key/2) counter lattice it tests like "lowbias32"
+    // (keep rate, key/query/diagonal correlations at the 1e-3 noise floor, 8-bit pattern chi-square ~1; sweep in
+    // tools/dropout_hash_quality.py); injective on counters below 2^24 (S <= 4096), distinct (b, head) differ by `key`.
+    __device__ __forceinline__ uint32_t hash(uint32_t x) const {
         x ^= key;
-        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        x ^= x >> 16; x = __umul24(x, 0xb5352du); x ^= x >> 13; x = __umul24(x, 0xca68b5u); x ^= x >> 16;
         return x;
     }
-    __device__ __forceinline__ float lo(uint32_t h) const { return (h & 0xFFFFu) < thr ? 0.f : inv_keep; }   // even key
-    __device__ __forceinline__ float hi(uint32_t h) const { return (h >> 16) < thr ? 0.f : inv_keep; }       // odd key
+    // keep decisions; the 1/(1-p) of the kept elements is folded into an operand or an output scale by each kernel
+    __device__ __forceinline__ bool keep_lo(uint32_t h) const { return (h & 0xFFFFu) >= thr; }   // even key
+    __device__ __forceinline__ bool keep_hi(uint32_t h) const { return (h >> 16) >= thr; }       // odd key
 };
 
 __device__ __forceinline__ float f4g(const float4 &v, int c) { return reinterpret_cast<const float *>(&v)[c]; }
@@ -78,6 +83,19 @@ template <> struct RowFrag<false> { float v[32]; };   // v[ks]    = X[row][2 ks 
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+template <bool BF16>
+__device__ __forceinline__ void scale_rowfrag(RowFrag<BF16> &f, float k) {
+    if constexpr (BF16) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f.v[ks][j] = (__bf16)((float)f.v[ks][j] * k);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) f.v[j] *= k;
+    }
+}
 
 template <bool BF16, typename T>
 __device__ __forceinline__ void load_rowfrag(RowFrag<BF16> &f, const T *rowptr, int half) {
@@ -116,7 +134,7 @@ __device__ __forceinline__ void load_rowfrag(RowFrag<BF16> &f, const T *rowptr, 
 struct TileRegs { float4 r[4]; };
 
 __device__ __forceinline__ void load_rows(TileRegs &t, const float *src, int64_t ld, int nvalid) {
-    const int row = threadIdx.x >> 2, seg = (threadIdx.x & 3) * 16;
+    const int tl = threadIdx.x & 255, row = tl >> 2, seg = (tl & 3) * 16;
 #pragma unroll
     for (int i = 0; i < 4; ++i) t.r[i] = row < nvalid ? ld4(src + (int64_t)row * ld + seg + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
@@ -124,7 +142,7 @@ __device__ __forceinline__ void load_rows(TileRegs &t, const float *src, int64_t
 template <bool BF16>
 __device__ __forceinline__ void store_rows(typename ACfg<BF16>::elem *S, const TileRegs &t) {
     constexpr int LR = ACfg<BF16>::LR;
-    const int row = threadIdx.x >> 2, seg = (threadIdx.x & 3) * 16;
+    const int tl = threadIdx.x & 255, row = tl >> 2, seg = (tl & 3) * 16;
     if constexpr (BF16) {
         bf16x8 lo, hi;
 #pragma unroll
@@ -143,14 +161,14 @@ __device__ __forceinline__ void store_rows(typename ACfg<BF16>::elem *S, const T
 }
 
 __device__ __forceinline__ void load_rows_T(TileRegs &t, const float *src, int64_t ld, int nvalid) {
-    const int rg = (threadIdx.x & 15) * 4, dg = (threadIdx.x >> 4) * 4;
+    const int tl = threadIdx.x & 255, rg = (tl & 15) * 4, dg = (tl >> 4) * 4;
 #pragma unroll
     for (int c = 0; c < 4; ++c) t.r[c] = (rg + c) < nvalid ? ld4(src + (int64_t)(rg + c) * ld + dg) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 __device__ __forceinline__ void store_rows_T(__bf16 *St, const TileRegs &t) {
     constexpr int LR = ACfg<true>::LR;
-    const int rg = (threadIdx.x & 15) * 4, dg = (threadIdx.x >> 4) * 4;
+    const int tl = threadIdx.x & 255, rg = (tl & 15) * 4, dg = (tl >> 4) * 4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         bf16x4 v;
@@ -165,26 +183,26 @@ struct TileRegs16 { u32x4 r[2]; };     // "rows" pattern: 16 contiguous bf16 of 
 struct TileRegs16T { u32x2 r[4]; };    // "rows_T" pattern: 4 rows x 4 contiguous bf16
 
 __device__ __forceinline__ void load_rows(TileRegs16 &t, const __bf16 *src, int64_t ld, int nvalid) {
-    const int row = threadIdx.x >> 2, seg = (threadIdx.x & 3) * 16;
+    const int tl = threadIdx.x & 255, row = tl >> 2, seg = (tl & 3) * 16;
     const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < 2; ++i) t.r[i] = row < nvalid ? *reinterpret_cast<const u32x4 *>(src + (int64_t)row * ld + seg + 8 * i) : z;
 }
 __device__ __forceinline__ void store_rows16(__bf16 *S, const TileRegs16 &t) {
     constexpr int LR = ACfg<true>::LR;
-    const int row = threadIdx.x >> 2, seg = (threadIdx.x & 3) * 16;
+    const int tl = threadIdx.x & 255, row = tl >> 2, seg = (tl & 3) * 16;
     *reinterpret_cast<u32x4 *>(&S[row * LR + seg]) = t.r[0];
     *reinterpret_cast<u32x4 *>(&S[row * LR + seg + 8]) = t.r[1];
 }
 __device__ __forceinline__ void load_rows_T(TileRegs16T &t, const __bf16 *src, int64_t ld, int nvalid) {
-    const int rg = (threadIdx.x & 15) * 4, dg = (threadIdx.x >> 4) * 4;
+    const int tl = threadIdx.x & 255, rg = (tl & 15) * 4, dg = (tl >> 4) * 4;
     const u32x2 z = {0u, 0u};
 #pragma unroll
     for (int c = 0; c < 4; ++c) t.r[c] = (rg + c) < nvalid ? *reinterpret_cast<const u32x2 *>(src + (int64_t)(rg + c) * ld + dg) : z;
 }
 __device__ __forceinline__ void store_rows_T16(__bf16 *St, const TileRegs16T &t) {
     constexpr int LR = ACfg<true>::LR;
-    const int rg = (threadIdx.x & 15) * 4, dg = (threadIdx.x >> 4) * 4;
+    const int tl = threadIdx.x & 255, rg = (tl & 15) * 4, dg = (tl >> 4) * 4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {        // element e of rows 0..3 -> 4 contiguous bf16 of transposed row dg+e
         const int w = e >> 1, sh = 16 * (e & 1);
@@ -281,16 +299,22 @@ __device__ __forceinline__ void store_row(T *dst_row, const f32x16 (&acc)[2], fl
 }
 
 // ------------------------------------------------------------------ forward
-template <bool BF16, bool ST16>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+// G = 1: 4 waves, every wave sees every key tile.  G = 2: 8 waves (2 per SIMD — the second wave's MFMAs and LDS
+// latencies hide under the first one's softmax VALU work and vice versa); wave group g takes the key tiles
+// g, g+2, g+4, ... of the same 128 queries with its own running (max, sum, O), and the two partial softmaxes are
+// merged through LDS at the end.  Each group stages its own tiles with its own 256 threads.
+template <bool BF16, bool ST16, int G>
+__global__ __launch_bounds__(256 * G) void attn_fwd_kernel(AttnArgs a) {
     using elem = typename ACfg<BF16>::elem;
     using SG = Stage<BF16, ST16>;
     using T = typename SG::T;
     constexpr int LR = ACfg<BF16>::LR, TILE = 64 * LR;
-    __shared__ __attribute__((aligned(16))) elem smem[2 * 2 * TILE];      // [buffer][K | V]
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];        // [buffer][group][K | V]
+    elem *smem = reinterpret_cast<elem *>(smem_raw);
     const int b = blockIdx.y / a.heads, hh = blockIdx.y % a.heads;
     const int qblk = blockIdx.x * 128;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, l31 = lane & 31;
+    const int lane = threadIdx.x & 63, wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, l31 = lane & 31;
+    const int wave = wave8 & 3, grp = wave8 >> 2;
     const int q = qblk + wave * 32 + l31;
     const bool qvalid = q < a.Sq;
     RowFrag<BF16> qf;
@@ -307,30 +331,45 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     if (a.causal && qblk + 128 < kend) kend = qblk + 128;
     const T *Kb = static_cast<const T *>(a.K) + (int64_t)b * a.Sk * a.ldk + hh * 64;
     const T *Vb = static_cast<const T *>(a.V) + (int64_t)b * a.Sk * a.ldv + hh * 64;
-    typename SG::R rk;
-    typename std::conditional<BF16, typename SG::RT, typename SG::R>::type rv;
-    uint32_t rkm = 0;                                     // key-mask byte of key (tile start + lane), prefetched with K/V
-    auto issue = [&](int k0) {
+    // Register staging with a prefetch distance of TWO tiles: the kernel is bound by the latency of the K/V loads, not by
+    // bandwidth or math (19 us at S=512 with one tile ahead: four dependent ~2 us round trips), so two register sets
+    // alternate and a tile's loads have two tile-times to land before they are written to LDS.
+    struct Regs {
+        typename SG::R rk;
+        typename std::conditional<BF16, typename SG::RT, typename SG::R>::type rv;
+        uint32_t rkm;                                     // key-mask byte of key (tile start + lane)
+    };
+    Regs ra, rb;
+    ra.rkm = rb.rkm = 0;
+    auto issue = [&](Regs &t, int k0) {
         const int nvalid = a.Sk - k0 < 64 ? a.Sk - k0 : 64;
-        load_rows(rk, Kb + (int64_t)k0 * a.ldk, a.ldk, nvalid);
-        if constexpr (BF16) load_rows_T(rv, Vb + (int64_t)k0 * a.ldv, a.ldv, nvalid);
-        else load_rows(rv, Vb + (int64_t)k0 * a.ldv, a.ldv, nvalid);
-        if (km) rkm = lane < nvalid ? km[k0 + lane] : 0u;
+        load_rows(t.rk, Kb + (int64_t)k0 * a.ldk, a.ldk, nvalid);
+        if constexpr (BF16) load_rows_T(t.rv, Vb + (int64_t)k0 * a.ldv, a.ldv, nvalid);
+        else load_rows(t.rv, Vb + (int64_t)k0 * a.ldv, a.ldv, nvalid);
+        t.rkm = km ? (lane < nvalid ? km[k0 + lane] : 0u) : 0u;
     };
-    auto commit = [&](int buf) {
-        SG::st(smem + buf * 2 * TILE, rk);
-        if constexpr (BF16) SG::stT(smem + buf * 2 * TILE + TILE, rv);
-        else SG::st(smem + buf * 2 * TILE + TILE, rv);
+    auto commit = [&](const Regs &t, int buf) {
+        elem *dst = smem + (buf * G + grp) * 2 * TILE;
+        SG::st(dst, t.rk);
+        if constexpr (BF16) SG::stT(dst + TILE, t.rv);
+        else SG::st(dst + TILE, t.rv);
     };
-    issue(0);
-    commit(0);
-    uint64_t kmbits = __ballot(rkm != 0u), kmnext = 0;    // bit j: key (tile start + j) is masked (wave-uniform)
+    constexpr int STEP = 64 * G;                          // this group's tiles: grp*64, grp*64 + STEP, ...
+    const int kfirst = grp * 64;
+    if (kfirst < kend) {
+        issue(ra, kfirst);
+        commit(ra, 0);
+    }
+    uint64_t kmbits = __ballot(ra.rkm != 0u), kmnext = 0;  // bit j: key (tile start + j) is masked (wave-uniform)
+    if (kfirst + STEP < kend) issue(ra, kfirst + STEP);         // tile 1 -> set a
+    if (kfirst + 2 * STEP < kend) issue(rb, kfirst + 2 * STEP); // tile 2 -> set b
     __syncthreads();
     int cur = 0;
-    for (int k0 = 0; k0 < kend; k0 += 64, cur ^= 1) {
-        const bool more = k0 + 64 < kend;
-        if (more) issue(k0 + 64);                       // next tile's global loads fly during this tile's MFMAs
-        const elem *Ks = smem + cur * 2 * TILE, *Vx = Ks + TILE;
+    // one tile: multiply tile k0 from LDS buffer `cur`, then write tile k0+STEP (register set X) to the other buffer and
+    // reuse X for tile k0+3*STEP
+    auto tile_step = [&](Regs &X, int kk0) {
+        const int k0 = kk0 + kfirst;
+        const elem *Ks = smem + (cur * G + grp) * 2 * TILE, *Vx = Ks + TILE;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int kb = k0 + sub * 32;
@@ -343,22 +382,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
             // masks are only evaluated on edge sub-tiles: ragged end, causal diagonal, or a masked key among the 32
             const bool edge = kb + 32 > a.Sk || (a.causal && kb + 31 > qmin) || kmsub != 0u;
             float p[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p[r] = s[r];
             if (edge) {
                 const uint32_t kml = kmsub >> (4 * half);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kb + frag_row(r, half);
                     const bool ok = key < a.Sk && !(a.causal && key > q) && !((kml >> frag_row(r, 0)) & 1u);
-                    p[r] = ok ? s[r] * c2 : -INFINITY;
+                    p[r] = ok ? p[r] : -INFINITY;
                 }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) p[r] = s[r] * c2;
             }
-            float mx = p[0];
+            float mx = p[0];                               // max of the raw scores; the scale c2 > 0 commutes with max
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, p[r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c2;
             const float mn = fmaxf(m, mx);
             if (__ballot(mn > m) != 0ull) {               // rescale only when some row's maximum moved (wave-uniform)
                 const float alpha = __builtin_amdgcn_exp2f(m - mn);
@@ -369,29 +407,52 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
             }
             float rs = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(p[r] - m); rs += p[r]; }
+            for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(fmaf(p[r], c2, -m)); rs += p[r]; }
             rs += __shfl_xor(rs, 32, 64);
             l += rs;
-            if (pd.thr) {                                  // the row sum l stays un-dropped: softmax first, dropout after
+            if (pd.thr) {                // the row sum l stays un-dropped: softmax first, dropout after; 1/(1-p) at the store
                 const uint32_t xb = pd.row(q, kb + 4 * half);
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const uint32_t hsh = pd.hash(xb + (uint32_t)(frag_row(r, 0) >> 1));
-                    p[r] *= pd.lo(hsh);
-                    p[r + 1] *= pd.hi(hsh);
+                    p[r] = pd.keep_lo(hsh) ? p[r] : 0.f;
+                    p[r + 1] = pd.keep_hi(hsh) ? p[r + 1] : 0.f;
                 }
             }
             mma_T_x_p<BF16>(o, Vx, sub * 32, p, l31, half);
         }
-        if (more) {
-            commit(cur ^ 1);
-            kmnext = __ballot(rkm != 0u);
+        kmnext = 0;
+        if (k0 + STEP < kend) {
+            commit(X, cur ^ 1);
+            kmnext = __ballot(X.rkm != 0u);
+            if (k0 + 3 * STEP < kend) issue(X, k0 + 3 * STEP);
         }
         kmbits = kmnext;
         __syncthreads();
+        cur ^= 1;
+    };
+    for (int kk0 = 0; kk0 < kend; kk0 += 2 * STEP) {      // the bound is the same for both groups (barriers)
+        tile_step(ra, kk0);
+        if (kk0 + STEP < kend) tile_step(rb, kk0 + STEP);
+    }
+    if constexpr (G == 2) {          // merge the two key groups' partial softmaxes: group 1 -> LDS -> group 0
+        float *mb = reinterpret_cast<float *>(smem_raw) + (wave * 64 + lane) * 34;      // (the loop's last barrier is behind us)
+        if (grp == 1) {
+            mb[0] = m; mb[1] = l;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { mb[2 + r] = o[0][r]; mb[18 + r] = o[1][r]; }
+        }
+        __syncthreads();
+        if (grp == 1) return;
+        const float m1 = mb[0], l1 = mb[1], mn = fmaxf(m, m1);
+        const float a0 = __builtin_amdgcn_exp2f(m - mn), a1 = __builtin_amdgcn_exp2f(m1 - mn);
+        l = l * a0 + l1 * a1;
+        m = mn;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[0][r] = o[0][r] * a0 + mb[2 + r] * a1; o[1][r] = o[1][r] * a0 + mb[18 + r] * a1; }
     }
     if (qvalid) {
-        const float inv = l > 0.f ? 1.f / l : 0.f;
+        const float inv = l > 0.f ? pd.inv_keep / l : 0.f;
         store_row<T>(static_cast<T *>(a.Out) + ((int64_t)b * a.Sq + q) * a.ldout + hh * 64, o, inv, half);
         if (half == 0) a.LSEo[((int64_t)b * a.heads + hh) * a.Sq + q] = l > 0.f ? (m + __builtin_amdgcn_logf(l)) * 0.6931471805599453f : INFINITY;
     }
@@ -413,13 +474,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     RowFrag<BF16> qf, dof;
     load_rowfrag<BF16, T>(qf, qvalid ? static_cast<const T *>(a.Q) + ((int64_t)b * a.Sq + q) * a.ldq + hh * 64 : nullptr, half);
     load_rowfrag<BF16, T>(dof, qvalid ? static_cast<const T *>(a.dO) + ((int64_t)b * a.Sq + q) * a.lddo + hh * 64 : nullptr, half);
+    ProbDrop pd;
+    pd.init(a, b, hh);
+    if (pd.thr) scale_rowfrag<BF16>(dof, pd.inv_keep);     // dP of a kept element carries 1/(1-p): fold it into dO once
     const float c2 = a.scale * 1.4426950408889634f;
     const float lse2 = qvalid ? a.LSE[((int64_t)b * a.heads + hh) * a.Sq + q] * 1.4426950408889634f : INFINITY;   // log2 domain
     const float dlt = qvalid ? a.Delta[((int64_t)b * a.heads + hh) * a.Sq + q] : 0.f;
     f32x16 dq[2];
     zero_acc(dq[0]); zero_acc(dq[1]);
-    ProbDrop pd;
-    pd.init(a, b, hh);
     const uint8_t *km = a.key_mask ? a.key_mask + (int64_t)b * a.Sk : nullptr;
     const int qmin = qblk + wave * 32;
     uint32_t rkm = 0;
@@ -478,8 +540,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const uint32_t hsh = pd.hash(xb + (uint32_t)(frag_row(r, 0) >> 1));
-                    ds[r] = pv[r] * (dp[r] * pd.lo(hsh) - dlt);
-                    ds[r + 1] = pv[r + 1] * (dp[r + 1] * pd.hi(hsh) - dlt);
+                    ds[r] = pv[r] * ((pd.keep_lo(hsh) ? dp[r] : 0.f) - dlt);
+                    ds[r + 1] = pv[r + 1] * ((pd.keep_hi(hsh) ? dp[r + 1] : 0.f) - dlt);
                 }
             } else {
 #pragma unroll
@@ -519,6 +581,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     zero_acc(dk[0]); zero_acc(dk[1]); zero_acc(dv[0]); zero_acc(dv[1]);
     ProbDrop pd;
     pd.init(a, b, hh);
+    if (pd.thr) scale_rowfrag<BF16>(vf, pd.inv_keep);       // dP = dO.V of a kept element carries 1/(1-p)
     const float c2 = a.scale * 1.4426950408889634f;
     const int kmaxw = kblk + wave * 32 + 31;                           // largest key of this wave
     const bool anydead = __ballot(!kalive) != 0ull;                    // masked / out-of-range keys in this wave
@@ -591,9 +654,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const uint32_t hsh = pd.hash(xb + (uint32_t)frag_row(r, 0) * pd.sk2);
-                    const float dm = odd ? pd.hi(hsh) : pd.lo(hsh);
-                    ds[r] = p[r] * (dp[r] * dm - dlt_r[frag_row(r, 0)]);
-                    p[r] *= dm;                                       // dropped probabilities feed dV
+                    const bool keep = odd ? pd.keep_hi(hsh) : pd.keep_lo(hsh);
+                    ds[r] = p[r] * ((keep ? dp[r] : 0.f) - dlt_r[frag_row(r, 0)]);
+                    p[r] = keep ? p[r] : 0.f;                         // dropped probabilities feed dV (1/(1-p) at the store)
                 }
             } else {
 #pragma unroll
@@ -607,7 +670,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     }
     if (kvalid) {
         store_row<T>(static_cast<T *>(a.Out) + ((int64_t)b * a.Sk + key) * a.ldout + hh * 64, dk, a.scale, half);
-        store_row<T>(static_cast<T *>(a.Out2) + ((int64_t)b * a.Sk + key) * a.ldout2 + hh * 64, dv, 1.f, half);
+        store_row<T>(static_cast<T *>(a.Out2) + ((int64_t)b * a.Sk + key) * a.ldout2 + hh * 64, dv, pd.inv_keep, half);
     }
 }
 
@@ -627,6 +690,34 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T *__restrict__ O
         }
     }
 }
+
+int g_attn_groups = 2;
+
+// Launch KERNEL<BF16, ST16, G> with G*256 threads and its dynamic LDS (buffers x groups x NT tiles; above 64 KB the
+// kernel attribute has to be raised once).
+template <typename K>
+int launch_attn(K kernel, dim3 grid, int G, size_t lds, hipStream_t s, const AttnArgs &a) {
+    if (lds > 64 * 1024) {
+        static thread_local const void *raised[16];
+        bool done = false;
+        for (const void *p : raised) done = done || p == (const void *)kernel;
+        if (!done) {
+            hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return kk_fail((int)e, "attention: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+            for (auto &p : raised)
+                if (!p) { p = (const void *)kernel; break; }
+        }
+    }
+    hipLaunchKernelGGL(kernel, grid, dim3(256 * G), lds, s, a);
+    return 0;
+}
+#define KK_ATTN_LDS(BF16, G, NT, EXTRA) ((size_t)2 * (G) * (NT) * 64 * ACfg<BF16>::LR * sizeof(typename ACfg<BF16>::elem) + (EXTRA))
+#define KK_ATTN_LAUNCH(KERNEL, BF16, ST16, G, NT)                                                                              \
+    do {                                                                                                                       \
+        int rc__ = (G) == 2 ? launch_attn(KERNEL<BF16, ST16, 2>, grid, 2, KK_ATTN_LDS(BF16, 2, NT, 0), (hipStream_t)stream, a) \
+                            : launch_attn(KERNEL<BF16, ST16, 1>, grid, 1, KK_ATTN_LDS(BF16, 1, NT, 0), (hipStream_t)stream, a); \
+        if (rc__) return rc__;                                                                                                 \
+    } while (0)
 
 int check_common(const char *name, int B, int heads, int Sq, int Sk, int math, const int64_t *lds, int nld) {
     KK_REQUIRE(B > 0 && heads > 0 && Sq > 0 && Sk > 0, "%s: bad shape B=%d heads=%d Sq=%d Sk=%d", name, B, heads, Sq, Sk);
@@ -652,9 +743,10 @@ extern "C" int kk_attn_fwd(const float *Q, const float *K, const float *V, float
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldout = ldo; a.scale = scale;
     a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop;
     dim3 grid(kk_cdiv(Sq, 128), B * heads);
-    if (io_bf16) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
-    else if (math == KK_MATH_BF16) hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    const int G = (Sk > 64 && g_attn_groups == 2) ? 2 : 1;          // one key tile: nothing to split
+    if (io_bf16) KK_ATTN_LAUNCH(attn_fwd_kernel, true, true, G, 2);
+    else if (math == KK_MATH_BF16) KK_ATTN_LAUNCH(attn_fwd_kernel, true, false, G, 2);
+    else KK_ATTN_LAUNCH(attn_fwd_kernel, false, false, G, 2);
     KK_LAUNCH_CHECK("kk_attn_fwd");
     return 0;
 }
