@@ -133,28 +133,88 @@ class FixedBatchSampler:
         yield from self.batches()
 
 
-class FrameBudgetBatchSampler:
-    """batch_size * longest_sample_frames <= max_frames, min/max batch size, rank-sharded round-robin."""
+def length_based_batch_sampler(dataset, batch_size: int, shuffle: bool = True, rank: int = 0, world: int = 1, seed: int = 0,
+                               drop_last: bool = False) -> "FrameBudgetBatchSampler":
+    """The reference's LengthBasedBatchSampler (data/dataset.py:1150-1180): fixed batch size, samples grouped by length —
+    the dynamic sampler with a frame budget that never binds and min_batch_size 1."""
+    longest = max((int(m["audio_length"]) for m in dataset.samples), default=10000)
+    return FrameBudgetBatchSampler(dataset, longest * batch_size, 1, batch_size, shuffle, rank, world, seed, drop_last)
 
-    def __init__(self, dataset: CachedFeatureDataset, max_frames: int, min_batch_size: int = 4, max_batch_size: int = 32,
-                 shuffle: bool = True, rank: int = 0, world: int = 1, seed: int = 0):
+
+class FrameBudgetBatchSampler:
+    """The reference's DynamicFrameBatchSampler (data/dataset.py:924-1147), restated, plus rank sharding.
+
+    Batches are lists of dataset indices whose cost `len(batch) * longest_sample_frames` stays within `max_frames`
+    (and whose size stays within `max_batch_size`):
+      1. quantile buckets — `min(16, max(1, int(sqrt(N))))` buckets cut at the percentiles of the sample lengths, a
+         sample goes to the last bucket whose lower cut is <= its length (dataset.py:1027-1045);
+      2. inside each bucket: shuffle, then greedy packing in that order; a batch below `min_batch_size` is kept
+         unless `drop_last` (dataset.py:1049-1075);
+      3. heavy-batch spreading — the `max(2, int(sqrt(n)))` costliest batches are anchors placed at even distances
+         (heaviest first), the shuffled remaining batches fill the gaps (dataset.py:1089-1127).
+    Randomness: the reference draws from the process-global `random` module; here every epoch draws from
+    `random.Random(seed + epoch)` in the same order (one shuffle per non-empty bucket, then one for the light
+    batches), so all ranks build the identical list without communication and a globally seeded reference run
+    reproduces it (tests/golden/sampler.json)."""
+
+    def __init__(self, dataset, max_frames: int = 20000, min_batch_size: int = 4, max_batch_size: int = 32,
+                 shuffle: bool = True, rank: int = 0, world: int = 1, seed: int = 0, drop_last: bool = False):
         self.ds, self.max_frames, self.min_bs, self.max_bs = dataset, max_frames, min_batch_size, max_batch_size
-        self.shuffle, self.rank, self.world, self.seed, self.epoch = shuffle, rank, world, seed, 0
+        self.shuffle, self.rank, self.world, self.seed, self.epoch, self.drop_last = shuffle, rank, world, seed, 0, drop_last
+
+    def _frames(self, i: int) -> int:
+        return int(self.ds.samples[i]["audio_length"])
 
     def global_batches(self) -> List[List[int]]:
-        order = sorted(range(len(self.ds)), key=lambda i: self.ds.samples[i]["audio_length"])
+        import numpy as np
+        n_samples = len(self.ds.samples)
+        if n_samples == 0:
+            return []
+        rng = random.Random(self.seed + self.epoch)
+        lengths = np.array([self._frames(i) for i in range(n_samples)], dtype=np.int64)
+        n_buckets = min(16, max(1, int(np.sqrt(n_samples))))
+        cuts = np.percentile(lengths, np.linspace(0, 100, n_buckets + 1))
+        buckets: List[List[int]] = [[] for _ in range(n_buckets)]
+        for i, ln in enumerate(lengths.tolist()):
+            b = int(np.searchsorted(cuts, ln, side="right") - 1)
+            buckets[max(0, min(n_buckets - 1, b))].append(i)
         out: List[List[int]] = []
-        cur: List[int] = []
-        for i in order:
-            longest = self.ds.samples[i]["audio_length"]           # sorted ⇒ the new sample is the longest
-            if cur and ((len(cur) + 1) * longest > self.max_frames or len(cur) >= self.max_bs):
+        keep = lambda batch: bool(batch) and (len(batch) >= self.min_bs or not self.drop_last)
+        for bucket in buckets:
+            if not bucket:
+                continue
+            if self.shuffle:
+                rng.shuffle(bucket)
+            cur: List[int] = []
+            longest = 0
+            for i in bucket:
+                fr = self._frames(i)
+                if cur and ((len(cur) + 1) * max(longest, fr) > self.max_frames or len(cur) >= self.max_bs):
+                    if keep(cur):
+                        out.append(cur)
+                    cur, longest = [], 0
+                cur.append(i)
+                longest = max(longest, fr)
+            if keep(cur):
                 out.append(cur)
-                cur = []
-            cur.append(i)
-        if cur:
-            out.append(cur)
-        if self.shuffle:
-            random.Random(self.seed + self.epoch).shuffle(out)
+        if self.shuffle and len(out) > 1:
+            n = len(out)
+            n_heavy = max(2, int(n ** 0.5))
+            cost = [max((self._frames(i) for i in b), default=0) * len(b) for b in out]
+            ranked = [out[i] for i in sorted(range(n), key=lambda i: cost[i], reverse=True)]     # stable, like the reference
+            heavy, light = ranked[:n_heavy], ranked[n_heavy:]
+            rng.shuffle(light)
+            gap, rem = divmod(len(light), n_heavy)
+            res: List[List[int]] = []
+            start = 0
+            for k, anchor in enumerate(heavy):
+                end = start + gap + (1 if k < rem else 0)
+                res.append(anchor)
+                res.extend(light[start:end])
+                start = end
+            out = res
+        elif self.shuffle:
+            rng.shuffle(out)
         return out
 
     def batches(self) -> List[List[int]]:

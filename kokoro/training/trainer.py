@@ -15,8 +15,8 @@ from typing import Dict, Optional
 
 import torch
 
-from kokoro.data.cached import (CachedFeatureDataset, FixedBatchSampler, FrameBudgetBatchSampler, collate_fn, split_indices,
-                                step_groups)
+from kokoro.data.cached import (CachedFeatureDataset, FrameBudgetBatchSampler, collate_fn, length_based_batch_sampler,
+                                split_indices, step_groups)
 from kokoro.training import checkpoint as ckpt
 from kokoro_ruslan_amd import dp, lib as kk
 from kokoro_ruslan_amd.spec import ModelDims, StepHyper
@@ -64,9 +64,10 @@ class KokoroTrainer:
         self.val_dataset = CachedFeatureDataset(config.feature_cache_dir, va_idx, config.max_seq_length, config.use_memory_cache) if va_idx else None
         if config.use_dynamic_batching:
             self.sampler = FrameBudgetBatchSampler(self.dataset, config.max_frames_per_batch, config.min_batch_size,
-                                                   config.max_batch_size, True, self.rank, self.world)
+                                                   config.max_batch_size, True, self.rank, self.world, drop_last=True)   # trainer.py:305-312
         else:
-            self.sampler = FixedBatchSampler(len(self.dataset), config.batch_size, True, self.rank, self.world)
+            self.sampler = length_based_batch_sampler(self.dataset, config.batch_size, True, self.rank, self.world,
+                                                      drop_last=True)                                                  # trainer.py:315-320
         G = max(1, config.gradient_accumulation_steps)
         steps_per_epoch = max(1, -(-len(self.sampler) // G))
         hp = StepHyper.from_config(config)

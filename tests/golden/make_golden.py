@@ -331,6 +331,39 @@ def section_tables():
         np.save(os.path.join(HERE, f"lr_seq_{total_steps}_{warm}.npy"), np.array(seq))
 
 
+def section_sampler():
+    """Golden batch lists from the reference's DynamicFrameBatchSampler (data/dataset.py:924-1147) on synthetic length
+    tables, with the process-global `random` seeded (the reference draws from it): pins kokoro/data/cached.py's
+    FrameBudgetBatchSampler, which draws the same stream from random.Random(seed + epoch)."""
+    print("== dynamic batch sampler")
+    import random as _random
+    from kokoro.data.dataset import DynamicFrameBatchSampler
+
+    class FakeDs:
+        def __init__(self, lengths):
+            self.samples = [{"audio_length": int(x)} for x in lengths]
+
+        def __len__(self):
+            return len(self.samples)
+    cases = []
+    rs = np.random.RandomState(5)
+    for name, lengths, kw in [
+        ("eleven", [40, 52, 61, 75, 90, 111, 130, 160, 199, 240, 300], dict(max_frames=200, min_batch_size=1, max_batch_size=4)),
+        ("two_hundred", rs.randint(60, 1500, size=200).tolist(), dict(max_frames=16384, min_batch_size=4, max_batch_size=32)),
+        ("thousand_drop_last", np.clip(rs.lognormal(6.2, 0.5, size=1000), 50, 1800).astype(int).tolist(),
+         dict(max_frames=16384, min_batch_size=4, max_batch_size=32, drop_last=True)),
+        ("no_shuffle", rs.randint(60, 900, size=150).tolist(), dict(max_frames=8000, min_batch_size=2, max_batch_size=16, shuffle=False)),
+        ("ties", [100] * 37 + [200] * 23, dict(max_frames=1000, min_batch_size=1, max_batch_size=8)),
+    ]:
+        for seed in (0, 7):
+            _random.seed(seed)
+            ref = DynamicFrameBatchSampler(FakeDs(lengths), **kw)
+            cases.append({"name": name, "lengths": lengths, "kwargs": kw, "seed": seed, "batches": [list(map(int, b)) for b in ref.batches]})
+            print(f"  {name} seed {seed}: {len(ref.batches)} batches")
+    with open(os.path.join(HERE, "sampler.json"), "w") as f:
+        json.dump(cases, f)
+
+
 def section_surface():
     """Dump the reference's Python surface for the drop-in tests: TrainingConfig fields and kokoro-train flags."""
     print("== drop-in surface")
@@ -422,6 +455,7 @@ if __name__ == "__main__":
     tiny = O.ModelDims(vocab=59, mel=20, hidden=128, heads=2, enc_layers=2, dec_layers=2, enc_ff=96,
                        dec_ff=96, var_filter=32, var_kernel=3, var_bins=16, max_len=700)
     section_surface()
+    section_sampler()
     section_lengths()
     section_loss_known_answers()
     section_model("tiny_full", tiny, B=2, T=40, Pn=6, seed=11, ragged=False, save_step=False)

@@ -88,9 +88,31 @@ def test_cached_features_collate_and_samplers(tmp_path):
     for b in bl:
         assert len(b) <= 4 and (len(b) == 1 or len(b) * max(ds.samples[i]["audio_length"] for i in b) <= 200)
     parts = [cached.FrameBudgetBatchSampler(ds, 200, 1, 4, True, r, 2, seed=3).batches() for r in range(2)]
-    assert sorted(i for pb in parts for b in pb for i in b) == list(range(11))        # ranks partition the epoch
+    glob = cached.FrameBudgetBatchSampler(ds, 200, 1, 4, True, 0, 1, seed=3).batches()
+    assert len(parts[0]) == len(parts[1]) == len(glob) // 2                            # same number of steps on every rank
+    assert [b for pair in zip(*parts) for b in pair] == glob[:len(glob) // 2 * 2]      # ranks interleave the global list
     with pytest.raises(FileNotFoundError):
         cached.CachedFeatureDataset(str(tmp_path / "nothing"))
+
+
+def test_dynamic_batch_sampler_matches_reference(golden_dir):
+    """FrameBudgetBatchSampler == the reference's DynamicFrameBatchSampler (golden batch lists dumped from the reference
+    with the global RNG seeded): quantile buckets, greedy packing, min-size/drop_last, heavy-batch spreading, ties."""
+    import json
+    import types
+    from kokoro.data import cached
+    cases = json.load(open(os.path.join(golden_dir, "sampler.json")))
+    assert len(cases) >= 10
+    for c in cases:
+        ds = types.SimpleNamespace(samples=[{"audio_length": x} for x in c["lengths"]])
+        kw = dict(c["kwargs"])
+        s = cached.FrameBudgetBatchSampler(ds, kw.pop("max_frames"), kw.pop("min_batch_size"), kw.pop("max_batch_size"),
+                                           kw.pop("shuffle", True), 0, 1, seed=c["seed"], drop_last=kw.pop("drop_last", False))
+        assert not kw
+        assert s.global_batches() == c["batches"], c["name"]
+        if c["kwargs"].get("shuffle", True):
+            s.epoch = 1
+            assert s.global_batches() != c["batches"], "a new epoch must reshuffle"
 
 
 def test_trainer_helpers():
