@@ -118,26 +118,57 @@ class KokoroTrainer:
         logger.info("epoch %d train: total %.4f mel %.4f dur %.4f stop %.4f pitch %.4f energy %.4f", epoch + 1, *avg)
         return avg[0]
 
+    def _val_batches(self):
+        """Validation batches like the reference (trainer.py:331-348): same sampler family, no shuffle, nothing dropped;
+        every rank validates the whole split (no gradient exchange happens here)."""
+        cfg = self.config
+        if cfg.use_dynamic_batching:
+            s = FrameBudgetBatchSampler(self.val_dataset, cfg.max_frames_per_batch, cfg.min_batch_size, cfg.max_batch_size, False)
+        else:
+            s = length_based_batch_sampler(self.val_dataset, cfg.batch_size, False)
+        return s.global_batches()
+
     @torch.no_grad()
     def validate_epoch(self) -> Optional[Dict[str, float]]:
+        """Losses on the EMA weights in fp32 + the reference's two validation metrics (trainer.py:1866-1910): spectral
+        convergence ||ref - pred||_F / ||ref||_F and frame-level F0 RMSE, each averaged per sample, then per batch, then
+        over batches — computed on the device with masks, one host read at the end of the epoch."""
         if not self.val_dataset or len(self.val_dataset) == 0:
             return None
         e = self.engine
-        saved_p = None
+        saved_p, saved_sync = None, e.loss_sync
+        e.loss_sync = None
         if e.arena.ema is not None:
             saved_p = e.arena.p.clone()
             e.arena.p.copy_(e.arena.ema)                     # evaluate the EMA replica
-        tot, n = torch.zeros(6, device=e.device), 0
-        bs = max(1, self.config.batch_size)
+        acc = torch.zeros(10, device=e.device, dtype=torch.float64)      # 6 losses, sc sum, sc batches, f0 sum, f0 batches
+        n = 0
         with e.fp32_math():                                  # validation runs without autocast (trainer.py:1821-1834)
-            for i in range(0, len(self.val_dataset), bs):
-                batch = cap_batch(self._to_device(collate_fn([self.val_dataset[j] for j in range(i, min(i + bs, len(self.val_dataset)))])))
-                tot += e.forward_backward(batch, backward=False)["losses"]
+            for idxs in self._val_batches():
+                batch = cap_batch(self._to_device(collate_fn([self.val_dataset[j] for j in idxs])))
+                out = e.forward_backward(batch, backward=False)
+                acc[:6] += out["losses"].double()
                 n += 1
+                T = batch["mel_specs"].shape[1]
+                valid = (torch.arange(T, device=e.device)[None, :] < batch["mel_lengths"][:, None])
+                ok = batch["mel_lengths"] > 0
+                m3 = valid[:, :, None].to(torch.float32)
+                num = ((batch["mel_specs"] - out["mel"]) * m3).flatten(1).norm(dim=1)
+                den = (batch["mel_specs"] * m3).flatten(1).norm(dim=1)
+                sc_ok = ok & (den > 0)
+                acc[6] += torch.where(sc_ok, num / den.clamp(min=1e-30), torch.zeros_like(num)).sum().double() / sc_ok.sum().clamp(min=1)
+                acc[7] += (sc_ok.sum() > 0).double()
+                se = ((batch["pitches"][:, :T] - out["pitch"]) ** 2 * valid).sum(1) / batch["mel_lengths"].clamp(min=1)
+                acc[8] += torch.where(ok, se.sqrt(), torch.zeros_like(se)).sum().double() / ok.sum().clamp(min=1)
+                acc[9] += (ok.sum() > 0).double()
         if saved_p is not None:
             e.arena.p.copy_(saved_p)                         # (the bf16 weight shadow was never touched)
-        v = (tot / n).cpu().tolist()
-        return dict(zip(("total", "mel", "dur", "stop", "pitch", "energy"), v))
+        e.loss_sync = saved_sync
+        v = acc.cpu().tolist()
+        res = dict(zip(("total", "mel", "dur", "stop", "pitch", "energy"), (x / max(n, 1) for x in v[:6])))
+        res["spectral_convergence"] = v[6] / v[7] if v[7] > 0 else None
+        res["f0_rmse"] = v[8] / v[9] if v[9] > 0 else None
+        return res
 
     def train(self) -> None:
         cfg = self.config
@@ -157,11 +188,14 @@ class KokoroTrainer:
             improved = False
             if val is not None:
                 logger.info("epoch %d val: total %.4f mel %.4f dur %.4f stop %.4f", epoch + 1, val["total"], val["mel"], val["dur"], val["stop"])
+                if val.get("spectral_convergence") is not None:
+                    logger.info("  SpectralConv: %.6f  f0_RMSE: %.6f", val["spectral_convergence"], val["f0_rmse"] or 0.0)
                 if val["total"] < self.best_val - cfg.early_stopping_min_delta:
                     self.best_val, self.best_epoch, improved, patience = val["total"], epoch, True, 0
                 else:
                     patience += 1
-            if self.rank == 0 and (improved or (epoch + 1) % max(1, cfg.save_every) == 0 or epoch + 1 == cfg.num_epochs):
+            periodic = (epoch + 1) % max(1, cfg.save_every) == 0 and (not self.val_dataset or patience > 0)     # trainer.py:2986-2998
+            if self.rank == 0 and (improved or periodic or epoch + 1 == cfg.num_epochs):
                 p = ckpt.save_checkpoint(self.engine, cfg, epoch, loss, cfg.output_dir, val, self.best_val, self.best_epoch)
                 logger.info("checkpoint saved: %s", p)
             if val is not None and patience >= cfg.early_stopping_patience:

@@ -68,3 +68,45 @@ def test_kokoro_train_cli_end_to_end(tmp_path):
                                         var_bins=16, mel=80, max_len=4000), spec.StepHyper())
     with pytest.raises(RuntimeError, match="architecture mismatch"):
         ckpt.load_checkpoint(small, str(out / "checkpoint_epoch_3.pth"))
+
+
+def test_validation_metrics_match_per_sample_loops(tmp_path):
+    """validate_epoch's masked, on-device spectral convergence / F0-RMSE == the reference's per-sample Python loops
+    (trainer.py:1866-1910) on the same predictions."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import math
+    from kokoro.cli.cli import create_config_from_args, parse_arguments
+    from kokoro.data.cached import collate_fn
+    from kokoro.training.trainer import KokoroTrainer, cap_batch
+    corpus = tmp_path / "corpus"
+    _fake_cache(corpus, n=14)
+    import sys
+    argv, sys.argv = sys.argv, ["kokoro-train", "--corpus", str(corpus), "--output", str(tmp_path / "m"), "--no-mfa",
+                                "--no-dynamic-batching", "--batch-size", "3", "--epochs", "1", "--val-split", "0.4"]
+    try:
+        cfg = create_config_from_args(parse_arguments())
+    finally:
+        sys.argv = argv
+    tr = KokoroTrainer(cfg)
+    val = tr.validate_epoch()
+    e = tr.engine
+    sc_sum = sc_n = f0_sum = f0_n = 0.0
+    with e.fp32_math():
+        for idxs in tr._val_batches():
+            batch = cap_batch(tr._to_device(collate_fn([tr.val_dataset[j] for j in idxs])))
+            out = e.forward_backward(batch, backward=False)
+            bs = bn = fs = fn = 0.0
+            for b in range(batch["mel_specs"].size(0)):
+                L = int(batch["mel_lengths"][b])
+                ref, pred = batch["mel_specs"][b, :L], out["mel"][b, :L]
+                den = float(torch.norm(ref))
+                if den > 0:
+                    bs += float(torch.norm(ref - pred)) / den
+                    bn += 1
+                fs += math.sqrt(float(torch.mean((batch["pitches"][b, :L] - out["pitch"][b, :L]) ** 2)))
+                fn += 1
+            sc_sum, sc_n, f0_sum, f0_n = sc_sum + bs / bn, sc_n + 1, f0_sum + fs / fn, f0_n + 1
+    assert abs(val["spectral_convergence"] - sc_sum / sc_n) < 1e-5 * max(1.0, sc_sum / sc_n)
+    assert abs(val["f0_rmse"] - f0_sum / f0_n) < 1e-5
+    assert len(tr._val_batches()) >= 2 and sorted(i for b in tr._val_batches() for i in b) == list(range(len(tr.val_dataset)))
