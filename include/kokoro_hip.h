@@ -180,6 +180,14 @@ int kk_shift_right(const float *mel, float *out, int B, int T, int M, void *stre
 int kk_dropout_fwd(const float *x, const float *res, int64_t res_mod, float *out, int64_t rows, int H, int S,
                    const uint32_t *seed, uint32_t site1, float p1, uint32_t site2, float p2, uint32_t site_dp,
                    float dp_rate, void *stream);
+/* Fused tail of an attention / feed-forward sub-layer (forward, p > 0 paths): x_out = res + dropout_p1(dropout_p2(
+ * drop_path([RMSNorm_gain](y)))) and, when ln_gamma is given, n = LayerNorm(x_out) with its mean / rstd — one launch
+ * instead of kk_rmsnorm_fwd + kk_dropout_fwd + kk_layernorm_fwd; identical masks, so kk_dropout_bwd is its backward.
+ * gain == NULL: no RMSNorm (attention output projection).  y: fp32 or bf16 (y_bf16); n: fp32 or bf16 (n_bf16). */
+int kk_sublayer_out_fwd(const float *y, int y_bf16, const float *gain, float *rstd_f, const float *res, float *x_out,
+                        const float *ln_gamma, const float *ln_beta, float *n, int n_bf16, float *mean, float *rstd,
+                        int64_t rows, int H, int S, const uint32_t *seed, uint32_t site1, float p1, uint32_t site2,
+                        float p2, uint32_t site_dp, float dp_rate, void *stream);
 int kk_dropout_bwd(const float *dy, float *dx, int64_t rows, int H, int S, const uint32_t *seed, uint32_t site1,
                    float p1, uint32_t site2, float p2, uint32_t site_dp, float dp_rate, int dx_bf16, void *stream);
 /* SpecAugment on the cross-attention memory, in place (trainer.py:1577-1604); call again on the memory gradient. */

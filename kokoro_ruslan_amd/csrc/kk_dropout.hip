@@ -7,6 +7,7 @@
 // Masks come from the counter RNG in kk_common.h; the backward kernels regenerate them.  These are the p > 0 paths;
 // with p == 0 the engine uses the fused GEMM / RMSNorm residual epilogues instead.
 #include "kk_common.h"
+#include <float.h>
 
 namespace {
 
@@ -49,6 +50,106 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float *__restrict__ 
         }
         stv4<TO>(out + row * H + c, make_float4(o[0], o[1], o[2], o[3]));
     }
+}
+
+// ---- fused sub-layer tail (forward): [RMSNorm(H)] -> dropout(s) -> DropPath -> + residual -> [LayerNorm of the sum] ----
+// One wave per row, the row in registers: replaces kk_rmsnorm_fwd + kk_dropout_fwd + kk_layernorm_fwd (three launches
+// and two extra round trips of the [rows, H] tensor) at the end of every attention / feed-forward sub-layer.  The
+// masks are the same functions of (seed, site, element) as dropout_kernel's, so kk_dropout_bwd regenerates them.
+struct SubOutArgs {
+    const void *y;                 // sub-layer result (TY): output projection (fp32) or FFN linear2 output (bf16 / fp32)
+    const float *gain;             // optional RMSNorm(H) gain (GLU output_norm, transformers.py:109-110) ...
+    float *rstd_f;                 // ... and where its 1/rms goes (saved for backward)
+    const float *res;              // residual stream in
+    float *x_out;                  // residual stream out = res + masks * norm(y)
+    const float *ln_gamma, *ln_beta;   // optional LayerNorm of x_out (the next sub-layer's pre-norm / the stack's final norm)
+    void *n;                       // its output (TN)
+    float *mean, *rstd;
+    int64_t rows;
+    int H;
+    DropArgs d;
+};
+
+template <typename TY, typename TN, int NV>
+__global__ __launch_bounds__(256) void sublayer_out_fwd_kernel(SubOutArgs a) {
+    const int lane = threadIdx.x & 63, H = a.H;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const uint32_t seed = *a.d.seed;
+    const uint32_t t1 = kk_drop_threshold(a.d.p1), t2 = kk_drop_threshold(a.d.p2);
+    const float k1 = a.d.p1 > 0.f ? 1.f / (1.f - a.d.p1) : 1.f, k2 = a.d.p2 > 0.f ? 1.f / (1.f - a.d.p2) : 1.f;
+    const TY *yr = static_cast<const TY *>(a.y) + row * H;
+    float4 v[NV];
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        v[i] = c < H ? ldv4<TY>(yr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        q += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+    }
+    float rs = 1.f;
+    if (a.gain) {
+        rs = 1.f / sqrtf(wave_sum(q) / (float)H + FLT_EPSILON);
+        if (lane == 0) a.rstd_f[row] = rs;
+    }
+    const float dp = row_scale(a.d, seed, row);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < H) {
+            float o[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+            if (a.gain) {
+                const float4 g = ld4(a.gain + c);
+                o[0] = o[0] * rs * g.x; o[1] = o[1] * rs * g.y; o[2] = o[2] * rs * g.z; o[3] = o[3] * rs * g.w;
+            }
+            const float4 r = ld4(a.res + row * H + c);
+            const float rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint64_t idx = (uint64_t)row * H + c + e;
+                o[e] = o[e] * (dp * kk_drop_mul(seed, a.d.site1, idx, t1, k1) * kk_drop_mul(seed, a.d.site2, idx, t2, k2)) + rr[e];
+            }
+            v[i] = make_float4(o[0], o[1], o[2], o[3]);
+            st4(a.x_out + row * H + c, v[i]);
+            s += o[0] + o[1] + o[2] + o[3];
+        }
+    }
+    if (!a.ln_gamma) return;
+    const float mean = wave_sum(s) / (float)H;
+    float qq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (lane * 4 + 256 * i < H) {
+            const float e0 = v[i].x - mean, e1 = v[i].y - mean, e2 = v[i].z - mean, e3 = v[i].w - mean;
+            qq += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+        }
+    }
+    const float rstd = 1.f / sqrtf(wave_sum(qq) / (float)H + 1e-5f);
+    TN *nr = static_cast<TN *>(a.n) + row * H;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < H) {
+            const float4 g = ld4(a.ln_gamma + c), b = ld4(a.ln_beta + c);
+            stv4<TN>(nr + c, make_float4((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
+                                         (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w));
+        }
+    }
+    if (lane == 0) {
+        a.mean[row] = mean;
+        a.rstd[row] = rstd;
+    }
+}
+
+template <typename TY, typename TN>
+void launch_subout(const SubOutArgs &a, hipStream_t s) {
+    const dim3 grid(kk_cdiv(a.rows, 4)), blk(256);
+    const int nv = kk_cdiv(a.H, 256);
+    if (nv <= 1) hipLaunchKernelGGL((sublayer_out_fwd_kernel<TY, TN, 1>), grid, blk, 0, s, a);
+    else if (nv <= 2) hipLaunchKernelGGL((sublayer_out_fwd_kernel<TY, TN, 2>), grid, blk, 0, s, a);
+    else if (nv <= 4) hipLaunchKernelGGL((sublayer_out_fwd_kernel<TY, TN, 4>), grid, blk, 0, s, a);
+    else hipLaunchKernelGGL((sublayer_out_fwd_kernel<TY, TN, 8>), grid, blk, 0, s, a);
 }
 
 // SpecAugment: per sample `nt` time masks of t in [0, time_limit) frames at t0 in [0, max(1, T - t)) and `nf`
@@ -109,6 +210,25 @@ extern "C" int kk_dropout_fwd(const float *x, const float *res, int64_t res_mod,
                               float dp_rate, void *stream) {
     return launch_dropout(x, res, res_mod, out, 0, rows, H, S, seed, site1, p1, site2, p2, site_dp, dp_rate, (hipStream_t)stream,
                           "kk_dropout_fwd");
+}
+
+extern "C" int kk_sublayer_out_fwd(const float *y, int y_bf16, const float *gain, float *rstd_f, const float *res, float *x_out,
+                                   const float *ln_gamma, const float *ln_beta, float *n, int n_bf16, float *mean, float *rstd,
+                                   int64_t rows, int H, int S, const uint32_t *seed, uint32_t site1, float p1, uint32_t site2,
+                                   float p2, uint32_t site_dp, float dp_rate, void *stream) {
+    KK_REQUIRE(y && res && x_out && seed && rows > 0 && H > 0 && H % 4 == 0 && H <= 2048 && S > 0, "kk_sublayer_out_fwd: bad args");
+    KK_REQUIRE(!gain || rstd_f, "kk_sublayer_out_fwd: the RMSNorm needs rstd_f");
+    KK_REQUIRE(!ln_gamma || (ln_beta && n && mean && rstd), "kk_sublayer_out_fwd: the LayerNorm needs beta, n, mean, rstd");
+    KK_REQUIRE(p1 >= 0.f && p1 < 1.f && p2 >= 0.f && p2 < 1.f && dp_rate >= 0.f && dp_rate < 1.f, "kk_sublayer_out_fwd: probabilities must be in [0,1)");
+    SubOutArgs a;
+    a.y = y; a.gain = gain; a.rstd_f = rstd_f; a.res = res; a.x_out = x_out; a.ln_gamma = ln_gamma; a.ln_beta = ln_beta; a.n = n;
+    a.mean = mean; a.rstd = rstd; a.rows = rows; a.H = H;
+    a.d = {seed, site1, site2, site_dp, p1, p2, dp_rate, S};
+    hipStream_t s = (hipStream_t)stream;
+    if (y_bf16) { if (n_bf16) launch_subout<__bf16, __bf16>(a, s); else launch_subout<__bf16, float>(a, s); }
+    else { if (n_bf16) launch_subout<float, __bf16>(a, s); else launch_subout<float, float>(a, s); }
+    KK_LAUNCH_CHECK("kk_sublayer_out_fwd");
+    return 0;
 }
 
 extern "C" int kk_dropout_bwd(const float *dy, float *dx, int64_t rows, int H, int S, const uint32_t *seed, uint32_t site1,

@@ -343,16 +343,28 @@ class KokoroEngine:
             return 0.0
         return (i / max(n - 1, 1)) * self.hp.stochastic_depth_rate
 
-    def _residual(self, y, x_res, x_out, S, site, p, dpr, p2=0.0):
-        """x_out = x_res + dropout_p(dropout_p2(drop_path(y))) through the mask kernel (p > 0 path)."""
-        kk.call("kk_dropout_fwd", y, x_res, 0, x_out, y.shape[0], y.shape[1], S, self.rng, site, p, site + 1, p2, site + 2, dpr)
+    def _sublayer_tail(self, y, x_res, x_out, S, site, p, dpr, p2, gain, rstd_f, next_ln):
+        """Fused tail of a sub-layer on the dropout path (kk_sublayer_out_fwd): x_out = x_res + masks * [RMSNorm](y), and
+        the LayerNorm `next_ln = (key, prefix, dtype)` of x_out when the caller names one; returns that LayerNorm's
+        output (else None)."""
+        P = self.arena.P
+        rows, H = y.shape
+        n = mean = rstd = g = b = None
+        if next_ln is not None:
+            key, prefix, dtype = next_ln
+            n, mean, rstd = self._buf(key + ".y", rows, H, dtype=dtype), self._buf(key + ".mean", rows), self._buf(key + ".rstd", rows)
+            g, b = P[prefix + ".weight"], P[prefix + ".bias"]
+        kk.call("kk_sublayer_out_fwd", y, _b16(y), gain, rstd_f, x_res, x_out, g, b, n, _b16(n), mean, rstd, rows, H, S, self.rng,
+                site, p, site + 1, p2, site + 2, dpr)
+        return n
 
     def _residual_bwd(self, dy, dx, S, site, p, dpr, p2=0.0):
         kk.call("kk_dropout_bwd", dy, dx, dy.shape[0], dy.shape[1], S, self.rng, site, p, site + 1, p2, site + 2, dpr, _b16(dx))
 
     # ------------------------------------------------------------------ attention sub-layer
-    def _attn_fwd(self, key, prefix, xq, xkv, B, Sq, Sk, rope, causal, key_mask, x_res, x_out, site=0, p=0.0, dpr=0.0):
-        """x_out = x_res + w_o(attention(...)) + b_o.  xq [B*Sq,H] (post-LN), xkv [B*Sk,H] (None = self-attention)."""
+    def _attn_fwd(self, key, prefix, xq, xkv, B, Sq, Sk, rope, causal, key_mask, x_res, x_out, site=0, p=0.0, dpr=0.0, next_ln=None):
+        """x_out = x_res + w_o(attention(...)) + b_o.  xq [B*Sq,H] (post-LN), xkv [B*Sk,H] (None = self-attention).
+        Returns LayerNorm_next_ln(x_out) when the fused dropout tail computed it, else None."""
         P, H, h = self.arena.P, self.dims.hidden, self.dims.heads
         Nq, Nk = B * Sq, B * Sk
         dt = xq.dtype                                   # storage of every activation of the sub-layer
@@ -378,9 +390,9 @@ class KokoroEngine:
         if p > 0.0 or dpr > 0.0:
             proj = self._buf("tmp.attn_proj", Nq, H)
             self._linear(ctx, self._W(prefix + ".w_o.weight"), P[prefix + ".w_o.bias"], proj)
-            self._residual(proj, x_res, x_out, Sq, site, p, dpr)
-        else:
-            self._linear(ctx, self._W(prefix + ".w_o.weight"), P[prefix + ".w_o.bias"], x_out, res=x_res)
+            return self._sublayer_tail(proj, x_res, x_out, Sq, site, p, dpr, 0.0, None, None, next_ln)
+        self._linear(ctx, self._W(prefix + ".w_o.weight"), P[prefix + ".w_o.bias"], x_out, res=x_res)
+        return None
 
     def _cross_kv_fwd(self, key, prefix, xkv, Nk, Sk, dt):
         """K/V projection + per-head RMSNorm of one cross-attention layer (no RoPE: transformers.py:268-277 applies it
@@ -452,7 +464,7 @@ class KokoroEngine:
         self._dgrad(dq_raw, self._W(prefix + ".w_q.weight"), d_xq)
 
     # ------------------------------------------------------------------ GLU feed-forward sub-layer
-    def _ffn_fwd(self, key, prefix, y, x_res, x_out, Fd, S=1, site=0, p=0.0, dpr=0.0):
+    def _ffn_fwd(self, key, prefix, y, x_res, x_out, Fd, S=1, site=0, p=0.0, dpr=0.0, next_ln=None):
         P = self.arena.P
         N, H = y.shape
         dt, i16 = y.dtype, _b16(y)
@@ -461,12 +473,11 @@ class KokoroEngine:
         self._linear(y, self._W(prefix + ".linear1.weight"), P[prefix + ".linear1.bias"], h1)
         kk.call("kk_glu_fwd", h1, g, N, Fd, self.rng, site + 4, p, i16)
         self._linear(g, self._W(prefix + ".linear2.weight"), P[prefix + ".linear2.bias"], f2)
-        if p > 0.0 or dpr > 0.0:      # rmsnorm -> FFN dropout (:111) -> drop_path -> residual dropout
-            nrm = self._buf("tmp.ffn_norm", N, H)
-            kk.call("kk_rmsnorm_fwd", f2, P[prefix + ".output_norm.weight"], None, nrm, self._buf(key + ".rstd_f", N), N, H, i16)
-            self._residual(nrm, x_res, x_out, S, site, p, dpr, p2=p)
-        else:
-            kk.call("kk_rmsnorm_fwd", f2, P[prefix + ".output_norm.weight"], x_res, x_out, self._buf(key + ".rstd_f", N), N, H, i16)
+        if p > 0.0 or dpr > 0.0:      # rmsnorm -> FFN dropout (:111) -> drop_path -> residual dropout (+ the next LayerNorm)
+            return self._sublayer_tail(f2, x_res, x_out, S, site, p, dpr, p, P[prefix + ".output_norm.weight"],
+                                       self._buf(key + ".rstd_f", N), next_ln)
+        kk.call("kk_rmsnorm_fwd", f2, P[prefix + ".output_norm.weight"], x_res, x_out, self._buf(key + ".rstd_f", N), N, H, i16)
+        return None
 
     def _ffn_bwd(self, key, prefix, d_out, y, d_y, Fd, S=1, site=0, p=0.0, dpr=0.0):
         P, G = self.arena.P, self.arena.G
@@ -558,18 +569,24 @@ class KokoroEngine:
         pe_drop, p_enc, p_dec, p_var = self._p(hp.encoder_dropout), self._p(hp.encoder_dropout), self._p(hp.decoder_dropout), self._p(hp.variance_dropout)
         kk.call("kk_embed_fwd", ids, stress, P["text_embedding.weight"], P["stress_embedding.weight"] if stress is not None else None,
                 pe, x, B, Pn, H, float(H ** 0.5), self.rng, 1, pe_drop)
-        for i in range(d.enc_layers):
+        y1 = None                                         # LayerNorm outputs come from the previous sub-layer's fused tail
+        for i in range(d.enc_layers):                     # when dropout is on, from _ln_fwd otherwise
             pf, key, st = f"transformer_encoder_layers.{i}", f"enc{i}", 1000 + 32 * i
             dpr = self._dpr(i, d.enc_layers)
-            y1 = self._ln_fwd(key + ".ln1", x, pf + ".norm1", edt)
+            if y1 is None:
+                y1 = self._ln_fwd(key + ".ln1", x, pf + ".norm1", edt)
             xm = self._buf(key + ".xm", Ne, H)
-            self._attn_fwd(key + ".sa", pf + ".self_attn", y1, None, B, Pn, Pn, True, False, text_mask, x, xm, st, p_enc, dpr)
-            y2 = self._ln_fwd(key + ".ln2", xm, pf + ".norm2", edt)
+            y2 = self._attn_fwd(key + ".sa", pf + ".self_attn", y1, None, B, Pn, Pn, True, False, text_mask, x, xm, st, p_enc, dpr,
+                                next_ln=(key + ".ln2", pf + ".norm2", edt))
+            if y2 is None:
+                y2 = self._ln_fwd(key + ".ln2", xm, pf + ".norm2", edt)
             xo = self._buf(key + ".xo", Ne, H)
-            self._ffn_fwd(key + ".ff", pf + ".ff", y2, xm, xo, d.enc_ff, Pn, st + 8, p_enc, dpr)
+            nxt = ((f"enc{i + 1}.ln1", f"transformer_encoder_layers.{i + 1}.norm1", edt) if i + 1 < d.enc_layers
+                   else ("enc.norm", "encoder_norm", torch.float32))
+            y1 = self._ffn_fwd(key + ".ff", pf + ".ff", y2, xm, xo, d.enc_ff, Pn, st + 8, p_enc, dpr, next_ln=nxt)
             x = xo
         enc_last = x
-        enc = self._ln_fwd("enc.norm", enc_last, "encoder_norm")
+        enc = y1 if y1 is not None else self._ln_fwd("enc.norm", enc_last, "encoder_norm")
 
         # ---- variance adaptor (variance_predictor.py:338-439) ----
         dur_pred = self._buf("out.log_dur", B, Pn)
@@ -612,23 +629,31 @@ class KokoroEngine:
             kk.call("kk_dropout_fwd", t1, None, 0, y, Nd, H, T, self.rng, 31, pe_drop, 0, 0.0, 0, 0.0)
         else:
             self._linear(shifted, self._W("mel_projection_in.weight"), P["mel_projection_in.bias"], y, res=pe, res_mod=T)
+        n1 = None
         for i in range(d.dec_layers):
             pf, key, st = f"decoder.layers.{i}", f"dec{i}", 2000 + 32 * i
             dpr = self._dpr(i, d.dec_layers)
-            n1 = self._ln_fwd(key + ".ln1", y, pf + ".norm1", ddt)
+            if n1 is None:
+                n1 = self._ln_fwd(key + ".ln1", y, pf + ".norm1", ddt)
             ya = self._buf(key + ".xa", Nd, H)
-            self._attn_fwd(key + ".sa", pf + ".self_attn", n1, None, B, T, T, True, True, None, y, ya, st, p_dec, dpr)
-            n2 = self._ln_fwd(key + ".ln2", ya, pf + ".norm2", ddt)
+            n2 = self._attn_fwd(key + ".sa", pf + ".self_attn", n1, None, B, T, T, True, True, None, y, ya, st, p_dec, dpr,
+                                next_ln=(key + ".ln2", pf + ".norm2", ddt))
+            if n2 is None:
+                n2 = self._ln_fwd(key + ".ln2", ya, pf + ".norm2", ddt)
             if i == 0:
                 self._join(self._kv)
             yc = self._buf(key + ".xc", Nd, H)
-            self._attn_fwd(key + ".ca", pf + ".cross_attn", n2, memory, B, T, T, False, False, fmask, ya, yc, st + 8, p_dec, dpr)
-            n3 = self._ln_fwd(key + ".ln3", yc, pf + ".norm3", ddt)
+            n3 = self._attn_fwd(key + ".ca", pf + ".cross_attn", n2, memory, B, T, T, False, False, fmask, ya, yc, st + 8, p_dec, dpr,
+                                next_ln=(key + ".ln3", pf + ".norm3", ddt))
+            if n3 is None:
+                n3 = self._ln_fwd(key + ".ln3", yc, pf + ".norm3", ddt)
             yo = self._buf(key + ".xo", Nd, H)
-            self._ffn_fwd(key + ".ff", pf + ".ff", n3, yc, yo, d.dec_ff, T, st + 16, p_dec, dpr)
+            nxt = ((f"dec{i + 1}.ln1", f"decoder.layers.{i + 1}.norm1", ddt) if i + 1 < d.dec_layers
+                   else ("dec.norm", "decoder.norm", ddt))
+            n1 = self._ffn_fwd(key + ".ff", pf + ".ff", n3, yc, yo, d.dec_ff, T, st + 16, p_dec, dpr, next_ln=nxt)
             y = yo
         dec_last = y
-        dec_out = self._ln_fwd("dec.norm", dec_last, "decoder.norm", ddt)
+        dec_out = n1 if n1 is not None else self._ln_fwd("dec.norm", dec_last, "decoder.norm", ddt)
         mel_pred, stop = self._buf("out.mel", B, T, M), self._buf("out.stop", B, T)
         self._linear(dec_out, self._W("mel_projection_out.weight"), P["mel_projection_out.bias"], mel_pred.view(Nd, M))
         kk.call("kk_rowdot_fwd", dec_out, P["stop_token_predictor.weight"], P["stop_token_predictor.bias"], None, stop, Nd, H, T, 0,

@@ -90,6 +90,7 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_bucket_embed_add_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "kk_bucket_embed_add_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "kk_dropout_fwd": [_P, _P, _L, _P, _L, _I, _I, _P, _U, _F, _U, _F, _U, _F, _P],
+    "kk_sublayer_out_fwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _I, _I, _P, _U, _F, _U, _F, _U, _F, _P],
     "kk_dropout_bwd": [_P, _P, _L, _I, _I, _P, _U, _F, _U, _F, _U, _F, _I, _P],
     "kk_specaug": [_P, _I, _I, _I, _P, _U, _I, _I, _I, _I, _I, _P],
     "kk_ids_eq_zero": [_P, _P, _L, _P],

@@ -874,3 +874,44 @@ def test_norm_bwd_partials_and_reduce(kk, rows, H):
         (got if use_part else ref).extend([dx, dxr, dg, db, dgn])
     for a, b, n in zip(got, ref, ("ln dx", "rms dx", "dgamma", "dbeta", "dgain")):
         close(a, b, 2e-4, 1e-4, n)
+
+
+@pytest.mark.parametrize("ffn,ln,bf", [(1, 1, 1), (0, 1, 1), (1, 0, 0), (0, 1, 0)])
+def test_sublayer_tail_equals_separate_kernels(kk, ffn, ln, bf):
+    """kk_sublayer_out_fwd == kk_rmsnorm_fwd -> kk_dropout_fwd (residual, two dropouts, DropPath) -> kk_layernorm_fwd with
+    the same seed and call sites (identical masks)."""
+    g = torch.Generator().manual_seed(3 + ffn + 2 * ln)
+    rows, H, S = 203, 512, 29
+    y = dev(torch.randn(rows, H, generator=g))
+    if bf and ffn:
+        y = y.bfloat16()
+    res, gain = dev(torch.randn(rows, H, generator=g)), dev(1 + 0.1 * torch.randn(H, generator=g))
+    gam, bet = dev(1 + 0.1 * torch.randn(H, generator=g)), dev(0.1 * torch.randn(H, generator=g))
+    seed = torch.tensor([77], dtype=torch.int32, device="cuda")
+    p1, p2, dpr = 0.2, (0.2 if ffn else 0.0), 0.1
+    # separate kernels
+    t = y
+    rs_a = torch.zeros(rows, device="cuda")
+    if ffn:
+        t = torch.empty(rows, H, device="cuda")
+        kk.call("kk_rmsnorm_fwd", y, gain, None, t, rs_a, rows, H, 1 if y.dtype == torch.bfloat16 else 0)
+    xa = torch.empty(rows, H, device="cuda")
+    kk.call("kk_dropout_fwd", t, res, 0, xa, rows, H, S, seed, 40, p1, 41, p2, 42, dpr)
+    ndt = torch.bfloat16 if bf else torch.float32
+    na, ma, ra = torch.empty(rows, H, device="cuda", dtype=ndt), torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    if ln:
+        kk.call("kk_layernorm_fwd", xa, gam, bet, na, ma, ra, rows, H, 1 if bf else 0)
+    # fused
+    xb = torch.empty(rows, H, device="cuda")
+    nb, mb, rb, rs_b = torch.empty_like(na), torch.empty_like(ma), torch.empty_like(ra), torch.zeros(rows, device="cuda")
+    kk.call("kk_sublayer_out_fwd", y, 1 if y.dtype == torch.bfloat16 else 0, gain if ffn else None, rs_b if ffn else None, res, xb,
+            gam if ln else None, bet if ln else None, nb if ln else None, 1 if bf else 0, mb if ln else None, rb if ln else None,
+            rows, H, S, seed, 40, p1, 41, p2, 42, dpr)
+    close(xb, xa, 1e-6, 1e-6, "fused tail: residual stream")
+    assert float((xb - res).abs().min()) == 0.0 and 0.1 < float(((xb - res) == 0).float().mean()) < 0.7   # masks really applied
+    if ffn:
+        close(rs_b, rs_a, 1e-6, 1e-6, "fused tail: rms 1/rms")
+    if ln:
+        close(mb, ma, 1e-6, 1e-6, "fused tail: LN mean")
+        close(rb, ra, 1e-5, 1e-5, "fused tail: LN rstd")
+        close(nb, na, 2e-2 if bf else 1e-5, 1e-2 if bf else 1e-5, "fused tail: LN output")
