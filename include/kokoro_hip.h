@@ -90,10 +90,10 @@ int kk_layernorm_fwd(const float *x, const float *gamma, const float *beta, floa
  * gradient vectors in one launch (the engine does this once per step: the atomics were ~40 % of the kernel). */
 int kk_norm_bwd_blocks(int64_t rows, int H);
 typedef struct KkReduceDesc {
-    const float *src;   /* [nblocks][ncols] partial sums */
+    const float *src;   /* [nblocks][ncols] partial sums, rows `stride` floats apart (0: ncols) */
     float *dst0;        /* columns [0, split) are added to dst0[c] */
     float *dst1;        /* columns [split, ncols) to dst1[c - split] */
-    int nblocks, ncols, split;
+    int nblocks, ncols, split, stride;
 } KkReduceDesc;
 int kk_partials_reduce(const KkReduceDesc *descs /* device memory */, int n, int max_cols, void *stream);
 int kk_layernorm_bwd(const float *dy, const float *x, const float *gamma, const float *mean,
@@ -188,6 +188,16 @@ int kk_sublayer_out_fwd(const float *y, int y_bf16, const float *gain, float *rs
                         const float *ln_gamma, const float *ln_beta, float *n, int n_bf16, float *mean, float *rstd,
                         int64_t rows, int H, int S, const uint32_t *seed, uint32_t site1, float p1, uint32_t site2,
                         float p2, uint32_t site_dp, float dp_rate, void *stream);
+/* Backward of kk_sublayer_out_fwd, fused with what follows it in the backward pass: dres (+)= LayerNorm_bwd(dn); dz = dres *
+ * masks; dy = RMSNorm_bwd(dz) (gain != NULL, FFN) or dz (attention output projection).  The column reductions go to
+ * partials[kk_sublayer_in_bwd_blocks(rows)][4][H] = (dgamma | dbeta | column sums of dy | dgain) for kk_partials_reduce
+ * (row stride 4H).  Replaces kk_layernorm_bwd + kk_dropout_bwd (+ kk_rmsnorm_bwd) + kk_colsum_acc. */
+int kk_sublayer_in_bwd_blocks(int64_t rows);
+int kk_sublayer_in_bwd(const float *dn, int dn_bf16, const float *x_out, const float *ln_gamma, const float *mean,
+                       const float *rstd, float *dres, int accumulate, const float *y, const float *gain,
+                       const float *rstd_f, float *dy, int y_bf16, float *partials, int64_t rows, int H, int S,
+                       const uint32_t *seed, uint32_t site1, float p1, uint32_t site2, float p2, uint32_t site_dp,
+                       float dp_rate, void *stream);
 int kk_dropout_bwd(const float *dy, float *dx, int64_t rows, int H, int S, const uint32_t *seed, uint32_t site1,
                    float p1, uint32_t site2, float p2, uint32_t site_dp, float dp_rate, int dx_bf16, void *stream);
 /* SpecAugment on the cross-attention memory, in place (trainer.py:1577-1604); call again on the memory gradient. */

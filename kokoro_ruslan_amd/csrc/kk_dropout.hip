@@ -152,6 +152,137 @@ void launch_subout(const SubOutArgs &a, hipStream_t s) {
     else hipLaunchKernelGGL((sublayer_out_fwd_kernel<TY, TN, 8>), grid, blk, 0, s, a);
 }
 
+// ---- fused sub-layer tail (backward) ------------------------------------------------------------------------------
+// The exact reverse of sublayer_out_fwd_kernel, one wave per row:
+//   g   = (accumulate ? dres : 0) + LayerNorm_backward(dn; x_out, gamma, mean, rstd)      -> dres (gradient of the stream)
+//   dz  = g * (the forward's masks)                                                        (kk_dropout_bwd)
+//   FFN : dy = RMSNorm_backward(dz; y, gain, rstd_f)  (kk_rmsnorm_bwd)      attention: dy = dz
+// and the four column reductions of the tail — LayerNorm gain / bias, RMSNorm gain, and the column sums of dy (the bias
+// gradient of the Linear that produced y) — leave the workgroup as one row of partials[blockIdx.x][4][H]
+// (dgamma | dbeta | dbias | dgain) for kk_partials_reduce.  Replaces 3-4 launches per sub-layer.
+struct SubInArgs {
+    const void *dn;                // gradient of the LayerNorm output (TN)
+    const float *x_out, *ln_gamma, *mean, *rstd;
+    float *dres;                   // residual-stream gradient, updated in place
+    int accumulate;
+    const void *y;                 // FFN: the RMSNorm input saved by the forward (TY); attention: unused
+    const float *gain, *rstd_f;    // FFN only (gain == nullptr: attention)
+    void *dy;                      // out (TY): gradient of y
+    float *partials;               // [gridDim.x][4][H]
+    int64_t rows;
+    int H;
+    DropArgs d;
+};
+
+template <typename TN, typename TY, int NV>
+__global__ __launch_bounds__(256) void sublayer_in_bwd_kernel(SubInArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [4 waves][4][H]: per-wave column sums, no LDS atomics
+    const int lane = threadIdx.x & 63, H = a.H;
+    const uint32_t seed = *a.d.seed;
+    const uint32_t t1 = kk_drop_threshold(a.d.p1), t2 = kk_drop_threshold(a.d.p2);
+    const float k1 = a.d.p1 > 0.f ? 1.f / (1.f - a.d.p1) : 1.f, k2 = a.d.p2 > 0.f ? 1.f / (1.f - a.d.p2) : 1.f;
+    const bool ffn = a.gain != nullptr;
+    float4 ag[NV], ab[NV], ac[NV], an[NV], gm[NV], gn[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        ag[i] = ab[i] = ac[i] = an[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        gm[i] = c < H ? ld4(a.ln_gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        gn[i] = (ffn && c < H) ? ld4(a.gain + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float invH = 1.f / (float)H;
+    const TN *dn = static_cast<const TN *>(a.dn);
+    const TY *yy = static_cast<const TY *>(a.y);
+    TY *dy = static_cast<TY *>(a.dy);
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < a.rows; row += (int64_t)gridDim.x * 4) {
+        const float mu = a.mean[row], rs = a.rstd[row], rsf = ffn ? a.rstd_f[row] : 0.f;
+        float4 xh[NV], dg[NV], old[NV], yv[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {                     // all loads of the row first
+            const int c = lane * 4 + 256 * i;
+            const bool ok = c < H;
+            xh[i] = ok ? ld4(a.x_out + row * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            dg[i] = ok ? ldv4<TN>(dn + row * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            old[i] = (ok && a.accumulate) ? ld4(a.dres + row * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            yv[i] = (ok && ffn) ? ldv4<TY>(yy + row * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float4 d = dg[i];
+            float4 &x = xh[i];
+            x = make_float4((x.x - mu) * rs, (x.y - mu) * rs, (x.z - mu) * rs, (x.w - mu) * rs);
+            if (lane * 4 + 256 * i >= H) x = make_float4(0.f, 0.f, 0.f, 0.f);
+            ag[i].x += d.x * x.x; ag[i].y += d.y * x.y; ag[i].z += d.z * x.z; ag[i].w += d.w * x.w;
+            ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+            dg[i] = make_float4(d.x * gm[i].x, d.y * gm[i].y, d.z * gm[i].z, d.w * gm[i].w);
+            s1 += dg[i].x + dg[i].y + dg[i].z + dg[i].w;
+            s2 += dg[i].x * x.x + dg[i].y * x.y + dg[i].z * x.z + dg[i].w * x.w;
+        }
+        s1 = wave_sum(s1) * invH;
+        s2 = wave_sum(s2) * invH;
+        const float dp = row_scale(a.d, seed, row);
+        float sk = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane * 4 + 256 * i;
+            if (c < H) {
+                float g[4] = {old[i].x + rs * (dg[i].x - s1 - xh[i].x * s2), old[i].y + rs * (dg[i].y - s1 - xh[i].y * s2),
+                              old[i].z + rs * (dg[i].z - s1 - xh[i].z * s2), old[i].w + rs * (dg[i].w - s1 - xh[i].w * s2)};
+                st4(a.dres + row * H + c, make_float4(g[0], g[1], g[2], g[3]));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint64_t idx = (uint64_t)row * H + c + e;
+                    g[e] *= dp * kk_drop_mul(seed, a.d.site1, idx, t1, k1) * kk_drop_mul(seed, a.d.site2, idx, t2, k2);
+                }
+                if (ffn) {                                  // dz -> RMSNorm backward (second pass below needs the row sum)
+                    const float4 y4 = yv[i];
+                    an[i].x += g[0] * y4.x * rsf; an[i].y += g[1] * y4.y * rsf; an[i].z += g[2] * y4.z * rsf; an[i].w += g[3] * y4.w * rsf;
+                    g[0] *= gn[i].x; g[1] *= gn[i].y; g[2] *= gn[i].z; g[3] *= gn[i].w;
+                    sk += g[0] * y4.x + g[1] * y4.y + g[2] * y4.z + g[3] * y4.w;
+                }
+                dg[i] = make_float4(g[0], g[1], g[2], g[3]);     // reuse: dz (attention) or dz*gain (FFN)
+            }
+        }
+        const float k = ffn ? wave_sum(sk) * invH * rsf * rsf * rsf : 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane * 4 + 256 * i;
+            if (c < H) {
+                float4 o = dg[i];
+                if (ffn) o = make_float4(rsf * o.x - yv[i].x * k, rsf * o.y - yv[i].y * k, rsf * o.z - yv[i].z * k, rsf * o.w - yv[i].w * k);
+                stv4<TY>(dy + row * H + c, o);
+                ac[i].x += o.x; ac[i].y += o.y; ac[i].z += o.z; ac[i].w += o.w;
+            }
+        }
+    }
+    float *mine = sm + (threadIdx.x >> 6) * 4 * H;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < H) {
+            st4(mine + c, ag[i]); st4(mine + H + c, ab[i]); st4(mine + 2 * H + c, ac[i]); st4(mine + 3 * H + c, an[i]);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x * 4; c < 4 * H; c += 1024) {
+        const float4 w0 = ld4(sm + c), w1 = ld4(sm + 4 * H + c), w2 = ld4(sm + 8 * H + c), w3 = ld4(sm + 12 * H + c);
+        st4(a.partials + (int64_t)blockIdx.x * 4 * H + c,
+            make_float4(w0.x + w1.x + w2.x + w3.x, w0.y + w1.y + w2.y + w3.y, w0.z + w1.z + w2.z + w3.z, w0.w + w1.w + w2.w + w3.w));
+    }
+}
+
+template <typename TN, typename TY>
+void launch_subin(const SubInArgs &a, int blocks, hipStream_t s) {
+    const dim3 grid(blocks), blk(256);
+    const size_t shm = (size_t)16 * a.H * sizeof(float);
+    const int nv = kk_cdiv(a.H, 256);
+    if (nv <= 1) hipLaunchKernelGGL((sublayer_in_bwd_kernel<TN, TY, 1>), grid, blk, shm, s, a);
+    else if (nv <= 2) hipLaunchKernelGGL((sublayer_in_bwd_kernel<TN, TY, 2>), grid, blk, shm, s, a);
+    else if (nv <= 4) hipLaunchKernelGGL((sublayer_in_bwd_kernel<TN, TY, 4>), grid, blk, shm, s, a);
+    else hipLaunchKernelGGL((sublayer_in_bwd_kernel<TN, TY, 8>), grid, blk, shm, s, a);
+}
+
 // SpecAugment: per sample `nt` time masks of t in [0, time_limit) frames at t0 in [0, max(1, T - t)) and `nf`
 // feature masks of f in [0, max(1, fmax)) dims at f0 in [0, max(1, H - f)); masked positions are zeroed (in place).
 template <typename TX>
@@ -228,6 +359,31 @@ extern "C" int kk_sublayer_out_fwd(const float *y, int y_bf16, const float *gain
     if (y_bf16) { if (n_bf16) launch_subout<__bf16, __bf16>(a, s); else launch_subout<__bf16, float>(a, s); }
     else { if (n_bf16) launch_subout<float, __bf16>(a, s); else launch_subout<float, float>(a, s); }
     KK_LAUNCH_CHECK("kk_sublayer_out_fwd");
+    return 0;
+}
+
+extern "C" int kk_sublayer_in_bwd_blocks(int64_t rows) {
+    int blocks = kk_cdiv(rows, 16);                       // four rows per wave: the column-sum epilogue is per workgroup
+    return blocks > 256 ? 256 : (blocks < 1 ? 1 : blocks);
+}
+
+extern "C" int kk_sublayer_in_bwd(const float *dn, int dn_bf16, const float *x_out, const float *ln_gamma, const float *mean,
+                                  const float *rstd, float *dres, int accumulate, const float *y, const float *gain,
+                                  const float *rstd_f, float *dy, int y_bf16, float *partials, int64_t rows, int H, int S,
+                                  const uint32_t *seed, uint32_t site1, float p1, uint32_t site2, float p2, uint32_t site_dp,
+                                  float dp_rate, void *stream) {
+    KK_REQUIRE(dn && x_out && ln_gamma && mean && rstd && dres && dy && partials && seed && rows > 0 && H > 0 && H % 4 == 0 &&
+                   H <= 2048 && S > 0, "kk_sublayer_in_bwd: bad args");
+    KK_REQUIRE(!gain || (y && rstd_f), "kk_sublayer_in_bwd: the RMSNorm backward needs y and rstd_f");
+    SubInArgs a;
+    a.dn = dn; a.x_out = x_out; a.ln_gamma = ln_gamma; a.mean = mean; a.rstd = rstd; a.dres = dres; a.accumulate = accumulate;
+    a.y = y; a.gain = gain; a.rstd_f = rstd_f; a.dy = dy; a.partials = partials; a.rows = rows; a.H = H;
+    a.d = {seed, site1, site2, site_dp, p1, p2, dp_rate, S};
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = kk_sublayer_in_bwd_blocks(rows);
+    if (dn_bf16) { if (y_bf16) launch_subin<__bf16, __bf16>(a, blocks, s); else launch_subin<__bf16, float>(a, blocks, s); }
+    else { if (y_bf16) launch_subin<float, __bf16>(a, blocks, s); else launch_subin<float, float>(a, blocks, s); }
+    KK_LAUNCH_CHECK("kk_sublayer_in_bwd");
     return 0;
 }
 

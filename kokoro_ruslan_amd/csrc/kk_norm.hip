@@ -272,8 +272,9 @@ __global__ __launch_bounds__(256) void partials_reduce_kernel(const KkReduceDesc
     float s = 0.f;
     if (c < d.ncols) {
         const float *p = d.src + c;
+        const int64_t stride = d.stride > 0 ? d.stride : d.ncols;
 #pragma unroll 8
-        for (int r = rg; r < d.nblocks; r += 4) s += p[(int64_t)r * d.ncols];
+        for (int r = rg; r < d.nblocks; r += 4) s += p[(int64_t)r * stride];
     }
     red[rg][threadIdx.x & 63] = s;
     __syncthreads();

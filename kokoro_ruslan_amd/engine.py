@@ -322,14 +322,43 @@ class KokoroEngine:
         kk.call("kk_layernorm_bwd", dy, x, P[prefix + ".weight"], self._buf(key + ".mean", rows), self._buf(key + ".rstd", rows),
                 dx, 1 if accumulate else 0, G[prefix + ".weight"], G[prefix + ".bias"], part, rows, H, _b16(dy))
 
+    def _tail_bwd(self, key, dn, x, prefix, dres, accumulate, head) -> bool:
+        """Backward of LayerNorm `key` (input x = the residual stream after the sub-layer `head`), fused — when that
+        sub-layer ran its dropout tail — with the head of the sub-layer's own backward (kk_sublayer_in_bwd): masks,
+        RMSNorm backward for an FFN, bias column sums.  head = (kind, ffn_key, prefix, S, site, p, dpr, dtype).
+        Returns True when the head was done here (the sub-layer's backward then starts from the prepared buffers)."""
+        kind, hkey, hprefix, S, site, p, dpr, dt = head
+        if not (p > 0.0 or dpr > 0.0):
+            self._ln_bwd(key, dn, x, prefix, dres, accumulate)
+            return False
+        P, G = self.arena.P, self.arena.G
+        rows, H = x.shape
+        nb = kk.load().kk_sublayer_in_bwd_blocks(rows)
+        part = self._buf(key + ".tpart", nb, 4 * H)
+        self._reduce_list.append((part, G[prefix + ".weight"], G[prefix + ".bias"], nb, 2 * H, H, 4 * H))
+        if kind == "ffn":
+            f2, gain = self._buf(hkey + ".f2", rows, H, dtype=dt), P[hprefix + ".output_norm.weight"]
+            rstd_f, dy = self._buf(hkey + ".rstd_f", rows), self._buf("tmp.df2", rows, H, dtype=dt)
+            self._reduce_list.append((part[:, 2 * H:], G[hprefix + ".linear2.bias"], G[hprefix + ".output_norm.weight"], nb, 2 * H, H, 4 * H))
+            p2 = p
+        else:
+            f2 = gain = rstd_f = None
+            dy = self._buf("tmp.d_attn_proj", rows, H, dtype=dt)
+            self._reduce_list.append((part[:, 2 * H:], G[hprefix + ".w_o.bias"], None, nb, H, H, 4 * H))
+            p2 = 0.0
+        kk.call("kk_sublayer_in_bwd", dn, _b16(dn), x, P[prefix + ".weight"], self._buf(key + ".mean", rows), self._buf(key + ".rstd", rows),
+                dres, 1 if accumulate else 0, f2, gain, rstd_f, dy, _b16(dy), part, rows, H, S, self.rng, site, p, site + 1, p2,
+                site + 2, dpr)
+        return True
+
     def _reduce_partials(self, shape_key) -> None:
         if not self._reduce_list:
             return
-        ent = self._reduce_tables.get(shape_key)
+        tkey = (shape_key, tuple(e[0].data_ptr() for e in self._reduce_list))      # which partial matrices this pass wrote
+        ent = self._reduce_tables.get(tkey)
         if ent is None:                               # workspace addresses are stable per batch shape: build the table once
             ent = (kk.reduce_table(self._reduce_list, self.device), len(self._reduce_list), max(e[4] for e in self._reduce_list))
-            self._reduce_tables[shape_key] = ent
-        assert ent[1] == len(self._reduce_list)
+            self._reduce_tables[tkey] = ent
         kk.call("kk_partials_reduce", ent[0], ent[1], ent[2])
         self._reduce_list = []
 
@@ -404,7 +433,7 @@ class KokoroEngine:
                 P[prefix + ".v_norm.weight"], None, 0, None, None, _b16(kv_raw))
 
     def _attn_bwd(self, key, prefix, d_out, xq, xkv, B, Sq, Sk, rope, causal, key_mask, d_xq, d_xkv, d_xkv_beta,
-                  site=0, p=0.0, dpr=0.0):
+                  site=0, p=0.0, dpr=0.0, head_done=False):
         """Given d_out = dL/d(sub-layer output, pre-residual), accumulate parameter grads, write d_xq (dL/d xq) and,
         for cross-attention, d_xkv (+= when d_xkv_beta == 1)."""
         a, P, G, H, h = self.arena, self.arena.P, self.arena.G, self.dims.hidden, self.dims.heads
@@ -416,11 +445,13 @@ class KokoroEngine:
         # cross-attention: dctx / delta are read by the K/V branch on its own stream, so each layer keeps its own
         ck = "tmp" if xkv is None else key
         dctx, delta = self._buf(ck + ".dctx", Nq, H, dtype=dt), self._buf(ck + ".delta", B, h, Sq)
-        if p > 0.0 or dpr > 0.0:
+        if head_done:                                     # _tail_bwd already wrote the masked gradient and the bias sums
+            d_out = self._buf("tmp.d_attn_proj", Nq, H, dtype=dt)
+        elif p > 0.0 or dpr > 0.0:
             masked = self._buf("tmp.d_attn_proj", Nq, H, dtype=dt)    # bf16 in the bf16 mode: operand of two GEMMs
             self._residual_bwd(d_out, masked, Sq, site, p, dpr)
             d_out = masked
-        self._wgrad(d_out, ctx, G[prefix + ".w_o.weight"], G[prefix + ".w_o.bias"])
+        self._wgrad(d_out, ctx, G[prefix + ".w_o.weight"], None if head_done else G[prefix + ".w_o.bias"])
         self._dgrad(d_out, self._W(prefix + ".w_o.weight"), dctx)
         kk.call("kk_attn_delta", ctx, dctx, delta, B, h, Sq, H, H, i16)
         if xkv is None:
@@ -479,7 +510,7 @@ class KokoroEngine:
         kk.call("kk_rmsnorm_fwd", f2, P[prefix + ".output_norm.weight"], x_res, x_out, self._buf(key + ".rstd_f", N), N, H, i16)
         return None
 
-    def _ffn_bwd(self, key, prefix, d_out, y, d_y, Fd, S=1, site=0, p=0.0, dpr=0.0):
+    def _ffn_bwd(self, key, prefix, d_out, y, d_y, Fd, S=1, site=0, p=0.0, dpr=0.0, head_done=False):
         P, G = self.arena.P, self.arena.G
         N, H = y.shape
         dt, i16 = y.dtype, _b16(y)
@@ -487,14 +518,15 @@ class KokoroEngine:
                      self._buf(key + ".f2", N, H, dtype=dt))
         df2, dg, dh1 = (self._buf("tmp.df2", N, H, dtype=dt), self._buf("tmp.dg", N, Fd, dtype=dt),
                         self._buf("tmp.dh1", N, 2 * Fd, dtype=dt))
-        if p > 0.0 or dpr > 0.0:
-            masked = self._buf("tmp.d_ffn_norm", N, H)
-            self._residual_bwd(d_out, masked, S, site, p, dpr, p2=p)
-            d_out = masked
-        part = self._partials(key + ".on", N, H, H, G[prefix + ".output_norm.weight"], None, H)
-        kk.call("kk_rmsnorm_bwd", d_out, f2, P[prefix + ".output_norm.weight"], self._buf(key + ".rstd_f", N), df2,
-                G[prefix + ".output_norm.weight"], part, N, H, i16)
-        self._wgrad(df2, g, G[prefix + ".linear2.weight"], G[prefix + ".linear2.bias"])
+        if not head_done:                                 # else _tail_bwd already produced df2 (masks + RMSNorm backward + bias sums)
+            if p > 0.0 or dpr > 0.0:
+                masked = self._buf("tmp.d_ffn_norm", N, H)
+                self._residual_bwd(d_out, masked, S, site, p, dpr, p2=p)
+                d_out = masked
+            part = self._partials(key + ".on", N, H, H, G[prefix + ".output_norm.weight"], None, H)
+            kk.call("kk_rmsnorm_bwd", d_out, f2, P[prefix + ".output_norm.weight"], self._buf(key + ".rstd_f", N), df2,
+                    G[prefix + ".output_norm.weight"], part, N, H, i16)
+        self._wgrad(df2, g, G[prefix + ".linear2.weight"], None if head_done else G[prefix + ".linear2.bias"])
         self._dgrad(df2, self._W(prefix + ".linear2.weight"), dg)
         kk.call("kk_glu_bwd", dg, h1, dh1, N, Fd, self.rng, site + 4, p, i16)
         self._wgrad(dh1, y, G[prefix + ".linear1.weight"], G[prefix + ".linear1.bias"])
@@ -687,7 +719,10 @@ class KokoroEngine:
             d_enc = self._buf("g.enc_out", Ne, H)
             self._varpred_bwd("vp.dur", f"{VA}.duration_predictor", ddur, enc, col_e, B, Pn, text_mask, d_enc, p_var)
             dx = self._buf("g.enc_stream", Ne, H)
-            self._ln_bwd("enc.norm", d_enc, enc_last, "encoder_norm", dx, accumulate=False)
+            # every LayerNorm's backward is fused with the head of the backward of the sub-layer that produced its input
+            ehead = lambda kind, i: (kind, f"enc{i}.ff", f"transformer_encoder_layers.{i}" + (".ff" if kind == "ffn" else ".self_attn"),
+                                     Pn, 1000 + 32 * i + (8 if kind == "ffn" else 0), p_enc, self._dpr(i, d.enc_layers), edt)
+            hd = self._tail_bwd("enc.norm", d_enc, enc_last, "encoder_norm", dx, False, ehead("ffn", d.enc_layers - 1))
             dne = self._buf("tmp.dne", Ne, H, dtype=edt)
             for i in reversed(range(d.enc_layers)):
                 pf, key, st = f"transformer_encoder_layers.{i}", f"enc{i}", 1000 + 32 * i
@@ -695,11 +730,14 @@ class KokoroEngine:
                 x_in = self._buf(f"enc{i - 1}.xo", Ne, H) if i > 0 else self._buf("enc.x0", Ne, H)
                 xm = self._buf(key + ".xm", Ne, H)
                 y1, y2 = self._buf(key + ".ln1.y", Ne, H, dtype=edt), self._buf(key + ".ln2.y", Ne, H, dtype=edt)
-                self._ffn_bwd(key + ".ff", pf + ".ff", dx, y2, dne, d.enc_ff, Pn, st + 8, p_enc, dpr)
-                self._ln_bwd(key + ".ln2", dne, xm, pf + ".norm2", dx, accumulate=True)
+                self._ffn_bwd(key + ".ff", pf + ".ff", dx, y2, dne, d.enc_ff, Pn, st + 8, p_enc, dpr, head_done=hd)
+                hd = self._tail_bwd(key + ".ln2", dne, xm, pf + ".norm2", dx, True, ehead("attn", i))
                 self._attn_bwd(key + ".sa", pf + ".self_attn", dx, y1, None, B, Pn, Pn, True, False, text_mask, dne, None, 0.0,
-                               st, p_enc, dpr)
-                self._ln_bwd(key + ".ln1", dne, x_in, pf + ".norm1", dx, accumulate=True)
+                               st, p_enc, dpr, head_done=hd)
+                if i > 0:
+                    hd = self._tail_bwd(key + ".ln1", dne, x_in, pf + ".norm1", dx, True, ehead("ffn", i - 1))
+                else:
+                    self._ln_bwd(key + ".ln1", dne, x_in, pf + ".norm1", dx, accumulate=True)
             kk.call("kk_embed_bwd", ids, stress, dx, G["text_embedding.weight"],
                     G["stress_embedding.weight"] if stress is not None else None, B, Pn, H, float(H ** 0.5), self.rng, 1, pe_drop)
         # heads (model.py:561-562): the stop head's input is detached
@@ -709,7 +747,11 @@ class KokoroEngine:
         self._wgrad(dmel.view(Nd, M), dec_out, G["mel_projection_out.weight"], G["mel_projection_out.bias"])
         self._dgrad(dmel.view(Nd, M), self._W("mel_projection_out.weight"), d_dec_out)
         dy = self._buf("g.dec_stream", Nd, H)          # gradient of the decoder residual stream, updated in place
-        self._ln_bwd("dec.norm", d_dec_out, dec_last, "decoder.norm", dy, accumulate=False)
+        def dhead(kind, i):                            # (kind, ffn buffer key, parameter prefix, S, site, p, drop-path, dtype)
+            sub = {"ffn": (".ff", 16), "ca": (".cross_attn", 8), "sa": (".self_attn", 0)}[kind]
+            return ("ffn" if kind == "ffn" else "attn", f"dec{i}.ff", f"decoder.layers.{i}" + sub[0], T, 2000 + 32 * i + sub[1],
+                    p_dec, self._dpr(i, d.dec_layers), ddt)
+        hd = self._tail_bwd("dec.norm", d_dec_out, dec_last, "decoder.norm", dy, False, dhead("ffn", d.dec_layers - 1))
         dmem = self._buf("g.memory", Nd, H)
         dn = self._buf("tmp.dn", Nd, H, dtype=ddt)
         first_mem = True
@@ -719,14 +761,18 @@ class KokoroEngine:
             x_in = self._buf(f"dec{i - 1}.xo", Nd, H) if i > 0 else self._buf("dec.x0", Nd, H)
             ya, yc = self._buf(key + ".xa", Nd, H), self._buf(key + ".xc", Nd, H)
             n1, n2, n3 = (self._buf(f"{key}.ln{j}.y", Nd, H, dtype=ddt) for j in (1, 2, 3))
-            self._ffn_bwd(key + ".ff", pf + ".ff", dy, n3, dn, d.dec_ff, T, st + 16, p_dec, dpr)
-            self._ln_bwd(key + ".ln3", dn, yc, pf + ".norm3", dy, accumulate=True)
+            self._ffn_bwd(key + ".ff", pf + ".ff", dy, n3, dn, d.dec_ff, T, st + 16, p_dec, dpr, head_done=hd)
+            hd = self._tail_bwd(key + ".ln3", dn, yc, pf + ".norm3", dy, True, dhead("ca", i))
             self._attn_bwd(key + ".ca", pf + ".cross_attn", dy, n2, memory, B, T, T, False, False, fmask, dn, dmem,
-                           0.0 if first_mem else 1.0, st + 8, p_dec, dpr)
+                           0.0 if first_mem else 1.0, st + 8, p_dec, dpr, head_done=hd)
             first_mem = False
-            self._ln_bwd(key + ".ln2", dn, ya, pf + ".norm2", dy, accumulate=True)
-            self._attn_bwd(key + ".sa", pf + ".self_attn", dy, n1, None, B, T, T, True, True, None, dn, None, 0.0, st, p_dec, dpr)
-            self._ln_bwd(key + ".ln1", dn, x_in, pf + ".norm1", dy, accumulate=True)
+            hd = self._tail_bwd(key + ".ln2", dn, ya, pf + ".norm2", dy, True, dhead("sa", i))
+            self._attn_bwd(key + ".sa", pf + ".self_attn", dy, n1, None, B, T, T, True, True, None, dn, None, 0.0, st, p_dec, dpr,
+                           head_done=hd)
+            if i > 0:
+                hd = self._tail_bwd(key + ".ln1", dn, x_in, pf + ".norm1", dy, True, dhead("ffn", i - 1))
+            else:
+                self._ln_bwd(key + ".ln1", dn, x_in, pf + ".norm1", dy, accumulate=True)
         # decoder input projection (the PE add and the shift are parameter-free; mel is data)
         if self.train_dropout and (p_din > 0.0 or pe_drop > 0.0):
             t1, dlin = self._buf("tmp.d_dec_t1", Nd, H), self._buf("tmp.d_dec_lin", Nd, H)

@@ -44,15 +44,15 @@ _P, _I, _L, _F, _D, _U = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, 
 # name -> argtypes, in header order (tests/test_abi.py cross-checks arity against include/kokoro_hip.h)
 class KkReduceDesc(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst0", C.c_void_p), ("dst1", C.c_void_p), ("nblocks", C.c_int), ("ncols", C.c_int),
-                ("split", C.c_int)]
+                ("split", C.c_int), ("stride", C.c_int)]
 
 
 def reduce_table(entries, device) -> "torch.Tensor":
-    """Device copy of a KkReduceDesc array from [(src, dst0, dst1 | None, nblocks, ncols, split)] of tensors/ints."""
+    """Device copy of a KkReduceDesc array from [(src, dst0, dst1 | None, nblocks, ncols, split[, row stride])]."""
     arr = (KkReduceDesc * len(entries))()
-    for d, (src, dst0, dst1, nb, nc, split) in zip(arr, entries):
+    for d, (src, dst0, dst1, nb, nc, split, *rest) in zip(arr, entries):
         d.src, d.dst0, d.dst1 = src.data_ptr(), dst0.data_ptr(), (dst1.data_ptr() if dst1 is not None else 0)
-        d.nblocks, d.ncols, d.split = nb, nc, split
+        d.nblocks, d.ncols, d.split, d.stride = nb, nc, split, (rest[0] if rest else 0)
     return torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
 
 
@@ -91,6 +91,8 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_bucket_embed_add_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "kk_dropout_fwd": [_P, _P, _L, _P, _L, _I, _I, _P, _U, _F, _U, _F, _U, _F, _P],
     "kk_sublayer_out_fwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _I, _I, _P, _U, _F, _U, _F, _U, _F, _P],
+    "kk_sublayer_in_bwd": [_P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _L, _I, _I, _P, _U, _F, _U, _F, _U, _F, _P],
+    "kk_sublayer_in_bwd_blocks": [_L],
     "kk_dropout_bwd": [_P, _P, _L, _I, _I, _P, _U, _F, _U, _F, _U, _F, _I, _P],
     "kk_specaug": [_P, _I, _I, _I, _P, _U, _I, _I, _I, _I, _I, _P],
     "kk_ids_eq_zero": [_P, _P, _L, _P],

@@ -915,3 +915,53 @@ def test_sublayer_tail_equals_separate_kernels(kk, ffn, ln, bf):
         close(mb, ma, 1e-6, 1e-6, "fused tail: LN mean")
         close(rb, ra, 1e-5, 1e-5, "fused tail: LN rstd")
         close(nb, na, 2e-2 if bf else 1e-5, 1e-2 if bf else 1e-5, "fused tail: LN output")
+
+
+@pytest.mark.parametrize("ffn,bf,acc", [(1, 1, 1), (0, 1, 1), (1, 0, 0), (0, 0, 1)])
+def test_sublayer_tail_backward_equals_separate_kernels(kk, ffn, bf, acc):
+    """kk_sublayer_in_bwd == kk_layernorm_bwd -> kk_dropout_bwd -> (kk_rmsnorm_bwd) -> kk_colsum_acc, same masks."""
+    g = torch.Generator().manual_seed(11 + ffn + 2 * bf)
+    rows, H, S = 221, 512, 17
+    dt = torch.bfloat16 if bf else torch.float32
+    x = dev(torch.randn(rows, H, generator=g))
+    dn = dev(torch.randn(rows, H, generator=g)).to(dt)
+    y = dev(torch.randn(rows, H, generator=g)).to(dt)
+    gam, bet, gain = (dev(1 + 0.1 * torch.randn(H, generator=g)) for _ in range(3))
+    dres0 = dev(torch.randn(rows, H, generator=g))
+    seed = torch.tensor([5], dtype=torch.int32, device="cuda")
+    p1, p2, dpr = 0.2, (0.2 if ffn else 0.0), 0.1
+    n_, mean, rstd = torch.empty(rows, H, device="cuda"), torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    kk.call("kk_layernorm_fwd", x, gam, bet, n_, mean, rstd, rows, H, 0)
+    rstd_f = torch.empty(rows, device="cuda")
+    kk.call("kk_rmsnorm_fwd", y, gain, None, torch.empty(rows, H, device="cuda"), rstd_f, rows, H, bf)
+    # separate kernels (atomics paths)
+    dres_a = dres0.clone() if acc else torch.zeros(rows, H, device="cuda")
+    dgam_a, dbet_a, dgain_a, dbias_a = (torch.zeros(H, device="cuda") for _ in range(4))
+    kk.call("kk_layernorm_bwd", dn, x, gam, mean, rstd, dres_a, acc, dgam_a, dbet_a, None, rows, H, bf)
+    masked = torch.empty(rows, H, device="cuda", dtype=torch.float32 if ffn else dt)
+    kk.call("kk_dropout_bwd", dres_a, masked, rows, H, S, seed, 40, p1, 41, p2, 42, dpr, 0 if ffn else bf)
+    if ffn:
+        dy_a = torch.empty(rows, H, device="cuda", dtype=dt)
+        kk.call("kk_rmsnorm_bwd", masked, y, gain, rstd_f, dy_a, dgain_a, None, rows, H, bf)
+    else:
+        dy_a = masked
+    kk.call("kk_colsum_acc", dy_a, H, rows, H, dbias_a, bf)
+    # fused + one reduce
+    dres_b = dres0.clone()
+    dy_b = torch.empty(rows, H, device="cuda", dtype=dt)
+    nb = kk.load().kk_sublayer_in_bwd_blocks(rows)
+    part = torch.full((nb, 4 * H), 3.0, device="cuda")
+    kk.call("kk_sublayer_in_bwd", dn, bf, x, gam, mean, rstd, dres_b, acc, y if ffn else None, gain if ffn else None,
+            rstd_f if ffn else None, dy_b, bf, part, rows, H, S, seed, 40, p1, 41, p2, 42, dpr)
+    dgam_b, dbet_b, dgain_b, dbias_b = (torch.zeros(H, device="cuda") for _ in range(4))
+    table = kk.reduce_table([(part, dgam_b, dbet_b, nb, 2 * H, H, 4 * H),
+                             (part[:, 2 * H:], dbias_b, dgain_b if ffn else None, nb, 2 * H if ffn else H, H, 4 * H)], "cuda")
+    kk.call("kk_partials_reduce", table, 2, 2 * H)
+    close(dres_b, dres_a, 2e-5, 1e-5, "fused bwd tail: stream gradient")
+    close(dy_b, dy_a, 3e-2 if bf else 2e-5, 1e-2 if bf else 1e-5, "fused bwd tail: dy")
+    close(dgam_b, dgam_a, 2e-3, 1e-4, "fused bwd tail: dgamma")
+    close(dbet_b, dbet_a, 2e-3, 1e-4, "fused bwd tail: dbeta")
+    # (the separate path sums the bf16-ROUNDED dy, the fused kernel sums before rounding: ~sqrt(rows) * 2^-9 * |dy| apart)
+    close(dbias_b, dbias_a, 0.5 if bf else 2e-3, 1e-2 if bf else 1e-4, "fused bwd tail: bias column sums")
+    if ffn:
+        close(dgain_b, dgain_a, 2e-3, 1e-4, "fused bwd tail: RMSNorm gain")
