@@ -103,7 +103,29 @@ __device__ __forceinline__ uint32_t kk_hash(uint32_t seed, uint32_t site, uint64
 __device__ __forceinline__ uint32_t kk_drop_threshold(float p) {       // drop iff hash < threshold
     return p <= 0.f ? 0u : (p >= 1.f ? 0xFFFFFFFFu : (uint32_t)((double)p * 4294967296.0));
 }
+// Element-wise dropout decisions: one hash serves the element PAIR (idx>>1) — 16-bit keep fields, the low one for the
+// even element — and is two xorshift-multiply rounds with 24-bit multipliers (v_mul_u32_u24 is full rate; the 32-bit
+// multiplies of kk_hash are quarter rate).  Statistically equivalent to lowbias32 on counters
+// (tools/dropout_hash_quality.py).  p is quantised to 1/65536 (thr >> 16, rounded).
+__device__ __forceinline__ uint32_t kk_pair_hash(uint32_t seed, uint32_t site, uint64_t idx) {
+    uint32_t x = (uint32_t)(idx >> 1) ^ (seed * 0x9E3779B9u + site * 0x85EBCA6Bu);
+    x ^= x >> 16; x = __umul24(x, 0xb5352du); x ^= x >> 13; x = __umul24(x, 0xca68b5u); x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t kk_thr16(uint32_t thr) { return thr >= 0xFFFF8000u ? 0xFFFFu : (thr + 0x8000u) >> 16; }
 // multiplicative mask value: 0 when dropped, 1/(1-p) when kept (p == 0 -> always 1)
 __device__ __forceinline__ float kk_drop_mul(uint32_t seed, uint32_t site, uint64_t idx, uint32_t thr, float inv_keep) {
-    return (thr != 0u && kk_hash(seed, site, idx) < thr) ? 0.f : inv_keep;
+    if (thr == 0u) return inv_keep;
+    const uint32_t h = kk_pair_hash(seed, site, idx);
+    return (((idx & 1) ? h >> 16 : h & 0xFFFFu) < kk_thr16(thr)) ? 0.f : inv_keep;
+}
+// four consecutive elements starting at a multiple of 4: two hashes
+__device__ __forceinline__ void kk_drop_mul4(uint32_t seed, uint32_t site, uint64_t idx0, uint32_t thr, float inv_keep, float (&m)[4]) {
+    m[0] = m[1] = m[2] = m[3] = inv_keep;
+    if (thr == 0u) return;
+    const uint32_t t = kk_thr16(thr), h0 = kk_pair_hash(seed, site, idx0), h1 = kk_pair_hash(seed, site, idx0 + 2);
+    m[0] = (h0 & 0xFFFFu) < t ? 0.f : inv_keep;
+    m[1] = (h0 >> 16) < t ? 0.f : inv_keep;
+    m[2] = (h1 & 0xFFFFu) < t ? 0.f : inv_keep;
+    m[3] = (h1 >> 16) < t ? 0.f : inv_keep;
 }

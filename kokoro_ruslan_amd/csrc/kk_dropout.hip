@@ -38,11 +38,11 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float *__restrict__ 
         const float rs = row_scale(d, seed, row);
         const float4 v = ld4(x + row * H + c);
         float o[4] = {v.x, v.y, v.z, v.w};
+        float m1[4], m2[4];
+        kk_drop_mul4(seed, d.site1, (uint64_t)row * H + c, t1, k1, m1);
+        kk_drop_mul4(seed, d.site2, (uint64_t)row * H + c, t2, k2, m2);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const uint64_t idx = (uint64_t)row * H + c + e;
-            o[e] *= rs * kk_drop_mul(seed, d.site1, idx, t1, k1) * kk_drop_mul(seed, d.site2, idx, t2, k2);
-        }
+        for (int e = 0; e < 4; ++e) o[e] *= rs * m1[e] * m2[e];
         if (res) {
             const int64_t rr = res_mod > 0 ? row % res_mod : row;
             const float4 r = ld4(res + rr * H + c);
@@ -105,11 +105,11 @@ __global__ __launch_bounds__(256) void sublayer_out_fwd_kernel(SubOutArgs a) {
             }
             const float4 r = ld4(a.res + row * H + c);
             const float rr[4] = {r.x, r.y, r.z, r.w};
+            float m1[4], m2[4];
+            kk_drop_mul4(seed, a.d.site1, (uint64_t)row * H + c, t1, k1, m1);
+            kk_drop_mul4(seed, a.d.site2, (uint64_t)row * H + c, t2, k2, m2);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint64_t idx = (uint64_t)row * H + c + e;
-                o[e] = o[e] * (dp * kk_drop_mul(seed, a.d.site1, idx, t1, k1) * kk_drop_mul(seed, a.d.site2, idx, t2, k2)) + rr[e];
-            }
+            for (int e = 0; e < 4; ++e) o[e] = o[e] * (dp * m1[e] * m2[e]) + rr[e];
             v[i] = make_float4(o[0], o[1], o[2], o[3]);
             st4(a.x_out + row * H + c, v[i]);
             s += o[0] + o[1] + o[2] + o[3];
@@ -230,11 +230,11 @@ __global__ __launch_bounds__(256) void sublayer_in_bwd_kernel(SubInArgs a) {
                 float g[4] = {old[i].x + rs * (dg[i].x - s1 - xh[i].x * s2), old[i].y + rs * (dg[i].y - s1 - xh[i].y * s2),
                               old[i].z + rs * (dg[i].z - s1 - xh[i].z * s2), old[i].w + rs * (dg[i].w - s1 - xh[i].w * s2)};
                 st4(a.dres + row * H + c, make_float4(g[0], g[1], g[2], g[3]));
+                float m1[4], m2[4];
+                kk_drop_mul4(seed, a.d.site1, (uint64_t)row * H + c, t1, k1, m1);
+                kk_drop_mul4(seed, a.d.site2, (uint64_t)row * H + c, t2, k2, m2);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const uint64_t idx = (uint64_t)row * H + c + e;
-                    g[e] *= dp * kk_drop_mul(seed, a.d.site1, idx, t1, k1) * kk_drop_mul(seed, a.d.site2, idx, t2, k2);
-                }
+                for (int e = 0; e < 4; ++e) g[e] *= dp * m1[e] * m2[e];
                 if (ffn) {                                  // dz -> RMSNorm backward (second pass below needs the row sum)
                     const float4 y4 = yv[i];
                     an[i].x += g[0] * y4.x * rsf; an[i].y += g[1] * y4.y * rsf; an[i].z += g[2] * y4.z * rsf; an[i].w += g[3] * y4.w * rsf;

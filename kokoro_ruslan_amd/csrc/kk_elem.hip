@@ -20,8 +20,9 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 struct Drop1 { const uint32_t *seed; uint32_t site; float p; };
 __device__ __forceinline__ float4 drop4(const Drop1 &d, uint32_t seed, uint32_t thr, float ik, uint64_t idx0) {
     if (thr == 0u) return make_float4(1.f, 1.f, 1.f, 1.f);
-    return make_float4(kk_drop_mul(seed, d.site, idx0, thr, ik), kk_drop_mul(seed, d.site, idx0 + 1, thr, ik),
-                       kk_drop_mul(seed, d.site, idx0 + 2, thr, ik), kk_drop_mul(seed, d.site, idx0 + 3, thr, ik));
+    float m[4];
+    kk_drop_mul4(seed, d.site, idx0, thr, ik, m);        // idx0 is a multiple of 4 at every call site
+    return make_float4(m[0], m[1], m[2], m[3]);
 }
 
 template <typename T>

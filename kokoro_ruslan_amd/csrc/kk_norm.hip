@@ -453,8 +453,9 @@ __global__ __launch_bounds__(256) void gn_apply_relu_kernel(const float *__restr
             o.z = fmaxf((v.z - mu) * rs * g.z + bt.z, 0.f);
             o.w = fmaxf((v.w - mu) * rs * g.w + bt.w, 0.f);
             if (thr) {
-                o.x *= kk_drop_mul(seed, site, (uint64_t)e, thr, ik); o.y *= kk_drop_mul(seed, site, (uint64_t)e + 1, thr, ik);
-                o.z *= kk_drop_mul(seed, site, (uint64_t)e + 2, thr, ik); o.w *= kk_drop_mul(seed, site, (uint64_t)e + 3, thr, ik);
+                float m[4];
+                kk_drop_mul4(seed, site, (uint64_t)e, thr, ik, m);
+                o.x *= m[0]; o.y *= m[1]; o.z *= m[2]; o.w *= m[3];
             }
         }
         st4(y + e, o);
