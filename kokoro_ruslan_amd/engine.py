@@ -164,6 +164,9 @@ class KokoroEngine:
         self._kv = torch.cuda.Stream(device=self.device)
         self.kv_fwd_aside = False
         self.kv_bwd_aside = False
+        # The same third stream runs the decoder's input projection and layer-0 self-attention beside the text encoder
+        # (they do not need its output); one fork, one join before the first cross-attention.
+        self.dec_head_aside = True
         self.spec_augment_active = True             # the trainer clears it for epochs < spec_augment_start_epoch
         self.rng = torch.full((1,), int(seed) & 0x7FFFFFFF, dtype=torch.int32, device=self.device)   # step seed, read on device
         for n, b in spec.make_buffers(self.dims).items():
@@ -590,6 +593,30 @@ class KokoroEngine:
         if T > d.max_len or Pn > d.max_len:
             raise ValueError(f"sequence longer than the positional table ({d.max_len})")
 
+        # ---- decoder head: mel input projection + layer-0 self-attention need no encoder output (model.py:519-531) ----
+        p_din = self._p(self.hp.decoder_input_dropout)
+        shifted = self._buf("dec.shifted", Nd, M)
+
+        def self_attn(i, y_in, n1_in):
+            key, pf, st = f"dec{i}", f"decoder.layers.{i}", 2000 + 32 * i
+            ya_ = self._buf(key + ".xa", Nd, H)
+            n2_ = self._attn_fwd(key + ".sa", pf + ".self_attn", n1_in, None, B, T, T, True, True, None, y_in, ya_, st, p_dec,
+                                 self._dpr(i, d.dec_layers), next_ln=(key + ".ln2", pf + ".norm2", ddt))
+            return ya_, (n2_ if n2_ is not None else self._ln_fwd(key + ".ln2", ya_, pf + ".norm2", ddt))
+
+        def decoder_head():
+            kk.call("kk_shift_right", mel, shifted, B, T, M)
+            y0 = self._buf("dec.x0", Nd, H)
+            if self.train_dropout and (p_din > 0.0 or pe_drop > 0.0):    # dropout(proj) + pe, then the PE module's dropout
+                lin, t1 = self._buf("tmp.dec_lin", Nd, H), self._buf("tmp.dec_t1", Nd, H)
+                self._linear(shifted, self._W("mel_projection_in.weight"), P["mel_projection_in.bias"], lin)
+                kk.call("kk_dropout_fwd", lin, pe, T, t1, Nd, H, T, self.rng, 30, p_din, 0, 0.0, 0, 0.0)
+                kk.call("kk_dropout_fwd", t1, None, 0, y0, Nd, H, T, self.rng, 31, pe_drop, 0, 0.0, 0, 0.0)
+            else:
+                self._linear(shifted, self._W("mel_projection_in.weight"), P["mel_projection_in.bias"], y0, res=pe, res_mod=T)
+            ya0, n20 = self_attn(0, y0, self._ln_fwd("dec0.ln1", y0, "decoder.layers.0.norm1", ddt))
+            return y0, ya0, n20
+
         # ---- encoder (model.py:375-388) ----
         text_mask = self._buf("text_mask", B, Pn, dtype=torch.uint8)
         kk.call("kk_ids_eq_zero", ids, text_mask, Ne)
@@ -599,6 +626,8 @@ class KokoroEngine:
         if self.train_dropout:
             self.rng.add_(1)                              # fresh masks every micro-batch (captured in the hipGraph)
         pe_drop, p_enc, p_dec, p_var = self._p(hp.encoder_dropout), self._p(hp.encoder_dropout), self._p(hp.decoder_dropout), self._p(hp.variance_dropout)
+        with self._on_stream(self._kv, "kv.", self.dec_head_aside):     # beside the encoder; joined before the first cross-attention
+            dec_head = decoder_head()
         kk.call("kk_embed_fwd", ids, stress, P["text_embedding.weight"], P["stress_embedding.weight"] if stress is not None else None,
                 pe, x, B, Pn, H, float(H ** 0.5), self.rng, 1, pe_drop)
         y1 = None                                         # LayerNorm outputs come from the previous sub-layer's fused tail
@@ -650,30 +679,17 @@ class KokoroEngine:
         with self._on_stream(self._kv, "kv.", self.kv_fwd_aside):   # all cross-attention K/V projections, beside decoder layer 0
             for i in range(d.dec_layers):
                 self._cross_kv_fwd(f"dec{i}.ca", f"decoder.layers.{i}.cross_attn", memory, Nd, T, ddt)
-        shifted = self._buf("dec.shifted", Nd, M)
-        kk.call("kk_shift_right", mel, shifted, B, T, M)
-        y = self._buf("dec.x0", Nd, H)
-        p_din = self._p(hp.decoder_input_dropout)
-        if self.train_dropout and (p_din > 0.0 or pe_drop > 0.0):    # dropout(proj) + pe, then the PE module's dropout
-            lin, t1 = self._buf("tmp.dec_lin", Nd, H), self._buf("tmp.dec_t1", Nd, H)
-            self._linear(shifted, self._W("mel_projection_in.weight"), P["mel_projection_in.bias"], lin)
-            kk.call("kk_dropout_fwd", lin, pe, T, t1, Nd, H, T, self.rng, 30, p_din, 0, 0.0, 0, 0.0)
-            kk.call("kk_dropout_fwd", t1, None, 0, y, Nd, H, T, self.rng, 31, pe_drop, 0, 0.0, 0, 0.0)
-        else:
-            self._linear(shifted, self._W("mel_projection_in.weight"), P["mel_projection_in.bias"], y, res=pe, res_mod=T)
         n1 = None
         for i in range(d.dec_layers):
             pf, key, st = f"decoder.layers.{i}", f"dec{i}", 2000 + 32 * i
             dpr = self._dpr(i, d.dec_layers)
-            if n1 is None:
-                n1 = self._ln_fwd(key + ".ln1", y, pf + ".norm1", ddt)
-            ya = self._buf(key + ".xa", Nd, H)
-            n2 = self._attn_fwd(key + ".sa", pf + ".self_attn", n1, None, B, T, T, True, True, None, y, ya, st, p_dec, dpr,
-                                next_ln=(key + ".ln2", pf + ".norm2", ddt))
-            if n2 is None:
-                n2 = self._ln_fwd(key + ".ln2", ya, pf + ".norm2", ddt)
-            if i == 0:
+            if i == 0:                                    # input projection + layer-0 self-attention ran beside the encoder
                 self._join(self._kv)
+                y, ya, n2 = dec_head
+            else:
+                if n1 is None:
+                    n1 = self._ln_fwd(key + ".ln1", y, pf + ".norm1", ddt)
+                ya, n2 = self_attn(i, y, n1)
             yc = self._buf(key + ".xc", Nd, H)
             n3 = self._attn_fwd(key + ".ca", pf + ".cross_attn", n2, memory, B, T, T, False, False, fmask, ya, yc, st + 8, p_dec, dpr,
                                 next_ln=(key + ".ln3", pf + ".norm3", ddt))
@@ -865,10 +881,12 @@ class KokoroEngine:
         if ent["fb"] is None:
             torch.cuda.synchronize()
             ent["fb"], ent["opt"] = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ent["fb"]):
+            # thread_local: with an RCCL process group alive, its watchdog thread polls events while we capture; only
+            # this thread's calls must be capture-safe
+            with torch.cuda.graph(ent["fb"], capture_error_mode="thread_local"):
                 self.zero_grad()
                 self.forward_backward(static, loss_scale=self.dp_loss_scale, adaptive=True)
-            with torch.cuda.graph(ent["opt"]):
+            with torch.cuda.graph(ent["opt"], capture_error_mode="thread_local"):
                 self.optimizer_step(T)
         ent["fb"].replay()
         if grad_sync is not None:
