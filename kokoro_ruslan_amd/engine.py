@@ -46,6 +46,11 @@ class Arena:
         self.dims, self.device = dims, device
         self.param_names = list(spec.param_shapes(dims).keys())
         segs = list(spec.param_shapes(dims).items()) + list(spec.buffer_shapes(dims).items())
+        # physical order: the K and V projections of all decoder cross-attention layers first and contiguous, so the
+        # memory is projected for every layer by ONE GEMM against a [layers*2H, H] matrix (and its two gradients
+        # likewise); everything else in state-dict order.  Names, not offsets, are the interface.
+        is_ckv = lambda n: n.endswith(".cross_attn.w_k.weight") or n.endswith(".cross_attn.w_v.weight")
+        segs = [x for x in segs if is_ckv(x[0])] + [x for x in segs if not is_ckv(x[0])]
         self.names = [n for n, _ in segs]
         self.shapes = dict(segs)
         self.offset: Dict[str, int] = {}
@@ -155,17 +160,12 @@ class KokoroEngine:
         self.overlap = True
         self._side = torch.cuda.Stream(device=self.device)
         self._tmp_ns = ""
-        # Optional third stream for the key/value branch of the decoder's cross-attention (forward: the K/V projections
-        # of all layers depend only on the memory; backward: dK/dV, their head-norm backward, the K/V weight gradient
-        # and the memory gradient feed nothing on the residual chain).  Measured on MI355X at 8x512, both are OFF:
-        # forward aside is neutral (568K vs 572K frames/s), backward aside loses 9 % (519K) — one fork per layer of
-        # chip-filling kernels costs more in cross-stream graph edges than it overlaps.  A stream per weight-gradient
-        # GEMM was worse still (447K).  Only the long independent encoder/predictor branch pays (470K -> 548K).
+        # Third stream: the decoder's input projection and layer-0 self-attention run beside the text encoder (they do not
+        # need its output); one fork, one join before the first cross-attention.  Forks are not free in a hipGraph:
+        # measured at 8x512, the long independent encoder/predictor branch pays (470K -> 548K frames/s) and so does this
+        # one (630K -> 638K), but a per-layer fork for the cross-attention K/V backward lost 9 %, a stream per
+        # weight-gradient GEMM 19 %, and moving the duration predictor's forward aside 2 %.
         self._kv = torch.cuda.Stream(device=self.device)
-        self.kv_fwd_aside = False
-        self.kv_bwd_aside = False
-        # The same third stream runs the decoder's input projection and layer-0 self-attention beside the text encoder
-        # (they do not need its output); one fork, one join before the first cross-attention.
         self.dec_head_aside = True
         self.spec_augment_active = True             # the trainer clears it for epochs < spec_augment_start_epoch
         self.rng = torch.full((1,), int(seed) & 0x7FFFFFFF, dtype=torch.int32, device=self.device)   # step seed, read on device
@@ -394,7 +394,8 @@ class KokoroEngine:
         kk.call("kk_dropout_bwd", dy, dx, dy.shape[0], dy.shape[1], S, self.rng, site, p, site + 1, p2, site + 2, dpr, _b16(dx))
 
     # ------------------------------------------------------------------ attention sub-layer
-    def _attn_fwd(self, key, prefix, xq, xkv, B, Sq, Sk, rope, causal, key_mask, x_res, x_out, site=0, p=0.0, dpr=0.0, next_ln=None):
+    def _attn_fwd(self, key, prefix, xq, xkv, B, Sq, Sk, rope, causal, key_mask, x_res, x_out, site=0, p=0.0, dpr=0.0, next_ln=None,
+                  layer=0):
         """x_out = x_res + w_o(attention(...)) + b_o.  xq [B*Sq,H] (post-LN), xkv [B*Sk,H] (None = self-attention).
         Returns LayerNorm_next_ln(x_out) when the fused dropout tail computed it, else None."""
         P, H, h = self.arena.P, self.dims.hidden, self.dims.heads
@@ -408,9 +409,9 @@ class KokoroEngine:
             q_raw, k_raw, v_raw, q_n, k_n, v_n = raw, raw[:, H:], raw[:, 2 * H:], nrm, nrm[:, H:], nrm[:, 2 * H:]
         else:
             q_raw, q_n = self._buf(key + ".q_raw", Nq, H, dtype=dt), self._buf(key + ".q_n", Nq, H, dtype=dt)
-            kv_raw, kv_n = self._buf(key + ".kv_raw", Nk, 2 * H, dtype=dt), self._buf(key + ".kv_n", Nk, 2 * H, dtype=dt)
+            kv_raw, kv_n = self._cross_kv(layer, Nk, dt)                              # filled by _cross_kv_fwd_all
             self._linear(xq, self._W(prefix + ".w_q.weight"), None, q_raw)
-            k_raw, v_raw, k_n, v_n = kv_raw, kv_raw[:, H:], kv_n, kv_n[:, H:]           # filled by _cross_kv_fwd
+            k_raw, v_raw, k_n, v_n = kv_raw, kv_raw[:, H:], kv_n, kv_n[:, H:]
         gq, gk, gv = P[prefix + ".q_norm.weight"], P[prefix + ".k_norm.weight"], P[prefix + ".v_norm.weight"]
         if xkv is None:       # q|k|v in one launch over the fused projection; RoPE on q and k only
             kk.call("kk_headnorm_rope_fwd", raw, 3 * H, nrm, 3 * H, Nq, h, Sq, 3, gq, gk, gv, 3 if rope else 0, cos, sin, i16)
@@ -426,17 +427,36 @@ class KokoroEngine:
         self._linear(ctx, self._W(prefix + ".w_o.weight"), P[prefix + ".w_o.bias"], x_out, res=x_res)
         return None
 
-    def _cross_kv_fwd(self, key, prefix, xkv, Nk, Sk, dt):
-        """K/V projection + per-head RMSNorm of one cross-attention layer (no RoPE: transformers.py:268-277 applies it
-        to self-attention only).  Depends on the memory alone."""
-        P, H, h = self.arena.P, self.dims.hidden, self.dims.heads
-        kv_raw, kv_n = self._buf(key + ".kv_raw", Nk, 2 * H, dtype=dt), self._buf(key + ".kv_n", Nk, 2 * H, dtype=dt)
-        self._linear(xkv, self._Wf(prefix + ".w_k.weight", 2), None, kv_raw)
-        kk.call("kk_headnorm_rope_fwd", kv_raw, 2 * H, kv_n, 2 * H, Nk, h, Sk, 2, P[prefix + ".k_norm.weight"],
-                P[prefix + ".v_norm.weight"], None, 0, None, None, _b16(kv_raw))
+    def _cross_kv(self, layer, Nk, dt, which=""):
+        """(raw, normed) K|V of cross-attention layer `layer`: column slices [.., 2H] of the all-layer buffers (row stride
+        layers*2H); which = "d" for their gradients."""
+        H, L = self.dims.hidden, self.dims.dec_layers
+        raw = self._buf(f"dec.ca.{which}kv_raw_all", Nk, 2 * H * L, dtype=dt)
+        nrm = self._buf(f"dec.ca.{which}kv_n_all", Nk, 2 * H * L, dtype=dt)
+        return raw[:, 2 * H * layer:2 * H * (layer + 1)], nrm[:, 2 * H * layer:2 * H * (layer + 1)]
+
+    def _cross_kv_fwd_all(self, xkv, Nk, Sk, dt):
+        """K/V projections of ALL decoder cross-attention layers in one GEMM (they depend on the memory alone and their
+        weights are contiguous in the arena), then the per-head RMSNorm of each layer's slice (no RoPE:
+        transformers.py:268-277 applies it to self-attention only)."""
+        P, H, h, L = self.arena.P, self.dims.hidden, self.dims.heads, self.dims.dec_layers
+        raw_all = self._buf("dec.ca.kv_raw_all", Nk, 2 * H * L, dtype=dt)
+        self._linear(xkv, self._Wf("decoder.layers.0.cross_attn.w_k.weight", 2 * L), None, raw_all)
+        for l in range(L):
+            raw, nrm = self._cross_kv(l, Nk, dt)
+            pf = f"decoder.layers.{l}.cross_attn"
+            kk.call("kk_headnorm_rope_fwd", raw, 2 * H * L, nrm, 2 * H * L, Nk, h, Sk, 2, P[pf + ".k_norm.weight"],
+                    P[pf + ".v_norm.weight"], None, 0, None, None, _b16(raw))
+
+    def _cross_kv_bwd_all(self, xkv, Nk, dt, d_xkv):
+        """Weight gradient of all layers' K/V projections and the memory gradient: two GEMMs over the all-layer buffer."""
+        a, H, L = self.arena, self.dims.hidden, self.dims.dec_layers
+        draw_all = self._buf("dec.ca.dkv_raw_all", Nk, 2 * H * L, dtype=dt)
+        self._wgrad(draw_all, xkv, a.fused(a.g, "decoder.layers.0.cross_attn.w_k.weight", 2 * L))
+        self._dgrad(draw_all, self._Wf("decoder.layers.0.cross_attn.w_k.weight", 2 * L), d_xkv)
 
     def _attn_bwd(self, key, prefix, d_out, xq, xkv, B, Sq, Sk, rope, causal, key_mask, d_xq, d_xkv, d_xkv_beta,
-                  site=0, p=0.0, dpr=0.0, head_done=False):
+                  site=0, p=0.0, dpr=0.0, head_done=False, layer=0):
         """Given d_out = dL/d(sub-layer output, pre-residual), accumulate parameter grads, write d_xq (dL/d xq) and,
         for cross-attention, d_xkv (+= when d_xkv_beta == 1)."""
         a, P, G, H, h = self.arena, self.arena.P, self.arena.G, self.dims.hidden, self.dims.heads
@@ -464,7 +484,7 @@ class KokoroEngine:
             dq_n, dk_n, dv_n, dq_raw, dk_raw, dv_raw = dn, dn[:, H:], dn[:, 2 * H:], draw, draw[:, H:], draw[:, 2 * H:]
         else:
             q_raw, q_n = self._buf(key + ".q_raw", Nq, H, dtype=dt), self._buf(key + ".q_n", Nq, H, dtype=dt)
-            kv_raw, kv_n = self._buf(key + ".kv_raw", Nk, 2 * H, dtype=dt), self._buf(key + ".kv_n", Nk, 2 * H, dtype=dt)
+            kv_raw, kv_n = self._cross_kv(layer, Nk, dt)
             dq_n, dq_raw = self._buf("tmp.dq_n", Nq, H, dtype=dt), self._buf("tmp.dq_raw", Nq, H, dtype=dt)
             k_raw, v_raw, k_n, v_n = kv_raw, kv_raw[:, H:], kv_n, kv_n[:, H:]
         ld = lambda t: t.stride(0)
@@ -481,15 +501,12 @@ class KokoroEngine:
             self._wgrad(draw, xq, a.fused(a.g, prefix + ".w_q.weight", 3))
             self._dgrad(draw, self._Wf(prefix + ".w_q.weight", 3), d_xq)
             return
-        if d_xkv is not None:
-            with self._on_stream(self._kv, "kv.", self.kv_bwd_aside):          # the key/value branch: nothing on the residual chain reads it
-                dkv_n, dkv_raw = self._buf("tmp.dkv_n", Nk, 2 * H, dtype=dt), self._buf("tmp.dkv_raw", Nk, 2 * H, dtype=dt)
-                kk.call("kk_attn_bwd_dkv", q_n, k_n, v_n, dctx, lse, delta, dkv_n, dkv_n[:, H:], B, h, Sq, Sk, ld(q_n), ld(k_n),
-                        ld(v_n), H, 2 * H, 2 * H, key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16)
-                kk.call("kk_headnorm_rope_bwd", dkv_n, 2 * H, kv_raw, 2 * H, dkv_raw, 2 * H, Nk, h, Sk, 2, gk, gv, None, dgk, dgv,
-                        None, self._headnorm_partials(key + ".kv", Nk, (dgk, dgv)), 0, None, None, i16)
-                self._wgrad(dkv_raw, xkv, a.fused(a.g, prefix + ".w_k.weight", 2))
-                self._dgrad(dkv_raw, self._Wf(prefix + ".w_k.weight", 2), d_xkv, beta=d_xkv_beta)
+        if d_xkv is not None:        # key/value branch; its two GEMMs run once for all layers (_cross_kv_bwd_all)
+            dkv_raw, dkv_n = self._cross_kv(layer, Nk, dt, "d")
+            kk.call("kk_attn_bwd_dkv", q_n, k_n, v_n, dctx, lse, delta, dkv_n, dkv_n[:, H:], B, h, Sq, Sk, ld(q_n), ld(k_n),
+                    ld(v_n), H, ld(dkv_n), ld(dkv_n), key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16)
+            kk.call("kk_headnorm_rope_bwd", dkv_n, ld(dkv_n), kv_raw, ld(kv_raw), dkv_raw, ld(dkv_raw), Nk, h, Sk, 2, gk, gv, None,
+                    dgk, dgv, None, self._headnorm_partials(key + ".kv", Nk, (dgk, dgv)), 0, None, None, i16)
         kk.call("kk_attn_bwd_dq", q_n, k_n, v_n, dctx, lse, delta, dq_n, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H, ld(dq_n),
                 key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16)
         kk.call("kk_headnorm_rope_bwd", dq_n, H, q_raw, H, dq_raw, H, Nq, h, Sq, 1, gq, None, None, dgq, None, None,
@@ -676,9 +693,7 @@ class KokoroEngine:
                     hp.spec_augment_num_time_masks, hp.spec_augment_num_freq_masks, _b16(memory))
 
         # ---- decoder (model.py:519-531; transformers.py:543-583,660) ----
-        with self._on_stream(self._kv, "kv.", self.kv_fwd_aside):   # all cross-attention K/V projections, beside decoder layer 0
-            for i in range(d.dec_layers):
-                self._cross_kv_fwd(f"dec{i}.ca", f"decoder.layers.{i}.cross_attn", memory, Nd, T, ddt)
+        self._cross_kv_fwd_all(memory, Nd, T, ddt)        # every layer's cross-attention K/V in one GEMM
         n1 = None
         for i in range(d.dec_layers):
             pf, key, st = f"decoder.layers.{i}", f"dec{i}", 2000 + 32 * i
@@ -692,7 +707,7 @@ class KokoroEngine:
                 ya, n2 = self_attn(i, y, n1)
             yc = self._buf(key + ".xc", Nd, H)
             n3 = self._attn_fwd(key + ".ca", pf + ".cross_attn", n2, memory, B, T, T, False, False, fmask, ya, yc, st + 8, p_dec, dpr,
-                                next_ln=(key + ".ln3", pf + ".norm3", ddt))
+                                next_ln=(key + ".ln3", pf + ".norm3", ddt), layer=i)
             if n3 is None:
                 n3 = self._ln_fwd(key + ".ln3", yc, pf + ".norm3", ddt)
             yo = self._buf(key + ".xo", Nd, H)
@@ -770,7 +785,6 @@ class KokoroEngine:
         hd = self._tail_bwd("dec.norm", d_dec_out, dec_last, "decoder.norm", dy, False, dhead("ffn", d.dec_layers - 1))
         dmem = self._buf("g.memory", Nd, H)
         dn = self._buf("tmp.dn", Nd, H, dtype=ddt)
-        first_mem = True
         for i in reversed(range(d.dec_layers)):
             pf, key, st = f"decoder.layers.{i}", f"dec{i}", 2000 + 32 * i
             dpr = self._dpr(i, d.dec_layers)
@@ -780,8 +794,7 @@ class KokoroEngine:
             self._ffn_bwd(key + ".ff", pf + ".ff", dy, n3, dn, d.dec_ff, T, st + 16, p_dec, dpr, head_done=hd)
             hd = self._tail_bwd(key + ".ln3", dn, yc, pf + ".norm3", dy, True, dhead("ca", i))
             self._attn_bwd(key + ".ca", pf + ".cross_attn", dy, n2, memory, B, T, T, False, False, fmask, dn, dmem,
-                           0.0 if first_mem else 1.0, st + 8, p_dec, dpr, head_done=hd)
-            first_mem = False
+                           0.0, st + 8, p_dec, dpr, head_done=hd, layer=i)
             hd = self._tail_bwd(key + ".ln2", dn, ya, pf + ".norm2", dy, True, dhead("sa", i))
             self._attn_bwd(key + ".sa", pf + ".self_attn", dy, n1, None, B, T, T, True, True, None, dn, None, 0.0, st, p_dec, dpr,
                            head_done=hd)
@@ -798,7 +811,7 @@ class KokoroEngine:
         else:
             self._wgrad(dy, shifted, G["mel_projection_in.weight"], G["mel_projection_in.bias"])
         # variance adaptor: memory gradient feeds only the two embedding tables (xf is detached, lengths.py:30)
-        self._join(self._kv)                              # dmem is accumulated by the K/V branch
+        self._cross_kv_bwd_all(memory, Nd, ddt, dmem)     # K/V weight gradients and the memory gradient, all layers at once
         if spec_aug:
             kk.call("kk_specaug", dmem, B, T, H, self.rng, 20, hp.spec_augment_time_mask_max, hp.spec_augment_freq_mask_max,
                     hp.spec_augment_num_time_masks, hp.spec_augment_num_freq_masks, 0)
