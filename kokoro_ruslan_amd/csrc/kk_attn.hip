@@ -459,16 +459,20 @@ __global__ __launch_bounds__(256 * G) void attn_fwd_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------ backward: dQ
-template <bool BF16, bool ST16>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+// Same decomposition as the forward: a lane owns a query, wave group g sweeps the key tiles g, g+G, ...; with G = 2
+// group 1's partial dQ is added to group 0's through LDS at the end.  Two register sets (prefetch distance 2).
+template <bool BF16, bool ST16, int G>
+__global__ __launch_bounds__(256 * G) void attn_bwd_dq_kernel(AttnArgs a) {
     using elem = typename ACfg<BF16>::elem;
     using SG = Stage<BF16, ST16>;
     using T = typename SG::T;
     constexpr int LR = ACfg<BF16>::LR, TILE = 64 * LR, NT = BF16 ? 3 : 2;   // K, V (+ K transposed for bf16)
-    __shared__ __attribute__((aligned(16))) elem smem[2 * NT * TILE];
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];        // [buffer][group][NT tiles]
+    elem *smem = reinterpret_cast<elem *>(smem_raw);
     const int b = blockIdx.y / a.heads, hh = blockIdx.y % a.heads;
     const int qblk = blockIdx.x * 128;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, l31 = lane & 31;
+    const int lane = threadIdx.x & 63, wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, l31 = lane & 31;
+    const int wave = wave8 & 3, grp = wave8 >> 2;
     const int q = qblk + wave * 32 + l31;
     const bool qvalid = q < a.Sq;
     RowFrag<BF16> qf, dof;
@@ -484,34 +488,44 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     zero_acc(dq[0]); zero_acc(dq[1]);
     const uint8_t *km = a.key_mask ? a.key_mask + (int64_t)b * a.Sk : nullptr;
     const int qmin = qblk + wave * 32;
-    uint32_t rkm = 0;
     int kend = a.Sk;
     if (a.causal && qblk + 128 < kend) kend = qblk + 128;
     const T *Kb = static_cast<const T *>(a.K) + (int64_t)b * a.Sk * a.ldk + hh * 64;
     const T *Vb = static_cast<const T *>(a.V) + (int64_t)b * a.Sk * a.ldv + hh * 64;
-    typename SG::R rk, rv;
-    typename SG::RT rkt;
-    auto issue = [&](int k0) {
+    struct Regs {
+        typename SG::R rk, rv;
+        typename SG::RT rkt;
+        uint32_t rkm;
+    };
+    Regs ra, rb;
+    ra.rkm = rb.rkm = 0;
+    auto issue = [&](Regs &t, int k0) {
         const int nvalid = a.Sk - k0 < 64 ? a.Sk - k0 : 64;
-        load_rows(rk, Kb + (int64_t)k0 * a.ldk, a.ldk, nvalid);
-        load_rows(rv, Vb + (int64_t)k0 * a.ldv, a.ldv, nvalid);
-        if constexpr (BF16) load_rows_T(rkt, Kb + (int64_t)k0 * a.ldk, a.ldk, nvalid);
-        if (km) rkm = lane < nvalid ? km[k0 + lane] : 0u;
+        load_rows(t.rk, Kb + (int64_t)k0 * a.ldk, a.ldk, nvalid);
+        load_rows(t.rv, Vb + (int64_t)k0 * a.ldv, a.ldv, nvalid);
+        if constexpr (BF16) load_rows_T(t.rkt, Kb + (int64_t)k0 * a.ldk, a.ldk, nvalid);
+        t.rkm = km ? (lane < nvalid ? km[k0 + lane] : 0u) : 0u;
     };
-    auto commit = [&](int buf) {
-        SG::st(smem + buf * NT * TILE, rk);
-        SG::st(smem + buf * NT * TILE + TILE, rv);
-        if constexpr (BF16) SG::stT(smem + buf * NT * TILE + 2 * TILE, rkt);
+    auto commit = [&](const Regs &t, int buf) {
+        elem *dst = smem + (buf * G + grp) * NT * TILE;
+        SG::st(dst, t.rk);
+        SG::st(dst + TILE, t.rv);
+        if constexpr (BF16) SG::stT(dst + 2 * TILE, t.rkt);
     };
-    issue(0);
-    commit(0);
-    uint64_t kmbits = __ballot(rkm != 0u), kmnext = 0;
+    constexpr int STEP = 64 * G;
+    const int kfirst = grp * 64;
+    if (kfirst < kend) {
+        issue(ra, kfirst);
+        commit(ra, 0);
+    }
+    uint64_t kmbits = __ballot(ra.rkm != 0u), kmnext = 0;
+    if (kfirst + STEP < kend) issue(ra, kfirst + STEP);
+    if (kfirst + 2 * STEP < kend) issue(rb, kfirst + 2 * STEP);
     __syncthreads();
     int cur = 0;
-    for (int k0 = 0; k0 < kend; k0 += 64, cur ^= 1) {
-        const bool more = k0 + 64 < kend;
-        if (more) issue(k0 + 64);
-        const elem *Ks = smem + cur * NT * TILE, *Vs = Ks + TILE, *Kt = BF16 ? Ks + 2 * TILE : Ks;
+    auto tile_step = [&](Regs &X, int kk0) {
+        const int k0 = kk0 + kfirst;
+        const elem *Ks = smem + (cur * G + grp) * NT * TILE, *Vs = Ks + TILE, *Kt = BF16 ? Ks + 2 * TILE : Ks;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int kb = k0 + sub * 32;
@@ -549,28 +563,52 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
             }
             mma_T_x_p<BF16>(dq, Kt, sub * 32, ds, l31, half);     // (the softmax scale is applied once, at the store)
         }
-        if (more) {
-            commit(cur ^ 1);
-            kmnext = __ballot(rkm != 0u);
+        kmnext = 0;
+        if (k0 + STEP < kend) {
+            commit(X, cur ^ 1);
+            kmnext = __ballot(X.rkm != 0u);
+            if (k0 + 3 * STEP < kend) issue(X, k0 + 3 * STEP);
         }
         kmbits = kmnext;
         __syncthreads();
+        cur ^= 1;
+    };
+    for (int kk0 = 0; kk0 < kend; kk0 += 2 * STEP) {      // the bound is the same for both groups (barriers)
+        tile_step(ra, kk0);
+        if (kk0 + STEP < kend) tile_step(rb, kk0 + STEP);
+    }
+    if constexpr (G == 2) {          // group 1's partial dQ -> LDS -> group 0
+        float *mb = reinterpret_cast<float *>(smem_raw) + (wave * 64 + lane) * 33;
+        if (grp == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { mb[r] = dq[0][r]; mb[16 + r] = dq[1][r]; }
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dq[0][r] += mb[r]; dq[1][r] += mb[16 + r]; }
     }
     if (qvalid) store_row<T>(static_cast<T *>(a.Out) + ((int64_t)b * a.Sq + q) * a.ldout + hh * 64, dq, a.scale, half);
 }
 
 // ------------------------------------------------------------------ backward: dK, dV
-template <bool BF16, bool ST16>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+// A lane owns a key; the workgroup sweeps the query tiles.  G = 2: two wave groups take alternate query tiles of the
+// same 128 keys (2 waves per SIMD, see attn_fwd_kernel) and group 1's dK / dV partial sums are added to group 0's
+// through LDS at the end.  Staging: with G = 1 two register sets alternate and a tile's loads have two tile-times to land;
+// with G = 2 the 256-register budget of 8 waves leaves room for one set (distance 1) — the second wave hides the rest.
+template <bool BF16, bool ST16, int G>
+__global__ __launch_bounds__(256 * G) void attn_bwd_dkv_kernel(AttnArgs a) {
     using elem = typename ACfg<BF16>::elem;
     using SG = Stage<BF16, ST16>;
     using T = typename SG::T;
     constexpr int LR = ACfg<BF16>::LR, TILE = 64 * LR, NT = BF16 ? 4 : 2;   // Q, dO (+ both transposed for bf16)
-    __shared__ __attribute__((aligned(16))) elem smem[2 * NT * TILE];
-    __shared__ float lse_s[2][64], dlt_s[2][64];
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];        // [buffer][group][NT tiles], then lse/delta rows
+    elem *smem = reinterpret_cast<elem *>(smem_raw);
+    float *stat = reinterpret_cast<float *>(smem_raw + (size_t)2 * G * NT * TILE * sizeof(elem));   // [buffer][group][2][64]
     const int b = blockIdx.y / a.heads, hh = blockIdx.y % a.heads;
     const int kblk = blockIdx.x * 128;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, l31 = lane & 31;
+    const int lane = threadIdx.x & 63, wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, l31 = lane & 31;
+    const int wave = wave8 & 3, grp = wave8 >> 2, tl = threadIdx.x & 255;
     const int key = kblk + wave * 32 + l31;
     const bool kvalid = key < a.Sk;
     const bool kalive = kvalid && !(a.key_mask && a.key_mask[(int64_t)b * a.Sk + key]);
@@ -589,43 +627,58 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     const T *Qb = static_cast<const T *>(a.Q) + (int64_t)b * a.Sq * a.ldq + hh * 64;
     const T *dOb = static_cast<const T *>(a.dO) + (int64_t)b * a.Sq * a.lddo + hh * 64;
     const float *LSEb = a.LSE + ((int64_t)b * a.heads + hh) * a.Sq, *DLb = a.Delta + ((int64_t)b * a.heads + hh) * a.Sq;
-    typename SG::R rq, rdo;
-    typename SG::RT rqt, rdot;
-    float r_lse = INFINITY, r_dlt = 0.f;
-    auto issue = [&](int q0) {
+    struct Regs {
+        typename SG::R rq, rdo;
+        typename SG::RT rqt, rdot;
+        float lse, dlt;
+    };
+    constexpr int DIST = G == 1 ? 2 : 1;                   // prefetch distance in tiles (= register sets)
+    Regs ra;
+    typename std::conditional<DIST == 2, Regs, int>::type rb_store;
+    Regs &rb = [&]() -> Regs & { if constexpr (DIST == 2) return rb_store; else return ra; }();
+    auto issue = [&](Regs &t, int q0) {
         const int nvalid = a.Sq - q0 < 64 ? a.Sq - q0 : 64;
-        load_rows(rq, Qb + (int64_t)q0 * a.ldq, a.ldq, nvalid);
-        load_rows(rdo, dOb + (int64_t)q0 * a.lddo, a.lddo, nvalid);
+        load_rows(t.rq, Qb + (int64_t)q0 * a.ldq, a.ldq, nvalid);
+        load_rows(t.rdo, dOb + (int64_t)q0 * a.lddo, a.lddo, nvalid);
         if constexpr (BF16) {
-            load_rows_T(rqt, Qb + (int64_t)q0 * a.ldq, a.ldq, nvalid);
-            load_rows_T(rdot, dOb + (int64_t)q0 * a.lddo, a.lddo, nvalid);
+            load_rows_T(t.rqt, Qb + (int64_t)q0 * a.ldq, a.ldq, nvalid);
+            load_rows_T(t.rdot, dOb + (int64_t)q0 * a.lddo, a.lddo, nvalid);
         }
-        if (threadIdx.x < 64) {
-            const int qq = q0 + threadIdx.x;
-            r_lse = qq < a.Sq ? LSEb[qq] * 1.4426950408889634f : INFINITY;      // log2 domain
-            r_dlt = qq < a.Sq ? DLb[qq] : 0.f;
+        if (tl < 64) {
+            const int qq = q0 + tl;
+            t.lse = qq < a.Sq ? LSEb[qq] * 1.4426950408889634f : INFINITY;      // log2 domain
+            t.dlt = qq < a.Sq ? DLb[qq] : 0.f;
         }
     };
-    auto commit = [&](int buf) {
-        SG::st(smem + buf * NT * TILE, rq);
-        SG::st(smem + buf * NT * TILE + TILE, rdo);
+    auto commit = [&](const Regs &t, int buf) {
+        elem *dst = smem + (buf * G + grp) * NT * TILE;
+        SG::st(dst, t.rq);
+        SG::st(dst + TILE, t.rdo);
         if constexpr (BF16) {
-            SG::stT(smem + buf * NT * TILE + 2 * TILE, rqt);
-            SG::stT(smem + buf * NT * TILE + 3 * TILE, rdot);
+            SG::stT(dst + 2 * TILE, t.rqt);
+            SG::stT(dst + 3 * TILE, t.rdot);
         }
-        if (threadIdx.x < 64) { lse_s[buf][threadIdx.x] = r_lse; dlt_s[buf][threadIdx.x] = r_dlt; }
+        if (tl < 64) {
+            float *st = stat + (buf * G + grp) * 128;
+            st[tl] = t.lse;
+            st[64 + tl] = t.dlt;
+        }
     };
-    if (qstart < a.Sq) {
-        issue(qstart);
-        commit(0);
+    constexpr int STEP = 64 * G;
+    const int qfirst = qstart + grp * 64;
+    if (qfirst < a.Sq) {
+        issue(ra, qfirst);
+        commit(ra, 0);
     }
+    if (qfirst + STEP < a.Sq) issue(ra, qfirst + STEP);
+    if (DIST == 2 && qfirst + 2 * STEP < a.Sq) issue(rb, qfirst + 2 * STEP);
     __syncthreads();
     int cur = 0;
-    for (int q0 = qstart; q0 < a.Sq; q0 += 64, cur ^= 1) {
-        const bool more = q0 + 64 < a.Sq;
-        if (more) issue(q0 + 64);
-        const elem *Qs = smem + cur * NT * TILE, *dOs = Qs + TILE;
+    auto tile_step = [&](Regs &X, int qq0) {
+        const int q0 = qq0 + grp * 64;
+        const elem *Qs = smem + (cur * G + grp) * NT * TILE, *dOs = Qs + TILE;
         const elem *Qt = BF16 ? Qs + 2 * TILE : Qs, *dOt = BF16 ? Qs + 3 * TILE : dOs;
+        const float *lse_t = stat + (cur * G + grp) * 128, *dlt_t = lse_t + 64;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int qb = q0 + sub * 32;
@@ -637,7 +690,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
             mma_tile_x_frag<BF16>(dp, dOs, sub * 32, vf, l31, half);
             const bool edge = anydead || qb + 32 > a.Sq || (a.causal && kmaxw > qb);
             float p[16], ds[16];
-            const float *lse_r = &lse_s[cur][sub * 32 + 4 * half], *dlt_r = &dlt_s[cur][sub * 32 + 4 * half];
+            const float *lse_r = lse_t + sub * 32 + 4 * half, *dlt_r = dlt_t + sub * 32 + 4 * half;
 #pragma unroll
             for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(s[r] * c2 - lse_r[frag_row(r, 0)]);
             if (edge) {
@@ -665,8 +718,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
             mma_T_x_p<BF16>(dv, dOt, sub * 32, p, l31, half);
             mma_T_x_p<BF16>(dk, Qt, sub * 32, ds, l31, half);
         }
-        if (more) commit(cur ^ 1);
+        if (q0 + STEP < a.Sq) {
+            commit(X, cur ^ 1);
+            if (q0 + (DIST + 1) * STEP < a.Sq) issue(X, q0 + (DIST + 1) * STEP);
+        }
         __syncthreads();
+        cur ^= 1;
+    };
+    for (int qq0 = qstart; qq0 < a.Sq; qq0 += 2 * STEP) {              // the bound is the same for both groups (barriers)
+        tile_step(ra, qq0);
+        if (qq0 + STEP < a.Sq) tile_step(rb, qq0 + STEP);
+    }
+    if constexpr (G == 2) {          // group 1's partial dK / dV -> LDS -> group 0
+        float *mb = reinterpret_cast<float *>(smem_raw) + (wave * 64 + lane) * 65;      // 64 floats per lane (+1: bank spread)
+        if (grp == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { mb[r] = dk[0][r]; mb[16 + r] = dk[1][r]; mb[32 + r] = dv[0][r]; mb[48 + r] = dv[1][r]; }
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[0][r] += mb[r]; dk[1][r] += mb[16 + r]; dv[0][r] += mb[32 + r]; dv[1][r] += mb[48 + r]; }
     }
     if (kvalid) {
         store_row<T>(static_cast<T *>(a.Out) + ((int64_t)b * a.Sk + key) * a.ldout + hh * 64, dk, a.scale, half);
@@ -712,12 +784,13 @@ int launch_attn(K kernel, dim3 grid, int G, size_t lds, hipStream_t s, const Att
     return 0;
 }
 #define KK_ATTN_LDS(BF16, G, NT, EXTRA) ((size_t)2 * (G) * (NT) * 64 * ACfg<BF16>::LR * sizeof(typename ACfg<BF16>::elem) + (EXTRA))
-#define KK_ATTN_LAUNCH(KERNEL, BF16, ST16, G, NT)                                                                              \
-    do {                                                                                                                       \
-        int rc__ = (G) == 2 ? launch_attn(KERNEL<BF16, ST16, 2>, grid, 2, KK_ATTN_LDS(BF16, 2, NT, 0), (hipStream_t)stream, a) \
-                            : launch_attn(KERNEL<BF16, ST16, 1>, grid, 1, KK_ATTN_LDS(BF16, 1, NT, 0), (hipStream_t)stream, a); \
-        if (rc__) return rc__;                                                                                                 \
+#define KK_ATTN_LAUNCH_X(KERNEL, BF16, ST16, G, NT, EXTRA)                                                                         \
+    do {                                                                                                                           \
+        int rc__ = (G) == 2 ? launch_attn(KERNEL<BF16, ST16, 2>, grid, 2, KK_ATTN_LDS(BF16, 2, NT, EXTRA), (hipStream_t)stream, a) \
+                            : launch_attn(KERNEL<BF16, ST16, 1>, grid, 1, KK_ATTN_LDS(BF16, 1, NT, EXTRA), (hipStream_t)stream, a); \
+        if (rc__) return rc__;                                                                                                     \
     } while (0)
+#define KK_ATTN_LAUNCH(KERNEL, BF16, ST16, G, NT) KK_ATTN_LAUNCH_X(KERNEL, BF16, ST16, G, NT, 0)
 
 int check_common(const char *name, int B, int heads, int Sq, int Sk, int math, const int64_t *lds, int nld) {
     KK_REQUIRE(B > 0 && heads > 0 && Sq > 0 && Sk > 0, "%s: bad shape B=%d heads=%d Sq=%d Sk=%d", name, B, heads, Sq, Sk);
@@ -780,9 +853,10 @@ extern "C" int kk_attn_bwd_dq(const float *Q, const float *K, const float *V, co
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.lddo = lddo; a.ldout = lddq; a.scale = scale;
     a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop;
     dim3 grid(kk_cdiv(Sq, 128), B * heads);
-    if (io_bf16) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
-    else if (math == KK_MATH_BF16) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((attn_bwd_dq_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    const int G = (Sk > 64 && g_attn_groups == 2) ? 2 : 1;
+    if (io_bf16) KK_ATTN_LAUNCH(attn_bwd_dq_kernel, true, true, G, 3);
+    else if (math == KK_MATH_BF16) KK_ATTN_LAUNCH(attn_bwd_dq_kernel, true, false, G, 3);
+    else KK_ATTN_LAUNCH(attn_bwd_dq_kernel, false, false, G, 2);
     KK_LAUNCH_CHECK("kk_attn_bwd_dq");
     return 0;
 }
@@ -801,9 +875,10 @@ extern "C" int kk_attn_bwd_dkv(const float *Q, const float *K, const float *V, c
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.lddo = lddo; a.ldout = lddk; a.ldout2 = lddv; a.scale = scale;
     a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop;
     dim3 grid(kk_cdiv(Sk, 128), B * heads);
-    if (io_bf16) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
-    else if (math == KK_MATH_BF16) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    const int G = (Sq > 64 && g_attn_groups == 2) ? 2 : 1;          // one query tile: nothing to split
+    if (io_bf16) KK_ATTN_LAUNCH_X(attn_bwd_dkv_kernel, true, true, G, 4, 2 * G * 128 * sizeof(float));
+    else if (math == KK_MATH_BF16) KK_ATTN_LAUNCH_X(attn_bwd_dkv_kernel, true, false, 1, 4, 2 * 128 * sizeof(float));   // (G = 2 would spill)
+    else KK_ATTN_LAUNCH_X(attn_bwd_dkv_kernel, false, false, G, 2, 2 * G * 128 * sizeof(float));
     KK_LAUNCH_CHECK("kk_attn_bwd_dkv");
     return 0;
 }

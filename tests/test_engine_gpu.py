@@ -251,7 +251,7 @@ def test_training_dropout_is_deterministic_per_seed_and_gradients_are_consistent
     l1, g1 = run(100)
     l2, g2 = run(100)
     l3, g3 = run(101)
-    assert l1 == l2                                      # identical masks => identical forward
+    assert abs(l1 - l2) <= 2e-6 * abs(l1)                # identical masks => identical forward (up to the order of fp32 atomics)
     for n in names:                                      # gradient sums use fp32 atomics: equal up to summation order
         assert float((g1[n] - g2[n]).abs().max()) <= 1e-5 + 1e-4 * float(g1[n].abs().max()), n
     assert l1 != l3
