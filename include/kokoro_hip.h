@@ -70,10 +70,13 @@ int kk_attn_fwd(const float *Q, const float *K, const float *V, float *O, float 
 /* Delta[b,head,q] = sum_d dO·O (first step of the backward). */
 int kk_attn_delta(const float *O, const float *dO, float *Delta, int B, int heads, int Sq, int64_t ldo,
                   int64_t lddo, int io_bf16, void *stream);
+/* O == NULL: Delta is read.  O != NULL: Delta is computed here from dO and O (row stride ldo) and WRITTEN, so the
+ * separate kk_attn_delta launch is not needed; kk_attn_bwd_dkv (launched after) reads it. */
 int kk_attn_bwd_dq(const float *Q, const float *K, const float *V, const float *dO, const float *LSE,
-                   const float *Delta, float *dQ, int B, int heads, int Sq, int Sk, int64_t ldq, int64_t ldk,
+                   float *Delta, float *dQ, int B, int heads, int Sq, int Sk, int64_t ldq, int64_t ldk,
                    int64_t ldv, int64_t lddo, int64_t lddq, const uint8_t *key_mask, int causal, float scale,
-                   const uint32_t *seed, uint32_t site, float p_drop, int math, int io_bf16, void *stream);
+                   const uint32_t *seed, uint32_t site, float p_drop, int math, int io_bf16, const float *O,
+                   int64_t ldo, void *stream);
 int kk_attn_bwd_dkv(const float *Q, const float *K, const float *V, const float *dO, const float *LSE,
                     const float *Delta, float *dK, float *dV, int B, int heads, int Sq, int Sk, int64_t ldq,
                     int64_t ldk, int64_t ldv, int64_t lddo, int64_t lddk, int64_t lddv,

@@ -32,6 +32,7 @@ struct AttnArgs {
     const float *LSE, *Delta;
     void *Out, *Out2;
     float *LSEo;
+    float *DeltaOut;                     // dQ kernel: when set (with O), compute Delta = rowsum(dO * O) here and store it
     const uint8_t *key_mask;
     int B, heads, Sq, Sk, causal;
     int64_t ldq, ldk, ldv, ldo, lddo, ldout, ldout2;
@@ -83,6 +84,21 @@ template <> struct RowFrag<false> { float v[32]; };   // v[ks]    = X[row][2 ks 
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+template <bool BF16>
+__device__ __forceinline__ float rowfrag_dot(const RowFrag<BF16> &x, const RowFrag<BF16> &y) {   // this lane's 32 of the 64 d
+    float s = 0.f;
+    if constexpr (BF16) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (float)x.v[ks][j] * (float)y.v[ks][j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) s += x.v[j] * y.v[j];
+    }
+    return s;
+}
 
 template <bool BF16>
 __device__ __forceinline__ void scale_rowfrag(RowFrag<BF16> &f, float k) {
@@ -478,12 +494,21 @@ __global__ __launch_bounds__(256 * G) void attn_bwd_dq_kernel(AttnArgs a) {
     RowFrag<BF16> qf, dof;
     load_rowfrag<BF16, T>(qf, qvalid ? static_cast<const T *>(a.Q) + ((int64_t)b * a.Sq + q) * a.ldq + hh * 64 : nullptr, half);
     load_rowfrag<BF16, T>(dof, qvalid ? static_cast<const T *>(a.dO) + ((int64_t)b * a.Sq + q) * a.lddo + hh * 64 : nullptr, half);
+    float dlt;
+    if (a.DeltaOut) {       // Delta[b,head,q] = sum_d dO*O from the two row fragments already at hand (saves kk_attn_delta)
+        RowFrag<BF16> of;
+        load_rowfrag<BF16, T>(of, qvalid ? static_cast<const T *>(a.O) + ((int64_t)b * a.Sq + q) * a.ldo + hh * 64 : nullptr, half);
+        dlt = rowfrag_dot<BF16>(dof, of);
+        dlt += __shfl_xor(dlt, 32, 64);
+        if (qvalid && half == 0 && grp == 0) a.DeltaOut[((int64_t)b * a.heads + hh) * a.Sq + q] = dlt;
+    } else {
+        dlt = qvalid ? a.Delta[((int64_t)b * a.heads + hh) * a.Sq + q] : 0.f;
+    }
     ProbDrop pd;
     pd.init(a, b, hh);
     if (pd.thr) scale_rowfrag<BF16>(dof, pd.inv_keep);     // dP of a kept element carries 1/(1-p): fold it into dO once
     const float c2 = a.scale * 1.4426950408889634f;
     const float lse2 = qvalid ? a.LSE[((int64_t)b * a.heads + hh) * a.Sq + q] * 1.4426950408889634f : INFINITY;   // log2 domain
-    const float dlt = qvalid ? a.Delta[((int64_t)b * a.heads + hh) * a.Sq + q] : 0.f;
     f32x16 dq[2];
     zero_acc(dq[0]); zero_acc(dq[1]);
     const uint8_t *km = a.key_mask ? a.key_mask + (int64_t)b * a.Sk : nullptr;
@@ -840,10 +865,10 @@ extern "C" int kk_attn_delta(const float *O, const float *dO, float *Delta, int 
 }
 
 extern "C" int kk_attn_bwd_dq(const float *Q, const float *K, const float *V, const float *dO, const float *LSE,
-                              const float *Delta, float *dQ, int B, int heads, int Sq, int Sk, int64_t ldq,
+                              float *Delta, float *dQ, int B, int heads, int Sq, int Sk, int64_t ldq,
                               int64_t ldk, int64_t ldv, int64_t lddo, int64_t lddq, const uint8_t *key_mask,
                               int causal, float scale, const uint32_t *seed, uint32_t site, float p_drop, int math,
-                              int io_bf16, void *stream) {
+                              int io_bf16, const float *O, int64_t ldo, void *stream) {
     KK_REQUIRE(!io_bf16 || math == KK_MATH_BF16, "kk_attn_bwd_dq: bf16 storage needs KK_MATH_BF16");
     const int64_t lds[5] = {ldq, ldk, ldv, lddo, lddq};
     if (int rc = check_common("kk_attn_bwd_dq", B, heads, Sq, Sk, math, lds, 5)) return rc;
@@ -851,6 +876,10 @@ extern "C" int kk_attn_bwd_dq(const float *Q, const float *K, const float *V, co
     a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.LSE = LSE; a.Delta = Delta; a.Out = dQ; a.key_mask = key_mask;
     a.B = B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.causal = causal;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.lddo = lddo; a.ldout = lddq; a.scale = scale;
+    if (O) {                                  // Delta is an OUTPUT of this call (and still the input of kk_attn_bwd_dkv)
+        KK_REQUIRE(ldo % 8 == 0 && ldo >= 64 * heads, "kk_attn_bwd_dq: row stride of O unsupported");
+        a.O = O; a.ldo = ldo; a.DeltaOut = Delta;
+    }
     a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop;
     dim3 grid(kk_cdiv(Sq, 128), B * heads);
     const int G = (Sk > 64 && g_attn_groups == 2) ? 2 : 1;

@@ -476,7 +476,7 @@ class KokoroEngine:
             d_out = masked
         self._wgrad(d_out, ctx, G[prefix + ".w_o.weight"], None if head_done else G[prefix + ".w_o.bias"])
         self._dgrad(d_out, self._W(prefix + ".w_o.weight"), dctx)
-        kk.call("kk_attn_delta", ctx, dctx, delta, B, h, Sq, H, H, i16)
+        # (Delta = rowsum(dctx * ctx) is computed by the dQ kernel from fragments it holds anyway, and read by the dK/dV kernel)
         if xkv is None:
             raw, nrm = self._buf(key + ".qkv_raw", Nq, 3 * H, dtype=dt), self._buf(key + ".qkv_n", Nq, 3 * H, dtype=dt)
             dn, draw = self._buf("tmp.dqkv_n", Nq, 3 * H, dtype=dt), self._buf("tmp.dqkv_raw", Nq, 3 * H, dtype=dt)
@@ -493,7 +493,7 @@ class KokoroEngine:
         cz = 1 if causal else 0
         if xkv is None:
             kk.call("kk_attn_bwd_dq", q_n, k_n, v_n, dctx, lse, delta, dq_n, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H, ld(dq_n),
-                    key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16)
+                    key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16, ctx, H)
             kk.call("kk_attn_bwd_dkv", q_n, k_n, v_n, dctx, lse, delta, dk_n, dv_n, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H,
                     ld(dk_n), ld(dv_n), key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16)
             kk.call("kk_headnorm_rope_bwd", dn, 3 * H, raw, 3 * H, draw, 3 * H, Nq, h, Sq, 3, gq, gk, gv, dgq, dgk, dgv,
@@ -501,14 +501,14 @@ class KokoroEngine:
             self._wgrad(draw, xq, a.fused(a.g, prefix + ".w_q.weight", 3))
             self._dgrad(draw, self._Wf(prefix + ".w_q.weight", 3), d_xq)
             return
+        kk.call("kk_attn_bwd_dq", q_n, k_n, v_n, dctx, lse, delta, dq_n, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H, ld(dq_n),
+                key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16, ctx, H)      # also writes delta
         if d_xkv is not None:        # key/value branch; its two GEMMs run once for all layers (_cross_kv_bwd_all)
             dkv_raw, dkv_n = self._cross_kv(layer, Nk, dt, "d")
             kk.call("kk_attn_bwd_dkv", q_n, k_n, v_n, dctx, lse, delta, dkv_n, dkv_n[:, H:], B, h, Sq, Sk, ld(q_n), ld(k_n),
                     ld(v_n), H, ld(dkv_n), ld(dkv_n), key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16)
             kk.call("kk_headnorm_rope_bwd", dkv_n, ld(dkv_n), kv_raw, ld(kv_raw), dkv_raw, ld(dkv_raw), Nk, h, Sk, 2, gk, gv, None,
                     dgk, dgv, None, self._headnorm_partials(key + ".kv", Nk, (dgk, dgv)), 0, None, None, i16)
-        kk.call("kk_attn_bwd_dq", q_n, k_n, v_n, dctx, lse, delta, dq_n, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H, ld(dq_n),
-                key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16)
         kk.call("kk_headnorm_rope_bwd", dq_n, H, q_raw, H, dq_raw, H, Nq, h, Sq, 1, gq, None, None, dgq, None, None,
                 self._headnorm_partials(key + ".q", Nq, (dgq,)), 0, None, None, i16)
         self._wgrad(dq_raw, xq, G[prefix + ".w_q.weight"])

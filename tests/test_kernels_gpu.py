@@ -196,7 +196,7 @@ def test_attention_fwd_bwd(kk, math_mode, B, h, Sq, Sk, causal, masked):
     delta = torch.zeros(B, h, Sq, device="cuda")
     kk.call("kk_attn_delta", Od, dOd, delta, B, h, Sq, H, H, 0)
     dQ, dK, dV = (torch.zeros_like(t) for t in (Qd, Kd, Vd))
-    kk.call("kk_attn_bwd_dq", Qd, Kd, Vd, dOd, lse, delta, dQ, B, h, Sq, Sk, H, H, H, H, H, kmd, causal, scale, None, 0, 0.0, math_mode, 0)
+    kk.call("kk_attn_bwd_dq", Qd, Kd, Vd, dOd, lse, delta, dQ, B, h, Sq, Sk, H, H, H, H, H, kmd, causal, scale, None, 0, 0.0, math_mode, 0, None, 0)
     kk.call("kk_attn_bwd_dkv", Qd, Kd, Vd, dOd, lse, delta, dK, dV, B, h, Sq, Sk, H, H, H, H, H, H, kmd, causal, scale,
             None, 0, 0.0, math_mode, 0)
     atol, rtol = (1e-4, 1e-3) if math_mode == 0 else (8e-2, 5e-2)
@@ -634,7 +634,7 @@ def test_attention_probability_dropout(kk, math_mode, causal):
     delta = torch.zeros(B, h, S, device="cuda")
     kk.call("kk_attn_delta", O2, dOd, delta, B, h, S, H, H, 0)
     dQ, dK, dV = torch.zeros_like(Qd), torch.zeros_like(Kd), torch.zeros_like(V2d)
-    kk.call("kk_attn_bwd_dq", Qd, Kd, V2d, dOd, lse, delta, dQ, B, h, S, S, H, H, H, H, H, None, causal, 0.125, _seed(5), 9, p, math_mode, 0)
+    kk.call("kk_attn_bwd_dq", Qd, Kd, V2d, dOd, lse, delta, dQ, B, h, S, S, H, H, H, H, H, None, causal, 0.125, _seed(5), 9, p, math_mode, 0, None, 0)
     kk.call("kk_attn_bwd_dkv", Qd, Kd, V2d, dOd, lse, delta, dK, dV, B, h, S, S, H, H, H, H, H, H, None, causal, 0.125,
             _seed(5), 9, p, math_mode, 0)
     atol, rtol = (2e-2, 1e-2) if math_mode == 0 else (0.15, 0.1)
@@ -706,8 +706,8 @@ def test_attention_bf16_storage(kk, B, h, Sq, Sk, causal, masked, strided):
         close(d16, d32, 1e-4, 1e-5, "attn delta bf16 storage")
         g32 = [torch.zeros(B, S, H, device="cuda") for S in (Sq, Sk, Sk)]
         g16 = [torch.zeros(B, S, H, device="cuda", dtype=torch.bfloat16) for S in (Sq, Sk, Sk)]
-        kk.call("kk_attn_bwd_dq", Q, K, V, dO, l32, d32, g32[0], B, h, Sq, Sk, ld, ld, ld, H, H, kmd, causal, 0.125, seed, 4, p, 1, 0)
-        kk.call("kk_attn_bwd_dq", Q16, K16, V16, dO16, l16, d16, g16[0], B, h, Sq, Sk, ld, ld, ld, H, H, kmd, causal, 0.125, seed, 4, p, 1, 1)
+        kk.call("kk_attn_bwd_dq", Q, K, V, dO, l32, d32, g32[0], B, h, Sq, Sk, ld, ld, ld, H, H, kmd, causal, 0.125, seed, 4, p, 1, 0, None, 0)
+        kk.call("kk_attn_bwd_dq", Q16, K16, V16, dO16, l16, d16, g16[0], B, h, Sq, Sk, ld, ld, ld, H, H, kmd, causal, 0.125, seed, 4, p, 1, 1, None, 0)
         kk.call("kk_attn_bwd_dkv", Q, K, V, dO, l32, d32, g32[1], g32[2], B, h, Sq, Sk, ld, ld, ld, H, H, H, kmd, causal, 0.125,
                 seed, 4, p, 1, 0)
         kk.call("kk_attn_bwd_dkv", Q16, K16, V16, dO16, l16, d16, g16[1], g16[2], B, h, Sq, Sk, ld, ld, ld, H, H, H, kmd, causal, 0.125,
@@ -965,3 +965,20 @@ def test_sublayer_tail_backward_equals_separate_kernels(kk, ffn, bf, acc):
     close(dbias_b, dbias_a, 0.5 if bf else 2e-3, 1e-2 if bf else 1e-4, "fused bwd tail: bias column sums")
     if ffn:
         close(dgain_b, dgain_a, 2e-3, 1e-4, "fused bwd tail: RMSNorm gain")
+
+
+def test_attention_dq_computes_delta_in_kernel(kk):
+    """kk_attn_bwd_dq with O given: Delta written by the kernel == kk_attn_delta, and dQ identical to the two-launch form."""
+    g = torch.Generator().manual_seed(2)
+    B, h, S = 2, 4, 200
+    H = h * 64
+    q, k, v, do = (dev(torch.randn(B * S, H, generator=g)).bfloat16() for _ in range(4))
+    o, lse = torch.empty(B * S, H, device="cuda", dtype=torch.bfloat16), torch.empty(B, h, S, device="cuda")
+    kk.call("kk_attn_fwd", q, k, v, o, lse, B, h, S, S, H, H, H, H, None, 1, 0.125, None, 0, 0.0, 1, 1)
+    d_ref, d_new = torch.empty(B, h, S, device="cuda"), torch.full((B, h, S), 9.0, device="cuda")
+    kk.call("kk_attn_delta", o, do, d_ref, B, h, S, H, H, 1)
+    dq_ref, dq_new = torch.empty_like(q), torch.empty_like(q)
+    kk.call("kk_attn_bwd_dq", q, k, v, do, lse, d_ref, dq_ref, B, h, S, S, H, H, H, H, H, None, 1, 0.125, None, 0, 0.0, 1, 1, None, 0)
+    kk.call("kk_attn_bwd_dq", q, k, v, do, lse, d_new, dq_new, B, h, S, S, H, H, H, H, H, None, 1, 0.125, None, 0, 0.0, 1, 1, o, H)
+    close(d_new, d_ref, 1e-5, 1e-5, "delta computed in the dQ kernel")
+    close(dq_new, dq_ref, 1e-3, 1e-3, "dQ with in-kernel delta")
