@@ -315,3 +315,35 @@ def test_global_loss_normalisers_two_shards_on_one_gpu(eng_mod, golden_dir):
     with pytest.raises(RuntimeError):
         e.loss_sync = fake_all_reduce
         e.train_step_graphed(_cuda(glob))
+
+
+def test_bf16_mode_odd_ragged_shapes(eng_mod, golden_dir):
+    """bf16 storage + DMA GEMM core + grouped attention on shapes that are multiples of nothing (B 3, T 437, P 53, ragged
+    lengths): finite, and the gradients point where the fp32 parity mode's do."""
+    fx, d, _, P = _load(golden_dir, "mid_chunked")
+    batch = O.synthetic_batch(3, 437, 53, d, seed=8)
+    batch["mel_lengths"] = torch.tensor([437, 301, 399])
+    batch["phoneme_lengths"] = torch.tensor([53, 37, 50])
+    ref = _engine(eng_mod, d, P)
+    ref.zero_grad()
+    lo = ref.forward_backward(_cuda(batch))["losses"].clone()
+    e = _engine(eng_mod, d, P, math_mode="bf16")
+    assert e.storage == "bf16"
+    e.zero_grad()
+    lb = e.forward_backward(_cuda(batch))["losses"]
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(lb).all())
+    np.testing.assert_allclose(lb.cpu().numpy(), lo.cpu().numpy(), atol=3e-2, rtol=3e-2)
+    cos = []
+    for n in O.param_shapes(d):
+        a, b = e.arena.G[n].double().flatten(), ref.arena.G[n].double().flatten()
+        assert bool(torch.isfinite(a).all()), n
+        if float(b.norm()) > 1e-6:
+            cos.append(float(a @ b / (a.norm() * b.norm() + 1e-30)))
+    assert min(cos) > 0.97 and float(np.mean(cos)) > 0.995, (min(cos), float(np.mean(cos)))
+    # and with every random mask on: finite, optimizer step not skipped
+    e.train_dropout = True
+    for _ in range(3):
+        e.train_step(_cuda(batch))
+    st = e.opt_stats()
+    assert st["skipped"] == 0 and bool(torch.isfinite(e.arena.p).all())
