@@ -135,10 +135,14 @@ def main():
     eng = KokoroEngine(ModelDims(), hp, math_mode=args.math, total_steps=20000, seed=0,
                        storage=args.storage)                           # same seed ⇒ identical replicas
     eng.train_dropout = not args.no_dropout          # reference-faithful: dropout, stochastic depth, SpecAugment on
-    sync = dp.GradSync(world)
+    force = os.environ.get("KK_DP_FORCE") == "1"       # run the data-parallel code path (1-rank group) on a single GPU
+    sync = dp.GradSync(world, force=force)
+    if os.environ.get("KK_DP_OVERLAP") == "1":          # two buckets, the first all-reduced beside the second half of the backward
+        eng.dp_overlap_layer = eng.dims.dec_layers // 2
     eng.dp_loss_scale = sync.loss_scale
     batch = {k: v.cuda() for k, v in synthetic_batch(B, T, P, seed=1234 + rank).items()}
-    step = (lambda: eng.train_step(batch)) if args.no_graph else (lambda: eng.train_step_graphed(batch, sync if world > 1 else None))
+    use_sync = world > 1 or force
+    step = (lambda: eng.train_step(batch)) if args.no_graph else (lambda: eng.train_step_graphed(batch, sync if use_sync else None))
     if args.no_graph and world > 1:
         def step():   # noqa: F811
             eng.zero_grad()
@@ -208,6 +212,9 @@ def main():
            "config": {"workload": f"kokoro acoustic-model train step, {B}x{T} mel frames x {P} phonemes per GPU "
                                   f"(BASELINE configs[1]), 49.4M params, fwd+loss+bwd+clip+AdamW+EMA every step",
                       "global_batch": world * B, "frames": T, "phonemes": P, "parallelism": f"dp{world}",
+                      "grad_allreduce": (("2 buckets, first overlapped with the backward of decoder layers < %d" % eng.dp_overlap_layer)
+                                         if (use_sync and not args.no_graph and eng.dp_overlap_layer is not None) else
+                                         ("after the backward" if use_sync else "none (1 GPU)")),
                       "grad_accumulation": 1,
                       "dropout": ("off (p=0 parity configuration)" if args.no_dropout else
                                   "on: enc 0.15 / dec 0.20 / dec-input 0.15 / variance 0.10, stochastic depth 0.1, SpecAugment (config.py defaults)"),

@@ -29,7 +29,7 @@ def env_world() -> Tuple[int, int, int]:
 
 def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
     rank, world, local = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("KK_DP_FORCE") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -54,21 +54,45 @@ class GradSync:
     """SUM all-reduce of the flat gradient arena in fixed-size buckets (one large message per bucket keeps the
     ring per-link bound instead of latency bound; 7 x ~153 GB/s xGMI links per GPU)."""
 
-    def __init__(self, world: int, bucket_elems: int = 32 * 1024 * 1024):
+    def __init__(self, world: int, bucket_elems: int = 32 * 1024 * 1024, force: bool = False):
         self.world = world
         self.bucket = bucket_elems
+        self.force = force          # exercise the collectives in a 1-rank group too (tests / KK_DP_FORCE=1)
 
     @property
     def loss_scale(self) -> float:
         """Fold the 1/world of the gradient mean into the loss so the collective is a plain SUM."""
         return 1.0 / self.world
 
+    def _active(self) -> bool:
+        return self.world > 1 or (self.force and dist.is_initialized())
+
     def __call__(self, flat_grad: torch.Tensor) -> None:
-        if self.world == 1:
+        if not self._active():
             return
         n = flat_grad.numel()
         for o in range(0, n, self.bucket):
             dist.all_reduce(flat_grad[o:min(n, o + self.bucket)], op=dist.ReduceOp.SUM)
+
+    # Overlapped form (engine.train_step_graphed): `start` launches the exchange of the ranges that are already final
+    # asynchronously — RCCL runs on its own stream after the work queued so far, the caller keeps queueing the rest of
+    # the backward — and `finish` exchanges the remaining ranges and makes the current stream wait for everything.
+    def start(self, flat_grad: torch.Tensor, ranges):
+        works = []
+        if self._active():
+            for beg, end in ranges:
+                for o in range(beg, end, self.bucket):
+                    works.append(dist.all_reduce(flat_grad[o:min(end, o + self.bucket)], op=dist.ReduceOp.SUM, async_op=True))
+        return works
+
+    def finish(self, flat_grad: torch.Tensor, ranges, works) -> None:
+        if not self._active():
+            return
+        for beg, end in ranges:
+            for o in range(beg, end, self.bucket):
+                dist.all_reduce(flat_grad[o:min(end, o + self.bucket)], op=dist.ReduceOp.SUM)
+        for w in works:
+            w.wait()
 
 
 class LossSync:

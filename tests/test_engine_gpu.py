@@ -347,3 +347,60 @@ def test_bf16_mode_odd_ragged_shapes(eng_mod, golden_dir):
         e.train_step(_cuda(batch))
     st = e.opt_stats()
     assert st["skipped"] == 0 and bool(torch.isfinite(e.arena.p).all())
+
+
+def test_split_backward_graphs_for_overlapped_allreduce(eng_mod, golden_dir):
+    """Data-parallel replay path: the backward captured as two hipGraphs with the exchange of the already-final gradient
+    ranges started in between.  With an identity exchange it must train exactly like the single-graph path, the early
+    and late ranges must partition the arena, and the early ranges must really be final at the split."""
+    fx, d, batch, P = _load(golden_dir, "tiny_full")
+    b = _cuda(batch)
+
+    class FakeSync:                                      # stands in for dp.GradSync (1 rank: the sum is the identity)
+        loss_scale = 1.0
+
+        def __init__(self):
+            self.calls, self.snap = [], None
+
+        def __call__(self, flat):
+            self.calls.append("all")
+
+        def start(self, flat, ranges):
+            self.calls.append(("start", tuple(ranges)))
+            self.snap = (flat.clone(), tuple(ranges))     # what an all-reduce launched here would read
+            return ["w"]
+
+        def finish(self, flat, ranges, works):
+            assert works == ["w"]
+            self.calls.append(("finish", tuple(ranges)))
+    engines, syncs = [], []
+    for overlap in (False, True):
+        e = _engine(eng_mod, d, P, math_mode="bf16", gradient_accumulation_steps=1)
+        e.train_dropout = True
+        e.dp_overlap_layer = d.dec_layers // 2 if overlap else None
+        s = FakeSync()
+        for _ in range(4):                               # eager, capture, replay, replay
+            e.train_step_graphed(b, s)
+        torch.cuda.synchronize()
+        engines.append(e)
+        syncs.append(s)
+    plain, split = engines
+    assert syncs[0].calls == ["all"] * 4
+    assert [c[0] if isinstance(c, tuple) else c for c in syncs[1].calls] == ["all", "start", "finish", "start", "finish", "start", "finish"]
+    early, late = split.early_late_ranges(split.dp_overlap_layer)
+    cover = sorted(early + late)
+    assert cover[0][0] == 0 and cover[-1][1] == split.arena.total and all(x[1] == y[0] for x, y in zip(cover, cover[1:]))
+    late_names = [n for n in split.arena.param_names if any(lo <= split.arena.offset[n] < hi for lo, hi in late)]
+    assert any(n.startswith("decoder.layers.0.") for n in late_names) and "mel_projection_in.weight" in late_names
+    ckv = lambda n: n.endswith("cross_attn.w_k.weight") or n.endswith("cross_attn.w_v.weight")      # batched: late for all layers
+    assert all(ckv(n) for n in late_names if n.startswith("decoder.layers.1."))                       # 2 layers: split at 1
+    assert not any(n.startswith("transformer_encoder") for n in late_names)
+    # the early ranges were final when `start` saw them (same values as at the end of the step's backward)
+    snap, ranges = syncs[1].snap
+    for lo, hi in ranges:
+        assert torch.equal(snap[lo:hi], split.arena.g[lo:hi]), "an early range changed after the exchange was started"
+    assert float(snap.abs().sum()) > 0
+    # same training trajectory (same seeds => same masks); fp32 atomics reorder sums
+    assert split.opt_stats()["attempt"] == plain.opt_stats()["attempt"] == 4
+    err = float((split.arena.p - plain.arena.p).abs().max())
+    assert err <= 2e-5, err
