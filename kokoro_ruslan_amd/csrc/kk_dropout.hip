@@ -174,9 +174,11 @@ struct SubInArgs {
     DropArgs d;
 };
 
-template <typename TN, typename TY, int NV>
-__global__ __launch_bounds__(256) void sublayer_in_bwd_kernel(SubInArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];   // [4 waves][4][H]: per-wave column sums, no LDS atomics
+// SIB_WAVES waves x 2 rows per workgroup; 8 waves (two per SIMD hide each other's load latency) while the per-wave
+// column-sum slabs fit 64 KB of LDS (H <= 512), fewer above.
+template <typename TN, typename TY, int NV, int SIB_WAVES>
+__global__ __launch_bounds__(64 * SIB_WAVES) void sublayer_in_bwd_kernel(SubInArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [waves][4][H]: per-wave column sums, no LDS atomics
     const int lane = threadIdx.x & 63, H = a.H;
     const uint32_t seed = *a.d.seed;
     const uint32_t t1 = kk_drop_threshold(a.d.p1), t2 = kk_drop_threshold(a.d.p2);
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(256) void sublayer_in_bwd_kernel(SubInArgs a) {
     const TN *dn = static_cast<const TN *>(a.dn);
     const TY *yy = static_cast<const TY *>(a.y);
     TY *dy = static_cast<TY *>(a.dy);
-    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < a.rows; row += (int64_t)gridDim.x * 4) {
+    for (int64_t row = (int64_t)blockIdx.x * SIB_WAVES + (threadIdx.x >> 6); row < a.rows; row += (int64_t)gridDim.x * SIB_WAVES) {
         const float mu = a.mean[row], rs = a.rstd[row], rsf = ffn ? a.rstd_f[row] : 0.f;
         float4 xh[NV], dg[NV], old[NV], yv[NV];
         float s1 = 0.f, s2 = 0.f;
@@ -265,22 +267,27 @@ __global__ __launch_bounds__(256) void sublayer_in_bwd_kernel(SubInArgs a) {
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x * 4; c < 4 * H; c += 1024) {
-        const float4 w0 = ld4(sm + c), w1 = ld4(sm + 4 * H + c), w2 = ld4(sm + 8 * H + c), w3 = ld4(sm + 12 * H + c);
-        st4(a.partials + (int64_t)blockIdx.x * 4 * H + c,
-            make_float4(w0.x + w1.x + w2.x + w3.x, w0.y + w1.y + w2.y + w3.y, w0.z + w1.z + w2.z + w3.z, w0.w + w1.w + w2.w + w3.w));
+    for (int c = threadIdx.x * 4; c < 4 * H; c += 256 * SIB_WAVES) {
+        float4 t = ld4(sm + c);
+#pragma unroll
+        for (int w = 1; w < SIB_WAVES; ++w) {
+            const float4 u = ld4(sm + w * 4 * H + c);
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        st4(a.partials + (int64_t)blockIdx.x * 4 * H + c, t);
     }
 }
 
 template <typename TN, typename TY>
 void launch_subin(const SubInArgs &a, int blocks, hipStream_t s) {
-    const dim3 grid(blocks), blk(256);
-    const size_t shm = (size_t)16 * a.H * sizeof(float);
+    const dim3 grid(blocks);
     const int nv = kk_cdiv(a.H, 256);
-    if (nv <= 1) hipLaunchKernelGGL((sublayer_in_bwd_kernel<TN, TY, 1>), grid, blk, shm, s, a);
-    else if (nv <= 2) hipLaunchKernelGGL((sublayer_in_bwd_kernel<TN, TY, 2>), grid, blk, shm, s, a);
-    else if (nv <= 4) hipLaunchKernelGGL((sublayer_in_bwd_kernel<TN, TY, 4>), grid, blk, shm, s, a);
-    else hipLaunchKernelGGL((sublayer_in_bwd_kernel<TN, TY, 8>), grid, blk, shm, s, a);
+#define KK_SIB(NV, WV) hipLaunchKernelGGL((sublayer_in_bwd_kernel<TN, TY, NV, WV>), grid, dim3(64 * WV), (size_t)WV * 4 * a.H * sizeof(float), s, a)
+    if (nv <= 1) KK_SIB(1, 8);
+    else if (nv <= 2) KK_SIB(2, 8);
+    else if (nv <= 4) KK_SIB(4, 4);
+    else KK_SIB(8, 2);
+#undef KK_SIB
 }
 
 // SpecAugment: per sample `nt` time masks of t in [0, time_limit) frames at t0 in [0, max(1, T - t)) and `nf`
@@ -363,7 +370,7 @@ extern "C" int kk_sublayer_out_fwd(const float *y, int y_bf16, const float *gain
 }
 
 extern "C" int kk_sublayer_in_bwd_blocks(int64_t rows) {
-    int blocks = kk_cdiv(rows, 16);                       // four rows per wave: the column-sum epilogue is per workgroup
+    int blocks = kk_cdiv(rows, 16);                       // the column-sum epilogue is per workgroup: few, fat workgroups
     return blocks > 256 ? 256 : (blocks < 1 ? 1 : blocks);
 }
 
