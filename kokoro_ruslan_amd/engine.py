@@ -331,15 +331,12 @@ class KokoroEngine:
         kk.call("kk_layernorm_bwd", dy, x, P[prefix + ".weight"], self._buf(key + ".mean", rows), self._buf(key + ".rstd", rows),
                 dx, 1 if accumulate else 0, G[prefix + ".weight"], G[prefix + ".bias"], part, rows, H, _b16(dy))
 
-    def _tail_bwd(self, key, dn, x, prefix, dres, accumulate, head) -> bool:
+    def _tail_bwd(self, key, dn, x, prefix, dres, accumulate, head) -> None:
         """Backward of LayerNorm `key` (input x = the residual stream after the sub-layer `head`), fused — when that
         sub-layer ran its dropout tail — with the head of the sub-layer's own backward (kk_sublayer_in_bwd): masks,
         RMSNorm backward for an FFN, bias column sums.  head = (kind, ffn_key, prefix, S, site, p, dpr, dtype).
-        Returns True when the head was done here (the sub-layer's backward then starts from the prepared buffers)."""
+        The sub-layer's backward then starts from the prepared buffers (tmp.df2 / tmp.d_attn_proj)."""
         kind, hkey, hprefix, S, site, p, dpr, dt = head
-        if not (p > 0.0 or dpr > 0.0):
-            self._ln_bwd(key, dn, x, prefix, dres, accumulate)
-            return False
         P, G = self.arena.P, self.arena.G
         rows, H = x.shape
         nb = kk.load().kk_sublayer_in_bwd_blocks(rows)
@@ -358,7 +355,6 @@ class KokoroEngine:
         kk.call("kk_sublayer_in_bwd", dn, _b16(dn), x, P[prefix + ".weight"], self._buf(key + ".mean", rows), self._buf(key + ".rstd", rows),
                 dres, 1 if accumulate else 0, f2, gain, rstd_f, dy, _b16(dy), part, rows, H, S, self.rng, site, p, site + 1, p2,
                 site + 2, dpr)
-        return True
 
     def _reduce_partials(self, shape_key) -> None:
         """One launch that adds the column sums of every partial matrix written so far (by streams already joined into
@@ -400,9 +396,6 @@ class KokoroEngine:
                 site, p, site + 1, p2, site + 2, dpr)
         return n
 
-    def _residual_bwd(self, dy, dx, S, site, p, dpr, p2=0.0):
-        kk.call("kk_dropout_bwd", dy, dx, dy.shape[0], dy.shape[1], S, self.rng, site, p, site + 1, p2, site + 2, dpr, _b16(dx))
-
     # ------------------------------------------------------------------ attention sub-layer
     def _attn_fwd(self, key, prefix, xq, xkv, B, Sq, Sk, rope, causal, key_mask, x_res, x_out, site=0, p=0.0, dpr=0.0, next_ln=None,
                   layer=0):
@@ -430,12 +423,9 @@ class KokoroEngine:
         ctx, lse = self._buf(key + ".ctx", Nq, H, dtype=dt), self._buf(key + ".lse", B, h, Sq)
         kk.call("kk_attn_fwd", q_n, k_n, v_n, ctx, lse, B, h, Sq, Sk, q_n.stride(0), k_n.stride(0), v_n.stride(0), H, key_mask,
                 1 if causal else 0, 0.125, self.rng, site + 3, p, self.math, i16)
-        if p > 0.0 or dpr > 0.0:
-            proj = self._buf("tmp.attn_proj", Nq, H)
-            self._linear(ctx, self._W(prefix + ".w_o.weight"), P[prefix + ".w_o.bias"], proj)
-            return self._sublayer_tail(proj, x_res, x_out, Sq, site, p, dpr, 0.0, None, None, next_ln)
-        self._linear(ctx, self._W(prefix + ".w_o.weight"), P[prefix + ".w_o.bias"], x_out, res=x_res)
-        return None
+        proj = self._buf("tmp.attn_proj", Nq, H)
+        self._linear(ctx, self._W(prefix + ".w_o.weight"), P[prefix + ".w_o.bias"], proj)
+        return self._sublayer_tail(proj, x_res, x_out, Sq, site, p, dpr, 0.0, None, None, next_ln)   # (p = 0: masks are all ones)
 
     def _cross_kv(self, layer, Nk, dt, which=""):
         """(raw, normed) K|V of cross-attention layer `layer`: column slices [.., 2H] of the all-layer buffers (row stride
@@ -466,7 +456,7 @@ class KokoroEngine:
         self._dgrad(draw_all, self._Wf("decoder.layers.0.cross_attn.w_k.weight", 2 * L), d_xkv)
 
     def _attn_bwd(self, key, prefix, d_out, xq, xkv, B, Sq, Sk, rope, causal, key_mask, d_xq, d_xkv, d_xkv_beta,
-                  site=0, p=0.0, dpr=0.0, head_done=False, layer=0):
+                  site=0, p=0.0, dpr=0.0, layer=0):
         """Given d_out = dL/d(sub-layer output, pre-residual), accumulate parameter grads, write d_xq (dL/d xq) and,
         for cross-attention, d_xkv (+= when d_xkv_beta == 1)."""
         a, P, G, H, h = self.arena, self.arena.P, self.arena.G, self.dims.hidden, self.dims.heads
@@ -478,13 +468,10 @@ class KokoroEngine:
         # cross-attention: dctx / delta are read by the K/V branch on its own stream, so each layer keeps its own
         ck = "tmp" if xkv is None else key
         dctx, delta = self._buf(ck + ".dctx", Nq, H, dtype=dt), self._buf(ck + ".delta", B, h, Sq)
-        if head_done:                                     # _tail_bwd already wrote the masked gradient and the bias sums
-            d_out = self._buf("tmp.d_attn_proj", Nq, H, dtype=dt)
-        elif p > 0.0 or dpr > 0.0:
-            masked = self._buf("tmp.d_attn_proj", Nq, H, dtype=dt)    # bf16 in the bf16 mode: operand of two GEMMs
-            self._residual_bwd(d_out, masked, Sq, site, p, dpr)
-            d_out = masked
-        self._wgrad(d_out, ctx, G[prefix + ".w_o.weight"], None if head_done else G[prefix + ".w_o.bias"])
+        # _tail_bwd (the fused LayerNorm backward before this call) already wrote the masked gradient of the projection
+        # output and the column sums for w_o.bias
+        d_out = self._buf("tmp.d_attn_proj", Nq, H, dtype=dt)
+        self._wgrad(d_out, ctx, G[prefix + ".w_o.weight"], None)
         self._dgrad(d_out, self._W(prefix + ".w_o.weight"), dctx)
         # (Delta = rowsum(dctx * ctx) is computed by the dQ kernel from fragments it holds anyway, and read by the dK/dV kernel)
         if xkv is None:
@@ -534,13 +521,11 @@ class KokoroEngine:
         self._linear(y, self._W(prefix + ".linear1.weight"), P[prefix + ".linear1.bias"], h1)
         kk.call("kk_glu_fwd", h1, g, N, Fd, self.rng, site + 4, p, i16)
         self._linear(g, self._W(prefix + ".linear2.weight"), P[prefix + ".linear2.bias"], f2)
-        if p > 0.0 or dpr > 0.0:      # rmsnorm -> FFN dropout (:111) -> drop_path -> residual dropout (+ the next LayerNorm)
-            return self._sublayer_tail(f2, x_res, x_out, S, site, p, dpr, p, P[prefix + ".output_norm.weight"],
-                                       self._buf(key + ".rstd_f", N), next_ln)
-        kk.call("kk_rmsnorm_fwd", f2, P[prefix + ".output_norm.weight"], x_res, x_out, self._buf(key + ".rstd_f", N), N, H, i16)
-        return None
+        # rmsnorm -> FFN dropout (:111) -> drop_path -> residual dropout (+ the next LayerNorm), one launch
+        return self._sublayer_tail(f2, x_res, x_out, S, site, p, dpr, p, P[prefix + ".output_norm.weight"],
+                                   self._buf(key + ".rstd_f", N), next_ln)
 
-    def _ffn_bwd(self, key, prefix, d_out, y, d_y, Fd, S=1, site=0, p=0.0, dpr=0.0, head_done=False):
+    def _ffn_bwd(self, key, prefix, d_out, y, d_y, Fd, S=1, site=0, p=0.0, dpr=0.0):
         P, G = self.arena.P, self.arena.G
         N, H = y.shape
         dt, i16 = y.dtype, _b16(y)
@@ -548,15 +533,8 @@ class KokoroEngine:
                      self._buf(key + ".f2", N, H, dtype=dt))
         df2, dg, dh1 = (self._buf("tmp.df2", N, H, dtype=dt), self._buf("tmp.dg", N, Fd, dtype=dt),
                         self._buf("tmp.dh1", N, 2 * Fd, dtype=dt))
-        if not head_done:                                 # else _tail_bwd already produced df2 (masks + RMSNorm backward + bias sums)
-            if p > 0.0 or dpr > 0.0:
-                masked = self._buf("tmp.d_ffn_norm", N, H)
-                self._residual_bwd(d_out, masked, S, site, p, dpr, p2=p)
-                d_out = masked
-            part = self._partials(key + ".on", N, H, H, G[prefix + ".output_norm.weight"], None, H)
-            kk.call("kk_rmsnorm_bwd", d_out, f2, P[prefix + ".output_norm.weight"], self._buf(key + ".rstd_f", N), df2,
-                    G[prefix + ".output_norm.weight"], part, N, H, i16)
-        self._wgrad(df2, g, G[prefix + ".linear2.weight"], None if head_done else G[prefix + ".linear2.bias"])
+        # _tail_bwd already produced df2 (masks + RMSNorm backward) and the column sums for linear2.bias / output_norm
+        self._wgrad(df2, g, G[prefix + ".linear2.weight"], None)
         self._dgrad(df2, self._W(prefix + ".linear2.weight"), dg)
         kk.call("kk_glu_bwd", dg, h1, dh1, N, Fd, self.rng, site + 4, p, i16)
         self._wgrad(dh1, y, G[prefix + ".linear1.weight"], G[prefix + ".linear1.bias"])
@@ -799,7 +777,7 @@ class KokoroEngine:
             # every LayerNorm's backward is fused with the head of the backward of the sub-layer that produced its input
             ehead = lambda kind, i: (kind, f"enc{i}.ff", f"transformer_encoder_layers.{i}" + (".ff" if kind == "ffn" else ".self_attn"),
                                      Pn, 1000 + 32 * i + (8 if kind == "ffn" else 0), p_enc, self._dpr(i, d.enc_layers), edt)
-            hd = self._tail_bwd("enc.norm", d_enc, enc_last, "encoder_norm", dx, False, ehead("ffn", d.enc_layers - 1))
+            self._tail_bwd("enc.norm", d_enc, enc_last, "encoder_norm", dx, False, ehead("ffn", d.enc_layers - 1))
             dne = self._buf("tmp.dne", Ne, H, dtype=edt)
             for i in reversed(range(d.enc_layers)):
                 pf, key, st = f"transformer_encoder_layers.{i}", f"enc{i}", 1000 + 32 * i
@@ -807,12 +785,12 @@ class KokoroEngine:
                 x_in = self._buf(f"enc{i - 1}.xo", Ne, H) if i > 0 else self._buf("enc.x0", Ne, H)
                 xm = self._buf(key + ".xm", Ne, H)
                 y1, y2 = self._buf(key + ".ln1.y", Ne, H, dtype=edt), self._buf(key + ".ln2.y", Ne, H, dtype=edt)
-                self._ffn_bwd(key + ".ff", pf + ".ff", dx, y2, dne, d.enc_ff, Pn, st + 8, p_enc, dpr, head_done=hd)
-                hd = self._tail_bwd(key + ".ln2", dne, xm, pf + ".norm2", dx, True, ehead("attn", i))
+                self._ffn_bwd(key + ".ff", pf + ".ff", dx, y2, dne, d.enc_ff, Pn, st + 8, p_enc, dpr)
+                self._tail_bwd(key + ".ln2", dne, xm, pf + ".norm2", dx, True, ehead("attn", i))
                 self._attn_bwd(key + ".sa", pf + ".self_attn", dx, y1, None, B, Pn, Pn, True, False, text_mask, dne, None, 0.0,
-                               st, p_enc, dpr, head_done=hd)
+                               st, p_enc, dpr)
                 if i > 0:
-                    hd = self._tail_bwd(key + ".ln1", dne, x_in, pf + ".norm1", dx, True, ehead("ffn", i - 1))
+                    self._tail_bwd(key + ".ln1", dne, x_in, pf + ".norm1", dx, True, ehead("ffn", i - 1))
                 else:
                     self._ln_bwd(key + ".ln1", dne, x_in, pf + ".norm1", dx, accumulate=True)
             kk.call("kk_embed_bwd", ids, stress, dx, G["text_embedding.weight"],
@@ -828,7 +806,7 @@ class KokoroEngine:
             sub = {"ffn": (".ff", 16), "ca": (".cross_attn", 8), "sa": (".self_attn", 0)}[kind]
             return ("ffn" if kind == "ffn" else "attn", f"dec{i}.ff", f"decoder.layers.{i}" + sub[0], T, 2000 + 32 * i + sub[1],
                     p_dec, self._dpr(i, d.dec_layers), ddt)
-        hd = self._tail_bwd("dec.norm", d_dec_out, dec_last, "decoder.norm", dy, False, dhead("ffn", d.dec_layers - 1))
+        self._tail_bwd("dec.norm", d_dec_out, dec_last, "decoder.norm", dy, False, dhead("ffn", d.dec_layers - 1))
         dmem = self._buf("g.memory", Nd, H)
         dn = self._buf("tmp.dn", Nd, H, dtype=ddt)
         for i in reversed(range(d.dec_layers)):
@@ -837,15 +815,14 @@ class KokoroEngine:
             x_in = self._buf(f"dec{i - 1}.xo", Nd, H) if i > 0 else self._buf("dec.x0", Nd, H)
             ya, yc = self._buf(key + ".xa", Nd, H), self._buf(key + ".xc", Nd, H)
             n1, n2, n3 = (self._buf(f"{key}.ln{j}.y", Nd, H, dtype=ddt) for j in (1, 2, 3))
-            self._ffn_bwd(key + ".ff", pf + ".ff", dy, n3, dn, d.dec_ff, T, st + 16, p_dec, dpr, head_done=hd)
-            hd = self._tail_bwd(key + ".ln3", dn, yc, pf + ".norm3", dy, True, dhead("ca", i))
+            self._ffn_bwd(key + ".ff", pf + ".ff", dy, n3, dn, d.dec_ff, T, st + 16, p_dec, dpr)
+            self._tail_bwd(key + ".ln3", dn, yc, pf + ".norm3", dy, True, dhead("ca", i))
             self._attn_bwd(key + ".ca", pf + ".cross_attn", dy, n2, memory, B, T, T, False, False, fmask, dn, dmem,
-                           0.0, st + 8, p_dec, dpr, head_done=hd, layer=i)
-            hd = self._tail_bwd(key + ".ln2", dn, ya, pf + ".norm2", dy, True, dhead("sa", i))
-            self._attn_bwd(key + ".sa", pf + ".self_attn", dy, n1, None, B, T, T, True, True, None, dn, None, 0.0, st, p_dec, dpr,
-                           head_done=hd)
+                           0.0, st + 8, p_dec, dpr, layer=i)
+            self._tail_bwd(key + ".ln2", dn, ya, pf + ".norm2", dy, True, dhead("sa", i))
+            self._attn_bwd(key + ".sa", pf + ".self_attn", dy, n1, None, B, T, T, True, True, None, dn, None, 0.0, st, p_dec, dpr)
             if i > 0:
-                hd = self._tail_bwd(key + ".ln1", dn, x_in, pf + ".norm1", dy, True, dhead("ffn", i - 1))
+                self._tail_bwd(key + ".ln1", dn, x_in, pf + ".norm1", dy, True, dhead("ffn", i - 1))
             else:
                 self._ln_bwd(key + ".ln1", dn, x_in, pf + ".norm1", dy, accumulate=True)
             if yield_at == i:                           # everything the early ranges hold is final from here on
