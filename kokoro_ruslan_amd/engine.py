@@ -582,11 +582,12 @@ class KokoroEngine:
 
     # ------------------------------------------------------------------ forward + losses + backward
     def forward_backward(self, batch: Dict[str, torch.Tensor], loss_scale: float = 1.0, adaptive: bool = False,
-                         backward: bool = True) -> Dict[str, torch.Tensor]:
+                         backward: bool = True, zero_grads: bool = False) -> Dict[str, torch.Tensor]:
         """One micro-batch: forward, the 6 losses, and (optionally) the full backward into the gradient arena
-        (which accumulates).  `batch` follows the reference collate contract (data/dataset.py:871-921), tensors on
-        the device.  Returns device tensors (no sync): losses[6] = (total, mel, dur, stop, pitch, energy) and outputs."""
-        gen = self._fb_gen(batch, loss_scale, adaptive, backward, None)
+        (which accumulates; zero_grads=True clears it first, overlapped with the forward).  `batch` follows the
+        reference collate contract (data/dataset.py:871-921), tensors on the device.  Returns device tensors (no sync):
+        losses[6] = (total, mel, dur, stop, pitch, energy) and outputs."""
+        gen = self._fb_gen(batch, loss_scale, adaptive, backward, None, zero_grads)
         while True:
             try:
                 next(gen)
@@ -616,7 +617,7 @@ class KokoroEngine:
                 r.append([beg, end])
         return [tuple(x) for x in out[False]], [tuple(x) for x in out[True]]
 
-    def _fb_gen(self, batch, loss_scale, adaptive, backward, split_layer):
+    def _fb_gen(self, batch, loss_scale, adaptive, backward, split_layer, zero_grads=False):
         """forward_backward as a generator: with split_layer = k it pauses once, after the backward of decoder layer k,
         with the side stream joined and every gradient of early_late_ranges(k)[0] final — the data-parallel step
         captures the two halves as separate hipGraphs and starts the all-reduce of the early ranges in between."""
@@ -666,6 +667,8 @@ class KokoroEngine:
             self.rng.add_(1)                              # fresh masks every micro-batch (captured in the hipGraph)
         pe_drop, p_enc, p_dec, p_var = self._p(hp.encoder_dropout), self._p(hp.encoder_dropout), self._p(hp.decoder_dropout), self._p(hp.variance_dropout)
         with self._on_stream(self._kv, "kv.", self.dec_head_aside):     # beside the encoder; joined before the first cross-attention
+            if zero_grads:                                # the 200 MB gradient memset also hides behind the encoder forward
+                self.zero_grad()
             dec_head = decoder_head()
         kk.call("kk_embed_fwd", ids, stress, P["text_embedding.weight"], P["stress_embedding.weight"] if stress is not None else None,
                 pe, x, B, Pn, H, float(H ** 0.5), self.rng, 1, pe_drop)
@@ -909,8 +912,7 @@ class KokoroEngine:
         if ent is None:                               # first sight of a shape: eager (allocates the workspaces and the
             static = {k: v.clone() for k, v in batch.items()}      # reduction tables — host-to-device copies, illegal in a capture)
             self._graphs[key] = {"static": static, "fb": None, "opt": None}
-            self.zero_grad()
-            gen = self._fb_gen(static, self.dp_loss_scale, True, True, self.dp_overlap_layer if overlap else None)
+            gen = self._fb_gen(static, self.dp_loss_scale, True, True, self.dp_overlap_layer if overlap else None, True)
             for _ in gen:                             # same pause point as the captured form, so the same tables get built
                 pass
             if grad_sync is not None:
@@ -927,9 +929,8 @@ class KokoroEngine:
             # thread_local: with an RCCL process group alive, its watchdog thread polls events while we capture; only
             # this thread's calls must be capture-safe
             if overlap:     # two graphs: the all-reduce of the gradients that are final at the split runs beside the second
-                gen = self._fb_gen(static, self.dp_loss_scale, True, True, self.dp_overlap_layer)
+                gen = self._fb_gen(static, self.dp_loss_scale, True, True, self.dp_overlap_layer, True)
                 with torch.cuda.graph(ent["fb"], capture_error_mode="thread_local"):
-                    self.zero_grad()
                     assert next(gen) == "split"
                 ent["fb2"] = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(ent["fb2"], capture_error_mode="thread_local"):
@@ -938,8 +939,7 @@ class KokoroEngine:
                 ent["ranges"] = self.early_late_ranges(self.dp_overlap_layer)
             else:
                 with torch.cuda.graph(ent["fb"], capture_error_mode="thread_local"):
-                    self.zero_grad()
-                    self.forward_backward(static, loss_scale=self.dp_loss_scale, adaptive=True)
+                    self.forward_backward(static, loss_scale=self.dp_loss_scale, adaptive=True, zero_grads=True)
             with torch.cuda.graph(ent["opt"], capture_error_mode="thread_local"):
                 self.optimizer_step(T)
         ent["fb"].replay()
