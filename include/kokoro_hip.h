@@ -47,6 +47,13 @@ int kk_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, const 
 /* tuning hook for benchmarks: 128x128-tile threshold (tile count) and XCD-aware tile order on/off */
 int kk_gemm_tune(int tm_threshold, int xcd_swizzle);
 int kk_gemm_tune16(int enable, int thr128, int thr12864, int split_target);   /* same, for the bf16 x bf16 DMA-staged core */
+/* GLU feed-forward backward, fused: dG = dy[T,H] . W[H,F] (the linear2 dgrad; bf16 operands, W row-major [H,F]) with the
+ * gate's backward as the epilogue — dh1[T,2F] is written directly from h1[T,2F] = [a | b] saved by the forward and the
+ * gate's dropout mask (seed, site, p as in kk_glu_fwd); the column sums of dh1 (linear1's bias gradient) go to
+ * partials[kk_gemm_dgrad_glu_blocks(T)][2F] for kk_partials_reduce.  Replaces kk_gemm + kk_glu_bwd + kk_colsum_acc. */
+int kk_gemm_dgrad_glu_blocks(int64_t T);
+int kk_gemm_dgrad_glu(int64_t T, int64_t F, int64_t H, const void *dy, int64_t lddy, const void *W, const void *h1,
+                      void *dh1, float *partials, const uint32_t *seed, uint32_t site, float p, void *stream);
 /* out[n] += sum_m X[m,n]  (bias gradients). */
 int kk_colsum_acc(const float *X, int64_t ldx, int64_t M, int64_t N, float *out, int x_bf16, void *stream);
 

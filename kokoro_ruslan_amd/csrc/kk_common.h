@@ -29,6 +29,9 @@ int kk_gemm16_launch(int ta, int tb, int64_t M, int64_t N, int64_t K, float alph
                      int64_t ldb, float beta, void *C, int64_t ldc, int c_bf16, const float *bias, const float *residual,
                      int64_t ldr, int64_t res_mod, int split_k, int xcd_swizzle, hipStream_t s);
 void kk_gemm16_tune(int thr128, int thr12864, int split_target);
+// dX = dY.W fused with the GLU gate's backward (see kk_gemm16.hip)
+int kk_gemm16_dgrad_glu(int64_t T, int64_t F, int64_t H, const void *dy, int64_t lddy, const void *W, const void *h1, void *dh1,
+                        float *partials, const uint32_t *seed, uint32_t site, float p, int xcd_swizzle, hipStream_t s);
 
 static inline int kk_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
@@ -128,4 +131,10 @@ __device__ __forceinline__ void kk_drop_mul4(uint32_t seed, uint32_t site, uint6
     m[1] = (h0 >> 16) < t ? 0.f : inv_keep;
     m[2] = (h1 & 0xFFFFu) < t ? 0.f : inv_keep;
     m[3] = (h1 >> 16) < t ? 0.f : inv_keep;
+}
+
+// exact-erf GELU (nn.GELU(), transformers.py:51) and its derivative
+__device__ __forceinline__ float kk_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float kk_gelu_grad(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
 }

@@ -10,10 +10,8 @@
 
 namespace {
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float gelu_grad_f(float x) {
-    return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
-}
+__device__ __forceinline__ float gelu_f(float x) { return kk_gelu(x); }
+__device__ __forceinline__ float gelu_grad_f(float x) { return kk_gelu_grad(x); }
 
 // ------------------------------------------------------------------ GLU
 // Dropout on the gated product (transformers.py:108) is fused: mask = f(seed, site, row*F + col).

@@ -435,3 +435,13 @@ extern "C" int kk_colsum_acc(const float *X, int64_t ldx, int64_t M, int64_t N, 
     KK_LAUNCH_CHECK("kk_colsum_acc");
     return 0;
 }
+
+// dG = dY.W2 with the GLU gate's backward as the epilogue (bf16 operands; see gemm16_kernel, EPI = 1).
+extern "C" int kk_gemm_dgrad_glu_blocks(int64_t T) { return 2 * kk_cdiv(T, 64); }
+extern "C" int kk_gemm_dgrad_glu(int64_t T, int64_t F, int64_t H, const void *dy, int64_t lddy, const void *W, const void *h1,
+                                 void *dh1, float *partials, const uint32_t *seed, uint32_t site, float p, void *stream) {
+    KK_REQUIRE(T > 0 && F > 0 && H > 0 && dy && W && h1 && dh1 && partials, "kk_gemm_dgrad_glu: bad args");
+    KK_REQUIRE(p >= 0.f && p < 1.f, "kk_gemm_dgrad_glu: dropout probability must be in [0,1)");
+    KK_REQUIRE(kk_gemm16_eligible(0, 1, T, F, H, dy, lddy, W, F), "kk_gemm_dgrad_glu: needs 16-byte aligned bf16 operands, H %% 64 == 0, F %% 8 == 0");
+    return kk_gemm16_dgrad_glu(T, F, H, dy, lddy, W, h1, dh1, partials, seed, site, p, g_xcd_swizzle, (hipStream_t)stream);
+}

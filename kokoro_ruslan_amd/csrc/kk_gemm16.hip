@@ -34,6 +34,13 @@ struct G16Args {
     int k_per_split, atomic, splits, split_major;
     int tiles_m, tiles_n, xcd_swizzle;
     uint32_t a_bytes, b_bytes;
+    // EPI == 1 (GLU backward epilogue): C is not written; see gemm16_kernel
+    const __bf16 *glu_h;
+    __bf16 *glu_dh;
+    float *glu_partials;
+    const uint32_t *glu_seed;
+    uint32_t glu_site;
+    float glu_p;
 };
 
 constexpr int BK = 64;
@@ -126,7 +133,12 @@ __device__ __forceinline__ void wait_frag(Frag &f) { asm volatile("s_waitcnt lgk
 // NS LDS stages: NS-1 k-tiles are in flight while one is multiplied.  The DMA of a tile is waited for with a COUNTED
 // vmcnt (the younger tiles stay in flight across the barrier), and the barrier is a raw s_barrier: __syncthreads()
 // would drain vmcnt(0) because an LDS-DMA is a pending LDS write.
-template <bool TA, bool TB, int BM, int BN, int NS>
+// EPI = 1: the GEMM is dG = dY.W2 of a GLU feed-forward (N = F columns) and the epilogue is the gate's backward
+// (transformers.py:107-108): with h1 = [a | b] saved by the forward and m the gate's dropout mask,
+//   dh1[:, c] = dG*m * b * gelu'(a),   dh1[:, F + c] = dG*m * gelu(a)
+// are written directly (dG never exists in HBM), and the column sums of dh1 — linear1's bias gradient — leave the
+// workgroup as plain rows partials[2*tile_m + wave_row][2F] for kk_partials_reduce.  Replaces kk_glu_bwd + kk_colsum_acc.
+template <bool TA, bool TB, int BM, int BN, int NS, int EPI = 0>
 __global__ __launch_bounds__(256) void gemm16_kernel(G16Args a) {
     constexpr int MI = BM / 64, NI = BN / 64;                  // 32x32 MFMA tiles per wave (wave tile = BM/2 x BN/2)
     using OA = Operand<BM, TA>;
@@ -225,6 +237,37 @@ __global__ __launch_bounds__(256) void gemm16_kernel(G16Args a) {
     }
     if (nk <= 0) return;
 
+    if constexpr (EPI == 1) {
+        static_assert(EPI == 0 || (BM == 64 && BN == 64), "the GLU epilogue is written for the 64x64 tile");
+        const int F = a.N;
+        const uint32_t thr = a.glu_seed ? kk_drop_threshold(a.glu_p) : 0u, seed = thr ? *a.glu_seed : 0u;
+        const float ik = thr ? 1.f / (1.f - a.glu_p) : 1.f;
+        const int col = n0 + wc * 32 + l31;
+        float sa = 0.f, sb = 0.f;
+        if (col < F) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * 32 + frag_row(r, half);
+                if (row >= a.M) continue;
+                const int64_t o = (int64_t)row * 2 * F + col;
+                const float av = (float)a.glu_h[o], bv = (float)a.glu_h[o + F];
+                const float d = acc[0][0][r] * kk_drop_mul(seed, a.glu_site, (uint64_t)row * F + col, thr, ik);
+                const float da = d * bv * kk_gelu_grad(av), db = d * kk_gelu(av);
+                a.glu_dh[o] = (__bf16)da;
+                a.glu_dh[o + F] = (__bf16)db;
+                sa += da;
+                sb += db;
+            }
+        }
+        sa += __shfl_xor(sa, 32, 64);
+        sb += __shfl_xor(sb, 32, 64);
+        if (half == 0 && col < F) {
+            float *pr = a.glu_partials + (int64_t)((m0 / 64) * 2 + wr) * 2 * F;
+            pr[col] = sa;
+            pr[F + col] = sb;
+        }
+        return;
+    }
     const bool lead = (ksl == 0);
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -283,6 +326,9 @@ template __global__ void gemm16_kernel<false, false, 64, 64, 4>(G16Args);
 template __global__ void gemm16_kernel<false, true, 64, 64, 4>(G16Args);
 template __global__ void gemm16_kernel<true, false, 64, 64, 4>(G16Args);
 template __global__ void gemm16_kernel<true, true, 64, 64, 4>(G16Args);
+
+template __global__ void gemm16_kernel<false, true, 64, 64, 2, 1>(G16Args);
+template __global__ void gemm16_kernel<false, true, 64, 64, 3, 1>(G16Args);
 
 template <int BM, int BN, int NS>
 void launch_tile(int ta, int tb, const G16Args &a, dim3 grid, hipStream_t s) {
@@ -367,5 +413,24 @@ int kk_gemm16_launch(int ta, int tb, int64_t M, int64_t N, int64_t K, float alph
     else if (ns == 3) launch_tile<64, 64, 3>(ta, tb, a, grid, s);
     else launch_tile<64, 64, 2>(ta, tb, a, grid, s);
     KK_LAUNCH_CHECK("kk_gemm");
+    return 0;
+}
+
+int kk_gemm16_dgrad_glu(int64_t T, int64_t F, int64_t H, const void *dy, int64_t lddy, const void *W, const void *h1, void *dh1,
+                        float *partials, const uint32_t *seed, uint32_t site, float p, int xcd_swizzle, hipStream_t s) {
+    auto cd = [](int64_t x, int64_t y) { return (int)((x + y - 1) / y); };
+    G16Args a = {};
+    a.M = (int)T; a.N = (int)F; a.K = (int)H;
+    a.alpha = 1.f; a.A = dy; a.B = W; a.lda = lddy; a.ldb = F;
+    a.k_per_split = cd(H, BK) * BK; a.splits = 1;
+    a.tiles_m = cd(T, 64); a.tiles_n = cd(F, 64); a.xcd_swizzle = xcd_swizzle;
+    a.a_bytes = (uint32_t)(((T - 1) * lddy + H) * 2);
+    a.b_bytes = (uint32_t)(((H - 1) * F + F) * 2);
+    a.glu_h = static_cast<const __bf16 *>(h1); a.glu_dh = static_cast<__bf16 *>(dh1); a.glu_partials = partials;
+    a.glu_seed = p > 0.f ? seed : nullptr; a.glu_site = site; a.glu_p = p;
+    dim3 grid(a.tiles_m * a.tiles_n);
+    if (cd(H, BK) < 3) hipLaunchKernelGGL((gemm16_kernel<false, true, 64, 64, 2, 1>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gemm16_kernel<false, true, 64, 64, 3, 1>), grid, dim3(256), 0, s, a);
+    KK_LAUNCH_CHECK("kk_gemm_dgrad_glu");
     return 0;
 }

@@ -535,9 +535,17 @@ class KokoroEngine:
                         self._buf("tmp.dh1", N, 2 * Fd, dtype=dt))
         # _tail_bwd already produced df2 (masks + RMSNorm backward) and the column sums for linear2.bias / output_norm
         self._wgrad(df2, g, G[prefix + ".linear2.weight"], None)
-        self._dgrad(df2, self._W(prefix + ".linear2.weight"), dg)
-        kk.call("kk_glu_bwd", dg, h1, dh1, N, Fd, self.rng, site + 4, p, i16)
-        self._wgrad(dh1, y, G[prefix + ".linear1.weight"], G[prefix + ".linear1.bias"])
+        W2 = self._W(prefix + ".linear2.weight")
+        if i16 and _b16(W2) and H % 64 == 0:             # bf16 mode: the gate's backward is the epilogue of the linear2 dgrad
+            nb = kk.load().kk_gemm_dgrad_glu_blocks(N)
+            part = self._buf(key + ".glupart", nb, 2 * Fd)
+            self._reduce_lists[self._tmp_ns].append((part, G[prefix + ".linear1.bias"], None, nb, 2 * Fd, 2 * Fd))
+            kk.call("kk_gemm_dgrad_glu", N, Fd, H, df2, df2.stride(0), W2, h1, dh1, part, self.rng, site + 4, p)
+            self._wgrad(dh1, y, G[prefix + ".linear1.weight"], None)
+        else:
+            self._dgrad(df2, W2, dg)
+            kk.call("kk_glu_bwd", dg, h1, dh1, N, Fd, self.rng, site + 4, p, i16)
+            self._wgrad(dh1, y, G[prefix + ".linear1.weight"], G[prefix + ".linear1.bias"])
         self._dgrad(dh1, self._W(prefix + ".linear1.weight"), d_y)
 
     # ------------------------------------------------------------------ variance predictor

@@ -982,3 +982,33 @@ def test_attention_dq_computes_delta_in_kernel(kk):
     kk.call("kk_attn_bwd_dq", q, k, v, do, lse, d_new, dq_new, B, h, S, S, H, H, H, H, H, None, 1, 0.125, None, 0, 0.0, 1, 1, o, H)
     close(d_new, d_ref, 1e-5, 1e-5, "delta computed in the dQ kernel")
     close(dq_new, dq_ref, 1e-3, 1e-3, "dQ with in-kernel delta")
+
+
+@pytest.mark.parametrize("T,F,H,p", [(200, 96, 128, 0.0), (1000, 1536, 512, 0.2), (77, 192, 64, 0.1)])
+def test_gemm_dgrad_glu_epilogue(kk, T, F, H, p):
+    """kk_gemm_dgrad_glu == kk_gemm (dgrad) -> kk_glu_bwd -> kk_colsum_acc, up to the bf16 rounding of the intermediate dG
+    that the fused form never makes."""
+    g = torch.Generator().manual_seed(T + F)
+    bf = torch.bfloat16
+    dy = dev(torch.randn(T, H, generator=g)).to(bf)
+    W = dev(torch.randn(H, F, generator=g) * 0.1).to(bf)
+    h1 = dev(torch.randn(T, 2 * F, generator=g)).to(bf)
+    seed = torch.tensor([21], dtype=torch.int32, device="cuda")
+    dg = torch.empty(T, F, device="cuda", dtype=bf)
+    kk.call("kk_gemm", 0, 1, T, F, H, 1.0, dy, H, W, F, 0.0, dg, F, None, None, 0, 0, 1, 1, 7)
+    dh_a = torch.empty(T, 2 * F, device="cuda", dtype=bf)
+    kk.call("kk_glu_bwd", dg, h1, dh_a, T, F, seed, 9, p, 1)
+    bias_a = torch.zeros(2 * F, device="cuda")
+    kk.call("kk_colsum_acc", dh_a, 2 * F, T, 2 * F, bias_a, 1)
+    nb = kk.load().kk_gemm_dgrad_glu_blocks(T)
+    part = torch.full((nb, 2 * F), 4.0, device="cuda")
+    dh_b = torch.full((T, 2 * F), 7.0, device="cuda", dtype=bf)
+    kk.call("kk_gemm_dgrad_glu", T, F, H, dy, H, W, h1, dh_b, part, seed, 9, p)
+    bias_b = torch.zeros(2 * F, device="cuda")
+    kk.call("kk_partials_reduce", kk.reduce_table([(part, bias_b, None, nb, 2 * F, 2 * F)], "cuda"), 1, 2 * F)
+    close(dh_b, dh_a, 0.05 * math.sqrt(H / 64), 3e-2, "fused GLU backward")
+    zero = (dh_a.float() == 0)
+    if p > 0:
+        assert 0.5 * p < float(zero.float().mean()) < 1.5 * p + 0.01
+        assert bool(((dh_b.float() == 0) == zero).float().mean() > 0.999), "same dropout mask"
+    close(bias_b, bias_a, 0.05 * math.sqrt(T) * math.sqrt(H / 64), 3e-2, "linear1 bias gradient from the epilogue partials")
