@@ -47,6 +47,11 @@ int kk_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, const 
 /* tuning hook for benchmarks: 128x128-tile threshold (tile count) and XCD-aware tile order on/off */
 int kk_gemm_tune(int tm_threshold, int xcd_swizzle);
 int kk_gemm_tune16(int enable, int thr128, int thr12864, int split_target);   /* same, for the bf16 x bf16 DMA-staged core */
+/* GLU feed-forward forward, fused: h1[T,2F] = x[T,K] . W[2F,K]^T + bias (saved for the backward, bf16) and the gated
+ * product g[T,F] = gelu(h1[:, :F]) * h1[:, F:] * dropout mask (seed, site, p as in kk_glu_fwd) from one launch: every
+ * workgroup owns a column block of BOTH halves.  bf16 operands and outputs.  Replaces kk_gemm + kk_glu_fwd. */
+int kk_gemm_linear_glu(int64_t T, int64_t F, int64_t K, const void *x, int64_t ldx, const void *W, const float *bias,
+                       void *h1, void *g, int64_t ldg, const uint32_t *seed, uint32_t site, float p, void *stream);
 /* GLU feed-forward backward, fused: dG = dy[T,H] . W[H,F] (the linear2 dgrad; bf16 operands, W row-major [H,F]) with the
  * gate's backward as the epilogue — dh1[T,2F] is written directly from h1[T,2F] = [a | b] saved by the forward and the
  * gate's dropout mask (seed, site, p as in kk_glu_fwd); the column sums of dh1 (linear1's bias gradient) go to

@@ -445,3 +445,12 @@ extern "C" int kk_gemm_dgrad_glu(int64_t T, int64_t F, int64_t H, const void *dy
     KK_REQUIRE(kk_gemm16_eligible(0, 1, T, F, H, dy, lddy, W, F), "kk_gemm_dgrad_glu: needs 16-byte aligned bf16 operands, H %% 64 == 0, F %% 8 == 0");
     return kk_gemm16_dgrad_glu(T, F, H, dy, lddy, W, h1, dh1, partials, seed, site, p, g_xcd_swizzle, (hipStream_t)stream);
 }
+
+// h1 = x.W1^T + b1 with the GLU gate as the epilogue (bf16 operands; see gemm16_kernel, EPI = 2).
+extern "C" int kk_gemm_linear_glu(int64_t T, int64_t F, int64_t K, const void *x, int64_t ldx, const void *W, const float *bias,
+                                  void *h1, void *g, int64_t ldg, const uint32_t *seed, uint32_t site, float p, void *stream) {
+    KK_REQUIRE(T > 0 && F > 0 && K > 0 && x && W && h1 && g, "kk_gemm_linear_glu: bad args");
+    KK_REQUIRE(p >= 0.f && p < 1.f, "kk_gemm_linear_glu: dropout probability must be in [0,1)");
+    KK_REQUIRE(kk_gemm16_eligible(0, 0, T, 2 * F, K, x, ldx, W, K), "kk_gemm_linear_glu: needs 16-byte aligned bf16 operands and K %% 64 == 0");
+    return kk_gemm16_linear_glu(T, F, K, x, ldx, W, bias, h1, g, ldg, seed, site, p, g_xcd_swizzle, (hipStream_t)stream);
+}

@@ -138,13 +138,17 @@ __device__ __forceinline__ void wait_frag(Frag &f) { asm volatile("s_waitcnt lgk
 //   dh1[:, c] = dG*m * b * gelu'(a),   dh1[:, F + c] = dG*m * gelu(a)
 // are written directly (dG never exists in HBM), and the column sums of dh1 — linear1's bias gradient — leave the
 // workgroup as plain rows partials[2*tile_m + wave_row][2F] for kk_partials_reduce.  Replaces kk_glu_bwd + kk_colsum_acc.
+// EPI = 2: the GEMM is h1 = x.W1^T + b1 of a GLU feed-forward; a workgroup owns output columns [n0, n0+64) AND
+// [F+n0, F+n0+64) (two B panels, two accumulators, the A tile is read from LDS once for both), so its epilogue writes
+// h1 = [a | b] (saved for the backward) and the gated product g = gelu(a)*b*mask in one go.  Replaces kk_glu_fwd.
 template <bool TA, bool TB, int BM, int BN, int NS, int EPI = 0>
 __global__ __launch_bounds__(256) void gemm16_kernel(G16Args a) {
     constexpr int MI = BM / 64, NI = BN / 64;                  // 32x32 MFMA tiles per wave (wave tile = BM/2 x BN/2)
     using OA = Operand<BM, TA>;
     using OB = Operand<BN, TB>;
-    constexpr int STAGE = OA::BYTES + OB::BYTES;
-    constexpr int NPT = OA::NP + OB::NP;                       // DMA instructions per thread per k-tile
+    constexpr int NB = EPI == 2 ? 2 : 1;                        // EPI == 2 multiplies A with TWO 64-row panels of B (see below)
+    constexpr int STAGE = OA::BYTES + NB * OB::BYTES;
+    constexpr int NPT = OA::NP + NB * OB::NP;                   // DMA instructions per thread per k-tile
     __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
 
     // Workgroup -> (tile, k-slice).  The dispatcher places workgroup i on XCD i % 8 (private 4 MiB L2 each).
@@ -174,27 +178,32 @@ __global__ __launch_bounds__(256) void gemm16_kernel(G16Args a) {
     const int wr = wave >> 1, wc = wave & 1, half = lane >> 5, l31 = lane & 31;
 
     OA oa;
-    OB ob;
+    OB ob, ob2;
     oa.init(a.A, a.a_bytes, a.lda, m0);
     ob.init(a.B, a.b_bytes, a.ldb, n0);
+    if constexpr (EPI == 2) ob2.init(a.B, a.b_bytes, a.ldb, n0 + a.N);
     FragAddr<BM, TA> fa;
     FragAddr<BN, TB> fb;
     fa.init(lane, wr * (BM / 2));
     fb.init(lane, wc * (BN / 2));
 
     f32x16 acc[MI][NI];
+    f32x16 acc2;                                                // EPI == 2: the second B panel's accumulator (MI = NI = 1)
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
 
 #pragma unroll
     for (int p = 0; p < NS - 1; ++p)
         if (p < nk) {
             oa.issue(smem + p * STAGE, kt0 + p, wave);
             ob.issue(smem + p * STAGE + OA::BYTES, kt0 + p, wave);
+            if constexpr (EPI == 2) ob2.issue(smem + p * STAGE + OA::BYTES + OB::BYTES, kt0 + p, wave);
         }
     int sc = 0, sn = NS - 1;                                    // stage being multiplied / stage being refilled
     for (int kt = 0; kt < nk; ++kt) {
@@ -208,6 +217,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(G16Args a) {
         if (kt + NS - 1 < nk) {
             oa.issue(smem + sn * STAGE, kt0 + kt + NS - 1, wave);
             ob.issue(smem + sn * STAGE + OA::BYTES, kt0 + kt + NS - 1, wave);
+            if constexpr (EPI == 2) ob2.issue(smem + sn * STAGE + OA::BYTES + OB::BYTES, kt0 + kt + NS - 1, wave);
         }
         const char *cur = smem + sc * STAGE;
         sn = sc;
@@ -233,6 +243,11 @@ __global__ __launch_bounds__(256) void gemm16_kernel(G16Args a) {
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_value(af[i], TA), frag_value(bf[j], TB), acc[i][j], 0, 0, 0);
+            if constexpr (EPI == 2) {
+                Frag b2;
+                fb.load(b2, Bi + OB::BYTES, 0, ks);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_value(af[0], TA), frag_value(b2, TB), acc2, 0, 0, 0);
+            }
         }
     }
     if (nk <= 0) return;
@@ -265,6 +280,27 @@ __global__ __launch_bounds__(256) void gemm16_kernel(G16Args a) {
             float *pr = a.glu_partials + (int64_t)((m0 / 64) * 2 + wr) * 2 * F;
             pr[col] = sa;
             pr[F + col] = sb;
+        }
+        return;
+    }
+    if constexpr (EPI == 2) {
+        const int F = a.N;
+        const uint32_t thr = a.glu_seed ? kk_drop_threshold(a.glu_p) : 0u, seed = thr ? *a.glu_seed : 0u;
+        const float ik = thr ? 1.f / (1.f - a.glu_p) : 1.f;
+        const int col = n0 + wc * 32 + l31;
+        if (col >= F) return;
+        const float ba = a.bias ? a.bias[col] : 0.f, bb = a.bias ? a.bias[F + col] : 0.f;
+        __bf16 *h = a.glu_dh, *g = static_cast<__bf16 *>(a.C);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wr * 32 + frag_row(r, half);
+            if (row >= a.M) continue;
+            const __bf16 av = (__bf16)(acc[0][0][r] + ba), bv = (__bf16)(acc2[r] + bb);     // what the backward will read
+            const int64_t o = (int64_t)row * 2 * F + col;
+            h[o] = av;
+            h[o + F] = bv;
+            g[(int64_t)row * a.ldc + col] =
+                (__bf16)(kk_gelu((float)av) * (float)bv * kk_drop_mul(seed, a.glu_site, (uint64_t)row * F + col, thr, ik));
         }
         return;
     }
@@ -327,6 +363,7 @@ template __global__ void gemm16_kernel<false, true, 64, 64, 4>(G16Args);
 template __global__ void gemm16_kernel<true, false, 64, 64, 4>(G16Args);
 template __global__ void gemm16_kernel<true, true, 64, 64, 4>(G16Args);
 
+template __global__ void gemm16_kernel<false, false, 64, 64, 2, 2>(G16Args);
 template __global__ void gemm16_kernel<false, true, 64, 64, 2, 1>(G16Args);
 template __global__ void gemm16_kernel<false, true, 64, 64, 3, 1>(G16Args);
 
@@ -432,5 +469,22 @@ int kk_gemm16_dgrad_glu(int64_t T, int64_t F, int64_t H, const void *dy, int64_t
     if (cd(H, BK) < 3) hipLaunchKernelGGL((gemm16_kernel<false, true, 64, 64, 2, 1>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((gemm16_kernel<false, true, 64, 64, 3, 1>), grid, dim3(256), 0, s, a);
     KK_LAUNCH_CHECK("kk_gemm_dgrad_glu");
+    return 0;
+}
+
+int kk_gemm16_linear_glu(int64_t T, int64_t F, int64_t K, const void *x, int64_t ldx, const void *W, const float *bias, void *h1,
+                         void *g, int64_t ldg, const uint32_t *seed, uint32_t site, float p, int xcd_swizzle, hipStream_t s) {
+    auto cd = [](int64_t a_, int64_t b_) { return (int)((a_ + b_ - 1) / b_); };
+    G16Args a = {};
+    a.M = (int)T; a.N = (int)F; a.K = (int)K;          // N = F: a workgroup covers columns n and F + n of the [T, 2F] product
+    a.alpha = 1.f; a.A = x; a.B = W; a.lda = ldx; a.ldb = K; a.bias = bias; a.C = g; a.ldc = ldg; a.c_bf16 = 1;
+    a.k_per_split = cd(K, BK) * BK; a.splits = 1;
+    a.tiles_m = cd(T, 64); a.tiles_n = cd(F, 64); a.xcd_swizzle = xcd_swizzle;
+    a.a_bytes = (uint32_t)(((T - 1) * ldx + K) * 2);
+    a.b_bytes = (uint32_t)(((2 * F - 1) * K + K) * 2);
+    a.glu_dh = static_cast<__bf16 *>(h1);
+    a.glu_seed = p > 0.f ? seed : nullptr; a.glu_site = site; a.glu_p = p;
+    hipLaunchKernelGGL((gemm16_kernel<false, false, 64, 64, 2, 2>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, s, a);
+    KK_LAUNCH_CHECK("kk_gemm_linear_glu");
     return 0;
 }

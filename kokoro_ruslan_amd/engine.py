@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import contextlib
 import math
+import os
 from collections import OrderedDict
 from typing import Dict, Optional, Tuple
 
@@ -173,6 +174,7 @@ class KokoroEngine:
         # weight-gradient GEMM 19 %, and moving the duration predictor's forward aside 2 %.
         self._kv = torch.cuda.Stream(device=self.device)
         self.dec_head_aside = True
+        self.fuse_glu_fwd = os.environ.get("KK_FUSE_GLU_FWD", "1") != "0"
         self.spec_augment_active = True             # the trainer clears it for epochs < spec_augment_start_epoch
         self.rng = torch.full((1,), int(seed) & 0x7FFFFFFF, dtype=torch.int32, device=self.device)   # step seed, read on device
         for n, b in spec.make_buffers(self.dims).items():
@@ -518,8 +520,12 @@ class KokoroEngine:
         dt, i16 = y.dtype, _b16(y)
         h1, g, f2 = (self._buf(key + ".h1", N, 2 * Fd, dtype=dt), self._buf(key + ".g", N, Fd, dtype=dt),
                      self._buf(key + ".f2", N, H, dtype=dt))
-        self._linear(y, self._W(prefix + ".linear1.weight"), P[prefix + ".linear1.bias"], h1)
-        kk.call("kk_glu_fwd", h1, g, N, Fd, self.rng, site + 4, p, i16)
+        W1 = self._W(prefix + ".linear1.weight")
+        if i16 and _b16(W1) and H % 64 == 0 and self.fuse_glu_fwd:             # bf16 mode: the gate is the epilogue of the linear1 GEMM
+            kk.call("kk_gemm_linear_glu", N, Fd, H, y, y.stride(0), W1, P[prefix + ".linear1.bias"], h1, g, Fd, self.rng, site + 4, p)
+        else:
+            self._linear(y, W1, P[prefix + ".linear1.bias"], h1)
+            kk.call("kk_glu_fwd", h1, g, N, Fd, self.rng, site + 4, p, i16)
         self._linear(g, self._W(prefix + ".linear2.weight"), P[prefix + ".linear2.bias"], f2)
         # rmsnorm -> FFN dropout (:111) -> drop_path -> residual dropout (+ the next LayerNorm), one launch
         return self._sublayer_tail(f2, x_res, x_out, S, site, p, dpr, p, P[prefix + ".output_norm.weight"],

@@ -58,6 +58,7 @@ def reduce_table(entries, device) -> "torch.Tensor":
 
 SIGNATURES: Dict[str, List[Any]] = {
     "kk_gemm": [_I, _I, _L, _L, _L, _F, _P, _L, _P, _L, _F, _P, _L, _P, _P, _L, _L, _I, _I, _I, _P],
+    "kk_gemm_linear_glu": [_L, _L, _L, _P, _L, _P, _P, _P, _P, _L, _P, _U, _F, _P],
     "kk_gemm_dgrad_glu": [_L, _L, _L, _P, _L, _P, _P, _P, _P, _P, _U, _F, _P],
     "kk_gemm_dgrad_glu_blocks": [_L],
     "kk_gemm_tune": [_I, _I],

@@ -1012,3 +1012,27 @@ def test_gemm_dgrad_glu_epilogue(kk, T, F, H, p):
         assert 0.5 * p < float(zero.float().mean()) < 1.5 * p + 0.01
         assert bool(((dh_b.float() == 0) == zero).float().mean() > 0.999), "same dropout mask"
     close(bias_b, bias_a, 0.05 * math.sqrt(T) * math.sqrt(H / 64), 3e-2, "linear1 bias gradient from the epilogue partials")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,F,H,p", [(64, 64, 64, 0.0), (333, 192, 128, 0.1), (4096, 2048, 512, 0.1), (70, 40, 64, 0.2)])
+def test_gemm_linear_glu_epilogue(kk, T, F, H, p):
+    """kk_gemm_linear_glu == kk_gemm (+bias, bf16 out) -> kk_glu_fwd: same h1 bits, same gate, same dropout mask."""
+    g = torch.Generator().manual_seed(T + F)
+    bf = torch.bfloat16
+    x = dev(torch.randn(T, H, generator=g)).to(bf)
+    W = dev(torch.randn(2 * F, H, generator=g) * 0.1).to(bf)
+    b = dev(torch.randn(2 * F, generator=g))
+    seed = torch.tensor([33], dtype=torch.int32, device="cuda")
+    h_a = torch.empty(T, 2 * F, device="cuda", dtype=bf)
+    kk.call("kk_gemm", 0, 0, T, 2 * F, H, 1.0, x, H, W, H, 0.0, h_a, 2 * F, b, None, 0, 0, 1, 1, 7)
+    g_a = torch.empty(T, F, device="cuda", dtype=bf)
+    kk.call("kk_glu_fwd", h_a, g_a, T, F, seed, 13, p, 1)
+    h_b = torch.full((T, 2 * F), 7.0, device="cuda", dtype=bf)
+    g_b = torch.full((T, F), 7.0, device="cuda", dtype=bf)
+    kk.call("kk_gemm_linear_glu", T, F, H, x, H, W, b, h_b, g_b, F, seed, 13, p)
+    assert torch.equal(h_b, h_a), "h1 from the dual-panel tile is the plain GEMM's, bit for bit"
+    assert torch.equal(g_b, g_a), "gate + mask"
+    ref = torch.nn.functional.gelu(h_a[:, :F].float()) * h_a[:, F:].float()
+    keep = g_a.float() != 0
+    close(g_a.float()[keep], (ref / (1 - p))[keep], 2e-2, 2e-2, "gate value")
