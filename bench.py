@@ -41,8 +41,8 @@ def gemm_symbol(ta, tb, M, N, K, math_bf16, dtypes):
         cd = lambda x, y: -(-x // y)
         tiles, ktiles = cd(M, 64) * cd(N, 64), cd(K, 64)
         splits = 1
-        if tiles * 2 <= 768 and not (dtypes & 4):
-            splits = max(1, min(cd(768, tiles), max(ktiles // 2, 1)))
+        if tiles * 2 <= 384 and not (dtypes & 4):
+            splits = max(1, min(cd(384, tiles), max(ktiles // 2, 1)))
         ns = 2 if ktiles // splits < 3 else 3
         return f"gemm16_kernel<{b(ta)},{b(tb)},64,64,{ns}> ({GEMM_ROLE[(ta, tb)]})"
     tile = 128 if -(-M // 128) * -(-N // 128) >= 512 else 64

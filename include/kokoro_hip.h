@@ -47,6 +47,19 @@ int kk_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, const 
 /* tuning hook for benchmarks: 128x128-tile threshold (tile count) and XCD-aware tile order on/off */
 int kk_gemm_tune(int tm_threshold, int xcd_swizzle);
 int kk_gemm_tune16(int enable, int thr128, int thr12864, int split_target);   /* same, for the bf16 x bf16 DMA-staged core */
+/* Weight gradients of several nn.Linear layers in one launch: for i < n,
+ *   dw_i[M_i, N_i] += dy_i[T_i, M_i]^T . x_i[T_i, N_i]      (bf16 dy / x, fp32 dw, like kk_gemm(ta=1, tb=1, beta=1)).
+ * A layer's weight gradients have no consumer before the optimizer, so the engine queues them through the layer's
+ * backward and issues them together (n <= 8): full-length reductions, no split-K atomics, one launch.  `descs` is a
+ * HOST array read during the call.  The operands must stay untouched until the launch has run. */
+typedef struct {
+    const void *dy; int64_t lddy;
+    const void *x;  int64_t ldx;
+    float *dw;      int64_t lddw;
+    int64_t M, N, T;
+} KkWgradDesc;
+int kk_gemm_wgrad_group(const KkWgradDesc *descs, int n, void *stream);
+int kk_gemm_tune_group(int split); /* tools: force the k-slice count of grouped launches (0 = automatic) */
 /* GLU feed-forward forward, fused: h1[T,2F] = x[T,K] . W[2F,K]^T + bias (saved for the backward, bf16) and the gated
  * product g[T,F] = gelu(h1[:, :F]) * h1[:, F:] * dropout mask (seed, site, p as in kk_glu_fwd) from one launch: every
  * workgroup owns a column block of BOTH halves.  bf16 operands and outputs.  Replaces kk_gemm + kk_glu_fwd. */

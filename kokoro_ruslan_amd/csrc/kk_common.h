@@ -29,6 +29,8 @@ int kk_gemm16_launch(int ta, int tb, int64_t M, int64_t N, int64_t K, float alph
                      int64_t ldb, float beta, void *C, int64_t ldc, int c_bf16, const float *bias, const float *residual,
                      int64_t ldr, int64_t res_mod, int split_k, int xcd_swizzle, hipStream_t s);
 void kk_gemm16_tune(int thr128, int thr12864, int split_target);
+int kk_gemm16_wgrad_group(const KkWgradDesc *d, int n, int xcd_swizzle, hipStream_t s);
+void kk_gemm16_tune_group(int split);
 int kk_gemm16_linear_glu(int64_t T, int64_t F, int64_t K, const void *x, int64_t ldx, const void *W, const float *bias, void *h1,
                          void *g, int64_t ldg, const uint32_t *seed, uint32_t site, float p, int xcd_swizzle, hipStream_t s);
 // dX = dY.W fused with the GLU gate's backward (see kk_gemm16.hip)

@@ -454,3 +454,10 @@ extern "C" int kk_gemm_linear_glu(int64_t T, int64_t F, int64_t K, const void *x
     KK_REQUIRE(kk_gemm16_eligible(0, 0, T, 2 * F, K, x, ldx, W, K), "kk_gemm_linear_glu: needs 16-byte aligned bf16 operands and K %% 64 == 0");
     return kk_gemm16_linear_glu(T, F, K, x, ldx, W, bias, h1, g, ldg, seed, site, p, g_xcd_swizzle, (hipStream_t)stream);
 }
+
+// A layer's weight gradients as one grouped launch (bf16 operands, fp32 accumulate into dW).
+extern "C" int kk_gemm_wgrad_group(const KkWgradDesc *descs, int n, void *stream) {
+    KK_REQUIRE(descs != nullptr, "kk_gemm_wgrad_group: null descriptor table");
+    return kk_gemm16_wgrad_group(descs, n, g_xcd_swizzle, (hipStream_t)stream);
+}
+extern "C" int kk_gemm_tune_group(int split) { kk_gemm16_tune_group(split); return 0; }

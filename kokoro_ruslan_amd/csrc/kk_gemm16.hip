@@ -16,6 +16,7 @@
 //     4x16 transpose read — so no software transpose exists anywhere.
 // Out-of-range rows (tile edges, the K tail of a k-strided operand) are zero-filled by the buffer bounds check.
 #include "kk_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -141,15 +142,14 @@ __device__ __forceinline__ void wait_frag(Frag &f) { asm volatile("s_waitcnt lgk
 // EPI = 2: the GEMM is h1 = x.W1^T + b1 of a GLU feed-forward; a workgroup owns output columns [n0, n0+64) AND
 // [F+n0, F+n0+64) (two B panels, two accumulators, the A tile is read from LDS once for both), so its epilogue writes
 // h1 = [a | b] (saved for the backward) and the gated product g = gelu(a)*b*mask in one go.  Replaces kk_glu_fwd.
-template <bool TA, bool TB, int BM, int BN, int NS, int EPI = 0>
-__global__ __launch_bounds__(256) void gemm16_kernel(G16Args a) {
+template <bool TA, bool TB, int BM, int BN, int NS, int EPI>
+__device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char *smem) {
     constexpr int MI = BM / 64, NI = BN / 64;                  // 32x32 MFMA tiles per wave (wave tile = BM/2 x BN/2)
     using OA = Operand<BM, TA>;
     using OB = Operand<BN, TB>;
     constexpr int NB = EPI == 2 ? 2 : 1;                        // EPI == 2 multiplies A with TWO 64-row panels of B (see below)
     constexpr int STAGE = OA::BYTES + NB * OB::BYTES;
     constexpr int NPT = OA::NP + NB * OB::NP;                   // DMA instructions per thread per k-tile
-    __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
 
     // Workgroup -> (tile, k-slice).  The dispatcher places workgroup i on XCD i % 8 (private 4 MiB L2 each).
     //  tile-major (default): every XCD sweeps a contiguous run of tiles (n fastest), all k-slices of a tile together;
@@ -159,12 +159,12 @@ __global__ __launch_bounds__(256) void gemm16_kernel(G16Args a) {
     //    launches are latency-bound, not HBM-bound, and a tile's atomics then come from eight XCDs.  Left off.
     int tid_lin, ksl;
     if (a.split_major) {
-        ksl = blockIdx.x % a.splits;
-        tid_lin = blockIdx.x / a.splits;
+        ksl = wg % a.splits;
+        tid_lin = wg / a.splits;
     } else {
         const int ntiles = a.tiles_m * a.tiles_n;
-        tid_lin = blockIdx.x % ntiles;
-        ksl = blockIdx.x / ntiles;
+        tid_lin = wg % ntiles;
+        ksl = wg / ntiles;
         if (a.xcd_swizzle) {                                    // bijective for any tile count (see kk_gemm.hip)
             const int q = ntiles >> 3, r = ntiles & 7, xcd = tid_lin & 7, in = tid_lin >> 3;
             tid_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + in;
@@ -336,6 +336,31 @@ __global__ __launch_bounds__(256) void gemm16_kernel(G16Args a) {
         }
 }
 
+template <bool TA, bool TB, int BM, int BN, int NS, int EPI = 0>
+__global__ __launch_bounds__(256) void gemm16_kernel(G16Args a) {
+    __shared__ __attribute__((aligned(16))) char smem[NS * (BM + (EPI == 2 ? 2 : 1) * BN) * BK * 2];
+    gemm16_body<TA, TB, BM, BN, NS, EPI>(a, blockIdx.x, smem);
+}
+
+// Several independent GEMMs of one operand layout in ONE launch (a layer's weight gradients: they have no consumer
+// before the optimizer, so they wait until the layer's backward is through and then fill the chip together — ~1000
+// 64x64 tiles with the full reduction length each, no split-K atomics, one launch instead of four to six).
+constexpr int GROUP_MAX = 8;
+struct G16Group {
+    int n;
+    int start[GROUP_MAX + 1];                                   // first workgroup of each problem
+    G16Args p[GROUP_MAX];
+};
+template <bool TA, bool TB, int BM, int BN, int NS>
+__global__ __launch_bounds__(256) void gemm16_group_kernel(G16Group g) {
+    __shared__ __attribute__((aligned(16))) char smem[NS * (BM + BN) * BK * 2];
+    int i = 0;
+    while (i + 1 < g.n && (int)blockIdx.x >= g.start[i + 1]) ++i;
+    gemm16_body<TA, TB, BM, BN, NS, 0>(g.p[i], (int)blockIdx.x - g.start[i], smem);
+}
+template __global__ void gemm16_group_kernel<true, true, 64, 64, 2>(G16Group);
+template __global__ void gemm16_group_kernel<true, true, 64, 64, 3>(G16Group);
+
 // (explicit instantiations: the host stubs of kernels only named inside launch_tile's if/else chain were not emitted)
 
 template __global__ void gemm16_kernel<false, false, 128, 128, 2>(G16Args);
@@ -378,7 +403,8 @@ void launch_tile(int ta, int tb, const G16Args &a, dim3 grid, hipStream_t s) {
 // Tile choice (by tile count): at this model's sizes (4096..8192 rows x 512..3072 columns) the 64x64 tile wins on
 // every shape measured inside the train step — the launches are latency-bound, so more, smaller workgroups with more
 // DMAs in flight beat the larger tiles' better bytes-per-flop.
-int g16_thr128 = 4096, g16_thr12864 = 4096, g16_split_target = 768, g16_stages = 3, g16_split_major = 0;
+int g16_thr128 = 4096, g16_thr12864 = 4096, g16_split_target = 384, g16_stages = 3, g16_split_major = 0;
+int g16_group_split = 0;                                        // grouped launches: 0 = by the split target, n = n k-slices
 
 }  // namespace
 
@@ -390,6 +416,7 @@ void kk_gemm16_tune(int thr128, int thr12864, int split_target) {
     g16_split_major = split_target / 100000 ? 1 : 0;                     // 1xxxxx: split-major split-K (A/B comparison)
     g16_split_target = split_target % 10000;
 }
+void kk_gemm16_tune_group(int split) { g16_group_split = split; }
 
 // True when this core can run the problem (both operands bf16 assumed by the caller).
 bool kk_gemm16_eligible(int ta, int tb, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, const void *B, int64_t ldb) {
@@ -486,5 +513,48 @@ int kk_gemm16_linear_glu(int64_t T, int64_t F, int64_t K, const void *x, int64_t
     a.glu_seed = p > 0.f ? seed : nullptr; a.glu_site = site; a.glu_p = p;
     hipLaunchKernelGGL((gemm16_kernel<false, false, 64, 64, 2, 2>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, s, a);
     KK_LAUNCH_CHECK("kk_gemm_linear_glu");
+    return 0;
+}
+
+// dW_i[M_i, N_i] += dY_i[T_i, M_i]^T . X_i[T_i, N_i] for i < n, one launch (see gemm16_group_kernel).
+int kk_gemm16_wgrad_group(const KkWgradDesc *d, int n, int xcd_swizzle, hipStream_t s) {
+    auto cd = [](int64_t x, int64_t y) { return (int)((x + y - 1) / y); };
+    if (n < 1 || n > GROUP_MAX) return kk_fail(KK_EINVAL, "kk_gemm_wgrad_group: 1..%d problems per launch, got %d", GROUP_MAX, n);
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        if (d[i].M <= 0 || d[i].N <= 0 || d[i].T <= 0 || !d[i].dy || !d[i].x || !d[i].dw)
+            return kk_fail(KK_EINVAL, "kk_gemm_wgrad_group: bad problem %d", i);
+        if (!kk_gemm16_eligible(1, 1, d[i].M, d[i].N, d[i].T, d[i].dy, d[i].lddy, d[i].x, d[i].ldx))
+            return kk_fail(KK_EINVAL, "kk_gemm_wgrad_group: problem %d needs 16-byte aligned bf16 operands with row strides %% 8 == 0", i);
+        total += cd(d[i].M, 64) * cd(d[i].N, 64);
+    }
+    int splits = 1;
+    if (g16_group_split > 0) splits = g16_group_split;
+    else if (total * 2 <= g16_split_target) splits = cd(g16_split_target, total);
+    G16Group g = {};
+    g.n = n;
+    int min_per = 1 << 30;
+    for (int i = 0; i < n; ++i) {
+        const int64_t M = d[i].M, N = d[i].N, K = d[i].T;
+        const int ktiles = cd(K, BK);
+        int sp = std::min(splits, std::max(ktiles / 2, 1));
+        const int kps = cd(ktiles, sp) * BK;
+        sp = cd(K, kps);
+        min_per = std::min(min_per, kps / BK);
+        G16Args &a = g.p[i];
+        a.M = (int)M; a.N = (int)N; a.K = (int)K;
+        a.alpha = 1.f; a.beta = 1.f;
+        a.A = d[i].dy; a.B = d[i].x; a.C = d[i].dw;
+        a.lda = d[i].lddy; a.ldb = d[i].ldx; a.ldc = d[i].lddw;
+        a.k_per_split = kps; a.splits = sp; a.atomic = sp > 1 ? 1 : 0;
+        a.tiles_m = cd(M, 64); a.tiles_n = cd(N, 64); a.xcd_swizzle = xcd_swizzle;
+        a.a_bytes = (uint32_t)(((K - 1) * a.lda + M) * 2);
+        a.b_bytes = (uint32_t)(((K - 1) * a.ldb + N) * 2);
+        g.start[i + 1] = g.start[i] + a.tiles_m * a.tiles_n * sp;
+    }
+    dim3 grid(g.start[n]);
+    if (min_per < 3 || g16_stages < 3) hipLaunchKernelGGL((gemm16_group_kernel<true, true, 64, 64, 2>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm16_group_kernel<true, true, 64, 64, 3>), grid, dim3(256), 0, s, g);
+    KK_LAUNCH_CHECK("kk_gemm_wgrad_group");
     return 0;
 }

@@ -175,6 +175,10 @@ class KokoroEngine:
         self._kv = torch.cuda.Stream(device=self.device)
         self.dec_head_aside = True
         self.fuse_glu_fwd = os.environ.get("KK_FUSE_GLU_FWD", "1") != "0"
+        self.group_wgrads = os.environ.get("KK_GROUP_WGRADS", "1") != "0"     # A/B switches for tools/ and bench sweeps
+        self._wgrad_queue, self._wgrad_tables = {}, {}
+        if os.environ.get("KK_GROUP_SPLIT"):
+            kk.load().kk_gemm_tune_group(int(os.environ["KK_GROUP_SPLIT"]))
         self.spec_augment_active = True             # the trainer clears it for epochs < spec_augment_start_epoch
         self.rng = torch.full((1,), int(seed) & 0x7FFFFFFF, dtype=torch.int32, device=self.device)   # step seed, read on device
         for n, b in spec.make_buffers(self.dims).items():
@@ -298,10 +302,37 @@ class KokoroEngine:
     def _wgrad(self, dy, x, dW, db=None):
         N, M = dy.shape
         K = x.shape[1]
+        q = self._wgrad_queue.get(self._tmp_ns)
+        if q is not None and db is None and _b16(dy) and _b16(x) and self.math == kk.KK_MATH_BF16:
+            q.append((dy, x, dW))                        # issued with the rest of the layer's weight gradients
+            return
         kk.call("kk_gemm", 1, 1, M, K, N, 1.0, dy, dy.stride(0), x, x.stride(0), 1.0, dW, K, None, None, 0, 0, 0, self.math,
                 _b16(dy) | _b16(x) << 1)
         if db is not None:
             kk.call("kk_colsum_acc", dy, dy.stride(0), N, M, db, _b16(dy))
+
+    @contextlib.contextmanager
+    def _grouped_wgrads(self):
+        """Weight-gradient GEMMs issued inside the block (one layer's backward) are queued and run as ONE grouped launch
+        at its end: nothing reads a weight gradient before the optimizer, and together they fill the chip with
+        full-length reductions (no split-K atomics).  Their operands — the saved activations and the layer's own
+        gradient buffers — are not rewritten before the next layer's backward starts."""
+        ns = self._tmp_ns
+        if not self.group_wgrads or ns in self._wgrad_queue:
+            yield
+            return
+        q = self._wgrad_queue[ns] = []
+        try:
+            yield
+        finally:
+            del self._wgrad_queue[ns]
+        for i in range(0, len(q), 8):
+            part = q[i:i + 8]
+            sig = tuple((dy.data_ptr(), x.data_ptr(), dw.data_ptr(), tuple(dy.shape), tuple(x.shape)) for dy, x, dw in part)
+            table = self._wgrad_tables.get(sig)
+            if table is None:
+                table = self._wgrad_tables[sig] = kk.wgrad_table(part)
+            kk.call("kk_gemm_wgrad_group", table, len(part))
 
     def _ln_fwd(self, key, x, prefix, dtype=torch.float32):
         P = self.arena.P
@@ -351,7 +382,7 @@ class KokoroEngine:
             p2 = p
         else:
             f2 = gain = rstd_f = None
-            dy = self._buf("tmp.d_attn_proj", rows, H, dtype=dt)
+            dy = self._buf("tmp.d_attn_proj" + (".x" if hprefix.endswith(".cross_attn") else ""), rows, H, dtype=dt)
             self._reduce_lists[self._tmp_ns].append((part[:, 2 * H:], G[hprefix + ".w_o.bias"], None, nb, H, H, 4 * H))
             p2 = 0.0
         kk.call("kk_sublayer_in_bwd", dn, _b16(dn), x, P[prefix + ".weight"], self._buf(key + ".mean", rows), self._buf(key + ".rstd", rows),
@@ -472,7 +503,7 @@ class KokoroEngine:
         dctx, delta = self._buf(ck + ".dctx", Nq, H, dtype=dt), self._buf(ck + ".delta", B, h, Sq)
         # _tail_bwd (the fused LayerNorm backward before this call) already wrote the masked gradient of the projection
         # output and the column sums for w_o.bias
-        d_out = self._buf("tmp.d_attn_proj", Nq, H, dtype=dt)
+        d_out = self._buf("tmp.d_attn_proj" + ("" if xkv is None else ".x"), Nq, H, dtype=dt)
         self._wgrad(d_out, ctx, G[prefix + ".w_o.weight"], None)
         self._dgrad(d_out, self._W(prefix + ".w_o.weight"), dctx)
         # (Delta = rowsum(dctx * ctx) is computed by the dQ kernel from fragments it holds anyway, and read by the dK/dV kernel)
@@ -802,10 +833,11 @@ class KokoroEngine:
                 x_in = self._buf(f"enc{i - 1}.xo", Ne, H) if i > 0 else self._buf("enc.x0", Ne, H)
                 xm = self._buf(key + ".xm", Ne, H)
                 y1, y2 = self._buf(key + ".ln1.y", Ne, H, dtype=edt), self._buf(key + ".ln2.y", Ne, H, dtype=edt)
-                self._ffn_bwd(key + ".ff", pf + ".ff", dx, y2, dne, d.enc_ff, Pn, st + 8, p_enc, dpr)
-                self._tail_bwd(key + ".ln2", dne, xm, pf + ".norm2", dx, True, ehead("attn", i))
-                self._attn_bwd(key + ".sa", pf + ".self_attn", dx, y1, None, B, Pn, Pn, True, False, text_mask, dne, None, 0.0,
-                               st, p_enc, dpr)
+                with self._grouped_wgrads():
+                    self._ffn_bwd(key + ".ff", pf + ".ff", dx, y2, dne, d.enc_ff, Pn, st + 8, p_enc, dpr)
+                    self._tail_bwd(key + ".ln2", dne, xm, pf + ".norm2", dx, True, ehead("attn", i))
+                    self._attn_bwd(key + ".sa", pf + ".self_attn", dx, y1, None, B, Pn, Pn, True, False, text_mask, dne, None, 0.0,
+                                   st, p_enc, dpr)
                 if i > 0:
                     self._tail_bwd(key + ".ln1", dne, x_in, pf + ".norm1", dx, True, ehead("ffn", i - 1))
                 else:
@@ -832,12 +864,13 @@ class KokoroEngine:
             x_in = self._buf(f"dec{i - 1}.xo", Nd, H) if i > 0 else self._buf("dec.x0", Nd, H)
             ya, yc = self._buf(key + ".xa", Nd, H), self._buf(key + ".xc", Nd, H)
             n1, n2, n3 = (self._buf(f"{key}.ln{j}.y", Nd, H, dtype=ddt) for j in (1, 2, 3))
-            self._ffn_bwd(key + ".ff", pf + ".ff", dy, n3, dn, d.dec_ff, T, st + 16, p_dec, dpr)
-            self._tail_bwd(key + ".ln3", dn, yc, pf + ".norm3", dy, True, dhead("ca", i))
-            self._attn_bwd(key + ".ca", pf + ".cross_attn", dy, n2, memory, B, T, T, False, False, fmask, dn, dmem,
-                           0.0, st + 8, p_dec, dpr, layer=i)
-            self._tail_bwd(key + ".ln2", dn, ya, pf + ".norm2", dy, True, dhead("sa", i))
-            self._attn_bwd(key + ".sa", pf + ".self_attn", dy, n1, None, B, T, T, True, True, None, dn, None, 0.0, st, p_dec, dpr)
+            with self._grouped_wgrads():
+                self._ffn_bwd(key + ".ff", pf + ".ff", dy, n3, dn, d.dec_ff, T, st + 16, p_dec, dpr)
+                self._tail_bwd(key + ".ln3", dn, yc, pf + ".norm3", dy, True, dhead("ca", i))
+                self._attn_bwd(key + ".ca", pf + ".cross_attn", dy, n2, memory, B, T, T, False, False, fmask, dn, dmem,
+                               0.0, st + 8, p_dec, dpr, layer=i)
+                self._tail_bwd(key + ".ln2", dn, ya, pf + ".norm2", dy, True, dhead("sa", i))
+                self._attn_bwd(key + ".sa", pf + ".self_attn", dy, n1, None, B, T, T, True, True, None, dn, None, 0.0, st, p_dec, dpr)
             if i > 0:
                 self._tail_bwd(key + ".ln1", dn, x_in, pf + ".norm1", dy, True, dhead("ffn", i - 1))
             else:

@@ -47,6 +47,20 @@ class KkReduceDesc(C.Structure):
                 ("split", C.c_int), ("stride", C.c_int)]
 
 
+class KkWgradDesc(C.Structure):
+    _fields_ = [("dy", C.c_void_p), ("lddy", C.c_int64), ("x", C.c_void_p), ("ldx", C.c_int64), ("dw", C.c_void_p),
+                ("lddw", C.c_int64), ("M", C.c_int64), ("N", C.c_int64), ("T", C.c_int64)]
+
+
+def wgrad_table(entries):
+    """Host KkWgradDesc array from [(dy [T, M] bf16, x [T, N] bf16, dW [M, N] fp32)] for kk_gemm_wgrad_group."""
+    arr = (KkWgradDesc * len(entries))()
+    for d, (dy, x, dw) in zip(arr, entries):
+        d.dy, d.lddy, d.x, d.ldx, d.dw, d.lddw = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(), dw.stride(0)
+        d.M, d.N, d.T = dy.shape[1], x.shape[1], dy.shape[0]
+    return arr
+
+
 def reduce_table(entries, device) -> "torch.Tensor":
     """Device copy of a KkReduceDesc array from [(src, dst0, dst1 | None, nblocks, ncols, split[, row stride])]."""
     arr = (KkReduceDesc * len(entries))()
@@ -61,6 +75,8 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_gemm_linear_glu": [_L, _L, _L, _P, _L, _P, _P, _P, _P, _L, _P, _U, _F, _P],
     "kk_gemm_dgrad_glu": [_L, _L, _L, _P, _L, _P, _P, _P, _P, _P, _U, _F, _P],
     "kk_gemm_dgrad_glu_blocks": [_L],
+    "kk_gemm_wgrad_group": [_P, _I, _P],
+    "kk_gemm_tune_group": [_I],
     "kk_gemm_tune": [_I, _I],
     "kk_gemm_tune16": [_I, _I, _I, _I],
     "kk_colsum_acc": [_P, _L, _L, _L, _P, _I, _P],

@@ -1036,3 +1036,38 @@ def test_gemm_linear_glu_epilogue(kk, T, F, H, p):
     ref = torch.nn.functional.gelu(h_a[:, :F].float()) * h_a[:, F:].float()
     keep = g_a.float() != 0
     close(g_a.float()[keep], (ref / (1 - p))[keep], 2e-2, 2e-2, "gate value")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,shapes,split", [(256, [(64, 64)], 0), (1000, [(512, 192), (72, 64), (192, 512), (64, 136)], 0),
+                                            (4096, [(512, 2048), (4096, 512), (512, 512), (1536, 512)], 0),
+                                            (4096, [(512, 512), (1536, 512)], 2), (520, [(128, 64)] * 8, 3)])
+def test_gemm_wgrad_group(kk, T, shapes, split):
+    """kk_gemm_wgrad_group == one kk_gemm(ta=1, tb=1, beta=1) per problem: bit for bit without k-slices (same tile code,
+    same order of accumulation), to fp32 atomics' reordering with them."""
+    g = torch.Generator().manual_seed(T)
+    bf = torch.bfloat16
+    probs = []
+    for M, N in shapes:
+        wide = dev(torch.randn(T, M + 8, generator=g)).to(bf)          # a strided view, like a slice of the fused q|k|v gradient
+        dy, x = wide[:, 8:], dev(torch.randn(T, N, generator=g)).to(bf)
+        probs.append((dy, x, dev(torch.randn(M, N, generator=g))))
+    ref = []
+    for dy, x, dw in probs:
+        r = dw.clone()
+        kk.call("kk_gemm", 1, 1, dy.shape[1], x.shape[1], T, 1.0, dy, dy.stride(0), x, x.stride(0), 1.0, r, x.shape[1], None, None,
+                0, 0, 1, 1, 3)
+        ref.append(r)
+    kk.load().kk_gemm_tune_group(split)
+    try:
+        kk.call("kk_gemm_wgrad_group", kk.wgrad_table(probs), len(probs))
+    finally:
+        kk.load().kk_gemm_tune_group(0)
+    torch.cuda.synchronize()
+    for (dy, x, dw), r in zip(probs, ref):
+        if split == 0 and sum(-(-m // 64) * -(-n // 64) for m, n in shapes) * 2 > 384:
+            assert torch.equal(dw, r)
+        else:
+            close(dw, r, 2e-3 * math.sqrt(T / 256), 1e-4, "grouped weight gradient (k-sliced)")
+    with pytest.raises(RuntimeError):
+        kk.call("kk_gemm_wgrad_group", kk.wgrad_table(probs * 9), len(probs) * 9)
