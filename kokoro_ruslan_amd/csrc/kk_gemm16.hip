@@ -107,13 +107,16 @@ template <int ROWS, bool KS> struct FragAddr {
             for (int rb = 0; rb < 4; ++rb) x[rb] = (uint32_t)((((wave_row0 >> 4) + 2 * rb + gi) ^ s) * 32);
         }
     }
-    // Fragment for 32-row block rb (relative to the wave's first row), k-slab ks (16 k).
-    // k-contiguous: one ds_read_b128 the compiler schedules and waits for.  k-strided: two transpose reads issued as
-    // inline asm — through the builtin, hipcc puts an s_waitcnt vmcnt(0) in front of every read while a DMA is in
-    // flight, which would serialise the pipeline; the caller retires them with wait_frags() before the MFMAs.
+    // Fragment for 32-row block rb (relative to the wave's first row), k-slab ks (16 k): one ds_read_b128 (k-contiguous)
+    // or two transpose reads (k-strided).  All of them are inline asm: the k-loop keeps the reads of the NEXT slabs in
+    // flight under the MFMAs of this one and retires them with counted lgkmcnt waits (wait_slab), which only works
+    // when every LDS read of the loop is in program order under our control.  (Through the builtin, hipcc also puts
+    // an s_waitcnt vmcnt(0) in front of every transpose read while a DMA is in flight.)
+    static constexpr int READS = KS ? 2 : 1;                    // LDS instructions per fragment
     __device__ __forceinline__ void load(Frag &f, const char *img, int rb, int ks) const {
         if constexpr (!KS) {
-            f.v = *reinterpret_cast<const bf16x8 *>(img + base + rb * 32 * (BK * 2) + x[ks]);
+            const uint32_t addr = (uint32_t)(uintptr_t)LDS_PTR(img) + base + x[ks] + rb * 32 * (BK * 2);
+            asm volatile("ds_read_b128 %0, %1" : "=v"(f.v) : "v"(addr));
         } else {
             const uint32_t addr = (uint32_t)(uintptr_t)LDS_PTR(img) + base + x[rb] + ks * 16 * (ROWS * 2);
             asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(addr));
@@ -128,8 +131,13 @@ __device__ __forceinline__ bf16x8 frag_value(const Frag &f, bool ks) {
     v[0] = f.lo[0]; v[1] = f.lo[1]; v[2] = f.lo[2]; v[3] = f.lo[3]; v[4] = f.hi[0]; v[5] = f.hi[1]; v[6] = f.hi[2]; v[7] = f.hi[3];
     return __builtin_bit_cast(bf16x8, v);
 }
-// s_waitcnt lgkmcnt(0) that the asm reads' results are data-dependent on (so no consumer can be scheduled above it)
-__device__ __forceinline__ void wait_frag(Frag &f) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.lo), "+v"(f.hi)); }
+// Wait until at most PENDING younger LDS reads are outstanding (they return in order), then pin the slab's fragments
+// behind the wait: the empty asm makes their registers data-dependent on this point, so no MFMA is scheduled above it.
+template <int PENDING> __device__ __forceinline__ void wait_reads() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(PENDING) : "memory"); }
+__device__ __forceinline__ void pin_frag(Frag &f, bool ks) {
+    if (ks) asm volatile("" : "+v"(f.lo), "+v"(f.hi));
+    else asm volatile("" : "+v"(f.v));
+}
 
 // NS LDS stages: NS-1 k-tiles are in flight while one is multiplied.  The DMA of a tile is waited for with a COUNTED
 // vmcnt (the younger tiles stay in flight across the barrier), and the barrier is a raw s_barrier: __syncthreads()
@@ -223,31 +231,39 @@ __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char
         sn = sc;
         sc = sc + 1 == NS ? 0 : sc + 1;
         const char *Ai = cur, *Bi = cur + OA::BYTES;
+        // The four 16-k slabs of the tile, software-pipelined inside the wave: the LDS reads of slabs ks+1..ks+AHEAD
+        // are in flight while slab ks is multiplied (the lgkmcnt counter holds 15, hence AHEAD by reads per slab).
+        constexpr int RPS = MI * FragAddr<BM, TA>::READS + (NI + (EPI == 2 ? 1 : 0)) * FragAddr<BN, TB>::READS;
+        constexpr int AHEAD = 3 * RPS <= 15 ? 2 : (2 * RPS <= 15 ? 1 : 0);
+        Frag af[4][MI], bf[4][NI], bf2[4];
+        auto read_slab = [&](int ks) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa.load(af[ks][i], Ai, i, ks);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) fb.load(bf[ks][j], Bi, j, ks);
+            if constexpr (EPI == 2) fb.load(bf2[ks], Bi + OB::BYTES, 0, ks);
+        };
+#pragma unroll
+        for (int ks = 0; ks < AHEAD; ++ks) read_slab(ks);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            Frag af[MI], bf[NI];
+            if (ks + AHEAD < 4) read_slab(ks + AHEAD);
+            if (ks + AHEAD < 4) wait_reads<AHEAD * RPS>();
+            else if (ks + 1 < 4 && AHEAD == 2 && ks == 2) wait_reads<RPS>();
+            else wait_reads<0>();
 #pragma unroll
-            for (int i = 0; i < MI; ++i) fa.load(af[i], Ai, i, ks);
+            for (int i = 0; i < MI; ++i) pin_frag(af[ks][i], TA);
 #pragma unroll
-            for (int j = 0; j < NI; ++j) fb.load(bf[j], Bi, j, ks);
-            if constexpr (TA) {
-#pragma unroll
-                for (int i = 0; i < MI; ++i) wait_frag(af[i]);
-            }
-            if constexpr (TB) {
-#pragma unroll
-                for (int j = 0; j < NI; ++j) wait_frag(bf[j]);
-            }
+            for (int j = 0; j < NI; ++j) pin_frag(bf[ks][j], TB);
+            if constexpr (EPI == 2) pin_frag(bf2[ks], TB);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_value(af[i], TA), frag_value(bf[j], TB), acc[i][j], 0, 0, 0);
-            if constexpr (EPI == 2) {
-                Frag b2;
-                fb.load(b2, Bi + OB::BYTES, 0, ks);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_value(af[0], TA), frag_value(b2, TB), acc2, 0, 0, 0);
-            }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_value(af[ks][i], TA), frag_value(bf[ks][j], TB), acc[i][j], 0, 0, 0);
+            if constexpr (EPI == 2)
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_value(af[ks][0], TA), frag_value(bf2[ks], TB), acc2, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);                  // keep the slab's MFMAs here, between the waits
         }
     }
     if (nk <= 0) return;
@@ -360,6 +376,8 @@ __global__ __launch_bounds__(256) void gemm16_group_kernel(G16Group g) {
 }
 template __global__ void gemm16_group_kernel<true, true, 64, 64, 2>(G16Group);
 template __global__ void gemm16_group_kernel<true, true, 64, 64, 3>(G16Group);
+template __global__ void gemm16_group_kernel<true, true, 128, 64, 2>(G16Group);
+template __global__ void gemm16_group_kernel<true, true, 128, 128, 2>(G16Group);
 
 // (explicit instantiations: the host stubs of kernels only named inside launch_tile's if/else chain were not emitted)
 
@@ -404,6 +422,7 @@ void launch_tile(int ta, int tb, const G16Args &a, dim3 grid, hipStream_t s) {
 // every shape measured inside the train step — the launches are latency-bound, so more, smaller workgroups with more
 // DMAs in flight beat the larger tiles' better bytes-per-flop.
 int g16_thr128 = 4096, g16_thr12864 = 4096, g16_split_target = 384, g16_stages = 3, g16_split_major = 0;
+int g16_group_tile = 1;                                         // grouped launches: 0 = 64x64, 1 = 128x64 (default: +1 % on the step), 2 = 128x128 tiles
 int g16_group_split = 0;                                        // grouped launches: 0 = by the split target, n = n k-slices
 
 }  // namespace
@@ -416,7 +435,7 @@ void kk_gemm16_tune(int thr128, int thr12864, int split_target) {
     g16_split_major = split_target / 100000 ? 1 : 0;                     // 1xxxxx: split-major split-K (A/B comparison)
     g16_split_target = split_target % 10000;
 }
-void kk_gemm16_tune_group(int split) { g16_group_split = split; }
+void kk_gemm16_tune_group(int split) { g16_group_split = split % 100; g16_group_tile = split / 100; }
 
 // True when this core can run the problem (both operands bf16 assumed by the caller).
 bool kk_gemm16_eligible(int ta, int tb, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, const void *B, int64_t ldb) {
@@ -521,12 +540,13 @@ int kk_gemm16_wgrad_group(const KkWgradDesc *d, int n, int xcd_swizzle, hipStrea
     auto cd = [](int64_t x, int64_t y) { return (int)((x + y - 1) / y); };
     if (n < 1 || n > GROUP_MAX) return kk_fail(KK_EINVAL, "kk_gemm_wgrad_group: 1..%d problems per launch, got %d", GROUP_MAX, n);
     int total = 0;
+    const int BM = g16_group_tile >= 1 ? 128 : 64, BN = g16_group_tile >= 2 ? 128 : 64;
     for (int i = 0; i < n; ++i) {
         if (d[i].M <= 0 || d[i].N <= 0 || d[i].T <= 0 || !d[i].dy || !d[i].x || !d[i].dw)
             return kk_fail(KK_EINVAL, "kk_gemm_wgrad_group: bad problem %d", i);
         if (!kk_gemm16_eligible(1, 1, d[i].M, d[i].N, d[i].T, d[i].dy, d[i].lddy, d[i].x, d[i].ldx))
             return kk_fail(KK_EINVAL, "kk_gemm_wgrad_group: problem %d needs 16-byte aligned bf16 operands with row strides %% 8 == 0", i);
-        total += cd(d[i].M, 64) * cd(d[i].N, 64);
+        total += cd(d[i].M, BM) * cd(d[i].N, BN);
     }
     int splits = 1;
     if (g16_group_split > 0) splits = g16_group_split;
@@ -547,13 +567,15 @@ int kk_gemm16_wgrad_group(const KkWgradDesc *d, int n, int xcd_swizzle, hipStrea
         a.A = d[i].dy; a.B = d[i].x; a.C = d[i].dw;
         a.lda = d[i].lddy; a.ldb = d[i].ldx; a.ldc = d[i].lddw;
         a.k_per_split = kps; a.splits = sp; a.atomic = sp > 1 ? 1 : 0;
-        a.tiles_m = cd(M, 64); a.tiles_n = cd(N, 64); a.xcd_swizzle = xcd_swizzle;
+        a.tiles_m = cd(M, BM); a.tiles_n = cd(N, BN); a.xcd_swizzle = xcd_swizzle;
         a.a_bytes = (uint32_t)(((K - 1) * a.lda + M) * 2);
         a.b_bytes = (uint32_t)(((K - 1) * a.ldb + N) * 2);
         g.start[i + 1] = g.start[i] + a.tiles_m * a.tiles_n * sp;
     }
     dim3 grid(g.start[n]);
-    if (min_per < 3 || g16_stages < 3) hipLaunchKernelGGL((gemm16_group_kernel<true, true, 64, 64, 2>), grid, dim3(256), 0, s, g);
+    if (BN == 128) hipLaunchKernelGGL((gemm16_group_kernel<true, true, 128, 128, 2>), grid, dim3(256), 0, s, g);
+    else if (BM == 128) hipLaunchKernelGGL((gemm16_group_kernel<true, true, 128, 64, 2>), grid, dim3(256), 0, s, g);
+    else if (min_per < 3 || g16_stages < 3) hipLaunchKernelGGL((gemm16_group_kernel<true, true, 64, 64, 2>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((gemm16_group_kernel<true, true, 64, 64, 3>), grid, dim3(256), 0, s, g);
     KK_LAUNCH_CHECK("kk_gemm_wgrad_group");
     return 0;

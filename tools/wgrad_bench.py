@@ -46,3 +46,20 @@ for label, cfg in configs:
         rows.setdefault(name, []).append(f"{label}: {t:6.1f}us {fl / t / 1e6:4.0f}TF")
 for name, r in rows.items():
     print(name, " | ".join(r))
+
+# one encoder layer's / one decoder layer's weight gradients as a grouped launch
+for label, shapes in [("enc layer", [(512, 2048), (4096, 512), (512, 512), (1536, 512)]),
+                      ("dec layer", [(512, 2048), (4096, 512), (512, 512), (512, 512), (512, 512), (1536, 512)])]:
+    probs = [(torch.randn(T, M, device="cuda").to(bf), torch.randn(T, N, device="cuda").to(bf), torch.zeros(M, N, device="cuda"))
+             for M, N in shapes]
+    fl = sum(2.0 * T * M * N for M, N in shapes)
+    table = kk.wgrad_table(probs)
+    out = []
+    for stages in (2, 3):
+        kk.load().kk_gemm_tune16(1, 4096, 4096, stages * 10000 + 384)
+        for split in (1, 2, 101, 102, 201, 202):
+            kk.load().kk_gemm_tune_group(split)
+            t = timeit(lambda: kk.call("kk_gemm_wgrad_group", table, len(probs)))
+            out.append(f"NS {stages} split {split}: {t:6.1f}us {fl / t / 1e6:4.0f}TF")
+    kk.load().kk_gemm_tune_group(0)
+    print("group", label, " | ".join(out))
