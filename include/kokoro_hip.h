@@ -315,6 +315,9 @@ int kk_weight_norm_project(float *p, const int32_t *block_seg, int64_t nblocks, 
 int kk_cast_f32_bf16(const float *src, void *dst, int64_t n, void *stream);
 
 /* ---- misc ---- */
+/* n <= 16 device-to-device copies (dst[i] <- src[i], bytes[i] each; host arrays of device pointers) as one launch:
+ * the hand-over of a batch's tensors into the buffers the captured step reads. */
+int kk_copy_many(const void *const *src, void *const *dst, const int64_t *bytes, int n, void *stream);
 int kk_axpby(float a, const float *x, float b, float *y, int64_t n, void *stream); /* y = a*x + b*y */
 int kk_mfma_probe(float *out_f32 /*32*32*/, float *out_bf16 /*32*32*/, void *stream);
 

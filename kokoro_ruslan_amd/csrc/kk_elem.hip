@@ -482,3 +482,50 @@ extern "C" int kk_shift_right(const float *mel, float *out, int B, int T, int M,
     KK_LAUNCH_CHECK("kk_shift_right");
     return 0;
 }
+
+// ------------------------------------------------------------------ batch hand-over
+// Up to 16 device-to-device copies as ONE launch: a step's batch (ids, mel, durations, pitch, ... — nine small tensors)
+// moves into the buffers the captured graphs read.  blockIdx.x walks 16 KiB chunks of the concatenation.
+namespace {
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr int COPY_MAX = 16;
+constexpr int64_t COPY_CHUNK = 16384;
+struct CopyMany {
+    const char *src[COPY_MAX];
+    char *dst[COPY_MAX];
+    int64_t bytes[COPY_MAX];
+    int start[COPY_MAX + 1];      // first chunk of each copy
+    int n;
+};
+__global__ __launch_bounds__(256) void copy_many_kernel(CopyMany c) {
+    int i = 0;
+    while (i + 1 < c.n && (int)blockIdx.x >= c.start[i + 1]) ++i;
+    const int64_t off = (int64_t)((int)blockIdx.x - c.start[i]) * COPY_CHUNK;
+    const int64_t len = min(COPY_CHUNK, c.bytes[i] - off);
+    const char *s = c.src[i] + off;
+    char *d = c.dst[i] + off;
+    if ((((uintptr_t)s | (uintptr_t)d) & 15) == 0) {
+        const int64_t nv = len >> 4;
+        for (int64_t j = threadIdx.x; j < nv; j += 256) reinterpret_cast<u32x4 *>(d)[j] = reinterpret_cast<const u32x4 *>(s)[j];
+        for (int64_t j = (nv << 4) + threadIdx.x; j < len; j += 256) d[j] = s[j];
+    } else {
+        for (int64_t j = threadIdx.x; j < len; j += 256) d[j] = s[j];
+    }
+}
+}  // namespace
+
+extern "C" int kk_copy_many(const void *const *src, void *const *dst, const int64_t *bytes, int n, void *stream) {
+    KK_REQUIRE(src && dst && bytes && n >= 1 && n <= COPY_MAX, "kk_copy_many: 1..16 copies per call");
+    CopyMany c = {};
+    c.n = n;
+    for (int i = 0; i < n; ++i) {
+        KK_REQUIRE(src[i] && dst[i] && bytes[i] > 0, "kk_copy_many: null pointer or empty copy");
+        c.src[i] = static_cast<const char *>(src[i]);
+        c.dst[i] = static_cast<char *>(dst[i]);
+        c.bytes[i] = bytes[i];
+        c.start[i + 1] = c.start[i] + (int)((bytes[i] + COPY_CHUNK - 1) / COPY_CHUNK);
+    }
+    hipLaunchKernelGGL(copy_many_kernel, dim3(c.start[n]), dim3(256), 0, (hipStream_t)stream, c);
+    KK_LAUNCH_CHECK("kk_copy_many");
+    return 0;
+}

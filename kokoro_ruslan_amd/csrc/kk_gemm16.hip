@@ -462,6 +462,10 @@ int kk_gemm16_launch(int ta, int tb, int64_t M, int64_t N, int64_t K, float alph
             if (splits > cap) splits = cap;
         }
     }
+    // beta == 0 with k-slices needs C zero-filled first: one more node in front of a GEMM that is latency-bound anyway
+    // (the encoder's 1000-row projections), so short reductions are not sliced then
+    // (+1 % on the train step)
+    if (split_k <= 0 && beta == 0.f && ktiles < 32) splits = 1;
     if (splits > ktiles) splits = ktiles;
     if (splits > 1 && (c_bf16 || !(beta == 1.f || (beta == 0.f && ldc == N)))) splits = 1;
     if (split_k <= 0 && splits >= 6 && g16_split_major) {       // a multiple of 8 slices: one XCD per slice residue class

@@ -235,14 +235,23 @@ class KokoroEngine:
 
     # ------------------------------------------------------------------ helpers
     @contextlib.contextmanager
-    def _on_stream(self, stream, ns, enable=True):
-        """Run the enclosed launches on `stream`, after everything already queued on the current stream; the caller
-        joins with _join(stream).  Scratch ("tmp.*") buffers get the namespace `ns` so that streams never share one.
-        With overlap off this is a no-op (same stream, same order)."""
+    def _on_stream(self, stream, ns, enable=True, after=None):
+        """Run the enclosed launches on `stream`, after everything already queued on the current stream (or, with
+        `after`, after that earlier point of it: an event from _fork_point); the caller joins with _join(stream).
+        Scratch ("tmp.*") buffers get the namespace `ns` so that streams never share one.
+        With overlap off this is a no-op (same stream, same order).
+
+        Under rocprofv3 the branch captured FIRST after a fork runs first and the other one starts late (the decoder
+        backward appeared 1.1 ms after the losses when the encoder backward was captured before it), so the
+        critical-path branch is captured first and the side branch afterwards, forked from an event recorded at the
+        fork point.  Unprofiled, the step time is the same either way."""
         if not (self.overlap and enable):
             yield
             return
-        stream.wait_stream(torch.cuda.current_stream())
+        if after is not None:
+            stream.wait_event(after)
+        else:
+            stream.wait_stream(torch.cuda.current_stream())
         saved, self._tmp_ns = self._tmp_ns, ns
         try:
             with torch.cuda.stream(stream):
@@ -250,8 +259,16 @@ class KokoroEngine:
         finally:
             self._tmp_ns = saved
 
-    def _on_side_stream(self):
-        return self._on_stream(self._side, "side.")
+    def _on_side_stream(self, after=None):
+        return self._on_stream(self._side, "side.", after=after)
+
+    def _fork_point(self):
+        """An event on the current stream that a later _on_stream(..., after=event) forks from."""
+        if not self.overlap:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        return ev
 
     def _join(self, stream) -> None:
         if self.overlap:
@@ -740,7 +757,8 @@ class KokoroEngine:
         dur_pred = self._buf("out.log_dur", B, Pn)
         col_e = self._buf("vp.col_enc", Ne, 3 * H, dtype=edt)
         kk.call("kk_im2col3_fwd", enc, col_e, B, Pn, H, CHUNK, _b16(col_e))
-        self._varpred_fwd("vp.dur", f"{VA}.duration_predictor", enc, col_e, B, Pn, text_mask, dur_pred, 10, p_var)
+        # (teacher forcing: the regulator and the embeddings below use the batch's durations / pitch / energy, so the three
+        #  predictors feed only the losses and run on the side stream — see predictors())
         idx, lens, tot = (self._buf("lr.idx", B, T, dtype=torch.int64), self._buf("lr.lens", B, dtype=torch.int64),
                           self._buf("lr.total", B, dtype=torch.int64))
         kk.call("kk_length_regulate_index", dur, idx, lens, tot, B, Pn, T)
@@ -754,9 +772,6 @@ class KokoroEngine:
         pitch_pred, energy_pred = self._buf("out.pitch", B, T), self._buf("out.energy", B, T)
         col_f = self._buf("vp.col_frames", Nd, 3 * H, dtype=ddt)
         kk.call("kk_im2col3_fwd", xf, col_f, B, T, H, CHUNK, _b16(col_f))
-        with self._on_side_stream():                      # joined before the losses
-            self._varpred_fwd("vp.pitch", f"{VA}.pitch_predictor", xf, col_f, B, T, fmask, pitch_pred, 12, p_var)
-            self._varpred_fwd("vp.energy", f"{VA}.energy_predictor", xf, col_f, B, T, fmask, energy_pred, 14, p_var)
         spec_aug = self.train_dropout and hp.use_spec_augment and self.spec_augment_active
         if spec_aug:                                      # on the cross-attention memory only (model.py:636-639)
             kk.call("kk_specaug", memory, B, T, H, self.rng, 20, hp.spec_augment_time_mask_max, hp.spec_augment_freq_mask_max,
@@ -764,6 +779,12 @@ class KokoroEngine:
 
         # ---- decoder (model.py:519-531; transformers.py:543-583,660) ----
         self._cross_kv_fwd_all(memory, Nd, T, ddt)        # every layer's cross-attention K/V in one GEMM
+        # Forked only here, after the K/V GEMM: started earlier (right after im2col3) the predictors' fp32 GEMMs compete
+        # with the critical path into the decoder; 2.8 % of the step (729K -> 749K frames/s).
+        with self._on_side_stream():                      # joined before the losses
+            self._varpred_fwd("vp.dur", f"{VA}.duration_predictor", enc, col_e, B, Pn, text_mask, dur_pred, 10, p_var)
+            self._varpred_fwd("vp.pitch", f"{VA}.pitch_predictor", xf, col_f, B, T, fmask, pitch_pred, 12, p_var)
+            self._varpred_fwd("vp.energy", f"{VA}.energy_predictor", xf, col_f, B, T, fmask, energy_pred, 14, p_var)
         n1 = None
         for i in range(d.dec_layers):
             pf, key, st = f"decoder.layers.{i}", f"dec{i}", 2000 + 32 * i
@@ -816,34 +837,43 @@ class KokoroEngine:
         dmel, ddur = self._buf("g.mel", B, T, M), self._buf("g.dur", B, Pn)
         dstop, dpitch, denergy = self._buf("g.stop", B, T), self._buf("g.pitch", B, T), self._buf("g.energy", B, T)
         kk.call("kk_losses_bwd", *largs, self.loss_coef, dmel, ddur, dstop, dpitch, denergy)
-        with self._on_side_stream():                      # independent of the decoder backward (disjoint gradient segments)
-            self._varpred_bwd("vp.pitch", f"{VA}.pitch_predictor", dpitch, xf, col_f, B, T, fmask, None, p_var)
-            self._varpred_bwd("vp.energy", f"{VA}.energy_predictor", denergy, xf, col_f, B, T, fmask, None, p_var)
-            d_enc = self._buf("g.enc_out", Ne, H)
-            self._varpred_bwd("vp.dur", f"{VA}.duration_predictor", ddur, enc, col_e, B, Pn, text_mask, d_enc, p_var)
-            dx = self._buf("g.enc_stream", Ne, H)
-            # every LayerNorm's backward is fused with the head of the backward of the sub-layer that produced its input
-            ehead = lambda kind, i: (kind, f"enc{i}.ff", f"transformer_encoder_layers.{i}" + (".ff" if kind == "ffn" else ".self_attn"),
-                                     Pn, 1000 + 32 * i + (8 if kind == "ffn" else 0), p_enc, self._dpr(i, d.enc_layers), edt)
-            self._tail_bwd("enc.norm", d_enc, enc_last, "encoder_norm", dx, False, ehead("ffn", d.enc_layers - 1))
-            dne = self._buf("tmp.dne", Ne, H, dtype=edt)
-            for i in reversed(range(d.enc_layers)):
-                pf, key, st = f"transformer_encoder_layers.{i}", f"enc{i}", 1000 + 32 * i
-                dpr = self._dpr(i, d.enc_layers)
-                x_in = self._buf(f"enc{i - 1}.xo", Ne, H) if i > 0 else self._buf("enc.x0", Ne, H)
-                xm = self._buf(key + ".xm", Ne, H)
-                y1, y2 = self._buf(key + ".ln1.y", Ne, H, dtype=edt), self._buf(key + ".ln2.y", Ne, H, dtype=edt)
-                with self._grouped_wgrads():
-                    self._ffn_bwd(key + ".ff", pf + ".ff", dx, y2, dne, d.enc_ff, Pn, st + 8, p_enc, dpr)
-                    self._tail_bwd(key + ".ln2", dne, xm, pf + ".norm2", dx, True, ehead("attn", i))
-                    self._attn_bwd(key + ".sa", pf + ".self_attn", dx, y1, None, B, Pn, Pn, True, False, text_mask, dne, None, 0.0,
-                                   st, p_enc, dpr)
-                if i > 0:
-                    self._tail_bwd(key + ".ln1", dne, x_in, pf + ".norm1", dx, True, ehead("ffn", i - 1))
-                else:
-                    self._ln_bwd(key + ".ln1", dne, x_in, pf + ".norm1", dx, accumulate=True)
-            kk.call("kk_embed_bwd", ids, stress, dx, G["text_embedding.weight"],
-                    G["stress_embedding.weight"] if stress is not None else None, B, Pn, H, float(H ** 0.5), self.rng, 1, pe_drop)
+        fork = self._fork_point()
+
+        def side_backward(after):                         # independent of the decoder backward (disjoint gradient segments)
+            with self._on_side_stream(after=after):
+                self._varpred_bwd("vp.pitch", f"{VA}.pitch_predictor", dpitch, xf, col_f, B, T, fmask, None, p_var)
+                self._varpred_bwd("vp.energy", f"{VA}.energy_predictor", denergy, xf, col_f, B, T, fmask, None, p_var)
+                d_enc = self._buf("g.enc_out", Ne, H)
+                self._varpred_bwd("vp.dur", f"{VA}.duration_predictor", ddur, enc, col_e, B, Pn, text_mask, d_enc, p_var)
+                dx = self._buf("g.enc_stream", Ne, H)
+                # every LayerNorm's backward is fused with the head of the backward of the sub-layer that produced its input
+                ehead = lambda kind, i: (kind, f"enc{i}.ff", f"transformer_encoder_layers.{i}" + (".ff" if kind == "ffn" else ".self_attn"),
+                                         Pn, 1000 + 32 * i + (8 if kind == "ffn" else 0), p_enc, self._dpr(i, d.enc_layers), edt)
+                self._tail_bwd("enc.norm", d_enc, enc_last, "encoder_norm", dx, False, ehead("ffn", d.enc_layers - 1))
+                dne = self._buf("tmp.dne", Ne, H, dtype=edt)
+                for i in reversed(range(d.enc_layers)):
+                    pf, key, st = f"transformer_encoder_layers.{i}", f"enc{i}", 1000 + 32 * i
+                    dpr = self._dpr(i, d.enc_layers)
+                    x_in = self._buf(f"enc{i - 1}.xo", Ne, H) if i > 0 else self._buf("enc.x0", Ne, H)
+                    xm = self._buf(key + ".xm", Ne, H)
+                    y1, y2 = self._buf(key + ".ln1.y", Ne, H, dtype=edt), self._buf(key + ".ln2.y", Ne, H, dtype=edt)
+                    with self._grouped_wgrads():
+                        self._ffn_bwd(key + ".ff", pf + ".ff", dx, y2, dne, d.enc_ff, Pn, st + 8, p_enc, dpr)
+                        self._tail_bwd(key + ".ln2", dne, xm, pf + ".norm2", dx, True, ehead("attn", i))
+                        self._attn_bwd(key + ".sa", pf + ".self_attn", dx, y1, None, B, Pn, Pn, True, False, text_mask, dne, None, 0.0,
+                                       st, p_enc, dpr)
+                    if i > 0:
+                        self._tail_bwd(key + ".ln1", dne, x_in, pf + ".norm1", dx, True, ehead("ffn", i - 1))
+                    else:
+                        self._ln_bwd(key + ".ln1", dne, x_in, pf + ".norm1", dx, accumulate=True)
+                kk.call("kk_embed_bwd", ids, stress, dx, G["text_embedding.weight"],
+                        G["stress_embedding.weight"] if stress is not None else None, B, Pn, H, float(H ** 0.5), self.rng, 1, pe_drop)
+
+        # The decoder backward is the critical path, so it is captured first and the predictors' + encoder's backward
+        # after it, forked from the point right after the loss gradients (see _on_stream).  With a split backward
+        # (data-parallel overlap) the early ranges must be final at the pause, so there the side branch goes first.
+        if yield_at is not None:
+            side_backward(None)
         # heads (model.py:561-562): the stop head's input is detached
         kk.call("kk_rowdot_bwd", dstop, dec_out, P["stop_token_predictor.weight"], None, None, G["stop_token_predictor.weight"],
                 G["stop_token_predictor.bias"], Nd, H, T, 0, _b16(dec_out))
@@ -894,6 +924,8 @@ class KokoroEngine:
                     hp.spec_augment_num_time_masks, hp.spec_augment_num_freq_masks, 0)
         kk.call("kk_bucket_embed_add_bwd", dmem, pidx, eidx, fmask, G[f"{VA}.pitch_embedding.weight"],
                 G[f"{VA}.energy_embedding.weight"], B, T, H)
+        if yield_at is None:
+            side_backward(fork)
         self._join(self._side)
         self._reduce_partials((B, T, Pn))
         return out
@@ -967,9 +999,17 @@ class KokoroEngine:
             self.optimizer_step(T)
             return self.losses
         static = ent["static"]
+        moved = []
         for k, v in batch.items():
-            if v.data_ptr() != static[k].data_ptr():
-                static[k].copy_(v, non_blocking=True)
+            d = static[k]
+            if v.data_ptr() == d.data_ptr():
+                continue
+            if v.shape == d.shape and v.dtype == d.dtype and v.device == d.device and v.is_contiguous() and d.is_contiguous():
+                moved.append((d, v))
+            else:
+                d.copy_(v, non_blocking=True)
+        if moved:
+            kk.copy_many(moved)                        # one launch for the whole batch
         if ent["fb"] is None:
             torch.cuda.synchronize()
             ent["fb"], ent["fb2"], ent["opt"] = torch.cuda.CUDAGraph(), None, torch.cuda.CUDAGraph()

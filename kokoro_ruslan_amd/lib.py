@@ -61,6 +61,17 @@ def wgrad_table(entries):
     return arr
 
 
+def copy_many(pairs) -> None:
+    """dst.copy_(src) for up to 16 (dst, src) pairs of contiguous same-size device tensors per launch."""
+    for i in range(0, len(pairs), 16):
+        part = pairs[i:i + 16]
+        n = len(part)
+        src = (C.c_void_p * n)(*[s.data_ptr() for _, s in part])
+        dst = (C.c_void_p * n)(*[d.data_ptr() for d, _ in part])
+        nbytes = (C.c_int64 * n)(*[d.numel() * d.element_size() for d, _ in part])
+        call("kk_copy_many", src, dst, nbytes, n)
+
+
 def reduce_table(entries, device) -> "torch.Tensor":
     """Device copy of a KkReduceDesc array from [(src, dst0, dst1 | None, nblocks, ncols, split[, row stride])]."""
     arr = (KkReduceDesc * len(entries))()
@@ -124,6 +135,7 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_adamw_ema": [_P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _F, _F, _F, _P, _I, _P, _P],
     "kk_weight_norm_project": [_P, _P, _L, _P, _P, _P, _D, _P, _P],
     "kk_cast_f32_bf16": [_P, _P, _L, _P],
+    "kk_copy_many": [_P, _P, _P, _I, _P],
     "kk_axpby": [_F, _P, _F, _P, _L, _P],
     "kk_mfma_probe": [_P, _P, _P],
 }

@@ -1071,3 +1071,18 @@ def test_gemm_wgrad_group(kk, T, shapes, split):
             close(dw, r, 2e-3 * math.sqrt(T / 256), 1e-4, "grouped weight gradient (k-sliced)")
     with pytest.raises(RuntimeError):
         kk.call("kk_gemm_wgrad_group", kk.wgrad_table(probs * 9), len(probs) * 9)
+
+
+@pytest.mark.gpu
+def test_copy_many(kk):
+    g = torch.Generator().manual_seed(5)
+    srcs = [dev(torch.randn(n, generator=g)) for n in (1, 7, 4096, 5000, 40000)] + \
+           [dev(torch.randint(0, 100, (n,), generator=g)) for n in (8, 513)] + [dev(torch.randint(0, 2, (33,), generator=g)).to(torch.uint8)]
+    srcs.append(dev(torch.randn(1001, generator=g))[1:])                      # 4-byte aligned only: the byte path
+    dsts = [torch.full_like(s, 3) for s in srcs]
+    kk.copy_many(list(zip(dsts, srcs)))
+    torch.cuda.synchronize()
+    for d, s in zip(dsts, srcs):
+        assert torch.equal(d, s)
+    with pytest.raises(RuntimeError):
+        kk.call("kk_copy_many", None, None, None, 0)
