@@ -60,6 +60,14 @@ typedef struct {
 } KkWgradDesc;
 int kk_gemm_wgrad_group(const KkWgradDesc *descs, int n, void *stream);
 int kk_gemm_tune_group(int split); /* tools: force the k-slice count of grouped launches (0 = automatic) */
+/* Attention projections with the per-head norm as the epilogue: raw[T, parts*heads*64] = x[T,K] . W^T (+bias), saved for
+ * the backward, and y = per-head RMSNorm(64)(raw) * gains[part] (+ RoPE on the parts set in rope_mask, position = row % S)
+ * from one launch — a 64x64 output tile is exactly 64 (row, head) vectors.  parts <= 12 column groups of heads*64 (q|k|v of
+ * a fused projection, or k|v of every decoder layer's cross-attention), `gains` a HOST array of `parts` device pointers.
+ * bf16 operands and outputs; same bits as kk_gemm + kk_headnorm_rope_fwd (transformers.py:246-277). */
+int kk_gemm_qkv_headnorm(int64_t T, int parts, int heads, int64_t K, const void *x, int64_t ldx, const void *W,
+                         const float *bias, void *raw, int64_t ldraw, void *y, int64_t ldy, int S,
+                         const float *const *gains, int rope_mask, const float *cos_t, const float *sin_t, void *stream);
 /* GLU feed-forward forward, fused: h1[T,2F] = x[T,K] . W[2F,K]^T + bias (saved for the backward, bf16) and the gated
  * product g[T,F] = gelu(h1[:, :F]) * h1[:, F:] * dropout mask (seed, site, p as in kk_glu_fwd) from one launch: every
  * workgroup owns a column block of BOTH halves.  bf16 operands and outputs.  Replaces kk_gemm + kk_glu_fwd. */

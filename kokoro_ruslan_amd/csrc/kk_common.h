@@ -31,6 +31,9 @@ int kk_gemm16_launch(int ta, int tb, int64_t M, int64_t N, int64_t K, float alph
 void kk_gemm16_tune(int thr128, int thr12864, int split_target);
 int kk_gemm16_wgrad_group(const KkWgradDesc *d, int n, int xcd_swizzle, hipStream_t s);
 void kk_gemm16_tune_group(int split);
+int kk_gemm16_qkv_headnorm(int64_t T, int parts, int heads, int64_t K, const void *x, int64_t ldx, const void *W, const float *bias,
+                           void *raw, int64_t ldraw, void *y, int64_t ldy, int S, const float *const *gains, int rope_mask,
+                           const float *cos_t, const float *sin_t, int xcd_swizzle, hipStream_t s);
 int kk_gemm16_linear_glu(int64_t T, int64_t F, int64_t K, const void *x, int64_t ldx, const void *W, const float *bias, void *h1,
                          void *g, int64_t ldg, const uint32_t *seed, uint32_t site, float p, int xcd_swizzle, hipStream_t s);
 // dX = dY.W fused with the GLU gate's backward (see kk_gemm16.hip)
@@ -135,6 +138,29 @@ __device__ __forceinline__ void kk_drop_mul4(uint32_t seed, uint32_t site, uint6
     m[1] = (h0 >> 16) < t ? 0.f : inv_keep;
     m[2] = (h1 & 0xFFFFu) < t ? 0.f : inv_keep;
     m[3] = (h1 >> 16) < t ? 0.f : inv_keep;
+}
+
+// per-head RMSNorm(64) (+ RoPE) of one (row, head) vector held by 16 lanes, one float4 each (sub = lane & 15): shared by
+// headnorm_rope_fwd_kernel and the q|k|v GEMM's epilogue so that the two give the same bits.
+// rotate_half(n)[d] = -n[d+32] (d<32), n[d-32] (d>=32)   (positional_encoding.py:152-157)
+__device__ __forceinline__ float kk_sum16(float v) {
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    return v;
+}
+__device__ __forceinline__ float4 kk_shfl8(const float4 &v) {
+    return make_float4(__shfl_xor(v.x, 8, 64), __shfl_xor(v.y, 8, 64), __shfl_xor(v.z, 8, 64), __shfl_xor(v.w, 8, 64));
+}
+__device__ __forceinline__ float4 kk_headnorm_rope(const float4 &v, const float4 &g, bool rope, const float *cos_row,
+                                                   const float *sin_row, int sub) {
+    const float rs = 1.f / sqrtf(kk_sum16(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w) * (1.f / 64.f) + 1.1920928955078125e-7f);
+    float4 n = make_float4(v.x * rs * g.x, v.y * rs * g.y, v.z * rs * g.z, v.w * rs * g.w);
+    if (rope) {
+        const float4 o = kk_shfl8(n), c = ld4(cos_row + sub * 4), sn = ld4(sin_row + sub * 4);
+        const float sg = sub < 8 ? -1.f : 1.f;
+        n = make_float4(n.x * c.x + sg * o.x * sn.x, n.y * c.y + sg * o.y * sn.y, n.z * c.z + sg * o.z * sn.z,
+                        n.w * c.w + sg * o.w * sn.w);
+    }
+    return n;
 }
 
 // exact-erf GELU (nn.GELU(), transformers.py:51) and its derivative

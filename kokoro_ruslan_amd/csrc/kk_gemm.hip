@@ -461,3 +461,19 @@ extern "C" int kk_gemm_wgrad_group(const KkWgradDesc *descs, int n, void *stream
     return kk_gemm16_wgrad_group(descs, n, g_xcd_swizzle, (hipStream_t)stream);
 }
 extern "C" int kk_gemm_tune_group(int split) { kk_gemm16_tune_group(split); return 0; }
+
+// q / k / v projection with the per-head RMSNorm (+ RoPE) as the epilogue (bf16 operands; see gemm16_kernel, EPI = 3).
+extern "C" int kk_gemm_qkv_headnorm(int64_t T, int parts, int heads, int64_t K, const void *x, int64_t ldx, const void *W,
+                                    const float *bias, void *raw, int64_t ldraw, void *y, int64_t ldy, int S,
+                                    const float *const *gains, int rope_mask, const float *cos_t, const float *sin_t, void *stream) {
+    KK_REQUIRE(T > 0 && parts >= 1 && parts <= 12 && heads > 0 && K > 0 && S > 0 && x && W && raw && y && gains,
+               "kk_gemm_qkv_headnorm: bad args (1..12 parts)");
+    for (int i = 0; i < parts; ++i) KK_REQUIRE(gains[i] != nullptr, "kk_gemm_qkv_headnorm: null gain vector");
+    KK_REQUIRE(rope_mask == 0 || (cos_t && sin_t), "kk_gemm_qkv_headnorm: RoPE needs cos/sin tables");
+    KK_REQUIRE(ldraw % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)raw & 7) == 0 && ((uintptr_t)y & 7) == 0,
+               "kk_gemm_qkv_headnorm: outputs must be 8-byte aligned with row strides %% 4 == 0");
+    KK_REQUIRE(kk_gemm16_eligible(0, 0, T, (int64_t)parts * heads * 64, K, x, ldx, W, K),
+               "kk_gemm_qkv_headnorm: needs 16-byte aligned bf16 operands and K %% 64 == 0");
+    return kk_gemm16_qkv_headnorm(T, parts, heads, K, x, ldx, W, bias, raw, ldraw, y, ldy, S, gains, rope_mask, cos_t, sin_t,
+                                  g_xcd_swizzle, (hipStream_t)stream);
+}

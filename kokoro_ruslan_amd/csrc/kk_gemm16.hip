@@ -42,6 +42,12 @@ struct G16Args {
     const uint32_t *glu_seed;
     uint32_t glu_site;
     float glu_p;
+    // EPI == 3 (per-head RMSNorm + RoPE epilogue): C receives the raw projection, hn_y the normalised one
+    const float *hn_gain[12];                                   // one gain vector per part (a part = hn_H columns: q | k | v | ...)
+    const float *hn_cos, *hn_sin;
+    __bf16 *hn_y;
+    int64_t hn_ldy;
+    int hn_S, hn_H, hn_rope_mask;
 };
 
 constexpr int BK = 64;
@@ -147,6 +153,9 @@ __device__ __forceinline__ void pin_frag(Frag &f, bool ks) {
 //   dh1[:, c] = dG*m * b * gelu'(a),   dh1[:, F + c] = dG*m * gelu(a)
 // are written directly (dG never exists in HBM), and the column sums of dh1 — linear1's bias gradient — leave the
 // workgroup as plain rows partials[2*tile_m + wave_row][2F] for kk_partials_reduce.  Replaces kk_glu_bwd + kk_colsum_acc.
+// EPI = 3: the GEMM is a q / k / v projection whose heads are 64 wide, so a 64x64 tile holds whole (row, head) vectors:
+// the epilogue writes the projection (saved for the backward) AND its per-head RMSNorm (+ RoPE) — the attention's
+// operands — through an LDS transpose of the tile.  Replaces kk_headnorm_rope_fwd (same math, same bits).
 // EPI = 2: the GEMM is h1 = x.W1^T + b1 of a GLU feed-forward; a workgroup owns output columns [n0, n0+64) AND
 // [F+n0, F+n0+64) (two B panels, two accumulators, the A tile is read from LDS once for both), so its epilogue writes
 // h1 = [a | b] (saved for the backward) and the gated product g = gelu(a)*b*mask in one go.  Replaces kk_glu_fwd.
@@ -299,6 +308,36 @@ __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char
         }
         return;
     }
+    if constexpr (EPI == 3) {
+        static_assert(EPI != 3 || (BM == 64 && BN == 64), "the head-norm epilogue is written for the 64x64 tile");
+        constexpr int PITCH = 72;                               // bf16 per LDS row: 144 B, rows land on different banks
+        __bf16 *tile = reinterpret_cast<__bf16 *>(smem);
+        __builtin_amdgcn_s_barrier();                           // every wave is done with the last stage
+        {
+            const int col = wc * 32 + l31;
+            const float bv = a.bias ? a.bias[n0 + col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tile[(wr * 32 + frag_row(r, half)) * PITCH + col] = (__bf16)(acc[0][0][r] + bv);
+        }
+        __syncthreads();
+        const int sub = threadIdx.x & 15, part = n0 / a.hn_H;
+        const bool rope = (a.hn_rope_mask >> part) & 1;
+        const float4 g = ld4(a.hn_gain[part] + sub * 4);
+        __bf16 *raw = static_cast<__bf16 *>(a.C);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int rl = it * 16 + (threadIdx.x >> 4), row = m0 + rl;
+            const bf16x4 r4 = *reinterpret_cast<const bf16x4 *>(tile + rl * PITCH + sub * 4);
+            const float4 v = make_float4((float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]);
+            const int pos = rope ? (row < a.M ? row : a.M - 1) % a.hn_S : 0;
+            const float4 n = kk_headnorm_rope(v, g, rope, a.hn_cos + pos * 64, a.hn_sin + pos * 64, sub);
+            if (row < a.M) {
+                *reinterpret_cast<bf16x4 *>(raw + (int64_t)row * a.ldc + n0 + sub * 4) = r4;
+                stv4<__bf16>(a.hn_y + (int64_t)row * a.hn_ldy + n0 + sub * 4, n);
+            }
+        }
+        return;
+    }
     if constexpr (EPI == 2) {
         const int F = a.N;
         const uint32_t thr = a.glu_seed ? kk_drop_threshold(a.glu_p) : 0u, seed = thr ? *a.glu_seed : 0u;
@@ -407,6 +446,8 @@ template __global__ void gemm16_kernel<true, false, 64, 64, 4>(G16Args);
 template __global__ void gemm16_kernel<true, true, 64, 64, 4>(G16Args);
 
 template __global__ void gemm16_kernel<false, false, 64, 64, 2, 2>(G16Args);
+template __global__ void gemm16_kernel<false, false, 64, 64, 2, 3>(G16Args);
+template __global__ void gemm16_kernel<false, false, 64, 64, 3, 3>(G16Args);
 template __global__ void gemm16_kernel<false, true, 64, 64, 2, 1>(G16Args);
 template __global__ void gemm16_kernel<false, true, 64, 64, 3, 1>(G16Args);
 
@@ -582,5 +623,27 @@ int kk_gemm16_wgrad_group(const KkWgradDesc *d, int n, int xcd_swizzle, hipStrea
     else if (min_per < 3 || g16_stages < 3) hipLaunchKernelGGL((gemm16_group_kernel<true, true, 64, 64, 2>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((gemm16_group_kernel<true, true, 64, 64, 3>), grid, dim3(256), 0, s, g);
     KK_LAUNCH_CHECK("kk_gemm_wgrad_group");
+    return 0;
+}
+
+int kk_gemm16_qkv_headnorm(int64_t T, int parts, int heads, int64_t K, const void *x, int64_t ldx, const void *W, const float *bias,
+                           void *raw, int64_t ldraw, void *y, int64_t ldy, int S, const float *const *gains, int rope_mask,
+                           const float *cos_t, const float *sin_t, int xcd_swizzle, hipStream_t s) {
+    auto cd = [](int64_t a_, int64_t b_) { return (int)((a_ + b_ - 1) / b_); };
+    const int64_t N = (int64_t)parts * heads * 64;
+    G16Args a = {};
+    a.M = (int)T; a.N = (int)N; a.K = (int)K;
+    a.alpha = 1.f; a.A = x; a.B = W; a.lda = ldx; a.ldb = K; a.bias = bias; a.C = raw; a.ldc = ldraw; a.c_bf16 = 1;
+    a.k_per_split = cd(K, BK) * BK; a.splits = 1;
+    a.tiles_m = cd(T, 64); a.tiles_n = cd(N, 64); a.xcd_swizzle = xcd_swizzle;
+    a.a_bytes = (uint32_t)(((T - 1) * ldx + K) * 2);
+    a.b_bytes = (uint32_t)(((N - 1) * K + K) * 2);
+    for (int i = 0; i < parts; ++i) a.hn_gain[i] = gains[i];
+    a.hn_cos = cos_t; a.hn_sin = sin_t; a.hn_y = static_cast<__bf16 *>(y); a.hn_ldy = ldy;
+    a.hn_S = S; a.hn_H = heads * 64; a.hn_rope_mask = rope_mask;
+    dim3 grid(a.tiles_m * a.tiles_n);
+    if (cd(K, BK) < 3) hipLaunchKernelGGL((gemm16_kernel<false, false, 64, 64, 2, 3>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gemm16_kernel<false, false, 64, 64, 3, 3>), grid, dim3(256), 0, s, a);
+    KK_LAUNCH_CHECK("kk_gemm_qkv_headnorm");
     return 0;
 }

@@ -320,16 +320,8 @@ __global__ __launch_bounds__(256) void headnorm_rope_fwd_kernel(HeadNormArgs a) 
         const int64_t row = pr / a.heads;
         const int col = part * H + (int)(pr - row * a.heads) * 64 + sub * 4;
         const float4 v = ldv4<T>(x + row * a.ldx + col);
-        const float rs = 1.f / sqrtf(sum16(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w) * (1.f / 64.f) + FLT_EPSILON);
-        float4 n = make_float4(v.x * rs * g.x, v.y * rs * g.y, v.z * rs * g.z, v.w * rs * g.w);
-        if (rope) {
-            const int pos = (int)(row % a.S);
-            const float4 o = shfl8(n), c = ld4(a.cos_t + pos * 64 + sub * 4), sn = ld4(a.sin_t + pos * 64 + sub * 4);
-            const float sg = sub < 8 ? -1.f : 1.f;
-            n = make_float4(n.x * c.x + sg * o.x * sn.x, n.y * c.y + sg * o.y * sn.y, n.z * c.z + sg * o.z * sn.z,
-                            n.w * c.w + sg * o.w * sn.w);
-        }
-        stv4<T>(y + row * a.ldy + col, n);
+        const int pos = rope ? (int)(row % a.S) : 0;
+        stv4<T>(y + row * a.ldy + col, kk_headnorm_rope(v, g, rope, a.cos_t + pos * 64, a.sin_t + pos * 64, sub));
     }
 }
 

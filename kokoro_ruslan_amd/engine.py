@@ -176,6 +176,8 @@ class KokoroEngine:
         self.dec_head_aside = True
         self.fuse_glu_fwd = os.environ.get("KK_FUSE_GLU_FWD", "1") != "0"
         self.group_wgrads = os.environ.get("KK_GROUP_WGRADS", "1") != "0"     # A/B switches for tools/ and bench sweeps
+        self.fuse_headnorm = os.environ.get("KK_FUSE_HEADNORM", "1") != "0"
+        self._ptr_tables = {}
         self._wgrad_queue, self._wgrad_tables = {}, {}
         if os.environ.get("KK_GROUP_SPLIT"):
             kk.load().kk_gemm_tune_group(int(os.environ["KK_GROUP_SPLIT"]))
@@ -456,20 +458,16 @@ class KokoroEngine:
         dt = xq.dtype                                   # storage of every activation of the sub-layer
         i16 = _b16(xq)
         cos, sin = self._rope_tables(max(Sq, Sk)) if rope else (None, None)
-        if xkv is None:
+        gq, gk, gv = P[prefix + ".q_norm.weight"], P[prefix + ".k_norm.weight"], P[prefix + ".v_norm.weight"]
+        if xkv is None:       # q|k|v from one fused projection; RoPE on q and k only
             raw, nrm = self._buf(key + ".qkv_raw", Nq, 3 * H, dtype=dt), self._buf(key + ".qkv_n", Nq, 3 * H, dtype=dt)
-            self._linear(xq, self._Wf(prefix + ".w_q.weight", 3), None, raw)
+            self._proj_headnorm(xq, self._Wf(prefix + ".w_q.weight", 3), raw, nrm, Sq, (gq, gk, gv), 3 if rope else 0, cos, sin)
             q_raw, k_raw, v_raw, q_n, k_n, v_n = raw, raw[:, H:], raw[:, 2 * H:], nrm, nrm[:, H:], nrm[:, 2 * H:]
         else:
             q_raw, q_n = self._buf(key + ".q_raw", Nq, H, dtype=dt), self._buf(key + ".q_n", Nq, H, dtype=dt)
             kv_raw, kv_n = self._cross_kv(layer, Nk, dt)                              # filled by _cross_kv_fwd_all
-            self._linear(xq, self._W(prefix + ".w_q.weight"), None, q_raw)
+            self._proj_headnorm(xq, self._W(prefix + ".w_q.weight"), q_raw, q_n, Sq, (gq,), 0, None, None)
             k_raw, v_raw, k_n, v_n = kv_raw, kv_raw[:, H:], kv_n, kv_n[:, H:]
-        gq, gk, gv = P[prefix + ".q_norm.weight"], P[prefix + ".k_norm.weight"], P[prefix + ".v_norm.weight"]
-        if xkv is None:       # q|k|v in one launch over the fused projection; RoPE on q and k only
-            kk.call("kk_headnorm_rope_fwd", raw, 3 * H, nrm, 3 * H, Nq, h, Sq, 3, gq, gk, gv, 3 if rope else 0, cos, sin, i16)
-        else:
-            kk.call("kk_headnorm_rope_fwd", q_raw, H, q_n, H, Nq, h, Sq, 1, gq, None, None, 0, None, None, i16)
         ctx, lse = self._buf(key + ".ctx", Nq, H, dtype=dt), self._buf(key + ".lse", B, h, Sq)
         kk.call("kk_attn_fwd", q_n, k_n, v_n, ctx, lse, B, h, Sq, Sk, q_n.stride(0), k_n.stride(0), v_n.stride(0), H, key_mask,
                 1 if causal else 0, 0.125, self.rng, site + 3, p, self.math, i16)
@@ -485,18 +483,35 @@ class KokoroEngine:
         nrm = self._buf(f"dec.ca.{which}kv_n_all", Nk, 2 * H * L, dtype=dt)
         return raw[:, 2 * H * layer:2 * H * (layer + 1)], nrm[:, 2 * H * layer:2 * H * (layer + 1)]
 
+    def _proj_headnorm(self, x, W, raw, nrm, S, gains, rope_mask, cos, sin):
+        """raw = x.W^T (an attention projection of len(gains) parts x heads x 64 columns, no bias: transformers.py:131-136)
+        and nrm = its per-head RMSNorm (+ RoPE): in bf16 mode one GEMM whose epilogue normalises, else GEMM + norm launches."""
+        H, h = self.dims.hidden, self.dims.heads
+        rows, parts = x.shape[0], len(gains)
+        if self.fuse_headnorm and _b16(x) and _b16(W) and _b16(raw) and parts <= 12 and x.shape[1] % 64 == 0:
+            key = tuple(g.data_ptr() for g in gains)
+            table = self._ptr_tables.get(key)
+            if table is None:
+                table = self._ptr_tables[key] = kk.pointer_table(gains)
+            kk.call("kk_gemm_qkv_headnorm", rows, parts, h, x.shape[1], x, x.stride(0), W, None, raw, raw.stride(0), nrm,
+                    nrm.stride(0), S, table, rope_mask, cos, sin)
+            return
+        self._linear(x, W, None, raw)
+        for p0 in range(0, parts, 3):                      # the norm kernel takes up to three parts per launch
+            g = list(gains[p0:p0 + 3]) + [None] * 3
+            n = min(3, parts - p0)
+            kk.call("kk_headnorm_rope_fwd", raw[:, p0 * H:], raw.stride(0), nrm[:, p0 * H:], nrm.stride(0), rows, h, S, n,
+                    g[0], g[1], g[2], (rope_mask >> p0) & 7, cos, sin, _b16(raw))
+
     def _cross_kv_fwd_all(self, xkv, Nk, Sk, dt):
         """K/V projections of ALL decoder cross-attention layers in one GEMM (they depend on the memory alone and their
         weights are contiguous in the arena), then the per-head RMSNorm of each layer's slice (no RoPE:
         transformers.py:268-277 applies it to self-attention only)."""
         P, H, h, L = self.arena.P, self.dims.hidden, self.dims.heads, self.dims.dec_layers
         raw_all = self._buf("dec.ca.kv_raw_all", Nk, 2 * H * L, dtype=dt)
-        self._linear(xkv, self._Wf("decoder.layers.0.cross_attn.w_k.weight", 2 * L), None, raw_all)
-        for l in range(L):
-            raw, nrm = self._cross_kv(l, Nk, dt)
-            pf = f"decoder.layers.{l}.cross_attn"
-            kk.call("kk_headnorm_rope_fwd", raw, 2 * H * L, nrm, 2 * H * L, Nk, h, Sk, 2, P[pf + ".k_norm.weight"],
-                    P[pf + ".v_norm.weight"], None, 0, None, None, _b16(raw))
+        nrm_all = self._buf("dec.ca.kv_n_all", Nk, 2 * H * L, dtype=dt)
+        gains = [P[f"decoder.layers.{l}.cross_attn.{kv}_norm.weight"] for l in range(L) for kv in ("k", "v")]
+        self._proj_headnorm(xkv, self._Wf("decoder.layers.0.cross_attn.w_k.weight", 2 * L), raw_all, nrm_all, Sk, gains, 0, None, None)
 
     def _cross_kv_bwd_all(self, xkv, Nk, dt, d_xkv):
         """Weight gradient of all layers' K/V projections and the memory gradient: two GEMMs over the all-layer buffer."""

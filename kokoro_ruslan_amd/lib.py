@@ -61,6 +61,11 @@ def wgrad_table(entries):
     return arr
 
 
+def pointer_table(tensors):
+    """Host array of device pointers (for the C entry points that take `const float *const *`)."""
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
 def copy_many(pairs) -> None:
     """dst.copy_(src) for up to 16 (dst, src) pairs of contiguous same-size device tensors per launch."""
     for i in range(0, len(pairs), 16):
@@ -83,6 +88,7 @@ def reduce_table(entries, device) -> "torch.Tensor":
 
 SIGNATURES: Dict[str, List[Any]] = {
     "kk_gemm": [_I, _I, _L, _L, _L, _F, _P, _L, _P, _L, _F, _P, _L, _P, _P, _L, _L, _I, _I, _I, _P],
+    "kk_gemm_qkv_headnorm": [_L, _I, _I, _L, _P, _L, _P, _P, _P, _L, _P, _L, _I, _P, _I, _P, _P, _P],
     "kk_gemm_linear_glu": [_L, _L, _L, _P, _L, _P, _P, _P, _P, _L, _P, _U, _F, _P],
     "kk_gemm_dgrad_glu": [_L, _L, _L, _P, _L, _P, _P, _P, _P, _P, _U, _F, _P],
     "kk_gemm_dgrad_glu_blocks": [_L],

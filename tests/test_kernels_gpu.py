@@ -1086,3 +1086,34 @@ def test_copy_many(kk):
         assert torch.equal(d, s)
     with pytest.raises(RuntimeError):
         kk.call("kk_copy_many", None, None, None, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,parts,heads,K,S,rope", [(64, 1, 1, 64, 64, 0), (333, 3, 2, 128, 111, 3), (4096, 3, 8, 512, 512, 3),
+                                                    (1000, 12, 8, 512, 125, 0), (70, 2, 3, 192, 35, 1)])
+def test_gemm_qkv_headnorm_epilogue(kk, T, parts, heads, K, S, rope):
+    """kk_gemm_qkv_headnorm == kk_gemm (bf16 out) -> kk_headnorm_rope_fwd per group of three parts: same raw bits, same
+    normalised bits; and the normalised rows have unit RMS before the gain."""
+    g = torch.Generator().manual_seed(T + parts)
+    bf = torch.bfloat16
+    H = heads * 64
+    N = parts * H
+    x = dev(torch.randn(T, K, generator=g)).to(bf)
+    W = dev(torch.randn(N, K, generator=g) * 0.1).to(bf)
+    gains = [dev(1.0 + 0.2 * torch.randn(64, generator=g)) for _ in range(parts)]
+    c, s = (dev(t) for t in O.rope_tables(S, 64))
+    raw_a = torch.empty(T, N, device="cuda", dtype=bf)
+    kk.call("kk_gemm", 0, 0, T, N, K, 1.0, x, K, W, K, 0.0, raw_a, N, None, None, 0, 0, 1, 1, 7)
+    y_a = torch.empty_like(raw_a)
+    for p0 in range(0, parts, 3):
+        gg = gains[p0:p0 + 3] + [None] * 3
+        kk.call("kk_headnorm_rope_fwd", raw_a[:, p0 * H:], N, y_a[:, p0 * H:], N, T, heads, S, min(3, parts - p0), gg[0], gg[1], gg[2],
+                (rope >> p0) & 7, c, s, 1)
+    raw_b, y_b = torch.full_like(raw_a, 7.0), torch.full_like(raw_a, 7.0)
+    kk.call("kk_gemm_qkv_headnorm", T, parts, heads, K, x, K, W, None, raw_b, N, y_b, N, S, kk.pointer_table(gains), rope, c, s)
+    torch.cuda.synchronize()
+    assert torch.equal(raw_b, raw_a), "projection saved for the backward"
+    assert torch.equal(y_b, y_a), "normalised (+ rotated) heads"
+    v = y_b[:, (parts - 1) * H:(parts - 1) * H + 64].float() / gains[parts - 1]
+    if not (rope >> (parts - 1)) & 1:
+        close(v.pow(2).mean(-1), torch.ones(T, device="cuda"), 2e-2, 0, "unit RMS per head")
