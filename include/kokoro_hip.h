@@ -103,18 +103,31 @@ int kk_attn_fwd(const float *Q, const float *K, const float *V, float *O, float 
 /* Delta[b,head,q] = sum_d dO·O (first step of the backward). */
 int kk_attn_delta(const float *O, const float *dO, float *Delta, int B, int heads, int Sq, int64_t ldo,
                   int64_t lddo, int io_bf16, void *stream);
+/* Optional epilogue of the two backward kernels (hn != NULL): the attention operand was y = RMSNorm64(raw)*gain (+ RoPE,
+ * position = row within the sequence), and the kernel writes the gradient of RAW (into dQ, or dK / dV) instead of the
+ * gradient of y, plus one row of 64 partial gain-gradient sums per workgroup into partials[kk_attn_bwd_blocks()][64]
+ * (to be added up by kk_partials_reduce).  Replaces kk_headnorm_rope_bwd.  kk_attn_bwd_dq takes one descriptor (Q),
+ * kk_attn_bwd_dkv an array of two (K, V). */
+typedef struct {
+    const void *raw; int64_t ldraw;     /* the projection output the norm was applied to, [rows, >= heads*64] */
+    const float *gain;                  /* [64] */
+    float *partials;                    /* [kk_attn_bwd_blocks(B, heads, S)][64] */
+    const float *cos_t, *sin_t;         /* [S, 64] RoPE tables (rope != 0) */
+    int rope;
+} KkAttnHeadNorm;
+int kk_attn_bwd_blocks(int B, int heads, int S);   /* S = Sq for kk_attn_bwd_dq, Sk for kk_attn_bwd_dkv */
 /* O == NULL: Delta is read.  O != NULL: Delta is computed here from dO and O (row stride ldo) and WRITTEN, so the
  * separate kk_attn_delta launch is not needed; kk_attn_bwd_dkv (launched after) reads it. */
 int kk_attn_bwd_dq(const float *Q, const float *K, const float *V, const float *dO, const float *LSE,
                    float *Delta, float *dQ, int B, int heads, int Sq, int Sk, int64_t ldq, int64_t ldk,
                    int64_t ldv, int64_t lddo, int64_t lddq, const uint8_t *key_mask, int causal, float scale,
                    const uint32_t *seed, uint32_t site, float p_drop, int math, int io_bf16, const float *O,
-                   int64_t ldo, void *stream);
+                   int64_t ldo, const KkAttnHeadNorm *hn, void *stream);
 int kk_attn_bwd_dkv(const float *Q, const float *K, const float *V, const float *dO, const float *LSE,
                     const float *Delta, float *dK, float *dV, int B, int heads, int Sq, int Sk, int64_t ldq,
                     int64_t ldk, int64_t ldv, int64_t lddo, int64_t lddk, int64_t lddv,
                     const uint8_t *key_mask, int causal, float scale, const uint32_t *seed, uint32_t site,
-                    float p_drop, int math, int io_bf16, void *stream);
+                    float p_drop, int math, int io_bf16, const KkAttnHeadNorm *hn, void *stream);
 
 /* ---- norms ----
  * LayerNorm (nn.LayerNorm eps 1e-5; transformers.py:461-462,518-520,612; model.py:122). */

@@ -41,6 +41,9 @@ struct AttnArgs {
     const uint32_t *seed;
     uint32_t site;
     float p_drop;
+    // backward kernels: the gradient of the per-head RMSNorm (+ RoPE) that produced Q (dQ kernel) / K and V (dK/dV
+    // kernel: hn[0], hn[1]) as the epilogue — Out / Out2 then receive the gradient of the RAW projection
+    KkAttnHeadNorm hn[2];
 };
 
 // Dropout on the probabilities.  The keep decision of element (b, head, q, key) is a 16-bit field of a 32-bit hash of
@@ -312,6 +315,85 @@ __device__ __forceinline__ void store_row(T *dst_row, const f32x16 (&acc)[2], fl
         for (int g = 0; g < 4; ++g)
             stv4<T>(dst_row + db * 32 + 8 * g + 4 * half,
                 make_float4(acc[db][4 * g] * mul, acc[db][4 * g + 1] * mul, acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul));
+}
+
+// Epilogue of the backward kernels: gradient of y = RMSNorm64(x)*gain (+ RoPE) for the (row, head) vector this lane
+// pair holds (same math as headnorm_rope_bwd_kernel, kk_norm.hip; acc*mul is first rounded to the storage type, as
+// the unfused path's store does).  A lane has d = db*32 + 8g + 4*half + e, so rotate_half's partner d^32 is its own
+// acc[db^1] element and the two row reductions are a local sum plus one xor-32 shuffle.  The gain gradient needs
+// column sums over the workgroup's 128 rows: every lane drops dn*x*rstd into colred[row][65] and hn_colsum() adds
+// the columns after a barrier.  Returns nothing; `valid` lanes store dx.
+template <typename T>
+__device__ __forceinline__ void hn_bwd_row(const f32x16 (&acc)[2], float mul, bool valid, const T *raw_row, T *out_row,
+                                           const KkAttnHeadNorm &h, int pos, int half, float *colred_row) {
+    float dn[32], v[32];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 x4 = valid ? ldv4<T>(raw_row + db * 32 + 8 * g + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[db * 16 + 4 * g] = x4.x; v[db * 16 + 4 * g + 1] = x4.y; v[db * 16 + 4 * g + 2] = x4.z; v[db * 16 + 4 * g + 3] = x4.w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dn[db * 16 + 4 * g + e] = valid ? (float)(T)(acc[db][4 * g + e] * mul) : 0.f;
+        }
+    float ssq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) ssq += v[i] * v[i];
+    ssq += __shfl_xor(ssq, 32, 64);
+    const float rs = 1.f / sqrtf(ssq * (1.f / 64.f) + 1.1920928955078125e-7f);
+    if (h.rope) {     // dn[d] = dy[d] cos[d] + (d < 32 ? dy[d+32] sin[d+32] : -dy[d-32] sin[d-32])
+        const int64_t pr = valid ? pos : 0;                      // (rows past the end of the sequence have no table row)
+        const float *cr = h.cos_t + pr * 64, *sr = h.sin_t + pr * 64;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = 8 * g + 4 * half;
+            const float4 c0 = ld4(cr + d), c1 = ld4(cr + 32 + d), s0 = ld4(sr + d), s1 = ld4(sr + 32 + d);
+            const float cl[4] = {c0.x, c0.y, c0.z, c0.w}, ch[4] = {c1.x, c1.y, c1.z, c1.w};
+            const float sl[4] = {s0.x, s0.y, s0.z, s0.w}, sh[4] = {s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float lo = dn[4 * g + e], hi = dn[16 + 4 * g + e];
+                dn[4 * g + e] = lo * cl[e] + hi * sh[e];
+                dn[16 + 4 * g + e] = hi * ch[e] - lo * sl[e];
+            }
+        }
+    }
+    float kdot = 0.f;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 g4 = ld4(h.gain + db * 32 + 8 * g + 4 * half);
+            const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = db * 16 + 4 * g + e;
+                colred_row[db * 32 + 8 * g + 4 * half + e] = dn[i] * v[i] * rs;
+                dn[i] *= gg[e];                                  // dg
+                kdot += dn[i] * v[i];
+            }
+        }
+    kdot += __shfl_xor(kdot, 32, 64);
+    const float k = kdot * (1.f / 64.f) * rs * rs * rs;
+    if (valid) {
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int i = db * 16 + 4 * g;
+                stv4<T>(out_row + db * 32 + 8 * g + 4 * half,
+                        make_float4(rs * dn[i] - v[i] * k, rs * dn[i + 1] - v[i + 1] * k, rs * dn[i + 2] - v[i + 2] * k, rs * dn[i + 3] - v[i + 3] * k));
+            }
+    }
+}
+// column sums of colred[128][65] -> partials[workgroup][64] (threads 0..63 of the workgroup; call between barriers)
+__device__ __forceinline__ void hn_colsum(const float *colred, float *partials) {
+    if (threadIdx.x < 64) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < 128; r += 2) { s0 += colred[r * 65 + threadIdx.x]; s1 += colred[(r + 1) * 65 + threadIdx.x]; }
+        partials[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 64 + threadIdx.x] = s0 + s1;
+    }
 }
 
 // ------------------------------------------------------------------ forward
@@ -609,11 +691,23 @@ __global__ __launch_bounds__(256 * G) void attn_bwd_dq_kernel(AttnArgs a) {
             for (int r = 0; r < 16; ++r) { mb[r] = dq[0][r]; mb[16 + r] = dq[1][r]; }
         }
         __syncthreads();
-        if (grp == 1) return;
+        if (grp == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { dq[0][r] += mb[r]; dq[1][r] += mb[16 + r]; }
+            for (int r = 0; r < 16; ++r) { dq[0][r] += mb[r]; dq[1][r] += mb[16 + r]; }
+        }
     }
-    if (qvalid) store_row<T>(static_cast<T *>(a.Out) + ((int64_t)b * a.Sq + q) * a.ldout + hh * 64, dq, a.scale, half);
+    T *out_row = static_cast<T *>(a.Out) + ((int64_t)b * a.Sq + q) * a.ldout + hh * 64;
+    if (a.hn[0].raw == nullptr) {
+        if (qvalid && grp == 0) store_row<T>(out_row, dq, a.scale, half);
+        return;
+    }
+    float *colred = reinterpret_cast<float *>(smem_raw);          // [128 rows][65]
+    __syncthreads();                                              // the staging tiles / merge buffer are free
+    if (grp == 0)
+        hn_bwd_row<T>(dq, a.scale, qvalid, static_cast<const T *>(a.hn[0].raw) + ((int64_t)b * a.Sq + q) * a.hn[0].ldraw + hh * 64,
+                      out_row, a.hn[0], q, half, colred + (wave * 32 + l31) * 65);
+    __syncthreads();
+    hn_colsum(colred, a.hn[0].partials);
 }
 
 // ------------------------------------------------------------------ backward: dK, dV
@@ -761,14 +855,34 @@ __global__ __launch_bounds__(256 * G) void attn_bwd_dkv_kernel(AttnArgs a) {
             for (int r = 0; r < 16; ++r) { mb[r] = dk[0][r]; mb[16 + r] = dk[1][r]; mb[32 + r] = dv[0][r]; mb[48 + r] = dv[1][r]; }
         }
         __syncthreads();
-        if (grp == 1) return;
+        if (grp == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { dk[0][r] += mb[r]; dk[1][r] += mb[16 + r]; dv[0][r] += mb[32 + r]; dv[1][r] += mb[48 + r]; }
+            for (int r = 0; r < 16; ++r) { dk[0][r] += mb[r]; dk[1][r] += mb[16 + r]; dv[0][r] += mb[32 + r]; dv[1][r] += mb[48 + r]; }
+        }
     }
-    if (kvalid) {
-        store_row<T>(static_cast<T *>(a.Out) + ((int64_t)b * a.Sk + key) * a.ldout + hh * 64, dk, a.scale, half);
-        store_row<T>(static_cast<T *>(a.Out2) + ((int64_t)b * a.Sk + key) * a.ldout2 + hh * 64, dv, pd.inv_keep, half);
+    T *dk_row = static_cast<T *>(a.Out) + ((int64_t)b * a.Sk + key) * a.ldout + hh * 64;
+    T *dv_row = static_cast<T *>(a.Out2) + ((int64_t)b * a.Sk + key) * a.ldout2 + hh * 64;
+    if (a.hn[0].raw == nullptr) {
+        if (kvalid && grp == 0) {
+            store_row<T>(dk_row, dk, a.scale, half);
+            store_row<T>(dv_row, dv, pd.inv_keep, half);
+        }
+        return;
     }
+    float *colred = reinterpret_cast<float *>(smem_raw);          // [128 rows][65]
+    const int64_t rrow = (int64_t)b * a.Sk + key;
+    __syncthreads();
+    if (grp == 0)
+        hn_bwd_row<T>(dk, a.scale, kvalid, static_cast<const T *>(a.hn[0].raw) + rrow * a.hn[0].ldraw + hh * 64, dk_row, a.hn[0], key,
+                      half, colred + (wave * 32 + l31) * 65);
+    __syncthreads();
+    hn_colsum(colred, a.hn[0].partials);
+    __syncthreads();
+    if (grp == 0)
+        hn_bwd_row<T>(dv, pd.inv_keep, kvalid, static_cast<const T *>(a.hn[1].raw) + rrow * a.hn[1].ldraw + hh * 64, dv_row, a.hn[1], key,
+                      half, colred + (wave * 32 + l31) * 65);
+    __syncthreads();
+    hn_colsum(colred, a.hn[1].partials);
 }
 
 // Delta[b,h,q] = sum_d dO*O : one wave per (row, head).
@@ -825,7 +939,18 @@ int check_common(const char *name, int B, int heads, int Sq, int Sk, int math, c
     return 0;
 }
 
+int check_headnorm(const char *name, const KkAttnHeadNorm *hn, int n) {
+    for (int i = 0; i < n; ++i) {
+        KK_REQUIRE(hn[i].raw && hn[i].gain && hn[i].partials && hn[i].ldraw % 8 == 0, "%s: head-norm epilogue %d needs raw, gain, partials", name, i);
+        KK_REQUIRE(!hn[i].rope || (hn[i].cos_t && hn[i].sin_t), "%s: head-norm epilogue %d: RoPE needs cos/sin tables", name, i);
+    }
+    return 0;
+}
+
 }  // namespace
+
+// rows of the [workgroups][64] partial gain-gradient matrix a backward launch with a head-norm epilogue writes
+extern "C" int kk_attn_bwd_blocks(int B, int heads, int S) { return kk_cdiv(S, 128) * B * heads; }
 
 extern "C" int kk_attn_fwd(const float *Q, const float *K, const float *V, float *O, float *LSE, int B, int heads,
                            int Sq, int Sk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
@@ -868,7 +993,7 @@ extern "C" int kk_attn_bwd_dq(const float *Q, const float *K, const float *V, co
                               float *Delta, float *dQ, int B, int heads, int Sq, int Sk, int64_t ldq,
                               int64_t ldk, int64_t ldv, int64_t lddo, int64_t lddq, const uint8_t *key_mask,
                               int causal, float scale, const uint32_t *seed, uint32_t site, float p_drop, int math,
-                              int io_bf16, const float *O, int64_t ldo, void *stream) {
+                              int io_bf16, const float *O, int64_t ldo, const KkAttnHeadNorm *hn, void *stream) {
     KK_REQUIRE(!io_bf16 || math == KK_MATH_BF16, "kk_attn_bwd_dq: bf16 storage needs KK_MATH_BF16");
     const int64_t lds[5] = {ldq, ldk, ldv, lddo, lddq};
     if (int rc = check_common("kk_attn_bwd_dq", B, heads, Sq, Sk, math, lds, 5)) return rc;
@@ -881,6 +1006,10 @@ extern "C" int kk_attn_bwd_dq(const float *Q, const float *K, const float *V, co
         a.O = O; a.ldo = ldo; a.DeltaOut = Delta;
     }
     a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop;
+    if (hn) {
+        if (int rc = check_headnorm("kk_attn_bwd_dq", hn, 1)) return rc;
+        a.hn[0] = hn[0];
+    }
     dim3 grid(kk_cdiv(Sq, 128), B * heads);
     const int G = (Sk > 64 && g_attn_groups == 2) ? 2 : 1;
     if (io_bf16) KK_ATTN_LAUNCH(attn_bwd_dq_kernel, true, true, G, 3);
@@ -894,7 +1023,7 @@ extern "C" int kk_attn_bwd_dkv(const float *Q, const float *K, const float *V, c
                                const float *Delta, float *dK, float *dV, int B, int heads, int Sq, int Sk,
                                int64_t ldq, int64_t ldk, int64_t ldv, int64_t lddo, int64_t lddk, int64_t lddv,
                                const uint8_t *key_mask, int causal, float scale, const uint32_t *seed, uint32_t site,
-                               float p_drop, int math, int io_bf16, void *stream) {
+                               float p_drop, int math, int io_bf16, const KkAttnHeadNorm *hn, void *stream) {
     KK_REQUIRE(!io_bf16 || math == KK_MATH_BF16, "kk_attn_bwd_dkv: bf16 storage needs KK_MATH_BF16");
     const int64_t lds[6] = {ldq, ldk, ldv, lddo, lddk, lddv};
     if (int rc = check_common("kk_attn_bwd_dkv", B, heads, Sq, Sk, math, lds, 6)) return rc;
@@ -903,6 +1032,10 @@ extern "C" int kk_attn_bwd_dkv(const float *Q, const float *K, const float *V, c
     a.B = B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.causal = causal;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.lddo = lddo; a.ldout = lddk; a.ldout2 = lddv; a.scale = scale;
     a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop;
+    if (hn) {
+        if (int rc = check_headnorm("kk_attn_bwd_dkv", hn, 2)) return rc;
+        a.hn[0] = hn[0]; a.hn[1] = hn[1];
+    }
     dim3 grid(kk_cdiv(Sk, 128), B * heads);
     const int G = (Sq > 64 && g_attn_groups == 2) ? 2 : 1;          // one query tile: nothing to split
     if (io_bf16) KK_ATTN_LAUNCH_X(attn_bwd_dkv_kernel, true, true, G, 4, 2 * G * 128 * sizeof(float));

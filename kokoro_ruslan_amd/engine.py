@@ -177,6 +177,8 @@ class KokoroEngine:
         self.fuse_glu_fwd = os.environ.get("KK_FUSE_GLU_FWD", "1") != "0"
         self.group_wgrads = os.environ.get("KK_GROUP_WGRADS", "1") != "0"     # A/B switches for tools/ and bench sweeps
         self.fuse_headnorm = os.environ.get("KK_FUSE_HEADNORM", "1") != "0"
+        self.fuse_headnorm_bwd = os.environ.get("KK_FUSE_HEADNORM_BWD", "1") != "0"
+        self._hn_tables = {}
         self._ptr_tables = {}
         self._wgrad_queue, self._wgrad_tables = {}, {}
         if os.environ.get("KK_GROUP_SPLIT"):
@@ -553,26 +555,59 @@ class KokoroEngine:
         gq, gk, gv = P[prefix + ".q_norm.weight"], P[prefix + ".k_norm.weight"], P[prefix + ".v_norm.weight"]
         dgq, dgk, dgv = G[prefix + ".q_norm.weight"], G[prefix + ".k_norm.weight"], G[prefix + ".v_norm.weight"]
         cz = 1 if causal else 0
+        fuse = self.fuse_headnorm_bwd
+
+        def hn_tables(tag, S, entries):
+            """KkAttnHeadNorm descriptors of one backward launch (cached: every pointer is a persistent buffer) with their
+            partial gain-gradient rows registered for the reduction at the end of the backward."""
+            tk = (self._tmp_ns, key, tag, B, S) + tuple(r.data_ptr() for r, *_ in entries)
+            if tk not in self._hn_tables:
+                nb = kk.load().kk_attn_bwd_blocks(B, h, S)
+                part = self._buf(f"{key}.hnpart.{tag}", len(entries), nb, 64)
+                self._hn_tables[tk] = (kk.attn_headnorm([(r, g_, part[j], c_, s_) for j, (r, g_, _, c_, s_) in enumerate(entries)]),
+                                       part, nb)
+            table, part, nb = self._hn_tables[tk]
+            for j, (_, _, dg_, _, _) in enumerate(entries):
+                self._reduce_lists[self._tmp_ns].append((part[j], dg_, None, nb, 64, 64))
+            return table
+
         if xkv is None:
-            kk.call("kk_attn_bwd_dq", q_n, k_n, v_n, dctx, lse, delta, dq_n, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H, ld(dq_n),
-                    key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16, ctx, H)
-            kk.call("kk_attn_bwd_dkv", q_n, k_n, v_n, dctx, lse, delta, dk_n, dv_n, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H,
-                    ld(dk_n), ld(dv_n), key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16)
-            kk.call("kk_headnorm_rope_bwd", dn, 3 * H, raw, 3 * H, draw, 3 * H, Nq, h, Sq, 3, gq, gk, gv, dgq, dgk, dgv,
-                    self._headnorm_partials(key, Nq, (dgq, dgk, dgv)), 3 if rope else 0, cos, sin, i16)
+            if fuse:       # the head norms' backward is the epilogue of the two attention backward kernels
+                kk.call("kk_attn_bwd_dq", q_n, k_n, v_n, dctx, lse, delta, dq_raw, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H, ld(dq_raw),
+                        key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16, ctx, H, hn_tables("q", Sq, [(q_raw, gq, dgq, cos, sin)]))
+                kk.call("kk_attn_bwd_dkv", q_n, k_n, v_n, dctx, lse, delta, dk_raw, dv_raw, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H,
+                        ld(dk_raw), ld(dv_raw), key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16,
+                        hn_tables("kv", Sk, [(k_raw, gk, dgk, cos, sin), (v_raw, gv, dgv, None, None)]))
+            else:
+                kk.call("kk_attn_bwd_dq", q_n, k_n, v_n, dctx, lse, delta, dq_n, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H, ld(dq_n),
+                        key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16, ctx, H, None)
+                kk.call("kk_attn_bwd_dkv", q_n, k_n, v_n, dctx, lse, delta, dk_n, dv_n, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H,
+                        ld(dk_n), ld(dv_n), key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16, None)
+                kk.call("kk_headnorm_rope_bwd", dn, 3 * H, raw, 3 * H, draw, 3 * H, Nq, h, Sq, 3, gq, gk, gv, dgq, dgk, dgv,
+                        self._headnorm_partials(key, Nq, (dgq, dgk, dgv)), 3 if rope else 0, cos, sin, i16)
             self._wgrad(draw, xq, a.fused(a.g, prefix + ".w_q.weight", 3))
             self._dgrad(draw, self._Wf(prefix + ".w_q.weight", 3), d_xq)
             return
-        kk.call("kk_attn_bwd_dq", q_n, k_n, v_n, dctx, lse, delta, dq_n, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H, ld(dq_n),
-                key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16, ctx, H)      # also writes delta
-        if d_xkv is not None:        # key/value branch; its two GEMMs run once for all layers (_cross_kv_bwd_all)
-            dkv_raw, dkv_n = self._cross_kv(layer, Nk, dt, "d")
-            kk.call("kk_attn_bwd_dkv", q_n, k_n, v_n, dctx, lse, delta, dkv_n, dkv_n[:, H:], B, h, Sq, Sk, ld(q_n), ld(k_n),
-                    ld(v_n), H, ld(dkv_n), ld(dkv_n), key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16)
-            kk.call("kk_headnorm_rope_bwd", dkv_n, ld(dkv_n), kv_raw, ld(kv_raw), dkv_raw, ld(dkv_raw), Nk, h, Sk, 2, gk, gv, None,
-                    dgk, dgv, None, self._headnorm_partials(key + ".kv", Nk, (dgk, dgv)), 0, None, None, i16)
-        kk.call("kk_headnorm_rope_bwd", dq_n, H, q_raw, H, dq_raw, H, Nq, h, Sq, 1, gq, None, None, dgq, None, None,
-                self._headnorm_partials(key + ".q", Nq, (dgq,)), 0, None, None, i16)
+        if fuse:
+            kk.call("kk_attn_bwd_dq", q_n, k_n, v_n, dctx, lse, delta, dq_raw, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H, ld(dq_raw),
+                    key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16, ctx, H,
+                    hn_tables("q", Sq, [(q_raw, gq, dgq, None, None)]))      # also writes delta
+            if d_xkv is not None:    # key/value branch; its two GEMMs run once for all layers (_cross_kv_bwd_all)
+                dkv_raw, _ = self._cross_kv(layer, Nk, dt, "d")
+                kk.call("kk_attn_bwd_dkv", q_n, k_n, v_n, dctx, lse, delta, dkv_raw, dkv_raw[:, H:], B, h, Sq, Sk, ld(q_n), ld(k_n),
+                        ld(v_n), H, ld(dkv_raw), ld(dkv_raw), key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16,
+                        hn_tables("kv", Sk, [(k_raw, gk, dgk, None, None), (v_raw, gv, dgv, None, None)]))
+        else:
+            kk.call("kk_attn_bwd_dq", q_n, k_n, v_n, dctx, lse, delta, dq_n, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H, ld(dq_n),
+                    key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16, ctx, H, None)      # also writes delta
+            if d_xkv is not None:
+                dkv_raw, dkv_n = self._cross_kv(layer, Nk, dt, "d")
+                kk.call("kk_attn_bwd_dkv", q_n, k_n, v_n, dctx, lse, delta, dkv_n, dkv_n[:, H:], B, h, Sq, Sk, ld(q_n), ld(k_n),
+                        ld(v_n), H, ld(dkv_n), ld(dkv_n), key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16, None)
+                kk.call("kk_headnorm_rope_bwd", dkv_n, ld(dkv_n), kv_raw, ld(kv_raw), dkv_raw, ld(dkv_raw), Nk, h, Sk, 2, gk, gv, None,
+                        dgk, dgv, None, self._headnorm_partials(key + ".kv", Nk, (dgk, dgv)), 0, None, None, i16)
+            kk.call("kk_headnorm_rope_bwd", dq_n, H, q_raw, H, dq_raw, H, Nq, h, Sq, 1, gq, None, None, dgq, None, None,
+                    self._headnorm_partials(key + ".q", Nq, (dgq,)), 0, None, None, i16)
         self._wgrad(dq_raw, xq, G[prefix + ".w_q.weight"])
         self._dgrad(dq_raw, self._W(prefix + ".w_q.weight"), d_xq)
 

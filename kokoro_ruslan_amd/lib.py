@@ -47,6 +47,20 @@ class KkReduceDesc(C.Structure):
                 ("split", C.c_int), ("stride", C.c_int)]
 
 
+class KkAttnHeadNorm(C.Structure):
+    _fields_ = [("raw", C.c_void_p), ("ldraw", C.c_int64), ("gain", C.c_void_p), ("partials", C.c_void_p),
+                ("cos_t", C.c_void_p), ("sin_t", C.c_void_p), ("rope", C.c_int)]
+
+
+def attn_headnorm(entries):
+    """Host KkAttnHeadNorm array from [(raw, gain, partials, cos | None, sin | None)] (rope when cos is given)."""
+    arr = (KkAttnHeadNorm * len(entries))()
+    for d, (raw, gain, part, cos, sin) in zip(arr, entries):
+        d.raw, d.ldraw, d.gain, d.partials = raw.data_ptr(), raw.stride(0), gain.data_ptr(), part.data_ptr()
+        d.cos_t, d.sin_t, d.rope = (cos.data_ptr(), sin.data_ptr(), 1) if cos is not None else (0, 0, 0)
+    return arr
+
+
 class KkWgradDesc(C.Structure):
     _fields_ = [("dy", C.c_void_p), ("lddy", C.c_int64), ("x", C.c_void_p), ("ldx", C.c_int64), ("dw", C.c_void_p),
                 ("lddw", C.c_int64), ("M", C.c_int64), ("N", C.c_int64), ("T", C.c_int64)]
@@ -99,8 +113,9 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_colsum_acc": [_P, _L, _L, _L, _P, _I, _P],
     "kk_attn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P],
     "kk_attn_delta": [_P, _P, _P, _I, _I, _I, _L, _L, _I, _P],
-    "kk_attn_bwd_dq": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P, _L, _P],
-    "kk_attn_bwd_dkv": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P],
+    "kk_attn_bwd_dq": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P, _L, _P, _P],
+    "kk_attn_bwd_dkv": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P, _P],
+    "kk_attn_bwd_blocks": [_I, _I, _I],
     "kk_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "kk_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _L, _I, _I, _P],
     "kk_norm_bwd_blocks": [_L, _I],

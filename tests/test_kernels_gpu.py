@@ -196,9 +196,9 @@ def test_attention_fwd_bwd(kk, math_mode, B, h, Sq, Sk, causal, masked):
     delta = torch.zeros(B, h, Sq, device="cuda")
     kk.call("kk_attn_delta", Od, dOd, delta, B, h, Sq, H, H, 0)
     dQ, dK, dV = (torch.zeros_like(t) for t in (Qd, Kd, Vd))
-    kk.call("kk_attn_bwd_dq", Qd, Kd, Vd, dOd, lse, delta, dQ, B, h, Sq, Sk, H, H, H, H, H, kmd, causal, scale, None, 0, 0.0, math_mode, 0, None, 0)
+    kk.call("kk_attn_bwd_dq", Qd, Kd, Vd, dOd, lse, delta, dQ, B, h, Sq, Sk, H, H, H, H, H, kmd, causal, scale, None, 0, 0.0, math_mode, 0, None, 0, None)
     kk.call("kk_attn_bwd_dkv", Qd, Kd, Vd, dOd, lse, delta, dK, dV, B, h, Sq, Sk, H, H, H, H, H, H, kmd, causal, scale,
-            None, 0, 0.0, math_mode, 0)
+            None, 0, 0.0, math_mode, 0, None)
     atol, rtol = (1e-4, 1e-3) if math_mode == 0 else (8e-2, 5e-2)
     close(dQ, Qr.grad, atol, rtol, "attn dQ")
     close(dK, Kr.grad, atol, rtol, "attn dK")
@@ -634,9 +634,9 @@ def test_attention_probability_dropout(kk, math_mode, causal):
     delta = torch.zeros(B, h, S, device="cuda")
     kk.call("kk_attn_delta", O2, dOd, delta, B, h, S, H, H, 0)
     dQ, dK, dV = torch.zeros_like(Qd), torch.zeros_like(Kd), torch.zeros_like(V2d)
-    kk.call("kk_attn_bwd_dq", Qd, Kd, V2d, dOd, lse, delta, dQ, B, h, S, S, H, H, H, H, H, None, causal, 0.125, _seed(5), 9, p, math_mode, 0, None, 0)
+    kk.call("kk_attn_bwd_dq", Qd, Kd, V2d, dOd, lse, delta, dQ, B, h, S, S, H, H, H, H, H, None, causal, 0.125, _seed(5), 9, p, math_mode, 0, None, 0, None)
     kk.call("kk_attn_bwd_dkv", Qd, Kd, V2d, dOd, lse, delta, dK, dV, B, h, S, S, H, H, H, H, H, H, None, causal, 0.125,
-            _seed(5), 9, p, math_mode, 0)
+            _seed(5), 9, p, math_mode, 0, None)
     atol, rtol = (2e-2, 1e-2) if math_mode == 0 else (0.15, 0.1)
     close(dV, Vr.grad, atol, rtol, "attn dV with dropout")
     close(dQ, Qr.grad, atol, rtol, "attn dQ with dropout")
@@ -706,12 +706,12 @@ def test_attention_bf16_storage(kk, B, h, Sq, Sk, causal, masked, strided):
         close(d16, d32, 1e-4, 1e-5, "attn delta bf16 storage")
         g32 = [torch.zeros(B, S, H, device="cuda") for S in (Sq, Sk, Sk)]
         g16 = [torch.zeros(B, S, H, device="cuda", dtype=torch.bfloat16) for S in (Sq, Sk, Sk)]
-        kk.call("kk_attn_bwd_dq", Q, K, V, dO, l32, d32, g32[0], B, h, Sq, Sk, ld, ld, ld, H, H, kmd, causal, 0.125, seed, 4, p, 1, 0, None, 0)
-        kk.call("kk_attn_bwd_dq", Q16, K16, V16, dO16, l16, d16, g16[0], B, h, Sq, Sk, ld, ld, ld, H, H, kmd, causal, 0.125, seed, 4, p, 1, 1, None, 0)
+        kk.call("kk_attn_bwd_dq", Q, K, V, dO, l32, d32, g32[0], B, h, Sq, Sk, ld, ld, ld, H, H, kmd, causal, 0.125, seed, 4, p, 1, 0, None, 0, None)
+        kk.call("kk_attn_bwd_dq", Q16, K16, V16, dO16, l16, d16, g16[0], B, h, Sq, Sk, ld, ld, ld, H, H, kmd, causal, 0.125, seed, 4, p, 1, 1, None, 0, None)
         kk.call("kk_attn_bwd_dkv", Q, K, V, dO, l32, d32, g32[1], g32[2], B, h, Sq, Sk, ld, ld, ld, H, H, H, kmd, causal, 0.125,
-                seed, 4, p, 1, 0)
+                seed, 4, p, 1, 0, None)
         kk.call("kk_attn_bwd_dkv", Q16, K16, V16, dO16, l16, d16, g16[1], g16[2], B, h, Sq, Sk, ld, ld, ld, H, H, H, kmd, causal, 0.125,
-                seed, 4, p, 1, 1)
+                seed, 4, p, 1, 1, None)
         for a, b, n in zip(g16, g32, "QKV"):
             close(a, b, 3e-2, 1e-2, f"attn d{n} bf16 storage p={p}")
 
@@ -978,8 +978,8 @@ def test_attention_dq_computes_delta_in_kernel(kk):
     d_ref, d_new = torch.empty(B, h, S, device="cuda"), torch.full((B, h, S), 9.0, device="cuda")
     kk.call("kk_attn_delta", o, do, d_ref, B, h, S, H, H, 1)
     dq_ref, dq_new = torch.empty_like(q), torch.empty_like(q)
-    kk.call("kk_attn_bwd_dq", q, k, v, do, lse, d_ref, dq_ref, B, h, S, S, H, H, H, H, H, None, 1, 0.125, None, 0, 0.0, 1, 1, None, 0)
-    kk.call("kk_attn_bwd_dq", q, k, v, do, lse, d_new, dq_new, B, h, S, S, H, H, H, H, H, None, 1, 0.125, None, 0, 0.0, 1, 1, o, H)
+    kk.call("kk_attn_bwd_dq", q, k, v, do, lse, d_ref, dq_ref, B, h, S, S, H, H, H, H, H, None, 1, 0.125, None, 0, 0.0, 1, 1, None, 0, None)
+    kk.call("kk_attn_bwd_dq", q, k, v, do, lse, d_new, dq_new, B, h, S, S, H, H, H, H, H, None, 1, 0.125, None, 0, 0.0, 1, 1, o, H, None)
     close(d_new, d_ref, 1e-5, 1e-5, "delta computed in the dQ kernel")
     close(dq_new, dq_ref, 1e-3, 1e-3, "dQ with in-kernel delta")
 
@@ -1117,3 +1117,64 @@ def test_gemm_qkv_headnorm_epilogue(kk, T, parts, heads, K, S, rope):
     v = y_b[:, (parts - 1) * H:(parts - 1) * H + 64].float() / gains[parts - 1]
     if not (rope >> (parts - 1)) & 1:
         close(v.pow(2).mean(-1), torch.ones(T, device="cuda"), 2e-2, 0, "unit RMS per head")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,h,Sq,Sk,causal,rope,bf16,p", [(2, 4, 200, 200, 1, 1, 1, 0.0), (2, 2, 64, 64, 0, 1, 1, 0.1), (1, 8, 512, 512, 1, 1, 1, 0.1),
+                                                         (2, 2, 130, 70, 0, 0, 1, 0.0), (2, 2, 100, 100, 1, 1, 0, 0.0)])
+def test_attention_backward_headnorm_epilogue(kk, B, h, Sq, Sk, causal, rope, bf16, p):
+    """kk_attn_bwd_dq / kk_attn_bwd_dkv with the head-norm descriptors == the plain kernels followed by
+    kk_headnorm_rope_bwd: same gradient of the raw projections (to the storage type's rounding: the row reductions are
+    summed in a different order), same gain gradients after kk_partials_reduce."""
+    g = torch.Generator().manual_seed(B * Sq + Sk)
+    H = h * 64
+    dt = torch.bfloat16 if bf16 else torch.float32
+    io = 1 if bf16 else 0
+    math_ = 1
+    raw_q = dev(torch.randn(B * Sq, H, generator=g)).to(dt)
+    raw_kv = dev(torch.randn(B * Sk, 2 * H, generator=g)).to(dt)
+    gains = [dev(1.0 + 0.2 * torch.randn(64, generator=g)) for _ in range(3)]
+    S = max(Sq, Sk)
+    c, s = ((dev(t) for t in O.rope_tables(S, 64)) if rope else (None, None))
+    q_n, kv_n = torch.empty_like(raw_q), torch.empty_like(raw_kv)
+    kk.call("kk_headnorm_rope_fwd", raw_q, H, q_n, H, B * Sq, h, Sq, 1, gains[0], None, None, 1 if rope else 0, c, s, io)
+    kk.call("kk_headnorm_rope_fwd", raw_kv, 2 * H, kv_n, 2 * H, B * Sk, h, Sk, 2, gains[1], gains[2], None, 1 if rope else 0, c, s, io)
+    k_n, v_n = kv_n, kv_n[:, H:]
+    do = dev(torch.randn(B * Sq, H, generator=g)).to(dt)
+    o, lse = torch.empty(B * Sq, H, device="cuda", dtype=dt), torch.empty(B, h, Sq, device="cuda")
+    seed = torch.tensor([77], dtype=torch.int32, device="cuda")
+    kk.call("kk_attn_fwd", q_n, k_n, v_n, o, lse, B, h, Sq, Sk, H, 2 * H, 2 * H, H, None, causal, 0.125, seed, 5, p, math_, io)
+    delta = torch.empty(B, h, Sq, device="cuda")
+    # reference: plain kernels, then the norm's backward
+    dq_n, dkv_n = torch.empty_like(raw_q), torch.empty_like(raw_kv)
+    kk.call("kk_attn_bwd_dq", q_n, k_n, v_n, do, lse, delta, dq_n, B, h, Sq, Sk, H, 2 * H, 2 * H, H, H, None, causal, 0.125, seed, 5, p,
+            math_, io, o, H, None)
+    kk.call("kk_attn_bwd_dkv", q_n, k_n, v_n, do, lse, delta, dkv_n, dkv_n[:, H:], B, h, Sq, Sk, H, 2 * H, 2 * H, H, 2 * H, 2 * H, None,
+            causal, 0.125, seed, 5, p, math_, io, None)
+    dq_a, dkv_a = torch.empty_like(raw_q), torch.empty_like(raw_kv)
+    dg_a = [torch.zeros(64, device="cuda") for _ in range(3)]
+    kk.call("kk_headnorm_rope_bwd", dq_n, H, raw_q, H, dq_a, H, B * Sq, h, Sq, 1, gains[0], None, None, dg_a[0], None, None, None,
+            1 if rope else 0, c, s, io)
+    kk.call("kk_headnorm_rope_bwd", dkv_n, 2 * H, raw_kv, 2 * H, dkv_a, 2 * H, B * Sk, h, Sk, 2, gains[1], gains[2], None, dg_a[1], dg_a[2],
+            None, None, 1 if rope else 0, c, s, io)
+    # fused
+    nbq, nbk = kk.load().kk_attn_bwd_blocks(B, h, Sq), kk.load().kk_attn_bwd_blocks(B, h, Sk)
+    pq, pkv = torch.full((1, nbq, 64), 5.0, device="cuda"), torch.full((2, nbk, 64), 5.0, device="cuda")
+    dq_b, dkv_b = torch.full_like(raw_q, 7.0), torch.full_like(raw_kv, 7.0)
+    delta_b = torch.empty_like(delta)
+    kk.call("kk_attn_bwd_dq", q_n, k_n, v_n, do, lse, delta_b, dq_b, B, h, Sq, Sk, H, 2 * H, 2 * H, H, H, None, causal, 0.125, seed, 5, p,
+            math_, io, o, H, kk.attn_headnorm([(raw_q, gains[0], pq[0], c, s)]))
+    kk.call("kk_attn_bwd_dkv", q_n, k_n, v_n, do, lse, delta_b, dkv_b, dkv_b[:, H:], B, h, Sq, Sk, H, 2 * H, 2 * H, H, 2 * H, 2 * H, None,
+            causal, 0.125, seed, 5, p, math_, io,
+            kk.attn_headnorm([(raw_kv, gains[1], pkv[0], c, s), (raw_kv[:, H:], gains[2], pkv[1], None, None)]))
+    dg_b = [torch.zeros(64, device="cuda") for _ in range(3)]
+    kk.call("kk_partials_reduce", kk.reduce_table([(pq[0], dg_b[0], None, nbq, 64, 64), (pkv[0], dg_b[1], None, nbk, 64, 64),
+                                                   (pkv[1], dg_b[2], None, nbk, 64, 64)], "cuda"), 3, 64)
+    torch.cuda.synchronize()
+    tol = (2e-2, 2e-2) if bf16 else (2e-5, 2e-5)
+    close(dq_b, dq_a, *tol, "d raw q")
+    close(dkv_b, dkv_a, *tol, "d raw k|v")
+    if bf16:
+        assert float((dq_b == dq_a).float().mean()) > 0.99 and float((dkv_b == dkv_a).float().mean()) > 0.99, "almost all bits equal"
+    for j, name in enumerate(("q", "k", "v")):
+        close(dg_b[j], dg_a[j], 2e-3 * math.sqrt(B * max(Sq, Sk)), 2e-3, f"gain gradient {name}")

@@ -27,6 +27,6 @@ for causal in (0, 1):
             f = lambda: kk.call("kk_attn_fwd", q, k, v, o, lse, B, h, S, S, 3 * H, 3 * H, 3 * H, H, mask, causal, 0.125, seed, 3, p, 1, 1)
             t1 = timeit(f)
             kk.call("kk_attn_delta", o, do, delta, B, h, S, H, H, 1)
-            t2 = timeit(lambda: kk.call("kk_attn_bwd_dq", q, k, v, do, lse, delta, dqkv, B, h, S, S, 3 * H, 3 * H, 3 * H, H, 3 * H, mask, causal, 0.125, seed, 3, p, 1, 1, None, 0))
-            t3 = timeit(lambda: kk.call("kk_attn_bwd_dkv", q, k, v, do, lse, delta, dqkv[:, H:], dqkv[:, 2 * H:], B, h, S, S, 3 * H, 3 * H, 3 * H, H, 3 * H, 3 * H, mask, causal, 0.125, seed, 3, p, 1, 1))
+            t2 = timeit(lambda: kk.call("kk_attn_bwd_dq", q, k, v, do, lse, delta, dqkv, B, h, S, S, 3 * H, 3 * H, 3 * H, H, 3 * H, mask, causal, 0.125, seed, 3, p, 1, 1, None, 0, None))
+            t3 = timeit(lambda: kk.call("kk_attn_bwd_dkv", q, k, v, do, lse, delta, dqkv[:, H:], dqkv[:, 2 * H:], B, h, S, S, 3 * H, 3 * H, 3 * H, H, 3 * H, 3 * H, mask, causal, 0.125, seed, 3, p, 1, 1, None))
             print(f"S={S} causal={causal} p={p} mask={'y' if mask is not None else 'n'}: fwd {t1:6.1f} us  dq {t2:6.1f} us  dkv {t3:6.1f} us")
