@@ -61,12 +61,32 @@ def kernel_table(records, math_bf16: bool):
             key = gemm_symbol(ta, tb, M, N, K, math_bf16, dt)
             flops = 2.0 * M * N * K
             byts = (2.0 if dt & 1 else 4.0) * M * K + (2.0 if dt & 2 else 4.0) * N * K + (2.0 if dt & 4 else 4.0) * M * N
+        elif name == "kk_gemm_wgrad_group":             # (n, then M, N, T of every problem); 128x64 tiles, see kk_gemm16.hip
+            dims = [int(x) for x in sc[1:]]
+            probs = [dims[i:i + 3] for i in range(0, len(dims), 3)]
+            key = "gemm16_group_kernel<true,true,128,64,2> (a layer's dY^T.X wgrads, one launch)"
+            flops = sum(2.0 * M * N * T_ for M, N, T_ in probs)
+            byts = sum(2.0 * T_ * (M + N) + 8.0 * M * N for M, N, T_ in probs)          # bf16 operands, fp32 dW read + written
+        elif name == "kk_gemm_linear_glu":              # (T, F, K, ...): h1 = x.W1^T (2F columns) + gate
+            T_, F_, K_ = (int(x) for x in sc[:3])
+            key = "gemm16_kernel<false,false,64,64,2,2> (X.W1^T + GLU gate epilogue)"
+            flops, byts = 2.0 * T_ * 2 * F_ * K_, 2.0 * (T_ * K_ + 2 * F_ * K_ + 3 * T_ * F_)
+        elif name == "kk_gemm_dgrad_glu":               # (T, F, H, ...): dG = dY.W2 + gate backward
+            T_, F_, H_ = (int(x) for x in sc[:3])
+            key = f"gemm16_kernel<false,true,64,64,{2 if H_ // 64 < 3 else 3},1> (dY.W2 + GLU backward epilogue)"
+            flops, byts = 2.0 * T_ * F_ * H_, 2.0 * (T_ * H_ + F_ * H_ + 4 * T_ * F_)
+        elif name == "kk_gemm_qkv_headnorm":            # (T, parts, heads, K, ...)
+            T_, parts, heads, K_ = (int(x) for x in sc[:4])
+            N_ = parts * heads * 64
+            key = f"gemm16_kernel<false,false,64,64,{2 if K_ // 64 < 3 else 3},3> (q|k|v projection + head-norm epilogue)"
+            flops, byts = 2.0 * T_ * N_ * K_, 2.0 * (T_ * K_ + N_ * K_ + 2 * T_ * N_)
         elif name in ("kk_attn_fwd", "kk_attn_bwd_dq", "kk_attn_bwd_dkv"):
             B, h, Sq, Sk = (int(x) for x in sc[:4])
-            causal = int(sc[-6])           # (..., causal, scale, site, p_drop, math, io_bf16)
+            off = 1 if name == "kk_attn_bwd_dq" else 0       # (..., causal, scale, site, p_drop, math, io_bf16[, ldo])
+            causal = int(sc[-6 - off])
             mm = {"kk_attn_fwd": 2, "kk_attn_bwd_dq": 3, "kk_attn_bwd_dkv": 4}[name]   # matmuls of Sq x Sk x 64
             flops = mm * 2.0 * B * h * Sq * Sk * 64 * (0.5 if causal else 1.0)
-            byts = (2.0 if int(sc[-1]) else 4.0) * B * h * 64 * (2 * Sq + 2 * Sk)
+            byts = (2.0 if int(sc[-1 - off]) else 4.0) * B * h * 64 * (2 * Sq + 2 * Sk)
         keys = [key]
         if name == "kk_gemm":
             keys.append(f"  shape ta={ta} tb={tb} M={M} N={N} K={K}")

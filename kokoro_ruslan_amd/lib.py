@@ -228,7 +228,11 @@ def call(name: str, *args) -> None:
         s.record()
         rc = getattr(lib, name)(*[_conv(a) for a in args], stream)
         e.record()
-        _prof.append((name, tuple(a for a in args if isinstance(a, (int, float))), s, e))
+        scalars = tuple(a for a in args if isinstance(a, (int, float)))
+        for a in args:                                   # a grouped launch's problem sizes live in its descriptor table
+            if isinstance(a, C.Array) and a._type_ is KkWgradDesc:
+                scalars += tuple(v for d in a for v in (d.M, d.N, d.T))
+        _prof.append((name, scalars, s, e))
     else:
         rc = getattr(lib, name)(*[_conv(a) for a in args], stream)
     if rc != 0:
