@@ -336,6 +336,8 @@ int kk_weight_norm_project(float *p, const int32_t *block_seg, int64_t nblocks, 
 int kk_cast_f32_bf16(const float *src, void *dst, int64_t n, void *stream);
 
 /* ---- misc ---- */
+/* *slot = device wall clock (100 MHz ticks) at the time this launch executes: in-graph time stamps for timelines. */
+int kk_timestamp(uint64_t *slot, void *stream);
 /* n <= 16 device-to-device copies (dst[i] <- src[i], bytes[i] each; host arrays of device pointers) as one launch:
  * the hand-over of a batch's tensors into the buffers the captured step reads. */
 int kk_copy_many(const void *const *src, void *const *dst, const int64_t *bytes, int n, void *stream);

@@ -63,3 +63,16 @@ extern "C" int kk_axpby(float a, const float *x, float b, float *y, int64_t n, v
     KK_LAUNCH_CHECK("kk_axpby");
     return 0;
 }
+
+// Device-side time stamp: *slot = the GPU's constant-rate wall clock (100 MHz ticks) when this one-thread kernel runs.
+// A captured step dotted with these is the only timeline that shows how the graph's branches really overlap
+// (rocprofv3 serialises them); see KokoroEngine.timeline().
+namespace {
+__global__ void timestamp_kernel(uint64_t *slot) { *slot = wall_clock64(); }
+}  // namespace
+extern "C" int kk_timestamp(uint64_t *slot, void *stream) {
+    KK_REQUIRE(slot != nullptr, "kk_timestamp: null slot");
+    hipLaunchKernelGGL(timestamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, slot);
+    KK_LAUNCH_CHECK("kk_timestamp");
+    return 0;
+}

@@ -184,6 +184,11 @@ class KokoroEngine:
         if os.environ.get("KK_GROUP_SPLIT"):
             kk.load().kk_gemm_tune_group(int(os.environ["KK_GROUP_SPLIT"]))
         self.spec_augment_active = True             # the trainer clears it for epochs < spec_augment_start_epoch
+        # KK_TRACE=1: one-thread time-stamp launches at the marks of a step (also inside the captured graphs), read back by
+        # timeline() — the real overlap of the graph's branches, which rocprofv3 cannot show (it serialises them)
+        self.trace = os.environ.get("KK_TRACE", "0") == "1"
+        self._marks: Dict[str, int] = {}
+        self._mark_buf = torch.zeros(512, dtype=torch.int64, device=self.device) if self.trace else None
         self.rng = torch.full((1,), int(seed) & 0x7FFFFFFF, dtype=torch.int32, device=self.device)   # step seed, read on device
         for n, b in spec.make_buffers(self.dims).items():
             self.arena.P[n].copy_(b)
@@ -273,6 +278,19 @@ class KokoroEngine:
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         return ev
+
+    def _mark(self, name: str) -> None:
+        if self.trace:
+            idx = self._marks.setdefault(name, len(self._marks))
+            kk.call("kk_timestamp", self._mark_buf[idx:])
+
+    def timeline(self):
+        """[(microseconds since the step's first mark, name)] of the last executed step (KK_TRACE=1), sorted by time."""
+        if not self.trace:
+            raise RuntimeError("timeline(): set KK_TRACE=1 before constructing the engine")
+        t = self._mark_buf.cpu().tolist()
+        rows = sorted((t[i], n) for n, i in self._marks.items() if t[i])
+        return [((v - rows[0][0]) / 100.0, n) for v, n in rows]          # 100 MHz ticks
 
     def _join(self, stream) -> None:
         if self.overlap:
@@ -778,10 +796,13 @@ class KokoroEngine:
         if self.train_dropout:
             self.rng.add_(1)                              # fresh masks every micro-batch (captured in the hipGraph)
         pe_drop, p_enc, p_dec, p_var = self._p(hp.encoder_dropout), self._p(hp.encoder_dropout), self._p(hp.decoder_dropout), self._p(hp.variance_dropout)
+        self._mark("step.start")
         with self._on_stream(self._kv, "kv.", self.dec_head_aside):     # beside the encoder; joined before the first cross-attention
             if zero_grads:                                # the 200 MB gradient memset also hides behind the encoder forward
                 self.zero_grad()
+            self._mark("kv: zero_grad done")
             dec_head = decoder_head()
+            self._mark("kv: decoder head done")
         kk.call("kk_embed_fwd", ids, stress, P["text_embedding.weight"], P["stress_embedding.weight"] if stress is not None else None,
                 pe, x, B, Pn, H, float(H ** 0.5), self.rng, 1, pe_drop)
         y1 = None                                         # LayerNorm outputs come from the previous sub-layer's fused tail
@@ -800,6 +821,7 @@ class KokoroEngine:
                    else ("enc.norm", "encoder_norm", torch.float32))
             y1 = self._ffn_fwd(key + ".ff", pf + ".ff", y2, xm, xo, d.enc_ff, Pn, st + 8, p_enc, dpr, next_ln=nxt)
             x = xo
+            self._mark(f"enc{i} fwd done")
         enc_last = x
         enc = y1 if y1 is not None else self._ln_fwd("enc.norm", enc_last, "encoder_norm")
 
@@ -828,13 +850,17 @@ class KokoroEngine:
                     hp.spec_augment_num_time_masks, hp.spec_augment_num_freq_masks, _b16(memory))
 
         # ---- decoder (model.py:519-531; transformers.py:543-583,660) ----
+        self._mark("memory ready")
         self._cross_kv_fwd_all(memory, Nd, T, ddt)        # every layer's cross-attention K/V in one GEMM
+        self._mark("cross K/V fwd done")
         # Forked only here, after the K/V GEMM: started earlier (right after im2col3) the predictors' fp32 GEMMs compete
         # with the critical path into the decoder; 2.8 % of the step (729K -> 749K frames/s).
         with self._on_side_stream():                      # joined before the losses
+            self._mark("side: predictors fwd start")
             self._varpred_fwd("vp.dur", f"{VA}.duration_predictor", enc, col_e, B, Pn, text_mask, dur_pred, 10, p_var)
             self._varpred_fwd("vp.pitch", f"{VA}.pitch_predictor", xf, col_f, B, T, fmask, pitch_pred, 12, p_var)
             self._varpred_fwd("vp.energy", f"{VA}.energy_predictor", xf, col_f, B, T, fmask, energy_pred, 14, p_var)
+            self._mark("side: predictors fwd done")
         n1 = None
         for i in range(d.dec_layers):
             pf, key, st = f"decoder.layers.{i}", f"dec{i}", 2000 + 32 * i
@@ -856,6 +882,7 @@ class KokoroEngine:
                    else ("dec.norm", "decoder.norm", ddt))
             n1 = self._ffn_fwd(key + ".ff", pf + ".ff", n3, yc, yo, d.dec_ff, T, st + 16, p_dec, dpr, next_ln=nxt)
             y = yo
+            self._mark(f"dec{i} fwd done")
         dec_last = y
         dec_out = n1 if n1 is not None else self._ln_fwd("dec.norm", dec_last, "decoder.norm", ddt)
         mel_pred, stop = self._buf("out.mel", B, T, M), self._buf("out.stop", B, T)
@@ -887,14 +914,17 @@ class KokoroEngine:
         dmel, ddur = self._buf("g.mel", B, T, M), self._buf("g.dur", B, Pn)
         dstop, dpitch, denergy = self._buf("g.stop", B, T), self._buf("g.pitch", B, T), self._buf("g.energy", B, T)
         kk.call("kk_losses_bwd", *largs, self.loss_coef, dmel, ddur, dstop, dpitch, denergy)
+        self._mark("losses + loss gradients done")
         fork = self._fork_point()
 
         def side_backward(after):                         # independent of the decoder backward (disjoint gradient segments)
             with self._on_side_stream(after=after):
+                self._mark("side: backward start")
                 self._varpred_bwd("vp.pitch", f"{VA}.pitch_predictor", dpitch, xf, col_f, B, T, fmask, None, p_var)
                 self._varpred_bwd("vp.energy", f"{VA}.energy_predictor", denergy, xf, col_f, B, T, fmask, None, p_var)
                 d_enc = self._buf("g.enc_out", Ne, H)
                 self._varpred_bwd("vp.dur", f"{VA}.duration_predictor", ddur, enc, col_e, B, Pn, text_mask, d_enc, p_var)
+                self._mark("side: predictors bwd done")
                 dx = self._buf("g.enc_stream", Ne, H)
                 # every LayerNorm's backward is fused with the head of the backward of the sub-layer that produced its input
                 ehead = lambda kind, i: (kind, f"enc{i}.ff", f"transformer_encoder_layers.{i}" + (".ff" if kind == "ffn" else ".self_attn"),
@@ -916,8 +946,10 @@ class KokoroEngine:
                         self._tail_bwd(key + ".ln1", dne, x_in, pf + ".norm1", dx, True, ehead("ffn", i - 1))
                     else:
                         self._ln_bwd(key + ".ln1", dne, x_in, pf + ".norm1", dx, accumulate=True)
+                    self._mark(f"side: enc{i} bwd done")
                 kk.call("kk_embed_bwd", ids, stress, dx, G["text_embedding.weight"],
                         G["stress_embedding.weight"] if stress is not None else None, B, Pn, H, float(H ** 0.5), self.rng, 1, pe_drop)
+                self._mark("side: backward done")
 
         # The decoder backward is the critical path, so it is captured first and the predictors' + encoder's backward
         # after it, forked from the point right after the loss gradients (see _on_stream).  With a split backward
@@ -955,6 +987,7 @@ class KokoroEngine:
                 self._tail_bwd(key + ".ln1", dn, x_in, pf + ".norm1", dy, True, dhead("ffn", i - 1))
             else:
                 self._ln_bwd(key + ".ln1", dn, x_in, pf + ".norm1", dy, accumulate=True)
+            self._mark(f"dec{i} bwd done")
             if yield_at == i:                           # everything the early ranges hold is final from here on
                 self._join(self._side)
                 self._reduce_partials((B, T, Pn, "early"))
@@ -974,10 +1007,12 @@ class KokoroEngine:
                     hp.spec_augment_num_time_masks, hp.spec_augment_num_freq_masks, 0)
         kk.call("kk_bucket_embed_add_bwd", dmem, pidx, eidx, fmask, G[f"{VA}.pitch_embedding.weight"],
                 G[f"{VA}.energy_embedding.weight"], B, T, H)
+        self._mark("main: backward tail done")
         if yield_at is None:
             side_backward(fork)
         self._join(self._side)
         self._reduce_partials((B, T, Pn))
+        self._mark("backward joined, partials reduced")
         return out
 
     # ------------------------------------------------------------------ optimizer boundary
@@ -999,6 +1034,7 @@ class KokoroEngine:
         FFN weight-norm projection.  All decisions on the device (see csrc/kk_optim.hip)."""
         a, hp = self.arena, self.hp
         cfg = self._opt_cfg(mel_length)
+        self._mark("optimizer start")
         kk.call("kk_seg_sumsq", a.g, a.block_seg, a.nblocks, self.grad_sumsq, a.nseg)
         kk.call("kk_opt_prepare", self.grad_sumsq, a.seg_preclip, a.seg_lr_mult, a.seg_wd, a.nseg, self.max_dur, cfg,
                 self.opt_state, self.seg_gscale, self.seg_decay, self.seg_stepsize, self.step_consts)
@@ -1007,6 +1043,7 @@ class KokoroEngine:
                 self.p_sumsq, a.nseg, a.p16)
         kk.call("kk_weight_norm_project", a.p, a.block_seg, a.nblocks, self.p_sumsq, a.seg_flags, self.step_consts,
                 float(hp.dec_ffn_max_weight_norm), a.p16)
+        self._mark("optimizer done")
 
     def train_step(self, batch: Dict[str, torch.Tensor], accumulation_divisor: Optional[int] = None,
                    boundary: Optional[bool] = None, grad_sync=None) -> torch.Tensor:

@@ -158,6 +158,7 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_cast_f32_bf16": [_P, _P, _L, _P],
     "kk_copy_many": [_P, _P, _P, _I, _P],
     "kk_axpby": [_F, _P, _F, _P, _L, _P],
+    "kk_timestamp": [_P, _P],
     "kk_mfma_probe": [_P, _P, _P],
 }
 
