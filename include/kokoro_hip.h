@@ -217,7 +217,7 @@ int kk_bucket_embed_add_fwd(const float *x, const float *pitch, const float *ene
                             int H, int nbins, int out_bf16, void *stream);
 int kk_bucket_embed_add_bwd(const float *dout, const int32_t *pidx, const int32_t *eidx,
                             const uint8_t *frame_mask, float *dpemb, float *deemb, int B, int T, int H,
-                            void *stream);
+                            int nbins, void *stream);   /* nbins = rows of the two embedding tables */
 /* text key mask: mask[i] = (ids[i] == 0)  (model.py:586-587). */
 int kk_ids_eq_zero(const int64_t *ids, uint8_t *mask, int64_t n, void *stream);
 /* decoder input shift-right (model.py:519): out[b,0,:]=0, out[b,t,:]=mel[b,t-1,:]. */

@@ -293,6 +293,51 @@ __global__ __launch_bounds__(256) void bucket_embed_add_bwd_kernel(const float *
     }
 }
 
+// The same scatter-add through LDS: a workgroup owns 16 columns of H and a quarter of the rows, adds its rows into two
+// private [nbins][16] tables with LDS atomics (4096 rows fall into <= nbins buckets, so the global tables see nbins*16
+// atomics per workgroup instead of rows*16), then flushes the non-zero entries.  64 us -> ~10 us at 4096 x 512.
+constexpr int BE_CW = 16, BE_RG = 8;
+__global__ __launch_bounds__(256) void bucket_embed_add_bwd_lds_kernel(const float *__restrict__ dout, const int32_t *__restrict__ pidx,
+                                                                       const int32_t *__restrict__ eidx, const uint8_t *__restrict__ fmask,
+                                                                       float *__restrict__ dpemb, float *__restrict__ deemb, int64_t rows,
+                                                                       int H, int nbins) {
+    extern __shared__ float be_tab[];                     // [2][nbins][BE_CW]
+    float *tp = be_tab, *te = be_tab + nbins * BE_CW;
+    for (int i = threadIdx.x; i < 2 * nbins * BE_CW; i += 256) be_tab[i] = 0.f;
+    __syncthreads();
+    const int c0 = blockIdx.x * BE_CW, col = threadIdx.x & (BE_CW - 1), rsub = threadIdx.x / BE_CW;
+    const int64_t per = (rows + gridDim.y - 1) / gridDim.y, r0 = blockIdx.y * per, r1 = r0 + per < rows ? r0 + per : rows;
+    if (c0 + col < H) {
+        constexpr int RS = 256 / BE_CW, U = 4;            // U rows in flight per thread: the loop is load-latency bound
+        for (int64_t rb = r0 + rsub; rb < r1; rb += RS * U) {
+            float d[U];
+            int pi[U], ei[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t r = rb + u * RS;
+                const bool ok = r < r1 && !fmask[r];
+                d[u] = ok ? dout[r * H + c0 + col] : 0.f;
+                pi[u] = ok ? pidx[r] : -1;
+                ei[u] = ok ? eidx[r] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (pi[u] < 0) continue;
+                atomicAdd(&tp[pi[u] * BE_CW + col], d[u]);
+                atomicAdd(&te[ei[u] * BE_CW + col], d[u]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nbins * BE_CW; i += 256) {
+        const int c = c0 + (i & (BE_CW - 1));
+        if (c >= H) continue;
+        const int64_t o = (int64_t)(i / BE_CW) * H + c;
+        if (tp[i] != 0.f) atomicAdd(&dpemb[o], tp[i]);
+        if (te[i] != 0.f) atomicAdd(&deemb[o], te[i]);
+    }
+}
+
 __global__ void ids_eq_zero_kernel(const int64_t *__restrict__ ids, uint8_t *__restrict__ mask, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         mask[i] = ids[i] == 0 ? 1 : 0;
@@ -458,9 +503,16 @@ extern "C" int kk_bucket_embed_add_fwd(const float *x, const float *pitch, const
 }
 extern "C" int kk_bucket_embed_add_bwd(const float *dout, const int32_t *pidx, const int32_t *eidx,
                                        const uint8_t *frame_mask, float *dpemb, float *deemb, int B, int T, int H,
-                                       void *stream) {
-    KK_REQUIRE(B > 0 && T > 0 && H > 0, "kk_bucket_embed_add_bwd: bad shape");
+                                       int nbins, void *stream) {
+    KK_REQUIRE(B > 0 && T > 0 && H > 0 && nbins > 0, "kk_bucket_embed_add_bwd: bad shape");
     const int64_t rows = (int64_t)B * T;
+    const size_t lds = (size_t)2 * nbins * BE_CW * sizeof(float);
+    if (lds <= 64 * 1024) {
+        hipLaunchKernelGGL(bucket_embed_add_bwd_lds_kernel, dim3(kk_cdiv(H, BE_CW), BE_RG), dim3(256), lds, (hipStream_t)stream, dout,
+                           pidx, eidx, frame_mask, dpemb, deemb, rows, H, nbins);
+        KK_LAUNCH_CHECK("kk_bucket_embed_add_bwd");
+        return 0;
+    }
     int blocks = kk_cdiv(rows, 4);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(bucket_embed_add_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, pidx, eidx,

@@ -537,7 +537,8 @@ class KokoroEngine:
         """Weight gradient of all layers' K/V projections and the memory gradient: two GEMMs over the all-layer buffer."""
         a, H, L = self.arena, self.dims.hidden, self.dims.dec_layers
         draw_all = self._buf("dec.ca.dkv_raw_all", Nk, 2 * H * L, dtype=dt)
-        self._wgrad(draw_all, xkv, a.fused(a.g, "decoder.layers.0.cross_attn.w_k.weight", 2 * L))
+        with self._grouped_wgrads():                    # (a group of one: the 128x64-tile, full-reduction launch)
+            self._wgrad(draw_all, xkv, a.fused(a.g, "decoder.layers.0.cross_attn.w_k.weight", 2 * L))
         self._dgrad(draw_all, self._Wf("decoder.layers.0.cross_attn.w_k.weight", 2 * L), d_xkv)
 
     def _attn_bwd(self, key, prefix, d_out, xq, xkv, B, Sq, Sk, rope, causal, key_mask, d_xq, d_xkv, d_xkv_beta,
@@ -1001,12 +1002,14 @@ class KokoroEngine:
         else:
             self._wgrad(dy, shifted, G["mel_projection_in.weight"], G["mel_projection_in.bias"])
         # variance adaptor: memory gradient feeds only the two embedding tables (xf is detached, lengths.py:30)
+        self._mark("decoder input projection bwd done")
         self._cross_kv_bwd_all(memory, Nd, ddt, dmem)     # K/V weight gradients and the memory gradient, all layers at once
+        self._mark("cross K/V bwd (all layers) done")
         if spec_aug:
             kk.call("kk_specaug", dmem, B, T, H, self.rng, 20, hp.spec_augment_time_mask_max, hp.spec_augment_freq_mask_max,
                     hp.spec_augment_num_time_masks, hp.spec_augment_num_freq_masks, 0)
         kk.call("kk_bucket_embed_add_bwd", dmem, pidx, eidx, fmask, G[f"{VA}.pitch_embedding.weight"],
-                G[f"{VA}.energy_embedding.weight"], B, T, H)
+                G[f"{VA}.energy_embedding.weight"], B, T, H, d.var_bins)
         self._mark("main: backward tail done")
         if yield_at is None:
             side_backward(fork)

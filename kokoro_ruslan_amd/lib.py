@@ -139,7 +139,7 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_rowdot_fwd": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
     "kk_rowdot_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
     "kk_bucket_embed_add_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "kk_bucket_embed_add_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "kk_bucket_embed_add_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "kk_dropout_fwd": [_P, _P, _L, _P, _L, _I, _I, _P, _U, _F, _U, _F, _U, _F, _P],
     "kk_sublayer_out_fwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _I, _I, _P, _U, _F, _U, _F, _U, _F, _P],
     "kk_sublayer_in_bwd": [_P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _L, _I, _I, _P, _U, _F, _U, _F, _U, _F, _P],

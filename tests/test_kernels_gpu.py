@@ -453,7 +453,7 @@ def test_bucket_embed_add(kk):
     assert torch.equal(fmd.cpu().bool(), fm)
     close(out, ref, 1e-6, 1e-6, "bucket-embed fwd")
     dp, de = torch.zeros(nb, H, device="cuda"), torch.zeros(nb, H, device="cuda")
-    kk.call("kk_bucket_embed_add_bwd", dev(dout), pi, ei, fmd, dp, de, B, T, H)
+    kk.call("kk_bucket_embed_add_bwd", dev(dout), pi, ei, fmd, dp, de, B, T, H, nb)
     close(dp, pr.grad, 1e-4, 1e-5, "bucket-embed dpitch_emb")
     close(de, er.grad, 1e-4, 1e-5, "bucket-embed denergy_emb")
 
