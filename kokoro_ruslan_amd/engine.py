@@ -186,6 +186,12 @@ class KokoroEngine:
         self.spec_augment_active = True             # the trainer clears it for epochs < spec_augment_start_epoch
         # KK_TRACE=1: one-thread time-stamp launches at the marks of a step (also inside the captured graphs), read back by
         # timeline() — the real overlap of the graph's branches, which rocprofv3 cannot show (it serialises them)
+        self._segmented = False
+        # train_step_graphed: capture the step as a program of single-stream graphs (_capture_segments) instead of one
+        # graph with parallel branches.  Cuts the host cost of a step from 2.5 ms to ~0.2 ms, but the GPU time is 3 %
+        # worse (770K vs 794K frames/s: the kernels inside a stretch run no closer together, and every stretch boundary
+        # costs 10-20 us), so it is off unless the host is the bottleneck.
+        self.segmented_graphs = os.environ.get("KK_SEGMENTED", "0") == "1"
         self.trace = os.environ.get("KK_TRACE", "0") == "1"
         self._marks: Dict[str, int] = {}
         self._mark_buf = torch.zeros(512, dtype=torch.int64, device=self.device) if self.trace else None
@@ -257,12 +263,15 @@ class KokoroEngine:
         if not (self.overlap and enable):
             yield
             return
-        if after is not None:
-            stream.wait_event(after)
-        else:
-            stream.wait_stream(torch.cuda.current_stream())
         saved, self._tmp_ns = self._tmp_ns, ns
         try:
+            if self._segmented:          # the capture driver switches graphs / streams at the generator's markers
+                yield
+                return
+            if after is not None:
+                stream.wait_event(after)
+            else:
+                stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(stream):
                 yield
         finally:
@@ -273,7 +282,7 @@ class KokoroEngine:
 
     def _fork_point(self):
         """An event on the current stream that a later _on_stream(..., after=event) forks from."""
-        if not self.overlap:
+        if not self.overlap or self._segmented:
             return None
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
@@ -751,8 +760,13 @@ class KokoroEngine:
     def _fb_gen(self, batch, loss_scale, adaptive, backward, split_layer, zero_grads=False):
         """forward_backward as a generator: with split_layer = k it pauses once, after the backward of decoder layer k,
         with the side stream joined and every gradient of early_late_ranges(k)[0] final — the data-parallel step
-        captures the two halves as separate hipGraphs and starts the all-reduce of the early ranges in between."""
+        captures the two halves as separate hipGraphs and starts the all-reduce of the early ranges in between.
+
+        With self._segmented set (by _capture_segments) the generator also yields a marker wherever the work moves to
+        another stream or waits for one — ("begin", stream[, "fork"]), ("end", stream), ("join", stream), ("fork",) —
+        and leaves the stream switching to the driver, which captures every stretch as its own single-stream hipGraph."""
         d, a, P, G = self.dims, self.arena, self.arena.P, self.arena.G
+        seg = self._segmented and self.overlap
         H, M, Fv = d.hidden, d.mel, d.var_filter
         ids, mel, dur = batch["phoneme_indices"], batch["mel_specs"], batch["phoneme_durations"]
         stress = batch.get("stress_indices")
@@ -798,12 +812,16 @@ class KokoroEngine:
             self.rng.add_(1)                              # fresh masks every micro-batch (captured in the hipGraph)
         pe_drop, p_enc, p_dec, p_var = self._p(hp.encoder_dropout), self._p(hp.encoder_dropout), self._p(hp.decoder_dropout), self._p(hp.variance_dropout)
         self._mark("step.start")
+        if seg and self.dec_head_aside:
+            yield ("begin", "kv")
         with self._on_stream(self._kv, "kv.", self.dec_head_aside):     # beside the encoder; joined before the first cross-attention
             if zero_grads:                                # the 200 MB gradient memset also hides behind the encoder forward
                 self.zero_grad()
             self._mark("kv: zero_grad done")
             dec_head = decoder_head()
             self._mark("kv: decoder head done")
+        if seg and self.dec_head_aside:
+            yield ("end", "kv")
         kk.call("kk_embed_fwd", ids, stress, P["text_embedding.weight"], P["stress_embedding.weight"] if stress is not None else None,
                 pe, x, B, Pn, H, float(H ** 0.5), self.rng, 1, pe_drop)
         y1 = None                                         # LayerNorm outputs come from the previous sub-layer's fused tail
@@ -856,18 +874,25 @@ class KokoroEngine:
         self._mark("cross K/V fwd done")
         # Forked only here, after the K/V GEMM: started earlier (right after im2col3) the predictors' fp32 GEMMs compete
         # with the critical path into the decoder; 2.8 % of the step (729K -> 749K frames/s).
+        if seg:
+            yield ("begin", "side")
         with self._on_side_stream():                      # joined before the losses
             self._mark("side: predictors fwd start")
             self._varpred_fwd("vp.dur", f"{VA}.duration_predictor", enc, col_e, B, Pn, text_mask, dur_pred, 10, p_var)
             self._varpred_fwd("vp.pitch", f"{VA}.pitch_predictor", xf, col_f, B, T, fmask, pitch_pred, 12, p_var)
             self._varpred_fwd("vp.energy", f"{VA}.energy_predictor", xf, col_f, B, T, fmask, energy_pred, 14, p_var)
             self._mark("side: predictors fwd done")
+        if seg:
+            yield ("end", "side")
         n1 = None
         for i in range(d.dec_layers):
             pf, key, st = f"decoder.layers.{i}", f"dec{i}", 2000 + 32 * i
             dpr = self._dpr(i, d.dec_layers)
             if i == 0:                                    # input projection + layer-0 self-attention ran beside the encoder
-                self._join(self._kv)
+                if seg and self.dec_head_aside:
+                    yield ("join", "kv")
+                else:
+                    self._join(self._kv)
                 y, ya, n2 = dec_head
             else:
                 if n1 is None:
@@ -892,7 +917,10 @@ class KokoroEngine:
                 _b16(dec_out))
 
         # ---- losses (losses.py) ----
-        self._join_side()
+        if seg:
+            yield ("join", "side")
+        else:
+            self._join_side()
         lcfg = kk.KkLossCfg(hp.duration_loss_weight, hp.stop_token_loss_weight, hp.pitch_loss_weight, hp.energy_loss_weight,
                             hp.duration_huber_delta, hp.pitch_huber_delta, hp.energy_huber_delta, hp.stop_token_pos_weight,
                             float(loss_scale), 1 if adaptive else 0)
@@ -917,6 +945,8 @@ class KokoroEngine:
         kk.call("kk_losses_bwd", *largs, self.loss_coef, dmel, ddur, dstop, dpitch, denergy)
         self._mark("losses + loss gradients done")
         fork = self._fork_point()
+        if seg:
+            yield ("fork",)
 
         def side_backward(after):                         # independent of the decoder backward (disjoint gradient segments)
             with self._on_side_stream(after=after):
@@ -1012,8 +1042,15 @@ class KokoroEngine:
                 G[f"{VA}.energy_embedding.weight"], B, T, H, d.var_bins)
         self._mark("main: backward tail done")
         if yield_at is None:
+            if seg:
+                yield ("begin", "side", "fork")
             side_backward(fork)
-        self._join(self._side)
+            if seg:
+                yield ("end", "side")
+        if seg:
+            yield ("join", "side")
+        else:
+            self._join(self._side)
         self._reduce_partials((B, T, Pn))
         self._mark("backward joined, partials reduced")
         return out
@@ -1067,6 +1104,89 @@ class KokoroEngine:
         return out["losses"]
 
     # ------------------------------------------------------------------ hipGraph replay of a whole step
+    def _capture_segments(self, static):
+        """Capture forward+backward as a PROGRAM of single-stream hipGraphs instead of one graph with parallel branches.
+
+        A hipGraph that forks onto several streams is launched node by node through the runtime's multi-queue path:
+        2.5 ms of host time per step here and 2.4 us between dependent kernels.  A single-stream graph takes the
+        packet-capture fast path: ~0.02 ms to launch, 1.5 us between dependent kernels (tools/probes/graph_gap_probe.py)
+        — 0.9 us less for each of the ~330 kernels of the main chain.  So every stretch of the step that runs on one
+        stream becomes its own graph, launched on that stream, and the edges between the branches (fork after the
+        cross K/V GEMM, join before the losses, ...) are ordinary events between graph launches.  The program is the
+        list of ("launch", stream, graph) / ("record", stream, event) / ("wait", stream, event) replayed every step;
+        the dependencies are exactly the ones the one-graph capture had."""
+        prog, graphs = [], []
+        last = {}                                   # stream name -> event after its latest graph
+        state = {"name": "main", "ctx": None, "g": None, "n0": 0, "fork": None}
+
+        def open_graph(name):
+            g = torch.cuda.CUDAGraph()
+            ctx = torch.cuda.graph(g, capture_error_mode="thread_local")
+            ctx.__enter__()
+            state.update(name=name, ctx=ctx, g=g, n0=kk.launches)
+
+        def close_graph():
+            state["ctx"].__exit__(None, None, None)
+            name = state["name"]
+            graphs.append(state["g"])              # (kept alive even when empty: a graph must not be destroyed during a capture)
+            if kk.launches > state["n0"]:
+                prog.append(("launch", name, state["g"]))
+            ev = torch.cuda.Event()
+            prog.append(("record", name, ev))
+            last[name] = ev
+            state["ctx"] = None
+
+        ev0 = torch.cuda.Event()                    # everything queued before this step (the previous optimizer pass)
+        prog.append(("record", "main", ev0))
+        last["main"] = ev0
+        self._segmented = True
+        try:
+            gen = self._fb_gen(static, self.dp_loss_scale, True, True, None, True)
+            open_graph("main")
+            for msg in gen:
+                kind = msg[0]
+                if kind == "begin":
+                    close_graph()
+                    dep = state["fork"] if len(msg) > 2 else last["main"]
+                    prog.append(("wait", msg[1], dep))
+                    open_graph(msg[1])
+                elif kind == "end":
+                    close_graph()
+                    open_graph("main")
+                elif kind == "join":
+                    close_graph()
+                    prog.append(("wait", "main", last[msg[1]]))
+                    open_graph("main")
+                elif kind == "fork":
+                    close_graph()
+                    state["fork"] = last["main"]
+                    open_graph("main")
+                else:
+                    raise RuntimeError(f"unexpected pause {msg!r} in a segmented capture")
+            close_graph()
+        finally:
+            self._segmented = False
+            if state["ctx"] is not None:
+                state["ctx"].__exit__(None, None, None)
+        self._segment_graphs = getattr(self, "_segment_graphs", []) + graphs
+        return prog
+
+    def _run_program(self, prog) -> None:
+        main = torch.cuda.current_stream()
+        streams = {"main": main, "kv": self._kv, "side": self._side}
+        for op, name, obj in prog:
+            st = streams[name]
+            if op == "launch":
+                if st is main:
+                    obj.replay()
+                else:
+                    with torch.cuda.stream(st):
+                        obj.replay()
+            elif op == "record":
+                obj.record(st)
+            else:
+                st.wait_event(obj)
+
     def train_step_graphed(self, batch: Dict[str, torch.Tensor], grad_sync=None) -> torch.Tensor:
         """Same semantics as train_step with gradient_accumulation_steps == 1, but the kernel sequence of a step is
         captured once per batch shape into hipGraphs and replayed (a step is ~700 launches; eager launch overhead
@@ -1114,12 +1234,17 @@ class KokoroEngine:
                     for _ in gen:
                         raise RuntimeError("forward_backward paused twice")
                 ent["ranges"] = self.early_late_ranges(self.dp_overlap_layer)
+            elif self.segmented_graphs and self.overlap:
+                ent["prog"] = self._capture_segments(static)
             else:
                 with torch.cuda.graph(ent["fb"], capture_error_mode="thread_local"):
                     self.forward_backward(static, loss_scale=self.dp_loss_scale, adaptive=True, zero_grads=True)
             with torch.cuda.graph(ent["opt"], capture_error_mode="thread_local"):
                 self.optimizer_step(T)
-        ent["fb"].replay()
+        if ent.get("prog") is not None:
+            self._run_program(ent["prog"])
+        else:
+            ent["fb"].replay()
         if ent["fb2"] is not None:
             early, late = ent["ranges"]
             works = grad_sync.start(self.arena.g, early)      # asynchronous, on the collective stream

@@ -219,10 +219,15 @@ def gemm_tune16(enable: int = 1, thr128: int = 0, thr12864: int = 0, split_targe
     load().kk_gemm_tune16(enable, thr128, thr12864, split_target)
 
 
+launches = 0          # kk.call invocations so far (the graph-capture driver uses it to drop empty segments)
+
+
 def call(name: str, *args) -> None:
     """Invoke ``name`` with torch tensors (→ device pointers), scalars and cfg structs; the current
     torch stream is appended as the trailing ``stream`` argument."""
+    global launches
     lib = load()
+    launches += 1
     stream = torch.cuda.current_stream().cuda_stream
     if _prof is not None:
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

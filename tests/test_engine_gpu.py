@@ -404,3 +404,26 @@ def test_split_backward_graphs_for_overlapped_allreduce(eng_mod, golden_dir):
     assert split.opt_stats()["attempt"] == plain.opt_stats()["attempt"] == 4
     err = float((split.arena.p - plain.arena.p).abs().max())
     assert err <= 2e-5, err
+
+
+def test_segmented_graph_program_trains_like_the_single_graph(eng_mod, golden_dir):
+    """train_step_graphed with segmented_graphs (a program of single-stream hipGraphs joined by events) must produce the
+    same training as the one-graph capture with parallel branches: same kernels, same dependencies."""
+    fx, d, batch, P = _load(golden_dir, "tiny_full")
+    b = _cuda(batch)
+    out = []
+    for seg in (False, True):
+        e = _engine(eng_mod, d, P, math_mode="bf16", gradient_accumulation_steps=1)
+        e.train_dropout = True
+        e.segmented_graphs = seg
+        for _ in range(5):                               # eager, capture, replay x3
+            losses = e.train_step_graphed(b).clone()
+        torch.cuda.synchronize()
+        assert e.opt_stats()["attempt"] == 5
+        out.append((losses, e.arena.p.clone()))
+        if seg:
+            ent = next(iter(e._graphs.values()))
+            kinds = [op for op, _, _ in ent["prog"]]
+            assert kinds.count("launch") >= 6 and "wait" in kinds
+    torch.testing.assert_close(out[1][0], out[0][0], rtol=2e-6, atol=1e-7)      # (fp32 atomics in a few reductions)
+    assert float((out[1][1] - out[0][1]).abs().max()) <= 2e-5 * float(out[0][1].abs().max())
