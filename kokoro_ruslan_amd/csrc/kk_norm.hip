@@ -471,7 +471,8 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float *__rest
     const int64_t base = ((int64_t)b * L + (int64_t)ci * chunk) * C;
     float ag = 0.f, ab = 0.f, s1 = 0.f, s2 = 0.f;
     if (nf >= 2)
-        for (int f = fbeg + fl; f < fend; f += lanes) {
+#pragma unroll 4
+        for (int f = fbeg + fl; f < fend; f += lanes) {             // (load-latency bound: few frames per block, loads unrolled)
             const int64_t o = base + (int64_t)f * C + c;
             const float d = y[o] > 0.f ? dy[o] * inv_keep : 0.f;   // y == 0 also where dropout removed the element
             const float xh = (x[o] - mu) * rs;
@@ -676,6 +677,9 @@ extern "C" int kk_groupnorm_relu_bwd(const float *dy, const float *x, const floa
     const int nch = kk_cdiv(L, chunk), total = B * nch;
     hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * 2 * total, s);
     if (e != hipSuccess) return kk_fail((int)e, "kk_groupnorm_relu_bwd: memset failed");
+    // 16 slabs x (b, chunk): a thin grid on purpose.  This runs on the side branch beside the decoder backward; with 64 or
+    // 128 slabs the kernel itself is 4x faster and the train step 1 % SLOWER (796K -> 790K -> 786K frames/s) — a burst of
+    // workgroups disturbs the critical chain more than a long thin launch does; 8 and 4 slabs are slower again.
     const int slabs = 16;
     hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(slabs, total), dim3(256), 0, s, dy, x, y, gamma, stats, scratch, dgamma,
                        dbeta, L, C, chunk, nch, slabs, inv_keep);
