@@ -1055,6 +1055,155 @@ class KokoroEngine:
         self._mark("backward joined, partials reduced")
         return out
 
+    # ------------------------------------------------------------------ inference
+    @torch.no_grad()
+    def generate(self, ids: torch.Tensor, stress: Optional[torch.Tensor] = None, max_len: int = 4000,
+                 stop_threshold: float = 0.5, min_len_ratio: float = 0.7, min_len_floor: int = 12,
+                 max_len_ratio: float = 3.0, max_len_cap: int = 1600, post_expected_stop_threshold: float = 0.2,
+                 check_every: int = 16) -> torch.Tensor:
+        """KokoroModel.forward_inference (model/model.py:676-790) + KokoroGenerator.generate (model/generator.py:24-127):
+        encode, expand by the model's own durations, pick the pitch / energy embeddings from its own (clamped)
+        predictions (variance_predictor.py:338-439 without targets), then decode one mel frame at a time against a KV
+        cache until the stop head fires, the output goes quiet or the length bound is reached.  Returns [B, frames, mel]
+        clamped to [-11.5, 2] like the reference.  Weights: the engine's current parameters, dropout off.
+
+        Decoder step = the training kernels at Sq = 1: the self-attention cache holds the NORMALISED (and, for K,
+        rotated by the absolute position) heads time-major as [t][B*H], so one attention launch with B*heads "heads"
+        serves the whole batch; the cross-attention K|V of all layers come from one GEMM (_cross_kv_fwd_all).  Like
+        the reference, the single query of a step is rotated by position 0 (RoPE offsets default to 0 in its
+        incremental path, transformers.py:276).  The stop decision needs the host; the reference syncs every frame,
+        here the frames of `check_every` steps are decoded before the host looks (frames past the stop are dropped, so
+        the result is the same)."""
+        d, P, H, M, h = self.dims, self.arena.P, self.dims.hidden, self.dims.mel, self.dims.heads
+        VA = "duration_adaptor.variance_adaptor"
+        ids = ids.to(self.device, torch.int64).contiguous()
+        stress = stress.to(self.device, torch.int64).contiguous() if stress is not None else None
+        B, Pn = ids.shape
+        Ne = B * Pn
+        edt, ddt = self.enc_dt, self.dec_dt
+        pe = P["positional_encoding.pe"].view(d.max_len, H)
+        saved_drop, self.train_dropout = self.train_dropout, False
+        try:
+            # ---- encode_text (model.py:375-388) ----
+            text_mask = self._buf("gen.text_mask", B, Pn, dtype=torch.uint8)
+            kk.call("kk_ids_eq_zero", ids, text_mask, Ne)
+            x = self._buf("enc.x0", Ne, H)
+            kk.call("kk_embed_fwd", ids, stress, P["text_embedding.weight"], P["stress_embedding.weight"] if stress is not None else None,
+                    pe, x, B, Pn, H, float(H ** 0.5), self.rng, 1, 0.0)
+            y1 = None
+            for i in range(d.enc_layers):
+                pf, key = f"transformer_encoder_layers.{i}", f"enc{i}"
+                if y1 is None:
+                    y1 = self._ln_fwd(key + ".ln1", x, pf + ".norm1", edt)
+                xm = self._buf(key + ".xm", Ne, H)
+                y2 = self._attn_fwd(key + ".sa", pf + ".self_attn", y1, None, B, Pn, Pn, True, False, text_mask, x, xm,
+                                    next_ln=(key + ".ln2", pf + ".norm2", edt))
+                xo = self._buf(key + ".xo", Ne, H)
+                nxt = ((f"enc{i + 1}.ln1", f"transformer_encoder_layers.{i + 1}.norm1", edt) if i + 1 < d.enc_layers
+                       else ("enc.norm", "encoder_norm", torch.float32))
+                y1 = self._ffn_fwd(key + ".ff", pf + ".ff", y2, xm, xo, d.enc_ff, Pn, next_ln=nxt)
+                x = xo
+            enc = y1
+            # ---- variance adaptor without targets ----
+            log_dur = self._buf("out.log_dur", B, Pn)
+            col_e = self._buf("vp.col_enc", Ne, 3 * H, dtype=edt)
+            kk.call("kk_im2col3_fwd", enc, col_e, B, Pn, H, CHUNK, _b16(col_e))
+            self._varpred_fwd("vp.dur", f"{VA}.duration_predictor", enc, col_e, B, Pn, text_mask, log_dur)
+            dur = torch.clamp(torch.round(torch.expm1(log_dur)), min=0).to(torch.int64)
+            expected = max(int(dur.sum(dim=1).max()), 3)           # (host sync: the expanded length sizes everything below)
+            T = expected
+            if T > d.max_len:
+                raise ValueError(f"predicted length {T} exceeds the positional table ({d.max_len})")
+            Nd = B * T
+            idx, lens, tot = (self._buf("lr.idx", B, T, dtype=torch.int64), self._buf("lr.lens", B, dtype=torch.int64),
+                              self._buf("lr.total", B, dtype=torch.int64))
+            kk.call("kk_length_regulate_index", dur, idx, lens, tot, B, Pn, T)
+            xf = self._buf("va.xf", Nd, H)
+            kk.call("kk_length_regulate_gather", enc, idx, xf, B, Pn, T, H)
+            fmask = (torch.arange(T, device=self.device)[None, :] >= lens[:, None]).to(torch.uint8).contiguous()
+            col_f = self._buf("vp.col_frames", Nd, 3 * H, dtype=ddt)
+            kk.call("kk_im2col3_fwd", xf, col_f, B, T, H, CHUNK, _b16(col_f))
+            pitch, energy = self._buf("out.pitch", B, T), self._buf("out.energy", B, T)
+            self._varpred_fwd("vp.pitch", f"{VA}.pitch_predictor", xf, col_f, B, T, fmask, pitch)
+            self._varpred_fwd("vp.energy", f"{VA}.energy_predictor", xf, col_f, B, T, fmask, energy)
+            memory, fm2 = self._buf("va.memory", Nd, H, dtype=ddt), self._buf("va.fmask", B, T, dtype=torch.uint8)
+            pidx, eidx = self._buf("va.pidx", B, T, dtype=torch.int32), self._buf("va.eidx", B, T, dtype=torch.int32)
+            kk.call("kk_bucket_embed_add_fwd", xf, pitch.clamp(0.0, 1.0), energy.clamp(0.0, 1.0), P[f"{VA}.pitch_bins"],
+                    P[f"{VA}.energy_bins"], P[f"{VA}.pitch_embedding.weight"], P[f"{VA}.energy_embedding.weight"], lens, memory,
+                    pidx, eidx, fm2, B, T, H, d.var_bins, _b16(memory))
+            self._cross_kv_fwd_all(memory, Nd, T, ddt)             # cross-attention K|V of every layer, normalised
+            # ---- generation bounds (model.py:741-750) ----
+            min_expected = max(min_len_floor, int(expected * min_len_ratio))
+            max_expected = min(max_len, max(expected + 80, int(expected * max_len_ratio)), max_len_cap)
+            if max_expected <= min_expected:
+                max_expected = min(max_len, min_expected + 1)
+            if max_expected > d.max_len:
+                raise ValueError(f"generation bound {max_expected} exceeds the positional table ({d.max_len})")
+            cos, sin = self._rope_tables(max_expected)
+            BH = B * H
+            Kc = [self._buf(f"gen.dec{i}.kcache", max_expected, BH, dtype=ddt) for i in range(d.dec_layers)]
+            Vc = [self._buf(f"gen.dec{i}.vcache", max_expected, BH, dtype=ddt) for i in range(d.dec_layers)]
+            mel_out = self._buf("gen.mel", B, max_expected + 1, M)                 # row 0 = the all-zero first input
+            mel_out.zero_()
+            stop_logit = self._buf("gen.stop", max_expected, B)
+            y = self._buf("gen.y", B, H)
+            frames = max_expected
+            done = 0
+            for t in range(max_expected):
+                # mel_projection_in + positional encoding at offset t (model.py:541-545)
+                self._linear(mel_out[:, t], self._W("mel_projection_in.weight"), P["mel_projection_in.bias"], y, res=pe[t:t + 1], res_mod=1)
+                n1 = self._ln_fwd("gen.dec0.ln1", y, "decoder.layers.0.norm1", ddt)
+                yl = y
+                for i in range(d.dec_layers):
+                    pf, key = f"decoder.layers.{i}", f"gen.dec{i}"
+                    gq, gk, gv = P[pf + ".self_attn.q_norm.weight"], P[pf + ".self_attn.k_norm.weight"], P[pf + ".self_attn.v_norm.weight"]
+                    raw, nrm = self._buf(key + ".qkv_raw", B, 3 * H, dtype=ddt), self._buf(key + ".qkv_n", B, 3 * H, dtype=ddt)
+                    self._proj_headnorm(n1, self._Wf(pf + ".self_attn.w_q.weight", 3), raw, nrm, 1, (gq, gk, gv), 2, cos[t:t + 1], sin[t:t + 1])
+                    qb = self._buf(key + ".q", 1, BH, dtype=ddt)
+                    qb.view(B, H).copy_(nrm[:, :H])
+                    Kc[i][t].view(B, H).copy_(nrm[:, H:2 * H])
+                    Vc[i][t].view(B, H).copy_(nrm[:, 2 * H:])
+                    ctx, lse = self._buf(key + ".ctx", 1, BH, dtype=ddt), self._buf(key + ".lse", 1, B * h, 1)
+                    kk.call("kk_attn_fwd", qb, Kc[i], Vc[i], ctx, lse, 1, B * h, 1, t + 1, BH, BH, BH, BH, None, 0, 0.125, self.rng, 0, 0.0,
+                            self.math, _b16(qb))
+                    proj = self._buf("tmp.gen_proj", B, H)
+                    self._linear(ctx.view(B, H), self._W(pf + ".self_attn.w_o.weight"), P[pf + ".self_attn.w_o.bias"], proj)
+                    ya = self._buf(key + ".xa", B, H)
+                    n2 = self._sublayer_tail(proj, yl, ya, 1, 0, 0.0, 0.0, 0.0, None, None, (key + ".ln2", pf + ".norm2", ddt))
+                    yc = self._buf(key + ".xc", B, H)
+                    n3 = self._attn_fwd(key + ".ca", pf + ".cross_attn", n2, memory, B, 1, T, False, False, fm2, ya, yc,
+                                        next_ln=(key + ".ln3", pf + ".norm3", ddt), layer=i)
+                    yo = self._buf(key + ".xo", B, H)
+                    nxt = ((f"gen.dec{i + 1}.ln1", f"decoder.layers.{i + 1}.norm1", ddt) if i + 1 < d.dec_layers
+                           else ("gen.dec.norm", "decoder.norm", ddt))
+                    n1 = self._ffn_fwd(key + ".ff", pf + ".ff", n3, yc, yo, d.dec_ff, 1, next_ln=nxt)
+                    yl = yo
+                dec_out = n1
+                self._linear(dec_out, self._W("mel_projection_out.weight"), P["mel_projection_out.bias"], mel_out[:, t + 1])
+                kk.call("kk_rowdot_fwd", dec_out, P["stop_token_predictor.weight"], P["stop_token_predictor.bias"], None, stop_logit[t],
+                        B, H, 1, 0, _b16(dec_out))
+                if (t + 1) % check_every == 0 or t + 1 == max_expected:
+                    sp = torch.sigmoid(stop_logit[done:t + 1]).mean(dim=1).cpu().tolist()
+                    mel_host = mel_out[:, 1:t + 2].float().cpu() if t + 1 >= 30 else None
+                    stop_at = None
+                    for tt in range(done, t + 1):
+                        if tt < min_expected:
+                            continue
+                        thr = stop_threshold if tt < expected else min(stop_threshold, post_expected_stop_threshold)
+                        if sp[tt - done] > thr:
+                            stop_at = tt
+                            break
+                        if tt + 1 >= 30 and float(mel_host[:, tt - 29:tt + 1].mean()) < -9.5:
+                            stop_at = tt
+                            break
+                    done = t + 1
+                    if stop_at is not None:
+                        frames = stop_at + 1
+                        break
+            return mel_out[:, 1:frames + 1].clamp(min=-11.5, max=2.0).clone()
+        finally:
+            self.train_dropout = saved_drop
+
     # ------------------------------------------------------------------ optimizer boundary
     def _opt_cfg(self, mel_length: int) -> kk.KkOptCfg:
         hp = self.hp

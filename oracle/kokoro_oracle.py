@@ -535,6 +535,116 @@ def forward(P: Dict[str, Tensor], Bf: Dict[str, Tensor], batch: Dict[str, Tensor
 
 
 # --------------------------------------------------------------------------------------
+# Inference: KokoroModel.forward_inference (model/model.py:676-790) + KokoroGenerator.generate
+# (model/generator.py:24-127) with the decoder's incremental (KV-cache) path
+# (transformers.py:237-277, 527-536, 543-583, 622-660)
+# --------------------------------------------------------------------------------------
+def encode_for_inference(P: Dict[str, Tensor], Bf: Dict[str, Tensor], ids: Tensor, stress: Optional[Tensor],
+                         d: ModelDims) -> Dict[str, Tensor]:
+    """encode_text + VarianceAdaptor.forward with no targets (variance_predictor.py:338-439): the model's own
+    durations clamp(round(expm1(log_dur)), 0) drive the length regulator, its own clamped pitch / energy
+    predictions pick the embeddings."""
+    H = d.hidden
+    va = "duration_adaptor.variance_adaptor"
+    pe = Bf["positional_encoding.pe"][0]
+    Pn = ids.shape[1]
+    text_mask = ids == 0
+    x = F.embedding(ids, P["text_embedding.weight"]) * (H ** 0.5)
+    if stress is not None:
+        x = x + F.embedding(stress, P["stress_embedding.weight"], padding_idx=0)
+    x = x + pe[:Pn]
+    for i in range(d.enc_layers):
+        x = encoder_block(P, i, x, text_mask, d.heads)
+    enc = _ln(P, "encoder_norm", x)
+    log_dur = variance_predictor(P, f"{va}.duration_predictor", enc, text_mask)
+    dur = torch.clamp(torch.round(torch.expm1(log_dur)), min=0)
+    xf = length_regulate(enc, dur, None)
+    if xf.size(1) < 3:
+        xf = F.pad(xf, (0, 0, 0, 3 - xf.size(1)))
+    lengths = dur.long().sum(dim=1)
+    Lp = xf.size(1)
+    frame_mask = torch.arange(Lp).unsqueeze(0) >= lengths.unsqueeze(1)
+    pitch = variance_predictor(P, f"{va}.pitch_predictor", xf, frame_mask)
+    energy = variance_predictor(P, f"{va}.energy_predictor", xf, frame_mask)
+    pb = torch.bucketize(pitch.clamp(0.0, 1.0), Bf[f"{va}.pitch_bins"])
+    eb = torch.bucketize(energy.clamp(0.0, 1.0), Bf[f"{va}.energy_bins"])
+    memory = xf + F.embedding(pb, P[f"{va}.pitch_embedding.weight"]) + F.embedding(eb, P[f"{va}.energy_embedding.weight"])
+    memory = memory.masked_fill(frame_mask.unsqueeze(-1), 0.0)
+    return {"memory": memory, "mem_mask": frame_mask, "log_dur": log_dur, "durations": dur.long(), "pitch": pitch,
+            "energy": energy, "enc": enc}
+
+
+def _attn_step(P: Dict[str, Tensor], prefix: str, x: Tensor, heads: int, cache: Dict[str, Tensor]) -> Tensor:
+    """Self-attention of ONE new position against the cache (transformers.py:237-253, 260-277).  The reference keeps
+    raw K (normalised again every step — the same values) and normalised V; RoPE is applied with both offsets 0, so
+    the keys are rotated by their absolute positions 0..t while the single query is rotated by position 0 (= not at
+    all) — the inference-time behaviour of the reference, kept as is."""
+    B, _, H = x.shape
+    dk = H // heads
+    q = F.linear(x, P[f"{prefix}.w_q.weight"]).view(B, 1, heads, dk).transpose(1, 2)
+    k = F.linear(x, P[f"{prefix}.w_k.weight"]).view(B, 1, heads, dk).transpose(1, 2)
+    v = F.linear(x, P[f"{prefix}.w_v.weight"]).view(B, 1, heads, dk).transpose(1, 2)
+    v = _rms_norm(v, P[f"{prefix}.v_norm.weight"])
+    cache["k_raw"] = k if "k_raw" not in cache else torch.cat([cache["k_raw"], k], dim=2)
+    cache["v"] = v if "v" not in cache else torch.cat([cache["v"], v], dim=2)
+    q = _rms_norm(q, P[f"{prefix}.q_norm.weight"])
+    kk_ = _rms_norm(cache["k_raw"], P[f"{prefix}.k_norm.weight"])
+    Sk = kk_.shape[2]
+    cos, sin = rope_tables(Sk, dk)
+    q = q * cos[:1] + _rotate_half(q) * sin[:1]
+    kk_ = kk_ * cos[:Sk] + _rotate_half(kk_) * sin[:Sk]
+    probs = torch.softmax(torch.matmul(q, kk_.transpose(-2, -1)) / math.sqrt(dk), dim=-1)
+    ctx = torch.matmul(probs, cache["v"]).transpose(1, 2).contiguous().view(B, 1, H)
+    return F.linear(ctx, P[f"{prefix}.w_o.weight"], P[f"{prefix}.w_o.bias"])
+
+
+def generate(P: Dict[str, Tensor], Bf: Dict[str, Tensor], ids: Tensor, stress: Optional[Tensor], d: ModelDims, *,
+             max_len: int = 4000, stop_threshold: float = 0.5, min_len_ratio: float = 0.7, min_len_floor: int = 12,
+             max_len_ratio: float = 3.0, max_len_cap: int = 1600, post_expected_stop_threshold: float = 0.2,
+             want: bool = False):
+    """forward_inference: encode + expand by the predicted durations, then autoregressive decoding one frame at a
+    time until the stop head fires (mean sigmoid over the batch > threshold, only from min_expected_length on; the
+    threshold drops to min(threshold, post_expected) past the expected length), the last 30 frames are quiet
+    (mean < -9.5), or max_expected_length frames exist.  The frame that triggers the stop is kept.  Output clamped
+    to [-11.5, 2]."""
+    enc = encode_for_inference(P, Bf, ids, stress, d)
+    memory, mem_mask = enc["memory"], enc["mem_mask"]
+    B, expected = memory.shape[0], memory.shape[1]
+    min_expected = max(min_len_floor, int(expected * min_len_ratio))
+    max_expected = min(max_len, max(expected + 80, int(expected * max_len_ratio)), max_len_cap)
+    if max_expected <= min_expected:
+        max_expected = min(max_len, min_expected + 1)
+    pe = Bf["positional_encoding.pe"][0]
+    caches = [dict() for _ in range(d.dec_layers)]
+    frame = torch.zeros(B, 1, d.mel)
+    frames, stop_probs = [], []
+    for t in range(max_expected):
+        y = F.linear(frame, P["mel_projection_in.weight"], P["mel_projection_in.bias"]) + pe[t:t + 1]
+        for i in range(d.dec_layers):
+            p = f"decoder.layers.{i}"
+            y = y + _attn_step(P, f"{p}.self_attn", _ln(P, f"{p}.norm1", y), d.heads, caches[i])
+            y = y + attention(P, f"{p}.cross_attn", _ln(P, f"{p}.norm2", y), memory, d.heads, rope=False, causal=False,
+                              key_mask=mem_mask)
+            y = y + glu_ffn(P, f"{p}.ff", _ln(P, f"{p}.norm3", y))
+        out = _ln(P, "decoder.norm", y)
+        frame = F.linear(out, P["mel_projection_out.weight"], P["mel_projection_out.bias"])
+        stop = F.linear(out, P["stop_token_predictor.weight"], P["stop_token_predictor.bias"]).squeeze(-1)
+        frames.append(frame)
+        sp = float(torch.sigmoid(stop).mean())
+        stop_probs.append(sp)
+        if t >= min_expected:
+            thr = stop_threshold if t < expected else min(stop_threshold, post_expected_stop_threshold)
+            if sp > thr:
+                break
+            if len(frames) >= 30 and float(torch.cat(frames[-30:], dim=1).mean()) < -9.5:
+                break
+    mel = torch.cat(frames, dim=1).clamp(min=-11.5, max=2.0)
+    if want:
+        return mel, {**enc, "stop_probs": torch.tensor(stop_probs), "bounds": (min_expected, expected, max_expected)}
+    return mel
+
+
+# --------------------------------------------------------------------------------------
 # Losses (training/losses.py:9-216; criteria trainer.py:410-444)
 # --------------------------------------------------------------------------------------
 def _huber(x: Tensor, y: Tensor, delta: float) -> Tensor:

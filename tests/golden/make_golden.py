@@ -272,6 +272,42 @@ def section_model(tag: str, d: O.ModelDims, B, T, Pn, seed, ragged, save_step: b
     print(f"  wrote {tag}.npz")
 
 
+def section_inference(d: O.ModelDims, seed: int):
+    """forward_inference (autoregressive decode with the KV cache) of the reference on seeded weights: pins
+    oracle.generate and is the golden for KokoroEngine.generate.  Only inputs and outputs are stored; both sides
+    regenerate the weights from the seed."""
+    print(f"== inference: dims={d} seed={seed}")
+    model = ref_model(d)
+    missing, unexpected = model.load_state_dict(seeded_params(d, seed), strict=False)
+    assert not unexpected
+    model.eval()
+    P = {n: p.detach().clone() for n, p in model.named_parameters()}
+    Bf = O.make_buffers(d)
+    g = torch.Generator().manual_seed(seed)
+    ids1 = torch.randint(1, d.vocab, (1, 7), generator=g)
+    ids2 = torch.randint(1, d.vocab, (2, 9), generator=g)
+    ids2[1, 6:] = 0                                            # padded second sequence
+    st2 = torch.randint(0, 3, (2, 9), generator=g)
+    st2[ids2 == 0] = 0
+    cases = [("never_stops", ids1, None, dict(max_len=15, stop_threshold=2.0)),
+             ("stops_at_min_length", ids1, None, dict(max_len=60, stop_threshold=0.0)),
+             ("batch2_padded_stress", ids2, st2, dict(max_len=10, stop_threshold=2.0))]
+    save = {"dims": np.array([getattr(d, f) for f in d.__dataclass_fields__]), "seed": np.array(seed)}
+    for name, ids, stress, kw in cases:
+        with torch.no_grad():
+            ref = model.forward_inference(ids, stress_indices=stress, **kw)
+        mine, info = O.generate(P, Bf, ids, stress, d, want=True, **kw)
+        assert ref.shape == mine.shape, (name, ref.shape, mine.shape)
+        check(f"inference {name}: mel {tuple(ref.shape)}", mine, ref, 2e-5)
+        save[f"{name}/ids"] = ids.numpy()
+        if stress is not None:
+            save[f"{name}/stress"] = stress.numpy()
+        save[f"{name}/mel"] = ref.numpy()
+        save[f"{name}/durations"] = info["durations"].numpy()
+        save[f"{name}/kw"] = np.array([kw["max_len"], kw["stop_threshold"]], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "inference_tiny.npz"), **save)
+
+
 def section_tables():
     print("== tables at default dims")
     d = O.ModelDims()
@@ -454,6 +490,9 @@ def section_loss_known_answers():
 if __name__ == "__main__":
     tiny = O.ModelDims(vocab=59, mel=20, hidden=128, heads=2, enc_layers=2, dec_layers=2, enc_ff=96,
                        dec_ff=96, var_filter=32, var_kernel=3, var_bins=16, max_len=700)
+    if sys.argv[1:] == ["inference"]:                            # only the decode fixture
+        section_inference(tiny, seed=21)
+        sys.exit(0)
     section_surface()
     section_sampler()
     section_lengths()
@@ -467,4 +506,5 @@ if __name__ == "__main__":
     # default dims (49.4 M params), small ragged batch: weights regenerated from the seed on both sides
     section_model("full_dims", O.ModelDims(), B=2, T=96, Pn=12, seed=14, ragged=True, save_step=False, seeded=True)
     section_tables()
+    section_inference(tiny, seed=21)
     print("ALL REFERENCE CHECKS PASSED")
