@@ -846,8 +846,7 @@ class KokoroEngine:
 
         # ---- variance adaptor (variance_predictor.py:338-439) ----
         dur_pred = self._buf("out.log_dur", B, Pn)
-        col_e = self._buf("vp.col_enc", Ne, 3 * H, dtype=edt)
-        kk.call("kk_im2col3_fwd", enc, col_e, B, Pn, H, CHUNK, _b16(col_e))
+        col_e = self._buf("vp.col_enc", Ne, 3 * H, dtype=edt)      # (both conv unfolds are the predictors' inputs only: side stream)
         # (teacher forcing: the regulator and the embeddings below use the batch's durations / pitch / energy, so the three
         #  predictors feed only the losses and run on the side stream — see predictors())
         idx, lens, tot = (self._buf("lr.idx", B, T, dtype=torch.int64), self._buf("lr.lens", B, dtype=torch.int64),
@@ -862,7 +861,6 @@ class KokoroEngine:
                 d.var_bins, _b16(memory))
         pitch_pred, energy_pred = self._buf("out.pitch", B, T), self._buf("out.energy", B, T)
         col_f = self._buf("vp.col_frames", Nd, 3 * H, dtype=ddt)
-        kk.call("kk_im2col3_fwd", xf, col_f, B, T, H, CHUNK, _b16(col_f))
         spec_aug = self.train_dropout and hp.use_spec_augment and self.spec_augment_active
         if spec_aug:                                      # on the cross-attention memory only (model.py:636-639)
             kk.call("kk_specaug", memory, B, T, H, self.rng, 20, hp.spec_augment_time_mask_max, hp.spec_augment_freq_mask_max,
@@ -878,6 +876,8 @@ class KokoroEngine:
             yield ("begin", "side")
         with self._on_side_stream():                      # joined before the losses
             self._mark("side: predictors fwd start")
+            kk.call("kk_im2col3_fwd", enc, col_e, B, Pn, H, CHUNK, _b16(col_e))
+            kk.call("kk_im2col3_fwd", xf, col_f, B, T, H, CHUNK, _b16(col_f))
             self._varpred_fwd("vp.dur", f"{VA}.duration_predictor", enc, col_e, B, Pn, text_mask, dur_pred, 10, p_var)
             self._varpred_fwd("vp.pitch", f"{VA}.pitch_predictor", xf, col_f, B, T, fmask, pitch_pred, 12, p_var)
             self._varpred_fwd("vp.energy", f"{VA}.energy_predictor", xf, col_f, B, T, fmask, energy_pred, 14, p_var)
