@@ -221,6 +221,7 @@ def main():
                 json.dump({"total_ms_2_steps": tot, "kernels": {k: v for k, v in rows}, "shapes": {k: v for k, v in srows}}, f, indent=1)
     dp.barrier()
     if rank != 0:
+        dp.shutdown()
         return
     frames = world * B * T * args.steps
     fpf = FLOP_PER_FRAME.get((B, T, P))
@@ -246,7 +247,8 @@ def main():
         out["model_mfma_frac"] = round(frames / dt * fpf / 1e12 / world / (PEAK_BF16_TFLOPS if args.math == "bf16" else PEAK_F32_TFLOPS), 4)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(B, T, P)
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+    dp.shutdown()
 
 
 if __name__ == "__main__":

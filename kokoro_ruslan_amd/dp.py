@@ -117,3 +117,12 @@ def all_max(x: torch.Tensor) -> torch.Tensor:
 def barrier() -> None:
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+def shutdown() -> None:
+    """Tear the process group down (quietens the "destroy_process_group() was not called" warning at exit)."""
+    if dist.is_initialized():
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
