@@ -47,7 +47,8 @@ int kk_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, const 
 /* tuning hook for benchmarks: 128x128-tile threshold (tile count) and XCD-aware tile order on/off */
 int kk_gemm_tune(int tm_threshold, int xcd_swizzle);
 int kk_gemm_tune16(int enable, int thr128, int thr12864, int split_target);   /* same, for the bf16 x bf16 DMA-staged core */
-/* Weight gradients of several nn.Linear layers in one launch: for i < n,
+/* Weight gradients of several nn.Linear layers in one launch (what autograd computes one by one for w_q/w_k/w_v/w_o,
+ * transformers.py:131-136, and linear1/linear2, transformers.py:90-91): for i < n,
  *   dw_i[M_i, N_i] += dy_i[T_i, M_i]^T . x_i[T_i, N_i]      (bf16 dy / x, fp32 dw, like kk_gemm(ta=1, tb=1, beta=1)).
  * A layer's weight gradients have no consumer before the optimizer, so the engine queues them through the layer's
  * backward and issues them together (n <= 8): full-length reductions, no split-K atomics, one launch.  `descs` is a
@@ -68,12 +69,12 @@ int kk_gemm_tune_group(int split); /* tools: force the k-slice count of grouped 
 int kk_gemm_qkv_headnorm(int64_t T, int parts, int heads, int64_t K, const void *x, int64_t ldx, const void *W,
                          const float *bias, void *raw, int64_t ldraw, void *y, int64_t ldy, int S,
                          const float *const *gains, int rope_mask, const float *cos_t, const float *sin_t, void *stream);
-/* GLU feed-forward forward, fused: h1[T,2F] = x[T,K] . W[2F,K]^T + bias (saved for the backward, bf16) and the gated
+/* GLU feed-forward forward (GLUFeedForward.forward, transformers.py:105-108), fused: h1[T,2F] = x[T,K] . W[2F,K]^T + bias (saved for the backward, bf16) and the gated
  * product g[T,F] = gelu(h1[:, :F]) * h1[:, F:] * dropout mask (seed, site, p as in kk_glu_fwd) from one launch: every
  * workgroup owns a column block of BOTH halves.  bf16 operands and outputs.  Replaces kk_gemm + kk_glu_fwd. */
 int kk_gemm_linear_glu(int64_t T, int64_t F, int64_t K, const void *x, int64_t ldx, const void *W, const float *bias,
                        void *h1, void *g, int64_t ldg, const uint32_t *seed, uint32_t site, float p, void *stream);
-/* GLU feed-forward backward, fused: dG = dy[T,H] . W[H,F] (the linear2 dgrad; bf16 operands, W row-major [H,F]) with the
+/* GLU feed-forward backward (autograd of transformers.py:105-108), fused: dG = dy[T,H] . W[H,F] (the linear2 dgrad; bf16 operands, W row-major [H,F]) with the
  * gate's backward as the epilogue — dh1[T,2F] is written directly from h1[T,2F] = [a | b] saved by the forward and the
  * gate's dropout mask (seed, site, p as in kk_glu_fwd); the column sums of dh1 (linear1's bias gradient) go to
  * partials[kk_gemm_dgrad_glu_blocks(T)][2F] for kk_partials_reduce.  Replaces kk_gemm + kk_glu_bwd + kk_colsum_acc. */
@@ -338,7 +339,7 @@ int kk_cast_f32_bf16(const float *src, void *dst, int64_t n, void *stream);
 /* ---- misc ---- */
 /* *slot = device wall clock (100 MHz ticks) at the time this launch executes: in-graph time stamps for timelines. */
 int kk_timestamp(uint64_t *slot, void *stream);
-/* n <= 16 device-to-device copies (dst[i] <- src[i], bytes[i] each; host arrays of device pointers) as one launch:
+/* (replaces the per-tensor `.to(device)` / copy of a batch dict, trainer.py:2257-2290)  n <= 16 device-to-device copies (dst[i] <- src[i], bytes[i] each; host arrays of device pointers) as one launch:
  * the hand-over of a batch's tensors into the buffers the captured step reads. */
 int kk_copy_many(const void *const *src, void *const *dst, const int64_t *bytes, int n, void *stream);
 int kk_axpby(float a, const float *x, float b, float *y, int64_t n, void *stream); /* y = a*x + b*y */
