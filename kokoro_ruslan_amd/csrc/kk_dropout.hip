@@ -79,14 +79,22 @@ __global__ __launch_bounds__(256) void sublayer_out_fwd_kernel(SubOutArgs a) {
     const uint32_t t1 = kk_drop_threshold(a.d.p1), t2 = kk_drop_threshold(a.d.p2);
     const float k1 = a.d.p1 > 0.f ? 1.f / (1.f - a.d.p1) : 1.f, k2 = a.d.p2 > 0.f ? 1.f / (1.f - a.d.p2) : 1.f;
     const TY *yr = static_cast<const TY *>(a.y) + row * H;
-    float4 v[NV];
+    // every global load of the row is issued here, before the first reduction: the kernel is three dependent phases
+    // (RMS statistic -> residual add -> LayerNorm) and was paying one memory latency per phase
+    float4 v[NV], rres[NV], gg[NV], lg[NV], lb[NV];
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = lane * 4 + 256 * i;
-        v[i] = c < H ? ldv4<TY>(yr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        q += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        v[i] = c < H ? ldv4<TY>(yr + c) : z;
+        rres[i] = c < H ? ld4(a.res + row * H + c) : z;
+        gg[i] = (a.gain && c < H) ? ld4(a.gain + c) : z;
+        lg[i] = (a.ln_gamma && c < H) ? ld4(a.ln_gamma + c) : z;
+        lb[i] = (a.ln_gamma && c < H) ? ld4(a.ln_beta + c) : z;
     }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) q += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
     float rs = 1.f;
     if (a.gain) {
         rs = 1.f / sqrtf(wave_sum(q) / (float)H + FLT_EPSILON);
@@ -100,10 +108,10 @@ __global__ __launch_bounds__(256) void sublayer_out_fwd_kernel(SubOutArgs a) {
         if (c < H) {
             float o[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
             if (a.gain) {
-                const float4 g = ld4(a.gain + c);
+                const float4 g = gg[i];
                 o[0] = o[0] * rs * g.x; o[1] = o[1] * rs * g.y; o[2] = o[2] * rs * g.z; o[3] = o[3] * rs * g.w;
             }
-            const float4 r = ld4(a.res + row * H + c);
+            const float4 r = rres[i];
             const float rr[4] = {r.x, r.y, r.z, r.w};
             float m1[4], m2[4];
             kk_drop_mul4(seed, a.d.site1, (uint64_t)row * H + c, t1, k1, m1);
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(256) void sublayer_out_fwd_kernel(SubOutArgs a) {
     for (int i = 0; i < NV; ++i) {
         const int c = lane * 4 + 256 * i;
         if (c < H) {
-            const float4 g = ld4(a.ln_gamma + c), b = ld4(a.ln_beta + c);
+            const float4 g = lg[i], b = lb[i];
             stv4<TN>(nr + c, make_float4((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
                                          (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w));
         }
