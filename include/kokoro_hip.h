@@ -311,6 +311,9 @@ typedef struct KkOptCfg {
 #define KK_OS_LAST_CLIP_NORM 8
 #define KK_OS_EXPL_EMA_VALID 9
 #define KK_OS_ATTEMPT 10      /* optimizer-step boundaries reached so far (successful = ATTEMPT - SKIPPED) */
+#define KK_OS_BAD_SEG 11      /* diagnostics of the most recent skipped boundary: 1 + first segment with a non-finite norm, */
+#define KK_OS_BAD_COUNT 12    /* how many segments had one, */
+#define KK_OS_BAD_ATTEMPT 13  /* and the boundary index (ATTEMPT) at which it happened */
 #define KK_OS_SIZE 16
 /* sumsq[seg] (double, zeroed by the call) = sum of squares of each arena segment of `buf`. */
 int kk_seg_sumsq(const float *buf, const int32_t *block_seg, int64_t nblocks, double *sumsq, int nseg,

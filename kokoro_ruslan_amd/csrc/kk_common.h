@@ -34,6 +34,12 @@ void kk_gemm16_tune_group(int split);
 int kk_gemm16_qkv_headnorm(int64_t T, int parts, int heads, int64_t K, const void *x, int64_t ldx, const void *W, const float *bias,
                            void *raw, int64_t ldraw, void *y, int64_t ldy, int S, const float *const *gains, int rope_mask,
                            const float *cos_t, const float *sin_t, int xcd_swizzle, hipStream_t s);
+// Zero `bytes` bytes at `p` (4-byte aligned, bytes % 4 == 0) with an ordinary kernel launch.  Used instead of
+// hipMemsetAsync everywhere: inside a captured hipGraph that is launched again while its previous launch is still in
+// flight, the runtime's memset node occasionally left the unaligned tail of the range (the last bytes % 32) holding
+// garbage — measured on the 311-double gradient-norm vector (3 stale doubles, one NaN, ~12 skipped optimizer steps in
+// 1 of 7 runs of 600 steps; tools/probes/skip_stress.py).
+int kk_zero_async(void *p, size_t bytes, hipStream_t s);
 int kk_gemm16_linear_glu(int64_t T, int64_t F, int64_t K, const void *x, int64_t ldx, const void *W, const float *bias, void *h1,
                          void *g, int64_t ldg, const uint32_t *seed, uint32_t site, float p, int xcd_swizzle, hipStream_t s);
 // dX = dY.W fused with the GLU gate's backward (see kk_gemm16.hip)

@@ -76,3 +76,30 @@ extern "C" int kk_timestamp(uint64_t *slot, void *stream) {
     KK_LAUNCH_CHECK("kk_timestamp");
     return 0;
 }
+
+namespace {
+__global__ __launch_bounds__(256) void zero_words_kernel(uint32_t *p, size_t words) {
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4, stride = (size_t)gridDim.x * 256 * 4;
+    const bool aligned = ((uintptr_t)p & 15) == 0;
+    for (size_t i = i0; i < words; i += stride) {
+        if (aligned && i + 4 <= words) {
+            const u32x4_t z = {0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4_t *>(p + i) = z;
+        } else {
+            for (size_t j = i; j < i + 4 && j < words; ++j) p[j] = 0u;
+        }
+    }
+}
+}  // namespace
+int kk_zero_async(void *p, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return 0;
+    if (!p || ((uintptr_t)p & 3) || (bytes & 3)) return kk_fail(KK_EINVAL, "kk_zero_async: needs a 4-byte aligned range");
+    const size_t words = bytes / 4;
+    size_t blocks = (words + 1023) / 1024;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<uint32_t *>(p), words);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return kk_fail((int)e, "kk_zero_async: launch failed: %s", hipGetErrorString(e));
+    return 0;
+}

@@ -409,8 +409,8 @@ extern "C" int kk_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, float al
     a.k_per_split = k_per_split;
     a.atomic = splits > 1 ? 1 : 0;
     if (splits > 1 && beta == 0.f) {
-        hipError_t e = hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), s);
-        if (e != hipSuccess) return kk_fail((int)e, "kk_gemm: memset: %s", hipGetErrorString(e));
+        const int e = kk_zero_async(C, (size_t)M * N * sizeof(float), s);
+        if (e != 0) return e;
     }
     a.tiles_m = kk_cdiv(M, TM);
     a.tiles_n = kk_cdiv(N, TM);

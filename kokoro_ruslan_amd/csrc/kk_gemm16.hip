@@ -530,8 +530,8 @@ int kk_gemm16_launch(int ta, int tb, int64_t M, int64_t N, int64_t K, float alph
     a.a_bytes = (uint32_t)(((ta ? (K - 1) * lda + M : (M - 1) * lda + K)) * 2);
     a.b_bytes = (uint32_t)(((tb ? (K - 1) * ldb + N : (N - 1) * ldb + K)) * 2);
     if (splits > 1 && beta == 0.f) {
-        hipError_t e = hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), s);
-        if (e != hipSuccess) return kk_fail((int)e, "kk_gemm: memset: %s", hipGetErrorString(e));
+        const int e = kk_zero_async(C, (size_t)M * N * sizeof(float), s);
+        if (e != 0) return e;
     }
     dim3 grid(a.tiles_m * a.tiles_n * splits);
     const int ns = ktiles / splits < 3 ? 2 : g16_stages;        // (a short reduction gains nothing from depth)

@@ -152,8 +152,8 @@ extern "C" int kk_losses_fwd(const float *mel_pred, const float *mel_tgt, const 
                              void *stream) {
     KK_REQUIRE(B > 0 && T > 0 && P > 0 && M > 0 && cfg, "kk_losses_fwd: bad args");
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(acc, 0, 10 * sizeof(double), s);
-    if (e != hipSuccess) return kk_fail((int)e, "kk_losses_fwd: memset failed");
+    const int e = kk_zero_async(acc, 10 * sizeof(double), s);
+    if (e != 0) return e;
     LossArgs a = pack(mel_pred, mel_tgt, dur_pred, dur, stop_logit, stop_tgt, pitch_pred, pitch_tgt, energy_pred,
                       energy_tgt, mel_len, ph_len, B, T, P, M, cfg);
     int blocks = kk_cdiv((int64_t)B * T * M, 256 * 8);

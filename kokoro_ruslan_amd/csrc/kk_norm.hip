@@ -653,8 +653,8 @@ extern "C" int kk_groupnorm_relu_fwd(const float *x, const float *gamma, const f
     KK_REQUIRE(B > 0 && L > 0 && C > 0 && C % 4 == 0 && chunk > 0 && p >= 0.f && p < 1.f, "kk_groupnorm_relu_fwd: bad shape");
     hipStream_t s = (hipStream_t)stream;
     const int nch = kk_cdiv(L, chunk), total = B * nch;
-    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * 2 * total, s);
-    if (e != hipSuccess) return kk_fail((int)e, "kk_groupnorm_relu_fwd: memset failed");
+    const int e = kk_zero_async(scratch, sizeof(double) * 2 * total, s);
+    if (e != 0) return e;
     const int slices = 32;
     hipLaunchKernelGGL(gn_partial_kernel, dim3(slices, total), dim3(256), 0, s, x, scratch, L, C, chunk, nch, slices);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(kk_cdiv(total, 64)), dim3(64), 0, s, scratch, stats, L, C, chunk, nch, total);
@@ -675,8 +675,8 @@ extern "C" int kk_groupnorm_relu_bwd(const float *dy, const float *x, const floa
     KK_REQUIRE(C <= 256 && 256 % C == 0, "kk_groupnorm_relu_bwd: C=%d must divide 256", C);
     hipStream_t s = (hipStream_t)stream;
     const int nch = kk_cdiv(L, chunk), total = B * nch;
-    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * 2 * total, s);
-    if (e != hipSuccess) return kk_fail((int)e, "kk_groupnorm_relu_bwd: memset failed");
+    const int e = kk_zero_async(scratch, sizeof(double) * 2 * total, s);
+    if (e != 0) return e;
     // 16 slabs x (b, chunk): a thin grid on purpose.  This runs on the side branch beside the decoder backward; with 64 or
     // 128 slabs the kernel itself is 4x faster and the train step 1 % SLOWER (796K -> 790K -> 786K frames/s) — a burst of
     // workgroups disturbs the critical chain more than a long thin launch does; 8 and 4 slabs are slower again.

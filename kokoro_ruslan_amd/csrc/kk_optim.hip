@@ -81,9 +81,13 @@ __global__ __launch_bounds__(256) void opt_prepare_kernel(const double *__restri
     __shared__ double red[4];
     __shared__ double sh[4];   // coef, base_lr, bc1, skip
     double part = 0.0, bad = 0.0;
+    __shared__ int first_bad;
+    if (threadIdx.x == 0) first_bad = 0x7fffffff;
+    __syncthreads();
     for (int i = threadIdx.x; i < nseg; i += 256) {
         const double ss = grad_sumsq[i];
         const bool fin = isfinite(ss);
+        if (!fin) atomicMin(&first_bad, i);
         double nr = sqrt(ss), sc = 1.0;
         const double pre = (double)seg_preclip[i];
         if (pre > 0.0 && fin && nr > pre) sc = pre / (nr + 1e-12);
@@ -129,7 +133,12 @@ __global__ __launch_bounds__(256) void opt_prepare_kernel(const double *__restri
         step_consts[2] = (float)c.eps;
         step_consts[3] = (float)blr;
         st[KK_OS_ATTEMPT] = attempt + 1.0;
-        if (skip) st[KK_OS_SKIPPED] += 1.0;
+        if (skip) {
+            st[KK_OS_SKIPPED] += 1.0;
+            st[KK_OS_BAD_SEG] = (double)(first_bad + 1);
+            st[KK_OS_BAD_COUNT] = nbad;
+            st[KK_OS_BAD_ATTEMPT] = attempt;
+        }
         st[KK_OS_LAST_GRAD_NORM] = total;
         st[KK_OS_LAST_CLIP_COEF] = coef;
         st[KK_OS_LAST_SKIP] = skip ? 1.0 : 0.0;
@@ -225,8 +234,8 @@ extern "C" int kk_seg_sumsq(const float *buf, const int32_t *block_seg, int64_t 
                             void *stream) {
     KK_REQUIRE(buf && block_seg && sumsq && nblocks > 0 && nseg > 0, "kk_seg_sumsq: bad args");
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(sumsq, 0, sizeof(double) * nseg, s);
-    if (e != hipSuccess) return kk_fail((int)e, "kk_seg_sumsq: memset failed");
+    const int e = kk_zero_async(sumsq, sizeof(double) * nseg, s);
+    if (e != 0) return e;
     int wgs = 2048;
     const int per = kk_cdiv(nblocks, wgs);
     wgs = kk_cdiv(nblocks, per);
@@ -254,8 +263,8 @@ extern "C" int kk_adamw_ema(float *p, const float *g, float *m, float *v, float 
     KK_REQUIRE(p && g && m && v && block_seg && nblocks > 0 && nblocks < (1ll << 31), "kk_adamw_ema: bad args");
     hipStream_t s = (hipStream_t)stream;
     if (p_sumsq) {
-        hipError_t e = hipMemsetAsync(p_sumsq, 0, sizeof(double) * nseg, s);
-        if (e != hipSuccess) return kk_fail((int)e, "kk_adamw_ema: memset failed");
+        const int e = kk_zero_async(p_sumsq, sizeof(double) * nseg, s);
+        if (e != 0) return e;
     }
     hipLaunchKernelGGL(adamw_ema_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, p, g, m, v, ema, block_seg, seg_gscale,
                        seg_decay, seg_stepsize, seg_flags, step_consts, beta1, beta2, ema_decay, p_sumsq, reinterpret_cast<__bf16 *>(p_bf16));

@@ -19,7 +19,8 @@ LIB_PATH = os.path.join(HERE, "libkokoro_hip.so")
 KK_MATH_F32, KK_MATH_BF16 = 0, 1
 KK_SEG_ALIGN = 1024
 OS = dict(SKIPPED=0, EXPL_EMA=1, EXPL_EMA_STEPS=2, EXPL_STREAK=3, LAST_GRAD_NORM=4, LAST_CLIP_COEF=5,
-          LAST_SKIP=6, LAST_BASE_LR=7, LAST_CLIP_NORM=8, EXPL_EMA_VALID=9, ATTEMPT=10, SIZE=16)
+          LAST_SKIP=6, LAST_BASE_LR=7, LAST_CLIP_NORM=8, EXPL_EMA_VALID=9, ATTEMPT=10, BAD_SEG=11, BAD_COUNT=12,
+          BAD_ATTEMPT=13, SIZE=16)
 
 
 class KkLossCfg(C.Structure):
