@@ -951,6 +951,11 @@ class KokoroEngine:
         def side_backward(after):                         # independent of the decoder backward (disjoint gradient segments)
             with self._on_side_stream(after=after):
                 self._mark("side: backward start")
+                # the output heads' weight gradients have no consumer on the decoder chain (the stop head's input is
+                # detached, model.py:561-562): 50 us off the critical path
+                kk.call("kk_rowdot_bwd", dstop, dec_out, P["stop_token_predictor.weight"], None, None, G["stop_token_predictor.weight"],
+                        G["stop_token_predictor.bias"], Nd, H, T, 0, _b16(dec_out))
+                self._wgrad(dmel.view(Nd, M), dec_out, G["mel_projection_out.weight"], G["mel_projection_out.bias"])
                 self._varpred_bwd("vp.pitch", f"{VA}.pitch_predictor", dpitch, xf, col_f, B, T, fmask, None, p_var)
                 self._varpred_bwd("vp.energy", f"{VA}.energy_predictor", denergy, xf, col_f, B, T, fmask, None, p_var)
                 d_enc = self._buf("g.enc_out", Ne, H)
@@ -987,11 +992,9 @@ class KokoroEngine:
         # (data-parallel overlap) the early ranges must be final at the pause, so there the side branch goes first.
         if yield_at is not None:
             side_backward(None)
-        # heads (model.py:561-562): the stop head's input is detached
-        kk.call("kk_rowdot_bwd", dstop, dec_out, P["stop_token_predictor.weight"], None, None, G["stop_token_predictor.weight"],
-                G["stop_token_predictor.bias"], Nd, H, T, 0, _b16(dec_out))
+        # heads: only the mel projection's input gradient continues down the decoder (the two heads' weight gradients are
+        # on the side branch, see side_backward)
         d_dec_out = self._buf("tmp.d_dec_out", Nd, H, dtype=ddt)
-        self._wgrad(dmel.view(Nd, M), dec_out, G["mel_projection_out.weight"], G["mel_projection_out.bias"])
         self._dgrad(dmel.view(Nd, M), self._W("mel_projection_out.weight"), d_dec_out)
         dy = self._buf("g.dec_stream", Nd, H)          # gradient of the decoder residual stream, updated in place
         def dhead(kind, i):                            # (kind, ffn buffer key, parameter prefix, S, site, p, drop-path, dtype)
