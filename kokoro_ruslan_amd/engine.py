@@ -330,6 +330,13 @@ class KokoroEngine:
             return self.arena.P16[name]
         return self.arena.P[name]
 
+    def _Wconv(self, name: str, rows: int, cols: int) -> torch.Tensor:
+        """Conv1d(k=3) weight [C_out, C_in, 3] as the [C_out, 3*C_in] operand of the unfolded GEMM: the bf16 shadow when the
+        row length allows 16-byte fetches (the shape's last dim is 3, so _W would fall back to the fp32 master)."""
+        if self.use_shadow and cols % 8 == 0:
+            return self.arena.P16[name].view(rows, cols)
+        return self.arena.P[name].view(rows, cols)
+
     def _Wf(self, first: str, count: int) -> torch.Tensor:
         a = self.arena
         return a.fused(a.p16 if self.use_shadow else a.p, first, count)
@@ -690,7 +697,7 @@ class KokoroEngine:
         for li in range(2):
             c, y = self._buf(f"{key}.c{li}", rows, Fv), self._buf(f"{key}.y{li}", rows, Fv)
             stats = self._buf(f"{key}.st{li}", B * nch, 2)
-            self._linear(inp_col, self._W(f"{prefix}.conv_layers.{li}.weight").view(Fv, 3 * cin), P[f"{prefix}.conv_layers.{li}.bias"], c)
+            self._linear(inp_col, self._Wconv(f"{prefix}.conv_layers.{li}.weight", Fv, 3 * cin), P[f"{prefix}.conv_layers.{li}.bias"], c)
             kk.call("kk_groupnorm_relu_fwd", c, P[f"{prefix}.norms.{li}.weight"], P[f"{prefix}.norms.{li}.bias"], y, stats,
                     scratch, B, L, Fv, CHUNK, self.rng, site + li, p)
             if li == 0:
@@ -713,7 +720,7 @@ class KokoroEngine:
             col = self._buf(f"{key}.col2", rows, 3 * Fv, dtype=col1.dtype) if li == 1 else col1
             kk.call("kk_groupnorm_relu_bwd", dy, c, y, P[f"{prefix}.norms.{li}.weight"], stats, dc, G[f"{prefix}.norms.{li}.weight"],
                     G[f"{prefix}.norms.{li}.bias"], scratch, B, L, Fv, CHUNK, p)
-            W, dW = self._W(f"{prefix}.conv_layers.{li}.weight").view(Fv, 3 * cin), G[f"{prefix}.conv_layers.{li}.weight"].view(Fv, 3 * cin)
+            W, dW = self._Wconv(f"{prefix}.conv_layers.{li}.weight", Fv, 3 * cin), G[f"{prefix}.conv_layers.{li}.weight"].view(Fv, 3 * cin)
             self._wgrad(dc, col, dW, G[f"{prefix}.conv_layers.{li}.bias"])
             if li == 1 or dx is not None:
                 dcol = self._buf(f"tmp.vp_dcol{li}", rows, 3 * cin, dtype=col1.dtype)
