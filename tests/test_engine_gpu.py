@@ -172,6 +172,8 @@ def test_nonfinite_gradients_skip_the_step(eng_mod, golden_dir):
     st = e.opt_stats()
     assert st["last_skip"] == 1.0 and st["skipped"] == 1.0
     assert torch.equal(e.arena.p, before), "a skipped step must leave every parameter untouched"
+    # the device records which tensor caused the skip (first segment with a non-finite norm, how many, at which boundary)
+    assert e.arena.names[int(st["bad_seg"]) - 1] == "mel_projection_out.bias" and st["bad_count"] == 1.0 and st["bad_attempt"] == 0.0
 
 
 @pytest.mark.parametrize("storage", ["f32", "bf16-dec", "bf16"])
