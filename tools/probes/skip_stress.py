@@ -13,7 +13,7 @@ from kokoro_ruslan_amd.synthetic import synthetic_batch
 
 runs = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 b = {k: v.cuda() for k, v in synthetic_batch(8, 512, 64, seed=1234).items()}
-for mode in ("free",) * runs:
+for mode in ("free", "sync") * runs:
     e = KokoroEngine(ModelDims(), StepHyper(gradient_accumulation_steps=1), math_mode="bf16", total_steps=20000, seed=0)
     e.train_dropout = True
     ev = None
