@@ -205,7 +205,7 @@ int kk_groupnorm_relu_fwd(const float *x, const float *gamma, const float *beta,
                           float p, void *stream);
 int kk_groupnorm_relu_bwd(const float *dy, const float *x, const float *y, const float *gamma,
                           const float *stats, float *dx, float *dgamma, float *dbeta, double *scratch, int B,
-                          int L, int C, int chunk, float p, void *stream);
+                          int L, int C, int chunk, float p, int dx_bf16 /* dx is written as bf16 */, void *stream);
 /* out[r] = mask[r] ? 0 : dot(x[r,:], w) + b  (Linear(C->1) + masked_fill; also the stop head, model.py:562). */
 int kk_rowdot_fwd(const float *x, const float *w, const float *b, const uint8_t *mask, float *out,
                   int64_t rows, int C, int L, int chunk, int x_bf16, void *stream);

@@ -488,10 +488,11 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float *__rest
     }
 }
 
+template <typename TO>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                            const float *__restrict__ y, const float *__restrict__ gamma,
                                                            const float *__restrict__ stats, const double *__restrict__ scratch,
-                                                           float *__restrict__ dx, int64_t total4, int L, int C, int chunk, int nch,
+                                                           TO *__restrict__ dx, int64_t total4, int L, int C, int chunk, int nch,
                                                            float inv_keep) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
         const int64_t e = i * 4;
@@ -512,7 +513,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float *__restri
             o.z = rs * ((yv.z > 0.f ? d.z * g.z : 0.f) - m1 - (xv.z - mu) * rs * m2);
             o.w = rs * ((yv.w > 0.f ? d.w * g.w : 0.f) - m1 - (xv.w - mu) * rs * m2);
         }
-        st4(dx + e, o);
+        stv4<TO>(dx + e, o);
     }
 }
 
@@ -669,7 +670,7 @@ extern "C" int kk_groupnorm_relu_fwd(const float *x, const float *gamma, const f
 
 extern "C" int kk_groupnorm_relu_bwd(const float *dy, const float *x, const float *y, const float *gamma,
                                      const float *stats, float *dx, float *dgamma, float *dbeta, double *scratch,
-                                     int B, int L, int C, int chunk, float p, void *stream) {
+                                     int B, int L, int C, int chunk, float p, int dx_bf16, void *stream) {
     KK_REQUIRE(B > 0 && L > 0 && C > 0 && C % 4 == 0 && chunk > 0 && p >= 0.f && p < 1.f, "kk_groupnorm_relu_bwd: bad shape");
     const float inv_keep = 1.f / (1.f - p);
     KK_REQUIRE(C <= 256 && 256 % C == 0, "kk_groupnorm_relu_bwd: C=%d must divide 256", C);
@@ -686,8 +687,12 @@ extern "C" int kk_groupnorm_relu_bwd(const float *dy, const float *x, const floa
     const int64_t total4 = (int64_t)B * L * C / 4;
     int blocks = kk_cdiv(total4, 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, s, dy, x, y, gamma, stats, scratch, dx, total4, L, C,
-                       chunk, nch, inv_keep);
+    if (dx_bf16)
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, dy, x, y, gamma, stats, scratch,
+                           reinterpret_cast<__bf16 *>(dx), total4, L, C, chunk, nch, inv_keep);
+    else
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(blocks), dim3(256), 0, s, dy, x, y, gamma, stats, scratch, dx, total4, L, C,
+                           chunk, nch, inv_keep);
     KK_LAUNCH_CHECK("kk_groupnorm_relu_bwd");
     return 0;
 }

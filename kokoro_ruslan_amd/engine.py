@@ -710,7 +710,9 @@ class KokoroEngine:
         P, G, Fv = self.arena.P, self.arena.G, self.dims.var_filter
         rows, nch, H = B * L, -(-L // CHUNK), x.shape[1]
         scratch = self._buf("tmp.gn_scratch", 2 * B * nch, dtype=torch.float64)
-        dy, dc = self._buf("tmp.vp_dy", rows, Fv), self._buf("tmp.vp_dc", rows, Fv)
+        # bf16 mode: the conv gradients' GEMM operand is stored as bf16 like every other dY of the step (DMA GEMM core)
+        dc_dt = col1.dtype
+        dy, dc = self._buf("tmp.vp_dy", rows, Fv), self._buf("tmp.vp_dc", rows, Fv, dtype=dc_dt)
         y1 = self._buf(f"{key}.y1", rows, Fv)
         kk.call("kk_rowdot_bwd", dout, y1, P[f"{prefix}.linear.weight"], mask, dy, G[f"{prefix}.linear.weight"],
                 G[f"{prefix}.linear.bias"], rows, Fv, L, CHUNK, 0)
@@ -719,7 +721,7 @@ class KokoroEngine:
             cin = Fv if li == 1 else H
             col = self._buf(f"{key}.col2", rows, 3 * Fv, dtype=col1.dtype) if li == 1 else col1
             kk.call("kk_groupnorm_relu_bwd", dy, c, y, P[f"{prefix}.norms.{li}.weight"], stats, dc, G[f"{prefix}.norms.{li}.weight"],
-                    G[f"{prefix}.norms.{li}.bias"], scratch, B, L, Fv, CHUNK, p)
+                    G[f"{prefix}.norms.{li}.bias"], scratch, B, L, Fv, CHUNK, p, _b16(dc))
             W, dW = self._Wconv(f"{prefix}.conv_layers.{li}.weight", Fv, 3 * cin), G[f"{prefix}.conv_layers.{li}.weight"].view(Fv, 3 * cin)
             self._wgrad(dc, col, dW, G[f"{prefix}.conv_layers.{li}.bias"])
             if li == 1 or dx is not None:

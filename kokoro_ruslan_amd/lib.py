@@ -136,7 +136,7 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_im2col3_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "kk_im2col3_bwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "kk_groupnorm_relu_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _U, _F, _P],
-    "kk_groupnorm_relu_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "kk_groupnorm_relu_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "kk_rowdot_fwd": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
     "kk_rowdot_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
     "kk_bucket_embed_add_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],

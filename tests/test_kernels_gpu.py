@@ -416,7 +416,7 @@ def test_variance_predictor_chain(kk, L):
         col, c, y, stats, cin = acts[li]
         dc = torch.empty(rows, Fv, device="cuda")
         kk.call("kk_groupnorm_relu_bwd", dy, c, y, Pd[f"vp.norms.{li}.weight"], stats, dc, Gd[f"vp.norms.{li}.weight"],
-                Gd[f"vp.norms.{li}.bias"], scratch, B, L, Fv, 512, 0.0)
+                Gd[f"vp.norms.{li}.bias"], scratch, B, L, Fv, 512, 0.0, 0)
         kk.call("kk_gemm", 1, 1, Fv, 3 * cin, rows, 1.0, dc, Fv, col, 3 * cin, 1.0, Gd[f"vp.conv_layers.{li}.weight"], 3 * cin,
                 None, None, 0, 0, 0, 0, 0)
         kk.call("kk_colsum_acc", dc, Fv, rows, Fv, Gd[f"vp.conv_layers.{li}.bias"], 0)
@@ -586,8 +586,8 @@ def test_fused_dropout_masks_match_between_forward_and_backward(kk):
     dy = torch.randn(Bn * L, C, generator=g)
     a0, a1 = torch.empty(Bn * L, C, device="cuda"), torch.empty(Bn * L, C, device="cuda")
     gg0, gb0, gg1, gb1 = (torch.zeros(C, device="cuda") for _ in range(4))
-    kk.call("kk_groupnorm_relu_bwd", dev(dy * mask), dev(x), y0, dev(gam), st, a0, gg0, gb0, scr, Bn, L, C, 512, 0.0)
-    kk.call("kk_groupnorm_relu_bwd", dev(dy), dev(x), y1, dev(gam), st, a1, gg1, gb1, scr, Bn, L, C, 512, pv)
+    kk.call("kk_groupnorm_relu_bwd", dev(dy * mask), dev(x), y0, dev(gam), st, a0, gg0, gb0, scr, Bn, L, C, 512, 0.0, 0)
+    kk.call("kk_groupnorm_relu_bwd", dev(dy), dev(x), y1, dev(gam), st, a1, gg1, gb1, scr, Bn, L, C, 512, pv, 0)
     close(a1, a0, 1e-5, 1e-4, "groupnorm dropout backward")
     close(gg1, gg0, 1e-4, 1e-4, "groupnorm dropout dgamma")
 
