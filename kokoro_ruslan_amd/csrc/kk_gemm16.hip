@@ -17,6 +17,7 @@
 // Out-of-range rows (tile edges, the K tail of a k-strided operand) are zero-filled by the buffer bounds check.
 #include "kk_common.h"
 #include <algorithm>
+#include <stdlib.h>
 
 namespace {
 
@@ -53,9 +54,9 @@ struct G16Args {
 constexpr int BK = 64;
 
 // One operand tile of ROWS x 64: DMA issue + fragment reads.
-template <int ROWS, bool KS> struct Operand {
+template <int ROWS, bool KS, int NT = 256> struct Operand {
     static constexpr int BYTES = ROWS * BK * 2;
-    static constexpr int NP = ROWS / 32;                       // 16-byte pieces per thread per tile (256 threads)
+    static constexpr int NP = ROWS * 8 / NT;                   // 16-byte pieces per thread per tile (NT threads)
     static constexpr int PITCH = KS ? ROWS * 2 : BK * 2;        // bytes per LDS row
     uint32_t voff[NP];                                          // per-thread byte offset of each piece (tile 0)
     uint32_t kstep;                                             // bytes to advance per k-tile
@@ -66,7 +67,7 @@ template <int ROWS, bool KS> struct Operand {
         const int t = threadIdx.x;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-            const int p = t + 256 * j;
+            const int p = t + NT * j;
             if constexpr (!KS) {
                 const int row = p >> 3, c = (p & 7) ^ ((row >> 1) & 7);
                 voff[j] = (uint32_t)(((int64_t)(r0 + row) * ld + c * 8) * 2);
@@ -85,7 +86,7 @@ template <int ROWS, bool KS> struct Operand {
         const uint32_t so = (uint32_t)kt * kstep;
 #pragma unroll
         for (int j = 0; j < NP; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(dst + (wave * 64 + 256 * j) * 16), 16, voff[j], so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(dst + (wave * 64 + NT * j) * 16), 16, voff[j], so, 0, 0);
     }
 };
 
@@ -159,11 +160,13 @@ __device__ __forceinline__ void pin_frag(Frag &f, bool ks) {
 // EPI = 2: the GEMM is h1 = x.W1^T + b1 of a GLU feed-forward; a workgroup owns output columns [n0, n0+64) AND
 // [F+n0, F+n0+64) (two B panels, two accumulators, the A tile is read from LDS once for both), so its epilogue writes
 // h1 = [a | b] (saved for the backward) and the gated product g = gelu(a)*b*mask in one go.  Replaces kk_glu_fwd.
-template <bool TA, bool TB, int BM, int BN, int NS, int EPI>
+template <bool TA, bool TB, int BM, int BN, int NS, int EPI, int WAVES = 4>
 __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char *smem) {
-    constexpr int MI = BM / 64, NI = BN / 64;                  // 32x32 MFMA tiles per wave (wave tile = BM/2 x BN/2)
-    using OA = Operand<BM, TA>;
-    using OB = Operand<BN, TB>;
+    constexpr int WR = WAVES / 2;                               // waves along M (two along N)
+    constexpr int MI = BM / (32 * WR), NI = BN / 64;            // 32x32 MFMA tiles per wave (wave tile = BM/WR x BN/2)
+    static_assert(EPI == 0 || WAVES == 4, "the epilogue variants are written for four waves");
+    using OA = Operand<BM, TA, 64 * WAVES>;
+    using OB = Operand<BN, TB, 64 * WAVES>;
     constexpr int NB = EPI == 2 ? 2 : 1;                        // EPI == 2 multiplies A with TWO 64-row panels of B (see below)
     constexpr int STAGE = OA::BYTES + NB * OB::BYTES;
     constexpr int NPT = OA::NP + NB * OB::NP;                   // DMA instructions per thread per k-tile
@@ -201,7 +204,7 @@ __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char
     if constexpr (EPI == 2) ob2.init(a.B, a.b_bytes, a.ldb, n0 + a.N);
     FragAddr<BM, TA> fa;
     FragAddr<BN, TB> fb;
-    fa.init(lane, wr * (BM / 2));
+    fa.init(lane, wr * (BM / WR));
     fb.init(lane, wc * (BN / 2));
 
     f32x16 acc[MI][NI];
@@ -369,7 +372,7 @@ __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char
             const float bv = (a.bias != nullptr && lead) ? a.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wr * (BM / 2) + i * 32 + frag_row(r, half);
+                const int row = m0 + wr * (BM / WR) + i * 32 + frag_row(r, half);
                 if (row >= a.M) continue;
                 float v = a.alpha * acc[i][j][r] + bv;
                 if (a.residual != nullptr && lead) {
@@ -406,13 +409,15 @@ struct G16Group {
     int start[GROUP_MAX + 1];                                   // first workgroup of each problem
     G16Args p[GROUP_MAX];
 };
-template <bool TA, bool TB, int BM, int BN, int NS>
-__global__ __launch_bounds__(256) void gemm16_group_kernel(G16Group g) {
+template <bool TA, bool TB, int BM, int BN, int NS, int WAVES = 4>
+__global__ __launch_bounds__(64 * WAVES) void gemm16_group_kernel(G16Group g) {
     __shared__ __attribute__((aligned(16))) char smem[NS * (BM + BN) * BK * 2];
     int i = 0;
     while (i + 1 < g.n && (int)blockIdx.x >= g.start[i + 1]) ++i;
-    gemm16_body<TA, TB, BM, BN, NS, 0>(g.p[i], (int)blockIdx.x - g.start[i], smem);
+    gemm16_body<TA, TB, BM, BN, NS, 0, WAVES>(g.p[i], (int)blockIdx.x - g.start[i], smem);
 }
+template __global__ void gemm16_group_kernel<true, true, 128, 64, 2, 8>(G16Group);
+template __global__ void gemm16_group_kernel<true, true, 128, 128, 2, 8>(G16Group);
 template __global__ void gemm16_group_kernel<true, true, 64, 64, 2>(G16Group);
 template __global__ void gemm16_group_kernel<true, true, 64, 64, 3>(G16Group);
 template __global__ void gemm16_group_kernel<true, true, 128, 64, 2>(G16Group);
@@ -464,6 +469,7 @@ void launch_tile(int ta, int tb, const G16Args &a, dim3 grid, hipStream_t s) {
 // DMAs in flight beat the larger tiles' better bytes-per-flop.
 int g16_thr128 = 4096, g16_thr12864 = 4096, g16_split_target = 384, g16_stages = 3, g16_split_major = 0;
 int g16_group_tile = 1;                                         // grouped launches: 0 = 64x64, 1 = 128x64 (default: +1 % on the step), 2 = 128x128 tiles
+int g16_group_waves = getenv("KK_GROUP_WAVES") ? atoi(getenv("KK_GROUP_WAVES")) : 8;   // 8-wave workgroups on the 128-row tiles (4: the old form)
 int g16_group_split = 0;                                        // grouped launches: 0 = by the split target, n = n k-slices
 
 }  // namespace
@@ -618,7 +624,9 @@ int kk_gemm16_wgrad_group(const KkWgradDesc *d, int n, int xcd_swizzle, hipStrea
         g.start[i + 1] = g.start[i] + a.tiles_m * a.tiles_n * sp;
     }
     dim3 grid(g.start[n]);
-    if (BN == 128) hipLaunchKernelGGL((gemm16_group_kernel<true, true, 128, 128, 2>), grid, dim3(256), 0, s, g);
+    if (BN == 128 && g16_group_waves == 8) hipLaunchKernelGGL((gemm16_group_kernel<true, true, 128, 128, 2, 8>), grid, dim3(512), 0, s, g);
+    else if (BN == 128) hipLaunchKernelGGL((gemm16_group_kernel<true, true, 128, 128, 2>), grid, dim3(256), 0, s, g);
+    else if (BM == 128 && g16_group_waves == 8) hipLaunchKernelGGL((gemm16_group_kernel<true, true, 128, 64, 2, 8>), grid, dim3(512), 0, s, g);
     else if (BM == 128) hipLaunchKernelGGL((gemm16_group_kernel<true, true, 128, 64, 2>), grid, dim3(256), 0, s, g);
     else if (min_per < 3 || g16_stages < 3) hipLaunchKernelGGL((gemm16_group_kernel<true, true, 64, 64, 2>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((gemm16_group_kernel<true, true, 64, 64, 3>), grid, dim3(256), 0, s, g);
