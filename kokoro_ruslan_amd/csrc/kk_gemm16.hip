@@ -160,10 +160,10 @@ __device__ __forceinline__ void pin_frag(Frag &f, bool ks) {
 // EPI = 2: the GEMM is h1 = x.W1^T + b1 of a GLU feed-forward; a workgroup owns output columns [n0, n0+64) AND
 // [F+n0, F+n0+64) (two B panels, two accumulators, the A tile is read from LDS once for both), so its epilogue writes
 // h1 = [a | b] (saved for the backward) and the gated product g = gelu(a)*b*mask in one go.  Replaces kk_glu_fwd.
-template <bool TA, bool TB, int BM, int BN, int NS, int EPI, int WAVES = 4>
+template <bool TA, bool TB, int BM, int BN, int NS, int EPI, int WAVES = 4, int WC = 2>
 __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char *smem) {
-    constexpr int WR = WAVES / 2;                               // waves along M (two along N)
-    constexpr int MI = BM / (32 * WR), NI = BN / 64;            // 32x32 MFMA tiles per wave (wave tile = BM/WR x BN/2)
+    constexpr int WR = WAVES / WC;                              // waves along M x waves along N
+    constexpr int MI = BM / (32 * WR), NI = BN / (32 * WC);     // 32x32 MFMA tiles per wave (wave tile = BM/WR x BN/WC)
     static_assert(EPI == 0 || WAVES == 4, "the epilogue variants are written for four waves");
     using OA = Operand<BM, TA, 64 * WAVES>;
     using OB = Operand<BN, TB, 64 * WAVES>;
@@ -195,7 +195,7 @@ __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char
     const int kend = min(a.K, kbeg + a.k_per_split);
     const int nk = (kend - kbeg + BK - 1) / BK, kt0 = kbeg / BK;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wr = wave >> 1, wc = wave & 1, half = lane >> 5, l31 = lane & 31;
+    const int wr = wave / WC, wc = wave % WC, half = lane >> 5, l31 = lane & 31;
 
     OA oa;
     OB ob, ob2;
@@ -205,7 +205,7 @@ __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char
     FragAddr<BM, TA> fa;
     FragAddr<BN, TB> fb;
     fa.init(lane, wr * (BM / WR));
-    fb.init(lane, wc * (BN / 2));
+    fb.init(lane, wc * (BN / WC));
 
     f32x16 acc[MI][NI];
     f32x16 acc2;                                                // EPI == 2: the second B panel's accumulator (MI = NI = 1)
@@ -367,7 +367,7 @@ __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            const int col = n0 + wc * (BN / 2) + j * 32 + l31;
+            const int col = n0 + wc * (BN / WC) + j * 32 + l31;
             if (col >= a.N) continue;
             const float bv = (a.bias != nullptr && lead) ? a.bias[col] : 0.f;
 #pragma unroll
@@ -409,13 +409,14 @@ struct G16Group {
     int start[GROUP_MAX + 1];                                   // first workgroup of each problem
     G16Args p[GROUP_MAX];
 };
-template <bool TA, bool TB, int BM, int BN, int NS, int WAVES = 4>
+template <bool TA, bool TB, int BM, int BN, int NS, int WAVES = 4, int WC = 2>
 __global__ __launch_bounds__(64 * WAVES) void gemm16_group_kernel(G16Group g) {
     __shared__ __attribute__((aligned(16))) char smem[NS * (BM + BN) * BK * 2];
     int i = 0;
     while (i + 1 < g.n && (int)blockIdx.x >= g.start[i + 1]) ++i;
-    gemm16_body<TA, TB, BM, BN, NS, 0, WAVES>(g.p[i], (int)blockIdx.x - g.start[i], smem);
+    gemm16_body<TA, TB, BM, BN, NS, 0, WAVES, WC>(g.p[i], (int)blockIdx.x - g.start[i], smem);
 }
+template __global__ void gemm16_group_kernel<true, true, 128, 128, 2, 16, 4>(G16Group);
 template __global__ void gemm16_group_kernel<true, true, 128, 64, 2, 8>(G16Group);
 template __global__ void gemm16_group_kernel<true, true, 128, 128, 2, 8>(G16Group);
 template __global__ void gemm16_group_kernel<true, true, 64, 64, 2>(G16Group);
@@ -624,7 +625,8 @@ int kk_gemm16_wgrad_group(const KkWgradDesc *d, int n, int xcd_swizzle, hipStrea
         g.start[i + 1] = g.start[i] + a.tiles_m * a.tiles_n * sp;
     }
     dim3 grid(g.start[n]);
-    if (BN == 128 && g16_group_waves == 8) hipLaunchKernelGGL((gemm16_group_kernel<true, true, 128, 128, 2, 8>), grid, dim3(512), 0, s, g);
+    if (BN == 128 && g16_group_waves == 16) hipLaunchKernelGGL((gemm16_group_kernel<true, true, 128, 128, 2, 16, 4>), grid, dim3(1024), 0, s, g);
+    else if (BN == 128 && g16_group_waves == 8) hipLaunchKernelGGL((gemm16_group_kernel<true, true, 128, 128, 2, 8>), grid, dim3(512), 0, s, g);
     else if (BN == 128) hipLaunchKernelGGL((gemm16_group_kernel<true, true, 128, 128, 2>), grid, dim3(256), 0, s, g);
     else if (BM == 128 && g16_group_waves == 8) hipLaunchKernelGGL((gemm16_group_kernel<true, true, 128, 64, 2, 8>), grid, dim3(512), 0, s, g);
     else if (BM == 128) hipLaunchKernelGGL((gemm16_group_kernel<true, true, 128, 64, 2>), grid, dim3(256), 0, s, g);
