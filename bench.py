@@ -64,7 +64,7 @@ def kernel_table(records, math_bf16: bool):
         elif name == "kk_gemm_wgrad_group":             # (n, then M, N, T of every problem); 128x64 tiles, see kk_gemm16.hip
             dims = [int(x) for x in sc[1:]]
             probs = [dims[i:i + 3] for i in range(0, len(dims), 3)]
-            key = "gemm16_group_kernel<true,true,128,64,2> (a layer's dY^T.X wgrads, one launch)"
+            key = "gemm16_group_kernel<true,true,128,64,2,8> (a layer's dY^T.X wgrads, one launch)"
             flops = sum(2.0 * M * N * T_ for M, N, T_ in probs)
             byts = sum(2.0 * T_ * (M + N) + 8.0 * M * N for M, N, T_ in probs)          # bf16 operands, fp32 dW read + written
         elif name == "kk_gemm_linear_glu":              # (T, F, K, ...): h1 = x.W1^T (2F columns) + gate
