@@ -43,7 +43,7 @@ def cases():
             "kk_gemm", 1, 1, M, N, T, 1.0, dy, M, x, N, 1.0, dw, N, None, None, 0, 0, 0, 1, 3))
 
 
-configs = [("old", (0, 0, 0, 0)), ("dma default", (1, 256, 192, 768))]
+configs = [("old", (0, 0, 0, 0)), ("dma default", (1, 4096, 4096, 384))]
 for spec in sys.argv[2:]:
     a, b, c = (int(v) for v in spec.split(","))
     configs.append((f"dma {spec}", (1, a, b, c)))
