@@ -193,6 +193,13 @@ int kk_length_regulate_gather(const float *x, const int64_t *idx, float *out, in
                               void *stream);
 /* max over a non-negative int64 vector (trainer.py:2224 reads phoneme_durations.max()). */
 int kk_max_i64(const int64_t *x, int64_t n, int64_t *out, void *stream);
+/* Expanded length T' = max_b sum(dur_b) != mel length T (model.py:607-628; variance_predictor.py:354-372, 396-420;
+ * losses.py:111,137): dst[r, c] = c < cols_src ? src[r, c] : 0 for c < cols_dst — truncates the T'-frame pitch / energy
+ * predictions to the T columns the losses read, and zero-pads their loss gradients / the frame-level targets back to T'. */
+int kk_pad2d_f32(const float *src, int64_t lds, int cols_src, float *dst, int64_t ldd, int cols_dst, int64_t rows,
+                 void *stream);
+/* frame padding mask of the expanded sequence: mask[b, f] = (f >= lens[b])  (variance_predictor.py:363-369). */
+int kk_frame_mask(const int64_t *lens, uint8_t *mask, int B, int T, void *stream);
 
 /* ---- variance adaptor pieces (variance_predictor.py:89-115, 363-437) ---- */
 /* col[(b,l), c*3+k] = x[b, l+k-1, c] inside the 512-frame chunk of l, else 0. */

@@ -5,11 +5,13 @@ Reads the per-utterance `.pt` files the reference's `kokoro-precompute` writes u
 [P] i64, stop_token_targets/pitch/energy [T] f32, mel_length, phoneme_length, text, audio_file, _cache_version).
 The audio front-end, MFA alignment and the phonemizer that PRODUCE these files stay on the reference (out of scope).
 `collate_fn` reproduces the reference's zero-padded batch dict (data/dataset.py:871-921).  The frame-budget sampler
-uses the reference's cost heuristic batch_size * max_frames_in_batch <= max_frames (dataset.py:924-1010) on a
-length-sorted order; the reference's quantile bucketing / heavy-batch spreading refinements are not reproduced.
+restates the reference's DynamicFrameBatchSampler (dataset.py:924-1147: quantile buckets, greedy packing under
+batch_size * longest <= max_frames, heavy-batch spreading) and is pinned against it by tests/golden/sampler.json.
 """
 from __future__ import annotations
 
+import json
+import os
 import random
 from pathlib import Path
 from typing import Dict, Iterator, List, Optional, Sequence
@@ -20,21 +22,61 @@ FEATURE_CACHE_VERSION = 7
 _TENSOR_KEYS = ("mel_spec", "phoneme_indices", "stress_indices", "phoneme_durations", "stop_token_targets", "pitch", "energy")
 
 
-class CachedFeatureDataset:
-    def __init__(self, cache_dir: str, indices: Optional[Sequence[int]] = None, max_seq_length: int = 1800,
-                 memory_cache: bool = True):
-        self.dir = Path(cache_dir)
-        files = sorted(self.dir.glob("*.pt"))
-        if not files:
-            raise FileNotFoundError(f"no cached features (*.pt) under {self.dir}; run the reference's kokoro-precompute")
-        metas = []
-        for f in files:
+def clip_durations(dur: torch.Tensor, T: int) -> torch.Tensor:
+    """Durations of an utterance whose mel was cut to T frames: every phoneme keeps the frames that fall before the
+    cut, so sum(dur) == min(sum(dur), T) and the expansion is a prefix of the original one (the reference reconciles
+    sum(dur) with the clipped mel length when it builds a sample, data/dataset.py:704-707,769-776)."""
+    cum = torch.cumsum(dur.clamp(min=0), 0).clamp(max=T)
+    return torch.diff(cum, prepend=cum.new_zeros(1))
+
+
+def scan_cache(cache_dir: str) -> List[Dict]:
+    """[{file, audio_length, phoneme_length}] for every cached utterance, sorted by length (dataset.py:398).  Reading the
+    lengths means un-pickling every file once; the result is kept in a sidecar index next to the cache (file name, size,
+    mtime, lengths) so that later runs — and the train / validation views of one run — do not repeat that."""
+    d = Path(cache_dir)
+    files = sorted(d.glob("*.pt"))
+    if not files:
+        raise FileNotFoundError(f"no cached features (*.pt) under {d}; run the reference's kokoro-precompute")
+    index_path = d / ".kk_index.json"
+    known = {}
+    try:
+        known = {e["name"]: e for e in json.loads(index_path.read_text())["entries"]}
+    except Exception:
+        known = {}
+    metas, entries, dirty = [], [], False
+    for f in files:
+        st = f.stat()
+        e = known.get(f.name)
+        if e is None or e.get("size") != st.st_size or e.get("mtime") != int(st.st_mtime):
             it = torch.load(f, map_location="cpu", weights_only=False)
             ver = it.get("_cache_version")
             if ver != FEATURE_CACHE_VERSION:
                 raise RuntimeError(f"{f.name}: feature cache version {ver}, expected {FEATURE_CACHE_VERSION}")
-            metas.append({"file": f, "audio_length": int(it["mel_length"])})
-        metas.sort(key=lambda m: m["audio_length"])               # dataset.py:398 (sorted by length)
+            e = {"name": f.name, "size": st.st_size, "mtime": int(st.st_mtime), "mel_length": int(it["mel_length"]),
+                 "phoneme_length": int(it["phoneme_length"])}
+            dirty = True
+        entries.append(e)
+        metas.append({"file": f, "audio_length": e["mel_length"], "phoneme_length": e["phoneme_length"]})
+    if dirty:
+        try:
+            tmp = index_path.with_suffix(".tmp%d" % os.getpid())
+            tmp.write_text(json.dumps({"version": FEATURE_CACHE_VERSION, "entries": entries}))
+            os.replace(tmp, index_path)
+        except OSError:
+            pass                                                   # read-only cache directory: scan again next time
+    metas.sort(key=lambda m: m["audio_length"])                    # dataset.py:398 (sorted by length; stable)
+    return metas
+
+
+class CachedFeatureDataset:
+    def __init__(self, cache_dir: str, indices: Optional[Sequence[int]] = None, max_seq_length: int = 1800,
+                 memory_cache: bool = True, metas: Optional[List[Dict]] = None):
+        self.dir = Path(cache_dir)
+        metas = scan_cache(cache_dir) if metas is None else list(metas)
+        # the reference's metadata holds the CLIPPED length (dataset.py:325-327) and sorts by it
+        metas = sorted((dict(m, audio_length=min(int(m["audio_length"]), int(max_seq_length))) for m in metas),
+                       key=lambda m: m["audio_length"])
         if indices is not None:
             metas = [metas[i] for i in indices if i < len(metas)]  # dataset.py:403-405
         self.samples = metas
@@ -57,6 +99,7 @@ class CachedFeatureDataset:
             it["mel_spec"] = it["mel_spec"][:, :T]
             for k in ("stop_token_targets", "pitch", "energy"):
                 it[k] = it[k][:T]
+            it["phoneme_durations"] = clip_durations(it["phoneme_durations"], T)
             it["mel_length"] = T
         if self._mem is not None:
             self._mem[i] = it
@@ -83,6 +126,68 @@ def collate_fn(batch: List[Dict]) -> Dict[str, torch.Tensor]:
     out["mel_lengths"] = torch.tensor(mel_len, dtype=torch.long)
     out["phoneme_lengths"] = torch.tensor(ph_len, dtype=torch.long)
     return out
+
+
+# ---- the same batch, written straight into caller-provided (pinned) memory ------------------------------------------
+# collate_fn above is the reference's contract and what validation / tests use.  The train loop's loader thread needs the
+# batch in ONE pinned staging buffer and has a few milliseconds per batch, so it lays the nine tensors out in a flat byte
+# range (batch_layout) and fills them with plain numpy copies (collate_into): no intermediate tensors, no torch dispatch
+# (a torch op on a 128-core host wakes an OpenMP team for a 160 KB copy), per-utterance arrays prepared once.
+BATCH_KEYS = ("mel_specs", "pitches", "energies", "stop_token_targets", "phoneme_indices", "phoneme_durations",
+              "stress_indices", "mel_lengths", "phoneme_lengths")
+
+
+def sample_arrays(it: Dict) -> Dict:
+    """numpy views of one cached utterance, the mel already frame-major [T, M] (kept inside the item: built once)."""
+    a = it.get("_np")
+    if a is None:
+        import numpy as np
+        mel_T = np.ascontiguousarray(it["mel_spec"].numpy().T)
+        it["mel_spec"] = torch.from_numpy(mel_T).T                 # same memory: the [M, T] tensor is now a view of it
+        a = it["_np"] = {"mel": mel_T, "pitch": it["pitch"].numpy(), "energy": it["energy"].numpy(),
+                         "stop": it["stop_token_targets"].numpy(), "ids": it["phoneme_indices"].numpy(),
+                         "dur": it["phoneme_durations"].numpy(), "stress": it["stress_indices"].numpy()}
+    return a
+
+
+def batch_layout(items: List[Dict], max_mel: int = 1 << 30, max_ph: int = 1 << 30, align: int = 256):
+    """(B, T, P, M, mel_len, ph_len, plan, total_bytes) of the padded batch of `items`, sequence dimensions capped like
+    _cap_batch_sequence_dimensions (reference trainer.py:3364-3411); plan = [(key, byte offset, bytes, shape, dtype name)]."""
+    B = len(items)
+    mel_len = [min(int(it["mel_length"]), max_mel) for it in items]
+    ph_len = [min(int(it["phoneme_length"]), max_ph) for it in items]
+    T, P, M = max(mel_len), max(ph_len), int(items[0]["mel_spec"].shape[0])
+    shapes = {"mel_specs": ((B, T, M), "float32"), "pitches": ((B, T), "float32"), "energies": ((B, T), "float32"),
+              "stop_token_targets": ((B, T), "float32"), "phoneme_indices": ((B, P), "int64"),
+              "phoneme_durations": ((B, P), "int64"), "stress_indices": ((B, P), "int64"), "mel_lengths": ((B,), "int64"),
+              "phoneme_lengths": ((B,), "int64")}
+    off, plan = 0, []
+    for k in BATCH_KEYS:
+        shape, dt = shapes[k]
+        n = (4 if dt == "float32" else 8)
+        for v in shape:
+            n *= v
+        plan.append((k, off, n, shape, dt))
+        off += (n + align - 1) // align * align
+    return B, T, P, M, mel_len, ph_len, plan, off
+
+
+def collate_into(items: List[Dict], out: Dict, mel_len: List[int], ph_len: List[int]) -> None:
+    """Fill the numpy arrays out[key] (shapes of batch_layout) with the zero-padded batch: equals
+    cap_batch(collate_fn(items)) element for element."""
+    for i, it in enumerate(items):
+        a = sample_arrays(it)
+        t, p = mel_len[i], ph_len[i]
+        out["mel_specs"][i, :t] = a["mel"][:t]
+        out["mel_specs"][i, t:] = 0.0
+        for key, src in (("pitches", "pitch"), ("energies", "energy"), ("stop_token_targets", "stop")):
+            out[key][i, :t] = a[src][:t]
+            out[key][i, t:] = 0.0
+        for key, src in (("phoneme_indices", "ids"), ("phoneme_durations", "dur"), ("stress_indices", "stress")):
+            out[key][i, :p] = a[src][:p]
+            out[key][i, p:] = 0
+    out["mel_lengths"][:] = mel_len
+    out["phoneme_lengths"][:] = ph_len
 
 
 def split_indices(n: int, val_split: float):
@@ -161,11 +266,17 @@ class FrameBudgetBatchSampler:
                  shuffle: bool = True, rank: int = 0, world: int = 1, seed: int = 0, drop_last: bool = False):
         self.ds, self.max_frames, self.min_bs, self.max_bs = dataset, max_frames, min_batch_size, max_batch_size
         self.shuffle, self.rank, self.world, self.seed, self.epoch, self.drop_last = shuffle, rank, world, seed, 0, drop_last
+        self._cached = (None, None)                                # (epoch, batch list): len() and batches() share one build
 
     def _frames(self, i: int) -> int:
         return int(self.ds.samples[i]["audio_length"])
 
     def global_batches(self) -> List[List[int]]:
+        if self._cached[0] != self.epoch:
+            self._cached = (self.epoch, self._build())
+        return self._cached[1]
+
+    def _build(self) -> List[List[int]]:
         import numpy as np
         n_samples = len(self.ds.samples)
         if n_samples == 0:

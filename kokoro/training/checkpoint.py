@@ -85,7 +85,7 @@ def load_optimizer_state_dict(engine, osd: Dict[str, Any]) -> None:
 
 
 def save_checkpoint(engine, config, epoch: int, loss: float, output_dir: str, val: Optional[Dict[str, float]] = None,
-                    best_val_loss: Optional[float] = None, best_val_epoch: int = -1) -> str:
+                    best_val_loss: Optional[float] = None, best_val_epoch: int = -1, early_stopping_counter: int = 0) -> str:
     val = val or {}
     st = engine.opt_stats()
     done = int(st["attempt"] - st["skipped"])
@@ -103,6 +103,8 @@ def save_checkpoint(engine, config, epoch: int, loss: float, output_dir: str, va
         "scheduler_config": {"onecycle_steps": c["onecycle_steps"], "max_lr": c["max_lr"], "pct_start": c["pct_start"],
                              "div_factor": c["div_factor"], "warmup_steps": c["warmup_steps"]},
         "engine_opt_state": engine.opt_state.detach().cpu().clone(),       # new key: device-side step-driver state
+        "engine_rng": int(engine.rng.item()),                              # new key: step seed of the dropout / DropPath masks
+        "early_stopping_counter": int(early_stopping_counter),             # (trainer.py:2918-3004 keeps it on the trainer)
     }
     if engine.arena.ema is not None:
         ckpt["ema_model_state_dict"] = {k: v.detach().cpu().clone() for k, v in engine.state_dict(ema=True).items()}
@@ -143,6 +145,8 @@ def load_checkpoint(engine, path: str) -> Dict[str, Any]:
         load_optimizer_state_dict(engine, ckpt["optimizer_state_dict"])
     if "engine_opt_state" in ckpt:
         engine.opt_state.copy_(ckpt["engine_opt_state"])
+    if "engine_rng" in ckpt:
+        engine.rng.fill_(int(ckpt["engine_rng"]))
     return ckpt
 
 

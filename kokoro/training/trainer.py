@@ -11,12 +11,15 @@ from __future__ import annotations
 import logging
 import math
 import os
-from typing import Dict, Optional
+import queue
+import threading
+import time
+from typing import Dict, List, Optional
 
 import torch
 
-from kokoro.data.cached import (CachedFeatureDataset, FrameBudgetBatchSampler, collate_fn, length_based_batch_sampler,
-                                split_indices, step_groups)
+from kokoro.data.cached import (CachedFeatureDataset, FrameBudgetBatchSampler, batch_layout, collate_fn, collate_into,
+                                length_based_batch_sampler, scan_cache, split_indices, step_groups)
 from kokoro.training import checkpoint as ckpt
 from kokoro_ruslan_amd import dp, lib as kk
 from kokoro_ruslan_amd.spec import ModelDims, StepHyper
@@ -51,6 +54,111 @@ def cap_batch(batch: Dict[str, torch.Tensor], max_mel: int = 2000, max_ph: int =
     return b
 
 
+_TORCH_DT = {"float32": torch.float32, "int64": torch.int64}
+
+
+class BatchPrefetcher:
+    """Background loader for the train loop: while the GPU runs step n, a thread reads and collates batch n+1 into a
+    PINNED staging slab and copies it to a device slab with ONE asynchronous H2D transfer on its own stream.
+
+    The reference runs `DataLoader(num_workers=0)` with `pin_memory` off (cli/cli.py:275-276, trainer.py:322-327): every
+    batch is loaded, collated and copied on the training thread, field by field, from pageable memory.  At a few
+    milliseconds per step that serialises the step behind the loader, so here the batch is ready on the device when the
+    step starts.  A ring of `depth` slab pairs; a slab is refilled only after the step that consumed it has finished on
+    the GPU (an event recorded by the consumer), which is also what bounds the loader's run-ahead.
+
+    Yields (batch of device views, expanded_len) where expanded_len = max_b sum(durations) is computed on the host
+    copy, and the consuming stream already waits for the transfer."""
+
+    def __init__(self, dataset, batches: List[List[int]], device: torch.device, depth: int = 3, max_mel: int = 2000,
+                 max_ph: int = 2000, hip_lock=None):
+        self.dataset, self.batches, self.device, self.depth = dataset, batches, device, max(2, depth)
+        self.max_mel, self.max_ph = max_mel, max_ph      # _cap_batch_sequence_dimensions (reference trainer.py:3364-3411)
+        self.hip_lock = hip_lock if hip_lock is not None else threading.Lock()    # engine.capture_lock: no HIP calls from
+        #                                                                           this thread while a graph is captured
+        self.device_index = device.index if device.index is not None else torch.cuda.current_device()
+        self.copy_stream = torch.cuda.Stream(device=device)
+        self.host = [None] * self.depth
+        self.dev = [None] * self.depth
+        # free slots, each with the event after which its slab may be overwritten (the step that read it is done); a slot
+        # comes back only when the consumer hands it back, which is also what bounds the loader's run-ahead
+        self.free_q: "queue.Queue" = queue.Queue()
+        for slot in range(self.depth):
+            self.free_q.put((slot, None))
+        self.q: "queue.Queue" = queue.Queue()
+        self.error: Optional[BaseException] = None
+        self.load_s = 0.0                                # seconds this thread spent reading + collating + staging
+        self.wait_s = 0.0                                # ... and waiting for the GPU to release a slab
+        self.stop = False
+        self.thread = threading.Thread(target=self._run, name="kokoro-batch-prefetch", daemon=True)
+        self.thread.start()
+
+    def _run(self) -> None:
+        import numpy as np
+        try:
+            torch.cuda.set_device(self.device_index)
+            host_np = [None] * self.depth
+            for idxs in self.batches:
+                if self.stop:
+                    break
+                t0 = time.perf_counter()
+                items = [self.dataset[i] for i in idxs]
+                B, T, P, M, mel_len, ph_len, plan, total = batch_layout(items, self.max_mel, self.max_ph)
+                self.load_s += time.perf_counter() - t0
+                slot, done = self.free_q.get()
+                if slot is None:                         # consumer gone
+                    break
+                t0 = time.perf_counter()
+                while done is not None and not done.query():      # the step that used this slab has left the GPU
+                    time.sleep(0.0002)                           # (polled: a blocking wait would sit on the lock)
+                self.wait_s += time.perf_counter() - t0
+                t0 = time.perf_counter()
+                if self.host[slot] is None or self.host[slot].numel() < total:
+                    with self.hip_lock:
+                        cap_bytes = total + total // 4
+                        self.host[slot] = torch.empty(cap_bytes, dtype=torch.uint8).pin_memory()
+                        self.dev[slot] = torch.empty(cap_bytes, dtype=torch.uint8, device=self.device)
+                        torch.cuda.synchronize(self.device_index)   # (a recycled block may still be in use on another stream)
+                    host_np[slot] = self.host[slot].numpy()
+                host, dev, hnp = self.host[slot], self.dev[slot], host_np[slot]
+                arrays, views = {}, {}
+                for k, off, n, shape, dt in plan:
+                    arrays[k] = hnp[off:off + n].view(dt).reshape(shape)
+                    views[k] = dev[off:off + n].view(_TORCH_DT[dt]).view(shape)
+                collate_into(items, arrays, mel_len, ph_len)
+                expanded = int(np.clip(arrays["phoneme_durations"], 0, None).sum(axis=1).max()) if B and P else 0
+                with self.hip_lock:
+                    ready = torch.cuda.Event()
+                    with torch.cuda.stream(self.copy_stream):
+                        dev[:total].copy_(host[:total], non_blocking=True)
+                        ready.record(self.copy_stream)
+                self.load_s += time.perf_counter() - t0
+                self.q.put((slot, views, expanded, ready))
+            self.q.put(None)
+        except BaseException as e:                       # surfaced on the training thread
+            self.error = e
+            self.q.put(None)
+
+    def __iter__(self):
+        try:
+            while True:
+                item = self.q.get()
+                if item is None:
+                    if self.error is not None:
+                        raise self.error
+                    return
+                slot, views, expanded, ready = item
+                torch.cuda.current_stream().wait_event(ready)
+                yield views, expanded
+                done = torch.cuda.Event()
+                done.record(torch.cuda.current_stream())      # everything the consumer queued on this batch
+                self.free_q.put((slot, done))
+        finally:                                              # consumer left early: let the loader thread run out
+            self.stop = True
+            self.free_q.put((None, None))
+            self.thread.join(timeout=30)
+
+
 class KokoroTrainer:
     def __init__(self, config, vocab_size: int = 59):
         from kokoro_ruslan_amd.engine import KokoroEngine
@@ -58,10 +166,15 @@ class KokoroTrainer:
         self.rank, self.world, self.local = dp.init()
         if torch.cuda.is_available():
             torch.cuda.set_device(self.local)
-        n_all = len(CachedFeatureDataset(config.feature_cache_dir, memory_cache=False))
-        tr_idx, va_idx = split_indices(n_all, config.validation_split)
-        self.dataset = CachedFeatureDataset(config.feature_cache_dir, tr_idx, config.max_seq_length, config.use_memory_cache)
-        self.val_dataset = CachedFeatureDataset(config.feature_cache_dir, va_idx, config.max_seq_length, config.use_memory_cache) if va_idx else None
+        metas = scan_cache(config.feature_cache_dir)          # one pass over the cache for both views (and an index file)
+        tr_idx, va_idx = split_indices(len(metas), config.validation_split)
+        self.dataset = CachedFeatureDataset(config.feature_cache_dir, tr_idx, config.max_seq_length, config.use_memory_cache, metas)
+        self.val_dataset = (CachedFeatureDataset(config.feature_cache_dir, va_idx, config.max_seq_length, config.use_memory_cache, metas)
+                            if va_idx else None)
+        for name, honoured in (("ema_update_every", 1), ("use_onecycle_lr", True)):
+            if getattr(config, name, honoured) != honoured:
+                raise ValueError(f"TrainingConfig.{name}={getattr(config, name)!r} is not supported by the MI355X engine "
+                                 f"(the device-side step driver implements {name}={honoured!r})")
         if config.use_dynamic_batching:
             self.sampler = FrameBudgetBatchSampler(self.dataset, config.max_frames_per_batch, config.min_batch_size,
                                                    config.max_batch_size, True, self.rank, self.world, drop_last=True)   # trainer.py:305-312
@@ -86,7 +199,9 @@ class KokoroTrainer:
             # pre-scaling per-rank means by 1/world, and feed the batch-shape heuristics the global-batch mel length
             self.engine.loss_sync = dp.LossSync(self.world)
             self.engine.dp_loss_scale = 1.0
-        self.start_epoch, self.best_val, self.best_epoch = 0, float("inf"), -1
+        self.start_epoch, self.best_val, self.best_epoch, self.patience = 0, float("inf"), -1, 0
+        self.use_graphs = os.environ.get("KK_TRAINER_GRAPHS", "1") != "0"
+        self.prefetch_depth = int(os.environ.get("KK_PREFETCH_DEPTH", "3"))
         logger.info("engine ready: %d params, %s math, %d train / %d val utterances, %d batches/epoch, world %d",
                     sum(math.prod(s) for s in self.engine.arena.shapes.values()), math_mode, len(self.dataset),
                     len(self.val_dataset) if self.val_dataset else 0, len(self.sampler), self.world)
@@ -96,22 +211,30 @@ class KokoroTrainer:
         return {k: v.to(self.engine.device, non_blocking=True) for k, v in batch.items()}
 
     def train_epoch(self, epoch: int) -> float:
-        cfg, G = self.config, max(1, self.config.gradient_accumulation_steps)
+        cfg, G, e = self.config, max(1, self.config.gradient_accumulation_steps), self.engine
         self.sampler.epoch = epoch
         batches = self.sampler.batches()
         groups = step_groups(self.sampler.global_batches(), self.world) if self.world > 1 else None
-        acc, losses, n = 0, torch.zeros(6, device=self.engine.device), 0
-        for bi, idxs in enumerate(batches):
-            batch = cap_batch(self._to_device(collate_fn([self.dataset[i] for i in idxs])))
-            if groups is not None:      # longest (capped) mel length among this step's batches on all ranks
-                self.engine.global_mel_length = min(2000, max(min(self.dataset.samples[i]["audio_length"], self.dataset.max_seq_length)
-                                                              for g in groups[bi] for i in g))
-            div = effective_accumulation_divisor(G, acc, bi, len(batches))
-            boundary = (acc + 1 >= G) or (bi == len(batches) - 1)
-            self.engine.micro_in_cycle = acc
-            losses += self.engine.train_step(batch, div, boundary, self.sync if self.world > 1 else None)
-            acc = 0 if boundary else acc + 1
-            n += 1
+        # model.train() with the configured regularisation (reference trainer.py:2038-2056): dropout, stochastic depth,
+        # and SpecAugment on the decoder memory from spec_augment_start_epoch on
+        e.train_dropout = True
+        e.spec_augment_active = bool(cfg.use_spec_augment) and epoch >= int(cfg.spec_augment_start_epoch)
+        step = e.train_step_auto if self.use_graphs else e.train_step
+        acc, losses, n = 0, torch.zeros(6, device=e.device), 0
+        try:
+            self.last_prefetch = BatchPrefetcher(self.dataset, batches, e.device, self.prefetch_depth, 2000, 2000, e.capture_lock)
+            for bi, (batch, expanded) in enumerate(self.last_prefetch):
+                if groups is not None:      # longest (capped) mel length among this step's batches on all ranks
+                    e.global_mel_length = min(2000, max(self.dataset.samples[i]["audio_length"] for g in groups[bi] for i in g))
+                div = effective_accumulation_divisor(G, acc, bi, len(batches))
+                boundary = (acc + 1 >= G) or (bi == len(batches) - 1)
+                e.micro_in_cycle = acc
+                T = batch["mel_specs"].shape[1]
+                losses += step(batch, div, boundary, self.sync if self.world > 1 else None, expanded if expanded != T else None)
+                acc = 0 if boundary else acc + 1
+                n += 1
+        finally:
+            e.train_dropout = False
         avg = (losses / max(n, 1)).cpu().tolist()          # the only host sync of the epoch
         if n == 0:
             logger.warning("epoch %d: no training batches", epoch + 1)
@@ -136,34 +259,34 @@ class KokoroTrainer:
         if not self.val_dataset or len(self.val_dataset) == 0:
             return None
         e = self.engine
-        saved_p, saved_sync = None, e.loss_sync
-        e.loss_sync = None
-        if e.arena.ema is not None:
-            saved_p = e.arena.p.clone()
-            e.arena.p.copy_(e.arena.ema)                     # evaluate the EMA replica
         acc = torch.zeros(10, device=e.device, dtype=torch.float64)      # 6 losses, sc sum, sc batches, f0 sum, f0 batches
         n = 0
-        with e.fp32_math():                                  # validation runs without autocast (trainer.py:1821-1834)
-            for idxs in self._val_batches():
-                batch = cap_batch(self._to_device(collate_fn([self.val_dataset[j] for j in idxs])))
-                out = e.forward_backward(batch, backward=False)
-                acc[:6] += out["losses"].double()
-                n += 1
-                T = batch["mel_specs"].shape[1]
-                valid = (torch.arange(T, device=e.device)[None, :] < batch["mel_lengths"][:, None])
-                ok = batch["mel_lengths"] > 0
-                m3 = valid[:, :, None].to(torch.float32)
-                num = ((batch["mel_specs"] - out["mel"]) * m3).flatten(1).norm(dim=1)
-                den = (batch["mel_specs"] * m3).flatten(1).norm(dim=1)
-                sc_ok = ok & (den > 0)
-                acc[6] += torch.where(sc_ok, num / den.clamp(min=1e-30), torch.zeros_like(num)).sum().double() / sc_ok.sum().clamp(min=1)
-                acc[7] += (sc_ok.sum() > 0).double()
-                se = ((batch["pitches"][:, :T] - out["pitch"]) ** 2 * valid).sum(1) / batch["mel_lengths"].clamp(min=1)
-                acc[8] += torch.where(ok, se.sqrt(), torch.zeros_like(se)).sum().double() / ok.sum().clamp(min=1)
-                acc[9] += (ok.sum() > 0).double()
-        if saved_p is not None:
-            e.arena.p.copy_(saved_p)                         # (the bf16 weight shadow was never touched)
-        e.loss_sync = saved_sync
+        saved_sync, saved_drop, e.loss_sync, e.train_dropout = e.loss_sync, e.train_dropout, None, False
+        try:
+            # validation runs without autocast on the EMA replica (trainer.py:1821-1834, 1771-1790): fp32 arithmetic,
+            # and the EMA slab read in place (no copy; nothing to restore but three references, whatever happens)
+            with e.fp32_math(), e.ema_weights():
+                for idxs in self._val_batches():
+                    cpu = cap_batch(collate_fn([self.val_dataset[j] for j in idxs]))
+                    expanded = int(cpu["phoneme_durations"].clamp(min=0).sum(dim=1).max())
+                    batch = self._to_device(cpu)
+                    T = batch["mel_specs"].shape[1]
+                    out = e.forward_backward(batch, backward=False, expanded_len=expanded if expanded != T else None)
+                    acc[:6] += out["losses"].double()
+                    n += 1
+                    valid = (torch.arange(T, device=e.device)[None, :] < batch["mel_lengths"][:, None])
+                    ok = batch["mel_lengths"] > 0
+                    m3 = valid[:, :, None].to(torch.float32)
+                    num = ((batch["mel_specs"] - out["mel"]) * m3).flatten(1).norm(dim=1)
+                    den = (batch["mel_specs"] * m3).flatten(1).norm(dim=1)
+                    sc_ok = ok & (den > 0)
+                    acc[6] += torch.where(sc_ok, num / den.clamp(min=1e-30), torch.zeros_like(num)).sum().double() / sc_ok.sum().clamp(min=1)
+                    acc[7] += (sc_ok.sum() > 0).double()
+                    se = ((batch["pitches"][:, :T] - out["pitch"][:, :T]) ** 2 * valid).sum(1) / batch["mel_lengths"].clamp(min=1)
+                    acc[8] += torch.where(ok, se.sqrt(), torch.zeros_like(se)).sum().double() / ok.sum().clamp(min=1)
+                    acc[9] += (ok.sum() > 0).double()
+        finally:
+            e.loss_sync, e.train_dropout = saved_sync, saved_drop
         v = acc.cpu().tolist()
         res = dict(zip(("total", "mel", "dur", "stop", "pitch", "energy"), (x / max(n, 1) for x in v[:6])))
         res["spectral_convergence"] = v[6] / v[7] if v[7] > 0 else None
@@ -180,8 +303,9 @@ class KokoroTrainer:
             self.start_epoch = int(c["epoch"]) + 1
             self.best_val = c.get("best_val_loss") or float("inf")
             self.best_epoch = c.get("best_val_epoch", -1)
+            self.patience = int(c.get("early_stopping_counter", 0))
             logger.info("resumed from %s at epoch %d", path, self.start_epoch)
-        patience = 0
+        patience = self.patience
         for epoch in range(self.start_epoch, cfg.num_epochs):
             loss = self.train_epoch(epoch)
             val = self.validate_epoch() if (epoch + 1) % max(1, cfg.validation_interval) == 0 else None
@@ -196,7 +320,7 @@ class KokoroTrainer:
                     patience += 1
             periodic = (epoch + 1) % max(1, cfg.save_every) == 0 and (not self.val_dataset or patience > 0)     # trainer.py:2986-2998
             if self.rank == 0 and (improved or periodic or epoch + 1 == cfg.num_epochs):
-                p = ckpt.save_checkpoint(self.engine, cfg, epoch, loss, cfg.output_dir, val, self.best_val, self.best_epoch)
+                p = ckpt.save_checkpoint(self.engine, cfg, epoch, loss, cfg.output_dir, val, self.best_val, self.best_epoch, patience)
                 logger.info("checkpoint saved: %s", p)
             if val is not None and patience >= cfg.early_stopping_patience:
                 logger.info("early stopping at epoch %d", epoch + 1)

@@ -581,3 +581,40 @@ extern "C" int kk_copy_many(const void *const *src, void *const *dst, const int6
     KK_LAUNCH_CHECK("kk_copy_many");
     return 0;
 }
+
+// ------------------------------------------------------------------ expanded length != mel length (model.py:607-628)
+// When the durations of a batch expand to T' = max_b sum(dur) > T frames, the pitch / energy predictors see T' frames
+// (variance_predictor.py:354-372) while the losses read their first T columns (losses.py:111,137) and the decoder memory
+// is the first T frames.  These two helpers move [B, T'] <-> [B, T] rows and build the T'-frame padding mask.
+namespace {
+__global__ __launch_bounds__(256) void pad2d_kernel(const float *__restrict__ src, int64_t lds, int cols_src, float *__restrict__ dst,
+                                                    int64_t ldd, int cols_dst, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cols_dst;
+        const int c = (int)(i - r * cols_dst);
+        dst[r * ldd + c] = c < cols_src ? src[r * lds + c] : 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void frame_mask_kernel(const int64_t *__restrict__ lens, uint8_t *__restrict__ mask, int T, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / T;
+        mask[i] = (i - b * T) >= lens[b] ? 1 : 0;
+    }
+}
+}  // namespace
+
+extern "C" int kk_pad2d_f32(const float *src, int64_t lds, int cols_src, float *dst, int64_t ldd, int cols_dst, int64_t rows,
+                            void *stream) {
+    KK_REQUIRE(src && dst && rows > 0 && cols_src > 0 && cols_dst > 0 && lds >= cols_src && ldd >= cols_dst, "kk_pad2d_f32: bad shape");
+    const int64_t total = rows * cols_dst;
+    hipLaunchKernelGGL(pad2d_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, lds, cols_src, dst, ldd, cols_dst, total);
+    KK_LAUNCH_CHECK("kk_pad2d_f32");
+    return 0;
+}
+extern "C" int kk_frame_mask(const int64_t *lens, uint8_t *mask, int B, int T, void *stream) {
+    KK_REQUIRE(lens && mask && B > 0 && T > 0, "kk_frame_mask: bad shape");
+    const int64_t total = (int64_t)B * T;
+    hipLaunchKernelGGL(frame_mask_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, lens, mask, T, total);
+    KK_LAUNCH_CHECK("kk_frame_mask");
+    return 0;
+}

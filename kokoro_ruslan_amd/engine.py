@@ -14,15 +14,15 @@ What it restates (reference file:line, relative to /root/reference/src/kokoro):
 Quirks kept on purpose: the length-regulated memory is detached (no gradient from the decoder into
 the text encoder, facts 5); key padding = (phoneme id == 0) (fact 6); GroupNorm(1,C) statistics per 512-frame
 chunk including padding (fact 7); stop head sees a detached decoder output (model.py:562).
-Restriction: the expanded length max_b Σdur must equal the batch mel length T (true for the reference's
-datasets, whose durations sum to the mel length); frames beyond T only affect the reference through the
-variance predictors' GroupNorm statistics.
+Expanded length T' = max_b Σdur != mel length T (model/model.py:607-628): see forward_backward(expanded_len=...).
+Activation memory: one workspace sized for the largest batch seen (see _buf), whatever the number of batch shapes.
 """
 from __future__ import annotations
 
 import contextlib
 import math
 import os
+import threading
 from collections import OrderedDict
 from typing import Dict, Optional, Tuple
 
@@ -33,6 +33,7 @@ from . import spec
 from .spec import VA, ModelDims, StepHyper
 
 CHUNK = 512   # variance_predictor.py:77
+_ITEMSIZE = {torch.float32: 4, torch.bfloat16: 2, torch.float64: 8, torch.int64: 8, torch.int32: 4, torch.uint8: 1}
 
 
 def _b16(t) -> int:
@@ -131,10 +132,26 @@ class KokoroEngine:
         self.arena = Arena(self.dims, self.hp, self.device, shadow_bf16=storage != "f32")
         self.use_shadow = storage != "f32"
         self.total_steps = total_steps
-        self._ws: Dict[Tuple, torch.Tensor] = {}
-        self._graphs: Dict[Tuple, Dict] = {}
+        # Workspace: ONE flat buffer per name, grown to the largest request ever made under that name, and handed out as
+        # views — so a run over ever-changing batch shapes (dynamic batching: B in [4, 32], T up to 1800) holds one
+        # activation set sized for the largest batch instead of one per shape.  Growing a buffer moves it, so everything
+        # that baked its address in (captured graphs, descriptor tables) is dropped with it (_invalidate).
+        self._ws: Dict[str, torch.Tensor] = {}
+        self._views: Dict[Tuple, torch.Tensor] = {}
+        self.ws_generation = 0
+        self.ws_bytes = 0
+        self.max_graphs = int(os.environ.get("KK_MAX_GRAPHS", "24"))     # LRU bound of captured batch shapes
+        self.max_tables = 8192                                           # descriptor tables (all kinds together)
+        self._graphs: "OrderedDict[Tuple, Dict]" = OrderedDict()
+        self._tables: "OrderedDict[Tuple, object]" = OrderedDict()
+        self._shape_seen: "OrderedDict[Tuple, int]" = OrderedDict()
+        # Held while a hipGraph capture is in progress.  Other host threads that talk to the HIP runtime (the trainer's
+        # batch prefetcher: event waits, pinned allocations, H2D copies) take it around those calls: on this runtime a
+        # concurrent call from another thread invalidates the capture (hipErrorStreamCaptureInvalidated), thread_local
+        # capture mode notwithstanding.
+        self.capture_lock = threading.Lock()
         self._rope: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
-        self._reduce_lists, self._reduce_tables = {"": [], "side.": [], "kv.": []}, {}    # per stream namespace
+        self._reduce_lists = {"": [], "side.": [], "kv.": []}             # per stream namespace
         self.opt_state = torch.zeros(kk.OS["SIZE"], dtype=torch.float64, device=self.device)
         ns = self.arena.nseg
         f32 = lambda n: torch.zeros(n, dtype=torch.float32, device=self.device)
@@ -178,11 +195,7 @@ class KokoroEngine:
         self.group_wgrads = os.environ.get("KK_GROUP_WGRADS", "1") != "0"     # A/B switches for tools/ and bench sweeps
         self.fuse_headnorm = os.environ.get("KK_FUSE_HEADNORM", "1") != "0"
         self.fuse_headnorm_bwd = os.environ.get("KK_FUSE_HEADNORM_BWD", "1") != "0"
-        self._hn_tables = {}
-        self._ptr_tables = {}
-        self._wgrad_queue, self._wgrad_tables = {}, {}
-        if os.environ.get("KK_GROUP_SPLIT"):
-            kk.load().kk_gemm_tune_group(int(os.environ["KK_GROUP_SPLIT"]))
+        self._wgrad_queue = {}
         self.spec_augment_active = True             # the trainer clears it for epochs < spec_augment_start_epoch
         # KK_TRACE=1: one-thread time-stamp launches at the marks of a step (also inside the captured graphs), read back by
         # timeline() — the real overlap of the graph's branches, which rocprofv3 cannot show (it serialises them)
@@ -222,6 +235,24 @@ class KokoroEngine:
             yield self
         finally:
             self.math, self.enc_dt, self.dec_dt, self.use_shadow = saved
+
+    @contextlib.contextmanager
+    def ema_weights(self):
+        """Run the enclosed forward passes on the EMA replica (reference validation, trainer.py:1771-1790) by pointing the
+        parameter views at the EMA slab — no copy, and nothing but two references to restore if the block raises.  Only
+        meaningful without the bf16 weight shadow (combine with fp32_math())."""
+        a = self.arena
+        if a.ema is None:
+            yield self
+            return
+        if self.use_shadow:
+            raise RuntimeError("ema_weights(): the bf16 shadow holds the live weights; use it inside fp32_math()")
+        saved = (a.P, a.p)
+        a.P, a.p = a.E, a.ema
+        try:
+            yield self
+        finally:
+            a.P, a.p = saved
 
     def sync_shadow(self) -> None:
         """Rebuild the bf16 weight shadow from the fp32 master arena (after any write to arena.p from outside the
@@ -309,20 +340,79 @@ class KokoroEngine:
         self._join(self._side)
 
     def _buf(self, key, *shape, dtype=torch.float32) -> torch.Tensor:
+        """A [shape] view of the workspace buffer `key` (scratch names "tmp.*" are private to the current stream)."""
         if key.startswith("tmp."):
             key = self._tmp_ns + key
-        k = (key, tuple(shape), dtype)
-        t = self._ws.get(k)
-        if t is None:
-            t = torch.empty(shape, dtype=dtype, device=self.device)
-            self._ws[k] = t
+        vk = (key, shape, dtype)
+        v = self._views.get(vk)
+        if v is not None:
+            return v
+        need = math.prod(shape) * _ITEMSIZE[dtype]
+        t = self._ws.get(key)
+        if t is None or t.numel() < need:
+            t = self._grow(key, need)
+        v = t[:need].view(dtype).view(shape)
+        if len(self._views) > 32768:
+            self._views.clear()
+        self._views[vk] = v
+        return v
+
+    def _grow(self, key: str, need: int) -> torch.Tensor:
+        old = self._ws.get(key)
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError(f"workspace '{key}' would be allocated inside a graph capture (run the shape eagerly first)")
+        if old is not None:
+            # the old block may still be in use by queued kernels of any stream, and captured graphs / tables hold its
+            # address: drain, drop them, then let it go.  12.5 % headroom so that slowly creeping shapes do not regrow
+            # every step.
+            torch.cuda.synchronize(self.device)
+            self._invalidate()
+            self.ws_bytes -= old.numel()
+            need = need + need // 8
+        need = (need + 255) // 256 * 256
+        t = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self._ws[key] = t
+        self.ws_bytes += need
         return t
 
+    def _invalidate(self) -> None:
+        """Forget everything that holds workspace addresses: views, descriptor tables, captured graphs."""
+        self._views.clear()
+        self._tables.clear()
+        self._graphs.clear()
+        self.ws_generation += 1
+
+    def _table(self, key: Tuple, build):
+        """Descriptor table cache (pointer / weight-gradient / head-norm / reduction tables), LRU-bounded.  A captured graph
+        reads device-resident tables when it replays, so evicting tables also drops the graphs."""
+        t = self._tables.get(key)
+        if t is None:
+            if len(self._tables) >= self.max_tables:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("descriptor-table cache overflow inside a graph capture")
+                torch.cuda.synchronize(self.device)
+                self._graphs.clear()
+                for _ in range(self.max_tables // 4):
+                    self._tables.popitem(last=False)
+            t = self._tables[key] = build()
+        else:
+            self._tables.move_to_end(key)
+        return t
+
+    def workspace_bytes(self) -> int:
+        """Bytes held by the activation workspace (bounded by the largest batch seen, not by the number of shapes)."""
+        return self.ws_bytes
+
     def _rope_tables(self, S: int):
-        if S not in self._rope:
-            c, s = spec.rope_tables(S, 64)
-            self._rope[S] = (c.to(self.device), s.to(self.device))
-        return self._rope[S]
+        """cos / sin tables for positions [0, S): prefixes of one pair built once for the longest supported sequence
+        (2 x max_len x 64 floats), so their addresses never change under captured graphs."""
+        if not self._rope:
+            c, s = spec.rope_tables(self.dims.max_len, 64)
+            self._rope[0] = (c.to(self.device), s.to(self.device))
+        if S > self.dims.max_len:
+            raise ValueError(f"sequence of {S} positions exceeds the positional table ({self.dims.max_len})")
+        c, s = self._rope[0]
+        return c[:S], s[:S]
 
     def _W(self, name: str) -> torch.Tensor:
         """GEMM weight operand: the bf16 shadow when there is one, else the fp32 master."""
@@ -383,10 +473,8 @@ class KokoroEngine:
             del self._wgrad_queue[ns]
         for i in range(0, len(q), 8):
             part = q[i:i + 8]
-            sig = tuple((dy.data_ptr(), x.data_ptr(), dw.data_ptr(), tuple(dy.shape), tuple(x.shape)) for dy, x, dw in part)
-            table = self._wgrad_tables.get(sig)
-            if table is None:
-                table = self._wgrad_tables[sig] = kk.wgrad_table(part)
+            sig = ("wg",) + tuple((dy.data_ptr(), x.data_ptr(), dw.data_ptr(), tuple(dy.shape), tuple(x.shape)) for dy, x, dw in part)
+            table = self._table(sig, lambda: kk.wgrad_table(part))
             kk.call("kk_gemm_wgrad_group", table, len(part))
 
     def _ln_fwd(self, key, x, prefix, dtype=torch.float32):
@@ -452,11 +540,9 @@ class KokoroEngine:
             self._reduce_lists[ns] = []
         if not todo:
             return
-        tkey = (shape_key, tuple(e[0].data_ptr() for e in todo))      # which partial matrices this pass wrote
-        ent = self._reduce_tables.get(tkey)
-        if ent is None:                               # workspace addresses are stable per batch shape: build the table once
-            ent = (kk.reduce_table(todo, self.device), len(todo), max(e[4] for e in todo))
-            self._reduce_tables[tkey] = ent
+        tkey = ("red", shape_key, tuple((e[0].data_ptr(), e[3]) for e in todo))      # which partial matrices this pass wrote
+        # workspace addresses are stable while no buffer grows: the table is built once per batch shape
+        ent = self._table(tkey, lambda: (kk.reduce_table(todo, self.device), len(todo), max(e[4] for e in todo)))
         kk.call("kk_partials_reduce", ent[0], ent[1], ent[2])
 
     # ------------------------------------------------------------------ dropout plumbing
@@ -525,10 +611,7 @@ class KokoroEngine:
         H, h = self.dims.hidden, self.dims.heads
         rows, parts = x.shape[0], len(gains)
         if self.fuse_headnorm and _b16(x) and _b16(W) and _b16(raw) and parts <= 12 and x.shape[1] % 64 == 0:
-            key = tuple(g.data_ptr() for g in gains)
-            table = self._ptr_tables.get(key)
-            if table is None:
-                table = self._ptr_tables[key] = kk.pointer_table(gains)
+            table = self._table(("ptr",) + tuple(g.data_ptr() for g in gains), lambda: kk.pointer_table(gains))
             kk.call("kk_gemm_qkv_headnorm", rows, parts, h, x.shape[1], x, x.stride(0), W, None, raw, raw.stride(0), nrm,
                     nrm.stride(0), S, table, rope_mask, cos, sin)
             return
@@ -595,13 +678,11 @@ class KokoroEngine:
         def hn_tables(tag, S, entries):
             """KkAttnHeadNorm descriptors of one backward launch (cached: every pointer is a persistent buffer) with their
             partial gain-gradient rows registered for the reduction at the end of the backward."""
-            tk = (self._tmp_ns, key, tag, B, S) + tuple(r.data_ptr() for r, *_ in entries)
-            if tk not in self._hn_tables:
-                nb = kk.load().kk_attn_bwd_blocks(B, h, S)
-                part = self._buf(f"{key}.hnpart.{tag}", len(entries), nb, 64)
-                self._hn_tables[tk] = (kk.attn_headnorm([(r, g_, part[j], c_, s_) for j, (r, g_, _, c_, s_) in enumerate(entries)]),
-                                       part, nb)
-            table, part, nb = self._hn_tables[tk]
+            nb = kk.load().kk_attn_bwd_blocks(B, h, S)
+            part = self._buf(f"{key}.hnpart.{tag}", len(entries), nb, 64)
+            tk = ("hn", self._tmp_ns, key, tag, B, S, part.data_ptr()) + tuple(
+                (r.data_ptr(), r.stride(0), g_.data_ptr(), c_.data_ptr() if c_ is not None else 0) for r, g_, _, c_, _ in entries)
+            table = self._table(tk, lambda: kk.attn_headnorm([(r, g_, part[j], c_, s_) for j, (r, g_, _, c_, s_) in enumerate(entries)]))
             for j, (_, _, dg_, _, _) in enumerate(entries):
                 self._reduce_lists[self._tmp_ns].append((part[j], dg_, None, nb, 64, 64))
             return table
@@ -731,12 +812,21 @@ class KokoroEngine:
 
     # ------------------------------------------------------------------ forward + losses + backward
     def forward_backward(self, batch: Dict[str, torch.Tensor], loss_scale: float = 1.0, adaptive: bool = False,
-                         backward: bool = True, zero_grads: bool = False) -> Dict[str, torch.Tensor]:
+                         backward: bool = True, zero_grads: bool = False, expanded_len: Optional[int] = None
+                         ) -> Dict[str, torch.Tensor]:
         """One micro-batch: forward, the 6 losses, and (optionally) the full backward into the gradient arena
         (which accumulates; zero_grads=True clears it first, overlapped with the forward).  `batch` follows the
         reference collate contract (data/dataset.py:871-921), tensors on the device.  Returns device tensors (no sync):
-        losses[6] = (total, mel, dur, stop, pitch, energy) and outputs."""
-        gen = self._fb_gen(batch, loss_scale, adaptive, backward, None, zero_grads)
+        losses[6] = (total, mel, dur, stop, pitch, energy) and outputs.
+
+        expanded_len = max_b sum(phoneme_durations[b]), the frame count T' the durations expand to, as a host integer
+        (the caller has the durations on the host before the copy; nothing in a step synchronises).  None means T' = T,
+        which holds for the reference's datasets unless an utterance was clipped (data/dataset.py:769-776).  T' > T:
+        the pitch / energy predictors run on all T' frames and their outputs are [B, T'] like the reference's, the
+        decoder memory is the first T frames (model/model.py:607-613), the losses read the first T columns
+        (losses.py:111,137).  T' < T: the reference fails in the pitch loss with a size-mismatch RuntimeError
+        (losses.py:126: [B, T'] predictions against [B, T] targets) — the same error is raised here, before any launch."""
+        gen = self._fb_gen(batch, loss_scale, adaptive, backward, None, zero_grads, expanded_len)
         while True:
             try:
                 next(gen)
@@ -766,7 +856,7 @@ class KokoroEngine:
                 r.append([beg, end])
         return [tuple(x) for x in out[False]], [tuple(x) for x in out[True]]
 
-    def _fb_gen(self, batch, loss_scale, adaptive, backward, split_layer, zero_grads=False):
+    def _fb_gen(self, batch, loss_scale, adaptive, backward, split_layer, zero_grads=False, expanded_len=None):
         """forward_backward as a generator: with split_layer = k it pauses once, after the backward of decoder layer k,
         with the side stream joined and every gradient of early_late_ranges(k)[0] final — the data-parallel step
         captures the two halves as separate hipGraphs and starts the all-reduce of the early ranges in between.
@@ -784,8 +874,13 @@ class KokoroEngine:
         Ne, Nd = B * Pn, B * T
         edt, ddt = self.enc_dt, self.dec_dt               # activation storage of the encoder / decoder stacks
         pe = P["positional_encoding.pe"].view(d.max_len, H)
-        if T > d.max_len or Pn > d.max_len:
+        Tp = T if expanded_len is None else max(int(expanded_len), 3)     # variance_predictor.py:358-360 (at least 3 frames)
+        if Tp < T:
+            raise RuntimeError(f"The size of tensor a ({Tp}) must match the size of tensor b ({T}) at non-singleton dimension 1 "
+                               f"(durations expand to {Tp} frames, the batch has {T} mel frames: losses.py:126)")
+        if max(T, Tp) > d.max_len or Pn > d.max_len:
             raise ValueError(f"sequence longer than the positional table ({d.max_len})")
+        Np = B * Tp
 
         # ---- decoder head: mel input projection + layer-0 self-attention need no encoder output (model.py:519-531) ----
         p_din = self._p(self.hp.decoder_input_dropout)
@@ -868,8 +963,13 @@ class KokoroEngine:
         kk.call("kk_bucket_embed_add_fwd", xf, batch["pitches"], batch["energies"], P[f"{VA}.pitch_bins"], P[f"{VA}.energy_bins"],
                 P[f"{VA}.pitch_embedding.weight"], P[f"{VA}.energy_embedding.weight"], lens, memory, pidx, eidx, fmask, B, T, H,
                 d.var_bins, _b16(memory))
-        pitch_pred, energy_pred = self._buf("out.pitch", B, T), self._buf("out.energy", B, T)
-        col_f = self._buf("vp.col_frames", Nd, 3 * H, dtype=ddt)
+        pitch_pred, energy_pred = self._buf("out.pitch", B, Tp), self._buf("out.energy", B, Tp)
+        col_f = self._buf("vp.col_frames", Np, 3 * H, dtype=ddt)
+        if Tp != T:      # the predictors' own T'-frame view of the expansion; the losses read the first T columns
+            xf_p, fmask_p = self._buf("va.xf_p", Np, H), self._buf("va.fmask_p", B, Tp, dtype=torch.uint8)
+            pitch_l, energy_l = self._buf("out.pitch_T", B, T), self._buf("out.energy_T", B, T)
+        else:
+            xf_p, fmask_p, pitch_l, energy_l = xf, fmask, pitch_pred, energy_pred
         spec_aug = self.train_dropout and hp.use_spec_augment and self.spec_augment_active
         if spec_aug:                                      # on the cross-attention memory only (model.py:636-639)
             kk.call("kk_specaug", memory, B, T, H, self.rng, 20, hp.spec_augment_time_mask_max, hp.spec_augment_freq_mask_max,
@@ -886,10 +986,18 @@ class KokoroEngine:
         with self._on_side_stream():                      # joined before the losses
             self._mark("side: predictors fwd start")
             kk.call("kk_im2col3_fwd", enc, col_e, B, Pn, H, CHUNK, _b16(col_e))
-            kk.call("kk_im2col3_fwd", xf, col_f, B, T, H, CHUNK, _b16(col_f))
+            if Tp != T:
+                idx_p, lens_p = self._buf("lr.idx_p", B, Tp, dtype=torch.int64), self._buf("lr.lens_p", B, dtype=torch.int64)
+                kk.call("kk_length_regulate_index", dur, idx_p, lens_p, self._buf("lr.total_p", B, dtype=torch.int64), B, Pn, Tp)
+                kk.call("kk_length_regulate_gather", enc, idx_p, xf_p, B, Pn, Tp, H)
+                kk.call("kk_frame_mask", lens_p, fmask_p, B, Tp)
+            kk.call("kk_im2col3_fwd", xf_p, col_f, B, Tp, H, CHUNK, _b16(col_f))
             self._varpred_fwd("vp.dur", f"{VA}.duration_predictor", enc, col_e, B, Pn, text_mask, dur_pred, 10, p_var)
-            self._varpred_fwd("vp.pitch", f"{VA}.pitch_predictor", xf, col_f, B, T, fmask, pitch_pred, 12, p_var)
-            self._varpred_fwd("vp.energy", f"{VA}.energy_predictor", xf, col_f, B, T, fmask, energy_pred, 14, p_var)
+            self._varpred_fwd("vp.pitch", f"{VA}.pitch_predictor", xf_p, col_f, B, Tp, fmask_p, pitch_pred, 12, p_var)
+            self._varpred_fwd("vp.energy", f"{VA}.energy_predictor", xf_p, col_f, B, Tp, fmask_p, energy_pred, 14, p_var)
+            if Tp != T:
+                kk.call("kk_pad2d_f32", pitch_pred, Tp, Tp, pitch_l, T, T, B)
+                kk.call("kk_pad2d_f32", energy_pred, Tp, Tp, energy_l, T, T, B)
             self._mark("side: predictors fwd done")
         if seg:
             yield ("end", "side")
@@ -933,7 +1041,7 @@ class KokoroEngine:
         lcfg = kk.KkLossCfg(hp.duration_loss_weight, hp.stop_token_loss_weight, hp.pitch_loss_weight, hp.energy_loss_weight,
                             hp.duration_huber_delta, hp.pitch_huber_delta, hp.energy_huber_delta, hp.stop_token_pos_weight,
                             float(loss_scale), 1 if adaptive else 0)
-        largs = (mel_pred, mel, dur_pred, dur, stop, batch["stop_token_targets"], pitch_pred, batch["pitches"], energy_pred,
+        largs = (mel_pred, mel, dur_pred, dur, stop, batch["stop_token_targets"], pitch_l, batch["pitches"], energy_l,
                  batch["energies"], batch["mel_lengths"], batch["phoneme_lengths"], B, T, Pn, M, lcfg)
         kk.call("kk_losses_fwd", *largs, self.max_dur, self.loss_acc, self.losses, self.loss_coef)
         if self.loss_sync is not None:
@@ -965,8 +1073,13 @@ class KokoroEngine:
                 kk.call("kk_rowdot_bwd", dstop, dec_out, P["stop_token_predictor.weight"], None, None, G["stop_token_predictor.weight"],
                         G["stop_token_predictor.bias"], Nd, H, T, 0, _b16(dec_out))
                 self._wgrad(dmel.view(Nd, M), dec_out, G["mel_projection_out.weight"], G["mel_projection_out.bias"])
-                self._varpred_bwd("vp.pitch", f"{VA}.pitch_predictor", dpitch, xf, col_f, B, T, fmask, None, p_var)
-                self._varpred_bwd("vp.energy", f"{VA}.energy_predictor", denergy, xf, col_f, B, T, fmask, None, p_var)
+                dpitch_p, denergy_p = dpitch, denergy
+                if Tp != T:                               # frames past T carry no loss: zero gradient there
+                    dpitch_p, denergy_p = self._buf("g.pitch_p", B, Tp), self._buf("g.energy_p", B, Tp)
+                    kk.call("kk_pad2d_f32", dpitch, T, T, dpitch_p, Tp, Tp, B)
+                    kk.call("kk_pad2d_f32", denergy, T, T, denergy_p, Tp, Tp, B)
+                self._varpred_bwd("vp.pitch", f"{VA}.pitch_predictor", dpitch_p, xf_p, col_f, B, Tp, fmask_p, None, p_var)
+                self._varpred_bwd("vp.energy", f"{VA}.energy_predictor", denergy_p, xf_p, col_f, B, Tp, fmask_p, None, p_var)
                 d_enc = self._buf("g.enc_out", Ne, H)
                 self._varpred_bwd("vp.dur", f"{VA}.duration_predictor", ddur, enc, col_e, B, Pn, text_mask, d_enc, p_var)
                 self._mark("side: predictors bwd done")
@@ -1033,7 +1146,7 @@ class KokoroEngine:
             self._mark(f"dec{i} bwd done")
             if yield_at == i:                           # everything the early ranges hold is final from here on
                 self._join(self._side)
-                self._reduce_partials((B, T, Pn, "early"))
+                self._reduce_partials((B, T, Pn, Tp, "early"))
                 yield "split"
         # decoder input projection (the PE add and the shift are parameter-free; mel is data)
         if self.train_dropout and (p_din > 0.0 or pe_drop > 0.0):
@@ -1063,7 +1176,7 @@ class KokoroEngine:
             yield ("join", "side")
         else:
             self._join(self._side)
-        self._reduce_partials((B, T, Pn))
+        self._reduce_partials((B, T, Pn, Tp))
         self._mark("backward joined, partials reduced")
         return out
 
@@ -1247,7 +1360,7 @@ class KokoroEngine:
         self._mark("optimizer done")
 
     def train_step(self, batch: Dict[str, torch.Tensor], accumulation_divisor: Optional[int] = None,
-                   boundary: Optional[bool] = None, grad_sync=None) -> torch.Tensor:
+                   boundary: Optional[bool] = None, grad_sync=None, expanded_len: Optional[int] = None) -> torch.Tensor:
         """One micro-batch of training in the reference's order (trainer.py:2257-2477): zero grads at the start of an
         accumulation cycle, forward+backward with loss_scale = adaptive/divisor, optimizer boundary when the cycle
         completes.  Returns the device tensor of 6 losses (no host sync)."""
@@ -1255,7 +1368,7 @@ class KokoroEngine:
         div = accumulation_divisor if accumulation_divisor is not None else G
         if self.micro_in_cycle == 0:
             self.zero_grad()
-        out = self.forward_backward(batch, loss_scale=self.dp_loss_scale / div, adaptive=True)
+        out = self.forward_backward(batch, loss_scale=self.dp_loss_scale / div, adaptive=True, expanded_len=expanded_len)
         self.micro_in_cycle += 1
         if boundary if boundary is not None else self.micro_in_cycle >= G:
             if grad_sync is not None:
@@ -1264,8 +1377,29 @@ class KokoroEngine:
             self.micro_in_cycle = 0
         return out["losses"]
 
+    def train_step_auto(self, batch: Dict[str, torch.Tensor], accumulation_divisor: Optional[int] = None,
+                        boundary: Optional[bool] = None, grad_sync=None, expanded_len: Optional[int] = None) -> torch.Tensor:
+        """train_step for a stream of batches whose shapes may or may not repeat (the trainer's entry point): a shape that
+        comes back is replayed from hipGraphs (train_step_graphed: ~0.2 ms of host time instead of ~2.5 ms for ~700
+        launches), a shape seen for the first time runs eagerly.  Large dynamic batches (max_frames 16384: 15-20 ms of
+        GPU time per step) hide the eager launches anyway; small fixed shapes are where the graphs pay.  At most
+        max_graphs shapes are kept (least recently used first out)."""
+        B, T = batch["mel_specs"].shape[:2]
+        key = (B, T, batch["phoneme_indices"].shape[1], T if expanded_len is None else int(expanded_len))
+        if self.loss_sync is None:              # (the loss-count exchange of ragged data-parallel shards runs between kernels)
+            if key in self._graphs:
+                return self.train_step_graphed(batch, grad_sync, accumulation_divisor, boundary, expanded_len)
+            n = self._shape_seen.get(key, 0) + 1
+            self._shape_seen[key] = n
+            self._shape_seen.move_to_end(key)
+            if len(self._shape_seen) > 4096:
+                self._shape_seen.popitem(last=False)
+            if n >= 2:
+                return self.train_step_graphed(batch, grad_sync, accumulation_divisor, boundary, expanded_len)
+        return self.train_step(batch, accumulation_divisor, boundary, grad_sync, expanded_len)
+
     # ------------------------------------------------------------------ hipGraph replay of a whole step
-    def _capture_segments(self, static):
+    def _capture_segments(self, static, scale=None, first=True, expanded_len=None):
         """Capture forward+backward as a PROGRAM of single-stream hipGraphs instead of one graph with parallel branches.
 
         A hipGraph that forks onto several streams is launched node by node through the runtime's multi-queue path:
@@ -1302,7 +1436,7 @@ class KokoroEngine:
         last["main"] = ev0
         self._segmented = True
         try:
-            gen = self._fb_gen(static, self.dp_loss_scale, True, True, None, True)
+            gen = self._fb_gen(static, self.dp_loss_scale if scale is None else scale, True, True, None, first, expanded_len)
             open_graph("main")
             for msg in gen:
                 kind = msg[0]
@@ -1348,27 +1482,69 @@ class KokoroEngine:
             else:
                 st.wait_event(obj)
 
-    def train_step_graphed(self, batch: Dict[str, torch.Tensor], grad_sync=None) -> torch.Tensor:
-        """Same semantics as train_step with gradient_accumulation_steps == 1, but the kernel sequence of a step is
-        captured once per batch shape into hipGraphs and replayed (a step is ~700 launches; eager launch overhead
-        would dominate).  `grad_sync` (data parallel) runs between the backward graph and the optimizer graph."""
+    def _capture_fb(self, static, scale, first, expanded_len, overlap, plain) -> Dict:
+        """Capture one micro-batch variant (forward + losses + backward) of a batch shape; called under capture_lock."""
+        torch.cuda.synchronize()
+        fb = {"g1": torch.cuda.CUDAGraph(), "g2": None, "prog": None}
+        # thread_local: with an RCCL process group alive, its watchdog thread polls events while we capture; only
+        # this thread's calls must be capture-safe
+        if overlap:     # two graphs: the all-reduce of the gradients that are final at the split runs beside the second
+            gen = self._fb_gen(static, scale, True, True, self.dp_overlap_layer, first, expanded_len)
+            with torch.cuda.graph(fb["g1"], capture_error_mode="thread_local"):
+                assert next(gen) == "split"
+            fb["g2"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(fb["g2"], capture_error_mode="thread_local"):
+                for _ in gen:
+                    raise RuntimeError("forward_backward paused twice")
+            fb["ranges"] = self.early_late_ranges(self.dp_overlap_layer)
+        elif plain and self.segmented_graphs and self.overlap:
+            fb["prog"] = self._capture_segments(static, scale, first, expanded_len)
+        else:
+            with torch.cuda.graph(fb["g1"], capture_error_mode="thread_local"):
+                self.forward_backward(static, loss_scale=scale, adaptive=True, zero_grads=first, expanded_len=expanded_len)
+        return fb
+
+    def train_step_graphed(self, batch: Dict[str, torch.Tensor], grad_sync=None, accumulation_divisor: Optional[int] = None,
+                           boundary: Optional[bool] = None, expanded_len: Optional[int] = None) -> torch.Tensor:
+        """Same semantics as train_step (gradient accumulation included), but the kernel sequence of a micro-batch is
+        captured once per (batch shape, accumulation divisor, first-of-cycle) into hipGraphs and replayed (a step is ~700
+        launches; eager launch overhead would dominate), and the optimizer boundary once per (shape, mel length).
+        `grad_sync` (data parallel) runs between the backward graph and the optimizer graph.  The first call with a new
+        shape runs eagerly: it sizes the workspace and builds the descriptor tables, neither of which may happen inside
+        a capture."""
         B, T = batch["mel_specs"].shape[:2]
-        key = (B, T, batch["phoneme_indices"].shape[1])
-        ent = self._graphs.get(key)
+        Tp = T if expanded_len is None else int(expanded_len)
+        key = (B, T, batch["phoneme_indices"].shape[1], Tp)
         if self.loss_sync is not None:
             raise RuntimeError("train_step_graphed: the loss-count exchange (loss_sync) runs between kernels of the step; "
                                "use train_step for ragged data-parallel shards")
-        overlap = grad_sync is not None and self.dp_overlap_layer is not None and hasattr(grad_sync, "start")
+        G = max(1, int(self.hp.gradient_accumulation_steps))
+        div = int(accumulation_divisor) if accumulation_divisor is not None else G
+        first = self.micro_in_cycle == 0
+        is_boundary = bool(boundary) if boundary is not None else self.micro_in_cycle + 1 >= G
+        scale = self.dp_loss_scale / div
+        mel_length = int(self.global_mel_length or T)
+        plain = G == 1 and div == 1                   # the split-backward / segmented forms exist for the one-micro-batch step
+        overlap = plain and grad_sync is not None and self.dp_overlap_layer is not None and hasattr(grad_sync, "start")
+        ent = self._graphs.get(key)
         if ent is None:                               # first sight of a shape: eager (allocates the workspaces and the
             static = {k: v.clone() for k, v in batch.items()}      # reduction tables — host-to-device copies, illegal in a capture)
-            self._graphs[key] = {"static": static, "fb": None, "opt": None}
-            gen = self._fb_gen(static, self.dp_loss_scale, True, True, self.dp_overlap_layer if overlap else None, True)
+            gen = self._fb_gen(static, scale, True, True, self.dp_overlap_layer if overlap else None, first, expanded_len)
             for _ in gen:                             # same pause point as the captured form, so the same tables get built
                 pass
-            if grad_sync is not None:
-                grad_sync(self.arena.g)
-            self.optimizer_step(T)
+            # (registered only now: growing a buffer during the eager pass drops every graph entry)
+            if len(self._graphs) >= self.max_graphs:
+                torch.cuda.synchronize(self.device)   # a graph about to be destroyed may still be running
+                self._graphs.popitem(last=False)
+            self._graphs[key] = {"static": static, "fb": {}, "opt": {}}
+            self.micro_in_cycle += 1
+            if is_boundary:
+                if grad_sync is not None:
+                    grad_sync(self.arena.g)
+                self.optimizer_step(mel_length)
+                self.micro_in_cycle = 0
             return self.losses
+        self._graphs.move_to_end(key)
         static = ent["static"]
         moved = []
         for k, v in batch.items():
@@ -1381,39 +1557,33 @@ class KokoroEngine:
                 d.copy_(v, non_blocking=True)
         if moved:
             kk.copy_many(moved)                        # one launch for the whole batch
-        if ent["fb"] is None:
-            torch.cuda.synchronize()
-            ent["fb"], ent["fb2"], ent["opt"] = torch.cuda.CUDAGraph(), None, torch.cuda.CUDAGraph()
-            # thread_local: with an RCCL process group alive, its watchdog thread polls events while we capture; only
-            # this thread's calls must be capture-safe
-            if overlap:     # two graphs: the all-reduce of the gradients that are final at the split runs beside the second
-                gen = self._fb_gen(static, self.dp_loss_scale, True, True, self.dp_overlap_layer, True)
-                with torch.cuda.graph(ent["fb"], capture_error_mode="thread_local"):
-                    assert next(gen) == "split"
-                ent["fb2"] = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ent["fb2"], capture_error_mode="thread_local"):
-                    for _ in gen:
-                        raise RuntimeError("forward_backward paused twice")
-                ent["ranges"] = self.early_late_ranges(self.dp_overlap_layer)
-            elif self.segmented_graphs and self.overlap:
-                ent["prog"] = self._capture_segments(static)
-            else:
-                with torch.cuda.graph(ent["fb"], capture_error_mode="thread_local"):
-                    self.forward_backward(static, loss_scale=self.dp_loss_scale, adaptive=True, zero_grads=True)
-            with torch.cuda.graph(ent["opt"], capture_error_mode="thread_local"):
-                self.optimizer_step(T)
-        if ent.get("prog") is not None:
-            self._run_program(ent["prog"])
+        fkey = (div, first, self.train_dropout, self.spec_augment_active, self.math, overlap)
+        fb = ent["fb"].get(fkey)
+        if fb is None:
+            with self.capture_lock:
+                fb = ent["fb"][fkey] = self._capture_fb(static, scale, first, expanded_len, overlap, plain)
+        if fb["prog"] is not None:
+            self._run_program(fb["prog"])
         else:
-            ent["fb"].replay()
-        if ent["fb2"] is not None:
-            early, late = ent["ranges"]
+            fb["g1"].replay()
+        self.micro_in_cycle += 1
+        if fb["g2"] is not None:
+            early, late = fb["ranges"]
             works = grad_sync.start(self.arena.g, early)      # asynchronous, on the collective stream
-            ent["fb2"].replay()                               # ... while the rest of the backward runs
+            fb["g2"].replay()                                 # ... while the rest of the backward runs
             grad_sync.finish(self.arena.g, late, works)
-        elif grad_sync is not None:
+        elif grad_sync is not None and is_boundary:
             grad_sync(self.arena.g)
-        ent["opt"].replay()
+        if is_boundary:
+            opt = ent["opt"].get(mel_length)
+            if opt is None:
+                with self.capture_lock:
+                    torch.cuda.synchronize()
+                    opt = ent["opt"][mel_length] = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(opt, capture_error_mode="thread_local"):
+                        self.optimizer_step(mel_length)
+            opt.replay()
+            self.micro_in_cycle = 0
         return self.losses
 
     def opt_stats(self) -> Dict[str, float]:

@@ -133,6 +133,8 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_length_regulate_index": [_P, _P, _P, _P, _I, _I, _I, _P],
     "kk_length_regulate_gather": [_P, _P, _P, _I, _I, _I, _I, _P],
     "kk_max_i64": [_P, _L, _P, _P],
+    "kk_pad2d_f32": [_P, _L, _I, _P, _L, _I, _L, _P],
+    "kk_frame_mask": [_P, _P, _I, _I, _P],
     "kk_im2col3_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "kk_im2col3_bwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "kk_groupnorm_relu_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _U, _F, _P],

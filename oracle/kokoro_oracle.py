@@ -861,12 +861,60 @@ class OptState:
     v: Dict[str, Tensor] = field(default_factory=dict)
 
 
+class ExplosionTracker:
+    """Gradient-explosion tracker of the step boundary (trainer.py:914-925 set-up, :1315-1330 threshold, :2367-2405 use).
+
+    threshold = floor(t) until the EMA of the total gradient norm has seen `min_ema_steps` norms, then
+    max(floor(t), multiplier * EMA); floor(t) decays linearly from warmup_floor to abs_floor over the first
+    `warmup_steps` COMPLETED optimizer steps.  A norm above the threshold caps the step's clip norm at 0.3
+    ("emergency clipping"); the EMA then takes the norm in either way.  Python semantics kept: `nan > thr` is False and
+    `max(floor, nan)` returns floor, so a non-finite norm never counts as an explosion but poisons the EMA for good
+    (the step itself is skipped by the non-finite guard, trainer.py:2407-2463)."""
+
+    def __init__(self, hp: "StepHyper"):
+        self.alpha = hp.grad_explosion_ema_alpha
+        self.abs_floor = hp.grad_explosion_abs_floor
+        self.multiplier = hp.grad_explosion_multiplier
+        self.warmup_steps = hp.grad_explosion_warmup_steps
+        self.warmup_floor = hp.grad_explosion_warmup_floor
+        self.min_ema_steps = hp.grad_explosion_min_ema_steps
+        self.ema: Optional[float] = None
+        self.ema_steps = 0
+        self.streak = 0
+
+    def threshold(self, steps_completed: int) -> Tuple[float, float, bool]:
+        w = max(0, self.warmup_steps)
+        if w > 0 and steps_completed < w:
+            floor = self.warmup_floor - (self.warmup_floor - self.abs_floor) * (steps_completed / float(w))
+        else:
+            floor = self.abs_floor
+        ready = self.ema_steps >= self.min_ema_steps
+        ema_thr = 0.0 if self.ema is None else self.ema * self.multiplier
+        return (floor if not ready else max(floor, ema_thr)), floor, ready
+
+    def observe(self, total_norm: float, steps_completed: int, clip_norm: float) -> Tuple[float, bool]:
+        """(clip norm for this step, exploding?) and the EMA / streak update."""
+        thr, _, _ = self.threshold(steps_completed)
+        exploding = total_norm > thr
+        if exploding:
+            self.streak += 1
+            clip_norm = min(clip_norm, 0.3)
+        else:
+            self.streak = 0
+        self.ema = total_norm if self.ema is None else self.alpha * self.ema + (1 - self.alpha) * total_norm
+        self.ema_steps += 1
+        return clip_norm, exploding
+
+
 def optimizer_step(P: Dict[str, Tensor], G: Dict[str, Tensor], st: OptState, hp: StepHyper,
                    base_lr: float, clip_norm: float, ema: Optional[Dict[str, Tensor]] = None,
-                   buffers: Optional[Dict[str, Tensor]] = None) -> Dict[str, float]:
+                   buffers: Optional[Dict[str, Tensor]] = None,
+                   tracker: Optional[ExplosionTracker] = None) -> Dict[str, float]:
     """One optimizer-step boundary, in the reference's order (trainer.py:2346-2477):
-    pre-clip → total norm → global clip (runtime_policies.py:76; clip_grad_norm_) → AdamW →
-    EMA over state_dict floats → FFN weight-norm projection.  Mutates P, G, st, ema."""
+    pre-clip → total norm → [explosion tracker: emergency clip] → [non-finite gradients: skip] → global clip
+    (runtime_policies.py:76; clip_grad_norm_) → AdamW → EMA over state_dict floats → FFN weight-norm projection.
+    Mutates P, G, st, ema (and `tracker`).  `clip_norm` is the batch-shape adaptive clip norm
+    (adaptive_loss_scale_and_clip) the reference enters the boundary with."""
     info: Dict[str, float] = {}
     with torch.no_grad():
         for n, g in G.items():                                     # S2
@@ -878,6 +926,12 @@ def optimizer_step(P: Dict[str, Tensor], G: Dict[str, Tensor], st: OptState, hp:
                 g.mul_(mx / (nr + 1e-12))
         total = math.sqrt(sum(float(g.norm(2)) ** 2 for g in G.values()))   # S3
         info["grad_norm"] = total
+        if tracker is not None:
+            clip_norm, info["exploding"] = tracker.observe(total, st.step, clip_norm)
+        info["clip_norm"] = clip_norm
+        if not all(bool(torch.isfinite(g).all()) for g in G.values()):      # trainer.py:2407-2463: skip, nothing moves
+            info["skipped"] = True
+            return info
         norms = torch.stack([g.norm(2) for g in G.values()])       # S4: clip_grad_norm_
         tn = torch.linalg.vector_norm(norms, 2)
         coef = torch.clamp(clip_norm / (tn + 1e-6), max=1.0)

@@ -11,6 +11,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # a hung test must not eat the GPU box's time limit: default per-test timeout when pytest-timeout is there
+    if config.pluginmanager.hasplugin("timeout") and not getattr(config.option, "timeout", None):
+        config.option.timeout = 600
 
 
 @pytest.fixture(scope="session")

@@ -487,11 +487,150 @@ def section_loss_known_answers():
     print("  [ok ] total = ln 2 with NaN in a padded frame")
 
 
+def _reference_block(first: str, last: str) -> str:
+    """The statements of KokoroTrainer.train_epoch from the line containing `first` to the line containing `last`
+    (inclusive), dedented — the reference keeps the batch-shape heuristics and the explosion bookkeeping inline in its
+    epoch loop, so the only way to RUN them is to lift the lines out of the imported source."""
+    import inspect
+    import textwrap
+    lines = inspect.getsource(KokoroTrainer.train_epoch).splitlines()
+    a = next(i for i, l in enumerate(lines) if first in l)
+    b = next(i for i in range(a, len(lines)) if last in lines[i])
+    return textwrap.dedent("\n".join(lines[a:b + 1]))
+
+
+def section_step_driver():
+    """Pins the oracle's step-boundary heuristics against the reference's own statements, executed from its source:
+    adaptive loss scale / clip norm from the batch shape (trainer.py:2218-2242) and the gradient-explosion tracker
+    (trainer.py:914-925, 1315-1330, 2367-2405) over a scripted sequence of gradient norms."""
+    print("== step driver: batch-shape heuristics + explosion tracker")
+    cfg = TrainingConfig()
+    hp = O.StepHyper()
+    model = ref_model(O.ModelDims(vocab=59, mel=20, hidden=64, heads=1, enc_layers=1, dec_layers=1, enc_ff=32, dec_ff=32,
+                                  var_filter=32, var_kernel=3, var_bins=16, max_len=100))
+    quiet = logging.getLogger("quiet")
+    # ---- adaptive loss scale / clip (the block ends with the hard-risk assignments; logging follows it) ----
+    src = _reference_block("max_mel_length = 1400", "adaptive_clip_norm = max(0.05")
+    code = compile(src, "<trainer.py:2218-2242>", "exec")
+    rows = []
+    for T in (64, 512, 1399, 1400, 1401, 1500, 1800, 2000, 2800, 5600, 9000):
+        for md in (1, 40, 149, 150, 151, 200, 300, 450, 600, 1200):
+            tr = make_trainer(model, cfg)
+            ns = {"self": tr, "mel_specs": torch.zeros(1, T, 1), "phoneme_durations": torch.tensor([[1, md]]),
+                  "logger": quiet, "batch_idx": 0, "getattr": getattr, "max": max, "min": min}
+            exec(code, ns)
+            scale, clip = O.adaptive_loss_scale_and_clip(T, md, hp.max_grad_norm)
+            assert abs(ns["adaptive_loss_scale"] - scale) < 1e-15 and abs(ns["adaptive_clip_norm"] - clip) < 1e-15, (T, md)
+            rows.append([T, md, ns["adaptive_loss_scale"], ns["adaptive_clip_norm"]])
+    print(f"  [ok ] adaptive loss scale / clip norm: {len(rows)} (mel length, max duration) pairs")
+    # ---- explosion tracker over a scripted norm sequence ----
+    src = _reference_block("grad_norm_ema_for_threshold =", "self.grad_explosion_ema_steps += 1")
+    code = compile(src, "<trainer.py:2367-2405>", "exec")
+    rs = np.random.RandomState(3)
+    norms = np.abs(rs.lognormal(1.0, 0.6, size=520)) * np.linspace(40.0, 1.0, 520)     # early training: large, decaying
+    norms[37] = 9500.0                    # above the warm-up floor (8000 -> 1000 over 400 steps)
+    norms[120:123] = [3000.0, 6500.0, 7000.0]       # streak of three while the floor is ~5900: only two are above it
+    norms[260] = 2600.0                   # floor 3450 at step 260, EMA-based threshold lower than the floor: quiet
+    norms[430] = 1200.0                   # past the floor's warm-up: threshold max(1000, 3*EMA)
+    norms[470] = float(norms[440:470].mean() * 3.5) + 1000.0
+    norms[500] = 900.0
+    tr = make_trainer(model, cfg)
+    tr._setup_grad_explosion_tracker()
+    tr.optimizer_steps_completed = 0
+    tr._has_nonfinite_gradients = lambda: False
+    mine = O.ExplosionTracker(hp)
+    out = []
+    for k, nv in enumerate(norms.tolist()):
+        thr_ref = tr._compute_grad_explosion_threshold()
+        thr_mine = mine.threshold(k)
+        assert abs(thr_ref[0] - thr_mine[0]) <= 1e-9 * max(1.0, abs(thr_ref[0])) and thr_ref[2] == thr_mine[2], (k, thr_ref, thr_mine)
+        ns = {"self": tr, "total_grad_norm": nv, "adaptive_clip_norm": cfg.max_grad_norm, "logger": quiet, "batch_idx": k,
+              "grad_norms_by_param": [], "has_nonfinite_grads": False}
+        exec(code, ns)
+        clip, expl = mine.observe(nv, k, hp.max_grad_norm)
+        assert clip == ns["adaptive_clip_norm"] and expl == bool(ns["is_exploding"]), (k, nv, clip, ns["adaptive_clip_norm"])
+        assert abs(mine.ema - tr.grad_explosion_norm_ema) <= 1e-9 * abs(mine.ema) and mine.streak == tr.grad_explosion_streak
+        out.append([nv, thr_ref[0], clip, float(expl), tr.grad_explosion_norm_ema, float(tr.grad_explosion_streak)])
+        tr.optimizer_steps_completed += 1          # (every step of this sequence succeeds)
+    n_expl = int(sum(r[3] for r in out))
+    assert n_expl >= 5, n_expl
+    print(f"  [ok ] explosion tracker: {len(out)} steps, {n_expl} explosions, thresholds / clip norms / EMA identical")
+    np.savez_compressed(os.path.join(HERE, "step_driver.npz"), adaptive=np.array(rows, dtype=np.float64),
+                        explosion=np.array(out, dtype=np.float64))
+
+
+def section_expanded_length(d: O.ModelDims):
+    """Expanded length T' = max_b sum(dur) != mel length T (model.py:607-628): T' > T is served (predictors on T' frames,
+    memory and losses on the first T), T' < T fails in the reference's pitch loss (losses.py:126)."""
+    print("== expanded length != mel length")
+    cfg = TrainingConfig()
+    hp = O.StepHyper()
+    model = ref_model(d)
+    P = seeded_params(d, 31)
+    sd = dict(P)
+    sd.update(O.make_buffers(d))
+    model.load_state_dict(sd, strict=True)
+    Bf = O.make_buffers(d)
+    save = {"dims": np.array([getattr(d, f) for f in ("vocab", "mel", "hidden", "heads", "enc_layers", "dec_layers", "enc_ff",
+                                                       "dec_ff", "var_filter", "var_kernel", "var_bins", "max_len")]),
+            "seed": np.array(31)}
+    for tag, B, T, Pn, extra in (("longer", 3, 37, 9, (5, 0, 11)), ("longer_chunk", 2, 509, 30, (9, 2))):
+        batch = O.synthetic_batch(B, T, Pn, d, seed=40 + B, ragged=True)
+        dur = batch["phoneme_durations"].clone()
+        for b, e in enumerate(extra):
+            dur[b, 1] += e
+        batch["phoneme_durations"] = dur
+        Tp = int(dur.sum(1).max())
+        assert Tp > T
+        out, ls = run_ref(model, cfg, batch)
+        mine = O.forward(P, Bf, batch, d)
+        lm = O.losses(mine, batch, hp)
+        for k, i in (("mel", 0), ("log_dur", 1), ("stop", 2), ("pitch", 3), ("energy", 4)):
+            assert tuple(out[i].shape) == tuple(mine[k].shape), (k, out[i].shape, mine[k].shape)
+            check(f"{tag} (T={T}, T'={Tp}) output {k} {tuple(out[i].shape)}", mine[k], out[i].detach(), 2e-6, 1e-6)
+        for a, b in zip(lm, ls):
+            check(f"{tag} loss", a, b.detach(), 2e-6, 1e-6)
+        G, _, _ = O.grads_of(P, Bf, batch, d, hp)
+        model.zero_grad()
+        ls[0].backward()
+        worst = 0.0
+        for n, p in model.named_parameters():
+            ref = p.grad if p.grad is not None else torch.zeros_like(p)
+            if float(ref.norm()) > 1e-9:
+                worst = max(worst, float((G[n] - ref).norm() / ref.norm()))
+        assert worst < 1e-4, worst
+        print(f"  [ok ] {tag}: all gradients, worst relative error {worst:.2e}")
+        for k, v in batch.items():
+            save[f"{tag}/batch/{k}"] = v.numpy()
+        for k, i in (("mel", 0), ("log_dur", 1), ("stop", 2), ("pitch", 3), ("energy", 4)):
+            save[f"{tag}/out/{k}"] = out[i].detach().numpy()
+        save[f"{tag}/losses"] = np.array([float(x) for x in ls])
+        names = list(O.param_shapes(d))
+        save[f"{tag}/grad_norms"] = np.array([float(G[n].norm()) for n in names])
+    # shorter: both sides must raise the size-mismatch RuntimeError
+    batch = O.synthetic_batch(2, 40, 6, d, seed=3, ragged=True)
+    batch["phoneme_durations"][:, 0] = (batch["phoneme_durations"][:, 0] - 3).clamp(min=0)
+    for who, fn in (("reference", lambda: run_ref(model, cfg, batch)), ("oracle", lambda: O.losses(O.forward(P, Bf, batch, d), batch, hp))):
+        try:
+            fn()
+        except RuntimeError as e:
+            assert "must match the size of tensor" in str(e), str(e)
+            print(f"  [ok ] {who} raises for T' < T: {str(e)[:70]}")
+        else:
+            raise AssertionError(f"{who} accepted T' < T")
+    np.savez_compressed(os.path.join(HERE, "expanded_length.npz"), **save)
+
+
 if __name__ == "__main__":
     tiny = O.ModelDims(vocab=59, mel=20, hidden=128, heads=2, enc_layers=2, dec_layers=2, enc_ff=96,
                        dec_ff=96, var_filter=32, var_kernel=3, var_bins=16, max_len=700)
     if sys.argv[1:] == ["inference"]:                            # only the decode fixture
         section_inference(tiny, seed=21)
+        sys.exit(0)
+    if sys.argv[1:] == ["step"]:                                 # only the step-driver / expanded-length fixtures
+        section_step_driver()
+        section_expanded_length(O.ModelDims(vocab=59, mel=80, hidden=128, heads=2, enc_layers=1, dec_layers=1, enc_ff=192,
+                                            dec_ff=192, var_filter=64, var_kernel=3, var_bins=256, max_len=700))
         sys.exit(0)
     section_surface()
     section_sampler()
@@ -506,5 +645,7 @@ if __name__ == "__main__":
     # default dims (49.4 M params), small ragged batch: weights regenerated from the seed on both sides
     section_model("full_dims", O.ModelDims(), B=2, T=96, Pn=12, seed=14, ragged=True, save_step=False, seeded=True)
     section_tables()
+    section_step_driver()
+    section_expanded_length(mid)
     section_inference(tiny, seed=21)
     print("ALL REFERENCE CHECKS PASSED")

@@ -129,3 +129,78 @@ def test_trainer_helpers():
          "phoneme_lengths": torch.tensor([5, 3])}
     c = cap_batch(b, max_mel=20, max_ph=4)
     assert c["mel_specs"].shape == (2, 20, 4) and c["mel_lengths"].tolist() == [20, 12] and c["phoneme_indices"].shape == (2, 4)
+
+
+def test_clip_durations_keeps_the_prefix():
+    import torch
+    from kokoro.data.cached import clip_durations
+    from oracle import kokoro_oracle as O
+    dur = torch.tensor([3, 0, 5, 2, 7, 1])
+    for T in (0, 1, 3, 4, 8, 10, 17, 18, 40):
+        c = clip_durations(dur, T)
+        assert int(c.sum()) == min(int(dur.sum()), T) and bool((c >= 0).all()) and bool((c <= dur).all())
+        idx_full, _, _ = O.length_regulate_index(dur[None].numpy(), None)
+        idx_clip, lens, _ = O.length_regulate_index(c[None].numpy(), None)
+        n = int(c.sum())
+        assert (idx_clip[0, :n] == idx_full[0, :n]).all()               # the expansion is a prefix of the original one
+
+
+def test_cached_dataset_scans_once_and_clips_durations(tmp_path):
+    import torch
+    from kokoro.data import cached
+    from kokoro_ruslan_amd.synthetic import synthetic_batch
+    d = tmp_path / ".feature_cache"
+    d.mkdir()
+    for i, (T, P) in enumerate(((50, 6), (90, 9), (70, 5))):
+        b = synthetic_batch(1, T, P, seed=i)
+        torch.save({"mel_spec": b["mel_specs"][0].T.contiguous(), "phoneme_indices": b["phoneme_indices"][0],
+                    "stress_indices": b["stress_indices"][0], "phoneme_durations": b["phoneme_durations"][0],
+                    "stop_token_targets": b["stop_token_targets"][0], "pitch": b["pitches"][0], "energy": b["energies"][0],
+                    "text": "x", "audio_file": f"u{i}", "mel_length": T, "phoneme_length": P, "_cache_version": 7}, d / f"u{i}.pt")
+    metas = cached.scan_cache(str(d))
+    assert [m["audio_length"] for m in metas] == [50, 70, 90] and (d / ".kk_index.json").exists()
+    loads = []
+    orig = torch.load
+    torch.load = lambda *a, **k: (loads.append(1), orig(*a, **k))[1]
+    try:
+        assert [m["audio_length"] for m in cached.scan_cache(str(d))] == [50, 70, 90]
+    finally:
+        torch.load = orig
+    assert not loads, "the second scan must come from the index file"
+    ds = cached.CachedFeatureDataset(str(d), None, max_seq_length=60, memory_cache=False, metas=metas)
+    assert [m["audio_length"] for m in ds.samples] == [50, 60, 60]
+    for i in range(3):
+        it = ds[i]
+        T = int(it["mel_length"])
+        assert T <= 60 and it["mel_spec"].shape[1] == T and int(it["phoneme_durations"].sum()) == T
+    batch = cached.collate_fn([ds[i] for i in range(3)])
+    assert int(batch["phoneme_durations"].sum(1).max()) == batch["mel_specs"].shape[1]
+
+
+def test_collate_into_equals_capped_collate_fn(tmp_path):
+    """The loader thread's numpy fill of a flat staging buffer == cap_batch(collate_fn(...)) of the reference contract."""
+    import numpy as np
+    import torch
+    from kokoro.data import cached
+    from kokoro.training.trainer import cap_batch
+    from kokoro_ruslan_amd.synthetic import synthetic_batch
+    items = []
+    for i, (T, P) in enumerate(((50, 6), (90, 9), (70, 5), (33, 12))):
+        b = synthetic_batch(1, T, P, seed=i)
+        items.append({"mel_spec": b["mel_specs"][0].T.contiguous(), "phoneme_indices": b["phoneme_indices"][0],
+                      "stress_indices": b["stress_indices"][0], "phoneme_durations": b["phoneme_durations"][0],
+                      "stop_token_targets": b["stop_token_targets"][0], "pitch": b["pitches"][0], "energy": b["energies"][0],
+                      "mel_length": T, "phoneme_length": P})
+    for max_mel, max_ph in ((2000, 2000), (60, 8)):
+        ref = cap_batch(cached.collate_fn(items), max_mel, max_ph)
+        B, T, P, M, mel_len, ph_len, plan, total = cached.batch_layout(items, max_mel, max_ph)
+        buf = np.full(total, 0xAB, dtype=np.uint8)                       # dirty memory: padding must be written
+        out = {k: buf[off:off + n].view(dt).reshape(shape) for k, off, n, shape, dt in plan}
+        cached.collate_into(items, out, mel_len, ph_len)
+        assert set(out) == set(ref)
+        for k in ref:
+            assert tuple(out[k].shape) == tuple(ref[k].shape), k
+            assert np.array_equal(out[k], ref[k].numpy()), k
+        assert all(off % 256 == 0 for _, off, _, _, _ in plan)
+    again = cached.collate_fn(items)                                     # items stay valid for the tensor-level collate
+    assert torch.equal(again["mel_specs"], cached.collate_fn(items)["mel_specs"])

@@ -424,8 +424,250 @@ def test_segmented_graph_program_trains_like_the_single_graph(eng_mod, golden_di
         assert e.opt_stats()["attempt"] == 5
         out.append((losses, e.arena.p.clone()))
         if seg:
-            ent = next(iter(e._graphs.values()))
+            ent = next(iter(next(iter(e._graphs.values()))["fb"].values()))
             kinds = [op for op, _, _ in ent["prog"]]
             assert kinds.count("launch") >= 6 and "wait" in kinds
     torch.testing.assert_close(out[1][0], out[0][0], rtol=2e-6, atol=1e-7)      # (fp32 atomics in a few reductions)
     assert float((out[1][1] - out[0][1]).abs().max()) <= 2e-5 * float(out[0][1].abs().max())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 2: expanded length, bounded workspace, the step driver's device branches, graph replay at the bench shape
+# ---------------------------------------------------------------------------------------------------------------------
+def test_expanded_length_parity(eng_mod, golden_dir):
+    """T' = max_b sum(dur) > T (model.py:607-628) against the reference's own outputs: [B, T'] pitch / energy predictions,
+    mel / losses / gradients on the first T frames; T' < T raises the reference's size-mismatch RuntimeError."""
+    fx = np.load(os.path.join(golden_dir, "expanded_length.npz"))
+    d = O.ModelDims(*[int(x) for x in fx["dims"]])
+    seed = int(fx["seed"])
+    P = O.init_params(d, seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    for n, p in P.items():
+        if p.dim() == 1:
+            p.add_(torch.randn(p.shape, generator=g) * 0.1)
+    e = _engine(eng_mod, d, P)
+    names = list(O.param_shapes(d))
+    for tag in ("longer", "longer_chunk"):
+        batch = {k.split("/", 2)[2]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith(f"{tag}/batch/")}
+        T, Tp = batch["mel_specs"].shape[1], int(batch["phoneme_durations"].sum(1).max())
+        e.zero_grad()
+        out = e.forward_backward(_cuda(batch), expanded_len=Tp)
+        torch.cuda.synchronize()
+        assert tuple(out["pitch"].shape) == (batch["mel_specs"].shape[0], Tp)
+        for k in ("mel", "log_dur", "stop", "pitch", "energy"):
+            ref = torch.from_numpy(fx[f"{tag}/out/{k}"])
+            err = float((out[k].cpu() - ref).abs().max())
+            assert err < 2e-4, f"{tag}: output {k} max|err| {err:.3e}"
+        np.testing.assert_allclose(out["losses"].cpu().double().numpy(), fx[f"{tag}/losses"], atol=1e-4, rtol=1e-5)
+        got = np.array([float(e.arena.G[n].double().norm()) for n in names])
+        np.testing.assert_allclose(got, fx[f"{tag}/grad_norms"], rtol=2e-3, atol=1e-6)
+        with pytest.raises(RuntimeError, match="must match the size of tensor"):
+            e.forward_backward(_cuda(batch), expanded_len=T - 2)
+    # without the hint the engine assumes T' = T; the same batch with consistent durations runs either way identically
+    b2 = O.synthetic_batch(2, 48, 7, d, seed=5, ragged=True)
+    l0 = e.forward_backward(_cuda(b2), backward=False)["losses"].clone()
+    l1 = e.forward_backward(_cuda(b2), backward=False, expanded_len=48)["losses"].clone()
+    torch.testing.assert_close(l0, l1, rtol=1e-5, atol=1e-6)          # (split-K fp32 atomics reorder a few sums)
+
+
+def test_workspace_is_bounded_by_the_largest_shape(eng_mod, golden_dir):
+    """Dynamic batching shows the engine a new (B, T, P) nearly every step: the activation workspace must be sized by the
+    largest batch, not by the number of shapes, and a shape must compute the same whether it came first or fiftieth."""
+    fx, d, _, P = _load(golden_dir, "tiny_full")
+    e = _engine(eng_mod, d, P, math_mode="bf16", gradient_accumulation_steps=1)
+    rs = np.random.RandomState(0)
+    shapes = [(4, 160, 24)] + [(int(rs.randint(1, 5)), int(rs.randint(48, 161)), int(rs.randint(4, 25))) for _ in range(50)]
+    torch.cuda.synchronize()
+    sizes, allocs = [], []
+    for i, (B, T, Pn) in enumerate(shapes):
+        b = _cuda(O.synthetic_batch(B, T, Pn, d, seed=200 + i, ragged=True))
+        e.train_step(b)
+        sizes.append(e.workspace_bytes())
+        allocs.append(torch.cuda.memory_allocated())
+    torch.cuda.synchronize()
+    assert e.opt_stats()["skipped"] == 0
+    assert sizes[-1] <= sizes[0] * 1.30, (sizes[0], sizes[-1])           # later, smaller shapes add (almost) nothing
+    assert allocs[-1] <= allocs[0] * 1.30 + (8 << 20), (allocs[0], allocs[-1])
+    assert len(e._tables) <= e.max_tables
+    # a shape seen late gives the losses and gradients of a fresh engine
+    probe = O.synthetic_batch(3, 77, 11, d, seed=9, ragged=True)
+    e2 = _engine(eng_mod, d, {n: e.arena.P[n].clone() for n in P}, math_mode="bf16", gradient_accumulation_steps=1)
+    for x in (e, e2):
+        x.zero_grad()
+        x.forward_backward(_cuda(probe))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(e.losses, e2.losses, rtol=1e-6, atol=1e-7)
+    assert float((e.arena.g - e2.arena.g).abs().max()) <= 1e-4 * float(e2.arena.g.abs().max()) + 1e-7
+
+
+def test_device_step_driver_against_reference_sequences(eng_mod, golden_dir):
+    """kk_opt_prepare over scripted gradient norms: explosion thresholds / emergency clip / EMA / streak against
+    step_driver.npz (produced by running the reference's statements), and the device LR schedule through warm-up AND the
+    cosine phase against the reference's scheduler sequence lr_seq_60_20.npy."""
+    from kokoro_ruslan_amd import lib as kk, spec
+    fx = np.load(os.path.join(golden_dir, "step_driver.npz"))
+    d = O.ModelDims(vocab=59, mel=20, hidden=128, heads=2, enc_layers=1, dec_layers=1, enc_ff=96, dec_ff=96, var_filter=32,
+                    var_kernel=3, var_bins=16, max_len=300)
+    P = O.init_params(d, 1)
+
+    def drive(e, norms, check):
+        a = e.arena
+        seg = a.names.index("decoder.norm.weight")           # a segment without a pre-clip ceiling
+        for k, nv in enumerate(norms):
+            e.grad_sumsq.zero_()
+            e.grad_sumsq[seg] = float(nv) ** 2
+            cfg = e._opt_cfg(64)
+            kk.call("kk_opt_prepare", e.grad_sumsq, a.seg_preclip, a.seg_lr_mult, a.seg_wd, a.nseg, e.max_dur, cfg, e.opt_state,
+                    e.seg_gscale, e.seg_decay, e.seg_stepsize, e.step_consts)
+            check(k, e.opt_stats(), e)
+    # ---- explosion tracker: 520 steps ----
+    e = _engine(eng_mod, d, P, gradient_accumulation_steps=1)
+    e.max_dur.zero_()
+    rows = fx["explosion"]
+
+    def chk_expl(k, st, eng):
+        norm, thr, clip, expl, ema, streak = rows[k]
+        assert abs(st["last_grad_norm"] - norm) <= 1e-9 * norm
+        assert abs(st["last_clip_norm"] - clip) < 1e-12, (k, st["last_clip_norm"], clip)
+        assert abs(st["expl_ema"] - ema) <= 1e-9 * abs(ema) and st["expl_streak"] == streak, (k, st, rows[k])
+        assert abs(st["last_clip_coef"] - min(1.0, clip / (norm + 1e-6))) < 1e-9
+    drive(e, rows[:, 0], chk_expl)
+    assert e.opt_stats()["attempt"] == len(rows) and e.opt_stats()["skipped"] == 0
+    # ---- LR schedule: 20 warm-up steps + 40 one-cycle steps + 3 beyond the end ----
+    seq = np.load(os.path.join(golden_dir, "lr_seq_60_20.npy"))          # [63, 10] per-group LR the reference used at step k
+    e = _engine(eng_mod, d, P, gradient_accumulation_steps=1, warmup_steps=20)
+    e.total_steps = 60
+    e.max_dur.zero_()
+    table = spec.group_lr_mult_wd(e.hp)
+    segs = {gi: next(i for i, n in enumerate(e.arena.names) if n in e.arena.param_names and spec.param_group_of(n) == gi) for gi in range(10)}
+
+    def chk_lr(k, st, eng):
+        for gi in range(10):
+            want = float(seq[k, gi])
+            assert abs(st["last_base_lr"] * table[gi][0] - want) <= 1e-12 + 1e-9 * want, (k, gi)
+        bc1 = 1.0 - eng.hp.adam_betas[0] ** (k + 1)
+        got = eng.seg_stepsize.cpu().double().numpy()
+        for gi, si in segs.items():
+            assert abs(got[si] - seq[k, gi] / bc1) <= 2e-7 * seq[k, gi] / bc1 + 1e-15, (k, gi)
+    drive(e, np.full(len(seq), 1.0), chk_lr)
+    lrs = seq[:, 2]
+    assert lrs[27] > lrs[40] > lrs[58] > lrs[59] > 0 and lrs[60] == lrs[61] == lrs[62]     # the cosine phase ran down to its floor
+
+
+def test_adaptive_loss_scale_and_clip_fire_on_long_batches(eng_mod, golden_dir):
+    """trainer.py:2218-2242 on the device: a 1500-frame batch with a 200-frame phoneme scales the loss by 0.75 and enters
+    the optimizer boundary with clip norm 0.433 (values from running the reference's statements: step_driver.npz)."""
+    fx = np.load(os.path.join(golden_dir, "step_driver.npz"))
+    row = next(r for r in fx["adaptive"] if int(r[0]) == 1500 and int(r[1]) == 200)
+    scale, clip = float(row[2]), float(row[3])
+    assert scale < 1.0 and clip < 1.5
+    d = O.ModelDims(vocab=59, mel=20, hidden=128, heads=2, enc_layers=1, dec_layers=1, enc_ff=96, dec_ff=96, var_filter=32,
+                    var_kernel=3, var_bins=16, max_len=1600)
+    P = O.init_params(d, 2)
+    batch = O.synthetic_batch(1, 1500, 30, d, seed=1)
+    dur = torch.full((1, 30), 44, dtype=torch.long)          # 200 + 29 x 44 + 24 = 1500 frames, one 200-frame phoneme
+    dur[0, 0] = 200
+    dur[0, 1:25] += 1
+    batch["phoneme_durations"] = dur
+    assert int(dur.sum()) == 1500 and int(dur.max()) == 200
+    e = _engine(eng_mod, d, P, gradient_accumulation_steps=1)
+    b = _cuda(batch)
+    e.zero_grad()
+    e.forward_backward(b, adaptive=False)
+    g0 = e.arena.g.clone()
+    e.zero_grad()
+    out = e.forward_backward(b, adaptive=True)
+    torch.cuda.synchronize()
+    ratio = float((e.arena.g.double() * g0.double()).sum() / (g0.double() ** 2).sum())
+    assert abs(ratio - scale) < 1e-4, (ratio, scale)
+    e.optimizer_step(1500)
+    st = e.opt_stats()
+    assert abs(st["last_clip_norm"] - clip) < 1e-9, (st["last_clip_norm"], clip)
+    # the oracle agrees on the scaled gradients (loss scale folded into the backward seed, losses reported unscaled)
+    Go, ls, _ = O.grads_of(P, O.make_buffers(d), batch, d, O.StepHyper(), loss_scale=scale)
+    np.testing.assert_allclose(out["losses"].cpu().numpy(), [float(x) for x in ls], atol=1e-4, rtol=1e-5)
+
+
+def test_graphed_accumulation_matches_eager(eng_mod, golden_dir):
+    """train_step_graphed with the reference's default accumulation (G = 2): micro-batch graphs (first / second of the
+    cycle) + the boundary graph give the parameters of the eager train_step sequence, masks included."""
+    fx, d, _, P = _load(golden_dir, "tiny_full")
+    batches = [_cuda(O.synthetic_batch(2, 40, 6, d, seed=300 + i, ragged=True)) for i in range(2)]
+    res = []
+    for graphed in (False, True):
+        e = _engine(eng_mod, d, P, math_mode="bf16", gradient_accumulation_steps=2)
+        e.train_dropout = True
+        for it in range(8):                                  # 4 optimizer steps; the graphs replay from the third cycle on
+            b = batches[it % 2]
+            (e.train_step_graphed if graphed else e.train_step)(b)
+        torch.cuda.synchronize()
+        st = e.opt_stats()
+        assert st["attempt"] == 4 and st["skipped"] == 0 and e.micro_in_cycle == 0
+        res.append(e.arena.p.clone())
+        if graphed:
+            assert len(e._graphs) == 1 and len(next(iter(e._graphs.values()))["fb"]) == 2
+    assert float((res[0] - res[1]).abs().max()) <= 2e-5 * float(res[0].abs().max())
+    # the auto path: eager on first sight, graphs once a shape repeats
+    e = _engine(eng_mod, d, P, math_mode="bf16", gradient_accumulation_steps=2)
+    e.train_dropout = True
+    for it in range(8):
+        e.train_step_auto(batches[it % 2])
+    torch.cuda.synchronize()
+    assert float((e.arena.p - res[0]).abs().max()) <= 2e-5 * float(res[0].abs().max())
+    assert len(e._graphs) == 1
+
+
+def test_bench_config_bf16_graph_replay_tracks_fp32_and_oracle(eng_mod):
+    """The configuration bench.py times — 8 x 512 frames x 64 phonemes, default 49.4 M-parameter model, bf16, hipGraph
+    replay — checked for what it computes: (1) losses against the CPU oracle and the fp32 engine, (2) every gradient's
+    direction against the fp32 engine, (3) with all dropout on, a replayed step is the eager step (same seed, same
+    masks), (4) 12 replayed optimizer steps: no skips, finite, the loss moves."""
+    from kokoro_ruslan_amd.synthetic import synthetic_batch
+    d = O.ModelDims()
+    P = O.init_params(d, 0)
+    cpu = synthetic_batch(8, 512, 64, seed=1234)
+    b = _cuda(cpu)
+    f32 = _engine(eng_mod, d, P, gradient_accumulation_steps=1)
+    f32.zero_grad()
+    l32 = f32.forward_backward(b)["losses"].clone()
+    with torch.no_grad():
+        lo = torch.stack([x.float() for x in O.losses(O.forward(P, O.make_buffers(d), cpu, d), cpu, O.StepHyper())])
+    torch.testing.assert_close(l32.cpu(), lo, rtol=2e-4, atol=2e-4)                  # mel-L1 within 1e-4 is asserted below
+    assert abs(float(l32[1]) - float(lo[1])) < 1e-4
+    e = _engine(eng_mod, d, P, math_mode="bf16", gradient_accumulation_steps=1)
+    e.zero_grad()
+    l16 = e.forward_backward(b)["losses"].clone()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(l16.cpu().numpy(), lo.numpy(), rtol=3e-2, atol=3e-2)
+    cos, rel = [], []
+    for n in O.param_shapes(d):
+        a, r = e.arena.G[n].double().flatten(), f32.arena.G[n].double().flatten()
+        if float(r.norm()) > 1e-7:
+            cos.append(float(a @ r / (a.norm() * r.norm() + 1e-30)))
+            rel.append(abs(float(a.norm()) / float(r.norm()) - 1.0))
+    assert min(cos) > 0.95 and float(np.mean(cos)) > 0.99, (min(cos), float(np.mean(cos)))
+    assert float(np.median(rel)) < 0.02, float(np.median(rel))
+    gn32 = float(f32.arena.g.double().norm())
+    assert abs(float(e.arena.g.double().norm()) / gn32 - 1.0) < 0.02
+    del f32
+    # (3) dropout on: eager step vs. graph replay from the same state and seed
+    e.train_dropout = True
+    e2 = _engine(eng_mod, d, P, math_mode="bf16", gradient_accumulation_steps=1)
+    e2.train_dropout = True
+    for _ in range(3):                                       # eager, capture, replay
+        e2.train_step_graphed(b)
+    for _ in range(3):
+        e.train_step(b)
+    torch.cuda.synchronize()
+    assert int(e.rng.item()) == int(e2.rng.item())
+    torch.testing.assert_close(e2.losses, e.losses, rtol=1e-4, atol=1e-5)
+    assert float((e.arena.p - e2.arena.p).abs().max()) <= 5e-5 * float(e.arena.p.abs().max())
+    # (4) keep replaying
+    first = e2.losses.clone()
+    for _ in range(12):
+        e2.train_step_graphed(b)
+    torch.cuda.synchronize()
+    st = e2.opt_stats()
+    assert st["attempt"] == 15 and st["skipped"] == 0
+    assert bool(torch.isfinite(e2.losses).all()) and bool(torch.isfinite(e2.arena.p).all())
+    assert float(e2.losses[0]) != float(first[0])

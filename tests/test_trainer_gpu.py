@@ -13,14 +13,19 @@ REF_CKPT_KEYS = {"epoch", "global_step", "model_state_dict", "optimizer_state_di
                  "scheduler_config", "ema_model_state_dict", "ema_updates"}
 
 
-def _fake_cache(root, n=12):
+def _fake_cache(root, n=12, tmin=40, tmax=120, pmin=4, pmax=14, extra_frames=()):
+    """n synthetic utterances in the reference's cache schema (v7); utterance i of `extra_frames` gets that many frames
+    added to one phoneme's duration, so its durations expand beyond its mel length (a clipped utterance)."""
     from kokoro_ruslan_amd.synthetic import synthetic_batch
     d = root / ".feature_cache"
     d.mkdir(parents=True)
     g = torch.Generator().manual_seed(0)
     for i in range(n):
-        T, P = int(torch.randint(40, 120, (1,), generator=g)), int(torch.randint(4, 14, (1,), generator=g))
+        T = tmin if tmin == tmax else int(torch.randint(tmin, tmax, (1,), generator=g))
+        P = pmin if pmin == pmax else int(torch.randint(pmin, pmax, (1,), generator=g))
         b = synthetic_batch(1, T, P, seed=i)
+        if i < len(extra_frames):
+            b["phoneme_durations"][0, P // 2] += extra_frames[i]
         torch.save({"mel_spec": b["mel_specs"][0].T.contiguous(), "phoneme_indices": b["phoneme_indices"][0],
                     "stress_indices": b["stress_indices"][0], "phoneme_durations": b["phoneme_durations"][0],
                     "stop_token_targets": b["stop_token_targets"][0], "pitch": b["pitches"][0], "energy": b["energies"][0],
@@ -92,7 +97,7 @@ def test_validation_metrics_match_per_sample_loops(tmp_path):
     val = tr.validate_epoch()
     e = tr.engine
     sc_sum = sc_n = f0_sum = f0_n = 0.0
-    with e.fp32_math():
+    with e.fp32_math(), e.ema_weights():
         for idxs in tr._val_batches():
             batch = cap_batch(tr._to_device(collate_fn([tr.val_dataset[j] for j in idxs])))
             out = e.forward_backward(batch, backward=False)
@@ -110,3 +115,143 @@ def test_validation_metrics_match_per_sample_loops(tmp_path):
     assert abs(val["spectral_convergence"] - sc_sum / sc_n) < 1e-5 * max(1.0, sc_sum / sc_n)
     assert abs(val["f0_rmse"] - f0_sum / f0_n) < 1e-5
     assert len(tr._val_batches()) >= 2 and sorted(i for b in tr._val_batches() for i in b) == list(range(len(tr.val_dataset)))
+
+
+def _config(tmp_path, corpus, *flags):
+    import sys
+    from kokoro.cli.cli import create_config_from_args, parse_arguments
+    argv, sys.argv = sys.argv, ["kokoro-train", "--corpus", str(corpus), "--output", str(tmp_path / "m"), "--no-mfa", *flags]
+    try:
+        return create_config_from_args(parse_arguments())
+    finally:
+        sys.argv = argv
+
+
+def test_trainer_turns_regularisation_on_and_validation_off(tmp_path):
+    """kokoro-train trains with the configured dropout / stochastic depth / SpecAugment (reference model.train(),
+    trainer.py:2038-2056) and validates without: an epoch over the same data twice gives different losses, validation
+    twice gives the same, and a failure inside validation leaves the live weights and flags untouched."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from kokoro.training.trainer import KokoroTrainer
+    corpus = tmp_path / "corpus"
+    _fake_cache(corpus, n=10)
+    cfg = _config(tmp_path, corpus, "--no-dynamic-batching", "--batch-size", "4", "--epochs", "2", "--val-split", "0.3")
+    cfg.learning_rate = 0.0                                  # the weights stay put: only the masks can change the loss
+    cfg.spec_augment_start_epoch = 1
+    tr = KokoroTrainer(cfg)
+    e = tr.engine
+    seen = []
+    orig = e.train_step_auto
+
+    def spy(*a, **k):
+        seen.append((e.train_dropout, e.spec_augment_active))
+        return orig(*a, **k)
+    e.train_step_auto = spy
+    l0 = tr.train_epoch(0)
+    assert seen and all(s == (True, False) for s in seen)    # epoch 0 < spec_augment_start_epoch
+    n0 = len(seen)
+    tr.sampler.epoch = 0
+    batches0 = tr.sampler.batches()
+    l1 = tr.train_epoch(0)
+    assert tr.sampler.batches() == batches0 and l0 != l1, "same batches, same weights: only fresh dropout masks differ"
+    tr.train_epoch(1)
+    assert all(s == (True, True) for s in seen[2 * n0:])
+    assert e.train_dropout is False
+    v0, v1 = tr.validate_epoch(), tr.validate_epoch()
+    assert v0["total"] == v1["total"] and v0["total"] == v0["total"]
+    # an exception inside validation must not leave the EMA slab as the live weights (ADVICE r1)
+    p_before, P_before, math_before = e.arena.p.data_ptr(), e.arena.P, e.math
+    boom = e.forward_backward
+    e.forward_backward = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("boom"))
+    with pytest.raises(RuntimeError, match="boom"):
+        tr.validate_epoch()
+    e.forward_backward = boom
+    assert e.arena.p.data_ptr() == p_before and e.arena.P is P_before and e.math == math_before and e.train_dropout is False
+
+
+def test_dynamic_batching_200_steps_memory_flat(tmp_path):
+    """BASELINE configs[2] on a synthetic ragged cache: dynamic batching with --max-frames 16384 (B in [4, 32], a new
+    batch shape nearly every step), MFA-style durations baked into the cache with some utterances whose durations expand
+    beyond their mel length.  >= 200 optimizer micro-steps with all regularisation on: finite losses, no skipped
+    optimizer step, device memory flat after the first epoch."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from kokoro.training.trainer import KokoroTrainer
+    corpus = tmp_path / "corpus"
+    _fake_cache(corpus, n=1200, tmin=90, tmax=1500, pmin=12, pmax=60, extra_frames=[3, 1, 7, 2, 5, 4, 9, 1, 2, 6] * 8)
+    cfg = _config(tmp_path, corpus, "--max-frames", "16384", "--min-batch-size", "4", "--max-batch-size", "32", "--epochs", "2",
+                  "--val-split", "0.05")
+    cfg.use_mixed_precision, cfg.mixed_precision_dtype = True, "bfloat16"
+    assert cfg.use_dynamic_batching
+    tr = KokoroTrainer(cfg)
+    e = tr.engine
+    shapes, expanded = set(), 0
+    orig = e.train_step_auto
+
+    def spy(batch, *a, **k):
+        nonlocal expanded
+        shapes.add((tuple(batch["mel_specs"].shape[:2]), batch["phoneme_indices"].shape[1]))
+        expanded += a[3] is not None if len(a) > 3 else k.get("expanded_len") is not None
+        return orig(batch, *a, **k)
+    e.train_step_auto = spy
+    l0 = tr.train_epoch(0)
+    torch.cuda.synchronize()
+    n_epoch = len(tr.sampler)
+    mem0, ws0 = torch.cuda.memory_allocated(), e.workspace_bytes()
+    l1 = tr.train_epoch(1)
+    l2 = tr.train_epoch(2)
+    torch.cuda.synchronize()
+    mem1, ws1 = torch.cuda.memory_allocated(), e.workspace_bytes()
+    st = e.opt_stats()
+    assert 3 * n_epoch >= 200 and len(shapes) >= 40, (n_epoch, len(shapes))
+    assert expanded >= 5, "some batches must have carried durations that expand beyond the mel length"
+    assert all(x == x and abs(x) < 1e4 for x in (l0, l1, l2))
+    assert st["skipped"] == 0 and st["attempt"] >= 100
+    assert bool(torch.isfinite(e.arena.p).all())
+    assert ws1 <= ws0 * 1.15 and mem1 <= mem0 * 1.15 + (64 << 20), (ws0, ws1, mem0, mem1)
+    assert max(b * t for (b, t), _ in shapes) <= 16384
+    val = tr.validate_epoch()
+    assert val is not None and val["total"] == val["total"]
+
+
+def test_kokoro_train_reaches_bench_speed_on_a_fixed_shape(tmp_path):
+    """The path that actually trains (kokoro-train: loader thread + pinned staging + graph replay with the reference's
+    default accumulation G = 2) against bench.py's loop (resident batch, train_step_graphed, G = 1) at the same shape:
+    frames/s within 15 % once the graphs exist (the trainer also pays an optimizer pass only every second micro-batch,
+    so it is compared against the bench loop run with G = 2 as well)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import time
+    from kokoro.training.trainer import KokoroTrainer
+    from kokoro_ruslan_amd.synthetic import synthetic_batch
+    corpus = tmp_path / "corpus"
+    _fake_cache(corpus, n=8 * 40, tmin=512, tmax=512, pmin=64, pmax=64)
+    cfg = _config(tmp_path, corpus, "--no-dynamic-batching", "--batch-size", "8", "--epochs", "3", "--val-split", "0.0")
+    cfg.use_mixed_precision, cfg.mixed_precision_dtype = True, "bfloat16"
+    tr = KokoroTrainer(cfg)
+    e = tr.engine
+    assert len(tr.sampler) == 40
+    tr.train_epoch(0)                                        # shapes seen, graphs captured, files in the page cache
+    tr.train_epoch(1)                                        # (SpecAugment switches on at epoch 1: one more capture)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tr.train_epoch(2)                                        # (ends with the epoch's one host read)
+    dt_train = time.perf_counter() - t0
+    print(f"loader: {tr.last_prefetch.load_s / 40 * 1e3:.2f} ms per batch on its thread, {tr.last_prefetch.wait_s / 40 * 1e3:.2f} ms waiting for the GPU; "
+          f"epoch {dt_train * 1e3:.1f} ms")
+    fps_train = 40 * 8 * 512 / dt_train
+    b = {k: v.cuda() for k, v in synthetic_batch(8, 512, 64, seed=1).items()}
+    e.train_dropout = True
+    e.micro_in_cycle = 0
+    for _ in range(6):
+        e.train_step_graphed(b)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(40):
+        e.train_step_graphed(b)
+    torch.cuda.synchronize()
+    fps_bench = 40 * 8 * 512 / (time.perf_counter() - t0)
+    print(f"kokoro-train {fps_train:,.0f} frames/s, resident-batch loop {fps_bench:,.0f} frames/s (G = 2)")
+    assert fps_train >= 0.85 * fps_bench, (fps_train, fps_bench)
+    assert e.opt_stats()["skipped"] == 0
