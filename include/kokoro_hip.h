@@ -262,8 +262,12 @@ int kk_specaug(float *x, int B, int T, int H, const uint32_t *seed, uint32_t sit
                int feat_mask_max, int n_time, int n_feat, int x_bf16, void *stream);
 
 /* ---- losses (training/losses.py:9-216) ----
- * acc: 10 doubles (5 sums, 5 counts) zeroed by the call.  losses: 6 floats (total, mel, dur, stop, pitch, energy).
- * coef: 5 floats = d(total*loss_scale)/d(per-element loss) for the backward kernel. */
+ * acc: 12 doubles (5 sums, 5 counts, the number of non-finite prediction elements, 1 spare) zeroed by the call.
+ * losses: 6 floats (total, mel, dur, stop, pitch, energy).
+ * coef: 5 floats = d(total*loss_scale)/d(per-element loss) for the backward kernel.
+ * guard (nullable): &opt_state[KK_OS_MICRO_BAD] — the reference's per-micro-batch guards (trainer.py:3233-3256 finite
+ * outputs, :3274-3296 finite losses): a flagged micro-batch back-propagates nothing (coef = 0) and marks its accumulation
+ * cycle, whose optimizer boundary kk_opt_prepare then skips (trainer.py:2304-2314 drops the accumulated gradients). */
 typedef struct KkLossCfg {
     float w_dur, w_stop, w_pitch, w_energy;
     float delta_dur, delta_pitch, delta_energy, pos_weight;
@@ -275,11 +279,11 @@ int kk_losses_fwd(const float *mel_pred, const float *mel_tgt, const float *dur_
                   const float *pitch_tgt, const float *energy_pred, const float *energy_tgt,
                   const int64_t *mel_len, const int64_t *ph_len, int B, int T, int P, int M,
                   const KkLossCfg *cfg, const int64_t *max_dur /* device scalar or null */, double *acc,
-                  float *losses, float *coef, void *stream);
+                  float *losses, float *coef, double *guard, void *stream);
 /* Recompute losses[6] and coef[5] from acc (see kk_losses_fwd) — used by data-parallel runs after acc has been
  * SUM-reduced and *max_dur MAX-reduced over the ranks: normalisers become the global valid-element counts. */
 int kk_losses_finalize(const double *acc, const KkLossCfg *cfg, const int64_t *max_dur, int T, float *losses,
-                       float *coef, void *stream);
+                       float *coef, double *guard, void *stream);
 int kk_losses_bwd(const float *mel_pred, const float *mel_tgt, const float *dur_pred, const int64_t *dur,
                   const float *stop_logit, const float *stop_tgt, const float *pitch_pred,
                   const float *pitch_tgt, const float *energy_pred, const float *energy_tgt,
@@ -321,6 +325,8 @@ typedef struct KkOptCfg {
 #define KK_OS_BAD_SEG 11      /* diagnostics of the most recent skipped boundary: 1 + first segment with a non-finite norm, */
 #define KK_OS_BAD_COUNT 12    /* how many segments had one, */
 #define KK_OS_BAD_ATTEMPT 13  /* and the boundary index (ATTEMPT) at which it happened */
+#define KK_OS_MICRO_BAD 14    /* set by kk_losses_*: a micro-batch of the current cycle had non-finite outputs / losses */
+#define KK_OS_MICRO_BAD_TOTAL 15 /* micro-batches flagged so far */
 #define KK_OS_SIZE 16
 /* sumsq[seg] (double, zeroed by the call) = sum of squares of each arena segment of `buf`. */
 int kk_seg_sumsq(const float *buf, const int32_t *block_seg, int64_t nblocks, double *sumsq, int nseg,

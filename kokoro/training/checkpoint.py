@@ -41,29 +41,34 @@ def build_model_metadata(config, dims: spec.ModelDims) -> Dict[str, Any]:
     }
 
 
-def optimizer_state_dict(engine) -> Dict[str, Any]:
-    """torch.optim.AdamW-shaped state: params numbered consecutively through the 10 groups."""
-    a, hp = engine.arena, engine.hp
-    st = engine.opt_stats()
-    steps = float(st["attempt"] - st["skipped"])
+def adamw_state_dict(param_names, exp_avg, exp_avg_sq, steps: float, hp, last_base_lr: Optional[float] = None) -> Dict[str, Any]:
+    """torch.optim.AdamW-shaped state for the reference's 10 param groups (trainer.py:503-642): params numbered
+    consecutively through the groups; exp_avg / exp_avg_sq map a parameter name to its CPU moment tensor."""
     table = spec.group_lr_mult_wd(hp)
     groups = [[] for _ in range(10)]
-    for n in a.param_names:
+    for n in param_names:
         groups[spec.param_group_of(n)].append(n)
     state, pgs, idx = {}, [], 0
     for gi, names in enumerate(groups):
         ids = []
         for n in names:
             if steps > 0:
-                state[idx] = {"step": torch.tensor(steps), "exp_avg": a.view(a.m, n).detach().cpu().clone(),
-                              "exp_avg_sq": a.view(a.v, n).detach().cpu().clone()}
+                state[idx] = {"step": torch.tensor(float(steps)), "exp_avg": exp_avg(n), "exp_avg_sq": exp_avg_sq(n)}
             ids.append(idx)
             idx += 1
-        pgs.append({"lr": st["last_base_lr"] * table[gi][0] if steps > 0 else hp.learning_rate * table[gi][0],
-                    "betas": tuple(hp.adam_betas), "eps": hp.adam_eps, "weight_decay": table[gi][1], "amsgrad": False,
-                    "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": True,
-                    "group_type": spec.GROUP_TYPES[gi], "params": ids})
+        base = last_base_lr if (steps > 0 and last_base_lr is not None) else hp.learning_rate
+        pgs.append({"lr": base * table[gi][0], "betas": tuple(hp.adam_betas), "eps": hp.adam_eps, "weight_decay": table[gi][1],
+                    "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                    "fused": True, "group_type": spec.GROUP_TYPES[gi], "params": ids})
     return {"state": state, "param_groups": pgs}
+
+
+def optimizer_state_dict(engine) -> Dict[str, Any]:
+    a = engine.arena
+    st = engine.opt_stats()
+    return adamw_state_dict(a.param_names, lambda n: a.view(a.m, n).detach().cpu().clone(),
+                            lambda n: a.view(a.v, n).detach().cpu().clone(), float(st["attempt"] - st["skipped"]), engine.hp,
+                            st["last_base_lr"])
 
 
 def load_optimizer_state_dict(engine, osd: Dict[str, Any]) -> None:
@@ -84,31 +89,50 @@ def load_optimizer_state_dict(engine, osd: Dict[str, Any]) -> None:
     engine.opt_state[kk.OS["SKIPPED"]] = 0.0
 
 
-def save_checkpoint(engine, config, epoch: int, loss: float, output_dir: str, val: Optional[Dict[str, float]] = None,
-                    best_val_loss: Optional[float] = None, best_val_epoch: int = -1, early_stopping_counter: int = 0) -> str:
+def assemble_checkpoint(*, model_sd: Dict[str, torch.Tensor], ema_sd: Optional[Dict[str, torch.Tensor]], optimizer_sd: Dict[str, Any],
+                        hp, dims: spec.ModelDims, config, total_steps: int, epoch: int, loss: float, steps_done: int,
+                        val: Optional[Dict[str, float]] = None, best_val_loss: Optional[float] = None, best_val_epoch: int = -1,
+                        extra: Optional[Dict[str, Any]] = None) -> Dict[str, Any]:
+    """The checkpoint dictionary in the reference's layout (save_checkpoint_with_scaler, trainer.py:1987-2036) from plain
+    CPU state — no engine, no GPU: what save_checkpoint writes, and what tests/golden/checkpoint_roundtrip.py feeds to the
+    reference's own loaders."""
     val = val or {}
-    st = engine.opt_stats()
-    done = int(st["attempt"] - st["skipped"])
-    c = spec.lr_schedule_consts(engine.hp, engine.total_steps)
+    c = spec.lr_schedule_consts(hp, total_steps)
+    last = max(0, steps_done - c["warmup_steps"])
     ckpt = {
-        "epoch": epoch, "global_step": done,
-        "model_state_dict": {k: v.detach().cpu().clone() for k, v in engine.state_dict().items()},
-        "optimizer_state_dict": optimizer_state_dict(engine),
-        "scheduler_state_dict": {"last_epoch": max(0, done - c["warmup_steps"]), "total_steps": c["onecycle_steps"]},
-        "current_optimizer_step": done, "optimizer_steps_completed": done,
+        "epoch": epoch, "global_step": steps_done,
+        "model_state_dict": model_sd,
+        "optimizer_state_dict": optimizer_sd,
+        # OneCycleLR.load_state_dict is a plain __dict__.update: the fields below are the ones it steps from
+        "scheduler_state_dict": {"last_epoch": last, "_step_count": last + 1, "total_steps": c["onecycle_steps"],
+                                 "_last_lr": [g["lr"] for g in optimizer_sd["param_groups"]]},
+        "current_optimizer_step": steps_done, "optimizer_steps_completed": steps_done,
         "loss": loss, "train_loss": loss, "val_loss": val.get("total"), "val_mel_loss": val.get("mel"),
         "val_stop_loss": val.get("stop"), "val_dur_loss": val.get("dur"),
         "best_val_loss": best_val_loss if best_val_loss is not None else val.get("total"), "best_val_epoch": best_val_epoch,
-        "config": config, "model_metadata": build_model_metadata(config, engine.dims),
+        "config": config, "model_metadata": build_model_metadata(config, dims),
         "scheduler_config": {"onecycle_steps": c["onecycle_steps"], "max_lr": c["max_lr"], "pct_start": c["pct_start"],
                              "div_factor": c["div_factor"], "warmup_steps": c["warmup_steps"]},
-        "engine_opt_state": engine.opt_state.detach().cpu().clone(),       # new key: device-side step-driver state
-        "engine_rng": int(engine.rng.item()),                              # new key: step seed of the dropout / DropPath masks
-        "early_stopping_counter": int(early_stopping_counter),             # (trainer.py:2918-3004 keeps it on the trainer)
     }
-    if engine.arena.ema is not None:
-        ckpt["ema_model_state_dict"] = {k: v.detach().cpu().clone() for k, v in engine.state_dict(ema=True).items()}
-        ckpt["ema_updates"] = done
+    if ema_sd is not None:
+        ckpt["ema_model_state_dict"] = ema_sd
+        ckpt["ema_updates"] = steps_done
+    ckpt.update(extra or {})
+    return ckpt
+
+
+def save_checkpoint(engine, config, epoch: int, loss: float, output_dir: str, val: Optional[Dict[str, float]] = None,
+                    best_val_loss: Optional[float] = None, best_val_epoch: int = -1, early_stopping_counter: int = 0) -> str:
+    st = engine.opt_stats()
+    done = int(st["attempt"] - st["skipped"])
+    cpu = lambda sd: {k: v.detach().cpu().clone() for k, v in sd.items()}
+    ckpt = assemble_checkpoint(
+        model_sd=cpu(engine.state_dict()), ema_sd=cpu(engine.state_dict(ema=True)) if engine.arena.ema is not None else None,
+        optimizer_sd=optimizer_state_dict(engine), hp=engine.hp, dims=engine.dims, config=config, total_steps=engine.total_steps,
+        epoch=epoch, loss=loss, steps_done=done, val=val, best_val_loss=best_val_loss, best_val_epoch=best_val_epoch,
+        extra={"engine_opt_state": engine.opt_state.detach().cpu().clone(),     # new key: device-side step-driver state
+               "engine_rng": int(engine.rng.item()),                            # new key: step seed of the dropout / DropPath masks
+               "early_stopping_counter": int(early_stopping_counter)})          # (trainer.py:2918-3004 keeps it on the trainer)
     os.makedirs(output_dir, exist_ok=True)
     path = os.path.join(output_dir, f"checkpoint_epoch_{epoch + 1}.pth")
     torch.save(ckpt, path)

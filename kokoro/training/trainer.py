@@ -201,6 +201,11 @@ class KokoroTrainer:
             self.engine.dp_loss_scale = 1.0
         self.start_epoch, self.best_val, self.best_epoch, self.patience = 0, float("inf"), -1, 0
         self.use_graphs = os.environ.get("KK_TRAINER_GRAPHS", "1") != "0"
+        # Per-micro-batch non-finite guard (reference trainer.py:2304-2314): by default the device flags the micro-batch
+        # and drops its accumulation cycle at the scheduled boundary, without any host round trip.  Strict mode also
+        # RE-PHASES the cycle like the reference (the next batch starts a new cycle), which needs the flag on the host:
+        # one synchronisation per micro-batch.
+        self.strict_nonfinite_guard = os.environ.get("KK_STRICT_NONFINITE", "0") == "1"
         self.prefetch_depth = int(os.environ.get("KK_PREFETCH_DEPTH", "3"))
         logger.info("engine ready: %d params, %s math, %d train / %d val utterances, %d batches/epoch, world %d",
                     sum(math.prod(s) for s in self.engine.arena.shapes.values()), math_mode, len(self.dataset),
@@ -230,7 +235,23 @@ class KokoroTrainer:
                 boundary = (acc + 1 >= G) or (bi == len(batches) - 1)
                 e.micro_in_cycle = acc
                 T = batch["mel_specs"].shape[1]
-                losses += step(batch, div, boundary, self.sync if self.world > 1 else None, expanded if expanded != T else None)
+                if self.strict_nonfinite_guard:
+                    flag = e.opt_state[kk.OS["MICRO_BAD"]]
+                    out = e.train_step(batch, div, False, None, expanded if expanded != T else None)
+                    if float(flag) != 0.0:                # (host sync) reset accumulation and skip, trainer.py:2304-2314
+                        logger.error("batch %d: non-finite outputs or losses - accumulation reset, batch skipped", bi)
+                        flag.zero_()
+                        e.zero_grad()
+                        acc = 0
+                        continue
+                    losses += out
+                    if boundary:
+                        if self.world > 1:
+                            self.sync(e.arena.g)
+                        e.optimizer_step(int(e.global_mel_length or T))
+                        e.micro_in_cycle = 0
+                else:
+                    losses += step(batch, div, boundary, self.sync if self.world > 1 else None, expanded if expanded != T else None)
                 acc = 0 if boundary else acc + 1
                 n += 1
         finally:

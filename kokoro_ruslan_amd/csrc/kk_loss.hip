@@ -32,23 +32,28 @@ __device__ __forceinline__ float bce_logits(float z, float y, float pw) { return
 __global__ __launch_bounds__(256) void losses_fwd_kernel(LossArgs a, double *__restrict__ acc) {
     __shared__ double red[4];
     float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, n[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    float bad = 0.f;       // non-finite prediction elements, padded positions included (finite-output guard, trainer.py:3233-3256)
     const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
     const int64_t nmel = (int64_t)a.B * a.T * a.M, nfr = (int64_t)a.B * a.T, nph = (int64_t)a.B * a.P;
     for (int64_t i = tid; i < nmel; i += stride) {
         const int64_t fr = i / a.M;
         const int b = (int)(fr / a.T), t = (int)(fr - (int64_t)b * a.T);
+        const float pr = a.mel_pred[i];
+        if (!isfinite(pr)) bad += 1.f;
         if (t < a.mel_len[b]) {
-            const float v = fabsf(a.mel_pred[i] - a.mel_tgt[i]);
+            const float v = fabsf(pr - a.mel_tgt[i]);
             if (isfinite(v)) { s[0] += v; n[0] += 1.f; }
         }
     }
     for (int64_t i = tid; i < nph; i += stride) {
         const int b = (int)(i / a.P), p = (int)(i - (int64_t)b * a.P);
         const int64_t d = a.dur[i];
+        if (!isfinite(a.dur_pred[i])) bad += 1.f;
         if (p < a.ph_len[b] && d > 0) { s[1] += huber(a.dur_pred[i] - logf((float)d + 1.f), a.cfg.delta_dur); n[1] += 1.f; }
     }
     for (int64_t i = tid; i < nfr; i += stride) {
         const int b = (int)(i / a.T), t = (int)(i - (int64_t)b * a.T);
+        if (!isfinite(a.stop_logit[i]) || !isfinite(a.pitch_pred[i]) || !isfinite(a.energy_pred[i])) bad += 1.f;
         if (t < a.mel_len[b]) {
             float v = bce_logits(a.stop_logit[i], a.stop_tgt[i], a.cfg.pos_weight);
             if (isfinite(v)) { s[2] += v; n[2] += 1.f; }
@@ -64,10 +69,15 @@ __global__ __launch_bounds__(256) void losses_fwd_kernel(LossArgs a, double *__r
         const double dn = block_sum_256_d((double)n[k], red);
         if (threadIdx.x == 0 && dn > 0.0) { atomicAdd(&acc[k], ds); atomicAdd(&acc[5 + k], dn); }
     }
+    const double db = block_sum_256_d((double)bad, red);
+    if (threadIdx.x == 0 && db > 0.0) atomicAdd(&acc[10], db);
 }
 
+// guard (nullable): 2 doubles of the step driver's state — [0] "a micro-batch of the current accumulation cycle had
+// non-finite outputs or losses" (the reference then drops the cycle's gradients and takes no optimizer step,
+// trainer.py:2304-2314; kk_opt_prepare honours and clears it), [1] how many micro-batches were flagged so far.
 __global__ void losses_finalize_kernel(const double *__restrict__ acc, KkLossCfg cfg, const int64_t *__restrict__ max_dur,
-                                       int T, float *__restrict__ losses, float *__restrict__ coef) {
+                                       int T, float *__restrict__ losses, float *__restrict__ coef, double *__restrict__ guard) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double scale = (double)cfg.loss_scale;
     if (cfg.adaptive) {                               // trainer.py:2218-2242 (second branch overrides the first)
@@ -88,6 +98,14 @@ __global__ void losses_finalize_kernel(const double *__restrict__ acc, KkLossCfg
         coef[k] = open ? (float)((double)w[k] * scale / cnt) : 0.f;
     }
     losses[0] = total;
+    // finite-output guard (trainer.py:3233-3256: every element of the five predictions) and finite-loss guard (:3274-3296)
+    bool ok = acc[10] == 0.0 && isfinite(total);
+    for (int k = 0; k < 5; ++k) ok = ok && isfinite(losses[1 + k]);
+    if (!ok && guard) {          // (without a guard slot the call is calculate_training_losses alone: elements masked, no veto)
+        for (int k = 0; k < 5; ++k) coef[k] = 0.f;
+        guard[0] = 1.0;
+        guard[1] += 1.0;
+    }
 }
 
 __global__ __launch_bounds__(256) void losses_bwd_kernel(LossArgs a, const float *__restrict__ coef, float *__restrict__ dmel,
@@ -149,17 +167,17 @@ extern "C" int kk_losses_fwd(const float *mel_pred, const float *mel_tgt, const 
                              const float *pitch_tgt, const float *energy_pred, const float *energy_tgt,
                              const int64_t *mel_len, const int64_t *ph_len, int B, int T, int P, int M,
                              const KkLossCfg *cfg, const int64_t *max_dur, double *acc, float *losses, float *coef,
-                             void *stream) {
+                             double *guard, void *stream) {
     KK_REQUIRE(B > 0 && T > 0 && P > 0 && M > 0 && cfg, "kk_losses_fwd: bad args");
     hipStream_t s = (hipStream_t)stream;
-    const int e = kk_zero_async(acc, 10 * sizeof(double), s);
+    const int e = kk_zero_async(acc, 12 * sizeof(double), s);
     if (e != 0) return e;
     LossArgs a = pack(mel_pred, mel_tgt, dur_pred, dur, stop_logit, stop_tgt, pitch_pred, pitch_tgt, energy_pred,
                       energy_tgt, mel_len, ph_len, B, T, P, M, cfg);
     int blocks = kk_cdiv((int64_t)B * T * M, 256 * 8);
     blocks = blocks > 1024 ? 1024 : (blocks < 1 ? 1 : blocks);
     hipLaunchKernelGGL(losses_fwd_kernel, dim3(blocks), dim3(256), 0, s, a, acc);
-    hipLaunchKernelGGL(losses_finalize_kernel, dim3(1), dim3(64), 0, s, acc, *cfg, max_dur, T, losses, coef);
+    hipLaunchKernelGGL(losses_finalize_kernel, dim3(1), dim3(64), 0, s, acc, *cfg, max_dur, T, losses, coef, guard);
     KK_LAUNCH_CHECK("kk_losses_fwd");
     return 0;
 }
@@ -168,9 +186,9 @@ extern "C" int kk_losses_fwd(const float *mel_pred, const float *mel_tgt, const 
 // max_dur MAX-all-reduced), every rank normalises by the GLOBAL valid-element counts, so the summed gradients are the
 // global-batch gradients also when the shards are ragged.  T = the global-batch mel length.
 extern "C" int kk_losses_finalize(const double *acc, const KkLossCfg *cfg, const int64_t *max_dur, int T, float *losses,
-                                  float *coef, void *stream) {
+                                  float *coef, double *guard, void *stream) {
     KK_REQUIRE(acc && cfg && losses && coef && T > 0, "kk_losses_finalize: bad args");
-    hipLaunchKernelGGL(losses_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, acc, *cfg, max_dur, T, losses, coef);
+    hipLaunchKernelGGL(losses_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, acc, *cfg, max_dur, T, losses, coef, guard);
     KK_LAUNCH_CHECK("kk_losses_finalize");
     return 0;
 }

@@ -123,7 +123,9 @@ __global__ __launch_bounds__(256) void opt_prepare_kernel(const double *__restri
         st[KK_OS_EXPL_EMA] = ema_valid ? c.expl_alpha * st[KK_OS_EXPL_EMA] + (1.0 - c.expl_alpha) * total : total;
         st[KK_OS_EXPL_EMA_VALID] = 1.0;
         st[KK_OS_EXPL_EMA_STEPS] += 1.0;
-        const bool skip = nbad > 0.0;
+        // non-finite gradients, or a micro-batch of this cycle failed the finite-output / finite-loss guard: no step
+        const bool skip = nbad > 0.0 || st[KK_OS_MICRO_BAD] != 0.0;
+        st[KK_OS_MICRO_BAD] = 0.0;
         const int64_t k = (int64_t)done;               // index of this step among successful steps
         const double coef = fmin(1.0, clip / (total + 1e-6));
         const double blr = base_lr_for(c, k);

@@ -160,7 +160,7 @@ class KokoroEngine:
         self.grad_sumsq = torch.zeros(ns, dtype=torch.float64, device=self.device)
         self.p_sumsq = torch.zeros(ns, dtype=torch.float64, device=self.device)
         self.max_dur = torch.zeros(1, dtype=torch.int64, device=self.device)
-        self.loss_acc = torch.zeros(10, dtype=torch.float64, device=self.device)
+        self.loss_acc = torch.zeros(12, dtype=torch.float64, device=self.device)    # 5 sums, 5 counts, non-finite outputs, spare
         self.losses = f32(6)
         self.loss_coef = f32(5)
         self.micro_in_cycle = 0
@@ -1043,11 +1043,16 @@ class KokoroEngine:
                             float(loss_scale), 1 if adaptive else 0)
         largs = (mel_pred, mel, dur_pred, dur, stop, batch["stop_token_targets"], pitch_l, batch["pitches"], energy_l,
                  batch["energies"], batch["mel_lengths"], batch["phoneme_lengths"], B, T, Pn, M, lcfg)
-        kk.call("kk_losses_fwd", *largs, self.max_dur, self.loss_acc, self.losses, self.loss_coef)
+        # per-micro-batch finite-output / finite-loss guard (trainer.py:3233-3296), device side: a flagged micro-batch
+        # back-propagates nothing and its accumulation cycle takes no optimizer step; forward-only calls (validation) do
+        # not touch the training cycle's flag
+        guard = self.opt_state[kk.OS["MICRO_BAD"]:] if backward else None
+        kk.call("kk_losses_fwd", *largs, self.max_dur, self.loss_acc, self.losses, self.loss_coef,
+                guard if self.loss_sync is None else None)
         if self.loss_sync is not None:
             self.loss_sync(self.loss_acc, self.max_dur)
             kk.call("kk_losses_finalize", self.loss_acc, lcfg, self.max_dur, int(self.global_mel_length or T), self.losses,
-                    self.loss_coef)
+                    self.loss_coef, guard)
         out = {"losses": self.losses, "mel": mel_pred, "log_dur": dur_pred, "stop": stop, "pitch": pitch_pred,
                "energy": energy_pred, "lr_idx": idx, "lr_lens": lens, "memory": memory.view(B, T, H)}
         if not backward:

@@ -20,7 +20,7 @@ KK_MATH_F32, KK_MATH_BF16 = 0, 1
 KK_SEG_ALIGN = 1024
 OS = dict(SKIPPED=0, EXPL_EMA=1, EXPL_EMA_STEPS=2, EXPL_STREAK=3, LAST_GRAD_NORM=4, LAST_CLIP_COEF=5,
           LAST_SKIP=6, LAST_BASE_LR=7, LAST_CLIP_NORM=8, EXPL_EMA_VALID=9, ATTEMPT=10, BAD_SEG=11, BAD_COUNT=12,
-          BAD_ATTEMPT=13, SIZE=16)
+          BAD_ATTEMPT=13, MICRO_BAD=14, MICRO_BAD_TOTAL=15, SIZE=16)
 
 
 class KkLossCfg(C.Structure):
@@ -151,8 +151,8 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_specaug": [_P, _I, _I, _I, _P, _U, _I, _I, _I, _I, _I, _P],
     "kk_ids_eq_zero": [_P, _P, _L, _P],
     "kk_shift_right": [_P, _P, _I, _I, _I, _P],
-    "kk_losses_fwd": [_P] * 12 + [_I, _I, _I, _I, C.POINTER(KkLossCfg), _P, _P, _P, _P, _P],
-    "kk_losses_finalize": [_P, C.POINTER(KkLossCfg), _P, _I, _P, _P, _P],
+    "kk_losses_fwd": [_P] * 12 + [_I, _I, _I, _I, C.POINTER(KkLossCfg), _P, _P, _P, _P, _P, _P],
+    "kk_losses_finalize": [_P, C.POINTER(KkLossCfg), _P, _I, _P, _P, _P, _P],
     "kk_losses_bwd": [_P] * 12 + [_I, _I, _I, _I, C.POINTER(KkLossCfg), _P, _P, _P, _P, _P, _P, _P],
     "kk_seg_sumsq": [_P, _P, _L, _P, _I, _P],
     "kk_opt_prepare": [_P, _P, _P, _P, _I, _P, C.POINTER(KkOptCfg), _P, _P, _P, _P, _P, _P],

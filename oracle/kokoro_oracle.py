@@ -725,6 +725,14 @@ def losses(out: Dict[str, Tensor], batch: Dict[str, Tensor], hp: StepHyper
     return total, loss_mel, loss_dur, loss_stop, loss_pitch, loss_energy
 
 
+def micro_batch_ok(out: Dict[str, Tensor], ls: Tuple[Tensor, ...]) -> bool:
+    """The two guards of _execute_training_step: every element of the five predictions finite (trainer.py:3233-3256)
+    and all six losses finite (:3274-3296).  A micro-batch failing either returns no step result: the trainer then drops
+    the gradients accumulated so far, restarts the accumulation cycle and takes no optimizer step (:2304-2314)."""
+    outs_ok = all(bool(torch.isfinite(out[k]).all()) for k in ("mel", "log_dur", "stop", "pitch", "energy"))
+    return outs_ok and all(bool(torch.isfinite(x)) for x in ls)
+
+
 # --------------------------------------------------------------------------------------
 # Step driver: param groups, pre-clip, clip, AdamW, EMA, weight-norm, LR schedule
 # --------------------------------------------------------------------------------------

@@ -204,3 +204,29 @@ def test_collate_into_equals_capped_collate_fn(tmp_path):
         assert all(off % 256 == 0 for _, off, _, _, _ in plan)
     again = cached.collate_fn(items)                                     # items stay valid for the tensor-level collate
     assert torch.equal(again["mel_specs"], cached.collate_fn(items)["mel_specs"])
+
+
+def test_checkpoint_assembles_from_plain_cpu_state():
+    """The checkpoint dictionary is built from CPU state dicts alone (no engine, no GPU) — the function save_checkpoint
+    uses and tests/golden/checkpoint_roundtrip.py feeds to the reference's load_checkpoint / KokoroTTS._load_model."""
+    import torch
+    from kokoro.training import checkpoint as ckpt
+    from kokoro.training.config import TrainingConfig
+    from kokoro_ruslan_amd import spec
+    dims = spec.ModelDims(hidden=128, heads=2, enc_layers=1, dec_layers=1, enc_ff=96, dec_ff=96, var_filter=32, var_bins=16, mel=20, max_len=300)
+    hp = spec.StepHyper()
+    P = spec.init_params(dims, 1)
+    sd = dict(P)
+    sd.update(spec.make_buffers(dims))
+    sd = {n: sd[n] for n in spec.state_dict_order(dims)}
+    osd = ckpt.adamw_state_dict(list(P), lambda n: torch.zeros_like(P[n]), lambda n: torch.ones_like(P[n]), 5, hp, 1e-5)
+    c = ckpt.assemble_checkpoint(model_sd=sd, ema_sd=sd, optimizer_sd=osd, hp=hp, dims=dims, config=TrainingConfig(), total_steps=100,
+                                 epoch=0, loss=1.0, steps_done=5)
+    ref_keys = {"epoch", "global_step", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict", "current_optimizer_step",
+                "optimizer_steps_completed", "loss", "train_loss", "val_loss", "val_mel_loss", "val_stop_loss", "val_dur_loss",
+                "best_val_loss", "best_val_epoch", "config", "model_metadata", "scheduler_config", "ema_model_state_dict", "ema_updates"}
+    assert ref_keys <= set(c)
+    assert len(osd["param_groups"]) == 10 and sum(len(g["params"]) for g in osd["param_groups"]) == len(P) == len(osd["state"])
+    assert [g["group_type"] for g in osd["param_groups"]] == list(spec.GROUP_TYPES)
+    assert c["scheduler_state_dict"]["_last_lr"] == [g["lr"] for g in osd["param_groups"]]
+    assert c["model_metadata"]["architecture"]["hidden_dim"] == 128

@@ -671,3 +671,44 @@ def test_bench_config_bf16_graph_replay_tracks_fp32_and_oracle(eng_mod):
     assert st["attempt"] == 15 and st["skipped"] == 0
     assert bool(torch.isfinite(e2.losses).all()) and bool(torch.isfinite(e2.arena.p).all())
     assert float(e2.losses[0]) != float(first[0])
+
+
+def test_micro_batch_finite_guard_drops_the_cycle(eng_mod, golden_dir):
+    """Reference guards per micro-batch (trainer.py:3233-3296, 2304-2314): an infinite mel-projection bias makes one
+    output column infinite while every loss stays finite (non-finite elements are masked out of the means) and every
+    gradient stays finite — only the finite-output guard can see it.  The flagged micro-batch must poison its
+    accumulation cycle: no optimizer step, parameters untouched; the next cycle trains normally."""
+    fx, d, _, P = _load(golden_dir, "tiny_full")
+    good = [O.synthetic_batch(2, 40, 6, d, seed=500 + i, ragged=True) for i in range(4)]
+    Pbad = {n: p.clone() for n, p in P.items()}
+    Pbad["mel_projection_out.bias"][3] = float("inf")
+    # the oracle's restatement of the guard agrees on which micro-batches are flagged
+    with torch.no_grad():
+        out = O.forward(Pbad, O.make_buffers(d), good[1], d)
+        ls = O.losses(out, good[1], O.StepHyper())
+        assert all(bool(torch.isfinite(x)) for x in ls) and not O.micro_batch_ok(out, ls)
+        out = O.forward(P, O.make_buffers(d), good[1], d)
+        assert O.micro_batch_ok(out, O.losses(out, good[1], O.StepHyper()))
+    e = _engine(eng_mod, d, P, gradient_accumulation_steps=2)
+    e.train_step(_cuda(good[0]))                              # cycle 1, micro-batch 1: fine
+    live = e.arena.P["mel_projection_out.bias"]
+    live[3] = float("inf")                                    # cycle 1, micro-batch 2: infinite output column
+    before = e.arena.p.clone()
+    losses = e.train_step(_cuda(good[1])).clone()
+    torch.cuda.synchronize()
+    st = e.opt_stats()
+    assert bool(torch.isfinite(losses).all()), "the losses mask non-finite elements out, like the reference's"
+    assert bool(torch.isfinite(e.arena.g).all()), "this case is invisible to the gradient check"
+    assert st["attempt"] == 1 and st["skipped"] == 1 and st["last_skip"] == 1 and st["micro_bad_total"] == 1 and st["micro_bad"] == 0
+    assert torch.equal(e.arena.p, before), "a dropped cycle must leave every parameter untouched"
+    live[3] = P["mel_projection_out.bias"][3]                 # healthy again: the next cycle steps
+    e.train_step(_cuda(good[2]))
+    e.train_step(_cuda(good[3]))
+    torch.cuda.synchronize()
+    st = e.opt_stats()
+    assert st["attempt"] == 2 and st["skipped"] == 1 and st["last_skip"] == 0 and not torch.equal(e.arena.p, before)
+    # forward-only calls (validation) never touch the training cycle's flag
+    live[3] = float("inf")
+    e.forward_backward(_cuda(good[0]), backward=False)
+    torch.cuda.synchronize()
+    assert e.opt_stats()["micro_bad"] == 0 and e.opt_stats()["micro_bad_total"] == 1

@@ -488,13 +488,13 @@ def test_losses_fwd_bwd(kk, ragged):
     (ls[0] * 0.5).backward()
     cfg = KkLossCfg(hp.duration_loss_weight, hp.stop_token_loss_weight, hp.pitch_loss_weight, hp.energy_loss_weight,
                     hp.duration_huber_delta, hp.pitch_huber_delta, hp.energy_huber_delta, hp.stop_token_pos_weight, 0.5, 0)
-    acc = torch.zeros(10, dtype=torch.float64, device="cuda")
+    acc = torch.zeros(12, dtype=torch.float64, device="cuda")
     losses, coef = torch.zeros(6, device="cuda"), torch.zeros(5, device="cuda")
     dv = {k: dev(v) for k, v in out.items()}
     bd = {k: dev(v) for k, v in b.items()}
     args = (dv["mel"], bd["mel_specs"], dv["log_dur"], bd["phoneme_durations"], dv["stop"], bd["stop_token_targets"], dv["pitch"],
             bd["pitches"], dv["energy"], bd["energies"], bd["mel_lengths"], bd["phoneme_lengths"], B, T, Pn, 80, cfg)
-    kk.call("kk_losses_fwd", *args, None, acc, losses, coef)
+    kk.call("kk_losses_fwd", *args, None, acc, losses, coef, None)
     close(losses, torch.stack([x.detach() for x in ls]), 1e-5, 1e-5, "losses")
     grads = [torch.empty_like(dv[k]) for k in ("mel", "log_dur", "stop", "pitch", "energy")]
     kk.call("kk_losses_bwd", *args, coef, *grads)
