@@ -162,6 +162,15 @@ def main():
     eng.dp_loss_scale = sync.loss_scale
     batch = {k: v.cuda() for k, v in synthetic_batch(B, T, P, seed=1234 + rank).items()}
     use_sync = world > 1 or force
+    # default data-parallel exchange: bucket by bucket INSIDE the step graph over the C ABI's kk_comm_* (RCCL);
+    # KK_DP_LEGACY=1 = one torch.distributed all-reduce between the backward graph and the optimizer graph
+    dp_mode = "none"
+    if use_sync:
+        dp_mode = "legacy" if (os.environ.get("KK_DP_LEGACY") == "1" or eng.dp_overlap_layer is not None) else "in-graph"
+    if dp_mode == "in-graph":
+        eng.dp_comm = dp.BucketedExchange.create(eng.dims, rank, world, eng.device)
+        dp_mode += f" ({eng.dp_comm.backend}, {eng.dp_comm.payload} payload, {len(eng.dp_comm.plan)} buckets)"
+        use_sync = False
     step = (lambda: eng.train_step(batch)) if args.no_graph else (lambda: eng.train_step_graphed(batch, sync if use_sync else None))
     if args.no_graph and world > 1:
         def step():   # noqa: F811
@@ -231,11 +240,13 @@ def main():
            "storage": eng.storage,
            "per_gpu": round(frames / dt / world, 1),
            "config": {"workload": f"kokoro acoustic-model train step, {B}x{T} mel frames x {P} phonemes per GPU "
-                                  f"(BASELINE configs[1]), 49.4M params, fwd+loss+bwd+clip+AdamW+EMA every step",
+                                  f"({'BASELINE configs[1]' if (B, T, P) == (8, 512, 64) else 'configs[3] per-GPU shape' if (B, T, P) == (8, 1024, 128) else 'non-baseline shape'}), "
+                                  f"49.4M params, fwd+loss+bwd+clip+AdamW+EMA every step",
                       "global_batch": world * B, "frames": T, "phonemes": P, "parallelism": f"dp{world}",
-                      "grad_allreduce": (("2 buckets, first overlapped with the backward of decoder layers < %d" % eng.dp_overlap_layer)
+                      "grad_allreduce": (dp_mode if dp_mode.startswith("in-graph") else
+                                         ("2 buckets, first overlapped with the backward of decoder layers < %d" % eng.dp_overlap_layer)
                                          if (use_sync and not args.no_graph and eng.dp_overlap_layer is not None) else
-                                         ("after the backward" if use_sync else "none (1 GPU)")),
+                                         ("after the backward (torch.distributed)" if use_sync else "none (1 GPU)")),
                       "grad_accumulation": 1,
                       "dropout": ("off (p=0 parity configuration)" if args.no_dropout else
                                   "on: enc 0.15 / dec 0.20 / dec-input 0.15 / variance 0.10, stochastic depth 0.1, SpecAugment (config.py defaults)"),

@@ -352,6 +352,29 @@ int kk_weight_norm_project(float *p, const int32_t *block_seg, int64_t nblocks, 
 /* dst (bf16) = src (fp32), n % 4 == 0: builds the weight shadow after a checkpoint load. */
 int kk_cast_f32_bf16(const float *src, void *dst, int64_t n, void *stream);
 
+/* ---- data-parallel gradient exchange over RCCL / xGMI (new functionality: the reference has no distributed code,
+ * SURVEY §0 fact 2; contract = "the same maths as one process seeing the global batch", §8e) ----
+ * One communicator per process (one process per GPU).  RCCL is bound at run time: the library loads without it, and
+ * kk_comm_load(path) lets the host name the instance to use (PyTorch-ROCm ships its own; default = the one already in
+ * the process, else the loader's search path).  rank 0 creates the 128-byte id (kk_comm_unique_id) and hands it to the
+ * other ranks by any side channel (the Python host uses the torch.distributed store).  Every collective is enqueued on
+ * `comm_stream` and never synchronises: the calls are legal inside a hipGraph capture, so the exchange of a bucket is
+ * a branch of the step's graph beside the rest of the backward.  dtype: 0 = fp32, 1 = bf16 payload. */
+int kk_comm_load(const char *rccl_path /* may be null */);
+int kk_comm_unique_id(void *id128);
+int kk_comm_init(int rank, int world, const void *nccl_unique_id);
+int kk_comm_world(void);                                           /* ranks of the live communicator, 0 = none */
+int kk_comm_destroy(void);
+/* in-place SUM all-reduce of one gradient bucket (ptr[0 .. count)) */
+int kk_comm_reduce_bucket(void *ptr, int64_t count, int dtype, void *comm_stream);
+/* n in-place SUM all-reduces base[begin[i] .. end[i]) (element indices; HOST arrays) as one RCCL group */
+int kk_comm_reduce_ranges(void *base, const int64_t *begin, const int64_t *end, int n, int dtype, void *comm_stream);
+/* the two halves of the ring all-reduce on their own (recv of rank r = block r of the sum / the concatenation) */
+int kk_comm_reduce_scatter(const void *send, void *recv, int64_t recv_count, int dtype, void *comm_stream);
+int kk_comm_all_gather(const void *send, void *recv, int64_t send_count, int dtype, void *comm_stream);
+/* y[i] = scale * float(x[i]) for a bf16 x: widens a bf16 gradient bucket after its exchange */
+int kk_cast_bf16_f32(const void *x, float *y, int64_t n, float scale, void *stream);
+
 /* ---- misc ---- */
 /* *slot = device wall clock (100 MHz ticks) at the time this launch executes: in-graph time stamps for timelines. */
 int kk_timestamp(uint64_t *slot, void *stream);

@@ -199,6 +199,11 @@ class KokoroTrainer:
             # pre-scaling per-rank means by 1/world, and feed the batch-shape heuristics the global-batch mel length
             self.engine.loss_sync = dp.LossSync(self.world)
             self.engine.dp_loss_scale = 1.0
+            # gradients: bucket by bucket inside the backward over the C ABI's kk_comm_* (RCCL); KK_DP_LEGACY=1 keeps the
+            # single torch.distributed all-reduce after the backward
+            if os.environ.get("KK_DP_LEGACY") != "1":
+                self.engine.dp_comm = dp.BucketedExchange.create(dims, self.rank, self.world, self.engine.device)
+                self.sync = None
         self.start_epoch, self.best_val, self.best_epoch, self.patience = 0, float("inf"), -1, 0
         self.use_graphs = os.environ.get("KK_TRAINER_GRAPHS", "1") != "0"
         # Per-micro-batch non-finite guard (reference trainer.py:2304-2314): by default the device flags the micro-batch
@@ -237,7 +242,12 @@ class KokoroTrainer:
                 T = batch["mel_specs"].shape[1]
                 if self.strict_nonfinite_guard:
                     flag = e.opt_state[kk.OS["MICRO_BAD"]]
-                    out = e.train_step(batch, div, False, None, expanded if expanded != T else None)
+                    if acc == 0:
+                        e.zero_grad()
+                    e._exchange_now = boundary                # (in-step bucket exchange: only the boundary micro-batch communicates)
+                    out = e.forward_backward(batch, loss_scale=e.dp_loss_scale / div, adaptive=True,
+                                             expanded_len=expanded if expanded != T else None)["losses"]
+                    e._exchange_now = True
                     if float(flag) != 0.0:                # (host sync) reset accumulation and skip, trainer.py:2304-2314
                         logger.error("batch %d: non-finite outputs or losses - accumulation reset, batch skipped", bi)
                         flag.zero_()
@@ -246,12 +256,12 @@ class KokoroTrainer:
                         continue
                     losses += out
                     if boundary:
-                        if self.world > 1:
+                        if self.world > 1 and self.sync is not None:
                             self.sync(e.arena.g)
                         e.optimizer_step(int(e.global_mel_length or T))
                         e.micro_in_cycle = 0
                 else:
-                    losses += step(batch, div, boundary, self.sync if self.world > 1 else None, expanded if expanded != T else None)
+                    losses += step(batch, div, boundary, self.sync if (self.world > 1 and self.sync is not None) else None, expanded if expanded != T else None)
                 acc = 0 if boundary else acc + 1
                 n += 1
         finally:

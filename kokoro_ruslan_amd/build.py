@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libkokoro_hip.so")
-SOURCES = ["kk_core.hip", "kk_gemm.hip", "kk_gemm16.hip", "kk_attn.hip", "kk_norm.hip", "kk_elem.hip", "kk_loss.hip", "kk_optim.hip", "kk_dropout.hip"]
+SOURCES = ["kk_core.hip", "kk_gemm.hip", "kk_gemm16.hip", "kk_attn.hip", "kk_norm.hip", "kk_elem.hip", "kk_loss.hip", "kk_optim.hip", "kk_dropout.hip", "kk_comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
 
 
@@ -54,7 +54,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     if force or _stale(LIB, objs):
-        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs,
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"],
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")

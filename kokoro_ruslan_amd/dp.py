@@ -15,7 +15,8 @@ The functions take plain tensors so the same code runs under `gloo` on CPU (test
 from __future__ import annotations
 
 import os
-from typing import Dict, Optional, Tuple
+from collections import OrderedDict
+from typing import Dict, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -108,6 +109,120 @@ class LossSync:
         dist.all_reduce(max_dur, op=dist.ReduceOp.MAX)    # adaptive loss scale / clip heuristics: same inputs on every rank
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Bucketed exchange inside the step (SURVEY §5.8 / §8e): buckets in the order the backward finishes them, each all-reduced on
+# a communication stream while the rest of the backward runs — captured into the step's hipGraph as one more branch.
+# ---------------------------------------------------------------------------------------------------------------------
+def bucket_plan(dims) -> "List[Tuple[str, List[Tuple[int, int]]]]":
+    """[(tag, [(begin, end) element ranges of the gradient arena])] in issue order.
+
+    A layer's weight-gradient GEMMs run as one grouped launch at the end of its backward, so its weight MATRICES are final
+    there (98 % of the bytes): bucket "dec{i}" / "enc{i}" = those matrices, issued from decoder layer L-1 down to 0 and from
+    encoder layer L-1 down to 0 (reverse-autograd order).  Everything else — the small vectors (their column sums are
+    reduced once, at the end of the backward), the batched cross-attention K/V projections, embeddings, predictors, heads —
+    is the "tail" bucket after the backward's last launch.  The buckets partition [0, total) (segment padding included)."""
+    from . import spec
+    names, shapes, offset, total = spec.arena_layout(dims)
+    size = {n: -(-_prod(shapes[n]) // spec.SEG_ALIGN) * spec.SEG_ALIGN for n in names}
+    mats = ("self_attn.w_q.weight", "self_attn.w_k.weight", "self_attn.w_v.weight", "self_attn.w_o.weight",
+            "cross_attn.w_q.weight", "cross_attn.w_o.weight", "ff.linear1.weight", "ff.linear2.weight")
+    tag_of = {}
+    for i in range(dims.dec_layers):
+        for m in mats:
+            tag_of[f"decoder.layers.{i}.{m}"] = f"dec{i}"
+    for i in range(dims.enc_layers):
+        for m in mats:
+            if not m.startswith("cross_attn"):
+                tag_of[f"transformer_encoder_layers.{i}.{m}"] = f"enc{i}"
+    ranges: Dict[str, List[List[int]]] = {}
+    for n in names:                                   # physical order: adjacent segments of a bucket merge
+        r = ranges.setdefault(tag_of.get(n, "tail"), [])
+        if r and r[-1][1] == offset[n]:
+            r[-1][1] = offset[n] + size[n]
+        else:
+            r.append([offset[n], offset[n] + size[n]])
+    order = [f"dec{i}" for i in reversed(range(dims.dec_layers))] + [f"enc{i}" for i in reversed(range(dims.enc_layers))] + ["tail"]
+    return [(t, [tuple(x) for x in ranges[t]]) for t in order if t in ranges]
+
+
+def _prod(shape) -> int:
+    n = 1
+    for v in shape:
+        n *= int(v)
+    return n
+
+
+class BucketedExchange:
+    """engine.dp_comm: SUM-reduces the gradient arena bucket by bucket as the backward releases them.
+
+    backend "rccl": the C ABI's kk_comm_* (RCCL called directly, on `stream`, legal inside a hipGraph capture);
+    backend "dist": torch.distributed all-reduces over the same ranges (gloo on CPU for tests, or when RCCL cannot be
+    bound).  payload "bf16" narrows each range into a bf16 staging arena before the exchange and widens it back
+    (half the xGMI bytes; sums of bf16-rounded gradients)."""
+
+    def __init__(self, dims, world: int, backend: str = "dist", payload: str = "f32", stream=None):
+        self.plan = OrderedDict(bucket_plan(dims))
+        self.world, self.backend, self.payload, self.stream = world, backend, payload, stream
+        self.issued: List[str] = []
+        self._tables: Dict[str, tuple] = {}
+        self._g16: Optional[torch.Tensor] = None
+
+    def begin_step(self) -> None:
+        self.issued = []
+
+    def reduce(self, flat: torch.Tensor, tag: str) -> None:
+        """Exchange bucket `tag` of the flat gradient arena in place (on the current stream)."""
+        ranges = self.plan[tag]
+        self.issued.append(tag)
+        if self.backend == "dist":
+            for b, e in ranges:
+                dist.all_reduce(flat[b:e], op=dist.ReduceOp.SUM)
+            return
+        import ctypes as C
+        from . import lib as kk
+        if tag not in self._tables:
+            n = len(ranges)
+            self._tables[tag] = ((C.c_int64 * n)(*[b for b, _ in ranges]), (C.c_int64 * n)(*[e for _, e in ranges]), n)
+        beg, end, n = self._tables[tag]
+        if self.payload == "bf16":
+            if self._g16 is None or self._g16.numel() != flat.numel():
+                self._g16 = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device)
+            for b, e in ranges:
+                kk.call("kk_cast_f32_bf16", flat[b:e], self._g16[b:e], e - b)
+            kk.call("kk_comm_reduce_ranges", self._g16, beg, end, n, 1)
+            for b, e in ranges:
+                kk.call("kk_cast_bf16_f32", self._g16[b:e], flat[b:e], e - b, 1.0)
+        else:
+            kk.call("kk_comm_reduce_ranges", flat, beg, end, n, 0)
+
+    @classmethod
+    def create(cls, dims, rank: int, world: int, device: torch.device, payload: Optional[str] = None) -> "BucketedExchange":
+        """Communicator over RCCL through the C ABI: rank 0 draws the id, the torch.distributed group (already up for
+        the rendezvous) carries it to the others.  Falls back to the "dist" backend if RCCL cannot be bound."""
+        import ctypes as C
+        from . import lib as kk
+        payload = payload or os.environ.get("KK_DP_PAYLOAD", "f32")
+        lib = kk.load()
+        try:
+            import torch as _t
+            path = os.path.join(os.path.dirname(_t.__file__), "lib", "librccl.so")
+            if lib.kk_comm_load(path.encode() if os.path.exists(path) else None) != 0:
+                raise RuntimeError(lib.kk_last_error().decode())
+            buf = (C.c_char * 128)()
+            if rank == 0 and lib.kk_comm_unique_id(buf) != 0:
+                raise RuntimeError(lib.kk_last_error().decode())
+            box = [bytes(buf)]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0)
+            if lib.kk_comm_world() == 0 and lib.kk_comm_init(rank, world, box[0]) != 0:
+                raise RuntimeError(lib.kk_last_error().decode())
+            return cls(dims, world, "rccl", payload, torch.cuda.Stream(device=device))
+        except Exception as e:                            # RCCL not bindable here: same ranges over torch.distributed
+            import logging
+            logging.getLogger(__name__).warning("kk_comm unavailable (%s); gradient buckets go through torch.distributed", e)
+            return cls(dims, world, "dist", "f32", torch.cuda.Stream(device=device))
+
+
 def all_max(x: torch.Tensor) -> torch.Tensor:
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(x, op=dist.ReduceOp.MAX)
@@ -120,7 +235,13 @@ def barrier() -> None:
 
 
 def shutdown() -> None:
-    """Tear the process group down (quietens the "destroy_process_group() was not called" warning at exit)."""
+    """Tear the communicator and the process group down (quietens the "destroy_process_group() was not called" warning)."""
+    try:
+        from . import lib as kk
+        if kk._lib is not None:
+            kk._lib.kk_comm_destroy()
+    except Exception:
+        pass
     if dist.is_initialized():
         try:
             dist.destroy_process_group()

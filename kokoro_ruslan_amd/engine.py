@@ -47,19 +47,12 @@ class Arena:
     def __init__(self, dims: ModelDims, hp: StepHyper, device: torch.device, shadow_bf16: bool = False):
         self.dims, self.device = dims, device
         self.param_names = list(spec.param_shapes(dims).keys())
-        segs = list(spec.param_shapes(dims).items()) + list(spec.buffer_shapes(dims).items())
-        # physical order: the K and V projections of all decoder cross-attention layers first and contiguous, so the
-        # memory is projected for every layer by ONE GEMM against a [layers*2H, H] matrix (and its two gradients
-        # likewise); everything else in state-dict order.  Names, not offsets, are the interface.
-        is_ckv = lambda n: n.endswith(".cross_attn.w_k.weight") or n.endswith(".cross_attn.w_v.weight")
-        segs = [x for x in segs if is_ckv(x[0])] + [x for x in segs if not is_ckv(x[0])]
-        self.names = [n for n, _ in segs]
-        self.shapes = dict(segs)
-        self.offset: Dict[str, int] = {}
-        off = 0
-        for n, s in segs:
-            self.offset[n] = off
-            off += -(-math.prod(s) // kk.KK_SEG_ALIGN) * kk.KK_SEG_ALIGN
+        # physical order (spec.arena_layout): the K and V projections of all decoder cross-attention layers first and
+        # contiguous, so the memory is projected for every layer by ONE GEMM against a [layers*2H, H] matrix (and its two
+        # gradients likewise); everything else in state-dict order.  Names, not offsets, are the interface.
+        assert spec.SEG_ALIGN == kk.KK_SEG_ALIGN
+        self.names, self.shapes, self.offset, off = spec.arena_layout(dims)
+        segs = [(n, self.shapes[n]) for n in self.names]
         self.total = off
         self.nblocks = off // kk.KK_SEG_ALIGN
         self.nseg = len(segs)
@@ -175,6 +168,14 @@ class KokoroEngine:
         # be joined at the pause and costs 0.43 ms/step at 8x512 (measured with a 1-rank RCCL group: 6.50 vs 6.07 ms),
         # about what hiding ~55 % of a ~1 ms all-reduce of 198 MB over xGMI would return.  Worth it for larger models.
         self.dp_overlap_layer = None
+        # Data-parallel exchange INSIDE the step (dp.BucketedExchange over the C ABI's kk_comm_*): every bucket of the
+        # gradient arena is all-reduced on the exchange's stream as soon as the backward has finished it — after each
+        # decoder / encoder layer's grouped weight gradients, the rest after the last launch — and the optimizer waits for
+        # that stream.  The collectives are captured with the step, so they are one more branch of its hipGraph (no graph
+        # split, nothing between the backward graph and the optimizer graph).  With gradient accumulation only the
+        # boundary micro-batch exchanges (_exchange_now).
+        self.dp_comm = None
+        self._exchange_now = True
         self.global_mel_length = None               # batch-max T over all ranks (adaptive loss scale / clip heuristics)
         # dropout / DropPath / SpecAugment: off = the parity configuration (reference with p = 0)
         self.train_dropout = False
@@ -318,6 +319,22 @@ class KokoroEngine:
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         return ev
+
+    def _comm_bucket(self, tag: str) -> None:
+        """The gradients of bucket `tag` are final on the current stream from here on: exchange them on the comm stream."""
+        c = self.dp_comm
+        if c is None or not self._exchange_now or self._segmented:
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        c.stream.wait_event(ev)
+        with torch.cuda.stream(c.stream):
+            c.reduce(self.arena.g, tag)
+
+    def _comm_join(self) -> None:
+        c = self.dp_comm
+        if c is not None and self._exchange_now and not self._segmented:
+            torch.cuda.current_stream().wait_stream(c.stream)
 
     def _mark(self, name: str) -> None:
         if self.trace:
@@ -1062,6 +1079,8 @@ class KokoroEngine:
         # =========================== backward ===========================
         for ns in self._reduce_lists:
             self._reduce_lists[ns] = []
+        if self.dp_comm is not None and self._exchange_now:
+            self.dp_comm.begin_step()
         dmel, ddur = self._buf("g.mel", B, T, M), self._buf("g.dur", B, Pn)
         dstop, dpitch, denergy = self._buf("g.stop", B, T), self._buf("g.pitch", B, T), self._buf("g.energy", B, T)
         kk.call("kk_losses_bwd", *largs, self.loss_coef, dmel, ddur, dstop, dpitch, denergy)
@@ -1105,6 +1124,7 @@ class KokoroEngine:
                         self._tail_bwd(key + ".ln2", dne, xm, pf + ".norm2", dx, True, ehead("attn", i))
                         self._attn_bwd(key + ".sa", pf + ".self_attn", dx, y1, None, B, Pn, Pn, True, False, text_mask, dne, None, 0.0,
                                        st, p_enc, dpr)
+                    self._comm_bucket(f"enc{i}")            # (the grouped weight-gradient launch is behind us)
                     if i > 0:
                         self._tail_bwd(key + ".ln1", dne, x_in, pf + ".norm1", dx, True, ehead("ffn", i - 1))
                     else:
@@ -1144,6 +1164,7 @@ class KokoroEngine:
                                0.0, st + 8, p_dec, dpr, layer=i)
                 self._tail_bwd(key + ".ln2", dn, ya, pf + ".norm2", dy, True, dhead("sa", i))
                 self._attn_bwd(key + ".sa", pf + ".self_attn", dy, n1, None, B, T, T, True, True, None, dn, None, 0.0, st, p_dec, dpr)
+            self._comm_bucket(f"dec{i}")                    # the layer's weight matrices are final: exchange beside the rest
             if i > 0:
                 self._tail_bwd(key + ".ln1", dn, x_in, pf + ".norm1", dy, True, dhead("ffn", i - 1))
             else:
@@ -1182,6 +1203,8 @@ class KokoroEngine:
         else:
             self._join(self._side)
         self._reduce_partials((B, T, Pn, Tp))
+        self._comm_bucket("tail")                       # everything that was not a layer's weight matrix
+        self._comm_join()
         self._mark("backward joined, partials reduced")
         return out
 
@@ -1373,9 +1396,12 @@ class KokoroEngine:
         div = accumulation_divisor if accumulation_divisor is not None else G
         if self.micro_in_cycle == 0:
             self.zero_grad()
+        is_boundary = bool(boundary) if boundary is not None else self.micro_in_cycle + 1 >= G
+        self._exchange_now = is_boundary                 # (in-step bucket exchange: only the boundary micro-batch communicates)
         out = self.forward_backward(batch, loss_scale=self.dp_loss_scale / div, adaptive=True, expanded_len=expanded_len)
+        self._exchange_now = True
         self.micro_in_cycle += 1
-        if boundary if boundary is not None else self.micro_in_cycle >= G:
+        if is_boundary:
             if grad_sync is not None:
                 grad_sync(self.arena.g)              # data parallel: SUM over ranks (dp.GradSync)
             self.optimizer_step(int(self.global_mel_length or batch["mel_specs"].shape[1]))
@@ -1532,11 +1558,13 @@ class KokoroEngine:
         plain = G == 1 and div == 1                   # the split-backward / segmented forms exist for the one-micro-batch step
         overlap = plain and grad_sync is not None and self.dp_overlap_layer is not None and hasattr(grad_sync, "start")
         ent = self._graphs.get(key)
+        self._exchange_now = is_boundary
         if ent is None:                               # first sight of a shape: eager (allocates the workspaces and the
             static = {k: v.clone() for k, v in batch.items()}      # reduction tables — host-to-device copies, illegal in a capture)
             gen = self._fb_gen(static, scale, True, True, self.dp_overlap_layer if overlap else None, first, expanded_len)
             for _ in gen:                             # same pause point as the captured form, so the same tables get built
                 pass
+            self._exchange_now = True
             # (registered only now: growing a buffer during the eager pass drops every graph entry)
             if len(self._graphs) >= self.max_graphs:
                 torch.cuda.synchronize(self.device)   # a graph about to be destroyed may still be running
@@ -1562,11 +1590,12 @@ class KokoroEngine:
                 d.copy_(v, non_blocking=True)
         if moved:
             kk.copy_many(moved)                        # one launch for the whole batch
-        fkey = (div, first, self.train_dropout, self.spec_augment_active, self.math, overlap)
+        fkey = (div, first, self.train_dropout, self.spec_augment_active, self.math, overlap, self.dp_comm is not None and is_boundary)
         fb = ent["fb"].get(fkey)
         if fb is None:
             with self.capture_lock:
                 fb = ent["fb"][fkey] = self._capture_fb(static, scale, first, expanded_len, overlap, plain)
+        self._exchange_now = True
         if fb["prog"] is not None:
             self._run_program(fb["prog"])
         else:

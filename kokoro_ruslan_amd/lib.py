@@ -159,6 +159,16 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_adamw_ema": [_P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _F, _F, _F, _P, _I, _P, _P],
     "kk_weight_norm_project": [_P, _P, _L, _P, _P, _P, _D, _P, _P],
     "kk_cast_f32_bf16": [_P, _P, _L, _P],
+    "kk_comm_load": [C.c_char_p],
+    "kk_comm_unique_id": [_P],
+    "kk_comm_init": [_I, _I, _P],
+    "kk_comm_world": [],
+    "kk_comm_destroy": [],
+    "kk_comm_reduce_bucket": [_P, _L, _I, _P],
+    "kk_comm_reduce_ranges": [_P, _P, _P, _I, _I, _P],
+    "kk_comm_reduce_scatter": [_P, _P, _L, _I, _P],
+    "kk_comm_all_gather": [_P, _P, _L, _I, _P],
+    "kk_cast_bf16_f32": [_P, _P, _L, _F, _P],
     "kk_copy_many": [_P, _P, _P, _I, _P],
     "kk_axpby": [_F, _P, _F, _P, _L, _P],
     "kk_timestamp": [_P, _P],

@@ -192,6 +192,23 @@ def rope_tables(seq_len: int, head_dim: int = 64, base: float = 10000.0):
     return emb.cos().contiguous(), emb.sin().contiguous()
 
 
+SEG_ALIGN = 1024      # == KK_SEG_ALIGN (include/kokoro_hip.h): arena segments start on multiples of this many elements
+
+
+def arena_layout(d: ModelDims):
+    """(names, shapes, offsets, total) of the flat parameter arena: one 1024-aligned segment per tensor.  Physical order: the K
+    and V projections of all decoder cross-attention layers first and contiguous (one GEMM projects the memory for every
+    layer), everything else in state-dict order.  Pure host arithmetic (the data-parallel bucket plan needs it on CPU)."""
+    segs = list(param_shapes(d).items()) + list(buffer_shapes(d).items())
+    is_ckv = lambda n: n.endswith(".cross_attn.w_k.weight") or n.endswith(".cross_attn.w_v.weight")
+    segs = [x for x in segs if is_ckv(x[0])] + [x for x in segs if not is_ckv(x[0])]
+    offset, off = {}, 0
+    for n, shp in segs:
+        offset[n] = off
+        off += -(-math.prod(shp) // SEG_ALIGN) * SEG_ALIGN
+    return [n for n, _ in segs], dict(segs), offset, off
+
+
 def state_dict_order(d: ModelDims) -> List[str]:
     out: List[str] = []
     for n in param_shapes(d):

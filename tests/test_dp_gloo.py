@@ -136,3 +136,72 @@ def test_shard_batch_and_env():
     with pytest.raises(ValueError):
         dp.shard_batch(b, 0, 3)
     assert dp.GradSync(8).loss_scale == 0.125
+
+
+# ---- bucketed in-step exchange: the engine-side plan and range logic (dp.bucket_plan / dp.BucketedExchange) -----------
+def test_bucket_plan_partitions_the_arena_in_backward_order():
+    from kokoro_ruslan_amd import dp, spec
+    for dims in (spec.ModelDims(), spec.ModelDims(hidden=128, heads=2, enc_layers=2, dec_layers=3, enc_ff=96, dec_ff=96, var_filter=32,
+                                                  var_bins=16, mel=20, max_len=300)):
+        names, shapes, offset, total = spec.arena_layout(dims)
+        plan = dp.bucket_plan(dims)
+        tags = [t for t, _ in plan]
+        assert tags == ([f"dec{i}" for i in reversed(range(dims.dec_layers))] + [f"enc{i}" for i in reversed(range(dims.enc_layers))] + ["tail"])
+        flat = sorted(r for _, rs in plan for r in rs)
+        assert flat[0][0] == 0 and flat[-1][1] == total and all(a[1] == b[0] for a, b in zip(flat, flat[1:])), "ranges must tile the arena"
+        where = {}
+        for t, rs in plan:
+            for b, e in rs:
+                for n in names:
+                    if b <= offset[n] < e:
+                        where[n] = t
+        H = dims.hidden
+        assert where["decoder.layers.1.ff.linear1.weight"] == "dec1" and where["decoder.layers.1.self_attn.w_v.weight"] == "dec1"
+        assert where["transformer_encoder_layers.0.self_attn.w_o.weight"] == "enc0"
+        # not final at the end of their layer: the batched cross K/V projections, every small vector, embeddings, heads
+        for n in ("decoder.layers.1.cross_attn.w_k.weight", "decoder.layers.1.norm2.weight", "decoder.layers.1.ff.linear1.bias",
+                  "decoder.layers.0.self_attn.q_norm.weight", "text_embedding.weight", "mel_projection_out.weight",
+                  "duration_adaptor.variance_adaptor.pitch_predictor.conv_layers.0.weight", "positional_encoding.pe"):
+            assert where[n] == "tail", n
+        big = sum(e - b for t, rs in plan if t != "tail" for b, e in rs)
+        frac = big / sum(int(np.prod(s)) for n, s in spec.param_shapes(dims).items())
+        assert frac > (0.85 if dims.hidden == 512 else 0.7), f"the layer buckets carry the bulk of the bytes ({frac:.2f})"
+        # a decoder layer's q|k|v projections are adjacent: they travel as one range
+        rs = dict(plan)["dec0"]
+        assert any(e - b >= 3 * H * H for b, e in rs)
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from kokoro_ruslan_amd import dp, spec
+    dp.init("gloo")
+    dims = spec.ModelDims(hidden=128, heads=2, enc_layers=2, dec_layers=2, enc_ff=96, dec_ff=96, var_filter=32, var_bins=16, mel=20, max_len=300)
+    total = spec.arena_layout(dims)[3]
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(total, generator=g)
+    whole = flat.clone()
+    dist.all_reduce(whole, op=dist.ReduceOp.SUM)                        # what one exchange of the whole arena gives
+    ex = dp.BucketedExchange(dims, world, backend="dist")
+    ex.begin_step()
+    for tag in ex.plan:                                                  # the engine issues the buckets in this order
+        ex.reduce(flat, tag)
+    dp.barrier()
+    if rank == 0:
+        q.put((bool(torch.equal(flat, whole)), list(ex.issued)))
+    dist.destroy_process_group()
+
+
+def test_bucketed_exchange_two_ranks_equals_one_all_reduce():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    same, issued = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert same, "bucket by bucket must give exactly the sum of the whole arena"
+    assert issued == ["dec1", "dec0", "enc1", "enc0", "tail"]

@@ -712,3 +712,60 @@ def test_micro_batch_finite_guard_drops_the_cycle(eng_mod, golden_dir):
     e.forward_backward(_cuda(good[0]), backward=False)
     torch.cuda.synchronize()
     assert e.opt_stats()["micro_bad"] == 0 and e.opt_stats()["micro_bad_total"] == 1
+
+
+def test_in_graph_bucket_exchange_over_rccl_one_rank(eng_mod, golden_dir):
+    """The data-parallel exchange as it runs on 8 GPUs, on one: a 1-rank RCCL communicator through the C ABI (kk_comm_*),
+    the buckets issued from inside the backward in reverse-autograd order, captured into the step's hipGraph.  With one
+    rank the sum is the identity, so training must be exactly the training without the exchange — eager, replayed, with
+    gradient accumulation (only the boundary micro-batch exchanges) and with the bf16 payload (identity up to bf16
+    rounding of the gradients)."""
+    from kokoro_ruslan_amd import dp, lib as kk
+    fx, d, _, P = _load(golden_dir, "tiny_full")
+    batches = [_cuda(O.synthetic_batch(2, 40, 6, d, seed=700 + i, ragged=True)) for i in range(2)]
+
+    def run(comm, graphed, G):
+        e = _engine(eng_mod, d, P, math_mode="bf16", gradient_accumulation_steps=G)
+        e.train_dropout = True
+        e.dp_comm = comm
+        log = []
+        if comm is not None:
+            orig = comm.reduce
+            comm.reduce = lambda flat, tag: (log.append(tag), orig(flat, tag))[1]
+        for it in range(4 * G):
+            (e.train_step_graphed if graphed else e.train_step)(batches[it % 2])
+        torch.cuda.synchronize()
+        if comm is not None:
+            comm.reduce = orig
+        assert e.opt_stats()["attempt"] == 4 and e.opt_stats()["skipped"] == 0
+        return e.arena.p.clone(), log
+    from kokoro_ruslan_amd.spec import ModelDims
+    dims = ModelDims(**d.__dict__)
+    comm = dp.BucketedExchange.create(dims, 0, 1, torch.device("cuda"))
+    assert comm.backend == "rccl" and kk.load().kk_comm_world() == 1, "RCCL must bind through the C ABI on the GPU box"
+    tags = list(comm.plan)
+    ref1, _ = run(None, False, 1)
+    for graphed in (False, True):
+        got, log = run(comm, graphed, 1)
+        assert float((got - ref1).abs().max()) <= 2e-5 * float(ref1.abs().max())
+        n_calls = 4 if not graphed else 2                     # replays do not go through Python: eager first sight + one capture
+        assert log == tags * n_calls, (graphed, log[:8])
+    ref2, _ = run(None, False, 2)
+    got, log = run(comm, True, 2)
+    assert float((got - ref2).abs().max()) <= 2e-5 * float(ref2.abs().max())
+    assert log and len(log) % len(tags) == 0 and log[:len(tags)] == tags
+    comm.payload = "bf16"
+    got, _ = run(comm, True, 1)
+    assert float((got - ref1).abs().max()) <= 2e-3 * float(ref1.abs().max())
+    assert float((got - ref1).abs().max()) > 0.0, "the bf16 payload must actually round the gradients"
+    # the raw entry points
+    x = torch.arange(1000, dtype=torch.float32, device="cuda")
+    kk.call("kk_comm_reduce_bucket", x, 1000, 0)
+    y = torch.empty(1000, dtype=torch.float32, device="cuda")
+    kk.call("kk_comm_reduce_scatter", x, y, 1000, 0)
+    z = torch.empty(1000, dtype=torch.float32, device="cuda")
+    kk.call("kk_comm_all_gather", y, z, 1000, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(x, torch.arange(1000, dtype=torch.float32, device="cuda")) and torch.equal(z, x)
+    with pytest.raises(RuntimeError, match="dtype"):
+        kk.call("kk_comm_reduce_bucket", x, 1000, 7)
