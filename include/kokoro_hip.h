@@ -44,9 +44,6 @@ int kk_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, const 
             const float *B, int64_t ldb, float beta, float *C, int64_t ldc, const float *bias,
             const float *residual, int64_t ldr, int64_t res_mod, int split_k, int math, int dtypes,
             void *stream);
-/* tuning hook for benchmarks: 128x128-tile threshold (tile count) and XCD-aware tile order on/off */
-int kk_gemm_tune(int tm_threshold, int xcd_swizzle);
-int kk_gemm_tune16(int enable, int thr128, int thr12864, int split_target);   /* same, for the bf16 x bf16 DMA-staged core */
 /* Weight gradients of several nn.Linear layers in one launch (what autograd computes one by one for w_q/w_k/w_v/w_o,
  * transformers.py:131-136, and linear1/linear2, transformers.py:90-91): for i < n,
  *   dw_i[M_i, N_i] += dy_i[T_i, M_i]^T . x_i[T_i, N_i]      (bf16 dy / x, fp32 dw, like kk_gemm(ta=1, tb=1, beta=1)).
@@ -59,8 +56,7 @@ typedef struct {
     float *dw;      int64_t lddw;
     int64_t M, N, T;
 } KkWgradDesc;
-int kk_gemm_wgrad_group(const KkWgradDesc *descs, int n, void *stream);
-int kk_gemm_tune_group(int split); /* tools: force the k-slice count of grouped launches (0 = automatic) */
+int kk_gemm_wgrad_group(const KkWgradDesc *descs, int n, int split_k /* k-slices per problem, 0 = automatic */, void *stream);
 /* Attention projections with the per-head norm as the epilogue: raw[T, parts*heads*64] = x[T,K] . W^T (+bias), saved for
  * the backward, and y = per-head RMSNorm(64)(raw) * gains[part] (+ RoPE on the parts set in rope_mask, position = row % S)
  * from one launch — a 64x64 output tile is exactly 64 (row, head) vectors.  parts <= 12 column groups of heads*64 (q|k|v of

@@ -34,16 +34,23 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, tuning: bool = False) -> str:
+    """tuning=True also exports the tools-only tuning hooks (include/kokoro_hip_tuning.h); the product build does not."""
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
+    stamp = os.path.join(OBJ, ".tuning")
+    was = os.path.exists(stamp)
+    if was != tuning:                                   # switching flavours recompiles everything
+        force = True
+        (open(stamp, "w").close() if tuning else os.remove(stamp))
+    flags = FLAGS + (["-DKK_TUNING_HOOKS"] if tuning else [])
     headers = [os.path.join(CSRC, "kk_common.h"), os.path.join(os.path.dirname(HERE), "include", "kokoro_hip.h")]
 
     def compile_one(src: str) -> str:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc] + flags + ["-c", s, "-o", o]
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
@@ -62,4 +69,4 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, tuning="--tuning" in sys.argv))

@@ -350,7 +350,10 @@ int g_use_gemm16 = 1;       // route bf16 x bf16 problems to the DMA-staged core
 
 }  // namespace
 
-// Test/tuning hook (not part of the product path): tile-selection threshold and XCD swizzle on/off.
+// Tuning hooks for tools/ (tile-selection thresholds, XCD swizzle, pipeline depth): NOT part of the product ABI — compiled
+// only into a library built with KK_TUNING_HOOKS (python -m kokoro_ruslan_amd.build --tuning; include/kokoro_hip_tuning.h).
+// The product library's tile policy is fixed at load time (optionally from KK_GEMM16_TUNE, read once in kk_gemm16.hip).
+#ifdef KK_TUNING_HOOKS
 extern "C" int kk_gemm_tune(int tm_threshold, int xcd_swizzle) {
     g_tm_threshold = tm_threshold;
     g_xcd_swizzle = xcd_swizzle;
@@ -361,6 +364,8 @@ extern "C" int kk_gemm_tune16(int enable, int thr128, int thr12864, int split_ta
     if (thr128 > 0) kk_gemm16_tune(thr128, thr12864, split_target);
     return 0;
 }
+extern "C" int kk_gemm_tune_group(int split) { kk_gemm16_tune_group(split); return 0; }
+#endif
 
 extern "C" int kk_gemm(int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, const float *A, int64_t lda,
                        const float *B, int64_t ldb, float beta, float *C, int64_t ldc, const float *bias,
@@ -456,11 +461,11 @@ extern "C" int kk_gemm_linear_glu(int64_t T, int64_t F, int64_t K, const void *x
 }
 
 // A layer's weight gradients as one grouped launch (bf16 operands, fp32 accumulate into dW).
-extern "C" int kk_gemm_wgrad_group(const KkWgradDesc *descs, int n, void *stream) {
+extern "C" int kk_gemm_wgrad_group(const KkWgradDesc *descs, int n, int split_k, void *stream) {
     KK_REQUIRE(descs != nullptr, "kk_gemm_wgrad_group: null descriptor table");
-    return kk_gemm16_wgrad_group(descs, n, g_xcd_swizzle, (hipStream_t)stream);
+    KK_REQUIRE(split_k >= 0 && split_k < 100, "kk_gemm_wgrad_group: split_k out of range");
+    return kk_gemm16_wgrad_group(descs, n, split_k, g_xcd_swizzle, (hipStream_t)stream);
 }
-extern "C" int kk_gemm_tune_group(int split) { kk_gemm16_tune_group(split); return 0; }
 
 // q / k / v projection with the per-head RMSNorm (+ RoPE) as the epilogue (bf16 operands; see gemm16_kernel, EPI = 3).
 extern "C" int kk_gemm_qkv_headnorm(int64_t T, int parts, int heads, int64_t K, const void *x, int64_t ldx, const void *W,

@@ -469,6 +469,21 @@ void launch_tile(int ta, int tb, const G16Args &a, dim3 grid, hipStream_t s) {
 // every shape measured inside the train step — the launches are latency-bound, so more, smaller workgroups with more
 // DMAs in flight beat the larger tiles' better bytes-per-flop.
 int g16_thr128 = 4096, g16_thr12864 = 4096, g16_split_target = 384, g16_stages = 3, g16_split_major = 0;
+// Optional override of the tile policy, read ONCE when the library is loaded (no mutable policy behind the ABI):
+// KK_GEMM16_TUNE="thr128,thr12864,code" with code = flags*100000 + stages*10000 + split target, as tools/ encode it.
+struct G16EnvInit {
+    G16EnvInit() {
+        const char *e = getenv("KK_GEMM16_TUNE");
+        int a = 0, b = 0, c = 0;
+        if (e && sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a > 0) {
+            g16_thr128 = a;
+            g16_thr12864 = b;
+            g16_stages = (c / 10000) % 10 ? (c / 10000) % 10 : 3;
+            g16_split_major = c / 100000 ? 1 : 0;
+            g16_split_target = c % 10000;
+        }
+    }
+} g16_env_init;
 int g16_group_tile = 1;                                         // grouped launches: 0 = 64x64, 1 = 128x64 (default: +1 % on the step), 2 = 128x128 tiles
 int g16_group_waves = getenv("KK_GROUP_WAVES") ? atoi(getenv("KK_GROUP_WAVES")) : 8;   // 8-wave workgroups on the 128-row tiles (4: the old form)
 int g16_group_split = 0;                                        // grouped launches: 0 = by the split target, n = n k-slices
@@ -588,7 +603,7 @@ int kk_gemm16_linear_glu(int64_t T, int64_t F, int64_t K, const void *x, int64_t
 }
 
 // dW_i[M_i, N_i] += dY_i[T_i, M_i]^T . X_i[T_i, N_i] for i < n, one launch (see gemm16_group_kernel).
-int kk_gemm16_wgrad_group(const KkWgradDesc *d, int n, int xcd_swizzle, hipStream_t s) {
+int kk_gemm16_wgrad_group(const KkWgradDesc *d, int n, int split_k, int xcd_swizzle, hipStream_t s) {
     auto cd = [](int64_t x, int64_t y) { return (int)((x + y - 1) / y); };
     if (n < 1 || n > GROUP_MAX) return kk_fail(KK_EINVAL, "kk_gemm_wgrad_group: 1..%d problems per launch, got %d", GROUP_MAX, n);
     int total = 0;
@@ -601,7 +616,8 @@ int kk_gemm16_wgrad_group(const KkWgradDesc *d, int n, int xcd_swizzle, hipStrea
         total += cd(d[i].M, BM) * cd(d[i].N, BN);
     }
     int splits = 1;
-    if (g16_group_split > 0) splits = g16_group_split;
+    if (split_k > 0) splits = split_k;                            // the caller's k-slice count (0 = by the split target)
+    else if (g16_group_split > 0) splits = g16_group_split;
     else if (total * 2 <= g16_split_target) splits = cd(g16_split_target, total);
     G16Group g = {};
     g.n = n;

@@ -492,7 +492,7 @@ class KokoroEngine:
             part = q[i:i + 8]
             sig = ("wg",) + tuple((dy.data_ptr(), x.data_ptr(), dw.data_ptr(), tuple(dy.shape), tuple(x.shape)) for dy, x, dw in part)
             table = self._table(sig, lambda: kk.wgrad_table(part))
-            kk.call("kk_gemm_wgrad_group", table, len(part))
+            kk.call("kk_gemm_wgrad_group", table, len(part), 0)
 
     def _ln_fwd(self, key, x, prefix, dtype=torch.float32):
         P = self.arena.P

@@ -107,10 +107,7 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_gemm_linear_glu": [_L, _L, _L, _P, _L, _P, _P, _P, _P, _L, _P, _U, _F, _P],
     "kk_gemm_dgrad_glu": [_L, _L, _L, _P, _L, _P, _P, _P, _P, _P, _U, _F, _P],
     "kk_gemm_dgrad_glu_blocks": [_L],
-    "kk_gemm_wgrad_group": [_P, _I, _P],
-    "kk_gemm_tune_group": [_I],
-    "kk_gemm_tune": [_I, _I],
-    "kk_gemm_tune16": [_I, _I, _I, _I],
+    "kk_gemm_wgrad_group": [_P, _I, _I, _P],
     "kk_colsum_acc": [_P, _L, _L, _L, _P, _I, _P],
     "kk_attn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P],
     "kk_attn_delta": [_P, _P, _P, _I, _I, _I, _L, _L, _I, _P],
@@ -223,13 +220,25 @@ def _conv(a):
     return a
 
 
+def _tuning_hook(name: str):
+    fn = getattr(load(), name, None)
+    if fn is None:
+        raise RuntimeError(f"{name} is a tools-only tuning hook (include/kokoro_hip_tuning.h): rebuild with "
+                           "`python -m kokoro_ruslan_amd.build --tuning`, or set KK_GEMM16_TUNE before the first call")
+    return fn
+
+
 def gemm_tune(tm_threshold: int = 512, xcd_swizzle: int = 1) -> None:
-    load().kk_gemm_tune(tm_threshold, xcd_swizzle)
+    _tuning_hook("kk_gemm_tune")(tm_threshold, xcd_swizzle)
 
 
 def gemm_tune16(enable: int = 1, thr128: int = 0, thr12864: int = 0, split_target: int = 0) -> None:
     """Benchmark hook for the bf16 x bf16 GEMM core: on/off, tile thresholds, split-K workgroup target (0 = keep)."""
-    load().kk_gemm_tune16(enable, thr128, thr12864, split_target)
+    _tuning_hook("kk_gemm_tune16")(enable, thr128, thr12864, split_target)
+
+
+def gemm_tune_group(split: int = 0) -> None:
+    _tuning_hook("kk_gemm_tune_group")(split)
 
 
 launches = 0          # kk.call invocations so far (the graph-capture driver uses it to drop empty segments)

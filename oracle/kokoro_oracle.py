@@ -286,7 +286,7 @@ def length_regulate_index(durations: np.ndarray, max_len: Optional[int] = None
 def length_regulate(tokens: Tensor, durations: Tensor, max_len: Optional[int] = None) -> Tensor:
     """``vectorized_expand_tokens`` (lengths.py:16-96): gather + zero-fill, output detached."""
     idx, _, L = length_regulate_index(durations.detach().cpu().numpy(), max_len)
-    idx_t = torch.from_numpy(idx)
+    idx_t = torch.from_numpy(idx).to(tokens.device)
     src = tokens.detach()
     safe = idx_t.clamp(min=0)
     if src.dim() == 3:
@@ -333,12 +333,12 @@ def attention(P: Dict[str, Tensor], prefix: str, xq: Tensor, xkv: Tensor, heads:
     q = _rms_norm(q, P[f"{prefix}.q_norm.weight"])
     k = _rms_norm(k, P[f"{prefix}.k_norm.weight"])
     if rope:
-        cos, sin = rope_tables(max(Sq, Sk), dk)
+        cos, sin = (t.to(q.device) for t in rope_tables(max(Sq, Sk), dk))
         q = q * cos[:Sq] + _rotate_half(q) * sin[:Sq]
         k = k * cos[:Sk] + _rotate_half(k) * sin[:Sk]
     scores = torch.matmul(q, k.transpose(-2, -1)) / math.sqrt(dk)
     if causal:
-        scores = scores + torch.triu(torch.full((Sq, Sk), float("-inf")), diagonal=1)
+        scores = scores + torch.triu(torch.full((Sq, Sk), float("-inf"), device=scores.device), diagonal=1)
     if key_mask is not None:
         scores = scores.masked_fill(key_mask.bool()[:, None, None, :], float("-inf"))
     probs = _drop(torch.softmax(scores, dim=-1), p_drop, drop_on)
@@ -366,7 +366,7 @@ def _drop_path(x: Tensor, rate: float, on: bool) -> Tensor:
     if not on or rate == 0.0:
         return x
     keep = 1.0 - rate
-    rnd = (keep + torch.rand((x.shape[0],) + (1,) * (x.dim() - 1))).floor_()
+    rnd = (keep + torch.rand((x.shape[0],) + (1,) * (x.dim() - 1), device=x.device)).floor_()
     return x.div(keep) * rnd
 
 
@@ -406,7 +406,7 @@ def variance_predictor(P, prefix: str, x: Tensor, mask: Optional[Tensor], p_drop
         xc = x[:, s:s + 512, :].transpose(1, 2)
         mc = mask[:, s:s + 512] if mask is not None else None
         if xc.size(2) < 2:
-            o = torch.zeros(B, xc.size(2), dtype=x.dtype)
+            o = torch.zeros(B, xc.size(2), dtype=x.dtype, device=x.device)
         else:
             h = xc
             for li in range(2):
@@ -481,7 +481,7 @@ def forward(P: Dict[str, Tensor], Bf: Dict[str, Tensor], batch: Dict[str, Tensor
         xf = F.pad(xf, (0, 0, 0, 3 - xf.size(1)))
     lengths = dur.long().sum(dim=1)
     Lp = xf.size(1)
-    frame_mask = torch.arange(Lp).unsqueeze(0) >= lengths.unsqueeze(1)
+    frame_mask = torch.arange(Lp, device=lengths.device).unsqueeze(0) >= lengths.unsqueeze(1)
     pitch_pred = variance_predictor(P, f"{va}.pitch_predictor", xf, frame_mask, drop.variance, on)
     energy_pred = variance_predictor(P, f"{va}.energy_predictor", xf, frame_mask, drop.variance, on)
 
@@ -563,7 +563,7 @@ def encode_for_inference(P: Dict[str, Tensor], Bf: Dict[str, Tensor], ids: Tenso
         xf = F.pad(xf, (0, 0, 0, 3 - xf.size(1)))
     lengths = dur.long().sum(dim=1)
     Lp = xf.size(1)
-    frame_mask = torch.arange(Lp).unsqueeze(0) >= lengths.unsqueeze(1)
+    frame_mask = torch.arange(Lp, device=lengths.device).unsqueeze(0) >= lengths.unsqueeze(1)
     pitch = variance_predictor(P, f"{va}.pitch_predictor", xf, frame_mask)
     energy = variance_predictor(P, f"{va}.energy_predictor", xf, frame_mask)
     pb = torch.bucketize(pitch.clamp(0.0, 1.0), Bf[f"{va}.pitch_bins"])
@@ -654,7 +654,7 @@ def _huber(x: Tensor, y: Tensor, delta: float) -> Tensor:
 
 def _masked_mean(v: Tensor, m: Tensor) -> Tensor:
     m = m & torch.isfinite(v)
-    return v[m].mean() if bool(m.any()) else torch.tensor(0.0)
+    return v[m].mean() if bool(m.any()) else torch.tensor(0.0, device=v.device)
 
 
 def loss_sums(out: Dict[str, Tensor], batch: Dict[str, Tensor], hp: StepHyper) -> Tuple[List[Tensor], List[Tensor]]:
@@ -663,8 +663,8 @@ def loss_sums(out: Dict[str, Tensor], batch: Dict[str, Tensor], hp: StepHyper) -
     ranks and normalise by the global counts (kk_losses_finalize)."""
     mel_t = batch["mel_specs"]
     T, Pn = mel_t.size(1), batch["phoneme_durations"].size(1)
-    mel_mask = torch.arange(T).unsqueeze(0) < batch["mel_lengths"].unsqueeze(1)
-    ph_mask = torch.arange(Pn).unsqueeze(0) < batch["phoneme_lengths"].unsqueeze(1)
+    mel_mask = torch.arange(T, device=mel_t.device).unsqueeze(0) < batch["mel_lengths"].unsqueeze(1)
+    ph_mask = torch.arange(Pn, device=mel_t.device).unsqueeze(0) < batch["phoneme_lengths"].unsqueeze(1)
     l1 = (out["mel"] - mel_t).abs()
     m3 = mel_mask.unsqueeze(-1).expand_as(l1)
     tgt_dur = torch.log(batch["phoneme_durations"].float() + 1.0)
@@ -694,8 +694,8 @@ def losses(out: Dict[str, Tensor], batch: Dict[str, Tensor], hp: StepHyper
     """(total, mel, dur, stop, pitch, energy)."""
     mel_t = batch["mel_specs"]
     T, Pn = mel_t.size(1), batch["phoneme_durations"].size(1)
-    mel_mask = torch.arange(T).unsqueeze(0) < batch["mel_lengths"].unsqueeze(1)
-    ph_mask = torch.arange(Pn).unsqueeze(0) < batch["phoneme_lengths"].unsqueeze(1)
+    mel_mask = torch.arange(T, device=mel_t.device).unsqueeze(0) < batch["mel_lengths"].unsqueeze(1)
+    ph_mask = torch.arange(Pn, device=mel_t.device).unsqueeze(0) < batch["phoneme_lengths"].unsqueeze(1)
 
     l1 = (out["mel"] - mel_t).abs()
     loss_mel = _masked_mean(l1, mel_mask.unsqueeze(-1).expand_as(l1))
@@ -703,7 +703,7 @@ def losses(out: Dict[str, Tensor], batch: Dict[str, Tensor], hp: StepHyper
     tgt_dur = torch.log(batch["phoneme_durations"].float() + 1.0)
     ld = _huber(out["log_dur"], tgt_dur, hp.duration_huber_delta)
     dv = ph_mask & (batch["phoneme_durations"] > 0)
-    loss_dur = ld[dv].mean() if bool(dv.any()) else torch.tensor(0.0)
+    loss_dur = ld[dv].mean() if bool(dv.any()) else torch.tensor(0.0, device=ld.device)
 
     z, y = out["stop"], batch["stop_token_targets"]
     # BCEWithLogits(pos_weight): -(pw*y*logσ(z) + (1-y)*logσ(-z))

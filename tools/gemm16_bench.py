@@ -49,7 +49,7 @@ for spec in sys.argv[2:]:
     configs.append((f"dma {spec}", (1, a, b, c)))
 rows = {}
 for label, cfg in configs:
-    kk.load().kk_gemm_tune16(*cfg)
+    kk.gemm_tune16(*cfg)
     for name, fl, fn in cases():
         t = timeit(fn)
         rows.setdefault(name, []).append(f"{label}: {t:6.1f}us {fl / t / 1e6:5.0f}TF")

@@ -33,7 +33,7 @@ for M, N, K in [(4096, 512, 4096), (2048, 2048, 4096), (4096, 4096, 512), (4096,
             B = torch.randn((K, N) if tb else (N, K), device="cuda").to(bf)
             Cm = torch.zeros(M, N, device="cuda")
             for stages in (2, 3):
-                kk.load().kk_gemm_tune16(1, 4096, 4096, stages * 10000 + 384)
+                kk.gemm_tune16(1, 4096, 4096, stages * 10000 + 384)
                 t = timeit(lambda: kk.call("kk_gemm", ta, tb, M, N, K, 1.0, A, A.stride(0), B, B.stride(0), 0.0, Cm, N, None, None,
                                            0, 0, 1, 1, 3))
                 out.append(f"ta{ta} tb{tb} NS{stages}: {t:6.1f}us {2.0 * M * N * K / t / 1e6:4.0f}TF")

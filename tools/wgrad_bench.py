@@ -40,7 +40,7 @@ for spec in sys.argv[2:]:
     configs.append((spec, (1, a, b, c)))
 rows = {}
 for label, cfg in configs:
-    kk.load().kk_gemm_tune16(*cfg)
+    kk.gemm_tune16(*cfg)
     for name, fl, fn in cases():
         t = timeit(fn)
         rows.setdefault(name, []).append(f"{label}: {t:6.1f}us {fl / t / 1e6:4.0f}TF")
@@ -56,10 +56,10 @@ for label, shapes in [("enc layer", [(512, 2048), (4096, 512), (512, 512), (1536
     table = kk.wgrad_table(probs)
     out = []
     for stages in (2, 3):
-        kk.load().kk_gemm_tune16(1, 4096, 4096, stages * 10000 + 384)
+        kk.gemm_tune16(1, 4096, 4096, stages * 10000 + 384)
         for split in (1, 2, 101, 102, 201, 202):
-            kk.load().kk_gemm_tune_group(split)
-            t = timeit(lambda: kk.call("kk_gemm_wgrad_group", table, len(probs)))
+            kk.gemm_tune_group(split)
+            t = timeit(lambda: kk.call("kk_gemm_wgrad_group", table, len(probs), 0))
             out.append(f"NS {stages} split {split}: {t:6.1f}us {fl / t / 1e6:4.0f}TF")
-    kk.load().kk_gemm_tune_group(0)
+    kk.gemm_tune_group(0)
     print("group", label, " | ".join(out))
