@@ -158,8 +158,8 @@ def torch_rocm_baseline(B, T, P, steps=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--frames", type=int, default=512)
     ap.add_argument("--phonemes", type=int, default=64)

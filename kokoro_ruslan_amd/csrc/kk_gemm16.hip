@@ -400,6 +400,32 @@ __global__ __launch_bounds__(256) void gemm16_kernel(G16Args a) {
     gemm16_body<TA, TB, BM, BN, NS, EPI>(a, blockIdx.x, smem);
 }
 
+// The same body run by EIGHT waves on the 128x64 tile (a 4x2 wave grid, one 32x32 MFMA chain per wave): twice the waves per
+// byte of LDS, which is what these latency-bound launches respond to (see the grouped weight gradients below).
+template <bool TA, bool TB, int NS>
+__global__ __launch_bounds__(512) void gemm16_kernel_w8(G16Args a) {
+    __shared__ __attribute__((aligned(16))) char smem[NS * (128 + 64) * BK * 2];
+    gemm16_body<TA, TB, 128, 64, NS, 0, 8, 2>(a, blockIdx.x, smem);
+}
+template __global__ void gemm16_kernel_w8<false, false, 2>(G16Args);
+template __global__ void gemm16_kernel_w8<false, true, 2>(G16Args);
+template __global__ void gemm16_kernel_w8<true, false, 2>(G16Args);
+template __global__ void gemm16_kernel_w8<true, true, 2>(G16Args);
+template __global__ void gemm16_kernel_w8<false, false, 3>(G16Args);
+template __global__ void gemm16_kernel_w8<false, true, 3>(G16Args);
+template __global__ void gemm16_kernel_w8<true, false, 3>(G16Args);
+template __global__ void gemm16_kernel_w8<true, true, 3>(G16Args);
+template <int NS>
+void launch_w8(int ta, int tb, const G16Args &a, dim3 grid, hipStream_t s) {
+    if (!ta && !tb) hipLaunchKernelGGL((gemm16_kernel_w8<false, false, NS>), grid, dim3(512), 0, s, a);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm16_kernel_w8<false, true, NS>), grid, dim3(512), 0, s, a);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm16_kernel_w8<true, false, NS>), grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((gemm16_kernel_w8<true, true, NS>), grid, dim3(512), 0, s, a);
+}
+// 8-wave 128x64 tiles, 3 stages, for single GEMMs with >= g16_thr12864 such tiles: +0.8 % on the 8x512 step, +2.2 % at 8x1024
+// (interleaved A/B, tools/probes/g16w8.sh); KK_G16_W8=0 restores the 4-wave form, =2 two stages.
+int g16_w8 = getenv("KK_G16_W8") ? atoi(getenv("KK_G16_W8")) : 3;
+
 // Several independent GEMMs of one operand layout in ONE launch (a layer's weight gradients: they have no consumer
 // before the optimizer, so they wait until the layer's backward is through and then fill the chip together — ~1000
 // 64x64 tiles with the full reduction length each, no split-K atomics, one launch instead of four to six).
@@ -465,10 +491,11 @@ void launch_tile(int ta, int tb, const G16Args &a, dim3 grid, hipStream_t s) {
     else hipLaunchKernelGGL((gemm16_kernel<true, true, BM, BN, NS>), grid, dim3(256), 0, s, a);
 }
 
-// Tile choice (by tile count): at this model's sizes (4096..8192 rows x 512..3072 columns) the 64x64 tile wins on
-// every shape measured inside the train step — the launches are latency-bound, so more, smaller workgroups with more
-// DMAs in flight beat the larger tiles' better bytes-per-flop.
-int g16_thr128 = 4096, g16_thr12864 = 4096, g16_split_target = 384, g16_stages = 3, g16_split_major = 0;
+// Tile choice (by tile count): with four waves per workgroup the 64x64 tile wins on every shape of this model measured
+// inside the train step (the launches are latency-bound: more, smaller workgroups keep more DMAs in flight); with EIGHT
+// waves the 128x64 tile is level or better from 128 tiles on (the decoder's 4096-row GEMMs), so those take it and the
+// encoder's 512-row GEMMs stay on 64x64.
+int g16_thr128 = 4096, g16_thr12864 = 128, g16_split_target = 384, g16_stages = 3, g16_split_major = 0;
 // Optional override of the tile policy, read ONCE when the library is loaded (no mutable policy behind the ABI):
 // KK_GEMM16_TUNE="thr128,thr12864,code" with code = flags*100000 + stages*10000 + split target, as tools/ encode it.
 struct G16EnvInit {
@@ -558,6 +585,7 @@ int kk_gemm16_launch(int ta, int tb, int64_t M, int64_t N, int64_t K, float alph
     dim3 grid(a.tiles_m * a.tiles_n * splits);
     const int ns = ktiles / splits < 3 ? 2 : g16_stages;        // (a short reduction gains nothing from depth)
     if (BM == 128 && BN == 128) launch_tile<128, 128, 2>(ta, tb, a, grid, s);
+    else if (BM == 128 && g16_w8) { if (ns >= 3 && g16_w8 >= 3) launch_w8<3>(ta, tb, a, grid, s); else launch_w8<2>(ta, tb, a, grid, s); }
     else if (BM == 128) { if (ns >= 3) launch_tile<128, 64, 3>(ta, tb, a, grid, s); else launch_tile<128, 64, 2>(ta, tb, a, grid, s); }
     else if (ns >= 4) launch_tile<64, 64, 4>(ta, tb, a, grid, s);
     else if (ns == 3) launch_tile<64, 64, 3>(ta, tb, a, grid, s);
