@@ -39,6 +39,8 @@ def gemm_symbol(ta, tb, M, N, K, math_bf16, dtypes):
     b = lambda v: "true" if v else "false"
     if math_bf16 and (dtypes & 3) == 3 and (K % 64 == 0 or (ta and tb)):      # DMA-staged bf16 x bf16 core, 64x64 tiles here
         cd = lambda x, y: -(-x // y)
+        if cd(M, 128) * cd(N, 64) >= 128 and os.environ.get("KK_G16_W8", "3") != "0":      # eight waves on 128x64 tiles
+            return f"gemm16_kernel_w8<{b(ta)},{b(tb)},{3 if cd(K, 64) >= 3 else 2}> ({GEMM_ROLE[(ta, tb)]}, 128x64 tiles)"
         tiles, ktiles = cd(M, 64) * cd(N, 64), cd(K, 64)
         splits = 1
         if tiles * 2 <= 384 and not (dtypes & 4):

@@ -13,8 +13,12 @@ B, T, P, math = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5
 out = {"workload": [B, T, P, math], "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on "
        "`bench.py --no-graph --steps 2 --warmup 2`; FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request), units of 1000 B", "kernels": {}}
 for mangled, c in raw.items():
+    w8 = re.search(r"gemm16_kernel_w8ILb(\d)ELb(\d)ELi(\d+)E", mangled)
     m = re.search(r"gemm16_(group_)?kernelILb(\d)ELb(\d)ELi(\d+)ELi(\d+)ELi(\d+)E(?:Li(\d+)E)?", mangled)
-    if m:
+    if w8:
+        b = lambda v: "true" if v == "1" else "false"
+        name = f"gemm16_kernel_w8<{b(w8.group(1))},{b(w8.group(2))},{w8.group(3)}>"
+    elif m:
         b = lambda v: "true" if v == "1" else "false"
         epi = f",{m.group(7)}" if m.group(7) not in (None, "0") else ""       # epilogue variant (0 = plain) as bench.py names it
         name = f"gemm16_{m.group(1) or ''}kernel<{b(m.group(2))},{b(m.group(3))},{m.group(4)},{m.group(5)},{m.group(6)}{epi}>"
