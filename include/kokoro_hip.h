@@ -257,6 +257,54 @@ int kk_dropout_bwd(const float *dy, float *dx, int64_t rows, int H, int S, const
 int kk_specaug(float *x, int B, int T, int H, const uint32_t *seed, uint32_t site, int time_mask_max,
                int feat_mask_max, int n_time, int n_feat, int x_bf16, void *stream);
 
+/* ---- the whole text-encoder forward as one persistent launch (model/model.py:375-388: the stack of FFT blocks,
+ * transformers.py:452-490 = pre-LN self-attention with per-head RMSNorm + RoPE :260-277,393-398 and the GLU feed-forward
+ * :86-112, each followed by dropout / DropPath / residual :482-487) ----
+ * Replaces, per layer, kk_gemm_qkv_headnorm + kk_attn_fwd + kk_gemm + kk_sublayer_out_fwd + kk_gemm_linear_glu + kk_gemm +
+ * kk_sublayer_out_fwd (bf16 storage) with the same outputs in the same buffers, so the per-kernel backward is unchanged.
+ * Work is partitioned by batch item: workgroups b, b+8, ... carry item b through all layers and meet at group barriers
+ * (csrc/kk_encstack.hip).  Limits: kk_encoder_stack_supported().  `sync` = 512 uint32 words, zero before the first call
+ * (the launch leaves them zero; word 0 != 0 afterwards means a barrier timed out and the outputs are invalid). */
+#define KK_ENC_MAX_LAYERS 8
+typedef struct KkEncLayer {
+    const void *w_qkv;                    /* [3H, H] bf16: w_q | w_k | w_v */
+    const float *g_q, *g_k, *g_v;         /* per-head RMSNorm gains [64] */
+    const void *w_o;  const float *b_o;   /* [H, H] bf16, [H] */
+    const float *ln2_g, *ln2_b;           /* LayerNorm in front of the feed-forward */
+    const void *w1;   const float *b1;    /* [2F, H] bf16, [2F] */
+    const void *w2;   const float *b2;    /* [H, F] bf16, [H] */
+    const float *ffn_gain;                /* RMSNorm(H) gain of the feed-forward output */
+    const float *next_g, *next_b;         /* the LayerNorm that follows the layer (next layer's norm1 / the stack's final norm) */
+    const void *y1;                       /* in: LayerNorm_1 output [N, H] bf16 (layer l > 0: layer l-1's next_y) */
+    void *qkv_raw, *qkv_n;                /* [N, 3H] bf16 */
+    void *ctx;  float *lse;               /* [N, H] bf16, [B, heads, S] */
+    float *proj;                          /* [N, H] fp32 scratch (one per layer) */
+    const float *x_in;                    /* residual stream in [N, H] fp32 */
+    float *xm;  void *y2;  float *mean2, *rstd2;          /* after attention: stream, LayerNorm_2 output (bf16) and statistics */
+    void *h1, *g, *f2;  float *rstd_f;    /* [N, 2F], [N, F], [N, H] bf16; 1/rms of f2 */
+    float *xo;  void *next_y;  float *next_mean, *next_rstd;   /* layer output stream, following LayerNorm output + statistics */
+    int next_y_bf16;                      /* storage of next_y (the stack's final norm is fp32) */
+    uint32_t site;                        /* dropout call-site base of the layer (attention: +0..3, feed-forward: +8..12) */
+    float p, dpr;                         /* dropout probability, stochastic-depth rate */
+} KkEncLayer;
+typedef struct KkEncStack {
+    int B, S, H, F, heads, layers;        /* N = B*S rows */
+    const uint8_t *key_mask;              /* [B, S], 1 = padded key (may be null) */
+    const float *cos_t, *sin_t;           /* RoPE tables [>= S, 64] */
+    const uint32_t *seed;                 /* step seed, read on the device */
+    uint32_t *sync;                       /* 512 words, see above */
+    int placement;                        /* 0: group = workgroup % 8 (the members of a group share an XCD under the observed
+                                             round-robin dispatch); 1: group = workgroup / members (a group spread over all XCDs) —
+                                             results are identical, 1 exists to test placement independence */
+    uint64_t *trace;                      /* optional (tools): workgroup `trace_wg` stamps the 100 MHz clock after every phase and
+                                             after every barrier: 2 * 7 * layers words per item */
+    int trace_wg;
+    KkEncLayer layer[KK_ENC_MAX_LAYERS];
+} KkEncStack;
+int kk_encoder_stack_supported(int B, int S, int H, int F, int heads, int layers);
+int kk_encoder_stack_workgroups(void);
+int kk_encoder_stack_fwd(const KkEncStack *desc /* host struct, read during the call */, void *stream);
+
 /* ---- losses (training/losses.py:9-216) ----
  * acc: 12 doubles (5 sums, 5 counts, the number of non-finite prediction elements, 1 spare) zeroed by the call.
  * losses: 6 floats (total, mel, dur, stop, pitch, energy).

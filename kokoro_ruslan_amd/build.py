@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libkokoro_hip.so")
-SOURCES = ["kk_core.hip", "kk_gemm.hip", "kk_gemm16.hip", "kk_attn.hip", "kk_norm.hip", "kk_elem.hip", "kk_loss.hip", "kk_optim.hip", "kk_dropout.hip", "kk_comm.hip"]
+SOURCES = ["kk_core.hip", "kk_gemm.hip", "kk_gemm16.hip", "kk_attn.hip", "kk_norm.hip", "kk_elem.hip", "kk_loss.hip", "kk_optim.hip", "kk_dropout.hip", "kk_comm.hip", "kk_encstack.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
 
 

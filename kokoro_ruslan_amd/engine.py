@@ -197,6 +197,13 @@ class KokoroEngine:
         self.fuse_headnorm = os.environ.get("KK_FUSE_HEADNORM", "1") != "0"
         self.fuse_headnorm_bwd = os.environ.get("KK_FUSE_HEADNORM_BWD", "1") != "0"
         self._wgrad_queue = {}
+        # Text-encoder forward as one persistent launch (kk_encoder_stack_fwd): bf16 mode, phoneme sequences <= 128;
+        # otherwise (and with KK_ENC_FUSED=0) the per-kernel sequence.  _enc_sync: its group-barrier words (word 0 != 0
+        # = a barrier timed out; encoder_stack_error() reads it).
+        self.enc_fused = os.environ.get("KK_ENC_FUSED", "1") != "0"
+        self.enc_placement = int(os.environ.get("KK_ENC_PLACEMENT", "0"))
+        self._enc_sync = torch.zeros(512, dtype=torch.int32, device=self.device)
+        self.enc_trace, self.enc_trace_wg = None, 0      # tools/probes/enc_stack_phases.py: per-phase clock stamps of one workgroup
         self.spec_augment_active = True             # the trainer clears it for epochs < spec_augment_start_epoch
         # KK_TRACE=1: one-thread time-stamp launches at the marks of a step (also inside the captured graphs), read back by
         # timeline() — the real overlap of the graph's branches, which rocprofv3 cannot show (it serialises them)
@@ -744,6 +751,50 @@ class KokoroEngine:
         self._wgrad(dq_raw, xq, G[prefix + ".w_q.weight"])
         self._dgrad(dq_raw, self._W(prefix + ".w_q.weight"), d_xq)
 
+    # ------------------------------------------------------------------ text encoder: all layers in one launch
+    def _encoder_stack_ok(self, B: int, Pn: int) -> bool:
+        d = self.dims
+        return bool(self.enc_fused and self.enc_dt == torch.bfloat16 and self.use_shadow and self.math == kk.KK_MATH_BF16 and
+                    kk.load().kk_encoder_stack_supported(B, Pn, d.hidden, d.enc_ff, d.heads, d.enc_layers))
+
+    def _encoder_stack_fwd(self, x0, B, Pn, text_mask, p_enc):
+        """Forward of every encoder layer by kk_encoder_stack_fwd: same buffers, same masks as the per-kernel sequence
+        (_attn_fwd / _ffn_fwd / _sublayer_tail), so the backward does not know the difference.  Returns (stream after the
+        last layer, encoder_norm output)."""
+        d, P, H, F, h, L = self.dims, self.arena.P, self.dims.hidden, self.dims.enc_ff, self.dims.heads, self.dims.enc_layers
+        Ne, edt = B * Pn, self.enc_dt
+        cos, sin = self._rope_tables(Pn)
+        layers = []
+        for i in range(L):
+            pf, key = f"transformer_encoder_layers.{i}", f"enc{i}"
+            nkey, npf, ndt = ((f"enc{i + 1}.ln1", f"transformer_encoder_layers.{i + 1}.norm1", edt) if i + 1 < L
+                              else ("enc.norm", "encoder_norm", torch.float32))
+            sa, ff = key + ".sa", key + ".ff"
+            layers.append(dict(
+                w_qkv=self._Wf(pf + ".self_attn.w_q.weight", 3), g_q=P[pf + ".self_attn.q_norm.weight"],
+                g_k=P[pf + ".self_attn.k_norm.weight"], g_v=P[pf + ".self_attn.v_norm.weight"],
+                w_o=self._W(pf + ".self_attn.w_o.weight"), b_o=P[pf + ".self_attn.w_o.bias"],
+                ln2_g=P[pf + ".norm2.weight"], ln2_b=P[pf + ".norm2.bias"],
+                w1=self._W(pf + ".ff.linear1.weight"), b1=P[pf + ".ff.linear1.bias"],
+                w2=self._W(pf + ".ff.linear2.weight"), b2=P[pf + ".ff.linear2.bias"], ffn_gain=P[pf + ".ff.output_norm.weight"],
+                next_g=P[npf + ".weight"], next_b=P[npf + ".bias"],
+                y1=self._buf(key + ".ln1.y", Ne, H, dtype=edt),
+                qkv_raw=self._buf(sa + ".qkv_raw", Ne, 3 * H, dtype=edt), qkv_n=self._buf(sa + ".qkv_n", Ne, 3 * H, dtype=edt),
+                ctx=self._buf(sa + ".ctx", Ne, H, dtype=edt), lse=self._buf(sa + ".lse", B, h, Pn),
+                proj=self._buf(sa + ".proj", Ne, H),
+                x_in=x0 if i == 0 else self._buf(f"enc{i - 1}.xo", Ne, H), xm=self._buf(key + ".xm", Ne, H),
+                y2=self._buf(key + ".ln2.y", Ne, H, dtype=edt), mean2=self._buf(key + ".ln2.mean", Ne), rstd2=self._buf(key + ".ln2.rstd", Ne),
+                h1=self._buf(ff + ".h1", Ne, 2 * F, dtype=edt), g=self._buf(ff + ".g", Ne, F, dtype=edt),
+                f2=self._buf(ff + ".f2", Ne, H, dtype=edt), rstd_f=self._buf(ff + ".rstd_f", Ne),
+                xo=self._buf(key + ".xo", Ne, H), next_y=self._buf(nkey + ".y", Ne, H, dtype=ndt),
+                next_mean=self._buf(nkey + ".mean", Ne), next_rstd=self._buf(nkey + ".rstd", Ne),
+                next_y_bf16=1 if ndt == torch.bfloat16 else 0, site=1000 + 32 * i, p=float(p_enc), dpr=float(self._dpr(i, L))))
+        sig = ("encstack", B, Pn, float(p_enc), self.train_dropout, self.enc_placement) + tuple(v.data_ptr() for v in layers[0].values() if hasattr(v, "data_ptr"))
+        desc = self._table(sig, lambda: kk.enc_stack(B, Pn, H, F, h, text_mask, cos, sin, self.rng, self._enc_sync, layers, self.enc_placement,
+                                                     self.enc_trace, self.enc_trace_wg))
+        kk.call("kk_encoder_stack_fwd", desc)
+        return self._buf(f"enc{L - 1}.xo", Ne, H), self._buf("enc.norm.y", Ne, H)
+
     # ------------------------------------------------------------------ GLU feed-forward sub-layer
     def _ffn_fwd(self, key, prefix, y, x_res, x_out, Fd, S=1, site=0, p=0.0, dpr=0.0, next_ln=None):
         P = self.arena.P
@@ -946,7 +997,12 @@ class KokoroEngine:
         kk.call("kk_embed_fwd", ids, stress, P["text_embedding.weight"], P["stress_embedding.weight"] if stress is not None else None,
                 pe, x, B, Pn, H, float(H ** 0.5), self.rng, 1, pe_drop)
         y1 = None                                         # LayerNorm outputs come from the previous sub-layer's fused tail
-        for i in range(d.enc_layers):                     # when dropout is on, from _ln_fwd otherwise
+        stack = self._encoder_stack_ok(B, Pn)
+        if stack:                                         # all layers in ONE persistent launch (csrc/kk_encstack.hip)
+            y1 = self._ln_fwd("enc0.ln1", x, "transformer_encoder_layers.0.norm1", edt)
+            x, y1 = self._encoder_stack_fwd(x, B, Pn, text_mask, p_enc)
+            self._mark(f"enc{d.enc_layers - 1} fwd done")
+        for i in range(0 if not stack else d.enc_layers, d.enc_layers):      # when dropout is on, from _ln_fwd otherwise
             pf, key, st = f"transformer_encoder_layers.{i}", f"enc{i}", 1000 + 32 * i
             dpr = self._dpr(i, d.enc_layers)
             if y1 is None:
@@ -1619,6 +1675,10 @@ class KokoroEngine:
             opt.replay()
             self.micro_in_cycle = 0
         return self.losses
+
+    def encoder_stack_error(self) -> int:
+        """Non-zero when a group barrier of kk_encoder_stack_fwd has ever timed out (host read: synchronises)."""
+        return int(self._enc_sync[0].item())
 
     def opt_stats(self) -> Dict[str, float]:
         """Host read-back of the device optimizer state (synchronises; for logging/tests only)."""

@@ -76,6 +76,37 @@ def wgrad_table(entries):
     return arr
 
 
+KK_ENC_MAX_LAYERS = 8
+
+
+class KkEncLayer(C.Structure):
+    _fields_ = ([(n, C.c_void_p) for n in (
+        "w_qkv", "g_q", "g_k", "g_v", "w_o", "b_o", "ln2_g", "ln2_b", "w1", "b1", "w2", "b2", "ffn_gain", "next_g", "next_b", "y1",
+        "qkv_raw", "qkv_n", "ctx", "lse", "proj", "x_in", "xm", "y2", "mean2", "rstd2", "h1", "g", "f2", "rstd_f", "xo", "next_y",
+        "next_mean", "next_rstd")] + [("next_y_bf16", C.c_int), ("site", C.c_uint32), ("p", C.c_float), ("dpr", C.c_float)])
+
+
+class KkEncStack(C.Structure):
+    _fields_ = [("B", C.c_int), ("S", C.c_int), ("H", C.c_int), ("F", C.c_int), ("heads", C.c_int), ("layers", C.c_int),
+                ("key_mask", C.c_void_p), ("cos_t", C.c_void_p), ("sin_t", C.c_void_p), ("seed", C.c_void_p), ("sync", C.c_void_p),
+                ("placement", C.c_int), ("trace", C.c_void_p), ("trace_wg", C.c_int),
+                ("layer", KkEncLayer * KK_ENC_MAX_LAYERS)]
+
+
+def enc_stack(B, S, H, F, heads, key_mask, cos, sin, seed, sync, layers, placement=0, trace=None, trace_wg=0) -> KkEncStack:
+    """Host KkEncStack from per-layer dicts {field: tensor | int | float} (see include/kokoro_hip.h)."""
+    d = KkEncStack()
+    d.B, d.S, d.H, d.F, d.heads, d.layers, d.placement = B, S, H, F, heads, len(layers), placement
+    d.key_mask = key_mask.data_ptr() if key_mask is not None else None
+    d.cos_t, d.sin_t, d.sync = cos.data_ptr(), sin.data_ptr(), sync.data_ptr()
+    d.seed = seed.data_ptr() if seed is not None else None
+    d.trace, d.trace_wg = (trace.data_ptr() if trace is not None else None), trace_wg
+    for L, src in zip(d.layer, layers):
+        for name, v in src.items():
+            setattr(L, name, v.data_ptr() if hasattr(v, "data_ptr") else v)
+    return d
+
+
 def pointer_table(tensors):
     """Host array of device pointers (for the C entry points that take `const float *const *`)."""
     return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
@@ -144,6 +175,9 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_sublayer_out_fwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _I, _I, _P, _U, _F, _U, _F, _U, _F, _P],
     "kk_sublayer_in_bwd": [_P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _L, _I, _I, _P, _U, _F, _U, _F, _U, _F, _P],
     "kk_sublayer_in_bwd_blocks": [_L],
+    "kk_encoder_stack_supported": [_I, _I, _I, _I, _I, _I],
+    "kk_encoder_stack_workgroups": [],
+    "kk_encoder_stack_fwd": [C.POINTER(KkEncStack), _P],
     "kk_dropout_bwd": [_P, _P, _L, _I, _I, _P, _U, _F, _U, _F, _U, _F, _I, _P],
     "kk_specaug": [_P, _I, _I, _I, _P, _U, _I, _I, _I, _I, _I, _P],
     "kk_ids_eq_zero": [_P, _P, _L, _P],
