@@ -169,6 +169,26 @@ __device__ __forceinline__ float4 kk_headnorm_rope(const float4 &v, const float4
     return n;
 }
 
+// GELU and its derivative for the bf16 mode (results are rounded to bf16 anyway): erf by Abramowitz-Stegun 7.1.26
+// (|error| <= 1.5e-7), whose exp(-z^2) with z = |x| / sqrt(2) IS the Gaussian exp(-x^2 / 2) the derivative needs — one
+// v_exp_f32, one v_rcp_f32 and ~15 other VALU operations for both values, against ~130 for erff() + expf().  In the GLU
+// epilogues of the GEMMs that arithmetic was a third of the kernel (the backward one: 2081 VALU instructions per wave
+// after the last MFMA).  The fp32 parity mode keeps the exact forms below.
+__device__ __forceinline__ void kk_gelu_pair_fast(float x, float &g, float &dg) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
+    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);           // exp(-x^2 / 2)
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float q = 0.5f * poly * e;                         // 0.5 erfc(|x| / sqrt 2)
+    const float phi = x >= 0.f ? 1.f - q : q;                // Phi(x)
+    g = x * phi;
+    dg = fmaf(x * e, 0.39894228040143267794f, phi);
+}
+__device__ __forceinline__ float kk_gelu_fast(float x) {
+    float g, dg;
+    kk_gelu_pair_fast(x, g, dg);
+    return g;
+}
 // exact-erf GELU (nn.GELU(), transformers.py:51) and its derivative
 __device__ __forceinline__ float kk_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float kk_gelu_grad(float x) {

@@ -10,8 +10,16 @@
 
 namespace {
 
-__device__ __forceinline__ float gelu_f(float x) { return kk_gelu(x); }
-__device__ __forceinline__ float gelu_grad_f(float x) { return kk_gelu_grad(x); }
+// fp32 storage = the parity mode: exact erf.  bf16 storage: the fast pair of kk_common.h (the same function the GEMM
+// epilogues use, so the fused and the unfused GLU give the same bits).
+template <typename T> __device__ __forceinline__ void gelu_pair(float x, float &g, float &dg) {
+    if constexpr (sizeof(T) == 2) kk_gelu_pair_fast(x, g, dg);
+    else { g = kk_gelu(x); dg = kk_gelu_grad(x); }
+}
+template <typename T> __device__ __forceinline__ float gelu_f(float x) {
+    if constexpr (sizeof(T) == 2) return kk_gelu_fast(x);
+    else return kk_gelu(x);
+}
 
 // ------------------------------------------------------------------ GLU
 // Dropout on the gated product (transformers.py:108) is fused: mask = f(seed, site, row*F + col).
@@ -33,7 +41,7 @@ __global__ __launch_bounds__(256) void glu_fwd_kernel(const T *__restrict__ h, T
         const int c = (int)(i - row * F4) * 4;
         const float4 a = ldv4<T>(h + row * 2 * F + c), b = ldv4<T>(h + row * 2 * F + F + c);
         const float4 m = drop4(d, seed, thr, ik, (uint64_t)row * F + c);
-        stv4<T>(g + row * F + c, make_float4(gelu_f(a.x) * b.x * m.x, gelu_f(a.y) * b.y * m.y, gelu_f(a.z) * b.z * m.z, gelu_f(a.w) * b.w * m.w));
+        stv4<T>(g + row * F + c, make_float4(gelu_f<T>(a.x) * b.x * m.x, gelu_f<T>(a.y) * b.y * m.y, gelu_f<T>(a.z) * b.z * m.z, gelu_f<T>(a.w) * b.w * m.w));
     }
 }
 
@@ -50,9 +58,10 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const T *__restrict__ dg, 
         float4 d = ldv4<T>(dg + row * F + c);
         const float4 m = drop4(dr, seed, thr, ik, (uint64_t)row * F + c);
         d.x *= m.x; d.y *= m.y; d.z *= m.z; d.w *= m.w;
-        stv4<T>(dh + row * 2 * F + c, make_float4(d.x * b.x * gelu_grad_f(a.x), d.y * b.y * gelu_grad_f(a.y),
-                                              d.z * b.z * gelu_grad_f(a.z), d.w * b.w * gelu_grad_f(a.w)));
-        stv4<T>(dh + row * 2 * F + F + c, make_float4(d.x * gelu_f(a.x), d.y * gelu_f(a.y), d.z * gelu_f(a.z), d.w * gelu_f(a.w)));
+        float gx, gy, gz, gw, dx, dy, dz, dw;
+        gelu_pair<T>(a.x, gx, dx); gelu_pair<T>(a.y, gy, dy); gelu_pair<T>(a.z, gz, dz); gelu_pair<T>(a.w, gw, dw);
+        stv4<T>(dh + row * 2 * F + c, make_float4(d.x * b.x * dx, d.y * b.y * dy, d.z * b.z * dz, d.w * b.w * dw));
+        stv4<T>(dh + row * 2 * F + F + c, make_float4(d.x * gx, d.y * gy, d.z * gz, d.w * gw));
     }
 }
 

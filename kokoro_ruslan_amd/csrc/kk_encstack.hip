@@ -525,8 +525,8 @@ __device__ __forceinline__ void phase_lin1(const Ctx &c, const KkEncLayer &L, in
                     float mk4[4];
                     kk_drop_mul4(c.seed, L.site + 12, (uint64_t)row * F + col, thr, ik, mk4);
                     st8(G, (uint32_t)((row * F + col) * 2),
-                        pack4(make_float4(kk_gelu(ar.x) * br.x * mk4[0], kk_gelu(ar.y) * br.y * mk4[1], kk_gelu(ar.z) * br.z * mk4[2],
-                                          kk_gelu(ar.w) * br.w * mk4[3])));
+                        pack4(make_float4(kk_gelu_fast(ar.x) * br.x * mk4[0], kk_gelu_fast(ar.y) * br.y * mk4[1], kk_gelu_fast(ar.z) * br.z * mk4[2],
+                                          kk_gelu_fast(ar.w) * br.w * mk4[3])));
                 }
             }
         }

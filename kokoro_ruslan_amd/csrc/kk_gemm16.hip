@@ -295,7 +295,9 @@ __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char
                 const int64_t o = (int64_t)row * 2 * F + col;
                 const float av = (float)a.glu_h[o], bv = (float)a.glu_h[o + F];
                 const float d = acc[0][0][r] * kk_drop_mul(seed, a.glu_site, (uint64_t)row * F + col, thr, ik);
-                const float da = d * bv * kk_gelu_grad(av), db = d * kk_gelu(av);
+                float gv, gd;
+                kk_gelu_pair_fast(av, gv, gd);
+                const float da = d * bv * gd, db = d * gv;
                 a.glu_dh[o] = (__bf16)da;
                 a.glu_dh[o + F] = (__bf16)db;
                 sa += da;
@@ -358,7 +360,7 @@ __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char
             h[o] = av;
             h[o + F] = bv;
             g[(int64_t)row * a.ldc + col] =
-                (__bf16)(kk_gelu((float)av) * (float)bv * kk_drop_mul(seed, a.glu_site, (uint64_t)row * F + col, thr, ik));
+                (__bf16)(kk_gelu_fast((float)av) * (float)bv * kk_drop_mul(seed, a.glu_site, (uint64_t)row * F + col, thr, ik));
         }
         return;
     }

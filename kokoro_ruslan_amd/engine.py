@@ -201,6 +201,7 @@ class KokoroEngine:
         # otherwise (and with KK_ENC_FUSED=0) the per-kernel sequence.  _enc_sync: its group-barrier words (word 0 != 0
         # = a barrier timed out; encoder_stack_error() reads it).
         self.enc_fused = os.environ.get("KK_ENC_FUSED", "1") != "0"
+        self.zero_late = os.environ.get("KK_ZERO_LATE", "1") != "0"      # gradient zero-fill after the decoder head's first launches
         self.enc_placement = int(os.environ.get("KK_ENC_PLACEMENT", "0"))
         self._enc_sync = torch.zeros(512, dtype=torch.int32, device=self.device)
         self.enc_trace, self.enc_trace_wg = None, 0      # tools/probes/enc_stack_phases.py: per-phase clock stamps of one workgroup
@@ -971,7 +972,15 @@ class KokoroEngine:
                 kk.call("kk_dropout_fwd", t1, None, 0, y0, Nd, H, T, self.rng, 31, pe_drop, 0, 0.0, 0, 0.0)
             else:
                 self._linear(shifted, self._W("mel_projection_in.weight"), P["mel_projection_in.bias"], y0, res=pe, res_mod=T)
-            ya0, n20 = self_attn(0, y0, self._ln_fwd("dec0.ln1", y0, "decoder.layers.0.norm1", ddt))
+            n10 = self._ln_fwd("dec0.ln1", y0, "decoder.layers.0.norm1", ddt)
+            # The 200 MB gradient zero-fill goes HERE: the launches above are in flight before the persistent encoder
+            # kernel (which takes every CU's LDS) starts; the fill needs no LDS and runs beside it, while the GEMMs and
+            # the attention below cannot and follow the encoder — with the fill in front of the whole head, none of the
+            # head ran early and it ended 46 us after the cross-attention K/V GEMM, on the critical path.
+            if zero_grads and self.zero_late:
+                self.zero_grad()
+            self._mark("kv: zero_grad done")
+            ya0, n20 = self_attn(0, y0, n10)
             return y0, ya0, n20
 
         # ---- encoder (model.py:375-388) ----
@@ -987,10 +996,9 @@ class KokoroEngine:
         if seg and self.dec_head_aside:
             yield ("begin", "kv")
         with self._on_stream(self._kv, "kv.", self.dec_head_aside):     # beside the encoder; joined before the first cross-attention
-            if zero_grads:                                # the 200 MB gradient memset also hides behind the encoder forward
+            if zero_grads and not self.zero_late:
                 self.zero_grad()
-            self._mark("kv: zero_grad done")
-            dec_head = decoder_head()
+            dec_head = decoder_head()                     # (includes the gradient zero-fill, see there)
             self._mark("kv: decoder head done")
         if seg and self.dec_head_aside:
             yield ("end", "kv")

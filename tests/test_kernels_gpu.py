@@ -785,11 +785,18 @@ def test_elementwise_bf16_storage(kk):
         g32, g16 = torch.empty(rows, Fd, device="cuda"), torch.empty(rows, Fd, device="cuda", dtype=torch.bfloat16)
         kk.call("kk_glu_fwd", hh, g32, rows, Fd, seed, 5, p, 0)
         kk.call("kk_glu_fwd", hh.bfloat16(), g16, rows, Fd, seed, 5, p, 1)
-        assert torch.equal(g16, g32.bfloat16()), "glu fwd: bf16 storage = rounded fp32 result"
+        # bf16 storage evaluates GELU by kk_gelu_pair_fast (|error| < 5e-7 before the rounding to bf16), fp32 storage by the
+        # exact erf: the rounded results differ in a last bit now and then, and the dropout masks are identical
+        def same(a16, a32, what):
+            ref = a32.bfloat16()
+            assert float((a16 == ref).float().mean()) > 0.995, what
+            assert torch.equal(a16 == 0, ref == 0) or p == 0.0, what + ": mask"
+            assert float((a16.float() - a32).abs().max()) <= 2 ** -8 * float(a32.abs().max()) + 1e-6, what
+        same(g16, g32, "glu fwd: bf16 storage = rounded fp32 result")
         d32, d16 = torch.empty(rows, 2 * Fd, device="cuda"), torch.empty(rows, 2 * Fd, device="cuda", dtype=torch.bfloat16)
         kk.call("kk_glu_bwd", dg, hh, d32, rows, Fd, seed, 5, p, 0)
         kk.call("kk_glu_bwd", dg.bfloat16(), hh.bfloat16(), d16, rows, Fd, seed, 5, p, 1)
-        assert torch.equal(d16, d32.bfloat16())
+        same(d16, d32, "glu bwd")
     # im2col3 (fp32 in, bf16 columns) and its transpose (bf16 columns in, fp32 out)
     B, L, C = 2, 600, 64
     x = dev(torch.randn(B * L, C, generator=g))
