@@ -19,6 +19,7 @@
 // KK_MATH_BF16 rounds Q/K/V/P/dS/dO to bf16 for the MFMAs and keeps scores, softmax and accumulators in fp32.
 #include "kk_common.h"
 #include <math.h>
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -533,21 +534,27 @@ __global__ __launch_bounds__(256 * G) void attn_fwd_kernel(AttnArgs a) {
         tile_step(ra, kk0);
         if (kk0 + STEP < kend) tile_step(rb, kk0 + STEP);
     }
-    if constexpr (G == 2) {          // merge the two key groups' partial softmaxes: group 1 -> LDS -> group 0
-        float *mb = reinterpret_cast<float *>(smem_raw) + (wave * 64 + lane) * 34;      // (the loop's last barrier is behind us)
-        if (grp == 1) {
+    if constexpr (G >= 2) {          // merge the key groups' partial softmaxes: groups 1 .. G-1 -> LDS -> group 0
+        float *mb0 = reinterpret_cast<float *>(smem_raw) + (wave * 64 + lane) * 34;     // (the loop's last barrier is behind us)
+        constexpr int GSTRIDE = 4 * 64 * 34;                                             // floats per group
+        if (grp >= 1) {
+            float *mb = mb0 + (grp - 1) * GSTRIDE;
             mb[0] = m; mb[1] = l;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { mb[2 + r] = o[0][r]; mb[18 + r] = o[1][r]; }
         }
         __syncthreads();
-        if (grp == 1) return;
-        const float m1 = mb[0], l1 = mb[1], mn = fmaxf(m, m1);
-        const float a0 = __builtin_amdgcn_exp2f(m - mn), a1 = __builtin_amdgcn_exp2f(m1 - mn);
-        l = l * a0 + l1 * a1;
-        m = mn;
+        if (grp >= 1) return;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { o[0][r] = o[0][r] * a0 + mb[2 + r] * a1; o[1][r] = o[1][r] * a0 + mb[18 + r] * a1; }
+        for (int g = 1; g < G; ++g) {
+            const float *mb = mb0 + (g - 1) * GSTRIDE;
+            const float m1 = mb[0], l1 = mb[1], mn = fmaxf(m, m1);
+            const float a0 = __builtin_amdgcn_exp2f(m - mn), a1 = __builtin_amdgcn_exp2f(m1 - mn);
+            l = l * a0 + l1 * a1;
+            m = mn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o[0][r] = o[0][r] * a0 + mb[2 + r] * a1; o[1][r] = o[1][r] * a0 + mb[18 + r] * a1; }
+        }
     }
     if (qvalid) {
         const float inv = l > 0.f ? pd.inv_keep / l : 0.f;
@@ -967,6 +974,15 @@ extern "C" int kk_attn_fwd(const float *Q, const float *K, const float *V, float
     a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop;
     dim3 grid(kk_cdiv(Sq, 128), B * heads);
     const int G = (Sk > 64 && g_attn_groups == 2) ? 2 : 1;          // one key tile: nothing to split
+    // Four key groups (16 waves): the longest chain of key-tile steps of a 128-query block halves again — a causal block
+    // near the end of the sequence sets the launch's duration, and at S = 512 the kernel is a chain of 4 dependent steps
+    static const int fwd_groups4 = getenv("KK_ATTN_FWD_G4") ? atoi(getenv("KK_ATTN_FWD_G4")) : 0;
+    if (io_bf16 && fwd_groups4 && G == 2 && Sk >= 256) {
+        int rc4 = launch_attn(attn_fwd_kernel<true, true, 4>, grid, 4, KK_ATTN_LDS(true, 4, 2, 0), (hipStream_t)stream, a);
+        if (rc4) return rc4;
+        KK_LAUNCH_CHECK("kk_attn_fwd");
+        return 0;
+    }
     if (io_bf16) KK_ATTN_LAUNCH(attn_fwd_kernel, true, true, G, 2);
     else if (math == KK_MATH_BF16) KK_ATTN_LAUNCH(attn_fwd_kernel, true, false, G, 2);
     else KK_ATTN_LAUNCH(attn_fwd_kernel, false, false, G, 2);

@@ -60,26 +60,30 @@ __device__ __forceinline__ float4 unpack4(u32x2 u) {
 // The counters are zero between launches: the last member to leave a launch resets them (every member has passed every
 // barrier by then), so a replayed hipGraph needs no memset node in front of the launch.
 struct GroupSync {
-    unsigned *arrive, *leave, *err;
+    unsigned *arrive_ctr, *leave, *err;
     unsigned target, members;
     bool dead;
     __device__ __forceinline__ void init(unsigned *words, int group, int nmembers) {
         err = words;
-        arrive = words + 32 + 32 * group;
-        leave = arrive + 16;
+        arrive_ctr = words + 32 + 32 * group;
+        leave = arrive_ctr + 16;
         target = 0;
         members = (unsigned)nmembers;
         dead = false;
     }
-    // every store of this workgroup issued before the call is visible to every member after it
-    __device__ __forceinline__ void barrier() {
+    // Split barrier: arrive() publishes this workgroup's stores (every store issued before it is visible to every member
+    // after its wait()); between the two a member does work that depends on nobody — it starts the DMA of the weights of
+    // its next GEMM phase there, so that the issue time of up to 96 KB hides behind the arrival of the slowest member.
+    __device__ __forceinline__ void arrive() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // each wave: its write-through stores have been acknowledged
         __syncthreads();
         target += members;
+        if (threadIdx.x == 0 && !dead) __hip_atomic_fetch_add(arrive_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ __forceinline__ void wait() {
         if (threadIdx.x == 0 && !dead) {
-            __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             unsigned spins = 0;
-            while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            while (__hip_atomic_load(arrive_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > (1u << 22)) {                        // seconds: a member is not resident / died — give up loudly
                     __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -94,11 +98,12 @@ struct GroupSync {
         }
         __syncthreads();
     }
+    __device__ __forceinline__ void barrier() { arrive(); wait(); }
     __device__ __forceinline__ void exit() {
         if (threadIdx.x == 0) {
             const unsigned old = __hip_atomic_fetch_add(leave, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (old == members - 1u) {
-                __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(arrive_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(leave, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
@@ -113,9 +118,9 @@ struct GroupSync {
 // fragments straight from global memory, one row per lane: 64 distinct lines per load instruction, L1-bypassing for
 // X — request-rate bound, 12-15 us per phase where the bytes need 1-2.)  The 16-byte chunk c of LDS row r holds the
 // operand's chunk c ^ (r & 15): the fragment reads (ds_read_b128, 16 rows x the same k) are bank-conflict free.
-// WEIGHTS DO NOT DEPEND ON THE PREVIOUS PHASE: a member starts the DMA of its next GEMM phase's weight rows as soon as
-// the MFMAs of the current one are done, so they land under the epilogue, the group barrier and whatever non-GEMM
-// phase lies in between; after a barrier only X is waited for.
+// WEIGHTS DO NOT DEPEND ON THE PREVIOUS PHASE: a member starts the DMA of its next GEMM phase's weight rows inside the
+// group barrier that ends the current one (between arriving and waiting), so that they land under the barrier and
+// whatever non-GEMM phase lies in between; after a barrier only X is waited for.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
 constexpr int XS_BYTES = 65536;              // X panel: 64 rows x K = 512 (or 32 rows x K = 1536 reaching into WS)
@@ -242,7 +247,7 @@ __device__ __forceinline__ void prefetch_weights(const Ctx &c, const KkEncLayer 
 }
 
 template <int HT, int FT>
-__device__ __forceinline__ void phase_qkv(const Ctx &c, const KkEncLayer &L, int next_layer, int next_kind) {
+__device__ __forceinline__ void phase_qkv(const Ctx &c, const KkEncLayer &L) {
     const int H = HT ? HT : c.H, S = c.S, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool active = c.member < 3 * c.heads;
     const rsrc_t RAW = mk(L.qkv_raw), NRM = mk(L.qkv_n);
@@ -259,7 +264,6 @@ __device__ __forceinline__ void phase_qkv(const Ctx &c, const KkEncLayer &L, int
         if (work) wave_mma<4, HT, 0, HT / 32>(acc, c.smem, wave * 16, c.ws(), 0, 4, H, 0, H / 32);
         __syncthreads();                                           // X panel (and, after the last pass, the weights) are free
         c.substamp();
-        if (r0 + 64 >= S && next_layer >= 0) prefetch_weights<HT, FT>(c, c.a->layer[next_layer], next_kind);
         if (work) {
             float *tile = c.tile();
             acc_to_tile<4>(tile, acc, 4);
@@ -450,7 +454,7 @@ __device__ __forceinline__ void phase_attn(const Ctx &c, const KkEncLayer &L) {
 
 // ---- phase 3: output projection (+ bias) -> fp32 ------------------------------------------------------------------------
 template <int HT, int FT>
-__device__ __forceinline__ void phase_wo(const Ctx &c, const KkEncLayer &L, int next_layer, int next_kind) {
+__device__ __forceinline__ void phase_wo(const Ctx &c, const KkEncLayer &L) {
     const int H = HT ? HT : c.H, S = c.S, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool active = c.member < H / 16;
     const rsrc_t Y = mk(L.proj);
@@ -464,7 +468,6 @@ __device__ __forceinline__ void phase_wo(const Ctx &c, const KkEncLayer &L, int 
         if (work) wave_mma<1, HT, 0, HT / 32>(acc, c.smem, wave * 16, c.ws(), 0, 1, H, 0, H / 32);
         __syncthreads();
         c.substamp();
-        if (r0 + 64 >= S && next_layer >= 0) prefetch_weights<HT, FT>(c, c.a->layer[next_layer], next_kind);
         if (work) {
             float *tile = c.tile();
             acc_to_tile<1>(tile, acc, 1);
@@ -482,7 +485,7 @@ __device__ __forceinline__ void phase_wo(const Ctx &c, const KkEncLayer &L, int 
 
 // ---- phase 5: linear1 + GLU gate (+ dropout): h1 = [a | b] saved, g = gelu(a) * b * mask -----------------------------
 template <int HT, int FT>
-__device__ __forceinline__ void phase_lin1(const Ctx &c, const KkEncLayer &L, int next_layer, int next_kind) {
+__device__ __forceinline__ void phase_lin1(const Ctx &c, const KkEncLayer &L) {
     const int H = HT ? HT : c.H, S = c.S, F = FT ? FT : c.F, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int first;
     const int cnt = lin1_blocks(c, first);                        // <= 3 blocks of 16 gate columns: a-rows then b-rows in LDS
@@ -505,7 +508,6 @@ __device__ __forceinline__ void phase_lin1(const Ctx &c, const KkEncLayer &L, in
         }
         __syncthreads();
         c.substamp();
-        if (r0 + 64 >= S && next_layer >= 0) prefetch_weights<HT, FT>(c, c.a->layer[next_layer], next_kind);
         if (work) {
             float *tile = c.tile();
             acc_to_tile<6>(tile, acc, 2 * cnt);
@@ -538,7 +540,7 @@ __device__ __forceinline__ void phase_lin1(const Ctx &c, const KkEncLayer &L, in
 // K = F does not fit beside its weights as a 64-row panel: 32-row passes (96 KB at F = 1536), the four waves = 2 row blocks x
 // 2 halves of K, the halves summed through LDS.
 template <int HT, int FT>
-__device__ __forceinline__ void phase_lin2(const Ctx &c, const KkEncLayer &L, int next_layer, int next_kind) {
+__device__ __forceinline__ void phase_lin2(const Ctx &c, const KkEncLayer &L) {
     const int H = HT ? HT : c.H, S = c.S, F = FT ? FT : c.F, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool active = c.member < H / 16;
     const rsrc_t Y = mk(L.f2);
@@ -557,7 +559,6 @@ __device__ __forceinline__ void phase_lin2(const Ctx &c, const KkEncLayer &L, in
         }
         __syncthreads();
         c.substamp();
-        if (r0 + 32 >= S && next_layer >= 0) prefetch_weights<HT, FT>(c, c.a->layer[next_layer], next_kind);
         float *tile = c.tile();
         if (work) acc_to_tile<1>(tile, acc, 1);
         __syncthreads();
@@ -695,18 +696,21 @@ __global__ __launch_bounds__(NTHREADS) void enc_stack_fwd_kernel(const KkEncStac
             const KkEncLayer &L = a.layer[l];
             // whose q|k|v weights follow this layer's linear2: the next layer's, the next item's first layer's, or nobody's
             const int after = l + 1 < a.layers ? l + 1 : (b + 8 < a.B ? 0 : -1);
-            phase_qkv<HT, FT>(c, L, l, G_WO);
-            stamp(); sy.barrier(); stamp();
+            // (the weights of the next GEMM phase start moving inside the barrier that ends the current one)
+            phase_qkv<HT, FT>(c, L);
+            stamp(); sy.arrive(); prefetch_weights<HT, FT>(c, L, G_WO); sy.wait(); stamp();
             phase_attn(c, L);
             stamp(); sy.barrier(); stamp();
-            phase_wo<HT, FT>(c, L, l, G_LIN1);
-            stamp(); sy.barrier(); stamp();
+            phase_wo<HT, FT>(c, L);
+            stamp(); sy.arrive(); prefetch_weights<HT, FT>(c, L, G_LIN1); sy.wait(); stamp();
             phase_tail<false>(c, L);
             stamp(); sy.barrier(); stamp();
-            phase_lin1<HT, FT>(c, L, l, G_LIN2);
-            stamp(); sy.barrier(); stamp();
-            phase_lin2<HT, FT>(c, L, after, G_QKV);
-            stamp(); sy.barrier(); stamp();
+            phase_lin1<HT, FT>(c, L);
+            stamp(); sy.arrive(); prefetch_weights<HT, FT>(c, L, G_LIN2); sy.wait(); stamp();
+            phase_lin2<HT, FT>(c, L);
+            stamp(); sy.arrive();
+            if (after >= 0) prefetch_weights<HT, FT>(c, a.layer[after], G_QKV);
+            sy.wait(); stamp();
             phase_tail<true>(c, L);
             stamp(); sy.barrier(); stamp();
         }
