@@ -318,6 +318,14 @@ __device__ __forceinline__ void attn_head(const Ctx &c, const KkEncLayer &L, int
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
     const rsrc_t N = mk(L.qkv_n);
     const int64_t row_b = (int64_t)b * S;
+    // this wave's query fragments first: their round trip overlaps the staging of K and V below
+    const int q = wave * 32 + l31;
+    const bool qvalid = q < S;
+    const int qr = qvalid ? q : S - 1;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        qf[ks] = __builtin_bit_cast(bf16x8, ld16(N, (uint32_t)(((row_b + qr) * 3 * H + hh * 64 + ks * 16 + half * 8) * 2)));
     // K rows -> Ks[key][d], V rows -> Vt[d][key]; keys >= S are zero
     for (int p = threadIdx.x; p < NSUB * 32 * 4; p += NTHREADS) {
         const int key = p >> 2, seg = (p & 3) * 16;
@@ -349,13 +357,6 @@ __device__ __forceinline__ void attn_head(const Ctx &c, const KkEncLayer &L, int
     }
     __syncthreads();
     if (wave * 32 < S) {
-        const int q = wave * 32 + l31;
-        const bool qvalid = q < S;
-        const int qr = qvalid ? q : S - 1;
-        bf16x8 qf[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-            qf[ks] = __builtin_bit_cast(bf16x8, ld16(N, (uint32_t)(((row_b + qr) * 3 * H + hh * 64 + ks * 16 + half * 8) * 2)));
         const uint8_t *km = c.a->key_mask ? c.a->key_mask + (int64_t)b * S : nullptr;
         uint64_t kmb[(NSUB + 1) / 2];                               // bit j of word t: key 64 t + j is padding (wave-uniform)
 #pragma unroll

@@ -447,6 +447,7 @@ extern "C" int kk_gemm_dgrad_glu(int64_t T, int64_t F, int64_t H, const void *dy
                                  void *dh1, float *partials, const uint32_t *seed, uint32_t site, float p, void *stream) {
     KK_REQUIRE(T > 0 && F > 0 && H > 0 && dy && W && h1 && dh1 && partials, "kk_gemm_dgrad_glu: bad args");
     KK_REQUIRE(p >= 0.f && p < 1.f, "kk_gemm_dgrad_glu: dropout probability must be in [0,1)");
+    KK_REQUIRE(F % 8 == 0, "kk_gemm_dgrad_glu: F must be a multiple of 8 (16-byte epilogue accesses)");
     KK_REQUIRE(kk_gemm16_eligible(0, 1, T, F, H, dy, lddy, W, F), "kk_gemm_dgrad_glu: needs 16-byte aligned bf16 operands, H %% 64 == 0, F %% 8 == 0");
     return kk_gemm16_dgrad_glu(T, F, H, dy, lddy, W, h1, dh1, partials, seed, site, p, g_xcd_swizzle, (hipStream_t)stream);
 }
@@ -457,6 +458,7 @@ extern "C" int kk_gemm_linear_glu(int64_t T, int64_t F, int64_t K, const void *x
     KK_REQUIRE(T > 0 && F > 0 && K > 0 && x && W && h1 && g, "kk_gemm_linear_glu: bad args");
     KK_REQUIRE(p >= 0.f && p < 1.f, "kk_gemm_linear_glu: dropout probability must be in [0,1)");
     KK_REQUIRE(kk_gemm16_eligible(0, 0, T, 2 * F, K, x, ldx, W, K), "kk_gemm_linear_glu: needs 16-byte aligned bf16 operands and K %% 64 == 0");
+    KK_REQUIRE(F % 8 == 0 && ldg % 8 == 0, "kk_gemm_linear_glu: F and the row stride of g must be multiples of 8 (16-byte epilogue stores)");
     return kk_gemm16_linear_glu(T, F, K, x, ldx, W, bias, h1, g, ldg, seed, site, p, g_xcd_swizzle, (hipStream_t)stream);
 }
 

@@ -164,7 +164,8 @@ template <bool TA, bool TB, int BM, int BN, int NS, int EPI, int WAVES = 4, int 
 __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char *smem) {
     constexpr int WR = WAVES / WC;                              // waves along M x waves along N
     constexpr int MI = BM / (32 * WR), NI = BN / (32 * WC);     // 32x32 MFMA tiles per wave (wave tile = BM/WR x BN/WC)
-    static_assert(EPI == 0 || WAVES == 4, "the epilogue variants are written for four waves");
+    static_assert(EPI == 0 || WAVES == 4 || ((EPI == 1 || EPI == 2) && WAVES == 8 && BM == 128 && BN == 64),
+                  "the epilogue variants are written for four waves (the two GLU ones also for the eight-wave 128x64 tile)");
     using OA = Operand<BM, TA, 64 * WAVES>;
     using OB = Operand<BN, TB, 64 * WAVES>;
     constexpr int NB = EPI == 2 ? 2 : 1;                        // EPI == 2 multiplies A with TWO 64-row panels of B (see below)
@@ -281,35 +282,64 @@ __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char
     if (nk <= 0) return;
 
     if constexpr (EPI == 1) {
-        static_assert(EPI == 0 || (BM == 64 && BN == 64), "the GLU epilogue is written for the 64x64 tile");
+        static_assert(EPI == 0 || (BM / WR == 32 && BN / WC == 32), "the GLU epilogues expect one 32x32 MFMA tile per wave");
+        // The epilogue moves 8 bytes per output element (h1 = [a | b] in, dh1 out) — as much HBM traffic as the GEMM itself.
+        // In the accumulator layout a lane owns ONE column of 16 rows: 64 two-byte accesses per lane, 64-byte segments.  So
+        // the wave's 32x32 tile goes through LDS once and a lane works on 8 consecutive columns of 2 rows: 16-byte loads
+        // and stores, eight of them per lane.
         const int F = a.N;
         const uint32_t thr = a.glu_seed ? kk_drop_threshold(a.glu_p) : 0u, seed = thr ? *a.glu_seed : 0u;
         const float ik = thr ? 1.f / (1.f - a.glu_p) : 1.f;
-        const int col = n0 + wc * 32 + l31;
-        float sa = 0.f, sb = 0.f;
-        if (col < F) {
+        constexpr int TP = 36;                                  // floats per tile row (16-byte aligned rows)
+        __builtin_amdgcn_s_barrier();                           // every wave is done with the last stage
+        float *tile = reinterpret_cast<float *>(smem) + wave * 32 * TP;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wr * 32 + frag_row(r, half);
-                if (row >= a.M) continue;
+        for (int r = 0; r < 16; ++r) tile[frag_row(r, half) * TP + l31] = acc[0][0][r];
+        __builtin_amdgcn_wave_barrier();                        // (one wave: its LDS operations complete in order)
+        const int c8 = (lane & 3) * 8, col = n0 + wc * 32 + c8;
+        float sa[8], sb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sa[j] = sb[j] = 0.f;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int rl = it * 16 + (lane >> 2), row = m0 + wr * 32 + rl;
+            if (row < a.M && col < F) {
+                const float4 d0 = ld4(tile + rl * TP + c8), d1 = ld4(tile + rl * TP + c8 + 4);
+                const float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
                 const int64_t o = (int64_t)row * 2 * F + col;
-                const float av = (float)a.glu_h[o], bv = (float)a.glu_h[o + F];
-                const float d = acc[0][0][r] * kk_drop_mul(seed, a.glu_site, (uint64_t)row * F + col, thr, ik);
-                float gv, gd;
-                kk_gelu_pair_fast(av, gv, gd);
-                const float da = d * bv * gd, db = d * gv;
-                a.glu_dh[o] = (__bf16)da;
-                a.glu_dh[o + F] = (__bf16)db;
-                sa += da;
-                sb += db;
+                const bf16x8 av = *reinterpret_cast<const bf16x8 *>(a.glu_h + o), bv = *reinterpret_cast<const bf16x8 *>(a.glu_h + o + F);
+                float mk[8];
+                kk_drop_mul4(seed, a.glu_site, (uint64_t)row * F + col, thr, ik, *reinterpret_cast<float(*)[4]>(mk));
+                kk_drop_mul4(seed, a.glu_site, (uint64_t)row * F + col + 4, thr, ik, *reinterpret_cast<float(*)[4]>(mk + 4));
+                bf16x8 oa, ob;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float gv, gd;
+                    kk_gelu_pair_fast((float)av[j], gv, gd);
+                    const float dd = d[j] * mk[j];
+                    const float da = dd * (float)bv[j] * gd, db = dd * gv;
+                    oa[j] = (__bf16)da;
+                    ob[j] = (__bf16)db;
+                    sa[j] += da;
+                    sb[j] += db;
+                }
+                *reinterpret_cast<bf16x8 *>(a.glu_dh + o) = oa;
+                *reinterpret_cast<bf16x8 *>(a.glu_dh + o + F) = ob;
             }
         }
-        sa += __shfl_xor(sa, 32, 64);
-        sb += __shfl_xor(sb, 32, 64);
-        if (half == 0 && col < F) {
-            float *pr = a.glu_partials + (int64_t)((m0 / 64) * 2 + wr) * 2 * F;
-            pr[col] = sa;
-            pr[F + col] = sb;
+        // column sums over the wave's 32 rows: the 16 lanes that share (lane & 3)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int m = 4; m < 64; m <<= 1) { sa[j] += __shfl_xor(sa[j], m, 64); sb[j] += __shfl_xor(sb[j], m, 64); }
+        }
+        const int prow = (m0 + wr * 32) / 32;                   // one partial row per 32 rows of dY, kk_gemm_dgrad_glu_blocks(T) of them
+        if (lane < 4 && col < F && prow < 2 * ((a.M + 63) / 64)) {
+            float *pr = a.glu_partials + (int64_t)prow * 2 * F;
+            st4(pr + col, make_float4(sa[0], sa[1], sa[2], sa[3]));
+            st4(pr + col + 4, make_float4(sa[4], sa[5], sa[6], sa[7]));
+            st4(pr + F + col, make_float4(sb[0], sb[1], sb[2], sb[3]));
+            st4(pr + F + col + 4, make_float4(sb[4], sb[5], sb[6], sb[7]));
         }
         return;
     }
@@ -344,23 +374,46 @@ __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char
         return;
     }
     if constexpr (EPI == 2) {
+        // (same transposition as EPI == 1: both accumulators through LDS, a lane stores 8 consecutive columns of 2 rows)
         const int F = a.N;
         const uint32_t thr = a.glu_seed ? kk_drop_threshold(a.glu_p) : 0u, seed = thr ? *a.glu_seed : 0u;
         const float ik = thr ? 1.f / (1.f - a.glu_p) : 1.f;
-        const int col = n0 + wc * 32 + l31;
-        if (col >= F) return;
-        const float ba = a.bias ? a.bias[col] : 0.f, bb = a.bias ? a.bias[F + col] : 0.f;
-        __bf16 *h = a.glu_dh, *g = static_cast<__bf16 *>(a.C);
+        constexpr int TP = 36;
+        __builtin_amdgcn_s_barrier();                           // every wave is done with the last stage
+        float *ta_ = reinterpret_cast<float *>(smem) + wave * 2 * 32 * TP, *tb_ = ta_ + 32 * TP;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wr * 32 + frag_row(r, half);
+            ta_[frag_row(r, half) * TP + l31] = acc[0][0][r];
+            tb_[frag_row(r, half) * TP + l31] = acc2[r];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int c8 = (lane & 3) * 8, col = n0 + wc * 32 + c8;
+        if (col >= F) return;
+        float ba[8], bb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ba[j] = a.bias ? a.bias[col + j] : 0.f; bb[j] = a.bias ? a.bias[F + col + j] : 0.f; }
+        __bf16 *h = a.glu_dh, *g = static_cast<__bf16 *>(a.C);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int rl = it * 16 + (lane >> 2), row = m0 + wr * 32 + rl;
             if (row >= a.M) continue;
-            const __bf16 av = (__bf16)(acc[0][0][r] + ba), bv = (__bf16)(acc2[r] + bb);     // what the backward will read
+            const float4 a0 = ld4(ta_ + rl * TP + c8), a1 = ld4(ta_ + rl * TP + c8 + 4);
+            const float4 b0 = ld4(tb_ + rl * TP + c8), b1 = ld4(tb_ + rl * TP + c8 + 4);
+            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            float mk[8];
+            kk_drop_mul4(seed, a.glu_site, (uint64_t)row * F + col, thr, ik, *reinterpret_cast<float(*)[4]>(mk));
+            kk_drop_mul4(seed, a.glu_site, (uint64_t)row * F + col + 4, thr, ik, *reinterpret_cast<float(*)[4]>(mk + 4));
+            bf16x8 oa, ob, og;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                oa[j] = (__bf16)(av[j] + ba[j]);                 // what the backward will read
+                ob[j] = (__bf16)(bv[j] + bb[j]);
+                og[j] = (__bf16)(kk_gelu_fast((float)oa[j]) * (float)ob[j] * mk[j]);
+            }
             const int64_t o = (int64_t)row * 2 * F + col;
-            h[o] = av;
-            h[o + F] = bv;
-            g[(int64_t)row * a.ldc + col] =
-                (__bf16)(kk_gelu_fast((float)av) * (float)bv * kk_drop_mul(seed, a.glu_site, (uint64_t)row * F + col, thr, ik));
+            *reinterpret_cast<bf16x8 *>(h + o) = oa;
+            *reinterpret_cast<bf16x8 *>(h + o + F) = ob;
+            *reinterpret_cast<bf16x8 *>(g + (int64_t)row * a.ldc + col) = og;
         }
         return;
     }
@@ -417,6 +470,16 @@ template __global__ void gemm16_kernel_w8<false, false, 3>(G16Args);
 template __global__ void gemm16_kernel_w8<false, true, 3>(G16Args);
 template __global__ void gemm16_kernel_w8<true, false, 3>(G16Args);
 template __global__ void gemm16_kernel_w8<true, true, 3>(G16Args);
+// ... and the two GLU epilogues on that tile (linear1 + gate: two B panels, 96 KB of LDS; linear2 dgrad + gate backward)
+template <bool TB, int NS, int EPI>
+__global__ __launch_bounds__(512) void gemm16_kernel_w8_glu(G16Args a) {
+    __shared__ __attribute__((aligned(16))) char smem[NS * (128 + (EPI == 2 ? 2 : 1) * 64) * BK * 2];
+    gemm16_body<false, TB, 128, 64, NS, EPI, 8, 2>(a, blockIdx.x, smem);
+}
+template __global__ void gemm16_kernel_w8_glu<false, 3, 2>(G16Args);
+template __global__ void gemm16_kernel_w8_glu<true, 3, 1>(G16Args);
+int g16_w8_glu = getenv("KK_G16_W8_GLU") ? atoi(getenv("KK_G16_W8_GLU")) : 0;      // measured: -0.7 % on the step, left off
+
 template <int NS>
 void launch_w8(int ta, int tb, const G16Args &a, dim3 grid, hipStream_t s) {
     if (!ta && !tb) hipLaunchKernelGGL((gemm16_kernel_w8<false, false, NS>), grid, dim3(512), 0, s, a);
@@ -608,6 +671,12 @@ int kk_gemm16_dgrad_glu(int64_t T, int64_t F, int64_t H, const void *dy, int64_t
     a.b_bytes = (uint32_t)(((H - 1) * F + F) * 2);
     a.glu_h = static_cast<const __bf16 *>(h1); a.glu_dh = static_cast<__bf16 *>(dh1); a.glu_partials = partials;
     a.glu_seed = p > 0.f ? seed : nullptr; a.glu_site = site; a.glu_p = p;
+    if (g16_w8_glu && cd(H, BK) >= 3 && cd(T, 128) * cd(F, 64) >= g16_thr12864) {       // eight waves on 128x64 tiles, like the plain GEMMs
+        a.tiles_m = cd(T, 128);
+        hipLaunchKernelGGL((gemm16_kernel_w8_glu<true, 3, 1>), dim3(a.tiles_m * a.tiles_n), dim3(512), 0, s, a);
+        KK_LAUNCH_CHECK("kk_gemm_dgrad_glu");
+        return 0;
+    }
     dim3 grid(a.tiles_m * a.tiles_n);
     if (cd(H, BK) < 3) hipLaunchKernelGGL((gemm16_kernel<false, true, 64, 64, 2, 1>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((gemm16_kernel<false, true, 64, 64, 3, 1>), grid, dim3(256), 0, s, a);
@@ -627,6 +696,12 @@ int kk_gemm16_linear_glu(int64_t T, int64_t F, int64_t K, const void *x, int64_t
     a.b_bytes = (uint32_t)(((2 * F - 1) * K + K) * 2);
     a.glu_dh = static_cast<__bf16 *>(h1);
     a.glu_seed = p > 0.f ? seed : nullptr; a.glu_site = site; a.glu_p = p;
+    if (g16_w8_glu && cd(K, BK) >= 3 && cd(T, 128) * cd(F, 64) >= g16_thr12864) {
+        a.tiles_m = cd(T, 128);
+        hipLaunchKernelGGL((gemm16_kernel_w8_glu<false, 3, 2>), dim3(a.tiles_m * a.tiles_n), dim3(512), 0, s, a);
+        KK_LAUNCH_CHECK("kk_gemm_linear_glu");
+        return 0;
+    }
     hipLaunchKernelGGL((gemm16_kernel<false, false, 64, 64, 2, 2>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, s, a);
     KK_LAUNCH_CHECK("kk_gemm_linear_glu");
     return 0;
