@@ -418,6 +418,43 @@ __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char
         return;
     }
     const bool lead = (ksl == 0);
+    // bf16 C without accumulation or residual (most dgrads, linear2): the tile goes through LDS so that a lane stores 8
+    // consecutive columns (16 bytes) of 2 rows instead of 16 two-byte values of one column
+    constexpr bool WIDE_OK = NS * STAGE >= WAVES * 32 * 36 * 4;      // the staging area holds one 32x32 fp32 tile per wave
+    if (WIDE_OK && a.c_bf16 && a.residual == nullptr && (a.ldc & 7) == 0 && (a.N & 7) == 0 && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0) {
+        constexpr int TP = 36;
+        __builtin_amdgcn_s_barrier();                           // every wave is done with the last stage
+        float *tile = reinterpret_cast<float *>(smem) + wave * 32 * TP;
+        __bf16 *C = static_cast<__bf16 *>(a.C);
+        const int c8 = (lane & 3) * 8;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tile[frag_row(r, half) * TP + l31] = acc[i][j][r];
+                __builtin_amdgcn_wave_barrier();
+                const int col = n0 + wc * (BN / WC) + j * 32 + c8;
+                if (col < a.N) {
+                    float bv[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bv[e] = (a.bias != nullptr && lead) ? a.bias[col + e] : 0.f;
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        const int rl = it * 16 + (lane >> 2), row = m0 + wr * (BM / WR) + i * 32 + rl;
+                        if (row >= a.M) continue;
+                        const float4 v0 = ld4(tile + rl * TP + c8), v1 = ld4(tile + rl * TP + c8 + 4);
+                        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                        bf16x8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = (__bf16)(a.alpha * v[e] + bv[e]);
+                        *reinterpret_cast<bf16x8 *>(C + (int64_t)row * a.ldc + col) = o;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
