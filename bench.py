@@ -63,12 +63,13 @@ def kernel_table(records, math_bf16: bool):
             key = gemm_symbol(ta, tb, M, N, K, math_bf16, dt)
             flops = 2.0 * M * N * K
             byts = (2.0 if dt & 1 else 4.0) * M * K + (2.0 if dt & 2 else 4.0) * N * K + (2.0 if dt & 4 else 4.0) * M * N
-        elif name == "kk_gemm_wgrad_group":             # (n, split_k, then M, N, T of every problem); 128x64 tiles, see kk_gemm16.hip
-            dims = [int(x) for x in sc[2:]]
+        elif name == "kk_gemm_wgrad_group":             # (n, split_k, overwrite, then M, N, T of every problem); 128x64 tiles, see kk_gemm16.hip
+            dims = [int(x) for x in sc[3:]]
+            overwrite = int(sc[2])
             probs = [dims[i:i + 3] for i in range(0, len(dims), 3)]
             key = "gemm16_group_kernel<true,true,128,64,2,8> (a layer's dY^T.X wgrads, one launch)"
             flops = sum(2.0 * M * N * T_ for M, N, T_ in probs)
-            byts = sum(2.0 * T_ * (M + N) + 8.0 * M * N for M, N, T_ in probs)          # bf16 operands, fp32 dW read + written
+            byts = sum(2.0 * T_ * (M + N) + (4.0 if overwrite else 8.0) * M * N for M, N, T_ in probs)   # bf16 operands, fp32 dW (read +) written
         elif name == "kk_gemm_linear_glu":              # (T, F, K, ...): h1 = x.W1^T (2F columns) + gate
             T_, F_, K_ = (int(x) for x in sc[:3])
             key = "gemm16_kernel<false,false,64,64,2,2> (X.W1^T + GLU gate epilogue)"

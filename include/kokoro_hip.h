@@ -56,7 +56,9 @@ typedef struct {
     float *dw;      int64_t lddw;
     int64_t M, N, T;
 } KkWgradDesc;
-int kk_gemm_wgrad_group(const KkWgradDesc *descs, int n, int split_k /* k-slices per problem, 0 = automatic */, void *stream);
+int kk_gemm_wgrad_group(const KkWgradDesc *descs, int n, int split_k /* k-slices per problem, 0 = automatic */,
+                        int overwrite /* 1: dw = product (the first micro-batch of an accumulation cycle: dw is not read; no k-slices), 0: dw += */,
+                        void *stream);
 /* Attention projections with the per-head norm as the epilogue: raw[T, parts*heads*64] = x[T,K] . W^T (+bias), saved for
  * the backward, and y = per-head RMSNorm(64)(raw) * gains[part] (+ RoPE on the parts set in rope_mask, position = row % S)
  * from one launch — a 64x64 output tile is exactly 64 (row, head) vectors.  parts <= 12 column groups of heads*64 (q|k|v of

@@ -29,7 +29,7 @@ int kk_gemm16_launch(int ta, int tb, int64_t M, int64_t N, int64_t K, float alph
                      int64_t ldb, float beta, void *C, int64_t ldc, int c_bf16, const float *bias, const float *residual,
                      int64_t ldr, int64_t res_mod, int split_k, int xcd_swizzle, hipStream_t s);
 void kk_gemm16_tune(int thr128, int thr12864, int split_target);
-int kk_gemm16_wgrad_group(const KkWgradDesc *d, int n, int split_k, int xcd_swizzle, hipStream_t s);
+int kk_gemm16_wgrad_group(const KkWgradDesc *d, int n, int split_k, int overwrite, int xcd_swizzle, hipStream_t s);
 void kk_gemm16_tune_group(int split);
 int kk_gemm16_qkv_headnorm(int64_t T, int parts, int heads, int64_t K, const void *x, int64_t ldx, const void *W, const float *bias,
                            void *raw, int64_t ldraw, void *y, int64_t ldy, int S, const float *const *gains, int rope_mask,

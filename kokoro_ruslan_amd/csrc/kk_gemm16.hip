@@ -745,7 +745,7 @@ int kk_gemm16_linear_glu(int64_t T, int64_t F, int64_t K, const void *x, int64_t
 }
 
 // dW_i[M_i, N_i] += dY_i[T_i, M_i]^T . X_i[T_i, N_i] for i < n, one launch (see gemm16_group_kernel).
-int kk_gemm16_wgrad_group(const KkWgradDesc *d, int n, int split_k, int xcd_swizzle, hipStream_t s) {
+int kk_gemm16_wgrad_group(const KkWgradDesc *d, int n, int split_k, int overwrite, int xcd_swizzle, hipStream_t s) {
     auto cd = [](int64_t x, int64_t y) { return (int)((x + y - 1) / y); };
     if (n < 1 || n > GROUP_MAX) return kk_fail(KK_EINVAL, "kk_gemm_wgrad_group: 1..%d problems per launch, got %d", GROUP_MAX, n);
     int total = 0;
@@ -761,6 +761,7 @@ int kk_gemm16_wgrad_group(const KkWgradDesc *d, int n, int split_k, int xcd_swiz
     if (split_k > 0) splits = split_k;                            // the caller's k-slice count (0 = by the split target)
     else if (g16_group_split > 0) splits = g16_group_split;
     else if (total * 2 <= g16_split_target) splits = cd(g16_split_target, total);
+    if (overwrite) splits = 1;                                    // (k-slices accumulate with atomics: they need the old value)
     G16Group g = {};
     g.n = n;
     int min_per = 1 << 30;
@@ -773,7 +774,7 @@ int kk_gemm16_wgrad_group(const KkWgradDesc *d, int n, int split_k, int xcd_swiz
         min_per = std::min(min_per, kps / BK);
         G16Args &a = g.p[i];
         a.M = (int)M; a.N = (int)N; a.K = (int)K;
-        a.alpha = 1.f; a.beta = 1.f;
+        a.alpha = 1.f; a.beta = overwrite ? 0.f : 1.f;
         a.A = d[i].dy; a.B = d[i].x; a.C = d[i].dw;
         a.lda = d[i].lddy; a.ldb = d[i].ldx; a.ldc = d[i].lddw;
         a.k_per_split = kps; a.splits = sp; a.atomic = sp > 1 ? 1 : 0;

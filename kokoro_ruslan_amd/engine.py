@@ -197,6 +197,11 @@ class KokoroEngine:
         self.fuse_headnorm = os.environ.get("KK_FUSE_HEADNORM", "1") != "0"
         self.fuse_headnorm_bwd = os.environ.get("KK_FUSE_HEADNORM_BWD", "1") != "0"
         self._wgrad_queue = {}
+        # The gradient arena was zeroed for THIS micro-batch (first of an accumulation cycle): a layer's grouped weight
+        # gradients are each written exactly once per micro-batch, so they overwrite instead of read-modify-write (dW is
+        # 31 MB per decoder layer: a sixth of the grouped launch's traffic).  _first_micro: set by train_step around its call.
+        self._grads_fresh = False
+        self._first_micro = False
         # Text-encoder forward as one persistent launch (kk_encoder_stack_fwd): bf16 mode, phoneme sequences <= 128;
         # otherwise (and with KK_ENC_FUSED=0) the per-kernel sequence.  _enc_sync: its group-barrier words (word 0 != 0
         # = a barrier timed out; encoder_stack_error() reads it).
@@ -500,7 +505,7 @@ class KokoroEngine:
             part = q[i:i + 8]
             sig = ("wg",) + tuple((dy.data_ptr(), x.data_ptr(), dw.data_ptr(), tuple(dy.shape), tuple(x.shape)) for dy, x, dw in part)
             table = self._table(sig, lambda: kk.wgrad_table(part))
-            kk.call("kk_gemm_wgrad_group", table, len(part), 0)
+            kk.call("kk_gemm_wgrad_group", table, len(part), 0, 1 if self._grads_fresh else 0)
 
     def _ln_fwd(self, key, x, prefix, dtype=torch.float32):
         P = self.arena.P
@@ -934,6 +939,7 @@ class KokoroEngine:
         another stream or waits for one — ("begin", stream[, "fork"]), ("end", stream), ("join", stream), ("fork",) —
         and leaves the stream switching to the driver, which captures every stretch as its own single-stream hipGraph."""
         d, a, P, G = self.dims, self.arena, self.arena.P, self.arena.G
+        self._grads_fresh = bool(zero_grads) or self._first_micro
         seg = self._segmented and self.overlap
         H, M, Fv = d.hidden, d.mel, d.var_filter
         ids, mel, dur = batch["phoneme_indices"], batch["mel_specs"], batch["phoneme_durations"]
@@ -1462,7 +1468,11 @@ class KokoroEngine:
             self.zero_grad()
         is_boundary = bool(boundary) if boundary is not None else self.micro_in_cycle + 1 >= G
         self._exchange_now = is_boundary                 # (in-step bucket exchange: only the boundary micro-batch communicates)
-        out = self.forward_backward(batch, loss_scale=self.dp_loss_scale / div, adaptive=True, expanded_len=expanded_len)
+        self._first_micro = self.micro_in_cycle == 0          # (zeroed just above)
+        try:
+            out = self.forward_backward(batch, loss_scale=self.dp_loss_scale / div, adaptive=True, expanded_len=expanded_len)
+        finally:
+            self._first_micro = False
         self._exchange_now = True
         self.micro_in_cycle += 1
         if is_boundary:

@@ -138,7 +138,7 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_gemm_linear_glu": [_L, _L, _L, _P, _L, _P, _P, _P, _P, _L, _P, _U, _F, _P],
     "kk_gemm_dgrad_glu": [_L, _L, _L, _P, _L, _P, _P, _P, _P, _P, _U, _F, _P],
     "kk_gemm_dgrad_glu_blocks": [_L],
-    "kk_gemm_wgrad_group": [_P, _I, _I, _P],
+    "kk_gemm_wgrad_group": [_P, _I, _I, _I, _P],
     "kk_colsum_acc": [_P, _L, _L, _L, _P, _I, _P],
     "kk_attn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P],
     "kk_attn_delta": [_P, _P, _P, _I, _I, _I, _L, _L, _I, _P],

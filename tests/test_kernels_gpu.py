@@ -1065,7 +1065,7 @@ def test_gemm_wgrad_group(kk, T, shapes, split):
         kk.call("kk_gemm", 1, 1, dy.shape[1], x.shape[1], T, 1.0, dy, dy.stride(0), x, x.stride(0), 1.0, r, x.shape[1], None, None,
                 0, 0, 1, 1, 3)
         ref.append(r)
-    kk.call("kk_gemm_wgrad_group", kk.wgrad_table(probs), len(probs), split)
+    kk.call("kk_gemm_wgrad_group", kk.wgrad_table(probs), len(probs), split, 0)
     torch.cuda.synchronize()
     for (dy, x, dw), r in zip(probs, ref):
         if split == 0 and sum(-(-m // 64) * -(-n // 64) for m, n in shapes) * 2 > 384:
@@ -1073,7 +1073,20 @@ def test_gemm_wgrad_group(kk, T, shapes, split):
         else:
             close(dw, r, 2e-3 * math.sqrt(T / 256), 1e-4, "grouped weight gradient (k-sliced)")
     with pytest.raises(RuntimeError):
-        kk.call("kk_gemm_wgrad_group", kk.wgrad_table(probs * 9), len(probs) * 9, 0)
+        kk.call("kk_gemm_wgrad_group", kk.wgrad_table(probs * 9), len(probs) * 9, 0, 0)
+    # overwrite (the first micro-batch of an accumulation cycle): dw = product whatever dw held, never k-sliced
+    fresh = []
+    for dy, x, dw in probs:
+        r = torch.zeros_like(dw)
+        kk.call("kk_gemm", 1, 1, dy.shape[1], x.shape[1], T, 1.0, dy, dy.stride(0), x, x.stride(0), 1.0, r, x.shape[1], None, None,
+                0, 0, 1, 1, 3)
+        fresh.append(r)
+        dw.fill_(float("nan"))
+    kk.call("kk_gemm_wgrad_group", kk.wgrad_table(probs), len(probs), 0, 1)
+    for (dy, x, dw), r in zip(probs, fresh):
+        close(dw, r, 2e-3 * math.sqrt(T / 256), 1e-4, "grouped weight gradient, overwrite")
+    with pytest.raises(RuntimeError):
+        kk.call("kk_gemm_wgrad_group", kk.wgrad_table(probs), len(probs), 2, 1)
 
 
 @pytest.mark.gpu
