@@ -239,7 +239,9 @@ def main():
         kk.profile_start()
         for _ in range(2):
             eng.zero_grad()
+            eng._first_micro = True              # like the timed step: the first micro-batch of a cycle (weight gradients overwrite)
             eng.forward_backward(batch, loss_scale=eng.dp_loss_scale, adaptive=True)
+            eng._first_micro = False
             eng.optimizer_step(T)
         table = kernel_table(kk.profile_stop(), args.math == "bf16")
         shapes = {k: v for k, v in table.items() if k.startswith("  shape")}
