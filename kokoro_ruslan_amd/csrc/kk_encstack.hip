@@ -721,12 +721,26 @@ __global__ __launch_bounds__(NTHREADS) void enc_stack_fwd_kernel(const KkEncStac
 
 }  // namespace
 
-extern "C" int kk_encoder_stack_workgroups(void) { return 256; }
+// One workgroup per CU, eight groups: the launch needs every workgroup resident at once (its barriers spin), so the grid
+// follows the device's CU count (256 on MI355X; fewer under a CU mask or on a partitioned device -> fewer members per group,
+// or "unsupported" when a member's share of a phase would no longer fit its LDS).
+extern "C" int kk_encoder_stack_workgroups(void) {
+    static int wgs = -1;
+    if (wgs < 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+        wgs = cus >= 256 ? 256 : (cus / 8) * 8;
+    }
+    return wgs;
+}
 
 extern "C" int kk_encoder_stack_supported(int B, int S, int H, int F, int heads, int layers) {
-    // LDS map: a 64-row panel of K = H (<= 64 KB), up to 96 weight rows of K = H, a 32-row panel of K = F beside 16 rows of it
-    return B > 0 && S > 0 && S <= SMAX && H > 0 && H <= 512 && H % 128 == 0 && F > 0 && F % 128 == 0 && F <= 1536 && heads * 64 == H &&
-           layers > 0 && layers <= KK_ENC_MAX_LAYERS;
+    const int members = kk_encoder_stack_workgroups() / 8;
+    // LDS map: a 64-row panel of K = H (<= 64 KB), up to 96 weight rows of K = H, a 32-row panel of K = F beside 16 rows of it;
+    // per member at most one (part, head) of q|k|v, 16 columns of w_o / linear2, 3 blocks of 16 gate columns of linear1
+    return members >= 1 && B > 0 && S > 0 && S <= SMAX && H > 0 && H <= 512 && H % 128 == 0 && F > 0 && F % 128 == 0 && F <= 1536 &&
+           heads * 64 == H && layers > 0 && layers <= KK_ENC_MAX_LAYERS && 3 * heads <= members && H / 16 <= members &&
+           (F / 16 + members - 1) / members <= 3;
 }
 
 extern "C" int kk_encoder_stack_fwd(const KkEncStack *d, void *stream) {
