@@ -20,6 +20,7 @@
 #include "kk_common.h"
 #include <math.h>
 #include <stdlib.h>
+#include <algorithm>
 #include <type_traits>
 
 namespace {
@@ -42,6 +43,8 @@ struct AttnArgs {
     const uint32_t *seed;
     uint32_t site;
     float p_drop;
+    int xcd_map;
+    int dbg;                             // timing probes (KK_ATTN_DBG; results are wrong when set)
     // backward kernels: the gradient of the per-head RMSNorm (+ RoPE) that produced Q (dQ kernel) / K and V (dK/dV
     // kernel: hn[0], hn[1]) as the epilogue — Out / Out2 then receive the gradient of the RAW projection
     KkAttnHeadNorm hn[2];
@@ -78,6 +81,21 @@ struct ProbDrop {
     __device__ __forceinline__ bool keep_lo(uint32_t h) const { return (h & 0xFFFFu) >= thr; }   // even key
     __device__ __forceinline__ bool keep_hi(uint32_t h) const { return (h >> 16) >= thr; }       // odd key
 };
+
+// Workgroup -> (128-row block, batch*head).  The dispatcher places workgroup i (x fastest) on XCD i % 8, each with a private
+// L2: in launch order the row blocks of one (batch, head) land on up to eight XCDs and every one of those L2s fetches that
+// head's K and V (Q and dO in the dK/dV kernel) again.  With xcd_map set, the workgroups of XCD x are the blocks of the
+// (batch, head) pairs = x (mod 8): a head's operands are fetched by one L2.  For causal launches the long blocks go first.
+__device__ __forceinline__ void attn_block(const AttnArgs &a, int &bx, int &by, bool long_first_is_high) {
+    bx = blockIdx.x; by = blockIdx.y;
+    const int nx = gridDim.x, ny = gridDim.y;
+    if (a.xcd_map && (ny & 7) == 0) {
+        const int L = bx + nx * by, slot = L >> 3;
+        by = (L & 7) + 8 * (slot / nx);
+        bx = slot % nx;
+    }
+    if (a.causal && a.xcd_map) bx = long_first_is_high ? nx - 1 - bx : bx;
+}
 
 __device__ __forceinline__ float f4g(const float4 &v, int c) { return reinterpret_cast<const float *>(&v)[c]; }
 
@@ -410,8 +428,10 @@ __global__ __launch_bounds__(256 * G) void attn_fwd_kernel(AttnArgs a) {
     constexpr int LR = ACfg<BF16>::LR, TILE = 64 * LR;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];        // [buffer][group][K | V]
     elem *smem = reinterpret_cast<elem *>(smem_raw);
-    const int b = blockIdx.y / a.heads, hh = blockIdx.y % a.heads;
-    const int qblk = blockIdx.x * 128;
+    int bx_, by_;
+    attn_block(a, bx_, by_, true);                         // (causal: blocks near the end of the sequence see the most keys)
+    const int b = by_ / a.heads, hh = by_ % a.heads;
+    const int qblk = bx_ * 128;
     const int lane = threadIdx.x & 63, wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, l31 = lane & 31;
     const int wave = wave8 & 3, grp = wave8 >> 2;
     const int q = qblk + wave * 32 + l31;
@@ -530,7 +550,7 @@ __global__ __launch_bounds__(256 * G) void attn_fwd_kernel(AttnArgs a) {
         __syncthreads();
         cur ^= 1;
     };
-    for (int kk0 = 0; kk0 < kend; kk0 += 2 * STEP) {      // the bound is the same for both groups (barriers)
+    for (int kk0 = 0; kk0 < ((a.dbg & 32) ? 0 : kend); kk0 += 2 * STEP) {      // the bound is the same for both groups (barriers)
         tile_step(ra, kk0);
         if (kk0 + STEP < kend) tile_step(rb, kk0 + STEP);
     }
@@ -563,6 +583,334 @@ __global__ __launch_bounds__(256 * G) void attn_fwd_kernel(AttnArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ forward, second generation (bf16 storage)
+// Same decomposition and the same arithmetic per score as attn_fwd_kernel<true, true, 2> (bit-identical dropout masks), but
+//  * K and V tiles reach LDS by the buffer-load-to-LDS DMA (16 bytes per lane, no VGPR staging, no ds_write pass, no
+//    software transpose): K as a [64 keys][64 d] image with XOR-ed 16-byte chunks (conflict-free ds_read_b128 fragments),
+//    V exactly as it lies in memory with XOR-ed 32-byte blocks, its V^T fragments read by ds_read_b64_tr_b16 (the
+//    hardware 4x16 transpose read) in the key order the accumulator registers hold the probabilities;
+//  * NS stages per wave group, one raw s_barrier per 64-key tile, DMA waits by counted vmcnt;
+//  * the wave is software-pipelined over 32-key units: the QK^T MFMAs of unit u+1 are issued BEFORE the softmax of
+//    unit u, so the matrix pipe works under the VALU phase of the same wave (the first-generation kernel alternated
+//    strictly: its phases add up).
+typedef float f32x4_ __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+#define KK_LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
+
+__device__ __forceinline__ bf16x8 tr_pair(const s16x4 &lo, const s16x4 &hi) {
+    s16x8 v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// ---- coalesced prologue / epilogue pieces of the second-generation kernels.  A row-per-lane access (one 128-byte head row
+// per lane: the RowFrag loads, store_row) touches 32 lines per wave instruction and is bound by requests, not bytes
+// (4 us of a 13 us forward launch were the Q loads and the O stores).
+// DMA of a [128 rows][64] bf16 head tile into a 16 KB LDS image with XOR-ed 16-byte chunks, by 512 threads (two pieces each).
+__device__ __forceinline__ void dma_rows128(const __bf16 *base, int64_t ld, int nrows, char *img, int wave8) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(base), 0, nrows > 0 ? (int)((((int64_t)nrows - 1) * ld + 64) * 2) : 0, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = threadIdx.x + 512 * j, row = p >> 3, pc = p & 7;
+        const uint32_t vo = (uint32_t)(((int64_t)row * ld + ((pc ^ ((row >> 1) & 7)) * 8)) * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, KK_LDS_PTR(img + wave8 * 1024 + j * 8192), 16, vo, 0, 0, 0);
+    }
+}
+// this lane's row (row0 + lane&31, row0 a multiple of 16) of such an image as an MFMA operand with k = d (RowFrag layout)
+__device__ __forceinline__ void rowfrag_from_image(RowFrag<true> &f, const char *img, int row0, int l31, int half) {
+    const uint32_t base = (uint32_t)(uintptr_t)KK_LDS_PTR(img) + (uint32_t)((row0 + l31) * 128);
+    const int swz = (l31 >> 1) & 7;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("ds_read_b128 %0, %1" : "=v"(f.v[ks]) : "v"(base + (uint32_t)(((2 * ks + half) ^ swz) * 16)));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(f.v[ks]));
+}
+// Store the wave's transposed accumulator pair (acc[db][r]: d = db*32 + 8(r>>2) + 4 half + (r&3), row = lane&31) times mul
+// as 32 bf16 rows of 64 through a wave-private 4608-byte LDS tile: 16-byte global stores, eight lanes per 128-byte row.
+__device__ __forceinline__ void store_rows_via_lds(__bf16 *dst_row0, int64_t ld, int nvalid, const f32x16 (&acc)[2], float mul,
+                                                   char *tile, int lane) {
+    const int l31 = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (__bf16)(acc[db][4 * g + e] * mul);
+            *reinterpret_cast<bf16x4 *>(tile + l31 * 144 + (db * 32 + 8 * g + 4 * half) * 2) = v;
+        }
+    __builtin_amdgcn_wave_barrier();                       // (one wave: its LDS operations complete in order)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (lane >> 3) + 8 * j, c = lane & 7;
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(tile + row * 144 + c * 16);
+        if (row < nvalid) *reinterpret_cast<u32x4 *>(dst_row0 + (int64_t)row * ld + c * 8) = v;
+    }
+}
+
+template <int NS>
+__global__ __launch_bounds__(512) void attn_fwd2_kernel(AttnArgs a) {
+    typedef __bf16 T;
+    constexpr int KIMG = 64 * 64 * 2, STAGE = 2 * KIMG, GSZ = NS * STAGE, STEP = 128;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];        // [group][stage][K image | V image], key-mask words
+    uint64_t *kmb = reinterpret_cast<uint64_t *>(smem_raw + 2 * GSZ);       // [64] one word per 64-key tile
+    int bx_, by_;
+    attn_block(a, bx_, by_, true);                         // (causal: blocks near the end of the sequence see the most keys)
+    const int b = by_ / a.heads, hh = by_ % a.heads;
+    const int qblk = bx_ * 128;
+    const int lane = threadIdx.x & 63, wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, l31 = lane & 31;
+    const int wave = wave8 & 3, grp = wave8 >> 2, tg = threadIdx.x & 255;
+    const int q = qblk + wave * 32 + l31;
+    const bool qvalid = q < a.Sq;
+    const int qmin = qblk + wave * 32;
+    int kend = a.Sk;
+    if (a.causal && qblk + 128 < kend) kend = qblk + 128;
+    int klim = kend;                                       // this wave multiplies the keys [0, klim)
+    if (a.causal && qmin + 32 < klim) klim = qmin + 32;
+    const int kfirst = grp * 64;
+    const int nt = kfirst < kend ? (kend - kfirst + STEP - 1) / STEP : 0;       // this group's tiles
+    const int nt0 = (kend + STEP - 1) / STEP;                                   // group 0's: the loop bound (barriers)
+    int nu = 0;                                            // this wave's 32-key units: a prefix of the group's
+    if (klim > kfirst) {
+        const int full = (klim - kfirst) / STEP, rem = (klim - kfirst) - full * STEP;
+        nu = 2 * full + (rem > 32 ? 2 : (rem > 0 ? 1 : 0));
+    }
+    RowFrag<true> qf;
+    char *qimg = smem_raw + 2 * GSZ + 512;                 // [128 queries][64] image (the oldest DMA: covered by every wait below)
+    dma_rows128(static_cast<const T *>(a.Q) + ((int64_t)b * a.Sq + qblk) * a.ldq + hh * 64, a.ldq, a.Sq - qblk < 128 ? a.Sq - qblk : 128, qimg, wave8);
+    const uint8_t *km = a.key_mask ? a.key_mask + (int64_t)b * a.Sk : nullptr;
+    uint32_t kmv[8];
+    if (km) {                                              // tile T's mask word: wave T % 8 (issued before the DMAs)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int key = (wave8 + 8 * i) * 64 + lane;
+            kmv[i] = key < kend ? km[key] : 0u;
+        }
+    }
+    // ---- DMA
+    const T *Kb = static_cast<const T *>(a.K) + (int64_t)b * a.Sk * a.ldk + hh * 64;
+    const T *Vb = static_cast<const T *>(a.V) + (int64_t)b * a.Sk * a.ldv + hh * 64;
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(Kb), 0, (int)((((int64_t)a.Sk - 1) * a.ldk + 64) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(Vb), 0, (int)((((int64_t)a.Sk - 1) * a.ldv + 64) * 2), 0x00020000);
+    uint32_t kvo[2], vvo[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = tg + 256 * j, row = p >> 3, pc = p & 7;
+        kvo[j] = (uint32_t)(((int64_t)row * a.ldk + ((pc ^ ((row >> 1) & 7)) * 8)) * 2);
+        const int sw = 2 * ((row >> 1) & 1), g = (((pc >> 1) ^ sw) << 1) | (pc & 1);
+        vvo[j] = (uint32_t)(((int64_t)row * a.ldv + g * 8) * 2);
+    }
+    char *gbase = smem_raw + grp * GSZ;
+    const uint32_t ktile = (uint32_t)(STEP * a.ldk * 2), vtile = (uint32_t)(STEP * a.ldv * 2);
+    const uint32_t kbeg = (uint32_t)(kfirst * a.ldk * 2), vbeg = (uint32_t)(kfirst * a.ldv * 2);
+    auto issue_tile = [&](int t, int st) {                 // (offsets in the VGPR: the range check then covers the tile's rows)
+        char *dst = gbase + st * STAGE + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, KK_LDS_PTR(dst + j * 4096), 16, kvo[j] + kbeg + (uint32_t)t * ktile, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, KK_LDS_PTR(dst + KIMG + j * 4096), 16, vvo[j] + vbeg + (uint32_t)t * vtile, 0, 0, 0);
+    };
+#pragma unroll
+    for (int t = 0; t < NS; ++t)
+        if (t < nt) issue_tile(t, t);
+    if (km) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint64_t bits = __ballot(kmv[i] != 0u);
+            if (lane == 0) kmb[wave8 + 8 * i] = bits;
+        }
+    }
+    // ---- fragment addresses (bytes inside a stage)
+    const uint32_t gl = (uint32_t)(uintptr_t)KK_LDS_PTR(gbase);
+    uint32_t ka[4], va[2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) ka[ks] = (uint32_t)(l31 * 128 + (((2 * ks + half) ^ ((l31 >> 1) & 7)) * 16));
+    {
+        const int L = lane & 15, kq = L >> 2, gi = (lane >> 4) & 1, sw = 2 * ((kq >> 1) & 1);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) va[db] = (uint32_t)((4 * half + kq) * 128 + (((2 * db + gi) ^ sw) * 32) + 8 * (L & 3));
+    }
+    bf16x8 kf[4];
+    s16x4 vlo[4], vhi[4];
+    // (plain lambdas with literal offsets: inline-asm operands are not captured inside generic lambdas)
+    auto read_k = [&](uint32_t img) {                      // img = LDS address of the unit's first K row
+        if (a.dbg & 16) return;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(kf[0]) : "v"(img + ka[0]));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(kf[1]) : "v"(img + ka[1]));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(kf[2]) : "v"(img + ka[2]));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(kf[3]) : "v"(img + ka[3]));
+    };
+    auto read_v = [&](uint32_t img) {                      // img = LDS address of the unit's first V row
+        if (a.dbg & 16) return;
+        const uint32_t a0 = img + va[0], a1 = img + va[1];
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vlo[0]) : "v"(a0));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(vhi[0]) : "v"(a0));
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vlo[1]) : "v"(a1));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(vhi[1]) : "v"(a1));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(vlo[2]) : "v"(a0));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:3072" : "=v"(vhi[2]) : "v"(a0));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(vlo[3]) : "v"(a1));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:3072" : "=v"(vhi[3]) : "v"(a1));
+    };
+    auto wait_lds = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+    auto qk = [&](f32x16 &s) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(kf[ks]));
+        zero_acc(s);
+        if (a.dbg & 4) { s[0] = (float)kf[0][0] + (float)kf[1][1] + (float)kf[2][2] + (float)kf[3][3]; return; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf.v[ks], s, 0, 0, 0);
+    };
+    f32x16 o[2];
+    zero_acc(o[0]); zero_acc(o[1]);
+    float m = -1e30f, l = 0.f;
+    const float c2 = a.scale * 1.4426950408889634f;
+    ProbDrop pd;
+    pd.init(a, b, hh);
+    // softmax (+ dropout) of one unit: s -> two B operands of the PV MFMAs; the arithmetic of attn_fwd_kernel
+    auto softmax_unit = [&](const f32x16 &s, int kb, uint32_t kmsub, bf16x8 (&pb)[2]) {
+        if (a.dbg & 2) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pb[s2][j] = (__bf16)s[8 * s2 + j];
+            return;
+        }
+        const bool edge = kb + 32 > a.Sk || (a.causal && kb + 31 > qmin) || kmsub != 0u;
+        float p[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[r] = s[r];
+        if (edge) {
+            const uint32_t kml = kmsub >> (4 * half);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb + frag_row(r, half);
+                const bool ok = key < a.Sk && !(a.causal && key > q) && !((kml >> frag_row(r, 0)) & 1u);
+                p[r] = ok ? p[r] : -INFINITY;
+            }
+        }
+        float mx = p[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, p[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c2;
+        const float mn = fmaxf(m, mx);
+        if (__ballot(mn > m) != 0ull) {
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);
+            l *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+            m = mn;
+        }
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(fmaf(p[r], c2, -m)); rs += p[r]; }
+        rs += __shfl_xor(rs, 32, 64);
+        l += rs;
+        if (pd.thr) {
+            const uint32_t xb = pd.row(q, kb + 4 * half);
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const uint32_t hsh = pd.hash(xb + (uint32_t)(frag_row(r, 0) >> 1));
+                p[r] = pd.keep_lo(hsh) ? p[r] : 0.f;
+                p[r + 1] = pd.keep_hi(hsh) ? p[r + 1] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pb[s2][j] = (__bf16)p[8 * s2 + j];
+    };
+    auto pv = [&](const bf16x8 (&pb)[2]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(vlo[i]), "+v"(vhi[i]));
+        if (a.dbg & 4) { o[0][0] += (float)pb[0][0] + (float)pb[1][0] + (float)vlo[0][0] + (float)vhi[3][0]; return; }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_pair(vlo[s2 * 2 + db], vhi[s2 * 2 + db]), pb[s2], o[db], 0, 0, 0);
+    };
+    // ---- prologue: tiles 0 and 1 landed (tile 2 may stay in flight), unit 0's scores, unit 1's K fragments
+    if (NS >= 4 && nt >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nt >= 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    rowfrag_from_image(qf, qimg, wave * 32, l31, half);
+    f32x16 sa, sb;
+    if (nu > 0) {
+        read_k(gl);
+        wait_lds();
+        qk(sa);
+        if (nu > 1) read_k(gl + 4096);
+    }
+    int st = 0;
+    for (int t = 0; t < ((a.dbg & 32) ? 0 : nt0); ++t) {
+        const int st1 = st + 1 == NS ? 0 : st + 1;
+        if (t > 0) {
+            // tile t+1 landed: the only DMA younger than it is tile t+2 when NS == 4
+            if (NS >= 4 && t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(a.dbg & 8)) __builtin_amdgcn_s_barrier();                  // ... for every wave, and every wave is done with tile t-1
+            asm volatile("" ::: "memory");
+            if (t + NS - 1 < nt && !(a.dbg & 1)) issue_tile(t + NS - 1, st == 0 ? NS - 1 : st - 1);
+        }
+        const int u0 = 2 * t;
+        if (u0 < nu) {
+            const int k0 = kfirst + t * STEP;
+            const uint64_t kmbits = km ? kmb[k0 >> 6] : 0ull;
+            const uint32_t cur = gl + st * STAGE, nxt = gl + st1 * STAGE;
+            bf16x8 pb[2];
+            // unit (t, 0): scores in sa; next unit (t, 1) -> sb
+            if (u0 + 1 < nu) { wait_lds(); qk(sb); }
+            __builtin_amdgcn_sched_barrier(0);
+            read_v(cur + KIMG);
+            softmax_unit(sa, k0, (uint32_t)kmbits, pb);
+            wait_lds();
+            pv(pb);
+            __builtin_amdgcn_sched_barrier(0);
+            if (u0 + 2 < nu) read_k(nxt);
+            if (u0 + 1 < nu) {
+                // unit (t, 1): scores in sb; next unit (t+1, 0) -> sa
+                if (u0 + 2 < nu) { wait_lds(); qk(sa); }
+                __builtin_amdgcn_sched_barrier(0);
+                read_v(cur + KIMG + 4096);
+                softmax_unit(sb, k0 + 32, (uint32_t)(kmbits >> 32), pb);
+                wait_lds();
+                pv(pb);
+                __builtin_amdgcn_sched_barrier(0);
+                if (u0 + 3 < nu) read_k(nxt + 4096);
+            }
+        }
+        st = st1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {                                // merge the two key groups' partial softmaxes: group 1 -> LDS -> group 0
+        float *mb = reinterpret_cast<float *>(smem_raw) + (wave * 64 + lane) * 34;
+        if (grp == 1) {
+            mb[0] = m; mb[1] = l;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { mb[2 + r] = o[0][r]; mb[18 + r] = o[1][r]; }
+        }
+        __syncthreads();
+        if (grp == 1) return;
+        const float m1 = mb[0], l1 = mb[1], mn = fmaxf(m, m1);
+        const float a0 = __builtin_amdgcn_exp2f(m - mn), a1 = __builtin_amdgcn_exp2f(m1 - mn);
+        l = l * a0 + l1 * a1;
+        m = mn;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[0][r] = o[0][r] * a0 + mb[2 + r] * a1; o[1][r] = o[1][r] * a0 + mb[18 + r] * a1; }
+    }
+    const float inv = l > 0.f ? pd.inv_keep / l : 0.f;
+    store_rows_via_lds(static_cast<T *>(a.Out) + ((int64_t)b * a.Sq + qmin) * a.ldout + hh * 64, a.ldout, a.Sq - qmin, o, inv,
+                       smem_raw + 36864 + wave * 4608, lane);
+    if (qvalid && half == 0) a.LSEo[((int64_t)b * a.heads + hh) * a.Sq + q] = l > 0.f ? (m + __builtin_amdgcn_logf(l)) * 0.6931471805599453f : INFINITY;
+}
+
 // ------------------------------------------------------------------ backward: dQ
 // Same decomposition as the forward: a lane owns a query, wave group g sweeps the key tiles g, g+G, ...; with G = 2
 // group 1's partial dQ is added to group 0's through LDS at the end.  Two register sets (prefetch distance 2).
@@ -574,8 +922,10 @@ __global__ __launch_bounds__(256 * G) void attn_bwd_dq_kernel(AttnArgs a) {
     constexpr int LR = ACfg<BF16>::LR, TILE = 64 * LR, NT = BF16 ? 3 : 2;   // K, V (+ K transposed for bf16)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];        // [buffer][group][NT tiles]
     elem *smem = reinterpret_cast<elem *>(smem_raw);
-    const int b = blockIdx.y / a.heads, hh = blockIdx.y % a.heads;
-    const int qblk = blockIdx.x * 128;
+    int bx_, by_;
+    attn_block(a, bx_, by_, true);                         // (causal: blocks near the end of the sequence see the most keys)
+    const int b = by_ / a.heads, hh = by_ % a.heads;
+    const int qblk = bx_ * 128;
     const int lane = threadIdx.x & 63, wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, l31 = lane & 31;
     const int wave = wave8 & 3, grp = wave8 >> 2;
     const int q = qblk + wave * 32 + l31;
@@ -687,7 +1037,7 @@ __global__ __launch_bounds__(256 * G) void attn_bwd_dq_kernel(AttnArgs a) {
         __syncthreads();
         cur ^= 1;
     };
-    for (int kk0 = 0; kk0 < kend; kk0 += 2 * STEP) {      // the bound is the same for both groups (barriers)
+    for (int kk0 = 0; kk0 < ((a.dbg & 32) ? 0 : kend); kk0 += 2 * STEP) {      // the bound is the same for both groups (barriers)
         tile_step(ra, kk0);
         if (kk0 + STEP < kend) tile_step(rb, kk0 + STEP);
     }
@@ -717,6 +1067,357 @@ __global__ __launch_bounds__(256 * G) void attn_bwd_dq_kernel(AttnArgs a) {
     hn_colsum(colred, a.hn[0].partials);
 }
 
+// ------------------------------------------------------------------ backward, second generation: shared pieces
+// XOR value (on the 32-byte block index of a 128-byte row) of an image that is read BOTH as row fragments (ds_read_b128, the
+// lane's own row) and through ds_read_b64_tr_b16 (four consecutive rows per 16-lane group): rows r and r+2 of a transpose
+// read must differ in bit 1 of the block index (conflict-free), and the four values spread the row-fragment reads (2-way).
+__device__ __forceinline__ int kk_xb(int r) { return (((r >> 1) & 1) << 1) | ((r >> 2) & 1); }
+
+// Head-norm (+ RoPE) backward of the (row, head) vector this lane pair holds — hn_bwd_row with every operand in LDS: the
+// raw projection tile and the RoPE rows were DMA'd there while the main loop ran, so the epilogue has no exposed global
+// latency and no row-per-lane requests.  rawimg: [128][64] bf16, cosimg / sinimg: columns 0..31 of the table rows as
+// [128][32] fp32 (rotate-half RoPE tables have identical halves, positional_encoding.py:129-150), all with the chunk XOR
+// of dma_rows128.  The gradient of the raw projection comes back in the accumulator layout (out), for store_rows_via_lds.
+__device__ __forceinline__ void hn_bwd_row2(const f32x16 (&acc)[2], float mul, bool valid, const char *rawimg, const char *cosimg,
+                                            const char *sinimg, int row, bool rope, const float *gain, int half, float *colred_row,
+                                            f32x16 (&out)[2]) {
+    float dn[32], v[32];
+    const int swz = (row >> 1) & 7;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const bf16x4 x4 = *reinterpret_cast<const bf16x4 *>(rawimg + row * 128 + (((4 * db + g) ^ swz) * 16) + half * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[db * 16 + 4 * g + e] = (float)x4[e];
+                dn[db * 16 + 4 * g + e] = valid ? (float)(__bf16)(acc[db][4 * g + e] * mul) : 0.f;
+            }
+        }
+    float ssq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) ssq += v[i] * v[i];
+    ssq += __shfl_xor(ssq, 32, 64);
+    const float rs = 1.f / sqrtf(ssq * (1.f / 64.f) + 1.1920928955078125e-7f);
+    if (rope) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 c4 = *reinterpret_cast<const float4 *>(cosimg + row * 128 + (((2 * g + half) ^ swz) * 16));
+            const float4 s4 = *reinterpret_cast<const float4 *>(sinimg + row * 128 + (((2 * g + half) ^ swz) * 16));
+            const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float lo = dn[4 * g + e], hi = dn[16 + 4 * g + e];
+                dn[4 * g + e] = lo * cc[e] + hi * ss[e];
+                dn[16 + 4 * g + e] = hi * cc[e] - lo * ss[e];
+            }
+        }
+    }
+    float kdot = 0.f;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 g4 = ld4(gain + db * 32 + 8 * g + 4 * half);
+            const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = db * 16 + 4 * g + e;
+                colred_row[db * 32 + 8 * g + 4 * half + e] = dn[i] * v[i] * rs;
+                dn[i] *= gg[e];
+                kdot += dn[i] * v[i];
+            }
+        }
+    kdot += __shfl_xor(kdot, 32, 64);
+    const float k = kdot * (1.f / 64.f) * rs * rs * rs;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[db][r] = rs * dn[db * 16 + r] - v[db * 16 + r] * k;
+}
+// the three epilogue images of a 128-row block (rows row0 .. of a sequence of S rows, position = row): raw | cos | sin
+__device__ __forceinline__ void hn_dma_inputs(const KkAttnHeadNorm &h, int64_t seq_row0, int pos0, int nrows, int hh, char *img, int wave8) {
+    dma_rows128(static_cast<const __bf16 *>(h.raw) + seq_row0 * h.ldraw + hh * 64, h.ldraw, nrows, img, wave8);
+    if (h.rope) {       // (fp32 rows of 64 = 128 bf16-sized elements; the first 128 bytes of each)
+        dma_rows128(reinterpret_cast<const __bf16 *>(h.cos_t + (int64_t)pos0 * 64), 128, nrows, img + 16384, wave8);
+        dma_rows128(reinterpret_cast<const __bf16 *>(h.sin_t + (int64_t)pos0 * 64), 128, nrows, img + 32768, wave8);
+    }
+}
+
+// ------------------------------------------------------------------ backward: dQ, second generation (bf16 storage)
+// attn_bwd_dq_kernel<true, true, 2>'s arithmetic in attn_fwd2_kernel's structure: K / V tiles by DMA (K once, in an image
+// that serves both the row fragments of S = K.Q^T and the transpose reads of dQ^T += K^T.dS^T), Q / dO / O rows by DMA (Delta
+// from the fragments), the scores and dP of unit u+1 issued before the exponentials of unit u, the head-norm epilogue's
+// operands prefetched into the prologue's LDS while the loop runs, 16-byte coalesced stores.
+__global__ __launch_bounds__(512) void attn_bwd_dq2_kernel(AttnArgs a) {
+    typedef __bf16 T;
+    constexpr int NS = 3, KIMG = 64 * 64 * 2, STAGE = 2 * KIMG, GSZ = NS * STAGE, STEP = 128;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];        // [group][stage][K | V], mask words, 3 x 16 KB images
+    uint64_t *kmb = reinterpret_cast<uint64_t *>(smem_raw + 2 * GSZ);
+    char *pro = smem_raw + 2 * GSZ + 512;                                  // Q | dO | O, later raw | cos | sin
+    int bx_, by_;
+    attn_block(a, bx_, by_, true);
+    const int b = by_ / a.heads, hh = by_ % a.heads;
+    const int qblk = bx_ * 128;
+    const int lane = threadIdx.x & 63, wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, l31 = lane & 31;
+    const int wave = wave8 & 3, grp = wave8 >> 2, tg = threadIdx.x & 255;
+    const int q = qblk + wave * 32 + l31;
+    const bool qvalid = q < a.Sq;
+    const int qmin = qblk + wave * 32;
+    int kend = a.Sk;
+    if (a.causal && qblk + 128 < kend) kend = qblk + 128;
+    int klim = kend;
+    if (a.causal && qmin + 32 < klim) klim = qmin + 32;
+    const int kfirst = grp * 64;
+    const int nt = kfirst < kend ? (kend - kfirst + STEP - 1) / STEP : 0;
+    const int nt0 = (kend + STEP - 1) / STEP;
+    int nu = 0;
+    if (klim > kfirst) {
+        const int full = (klim - kfirst) / STEP, rem = (klim - kfirst) - full * STEP;
+        nu = 2 * full + (rem > 32 ? 2 : (rem > 0 ? 1 : 0));
+    }
+    // every other global read is issued before the tile DMAs (the counted vmcnt waits assume the tiles are the youngest)
+    const int64_t statrow = ((int64_t)b * a.heads + hh) * a.Sq + q;
+    float lse2 = qvalid ? a.LSE[statrow] * 1.4426950408889634f : INFINITY;
+    const bool want_delta = a.DeltaOut != nullptr;
+    float dlt = (!want_delta && qvalid) ? a.Delta[statrow] : 0.f;
+    const uint8_t *km = a.key_mask ? a.key_mask + (int64_t)b * a.Sk : nullptr;
+    uint32_t kmv[8];
+    if (km) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int key = (wave8 + 8 * i) * 64 + lane;
+            kmv[i] = key < kend ? km[key] : 0u;
+        }
+    }
+    const int nrows = a.Sq - qblk < 128 ? a.Sq - qblk : 128;
+    dma_rows128(static_cast<const T *>(a.Q) + ((int64_t)b * a.Sq + qblk) * a.ldq + hh * 64, a.ldq, nrows, pro, wave8);
+    dma_rows128(static_cast<const T *>(a.dO) + ((int64_t)b * a.Sq + qblk) * a.lddo + hh * 64, a.lddo, nrows, pro + 16384, wave8);
+    if (want_delta) dma_rows128(static_cast<const T *>(a.O) + ((int64_t)b * a.Sq + qblk) * a.ldo + hh * 64, a.ldo, nrows, pro + 32768, wave8);
+    const T *Kb = static_cast<const T *>(a.K) + (int64_t)b * a.Sk * a.ldk + hh * 64;
+    const T *Vb = static_cast<const T *>(a.V) + (int64_t)b * a.Sk * a.ldv + hh * 64;
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(Kb), 0, (int)((((int64_t)a.Sk - 1) * a.ldk + 64) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(Vb), 0, (int)((((int64_t)a.Sk - 1) * a.ldv + 64) * 2), 0x00020000);
+    uint32_t kvo[2], vvo[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = tg + 256 * j, row = p >> 3, pc = p & 7;
+        kvo[j] = (uint32_t)(((int64_t)row * a.ldk + ((pc ^ (kk_xb(row) << 1)) * 8)) * 2);
+        vvo[j] = (uint32_t)(((int64_t)row * a.ldv + ((pc ^ ((row >> 1) & 7)) * 8)) * 2);
+    }
+    char *gbase = smem_raw + grp * GSZ;
+    const uint32_t ktile = (uint32_t)(STEP * a.ldk * 2), vtile = (uint32_t)(STEP * a.ldv * 2);
+    const uint32_t kbeg = (uint32_t)(kfirst * a.ldk * 2), vbeg = (uint32_t)(kfirst * a.ldv * 2);
+    auto issue_tile = [&](int t, int st) {
+        char *dst = gbase + st * STAGE + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, KK_LDS_PTR(dst + j * 4096), 16, kvo[j] + kbeg + (uint32_t)t * ktile, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, KK_LDS_PTR(dst + KIMG + j * 4096), 16, vvo[j] + vbeg + (uint32_t)t * vtile, 0, 0, 0);
+    };
+#pragma unroll
+    for (int t = 0; t < NS; ++t)
+        if (t < nt) issue_tile(t, t);
+    if (km) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint64_t bits = __ballot(kmv[i] != 0u);
+            if (lane == 0) kmb[wave8 + 8 * i] = bits;
+        }
+    }
+    // ---- fragment addresses (bytes inside a stage)
+    const uint32_t gl = (uint32_t)(uintptr_t)KK_LDS_PTR(gbase);
+    uint32_t ka[4], va[4], ta[2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        ka[ks] = (uint32_t)(l31 * 128 + (((2 * ks + half) ^ (kk_xb(l31) << 1)) * 16));
+        va[ks] = (uint32_t)(KIMG + l31 * 128 + (((2 * ks + half) ^ ((l31 >> 1) & 7)) * 16));
+    }
+    {
+        const int L = lane & 15, kq = L >> 2, gi = (lane >> 4) & 1, xb = (((kq >> 1) & 1) << 1) | half;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) ta[db] = (uint32_t)((4 * half + kq) * 128 + (((2 * db + gi) ^ xb) * 32) + 8 * (L & 3));
+    }
+    bf16x8 kf[4], vf[4];
+    s16x4 tlo[4], thi[4];
+    auto read_kv = [&](uint32_t img) {                     // row fragments of the unit's 32 keys (img = its first K row)
+        asm volatile("ds_read_b128 %0, %1" : "=v"(kf[0]) : "v"(img + ka[0]));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(kf[1]) : "v"(img + ka[1]));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(kf[2]) : "v"(img + ka[2]));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(kf[3]) : "v"(img + ka[3]));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(vf[0]) : "v"(img + va[0]));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(vf[1]) : "v"(img + va[1]));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(vf[2]) : "v"(img + va[2]));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(vf[3]) : "v"(img + va[3]));
+    };
+    auto read_kt = [&](uint32_t img) {                     // K^T fragments of the same keys
+        const uint32_t a0 = img + ta[0], a1 = img + ta[1];
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(tlo[0]) : "v"(a0));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(thi[0]) : "v"(a0));
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(tlo[1]) : "v"(a1));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(thi[1]) : "v"(a1));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(tlo[2]) : "v"(a0));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:3072" : "=v"(thi[2]) : "v"(a0));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(tlo[3]) : "v"(a1));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:3072" : "=v"(thi[3]) : "v"(a1));
+    };
+    auto wait_lds = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+    RowFrag<true> qf, dof;
+    auto scores = [&](f32x16 &s, f32x16 &dp) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));
+        zero_acc(s); zero_acc(dp);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf.v[ks], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[ks], dof.v[ks], dp, 0, 0, 0);
+        }
+    };
+    f32x16 dq[2];
+    zero_acc(dq[0]); zero_acc(dq[1]);
+    const float c2 = a.scale * 1.4426950408889634f;
+    ProbDrop pd;
+    pd.init(a, b, hh);
+    auto ds_unit = [&](const f32x16 &s, const f32x16 &dp, int kb, uint32_t kmsub, bf16x8 (&db8)[2]) {
+        const bool edge = kb + 32 > a.Sk || (a.causal && kb + 31 > qmin) || kmsub != 0u;
+        float pv[16], ds[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pv[r] = __builtin_amdgcn_exp2f(s[r] * c2 - lse2);
+        if (edge) {
+            const uint32_t kml = kmsub >> (4 * half);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb + frag_row(r, half);
+                const bool ok = key < a.Sk && !(a.causal && key > q) && !((kml >> frag_row(r, 0)) & 1u);
+                pv[r] = ok ? pv[r] : 0.f;
+            }
+        }
+        if (pd.thr) {
+            const uint32_t xb = pd.row(q, kb + 4 * half);
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const uint32_t hsh = pd.hash(xb + (uint32_t)(frag_row(r, 0) >> 1));
+                ds[r] = pv[r] * ((pd.keep_lo(hsh) ? dp[r] : 0.f) - dlt);
+                ds[r + 1] = pv[r + 1] * ((pd.keep_hi(hsh) ? dp[r + 1] : 0.f) - dlt);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ds[r] = pv[r] * (dp[r] - dlt);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) db8[s2][j] = (__bf16)ds[8 * s2 + j];
+    };
+    auto dq_acc = [&](const bf16x8 (&db8)[2]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(tlo[i]), "+v"(thi[i]));
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+                dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_pair(tlo[s2 * 2 + db], thi[s2 * 2 + db]), db8[s2], dq[db], 0, 0, 0);
+    };
+    // ---- prologue
+    if (nt >= 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(lse2), "+v"(dlt));              // (their loads are older than the tiles: consumed here, not in the loop)
+    __syncthreads();
+    rowfrag_from_image(qf, pro, wave * 32, l31, half);
+    rowfrag_from_image(dof, pro + 16384, wave * 32, l31, half);
+    if (want_delta) {
+        RowFrag<true> of;
+        rowfrag_from_image(of, pro + 32768, wave * 32, l31, half);
+        dlt = rowfrag_dot<true>(dof, of);
+        dlt += __shfl_xor(dlt, 32, 64);
+        if (qvalid && half == 0 && grp == 0) a.DeltaOut[statrow] = dlt;
+    }
+    if (pd.thr) scale_rowfrag<true>(dof, pd.inv_keep);
+    const bool has_hn = a.hn[0].raw != nullptr;
+    bool hn_issued = false;
+    f32x16 sa, dpa, sb, dpb;
+    if (nu > 0) {
+        read_kv(gl);
+        wait_lds();
+        scores(sa, dpa);
+        if (nu > 1) read_kv(gl + 4096);
+    }
+    int st = 0;
+    for (int t = 0; t < ((a.dbg & 32) ? 0 : nt0); ++t) {
+        const int st1 = st + 1 == NS ? 0 : st + 1;
+        if (t > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // tile t+1 (and whatever else was in flight) landed
+            __builtin_amdgcn_s_barrier();                           // ... for every wave; every wave is done with tile t-1
+            asm volatile("" ::: "memory");
+            if (t + NS - 1 < nt) issue_tile(t + NS - 1, st == 0 ? NS - 1 : st - 1);
+            if (has_hn && !hn_issued) {                             // the prologue images are free since that barrier
+                hn_dma_inputs(a.hn[0], (int64_t)b * a.Sq + qblk, qblk, nrows, hh, pro, wave8);
+                hn_issued = true;
+            }
+        }
+        const int u0 = 2 * t;
+        if (u0 < nu) {
+            const int k0 = kfirst + t * STEP;
+            const uint64_t kmbits = km ? kmb[k0 >> 6] : 0ull;
+            const uint32_t cur = gl + st * STAGE, nxt = gl + st1 * STAGE;
+            bf16x8 d8[2];
+            if (u0 + 1 < nu) { wait_lds(); scores(sb, dpb); }
+            __builtin_amdgcn_sched_barrier(0);
+            read_kt(cur);
+            ds_unit(sa, dpa, k0, (uint32_t)kmbits, d8);
+            wait_lds();
+            dq_acc(d8);
+            __builtin_amdgcn_sched_barrier(0);
+            if (u0 + 2 < nu) read_kv(nxt);
+            if (u0 + 1 < nu) {
+                if (u0 + 2 < nu) { wait_lds(); scores(sa, dpa); }
+                __builtin_amdgcn_sched_barrier(0);
+                read_kt(cur + 4096);
+                ds_unit(sb, dpb, k0 + 32, (uint32_t)(kmbits >> 32), d8);
+                wait_lds();
+                dq_acc(d8);
+                __builtin_amdgcn_sched_barrier(0);
+                if (u0 + 3 < nu) read_kv(nxt + 4096);
+            }
+        }
+        st = st1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (has_hn && !hn_issued) hn_dma_inputs(a.hn[0], (int64_t)b * a.Sq + qblk, qblk, nrows, hh, pro, wave8);   // (single-tile launches)
+    {                                // group 1's partial dQ -> LDS -> group 0
+        float *mb = reinterpret_cast<float *>(smem_raw) + (wave * 64 + lane) * 33;
+        if (grp == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { mb[r] = dq[0][r]; mb[16 + r] = dq[1][r]; }
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dq[0][r] += mb[r]; dq[1][r] += mb[16 + r]; }
+        }
+    }
+    T *out0 = static_cast<T *>(a.Out) + ((int64_t)b * a.Sq + qmin) * a.ldout + hh * 64;
+    char *otile = smem_raw + 36864 + wave * 4608;
+    if (!has_hn) {
+        if (grp == 0) store_rows_via_lds(out0, a.ldout, a.Sq - qmin, dq, a.scale, otile, lane);
+        return;
+    }
+    float *colred = reinterpret_cast<float *>(smem_raw);          // [128 rows][65]
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the epilogue images
+    __syncthreads();                                              // ... for every wave; the merge buffer is free
+    if (grp == 0) {
+        f32x16 dx[2];
+        hn_bwd_row2(dq, a.scale, qvalid, pro, pro + 16384, pro + 32768, wave * 32 + l31, a.hn[0].rope != 0, a.hn[0].gain, half,
+                    colred + (wave * 32 + l31) * 65, dx);
+        store_rows_via_lds(out0, a.ldout, a.Sq - qmin, dx, 1.f, otile, lane);
+    }
+    __syncthreads();
+    hn_colsum(colred, a.hn[0].partials);
+}
+
 // ------------------------------------------------------------------ backward: dK, dV
 // A lane owns a key; the workgroup sweeps the query tiles.  G = 2: two wave groups take alternate query tiles of the
 // same 128 keys (2 waves per SIMD, see attn_fwd_kernel) and group 1's dK / dV partial sums are added to group 0's
@@ -731,8 +1432,10 @@ __global__ __launch_bounds__(256 * G) void attn_bwd_dkv_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];        // [buffer][group][NT tiles], then lse/delta rows
     elem *smem = reinterpret_cast<elem *>(smem_raw);
     float *stat = reinterpret_cast<float *>(smem_raw + (size_t)2 * G * NT * TILE * sizeof(elem));   // [buffer][group][2][64]
-    const int b = blockIdx.y / a.heads, hh = blockIdx.y % a.heads;
-    const int kblk = blockIdx.x * 128;
+    int bx_, by_;
+    attn_block(a, bx_, by_, false);                        // (causal: the first key blocks see the most queries)
+    const int b = by_ / a.heads, hh = by_ % a.heads;
+    const int kblk = bx_ * 128;
     const int lane = threadIdx.x & 63, wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, l31 = lane & 31;
     const int wave = wave8 & 3, grp = wave8 >> 2, tl = threadIdx.x & 255;
     const int key = kblk + wave * 32 + l31;
@@ -851,7 +1554,7 @@ __global__ __launch_bounds__(256 * G) void attn_bwd_dkv_kernel(AttnArgs a) {
         __syncthreads();
         cur ^= 1;
     };
-    for (int qq0 = qstart; qq0 < a.Sq; qq0 += 2 * STEP) {              // the bound is the same for both groups (barriers)
+    for (int qq0 = qstart; qq0 < ((a.dbg & 32) ? 0 : a.Sq); qq0 += 2 * STEP) {              // the bound is the same for both groups (barriers)
         tile_step(ra, qq0);
         if (qq0 + STEP < a.Sq) tile_step(rb, qq0 + STEP);
     }
@@ -892,6 +1595,285 @@ __global__ __launch_bounds__(256 * G) void attn_bwd_dkv_kernel(AttnArgs a) {
     hn_colsum(colred, a.hn[1].partials);
 }
 
+// ------------------------------------------------------------------ backward: dK, dV, second generation (bf16 storage)
+// attn_bwd_dkv_kernel<true, true, 2>'s arithmetic; Q and dO tiles reach LDS once each by DMA, in the image that serves both
+// the row fragments (S^T = Q.K^T, dP^T = dO.V^T) and the transpose reads (dV^T += dO^T.P, dK^T += Q^T.dS) — the first
+// generation staged four tiles (two of them transposed in registers) per step; lse / Delta rows by DMA; K and V rows, the
+// head-norm epilogues' operands and the outputs as in attn_bwd_dq2_kernel.
+__global__ __launch_bounds__(512) void attn_bwd_dkv2_kernel(AttnArgs a) {
+    typedef __bf16 T;
+    constexpr int NS = 3, IMG = 64 * 64 * 2, STAGE = 2 * IMG + 512, GSZ = NS * STAGE, STEP = 128;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];        // [group][stage][Q | dO | lse | delta], 3 x 16 KB images
+    char *pro = smem_raw + 2 * GSZ;                                        // K | V, later raw K | cos | sin
+    char *rawv_img = smem_raw + 81920;                                     // (inside the stages: free after the loop)
+    int bx_, by_;
+    attn_block(a, bx_, by_, false);
+    const int b = by_ / a.heads, hh = by_ % a.heads;
+    const int kblk = bx_ * 128;
+    const int lane = threadIdx.x & 63, wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, l31 = lane & 31;
+    const int wave = wave8 & 3, grp = wave8 >> 2, tg = threadIdx.x & 255;
+    const int kmin = kblk + wave * 32, key = kmin + l31;
+    const bool kvalid = key < a.Sk;
+    const bool kalive = kvalid && !(a.key_mask && a.key_mask[(int64_t)b * a.Sk + key]);     // (older than every DMA)
+    const int kmaxw = kmin + 31;
+    const int qstart = a.causal ? (kblk / 64) * 64 : 0;
+    const int qfirst = qstart + grp * 64;
+    const int nt = qfirst < a.Sq ? (a.Sq - qfirst + STEP - 1) / STEP : 0;
+    const int nt0 = qstart < a.Sq ? (a.Sq - qstart + STEP - 1) / STEP : 0;
+    const int nrows = a.Sk - kblk < 128 ? a.Sk - kblk : 128;
+    dma_rows128(static_cast<const T *>(a.K) + ((int64_t)b * a.Sk + kblk) * a.ldk + hh * 64, a.ldk, nrows, pro, wave8);
+    dma_rows128(static_cast<const T *>(a.V) + ((int64_t)b * a.Sk + kblk) * a.ldv + hh * 64, a.ldv, nrows, pro + 16384, wave8);
+    const T *Qb = static_cast<const T *>(a.Q) + (int64_t)b * a.Sq * a.ldq + hh * 64;
+    const T *dOb = static_cast<const T *>(a.dO) + (int64_t)b * a.Sq * a.lddo + hh * 64;
+    const float *LSEb = a.LSE + ((int64_t)b * a.heads + hh) * a.Sq, *DLb = a.Delta + ((int64_t)b * a.heads + hh) * a.Sq;
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(Qb), 0, (int)((((int64_t)a.Sq - 1) * a.ldq + 64) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(dOb), 0, (int)((((int64_t)a.Sq - 1) * a.lddo + 64) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wave == 0 ? LSEb : DLb), 0, a.Sq * 4, 0x00020000);
+    uint32_t qvo[2], dvo[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = tg + 256 * j, row = p >> 3, pc = p & 7, c = pc ^ (kk_xb(row) << 1);
+        qvo[j] = (uint32_t)(((int64_t)row * a.ldq + c * 8) * 2);
+        dvo[j] = (uint32_t)(((int64_t)row * a.lddo + c * 8) * 2);
+    }
+    char *gbase = smem_raw + grp * GSZ;
+    const uint32_t qtile = (uint32_t)(STEP * a.ldq * 2), dtile = (uint32_t)(STEP * a.lddo * 2);
+    const uint32_t qbeg = (uint32_t)(qfirst * a.ldq * 2), dbeg = (uint32_t)(qfirst * a.lddo * 2);
+    const bool stat_lane = wave < 2 && lane < 16;          // wave 0: the tile's 64 lse values, wave 1: its 64 Delta values
+    auto issue_tile = [&](int t, int st) {
+        char *dst = gbase + st * STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, KK_LDS_PTR(dst + wave * 1024 + j * 4096), 16, qvo[j] + qbeg + (uint32_t)t * qtile, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rdo, KK_LDS_PTR(dst + IMG + wave * 1024 + j * 4096), 16, dvo[j] + dbeg + (uint32_t)t * dtile, 0, 0, 0);
+        if (stat_lane)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rst, KK_LDS_PTR(dst + 2 * IMG + wave * 256), 16, (uint32_t)((qfirst + t * STEP) * 4 + lane * 16), 0, 0, 0);
+    };
+#pragma unroll
+    for (int t = 0; t < NS; ++t)
+        if (t < nt) issue_tile(t, t);
+    // ---- fragment addresses (bytes inside a stage)
+    const uint32_t gl = (uint32_t)(uintptr_t)KK_LDS_PTR(gbase);
+    uint32_t ra_[4], ta[2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) ra_[ks] = (uint32_t)(l31 * 128 + (((2 * ks + half) ^ (kk_xb(l31) << 1)) * 16));
+    {
+        const int L = lane & 15, kq = L >> 2, gi = (lane >> 4) & 1, xb = (((kq >> 1) & 1) << 1) | half;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) ta[db] = (uint32_t)((4 * half + kq) * 128 + (((2 * db + gi) ^ xb) * 32) + 8 * (L & 3));
+    }
+    bf16x8 qr[4], dr[4];
+    s16x4 qlo[4], qhi[4], dlo[4], dhi[4];
+    auto read_rows = [&](uint32_t img) {                   // row fragments of the unit's 32 queries (img = first Q row)
+        asm volatile("ds_read_b128 %0, %1" : "=v"(qr[0]) : "v"(img + ra_[0]));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(qr[1]) : "v"(img + ra_[1]));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(qr[2]) : "v"(img + ra_[2]));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(qr[3]) : "v"(img + ra_[3]));
+        asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(dr[0]) : "v"(img + ra_[0]));
+        asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(dr[1]) : "v"(img + ra_[1]));
+        asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(dr[2]) : "v"(img + ra_[2]));
+        asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(dr[3]) : "v"(img + ra_[3]));
+    };
+    auto wait_lds = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+    RowFrag<true> kf, vf;
+    f32x16 dk[2], dv[2];
+    zero_acc(dk[0]); zero_acc(dk[1]); zero_acc(dv[0]); zero_acc(dv[1]);
+    ProbDrop pd;
+    pd.init(a, b, hh);
+    const float c2 = a.scale * 1.4426950408889634f;
+    const bool anydead = __ballot(!kalive) != 0ull;
+    // ---- prologue: K, V rows and tiles 0, 1 landed (tile 2 may stay in flight)
+    if (nt >= 3) {
+        if (wave < 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    rowfrag_from_image(kf, pro, wave * 32, l31, half);
+    rowfrag_from_image(vf, pro + 16384, wave * 32, l31, half);
+    if (pd.thr) scale_rowfrag<true>(vf, pd.inv_keep);
+    const bool has_hn = a.hn[0].raw != nullptr;
+    bool hn_issued = false;
+    auto unit_live = [&](int qb) { return qb < a.Sq && !(a.causal && qb + 31 < kmin); };
+    bool pref = false;                                     // (wave-uniform) the next live unit's row fragments are in flight
+    int st = 0;
+    for (int t = 0; t < ((a.dbg & 32) ? 0 : nt0); ++t) {
+        const int st1 = st + 1 == NS ? 0 : st + 1;
+        if (t > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t + NS - 1 < nt) issue_tile(t + NS - 1, st == 0 ? NS - 1 : st - 1);
+            if (has_hn && !hn_issued) {
+                hn_dma_inputs(a.hn[0], (int64_t)b * a.Sk + kblk, kblk, nrows, hh, pro, wave8);
+                hn_issued = true;
+            }
+        }
+        const int q0 = qfirst + t * STEP;
+        const uint32_t cur = gl + st * STAGE, nxt = gl + st1 * STAGE;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int qb = q0 + sub * 32;
+            if (!unit_live(qb)) continue;
+            f32x16 s, dp;
+            if (!pref) read_rows(cur + sub * 4096);
+            wait_lds();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qr[ks]), "+v"(dr[ks]));
+            zero_acc(s); zero_acc(dp);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qr[ks], kf.v[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dr[ks], vf.v[ks], dp, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // Register diet (two waves per SIMD: 256 registers, and a spill is fatal here — scratch reloads queue behind the tile
+            // DMAs): lse rows -> P -> Delta rows -> dS, the dO^T fragments fetched under the exponentials, the Q^T fragments under dS.
+            const uint32_t tq0 = cur + sub * 4096 + ta[0], tq1 = cur + sub * 4096 + ta[1];
+            const uint32_t sa_ = cur + 2 * IMG + (uint32_t)((sub * 32 + 4 * half) * 4);
+            f32x4_ st4[4];
+            asm volatile("ds_read_b128 %0, %1" : "=v"(st4[0]) : "v"(sa_));
+            asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(st4[1]) : "v"(sa_));
+            asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(st4[2]) : "v"(sa_));
+            asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(st4[3]) : "v"(sa_));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(dlo[0]) : "v"(tq0));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:9216" : "=v"(dhi[0]) : "v"(tq0));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(dlo[1]) : "v"(tq1));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:9216" : "=v"(dhi[1]) : "v"(tq1));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:10240" : "=v"(dlo[2]) : "v"(tq0));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:11264" : "=v"(dhi[2]) : "v"(tq0));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:10240" : "=v"(dlo[3]) : "v"(tq1));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:11264" : "=v"(dhi[3]) : "v"(tq1));
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                      // the four lse reads
+#pragma unroll
+            for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(st4[g]));
+            const bool edge = anydead || qb + 32 > a.Sq || (a.causal && kmaxw > qb);
+            float p[16], ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(s[r] * c2 - st4[r >> 2][r & 3] * 1.4426950408889634f);
+            if (edge) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qq = qb + frag_row(r, half);
+                    const bool ok = kalive && qq < a.Sq && !(a.causal && key > qq);
+                    p[r] = ok ? p[r] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(p[r]));            // P exists: the lse registers are free
+            asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(st4[0]) : "v"(sa_));
+            asm volatile("ds_read_b128 %0, %1 offset:288" : "=v"(st4[1]) : "v"(sa_));
+            asm volatile("ds_read_b128 %0, %1 offset:320" : "=v"(st4[2]) : "v"(sa_));
+            asm volatile("ds_read_b128 %0, %1 offset:352" : "=v"(st4[3]) : "v"(sa_));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(st4[g]));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(dlo[i]), "+v"(dhi[i]));
+            bf16x8 p8[2], d8[2];
+            if (pd.thr) {
+                const uint32_t xb = pd.row(qb + 4 * half, key);
+                const bool odd = key & 1;
+                uint32_t sk2v = pd.sk2;
+                asm volatile("" : "+s"(sk2v));             // (or the sixteen row offsets are hoisted out of the loop and spilled)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t hsh = pd.hash(xb + (uint32_t)frag_row(r, 0) * sk2v);
+                    const bool keep = odd ? pd.keep_hi(hsh) : pd.keep_lo(hsh);
+                    ds[r] = p[r] * ((keep ? dp[r] : 0.f) - st4[r >> 2][r & 3]);
+                    p[r] = keep ? p[r] : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ds[r] = p[r] * (dp[r] - st4[r >> 2][r & 3]);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) p8[s2][j] = (__bf16)p[8 * s2 + j];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_pair(dlo[s2 * 2 + db], dhi[s2 * 2 + db]), p8[s2], dv[db], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(qlo[0]) : "v"(tq0));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(qhi[0]) : "v"(tq0));
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(qlo[1]) : "v"(tq1));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(qhi[1]) : "v"(tq1));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(qlo[2]) : "v"(tq0));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:3072" : "=v"(qhi[2]) : "v"(tq0));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(qlo[3]) : "v"(tq1));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:3072" : "=v"(qhi[3]) : "v"(tq1));
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d8[s2][j] = (__bf16)ds[8 * s2 + j];
+            wait_lds();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(qlo[i]), "+v"(qhi[i]));
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_pair(qlo[s2 * 2 + db], qhi[s2 * 2 + db]), d8[s2], dk[db], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // the next unit's row fragments (same tile, or the next tile: landed since this iteration's barrier)
+            pref = sub == 0 ? unit_live(qb + 32) : (t + 1 < nt && unit_live(q0 + STEP));
+            if (pref) read_rows(sub == 0 ? cur + 4096 : nxt);
+        }
+        st = st1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (has_hn) {
+        if (!hn_issued) hn_dma_inputs(a.hn[0], (int64_t)b * a.Sk + kblk, kblk, nrows, hh, pro, wave8);
+        dma_rows128(static_cast<const T *>(a.hn[1].raw) + ((int64_t)b * a.Sk + kblk) * a.hn[1].ldraw + hh * 64, a.hn[1].ldraw, nrows, rawv_img, wave8);
+    }
+    {                                // group 1's partial dK / dV -> LDS -> group 0
+        float *mb = reinterpret_cast<float *>(smem_raw) + (wave * 64 + lane) * 65;
+        if (grp == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { mb[r] = dk[0][r]; mb[16 + r] = dk[1][r]; mb[32 + r] = dv[0][r]; mb[48 + r] = dv[1][r]; }
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dk[0][r] += mb[r]; dk[1][r] += mb[16 + r]; dv[0][r] += mb[32 + r]; dv[1][r] += mb[48 + r]; }
+        }
+    }
+    T *dk0 = static_cast<T *>(a.Out) + ((int64_t)b * a.Sk + kmin) * a.ldout + hh * 64;
+    T *dv0 = static_cast<T *>(a.Out2) + ((int64_t)b * a.Sk + kmin) * a.ldout2 + hh * 64;
+    char *otile = smem_raw + 36864 + wave * 4608;
+    if (!has_hn) {
+        if (grp == 0) {
+            store_rows_via_lds(dk0, a.ldout, a.Sk - kmin, dk, a.scale, otile, lane);
+            store_rows_via_lds(dv0, a.ldout2, a.Sk - kmin, dv, pd.inv_keep, otile, lane);
+        }
+        return;
+    }
+    float *colred = reinterpret_cast<float *>(smem_raw);          // [128 rows][65]
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the epilogue images
+    __syncthreads();                                              // ... for every wave; the merge buffer is free
+    f32x16 dx[2];
+    if (grp == 0) {
+        hn_bwd_row2(dk, a.scale, kvalid, pro, pro + 16384, pro + 32768, wave * 32 + l31, a.hn[0].rope != 0, a.hn[0].gain, half,
+                    colred + (wave * 32 + l31) * 65, dx);
+        store_rows_via_lds(dk0, a.ldout, a.Sk - kmin, dx, 1.f, otile, lane);
+    }
+    __syncthreads();
+    hn_colsum(colred, a.hn[0].partials);
+    __syncthreads();
+    if (grp == 0) {
+        hn_bwd_row2(dv, pd.inv_keep, kvalid, rawv_img, nullptr, nullptr, wave * 32 + l31, false, a.hn[1].gain, half,
+                    colred + (wave * 32 + l31) * 65, dx);
+        store_rows_via_lds(dv0, a.ldout2, a.Sk - kmin, dx, 1.f, otile, lane);
+    }
+    __syncthreads();
+    hn_colsum(colred, a.hn[1].partials);
+}
+
 // Delta[b,h,q] = sum_d dO*O : one wave per (row, head).
 template <typename T>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const T *__restrict__ O, const T *__restrict__ dO,
@@ -910,6 +1892,15 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T *__restrict__ O
 }
 
 int g_attn_groups = 2;
+static int attn_v2_mask() {              // bit 0: forward, bit 1: dQ, bit 2: dK/dV second-generation kernels
+    static const int v = getenv("KK_ATTN_V2") ? atoi(getenv("KK_ATTN_V2")) : 7;
+    return v;
+}
+static bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+static int attn_xcd_map() {
+    static const int v = getenv("KK_ATTN_XCD") ? atoi(getenv("KK_ATTN_XCD")) : 1;
+    return v;
+}
 
 // Launch KERNEL<BF16, ST16, G> with G*256 threads and its dynamic LDS (buffers x groups x NT tiles; above 64 KB the
 // kernel attribute has to be raised once).
@@ -971,7 +1962,7 @@ extern "C" int kk_attn_fwd(const float *Q, const float *K, const float *V, float
     a.Q = Q; a.K = K; a.V = V; a.Out = O; a.LSEo = LSE; a.key_mask = key_mask;
     a.B = B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.causal = causal;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldout = ldo; a.scale = scale;
-    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop;
+    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(); a.dbg = getenv("KK_ATTN_DBG") ? atoi(getenv("KK_ATTN_DBG")) : 0;
     dim3 grid(kk_cdiv(Sq, 128), B * heads);
     const int G = (Sk > 64 && g_attn_groups == 2) ? 2 : 1;          // one key tile: nothing to split
     // Four key groups (16 waves): the longest chain of key-tile steps of a 128-query block halves again — a causal block
@@ -980,6 +1971,16 @@ extern "C" int kk_attn_fwd(const float *Q, const float *K, const float *V, float
     if (io_bf16 && fwd_groups4 && G == 2 && Sk >= 256) {
         int rc4 = launch_attn(attn_fwd_kernel<true, true, 4>, grid, 4, KK_ATTN_LDS(true, 4, 2, 0), (hipStream_t)stream, a);
         if (rc4) return rc4;
+        KK_LAUNCH_CHECK("kk_attn_fwd");
+        return 0;
+    }
+    // second-generation kernel (DMA-staged, software-pipelined): bf16 storage, two key groups, 16-byte aligned operands
+    const int fwd_v2 = attn_v2_mask() & 1;
+    if (io_bf16 && fwd_v2 && G == 2 && Sk <= 4096 && (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) == 0 && (int64_t)Sk * std::max(ldk, ldv) * 2 < (1ll << 31)) {
+        static const int ns2 = getenv("KK_ATTN_NS") ? atoi(getenv("KK_ATTN_NS")) : 3;
+        int rc2 = ns2 == 4 ? launch_attn(attn_fwd2_kernel<4>, grid, 2, (size_t)2 * 4 * 16384 + 512 + 16384, (hipStream_t)stream, a)
+                           : launch_attn(attn_fwd2_kernel<3>, grid, 2, (size_t)2 * 3 * 16384 + 512 + 16384, (hipStream_t)stream, a);
+        if (rc2) return rc2;
         KK_LAUNCH_CHECK("kk_attn_fwd");
         return 0;
     }
@@ -1021,13 +2022,20 @@ extern "C" int kk_attn_bwd_dq(const float *Q, const float *K, const float *V, co
         KK_REQUIRE(ldo % 8 == 0 && ldo >= 64 * heads, "kk_attn_bwd_dq: row stride of O unsupported");
         a.O = O; a.ldo = ldo; a.DeltaOut = Delta;
     }
-    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop;
+    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(); a.dbg = getenv("KK_ATTN_DBG") ? atoi(getenv("KK_ATTN_DBG")) : 0;
     if (hn) {
         if (int rc = check_headnorm("kk_attn_bwd_dq", hn, 1)) return rc;
         a.hn[0] = hn[0];
     }
     dim3 grid(kk_cdiv(Sq, 128), B * heads);
     const int G = (Sk > 64 && g_attn_groups == 2) ? 2 : 1;
+    if (io_bf16 && (attn_v2_mask() & 2) && G == 2 && Sk <= 4096 && al16(Q) && al16(K) && al16(V) && al16(dO) && al16(dQ) && (!O || al16(O)) &&
+        (!hn || (al16(hn->raw) && (!hn->rope || (al16(hn->cos_t) && al16(hn->sin_t))))) && (int64_t)Sk * std::max(ldk, ldv) * 2 < (1ll << 31)) {
+        int rc2 = launch_attn(attn_bwd_dq2_kernel, grid, 2, (size_t)2 * 3 * 16384 + 512 + 3 * 16384, (hipStream_t)stream, a);
+        if (rc2) return rc2;
+        KK_LAUNCH_CHECK("kk_attn_bwd_dq");
+        return 0;
+    }
     if (io_bf16) KK_ATTN_LAUNCH(attn_bwd_dq_kernel, true, true, G, 3);
     else if (math == KK_MATH_BF16) KK_ATTN_LAUNCH(attn_bwd_dq_kernel, true, false, G, 3);
     else KK_ATTN_LAUNCH(attn_bwd_dq_kernel, false, false, G, 2);
@@ -1047,13 +2055,21 @@ extern "C" int kk_attn_bwd_dkv(const float *Q, const float *K, const float *V, c
     a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.LSE = LSE; a.Delta = Delta; a.Out = dK; a.Out2 = dV; a.key_mask = key_mask;
     a.B = B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.causal = causal;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.lddo = lddo; a.ldout = lddk; a.ldout2 = lddv; a.scale = scale;
-    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop;
+    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(); a.dbg = getenv("KK_ATTN_DBG") ? atoi(getenv("KK_ATTN_DBG")) : 0;
     if (hn) {
         if (int rc = check_headnorm("kk_attn_bwd_dkv", hn, 2)) return rc;
         a.hn[0] = hn[0]; a.hn[1] = hn[1];
     }
     dim3 grid(kk_cdiv(Sk, 128), B * heads);
     const int G = (Sq > 64 && g_attn_groups == 2) ? 2 : 1;          // one query tile: nothing to split
+    if (io_bf16 && (attn_v2_mask() & 4) && G == 2 && al16(Q) && al16(K) && al16(V) && al16(dO) && al16(dK) && al16(dV) &&
+        (!hn || (al16(hn[0].raw) && al16(hn[1].raw) && !hn[1].rope && (!hn[0].rope || (al16(hn[0].cos_t) && al16(hn[0].sin_t))))) &&
+        (int64_t)Sq * std::max(ldq, lddo) * 2 < (1ll << 31)) {
+        int rc2 = launch_attn(attn_bwd_dkv2_kernel, grid, 2, (size_t)2 * 3 * (16384 + 512) + 3 * 16384, (hipStream_t)stream, a);
+        if (rc2) return rc2;
+        KK_LAUNCH_CHECK("kk_attn_bwd_dkv");
+        return 0;
+    }
     if (io_bf16) KK_ATTN_LAUNCH_X(attn_bwd_dkv_kernel, true, true, G, 4, 2 * G * 128 * sizeof(float));
     else if (math == KK_MATH_BF16) KK_ATTN_LAUNCH_X(attn_bwd_dkv_kernel, true, false, 1, 4, 2 * 128 * sizeof(float));   // (G = 2 would spill)
     else KK_ATTN_LAUNCH_X(attn_bwd_dkv_kernel, false, false, G, 2, 2 * G * 128 * sizeof(float));
