@@ -604,6 +604,25 @@ __device__ __forceinline__ bf16x8 tr_pair(const s16x4 &lo, const s16x4 &hi) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// value of the lane 32 away combined with the own one, by v_permlane32_swap (a VALU instruction; __shfl_xor(.., 32) is a
+// ds_bpermute round trip through the LDS queue): the swap of v with itself returns {own, partner} in some order
+// (inline asm: with this compiler __builtin_amdgcn_permlane32_swap hands back its FIRST result for both elements of the
+// returned pair — `v_add_f32 v, v9, v9` after the swap; the s_nops cover the VALU-write -> swap -> VALU-read wait states)
+__device__ __forceinline__ void xor32_pair(float v, float &lo, float &hi) {
+    lo = v; hi = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+    float a, b;
+    xor32_pair(v, a, b);
+    return a + b;
+}
+__device__ __forceinline__ float xor32_max(float v) {
+    float a, b;
+    xor32_pair(v, a, b);
+    return fmaxf(a, b);
+}
+
 // ---- coalesced prologue / epilogue pieces of the second-generation kernels.  A row-per-lane access (one 128-byte head row
 // per lane: the RowFrag loads, store_row) touches 32 lines per wave instruction and is bound by requests, not bytes
 // (4 us of a 13 us forward launch were the Q loads and the O stores).
@@ -678,6 +697,7 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(AttnArgs a) {
         nu = 2 * full + (rem > 32 ? 2 : (rem > 0 ? 1 : 0));
     }
     RowFrag<true> qf;
+    if (a.dbg & 64) return;                                // (timing probe: the launch alone)
     char *qimg = smem_raw + 2 * GSZ + 512;                 // [128 queries][64] image (the oldest DMA: covered by every wait below)
     dma_rows128(static_cast<const T *>(a.Q) + ((int64_t)b * a.Sq + qblk) * a.ldq + hh * 64, a.ldq, a.Sq - qblk < 128 ? a.Sq - qblk : 128, qimg, wave8);
     const uint8_t *km = a.key_mask ? a.key_mask + (int64_t)b * a.Sk : nullptr;
@@ -796,7 +816,7 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(AttnArgs a) {
         float mx = p[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, p[r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c2;
+        mx = xor32_max(mx) * c2;
         const float mn = fmaxf(m, mx);
         if (__ballot(mn > m) != 0ull) {
             const float alpha = __builtin_amdgcn_exp2f(m - mn);
@@ -808,7 +828,7 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(AttnArgs a) {
         float rs = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(fmaf(p[r], c2, -m)); rs += p[r]; }
-        rs += __shfl_xor(rs, 32, 64);
+        rs = xor32_sum(rs);
         l += rs;
         if (pd.thr) {
             const uint32_t xb = pd.row(q, kb + 4 * half);
@@ -834,6 +854,7 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(AttnArgs a) {
             for (int db = 0; db < 2; ++db)
                 o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_pair(vlo[s2 * 2 + db], vhi[s2 * 2 + db]), pb[s2], o[db], 0, 0, 0);
     };
+    if (a.dbg & 128) return;                               // (timing probe: launch + DMA issue, nothing waited for)
     // ---- prologue: tiles 0 and 1 landed (tile 2 may stay in flight), unit 0's scores, unit 1's K fragments
     if (NS >= 4 && nt >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (nt >= 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -1097,7 +1118,7 @@ __device__ __forceinline__ void hn_bwd_row2(const f32x16 (&acc)[2], float mul, b
     float ssq = 0.f;
 #pragma unroll
     for (int i = 0; i < 32; ++i) ssq += v[i] * v[i];
-    ssq += __shfl_xor(ssq, 32, 64);
+    ssq = xor32_sum(ssq);
     const float rs = 1.f / sqrtf(ssq * (1.f / 64.f) + 1.1920928955078125e-7f);
     if (rope) {
 #pragma unroll
@@ -1128,7 +1149,7 @@ __device__ __forceinline__ void hn_bwd_row2(const f32x16 (&acc)[2], float mul, b
                 kdot += dn[i] * v[i];
             }
         }
-    kdot += __shfl_xor(kdot, 32, 64);
+    kdot = xor32_sum(kdot);
     const float k = kdot * (1.f / 64.f) * rs * rs * rs;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -1331,7 +1352,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq2_kernel(AttnArgs a) {
         RowFrag<true> of;
         rowfrag_from_image(of, pro + 32768, wave * 32, l31, half);
         dlt = rowfrag_dot<true>(dof, of);
-        dlt += __shfl_xor(dlt, 32, 64);
+        dlt = xor32_sum(dlt);
         if (qvalid && half == 0 && grp == 0) a.DeltaOut[statrow] = dlt;
     }
     if (pd.thr) scale_rowfrag<true>(dof, pd.inv_keep);

@@ -672,7 +672,8 @@ BF = (2e-2, 1e-2)   # (atol, rtol): one bf16 rounding (2^-8 relative) of O(1) ou
 
 
 @pytest.mark.parametrize("B,h,Sq,Sk,causal,masked,strided", [(2, 2, 64, 64, 0, 1, 0), (1, 2, 200, 200, 1, 0, 1),
-                                                              (2, 1, 37, 150, 0, 1, 0), (1, 8, 300, 300, 1, 0, 1)])
+                                                              (2, 1, 37, 150, 0, 1, 0), (1, 8, 300, 300, 1, 0, 1),
+                                                              (1, 2, 1100, 1100, 1, 1, 1), (1, 2, 777, 1030, 0, 1, 0)])
 def test_attention_bf16_storage(kk, B, h, Sq, Sk, causal, masked, strided):
     g = torch.Generator().manual_seed(Sq + 7 * Sk + causal)
     H = h * 64
@@ -1137,6 +1138,7 @@ def test_gemm_qkv_headnorm_epilogue(kk, T, parts, heads, K, S, rope):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,h,Sq,Sk,causal,rope,bf16,p", [(2, 4, 200, 200, 1, 1, 1, 0.0), (2, 2, 64, 64, 0, 1, 1, 0.1), (1, 8, 512, 512, 1, 1, 1, 0.1),
+                                                         (1, 2, 900, 1000, 0, 1, 1, 0.1), (1, 2, 1000, 1000, 1, 1, 1, 0.2),
                                                          (2, 2, 130, 70, 0, 0, 1, 0.0), (2, 2, 100, 100, 1, 1, 0, 0.0)])
 def test_attention_backward_headnorm_epilogue(kk, B, h, Sq, Sk, causal, rope, bf16, p):
     """kk_attn_bwd_dq / kk_attn_bwd_dkv with the head-norm descriptors == the plain kernels followed by
