@@ -1794,16 +1794,28 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv2_kernel(AttnArgs a) {
             for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(dlo[i]), "+v"(dhi[i]));
             bf16x8 p8[2], d8[2];
             if (pd.thr) {
-                const uint32_t xb = pd.row(qb + 4 * half, key);
-                const bool odd = key & 1;
+                // The keep decisions of (q, key) and (q, key ^ 1) are the two 16-bit fields of ONE hash (ProbDrop), and lanes l, l ^ 1
+                // own such a key pair: the even lane hashes the even query rows of the accumulator, the odd lane the odd ones, each
+                // keeps its own field and hands the other one to its neighbour through DPP — 8 hashes per unit instead of 16, the
+                // same mask bit for bit.  Which of (own, received) belongs to a given register is a function of the lane parity:
+                // resolved on the comparison masks (scalar xor / and), the selects read them directly.
                 uint32_t sk2v = pd.sk2;
-                asm volatile("" : "+s"(sk2v));             // (or the sixteen row offsets are hoisted out of the loop and spilled)
+                asm volatile("" : "+s"(sk2v));             // (or the row offsets are hoisted out of the loop and spilled)
+                const uint32_t par = (uint32_t)key & 1u, shm = 16u * par, shs = 16u - shm;
+                const uint32_t xbp = pd.row(qb + 4 * half, key) + par * sk2v;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const uint32_t hsh = pd.hash(xb + (uint32_t)frag_row(r, 0) * sk2v);
-                    const bool keep = odd ? pd.keep_hi(hsh) : pd.keep_lo(hsh);
-                    ds[r] = p[r] * ((keep ? dp[r] : 0.f) - st4[r >> 2][r & 3]);
-                    p[r] = keep ? p[r] : 0.f;
+                for (int i = 0; i < 8; ++i) {
+                    const uint32_t hsh = pd.hash(xbp + (uint32_t)frag_row(2 * i, 0) * sk2v);
+                    const uint32_t mine = (hsh >> shm) & 0xFFFFu, send = (hsh >> shs) & 0xFFFFu;
+                    const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xF, 0xF, true);      // lane ^ 1
+                    const uint64_t cm = __builtin_amdgcn_uicmp(mine, pd.thr, 35), cr = __builtin_amdgcn_uicmp(recv, pd.thr, 35);   // >=
+                    const uint64_t u = (cm ^ cr) & 0xAAAAAAAAAAAAAAAAull;
+                    const bool k0 = __builtin_amdgcn_inverse_ballot_w64(cm ^ u), k1 = __builtin_amdgcn_inverse_ballot_w64(cr ^ u);
+                    const int r0 = 2 * i, r1 = 2 * i + 1;
+                    ds[r0] = p[r0] * ((k0 ? dp[r0] : 0.f) - st4[r0 >> 2][r0 & 3]);
+                    p[r0] = k0 ? p[r0] : 0.f;
+                    ds[r1] = p[r1] * ((k1 ? dp[r1] : 0.f) - st4[r1 >> 2][r1 & 3]);
+                    p[r1] = k1 ? p[r1] : 0.f;
                 }
             } else {
 #pragma unroll
