@@ -111,7 +111,9 @@ typedef struct {
     const void *raw; int64_t ldraw;     /* the projection output the norm was applied to, [rows, >= heads*64] */
     const float *gain;                  /* [64] */
     float *partials;                    /* [kk_attn_bwd_blocks(B, heads, S)][64] */
-    const float *cos_t, *sin_t;         /* [S, 64] RoPE tables (rope != 0) */
+    const float *cos_t, *sin_t;         /* [S, 64] rotate-half RoPE tables (rope != 0): columns d and d + 32 are identical, as
+                                           positional_encoding.py:129-150 builds them (emb = cat(freqs, freqs)); the bf16-storage
+                                           kernels stage columns 0..31 only */
     int rope;
 } KkAttnHeadNorm;
 int kk_attn_bwd_blocks(int B, int heads, int S);   /* S = Sq for kk_attn_bwd_dq, Sk for kk_attn_bwd_dkv */

@@ -1929,6 +1929,10 @@ static int attn_v2_mask() {              // bit 0: forward, bit 1: dQ, bit 2: dK
     static const int v = getenv("KK_ATTN_V2") ? atoi(getenv("KK_ATTN_V2")) : 7;
     return v;
 }
+static int attn_dbg() {                  // timing probes of tools/probes (results are wrong when set)
+    static const int v = getenv("KK_ATTN_DBG") ? atoi(getenv("KK_ATTN_DBG")) : 0;
+    return v;
+}
 static bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 static int attn_xcd_map() {
     static const int v = getenv("KK_ATTN_XCD") ? atoi(getenv("KK_ATTN_XCD")) : 1;
@@ -1995,7 +1999,7 @@ extern "C" int kk_attn_fwd(const float *Q, const float *K, const float *V, float
     a.Q = Q; a.K = K; a.V = V; a.Out = O; a.LSEo = LSE; a.key_mask = key_mask;
     a.B = B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.causal = causal;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldout = ldo; a.scale = scale;
-    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(); a.dbg = getenv("KK_ATTN_DBG") ? atoi(getenv("KK_ATTN_DBG")) : 0;
+    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(); a.dbg = attn_dbg();
     dim3 grid(kk_cdiv(Sq, 128), B * heads);
     const int G = (Sk > 64 && g_attn_groups == 2) ? 2 : 1;          // one key tile: nothing to split
     // Four key groups (16 waves): the longest chain of key-tile steps of a 128-query block halves again — a causal block
@@ -2055,7 +2059,7 @@ extern "C" int kk_attn_bwd_dq(const float *Q, const float *K, const float *V, co
         KK_REQUIRE(ldo % 8 == 0 && ldo >= 64 * heads, "kk_attn_bwd_dq: row stride of O unsupported");
         a.O = O; a.ldo = ldo; a.DeltaOut = Delta;
     }
-    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(); a.dbg = getenv("KK_ATTN_DBG") ? atoi(getenv("KK_ATTN_DBG")) : 0;
+    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(); a.dbg = attn_dbg();
     if (hn) {
         if (int rc = check_headnorm("kk_attn_bwd_dq", hn, 1)) return rc;
         a.hn[0] = hn[0];
@@ -2088,7 +2092,7 @@ extern "C" int kk_attn_bwd_dkv(const float *Q, const float *K, const float *V, c
     a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.LSE = LSE; a.Delta = Delta; a.Out = dK; a.Out2 = dV; a.key_mask = key_mask;
     a.B = B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.causal = causal;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.lddo = lddo; a.ldout = lddk; a.ldout2 = lddv; a.scale = scale;
-    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(); a.dbg = getenv("KK_ATTN_DBG") ? atoi(getenv("KK_ATTN_DBG")) : 0;
+    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(); a.dbg = attn_dbg();
     if (hn) {
         if (int rc = check_headnorm("kk_attn_bwd_dkv", hn, 2)) return rc;
         a.hn[0] = hn[0]; a.hn[1] = hn[1];
