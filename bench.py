@@ -218,8 +218,40 @@ def main():
             sync(eng.arena.g)
             eng.optimizer_step(T)
 
-    for _ in range(max(args.warmup, 2)):       # >= 2: first call allocates workspaces, second captures the graphs
-        step()
+    def warm():
+        for _ in range(max(args.warmup, 2)):   # >= 2: first call allocates workspaces, second captures the graphs
+            step()
+
+    replicas_ok = None
+    try:
+        warm()
+        if world > 1 or force:
+            replicas_ok = dp.replicas_in_step(eng.arena.p)
+    except Exception as e:                     # (a hang cannot be caught; an error of the in-graph exchange can)
+        if not dp_mode.startswith("in-graph"):
+            raise
+        print(f"[bench] rank {rank}: in-graph exchange failed ({e}); falling back to the after-the-backward all-reduce", file=sys.stderr)
+        replicas_ok = False
+    if dp_mode.startswith("in-graph") and world > 1:
+        # every rank must take the same branch: any rank that saw an error or diverged replicas sends all of them to the
+        # round-1 form (one torch.distributed all-reduce between the backward graph and the optimizer graph)
+        bad = torch.tensor([0.0 if replicas_ok else 1.0], device="cuda")
+        dp.all_max(bad)
+        if float(bad) > 0:
+            if rank == 0:
+                print("[bench] replicas out of step after the in-graph exchange; using the torch.distributed all-reduce", file=sys.stderr)
+            eng.dp_comm = None
+            eng._graphs.clear()
+            dist_p = eng.arena.p.clone()
+            torch.distributed.broadcast(dist_p, src=0)          # re-align the replicas on rank 0's weights and state
+            eng.arena.p.copy_(dist_p)
+            for slab in (eng.arena.m, eng.arena.v, eng.arena.ema, eng.opt_state):
+                torch.distributed.broadcast(slab, src=0)
+            eng.sync_shadow()
+            dp_mode = "legacy (fallback)"
+            step = lambda: eng.train_step_graphed(batch, sync)   # noqa: E731
+            warm()
+            replicas_ok = dp.replicas_in_step(eng.arena.p)
     dp.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -291,6 +323,7 @@ def main():
                                          ("2 buckets, first overlapped with the backward of decoder layers < %d" % eng.dp_overlap_layer)
                                          if (use_sync and not args.no_graph and eng.dp_overlap_layer is not None) else
                                          ("after the backward (torch.distributed)" if use_sync else "none (1 GPU)")),
+                      "replicas_in_step": replicas_ok,       # bit-identical weights on every rank after the warm-up (None: 1 GPU)
                       "grad_accumulation": 1,
                       "dropout": ("off (p=0 parity configuration)" if args.no_dropout else
                                   "on: enc 0.15 / dec 0.20 / dec-input 0.15 / variance 0.10, stochastic depth 0.1, SpecAugment (config.py defaults)"),

@@ -229,6 +229,20 @@ def all_max(x: torch.Tensor) -> torch.Tensor:
     return x
 
 
+def replicas_in_step(flat_params: torch.Tensor) -> bool:
+    """True when every rank holds bit-identical parameters (data-parallel replicas never exchange weights: identical reduced
+    gradients through the identical optimizer pass keep them equal, so any difference means the exchange went wrong).
+    Two fp64 checksums (sum, sum of squares), MIN- and MAX-reduced; collective — call it on every rank."""
+    x = flat_params.double()
+    chk = torch.stack([x.sum(), (x * x).sum()])
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return bool(torch.isfinite(chk).all())
+    lo, hi = chk.clone(), chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return bool(torch.isfinite(hi).all() and torch.equal(lo, hi))
+
+
 def barrier() -> None:
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
