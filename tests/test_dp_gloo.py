@@ -187,8 +187,14 @@ def _bucket_worker(rank, world, port, q):
     for tag in ex.plan:                                                  # the engine issues the buckets in this order
         ex.reduce(flat, tag)
     dp.barrier()
+    # bench.py's guard: after the exchange every rank holds the same arena; one differing element on one rank is seen
+    in_step = dp.replicas_in_step(flat)
+    other = flat.clone()
+    if rank == 1:
+        other[total // 2] += 1e-3
+    diverged_seen = not dp.replicas_in_step(other)
     if rank == 0:
-        q.put((bool(torch.equal(flat, whole)), list(ex.issued)))
+        q.put((bool(torch.equal(flat, whole)), list(ex.issued), in_step, diverged_seen))
     dist.destroy_process_group()
 
 
@@ -199,9 +205,10 @@ def test_bucketed_exchange_two_ranks_equals_one_all_reduce():
     procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    same, issued = q.get(timeout=300)
+    same, issued, in_step, diverged_seen = q.get(timeout=300)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert same, "bucket by bucket must give exactly the sum of the whole arena"
+    assert in_step and diverged_seen, "replicas_in_step must accept equal arenas and flag one differing element"
     assert issued == ["dec1", "dec0", "enc1", "enc0", "tail"]
