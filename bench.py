@@ -83,6 +83,17 @@ def kernel_table(records, math_bf16: bool):
             N_ = parts * heads * 64
             key = f"gemm16_kernel<false,false,64,64,{2 if K_ // 64 < 3 else 3},3> (q|k|v projection + head-norm epilogue)"
             flops, byts = 2.0 * T_ * N_ * K_, 2.0 * (T_ * K_ + N_ * K_ + 2 * T_ * N_)
+        elif name == "kk_gemm_dgrad_delta":             # (M, N, K, ...): the w_o dgrad with the Delta epilogue, same instantiation as kk_gemm's
+            M, N, K = (int(x) for x in sc[:3])
+            ta, tb = 0, 1
+            key = gemm_symbol(0, 1, M, N, K, math_bf16, 7)
+            flops, byts = 2.0 * M * N * K, 2.0 * (M * K + N * K + 2 * M * N)
+        elif name == "kk_attn_bwd":                     # (B, h, Sq, Sk, 7 row strides, causal, scale, site, p_drop, math, io_bf16)
+            B, h, Sq, Sk = (int(x) for x in sc[:4])
+            causal = int(sc[-6])
+            key = "attn_bwd_pair2_kernel (dQ | dK, dV in one launch)"
+            flops = 7 * 2.0 * B * h * Sq * Sk * 64 * (0.5 if causal else 1.0)
+            byts = (2.0 if int(sc[-1]) else 4.0) * B * h * 64 * (4 * Sq + 4 * Sk)
         elif name in ("kk_attn_fwd", "kk_attn_bwd_dq", "kk_attn_bwd_dkv"):
             B, h, Sq, Sk = (int(x) for x in sc[:4])
             off = 1 if name == "kk_attn_bwd_dq" else 0       # (..., causal, scale, site, p_drop, math, io_bf16[, ldo])
@@ -91,7 +102,7 @@ def kernel_table(records, math_bf16: bool):
             flops = mm * 2.0 * B * h * Sq * Sk * 64 * (0.5 if causal else 1.0)
             byts = (2.0 if int(sc[-1 - off]) else 4.0) * B * h * 64 * (2 * Sq + 2 * Sk)
         keys = [key]
-        if name == "kk_gemm":
+        if name in ("kk_gemm", "kk_gemm_dgrad_delta"):
             keys.append(f"  shape ta={ta} tb={tb} M={M} N={N} K={K}")
         elif name.startswith("kk_attn_") and name != "kk_attn_delta":
             keys.append(f"  shape {name} B={B} h={h} Sq={Sq} Sk={Sk} causal={causal}")

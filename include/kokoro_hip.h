@@ -72,6 +72,14 @@ int kk_gemm_qkv_headnorm(int64_t T, int parts, int heads, int64_t K, const void 
  * workgroup owns a column block of BOTH halves.  bf16 operands and outputs.  Replaces kk_gemm + kk_glu_fwd. */
 int kk_gemm_linear_glu(int64_t T, int64_t F, int64_t K, const void *x, int64_t ldx, const void *W, const float *bias,
                        void *h1, void *g, int64_t ldg, const uint32_t *seed, uint32_t site, float p, void *stream);
+/* dX[M,N] = dY[M,K].W[K,N] of an attention OUTPUT projection (w_o backward, transformers.py:398 `self.w_o(context)`), bf16
+ * operands and result, with the attention backward's row term as the epilogue: a 128x64 tile's columns are one head, so
+ * Delta[b, head, q] = sum_d dX[b*S+q, 64*head+d] * O[b*S+q, 64*head+d] (fp32, [B, heads, S]) leaves with the tile.  Replaces
+ * kk_gemm (dgrad) + the Delta pass inside kk_attn_bwd_dq / kk_attn_delta.  Only shapes that take the eight-wave 128x64 tile
+ * (ask _supported). */
+int kk_gemm_dgrad_delta_supported(int64_t M, int64_t N, int64_t K);
+int kk_gemm_dgrad_delta(int64_t M, int64_t N, int64_t K, const void *dy, int64_t lddy, const void *W, int64_t ldw,
+                        void *dx, int64_t lddx, const void *O, int64_t ldo, float *delta, int S, int heads, void *stream);
 /* GLU feed-forward backward (autograd of transformers.py:105-108), fused: dG = dy[T,H] . W[H,F] (the linear2 dgrad; bf16 operands, W row-major [H,F]) with the
  * gate's backward as the epilogue — dh1[T,2F] is written directly from h1[T,2F] = [a | b] saved by the forward and the
  * gate's dropout mask (seed, site, p as in kk_glu_fwd); the column sums of dh1 (linear1's bias gradient) go to
@@ -129,6 +137,16 @@ int kk_attn_bwd_dkv(const float *Q, const float *K, const float *V, const float 
                     int64_t ldk, int64_t ldv, int64_t lddo, int64_t lddk, int64_t lddv,
                     const uint8_t *key_mask, int causal, float scale, const uint32_t *seed, uint32_t site,
                     float p_drop, int math, int io_bf16, const KkAttnHeadNorm *hn, void *stream);
+/* dQ, dK and dV of one attention in ONE launch (bf16 storage, two key groups: the second-generation kernels of the two
+ * calls above as the z = 0 / z = 1 halves of one grid; any other case runs them as two launches, in order).  Delta is an
+ * INPUT (kk_gemm_dgrad_delta writes it with dO; or kk_attn_delta), so the halves are independent: on a causal launch the
+ * CUs that finish a short dQ block pick up the long dK/dV blocks.  hn_q: one descriptor, hn_kv: two (both or neither).
+ * Same call sites as the two calls above (transformers.py:393-398 backward). */
+int kk_attn_bwd(const float *Q, const float *K, const float *V, const float *dO, const float *LSE, const float *Delta,
+                float *dQ, float *dK, float *dV, int B, int heads, int Sq, int Sk, int64_t ldq, int64_t ldk,
+                int64_t ldv, int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, const uint8_t *key_mask,
+                int causal, float scale, const uint32_t *seed, uint32_t site, float p_drop, int math, int io_bf16,
+                const KkAttnHeadNorm *hn_q, const KkAttnHeadNorm *hn_kv, void *stream);
 
 /* ---- norms ----
  * LayerNorm (nn.LayerNorm eps 1e-5; transformers.py:461-462,518-520,612; model.py:122). */

@@ -45,6 +45,7 @@ def build(force: bool = False, verbose: bool = False, tuning: bool = False) -> s
         (open(stamp, "w").close() if tuning else os.remove(stamp))
     flags = FLAGS + (["-DKK_TUNING_HOOKS"] if tuning else [])
     headers = [os.path.join(CSRC, "kk_common.h"), os.path.join(os.path.dirname(HERE), "include", "kokoro_hip.h")]
+    headers += [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".inc")]      # kernel bodies included by kk_attn.hip
 
     def compile_one(src: str) -> str:
         s = os.path.join(CSRC, src)

@@ -57,7 +57,7 @@ struct AttnArgs {
 struct ProbDrop {
     uint32_t thr, key, sk2;      // thr == 0: dropout off
     float inv_keep;
-    __device__ __forceinline__ void init(const AttnArgs &a, int b, int hh) {
+    template <typename A> __device__ __forceinline__ void init(A &a, int b, int hh) {
         thr = 0u;
         if (a.seed && a.p_drop > 0.f) {
             thr = (uint32_t)(a.p_drop * 65536.f + 0.5f);
@@ -85,14 +85,23 @@ struct ProbDrop {
 // Workgroup -> (128-row block, batch*head).  The dispatcher places workgroup i (x fastest) on XCD i % 8, each with a private
 // L2: in launch order the row blocks of one (batch, head) land on up to eight XCDs and every one of those L2s fetches that
 // head's K and V (Q and dO in the dK/dV kernel) again.  With xcd_map set, the workgroups of XCD x are the blocks of the
-// (batch, head) pairs = x (mod 8): a head's operands are fetched by one L2.  For causal launches the long blocks go first.
-__device__ __forceinline__ void attn_block(const AttnArgs &a, int &bx, int &by, bool long_first_is_high) {
+// (batch, head) pairs = x (mod 8): a head's operands are fetched by one L2.  For causal launches the long blocks go first:
+// per head (xcd_map = 1), or — xcd_map = 2, the causal pair launch of the backward — the longest blocks of ALL of an XCD's heads,
+// then the second longest, ...: the dK/dV half of that launch is handed out as CUs finish their dQ block, and only in this order
+// do the CUs that held the shortest dQ blocks receive the longest dK/dV blocks (5 block-units per CU instead of 7).
+template <typename A> __device__ __forceinline__ void attn_block(A &a, int &bx, int &by, bool long_first_is_high) {
     bx = blockIdx.x; by = blockIdx.y;
     const int nx = gridDim.x, ny = gridDim.y;
     if (a.xcd_map && (ny & 7) == 0) {
         const int L = bx + nx * by, slot = L >> 3;
-        by = (L & 7) + 8 * (slot / nx);
-        bx = slot % nx;
+        if (a.xcd_map == 2) {                                  // block-major inside an XCD: ALL its longest blocks first (pair launch)
+            const int per = ny >> 3;
+            by = (L & 7) + 8 * (slot % per);
+            bx = slot / per;
+        } else {
+            by = (L & 7) + 8 * (slot / nx);
+            bx = slot % nx;
+        }
     }
     if (a.causal && a.xcd_map) bx = long_first_is_high ? nx - 1 - bx : bx;
 }
@@ -1157,7 +1166,7 @@ __device__ __forceinline__ void hn_bwd_row2(const f32x16 (&acc)[2], float mul, b
         for (int r = 0; r < 16; ++r) out[db][r] = rs * dn[db * 16 + r] - v[db * 16 + r] * k;
 }
 // the three epilogue images of a 128-row block (rows row0 .. of a sequence of S rows, position = row): raw | cos | sin
-__device__ __forceinline__ void hn_dma_inputs(const KkAttnHeadNorm &h, int64_t seq_row0, int pos0, int nrows, int hh, char *img, int wave8) {
+template <typename HN> __device__ __forceinline__ void hn_dma_inputs(HN &h, int64_t seq_row0, int pos0, int nrows, int hh, char *img, int wave8) {
     dma_rows128(static_cast<const __bf16 *>(h.raw) + seq_row0 * h.ldraw + hh * 64, h.ldraw, nrows, img, wave8);
     if (h.rope) {       // (fp32 rows of 64 = 128 bf16-sized elements; the first 128 bytes of each)
         dma_rows128(reinterpret_cast<const __bf16 *>(h.cos_t + (int64_t)pos0 * 64), 128, nrows, img + 16384, wave8);
@@ -1170,274 +1179,7 @@ __device__ __forceinline__ void hn_dma_inputs(const KkAttnHeadNorm &h, int64_t s
 // that serves both the row fragments of S = K.Q^T and the transpose reads of dQ^T += K^T.dS^T), Q / dO / O rows by DMA (Delta
 // from the fragments), the scores and dP of unit u+1 issued before the exponentials of unit u, the head-norm epilogue's
 // operands prefetched into the prologue's LDS while the loop runs, 16-byte coalesced stores.
-__global__ __launch_bounds__(512) void attn_bwd_dq2_kernel(AttnArgs a) {
-    typedef __bf16 T;
-    constexpr int NS = 3, KIMG = 64 * 64 * 2, STAGE = 2 * KIMG, GSZ = NS * STAGE, STEP = 128;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];        // [group][stage][K | V], mask words, 3 x 16 KB images
-    uint64_t *kmb = reinterpret_cast<uint64_t *>(smem_raw + 2 * GSZ);
-    char *pro = smem_raw + 2 * GSZ + 512;                                  // Q | dO | O, later raw | cos | sin
-    int bx_, by_;
-    attn_block(a, bx_, by_, true);
-    const int b = by_ / a.heads, hh = by_ % a.heads;
-    const int qblk = bx_ * 128;
-    const int lane = threadIdx.x & 63, wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, l31 = lane & 31;
-    const int wave = wave8 & 3, grp = wave8 >> 2, tg = threadIdx.x & 255;
-    const int q = qblk + wave * 32 + l31;
-    const bool qvalid = q < a.Sq;
-    const int qmin = qblk + wave * 32;
-    int kend = a.Sk;
-    if (a.causal && qblk + 128 < kend) kend = qblk + 128;
-    int klim = kend;
-    if (a.causal && qmin + 32 < klim) klim = qmin + 32;
-    const int kfirst = grp * 64;
-    const int nt = kfirst < kend ? (kend - kfirst + STEP - 1) / STEP : 0;
-    const int nt0 = (kend + STEP - 1) / STEP;
-    int nu = 0;
-    if (klim > kfirst) {
-        const int full = (klim - kfirst) / STEP, rem = (klim - kfirst) - full * STEP;
-        nu = 2 * full + (rem > 32 ? 2 : (rem > 0 ? 1 : 0));
-    }
-    // every other global read is issued before the tile DMAs (the counted vmcnt waits assume the tiles are the youngest)
-    const int64_t statrow = ((int64_t)b * a.heads + hh) * a.Sq + q;
-    float lse2 = qvalid ? a.LSE[statrow] * 1.4426950408889634f : INFINITY;
-    const bool want_delta = a.DeltaOut != nullptr;
-    float dlt = (!want_delta && qvalid) ? a.Delta[statrow] : 0.f;
-    const uint8_t *km = a.key_mask ? a.key_mask + (int64_t)b * a.Sk : nullptr;
-    uint32_t kmv[8];
-    if (km) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int key = (wave8 + 8 * i) * 64 + lane;
-            kmv[i] = key < kend ? km[key] : 0u;
-        }
-    }
-    const int nrows = a.Sq - qblk < 128 ? a.Sq - qblk : 128;
-    dma_rows128(static_cast<const T *>(a.Q) + ((int64_t)b * a.Sq + qblk) * a.ldq + hh * 64, a.ldq, nrows, pro, wave8);
-    dma_rows128(static_cast<const T *>(a.dO) + ((int64_t)b * a.Sq + qblk) * a.lddo + hh * 64, a.lddo, nrows, pro + 16384, wave8);
-    if (want_delta) dma_rows128(static_cast<const T *>(a.O) + ((int64_t)b * a.Sq + qblk) * a.ldo + hh * 64, a.ldo, nrows, pro + 32768, wave8);
-    const T *Kb = static_cast<const T *>(a.K) + (int64_t)b * a.Sk * a.ldk + hh * 64;
-    const T *Vb = static_cast<const T *>(a.V) + (int64_t)b * a.Sk * a.ldv + hh * 64;
-    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(Kb), 0, (int)((((int64_t)a.Sk - 1) * a.ldk + 64) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(Vb), 0, (int)((((int64_t)a.Sk - 1) * a.ldv + 64) * 2), 0x00020000);
-    uint32_t kvo[2], vvo[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int p = tg + 256 * j, row = p >> 3, pc = p & 7;
-        kvo[j] = (uint32_t)(((int64_t)row * a.ldk + ((pc ^ (kk_xb(row) << 1)) * 8)) * 2);
-        vvo[j] = (uint32_t)(((int64_t)row * a.ldv + ((pc ^ ((row >> 1) & 7)) * 8)) * 2);
-    }
-    char *gbase = smem_raw + grp * GSZ;
-    const uint32_t ktile = (uint32_t)(STEP * a.ldk * 2), vtile = (uint32_t)(STEP * a.ldv * 2);
-    const uint32_t kbeg = (uint32_t)(kfirst * a.ldk * 2), vbeg = (uint32_t)(kfirst * a.ldv * 2);
-    auto issue_tile = [&](int t, int st) {
-        char *dst = gbase + st * STAGE + wave * 1024;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, KK_LDS_PTR(dst + j * 4096), 16, kvo[j] + kbeg + (uint32_t)t * ktile, 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, KK_LDS_PTR(dst + KIMG + j * 4096), 16, vvo[j] + vbeg + (uint32_t)t * vtile, 0, 0, 0);
-    };
-#pragma unroll
-    for (int t = 0; t < NS; ++t)
-        if (t < nt) issue_tile(t, t);
-    if (km) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const uint64_t bits = __ballot(kmv[i] != 0u);
-            if (lane == 0) kmb[wave8 + 8 * i] = bits;
-        }
-    }
-    // ---- fragment addresses (bytes inside a stage)
-    const uint32_t gl = (uint32_t)(uintptr_t)KK_LDS_PTR(gbase);
-    uint32_t ka[4], va[4], ta[2];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        ka[ks] = (uint32_t)(l31 * 128 + (((2 * ks + half) ^ (kk_xb(l31) << 1)) * 16));
-        va[ks] = (uint32_t)(KIMG + l31 * 128 + (((2 * ks + half) ^ ((l31 >> 1) & 7)) * 16));
-    }
-    {
-        const int L = lane & 15, kq = L >> 2, gi = (lane >> 4) & 1, xb = (((kq >> 1) & 1) << 1) | half;
-#pragma unroll
-        for (int db = 0; db < 2; ++db) ta[db] = (uint32_t)((4 * half + kq) * 128 + (((2 * db + gi) ^ xb) * 32) + 8 * (L & 3));
-    }
-    bf16x8 kf[4], vf[4];
-    s16x4 tlo[4], thi[4];
-    auto read_kv = [&](uint32_t img) {                     // row fragments of the unit's 32 keys (img = its first K row)
-        asm volatile("ds_read_b128 %0, %1" : "=v"(kf[0]) : "v"(img + ka[0]));
-        asm volatile("ds_read_b128 %0, %1" : "=v"(kf[1]) : "v"(img + ka[1]));
-        asm volatile("ds_read_b128 %0, %1" : "=v"(kf[2]) : "v"(img + ka[2]));
-        asm volatile("ds_read_b128 %0, %1" : "=v"(kf[3]) : "v"(img + ka[3]));
-        asm volatile("ds_read_b128 %0, %1" : "=v"(vf[0]) : "v"(img + va[0]));
-        asm volatile("ds_read_b128 %0, %1" : "=v"(vf[1]) : "v"(img + va[1]));
-        asm volatile("ds_read_b128 %0, %1" : "=v"(vf[2]) : "v"(img + va[2]));
-        asm volatile("ds_read_b128 %0, %1" : "=v"(vf[3]) : "v"(img + va[3]));
-    };
-    auto read_kt = [&](uint32_t img) {                     // K^T fragments of the same keys
-        const uint32_t a0 = img + ta[0], a1 = img + ta[1];
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(tlo[0]) : "v"(a0));
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(thi[0]) : "v"(a0));
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(tlo[1]) : "v"(a1));
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(thi[1]) : "v"(a1));
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(tlo[2]) : "v"(a0));
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:3072" : "=v"(thi[2]) : "v"(a0));
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(tlo[3]) : "v"(a1));
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:3072" : "=v"(thi[3]) : "v"(a1));
-    };
-    auto wait_lds = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
-    RowFrag<true> qf, dof;
-    auto scores = [&](f32x16 &s, f32x16 &dp) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));
-        zero_acc(s); zero_acc(dp);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf.v[ks], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[ks], dof.v[ks], dp, 0, 0, 0);
-        }
-    };
-    f32x16 dq[2];
-    zero_acc(dq[0]); zero_acc(dq[1]);
-    const float c2 = a.scale * 1.4426950408889634f;
-    ProbDrop pd;
-    pd.init(a, b, hh);
-    auto ds_unit = [&](const f32x16 &s, const f32x16 &dp, int kb, uint32_t kmsub, bf16x8 (&db8)[2]) {
-        const bool edge = kb + 32 > a.Sk || (a.causal && kb + 31 > qmin) || kmsub != 0u;
-        float pv[16], ds[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) pv[r] = __builtin_amdgcn_exp2f(s[r] * c2 - lse2);
-        if (edge) {
-            const uint32_t kml = kmsub >> (4 * half);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kb + frag_row(r, half);
-                const bool ok = key < a.Sk && !(a.causal && key > q) && !((kml >> frag_row(r, 0)) & 1u);
-                pv[r] = ok ? pv[r] : 0.f;
-            }
-        }
-        if (pd.thr) {
-            const uint32_t xb = pd.row(q, kb + 4 * half);
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const uint32_t hsh = pd.hash(xb + (uint32_t)(frag_row(r, 0) >> 1));
-                ds[r] = pv[r] * ((pd.keep_lo(hsh) ? dp[r] : 0.f) - dlt);
-                ds[r + 1] = pv[r + 1] * ((pd.keep_hi(hsh) ? dp[r + 1] : 0.f) - dlt);
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ds[r] = pv[r] * (dp[r] - dlt);
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) db8[s2][j] = (__bf16)ds[8 * s2 + j];
-    };
-    auto dq_acc = [&](const bf16x8 (&db8)[2]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(tlo[i]), "+v"(thi[i]));
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int db = 0; db < 2; ++db)
-                dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_pair(tlo[s2 * 2 + db], thi[s2 * 2 + db]), db8[s2], dq[db], 0, 0, 0);
-    };
-    // ---- prologue
-    if (nt >= 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("" : "+v"(lse2), "+v"(dlt));              // (their loads are older than the tiles: consumed here, not in the loop)
-    __syncthreads();
-    rowfrag_from_image(qf, pro, wave * 32, l31, half);
-    rowfrag_from_image(dof, pro + 16384, wave * 32, l31, half);
-    if (want_delta) {
-        RowFrag<true> of;
-        rowfrag_from_image(of, pro + 32768, wave * 32, l31, half);
-        dlt = rowfrag_dot<true>(dof, of);
-        dlt = xor32_sum(dlt);
-        if (qvalid && half == 0 && grp == 0) a.DeltaOut[statrow] = dlt;
-    }
-    if (pd.thr) scale_rowfrag<true>(dof, pd.inv_keep);
-    const bool has_hn = a.hn[0].raw != nullptr;
-    bool hn_issued = false;
-    f32x16 sa, dpa, sb, dpb;
-    if (nu > 0) {
-        read_kv(gl);
-        wait_lds();
-        scores(sa, dpa);
-        if (nu > 1) read_kv(gl + 4096);
-    }
-    int st = 0;
-    for (int t = 0; t < ((a.dbg & 32) ? 0 : nt0); ++t) {
-        const int st1 = st + 1 == NS ? 0 : st + 1;
-        if (t > 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // tile t+1 (and whatever else was in flight) landed
-            __builtin_amdgcn_s_barrier();                           // ... for every wave; every wave is done with tile t-1
-            asm volatile("" ::: "memory");
-            if (t + NS - 1 < nt) issue_tile(t + NS - 1, st == 0 ? NS - 1 : st - 1);
-            if (has_hn && !hn_issued) {                             // the prologue images are free since that barrier
-                hn_dma_inputs(a.hn[0], (int64_t)b * a.Sq + qblk, qblk, nrows, hh, pro, wave8);
-                hn_issued = true;
-            }
-        }
-        const int u0 = 2 * t;
-        if (u0 < nu) {
-            const int k0 = kfirst + t * STEP;
-            const uint64_t kmbits = km ? kmb[k0 >> 6] : 0ull;
-            const uint32_t cur = gl + st * STAGE, nxt = gl + st1 * STAGE;
-            bf16x8 d8[2];
-            if (u0 + 1 < nu) { wait_lds(); scores(sb, dpb); }
-            __builtin_amdgcn_sched_barrier(0);
-            read_kt(cur);
-            ds_unit(sa, dpa, k0, (uint32_t)kmbits, d8);
-            wait_lds();
-            dq_acc(d8);
-            __builtin_amdgcn_sched_barrier(0);
-            if (u0 + 2 < nu) read_kv(nxt);
-            if (u0 + 1 < nu) {
-                if (u0 + 2 < nu) { wait_lds(); scores(sa, dpa); }
-                __builtin_amdgcn_sched_barrier(0);
-                read_kt(cur + 4096);
-                ds_unit(sb, dpb, k0 + 32, (uint32_t)(kmbits >> 32), d8);
-                wait_lds();
-                dq_acc(d8);
-                __builtin_amdgcn_sched_barrier(0);
-                if (u0 + 3 < nu) read_kv(nxt + 4096);
-            }
-        }
-        st = st1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (has_hn && !hn_issued) hn_dma_inputs(a.hn[0], (int64_t)b * a.Sq + qblk, qblk, nrows, hh, pro, wave8);   // (single-tile launches)
-    {                                // group 1's partial dQ -> LDS -> group 0
-        float *mb = reinterpret_cast<float *>(smem_raw) + (wave * 64 + lane) * 33;
-        if (grp == 1) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { mb[r] = dq[0][r]; mb[16 + r] = dq[1][r]; }
-        }
-        __syncthreads();
-        if (grp == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { dq[0][r] += mb[r]; dq[1][r] += mb[16 + r]; }
-        }
-    }
-    T *out0 = static_cast<T *>(a.Out) + ((int64_t)b * a.Sq + qmin) * a.ldout + hh * 64;
-    char *otile = smem_raw + 36864 + wave * 4608;
-    if (!has_hn) {
-        if (grp == 0) store_rows_via_lds(out0, a.ldout, a.Sq - qmin, dq, a.scale, otile, lane);
-        return;
-    }
-    float *colred = reinterpret_cast<float *>(smem_raw);          // [128 rows][65]
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the epilogue images
-    __syncthreads();                                              // ... for every wave; the merge buffer is free
-    if (grp == 0) {
-        f32x16 dx[2];
-        hn_bwd_row2(dq, a.scale, qvalid, pro, pro + 16384, pro + 32768, wave * 32 + l31, a.hn[0].rope != 0, a.hn[0].gain, half,
-                    colred + (wave * 32 + l31) * 65, dx);
-        store_rows_via_lds(out0, a.ldout, a.Sq - qmin, dx, 1.f, otile, lane);
-    }
-    __syncthreads();
-    hn_colsum(colred, a.hn[0].partials);
-}
+// (body of the dQ kernel: kk_attn_bwd_dq2.inc, included into attn_bwd_dq2_kernel and attn_bwd_pair2_kernel below)
 
 // ------------------------------------------------------------------ backward: dK, dV
 // A lane owns a key; the workgroup sweeps the query tiles.  G = 2: two wave groups take alternate query tiles of the
@@ -1621,290 +1363,33 @@ __global__ __launch_bounds__(256 * G) void attn_bwd_dkv_kernel(AttnArgs a) {
 // the row fragments (S^T = Q.K^T, dP^T = dO.V^T) and the transpose reads (dV^T += dO^T.P, dK^T += Q^T.dS) — the first
 // generation staged four tiles (two of them transposed in registers) per step; lse / Delta rows by DMA; K and V rows, the
 // head-norm epilogues' operands and the outputs as in attn_bwd_dq2_kernel.
+// (body of the dK/dV kernel: kk_attn_bwd_dkv2.inc, included into attn_bwd_dkv2_kernel and attn_bwd_pair2_kernel below)
+
+// The bodies live in .inc files because they must name a by-value KERNEL parameter: handed to a device function by reference
+// (or read through a pointer to the kernarg segment) the same code spills 5-11 vector registers, and a spill is fatal beside
+// LDS-DMA (scratch reloads queue behind the tile DMAs).
+__global__ __launch_bounds__(512) void attn_bwd_dq2_kernel(AttnArgs a) {
+#include "kk_attn_bwd_dq2.inc"
+}
 __global__ __launch_bounds__(512) void attn_bwd_dkv2_kernel(AttnArgs a) {
-    typedef __bf16 T;
-    constexpr int NS = 3, IMG = 64 * 64 * 2, STAGE = 2 * IMG + 512, GSZ = NS * STAGE, STEP = 128;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];        // [group][stage][Q | dO | lse | delta], 3 x 16 KB images
-    char *pro = smem_raw + 2 * GSZ;                                        // K | V, later raw K | cos | sin
-    char *rawv_img = smem_raw + 81920;                                     // (inside the stages: free after the loop)
-    int bx_, by_;
-    attn_block(a, bx_, by_, false);
-    const int b = by_ / a.heads, hh = by_ % a.heads;
-    const int kblk = bx_ * 128;
-    const int lane = threadIdx.x & 63, wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, l31 = lane & 31;
-    const int wave = wave8 & 3, grp = wave8 >> 2, tg = threadIdx.x & 255;
-    const int kmin = kblk + wave * 32, key = kmin + l31;
-    const bool kvalid = key < a.Sk;
-    const bool kalive = kvalid && !(a.key_mask && a.key_mask[(int64_t)b * a.Sk + key]);     // (older than every DMA)
-    const int kmaxw = kmin + 31;
-    const int qstart = a.causal ? (kblk / 64) * 64 : 0;
-    const int qfirst = qstart + grp * 64;
-    const int nt = qfirst < a.Sq ? (a.Sq - qfirst + STEP - 1) / STEP : 0;
-    const int nt0 = qstart < a.Sq ? (a.Sq - qstart + STEP - 1) / STEP : 0;
-    const int nrows = a.Sk - kblk < 128 ? a.Sk - kblk : 128;
-    dma_rows128(static_cast<const T *>(a.K) + ((int64_t)b * a.Sk + kblk) * a.ldk + hh * 64, a.ldk, nrows, pro, wave8);
-    dma_rows128(static_cast<const T *>(a.V) + ((int64_t)b * a.Sk + kblk) * a.ldv + hh * 64, a.ldv, nrows, pro + 16384, wave8);
-    const T *Qb = static_cast<const T *>(a.Q) + (int64_t)b * a.Sq * a.ldq + hh * 64;
-    const T *dOb = static_cast<const T *>(a.dO) + (int64_t)b * a.Sq * a.lddo + hh * 64;
-    const float *LSEb = a.LSE + ((int64_t)b * a.heads + hh) * a.Sq, *DLb = a.Delta + ((int64_t)b * a.heads + hh) * a.Sq;
-    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(Qb), 0, (int)((((int64_t)a.Sq - 1) * a.ldq + 64) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(dOb), 0, (int)((((int64_t)a.Sq - 1) * a.lddo + 64) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wave == 0 ? LSEb : DLb), 0, a.Sq * 4, 0x00020000);
-    uint32_t qvo[2], dvo[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int p = tg + 256 * j, row = p >> 3, pc = p & 7, c = pc ^ (kk_xb(row) << 1);
-        qvo[j] = (uint32_t)(((int64_t)row * a.ldq + c * 8) * 2);
-        dvo[j] = (uint32_t)(((int64_t)row * a.lddo + c * 8) * 2);
+#include "kk_attn_bwd_dkv2.inc"
+}
+// dQ and dK/dV of one attention in ONE launch (grid z = 0: the dQ workgroups, z = 1: the dK/dV workgroups; Delta is an INPUT of
+// both, see kk_gemm_dgrad_delta).  The two kernels are independent once Delta exists, each keeps one workgroup per CU (148 KB of
+// LDS), and a causal launch is lopsided: dQ blocks near the end of the sequence see the most keys, dK/dV blocks near its start the
+// most queries.  Dispatched in this order (x, y, then z; long blocks first inside each half) the CUs that finish a short dQ block
+// pick up the long dK/dV blocks, so at S = 512 (one workgroup per CU and kernel) the pair takes about 5 block-units instead of
+// 4 + 4, and a non-causal pair saves one launch's ramp and tail.
+__global__ __launch_bounds__(512) void attn_bwd_pair2_kernel(AttnArgs a_dq, AttnArgs a_dkv) {
+    if (blockIdx.z == 0) {
+#define a a_dq
+#include "kk_attn_bwd_dq2.inc"
+#undef a
+    } else {
+#define a a_dkv
+#include "kk_attn_bwd_dkv2.inc"
+#undef a
     }
-    char *gbase = smem_raw + grp * GSZ;
-    const uint32_t qtile = (uint32_t)(STEP * a.ldq * 2), dtile = (uint32_t)(STEP * a.lddo * 2);
-    const uint32_t qbeg = (uint32_t)(qfirst * a.ldq * 2), dbeg = (uint32_t)(qfirst * a.lddo * 2);
-    const bool stat_lane = wave < 2 && lane < 16;          // wave 0: the tile's 64 lse values, wave 1: its 64 Delta values
-    auto issue_tile = [&](int t, int st) {
-        char *dst = gbase + st * STAGE;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, KK_LDS_PTR(dst + wave * 1024 + j * 4096), 16, qvo[j] + qbeg + (uint32_t)t * qtile, 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rdo, KK_LDS_PTR(dst + IMG + wave * 1024 + j * 4096), 16, dvo[j] + dbeg + (uint32_t)t * dtile, 0, 0, 0);
-        if (stat_lane)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rst, KK_LDS_PTR(dst + 2 * IMG + wave * 256), 16, (uint32_t)((qfirst + t * STEP) * 4 + lane * 16), 0, 0, 0);
-    };
-#pragma unroll
-    for (int t = 0; t < NS; ++t)
-        if (t < nt) issue_tile(t, t);
-    // ---- fragment addresses (bytes inside a stage)
-    const uint32_t gl = (uint32_t)(uintptr_t)KK_LDS_PTR(gbase);
-    uint32_t ra_[4], ta[2];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) ra_[ks] = (uint32_t)(l31 * 128 + (((2 * ks + half) ^ (kk_xb(l31) << 1)) * 16));
-    {
-        const int L = lane & 15, kq = L >> 2, gi = (lane >> 4) & 1, xb = (((kq >> 1) & 1) << 1) | half;
-#pragma unroll
-        for (int db = 0; db < 2; ++db) ta[db] = (uint32_t)((4 * half + kq) * 128 + (((2 * db + gi) ^ xb) * 32) + 8 * (L & 3));
-    }
-    bf16x8 qr[4], dr[4];
-    s16x4 qlo[4], qhi[4], dlo[4], dhi[4];
-    auto read_rows = [&](uint32_t img) {                   // row fragments of the unit's 32 queries (img = first Q row)
-        asm volatile("ds_read_b128 %0, %1" : "=v"(qr[0]) : "v"(img + ra_[0]));
-        asm volatile("ds_read_b128 %0, %1" : "=v"(qr[1]) : "v"(img + ra_[1]));
-        asm volatile("ds_read_b128 %0, %1" : "=v"(qr[2]) : "v"(img + ra_[2]));
-        asm volatile("ds_read_b128 %0, %1" : "=v"(qr[3]) : "v"(img + ra_[3]));
-        asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(dr[0]) : "v"(img + ra_[0]));
-        asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(dr[1]) : "v"(img + ra_[1]));
-        asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(dr[2]) : "v"(img + ra_[2]));
-        asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(dr[3]) : "v"(img + ra_[3]));
-    };
-    auto wait_lds = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
-    RowFrag<true> kf, vf;
-    f32x16 dk[2], dv[2];
-    zero_acc(dk[0]); zero_acc(dk[1]); zero_acc(dv[0]); zero_acc(dv[1]);
-    ProbDrop pd;
-    pd.init(a, b, hh);
-    const float c2 = a.scale * 1.4426950408889634f;
-    const bool anydead = __ballot(!kalive) != 0ull;
-    // ---- prologue: K, V rows and tiles 0, 1 landed (tile 2 may stay in flight)
-    if (nt >= 3) {
-        if (wave < 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    rowfrag_from_image(kf, pro, wave * 32, l31, half);
-    rowfrag_from_image(vf, pro + 16384, wave * 32, l31, half);
-    if (pd.thr) scale_rowfrag<true>(vf, pd.inv_keep);
-    const bool has_hn = a.hn[0].raw != nullptr;
-    bool hn_issued = false;
-    auto unit_live = [&](int qb) { return qb < a.Sq && !(a.causal && qb + 31 < kmin); };
-    bool pref = false;                                     // (wave-uniform) the next live unit's row fragments are in flight
-    int st = 0;
-    for (int t = 0; t < ((a.dbg & 32) ? 0 : nt0); ++t) {
-        const int st1 = st + 1 == NS ? 0 : st + 1;
-        if (t > 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (t + NS - 1 < nt) issue_tile(t + NS - 1, st == 0 ? NS - 1 : st - 1);
-            if (has_hn && !hn_issued) {
-                hn_dma_inputs(a.hn[0], (int64_t)b * a.Sk + kblk, kblk, nrows, hh, pro, wave8);
-                hn_issued = true;
-            }
-        }
-        const int q0 = qfirst + t * STEP;
-        const uint32_t cur = gl + st * STAGE, nxt = gl + st1 * STAGE;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            const int qb = q0 + sub * 32;
-            if (!unit_live(qb)) continue;
-            f32x16 s, dp;
-            if (!pref) read_rows(cur + sub * 4096);
-            wait_lds();
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qr[ks]), "+v"(dr[ks]));
-            zero_acc(s); zero_acc(dp);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qr[ks], kf.v[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dr[ks], vf.v[ks], dp, 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // Register diet (two waves per SIMD: 256 registers, and a spill is fatal here — scratch reloads queue behind the tile
-            // DMAs): lse rows -> P -> Delta rows -> dS, the dO^T fragments fetched under the exponentials, the Q^T fragments under dS.
-            const uint32_t tq0 = cur + sub * 4096 + ta[0], tq1 = cur + sub * 4096 + ta[1];
-            const uint32_t sa_ = cur + 2 * IMG + (uint32_t)((sub * 32 + 4 * half) * 4);
-            f32x4_ st4[4];
-            asm volatile("ds_read_b128 %0, %1" : "=v"(st4[0]) : "v"(sa_));
-            asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(st4[1]) : "v"(sa_));
-            asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(st4[2]) : "v"(sa_));
-            asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(st4[3]) : "v"(sa_));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(dlo[0]) : "v"(tq0));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:9216" : "=v"(dhi[0]) : "v"(tq0));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(dlo[1]) : "v"(tq1));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:9216" : "=v"(dhi[1]) : "v"(tq1));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:10240" : "=v"(dlo[2]) : "v"(tq0));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:11264" : "=v"(dhi[2]) : "v"(tq0));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:10240" : "=v"(dlo[3]) : "v"(tq1));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:11264" : "=v"(dhi[3]) : "v"(tq1));
-            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                      // the four lse reads
-#pragma unroll
-            for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(st4[g]));
-            const bool edge = anydead || qb + 32 > a.Sq || (a.causal && kmaxw > qb);
-            float p[16], ds[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(s[r] * c2 - st4[r >> 2][r & 3] * 1.4426950408889634f);
-            if (edge) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int qq = qb + frag_row(r, half);
-                    const bool ok = kalive && qq < a.Sq && !(a.causal && key > qq);
-                    p[r] = ok ? p[r] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(p[r]));            // P exists: the lse registers are free
-            asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(st4[0]) : "v"(sa_));
-            asm volatile("ds_read_b128 %0, %1 offset:288" : "=v"(st4[1]) : "v"(sa_));
-            asm volatile("ds_read_b128 %0, %1 offset:320" : "=v"(st4[2]) : "v"(sa_));
-            asm volatile("ds_read_b128 %0, %1 offset:352" : "=v"(st4[3]) : "v"(sa_));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(st4[g]));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(dlo[i]), "+v"(dhi[i]));
-            bf16x8 p8[2], d8[2];
-            if (pd.thr) {
-                // The keep decisions of (q, key) and (q, key ^ 1) are the two 16-bit fields of ONE hash (ProbDrop), and lanes l, l ^ 1
-                // own such a key pair: the even lane hashes the even query rows of the accumulator, the odd lane the odd ones, each
-                // keeps its own field and hands the other one to its neighbour through DPP — 8 hashes per unit instead of 16, the
-                // same mask bit for bit.  Which of (own, received) belongs to a given register is a function of the lane parity:
-                // resolved on the comparison masks (scalar xor / and), the selects read them directly.
-                uint32_t sk2v = pd.sk2;
-                asm volatile("" : "+s"(sk2v));             // (or the row offsets are hoisted out of the loop and spilled)
-                const uint32_t par = (uint32_t)key & 1u, shm = 16u * par, shs = 16u - shm;
-                const uint32_t xbp = pd.row(qb + 4 * half, key) + par * sk2v;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const uint32_t hsh = pd.hash(xbp + (uint32_t)frag_row(2 * i, 0) * sk2v);
-                    const uint32_t mine = (hsh >> shm) & 0xFFFFu, send = (hsh >> shs) & 0xFFFFu;
-                    const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xF, 0xF, true);      // lane ^ 1
-                    const uint64_t cm = __builtin_amdgcn_uicmp(mine, pd.thr, 35), cr = __builtin_amdgcn_uicmp(recv, pd.thr, 35);   // >=
-                    const uint64_t u = (cm ^ cr) & 0xAAAAAAAAAAAAAAAAull;
-                    const bool k0 = __builtin_amdgcn_inverse_ballot_w64(cm ^ u), k1 = __builtin_amdgcn_inverse_ballot_w64(cr ^ u);
-                    const int r0 = 2 * i, r1 = 2 * i + 1;
-                    ds[r0] = p[r0] * ((k0 ? dp[r0] : 0.f) - st4[r0 >> 2][r0 & 3]);
-                    p[r0] = k0 ? p[r0] : 0.f;
-                    ds[r1] = p[r1] * ((k1 ? dp[r1] : 0.f) - st4[r1 >> 2][r1 & 3]);
-                    p[r1] = k1 ? p[r1] : 0.f;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) ds[r] = p[r] * (dp[r] - st4[r >> 2][r & 3]);
-            }
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) p8[s2][j] = (__bf16)p[8 * s2 + j];
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int db = 0; db < 2; ++db)
-                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_pair(dlo[s2 * 2 + db], dhi[s2 * 2 + db]), p8[s2], dv[db], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(qlo[0]) : "v"(tq0));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(qhi[0]) : "v"(tq0));
-            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(qlo[1]) : "v"(tq1));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(qhi[1]) : "v"(tq1));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(qlo[2]) : "v"(tq0));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:3072" : "=v"(qhi[2]) : "v"(tq0));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(qlo[3]) : "v"(tq1));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:3072" : "=v"(qhi[3]) : "v"(tq1));
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) d8[s2][j] = (__bf16)ds[8 * s2 + j];
-            wait_lds();
-#pragma unroll
-            for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(qlo[i]), "+v"(qhi[i]));
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int db = 0; db < 2; ++db)
-                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_pair(qlo[s2 * 2 + db], qhi[s2 * 2 + db]), d8[s2], dk[db], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            // the next unit's row fragments (same tile, or the next tile: landed since this iteration's barrier)
-            pref = sub == 0 ? unit_live(qb + 32) : (t + 1 < nt && unit_live(q0 + STEP));
-            if (pref) read_rows(sub == 0 ? cur + 4096 : nxt);
-        }
-        st = st1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (has_hn) {
-        if (!hn_issued) hn_dma_inputs(a.hn[0], (int64_t)b * a.Sk + kblk, kblk, nrows, hh, pro, wave8);
-        dma_rows128(static_cast<const T *>(a.hn[1].raw) + ((int64_t)b * a.Sk + kblk) * a.hn[1].ldraw + hh * 64, a.hn[1].ldraw, nrows, rawv_img, wave8);
-    }
-    {                                // group 1's partial dK / dV -> LDS -> group 0
-        float *mb = reinterpret_cast<float *>(smem_raw) + (wave * 64 + lane) * 65;
-        if (grp == 1) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { mb[r] = dk[0][r]; mb[16 + r] = dk[1][r]; mb[32 + r] = dv[0][r]; mb[48 + r] = dv[1][r]; }
-        }
-        __syncthreads();
-        if (grp == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { dk[0][r] += mb[r]; dk[1][r] += mb[16 + r]; dv[0][r] += mb[32 + r]; dv[1][r] += mb[48 + r]; }
-        }
-    }
-    T *dk0 = static_cast<T *>(a.Out) + ((int64_t)b * a.Sk + kmin) * a.ldout + hh * 64;
-    T *dv0 = static_cast<T *>(a.Out2) + ((int64_t)b * a.Sk + kmin) * a.ldout2 + hh * 64;
-    char *otile = smem_raw + 36864 + wave * 4608;
-    if (!has_hn) {
-        if (grp == 0) {
-            store_rows_via_lds(dk0, a.ldout, a.Sk - kmin, dk, a.scale, otile, lane);
-            store_rows_via_lds(dv0, a.ldout2, a.Sk - kmin, dv, pd.inv_keep, otile, lane);
-        }
-        return;
-    }
-    float *colred = reinterpret_cast<float *>(smem_raw);          // [128 rows][65]
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the epilogue images
-    __syncthreads();                                              // ... for every wave; the merge buffer is free
-    f32x16 dx[2];
-    if (grp == 0) {
-        hn_bwd_row2(dk, a.scale, kvalid, pro, pro + 16384, pro + 32768, wave * 32 + l31, a.hn[0].rope != 0, a.hn[0].gain, half,
-                    colred + (wave * 32 + l31) * 65, dx);
-        store_rows_via_lds(dk0, a.ldout, a.Sk - kmin, dx, 1.f, otile, lane);
-    }
-    __syncthreads();
-    hn_colsum(colred, a.hn[0].partials);
-    __syncthreads();
-    if (grp == 0) {
-        hn_bwd_row2(dv, pd.inv_keep, kvalid, rawv_img, nullptr, nullptr, wave * 32 + l31, false, a.hn[1].gain, half,
-                    colred + (wave * 32 + l31) * 65, dx);
-        store_rows_via_lds(dv0, a.ldout2, a.Sk - kmin, dx, 1.f, otile, lane);
-    }
-    __syncthreads();
-    hn_colsum(colred, a.hn[1].partials);
 }
 
 // Delta[b,h,q] = sum_d dO*O : one wave per (row, head).
@@ -1934,6 +1419,10 @@ static int attn_dbg() {                  // timing probes of tools/probes (resul
     return v;
 }
 static bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+static int attn_pair() {                 // KK_ATTN_PAIR=0: kk_attn_bwd issues the dQ and the dK/dV kernel as two launches
+    static const int v = getenv("KK_ATTN_PAIR") ? atoi(getenv("KK_ATTN_PAIR")) : 1;
+    return v;
+}
 static int attn_xcd_map() {
     static const int v = getenv("KK_ATTN_XCD") ? atoi(getenv("KK_ATTN_XCD")) : 1;
     return v;
@@ -2111,5 +1600,59 @@ extern "C" int kk_attn_bwd_dkv(const float *Q, const float *K, const float *V, c
     else if (math == KK_MATH_BF16) KK_ATTN_LAUNCH_X(attn_bwd_dkv_kernel, true, false, 1, 4, 2 * 128 * sizeof(float));   // (G = 2 would spill)
     else KK_ATTN_LAUNCH_X(attn_bwd_dkv_kernel, false, false, G, 2, 2 * G * 128 * sizeof(float));
     KK_LAUNCH_CHECK("kk_attn_bwd_dkv");
+    return 0;
+}
+
+// dQ, dK and dV in one launch (attn_bwd_pair2_kernel) when both second-generation kernels apply; otherwise the two launches
+// above, in order.  Delta[b, head, q] = sum_d dO * O is an INPUT here (kk_gemm_dgrad_delta writes it with dO, or kk_attn_delta).
+// hn_q / hn_kv: the head-norm backward epilogues of kk_attn_bwd_dq / kk_attn_bwd_dkv (both or neither).
+extern "C" int kk_attn_bwd(const float *Q, const float *K, const float *V, const float *dO, const float *LSE, const float *Delta,
+                           float *dQ, float *dK, float *dV, int B, int heads, int Sq, int Sk, int64_t ldq, int64_t ldk,
+                           int64_t ldv, int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, const uint8_t *key_mask,
+                           int causal, float scale, const uint32_t *seed, uint32_t site, float p_drop, int math, int io_bf16,
+                           const KkAttnHeadNorm *hn_q, const KkAttnHeadNorm *hn_kv, void *stream) {
+    KK_REQUIRE(Delta != nullptr, "kk_attn_bwd: Delta is an input of this call");
+    KK_REQUIRE((hn_q == nullptr) == (hn_kv == nullptr), "kk_attn_bwd: head-norm epilogues for both kernels or for neither");
+    const int G = (Sk > 64 && Sq > 64 && g_attn_groups == 2) ? 2 : 1;
+    const bool pair = io_bf16 && math == KK_MATH_BF16 && (attn_v2_mask() & 6) == 6 && attn_pair() && G == 2 && Sk <= 4096 &&
+                      kk_cdiv(Sq, 128) == kk_cdiv(Sk, 128) && al16(Q) && al16(K) && al16(V) && al16(dO) && al16(dQ) && al16(dK) && al16(dV) &&
+                      (!hn_q || (al16(hn_q->raw) && (!hn_q->rope || (al16(hn_q->cos_t) && al16(hn_q->sin_t))))) &&
+                      (!hn_kv || (al16(hn_kv[0].raw) && al16(hn_kv[1].raw) && !hn_kv[1].rope &&
+                                  (!hn_kv[0].rope || (al16(hn_kv[0].cos_t) && al16(hn_kv[0].sin_t))))) &&
+                      (int64_t)Sk * std::max(ldk, ldv) * 2 < (1ll << 31) && (int64_t)Sq * std::max(ldq, lddo) * 2 < (1ll << 31);
+    if (!pair) {
+        if (int rc = kk_attn_bwd_dq(Q, K, V, dO, LSE, const_cast<float *>(Delta), dQ, B, heads, Sq, Sk, ldq, ldk, ldv, lddo, lddq, key_mask,
+                                    causal, scale, seed, site, p_drop, math, io_bf16, nullptr, 0, hn_q, stream))
+            return rc;
+        return kk_attn_bwd_dkv(Q, K, V, dO, LSE, Delta, dK, dV, B, heads, Sq, Sk, ldq, ldk, ldv, lddo, lddk, lddv, key_mask, causal,
+                               scale, seed, site, p_drop, math, io_bf16, hn_kv, stream);
+    }
+    KK_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "kk_attn_bwd: dropout probability must be in [0,1)");
+    const int64_t lds[7] = {ldq, ldk, ldv, lddo, lddq, lddk, lddv};
+    if (int rc = check_common("kk_attn_bwd", B, heads, Sq, Sk, math, lds, 7)) return rc;
+    struct { AttnArgs dq, dkv; } p = {};
+    AttnArgs &a = p.dq;
+    a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.LSE = LSE; a.Delta = Delta; a.Out = dQ; a.key_mask = key_mask;
+    a.B = B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.causal = causal;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.lddo = lddo; a.ldout = lddq; a.scale = scale;
+    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(); a.dbg = attn_dbg();
+    if (a.xcd_map && causal) a.xcd_map = 2;
+    p.dkv = a;
+    p.dkv.Out = dK; p.dkv.Out2 = dV; p.dkv.ldout = lddk; p.dkv.ldout2 = lddv;
+    if (hn_q) {
+        if (int rc = check_headnorm("kk_attn_bwd", hn_q, 1)) return rc;
+        if (int rc = check_headnorm("kk_attn_bwd", hn_kv, 2)) return rc;
+        p.dq.hn[0] = hn_q[0];
+        p.dkv.hn[0] = hn_kv[0]; p.dkv.hn[1] = hn_kv[1];
+    }
+    const size_t lds_bytes = std::max((size_t)2 * 3 * 16384 + 512 + 3 * 16384, (size_t)2 * 3 * (16384 + 512) + 3 * 16384);
+    static thread_local bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute((const void *)attn_bwd_pair2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return kk_fail((int)e, "kk_attn_bwd: cannot reserve %zu bytes of LDS: %s", lds_bytes, hipGetErrorString(e));
+        raised = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_pair2_kernel, dim3(kk_cdiv(Sq, 128), B * heads, 2), dim3(512), lds_bytes, (hipStream_t)stream, p.dq, p.dkv);
+    KK_LAUNCH_CHECK("kk_attn_bwd");
     return 0;
 }

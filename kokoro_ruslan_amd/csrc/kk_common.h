@@ -42,6 +42,10 @@ int kk_gemm16_qkv_headnorm(int64_t T, int parts, int heads, int64_t K, const voi
 int kk_zero_async(void *p, size_t bytes, hipStream_t s);
 int kk_gemm16_linear_glu(int64_t T, int64_t F, int64_t K, const void *x, int64_t ldx, const void *W, const float *bias, void *h1,
                          void *g, int64_t ldg, const uint32_t *seed, uint32_t site, float p, int xcd_swizzle, hipStream_t s);
+// dX = dY.W of an attention output projection with Delta = rowsum_head(dX * O) as the epilogue (see kk_gemm16.hip)
+bool kk_gemm16_dgrad_delta_supported(int64_t M, int64_t N, int64_t K);
+int kk_gemm16_dgrad_delta(int64_t M, int64_t N, int64_t K, const void *dy, int64_t lddy, const void *W, int64_t ldw, void *dx,
+                          int64_t lddx, const void *O, int64_t ldo, float *delta, int S, int heads, int xcd_swizzle, hipStream_t s);
 // dX = dY.W fused with the GLU gate's backward (see kk_gemm16.hip)
 int kk_gemm16_dgrad_glu(int64_t T, int64_t F, int64_t H, const void *dy, int64_t lddy, const void *W, const void *h1, void *dh1,
                         float *partials, const uint32_t *seed, uint32_t site, float p, int xcd_swizzle, hipStream_t s);

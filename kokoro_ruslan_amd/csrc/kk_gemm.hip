@@ -452,6 +452,23 @@ extern "C" int kk_gemm_dgrad_glu(int64_t T, int64_t F, int64_t H, const void *dy
     return kk_gemm16_dgrad_glu(T, F, H, dy, lddy, W, h1, dh1, partials, seed, site, p, g_xcd_swizzle, (hipStream_t)stream);
 }
 
+// dX = dY.W of an attention output projection (bf16 operands and result) with the attention backward's row term
+// Delta[b, head, q] = sum_d dX[b*S+q, 64 head + d] * O[b*S+q, 64 head + d] as the epilogue (see gemm16_body, DELTA_OK).
+extern "C" int kk_gemm_dgrad_delta_supported(int64_t M, int64_t N, int64_t K) {
+    return (g_use_gemm16 && kk_gemm16_dgrad_delta_supported(M, N, K)) ? 1 : 0;
+}
+extern "C" int kk_gemm_dgrad_delta(int64_t M, int64_t N, int64_t K, const void *dy, int64_t lddy, const void *W, int64_t ldw,
+                                   void *dx, int64_t lddx, const void *O, int64_t ldo, float *delta, int S, int heads, void *stream) {
+    KK_REQUIRE(M > 0 && N > 0 && K > 0 && dy && W && dx && O && delta, "kk_gemm_dgrad_delta: bad args");
+    KK_REQUIRE(S > 0 && M % S == 0 && heads * 64 == N, "kk_gemm_dgrad_delta: rows must be whole sequences of S and N = heads x 64");
+    KK_REQUIRE(lddx % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)dx & 15) == 0 && ((uintptr_t)O & 15) == 0,
+               "kk_gemm_dgrad_delta: dX and O must be 16-byte aligned with row strides %% 8 == 0");
+    KK_REQUIRE(kk_gemm16_eligible(0, 1, M, N, K, dy, lddy, W, ldw), "kk_gemm_dgrad_delta: needs 16-byte aligned bf16 operands and K %% 64 == 0");
+    KK_REQUIRE(kk_gemm_dgrad_delta_supported(M, N, K), "kk_gemm_dgrad_delta: shape %ldx%ldx%ld does not take the eight-wave 128x64 tile "
+               "(ask kk_gemm_dgrad_delta_supported first)", (long)M, (long)N, (long)K);
+    return kk_gemm16_dgrad_delta(M, N, K, dy, lddy, W, ldw, dx, lddx, O, ldo, delta, S, heads, g_xcd_swizzle, (hipStream_t)stream);
+}
+
 // h1 = x.W1^T + b1 with the GLU gate as the epilogue (bf16 operands; see gemm16_kernel, EPI = 2).
 extern "C" int kk_gemm_linear_glu(int64_t T, int64_t F, int64_t K, const void *x, int64_t ldx, const void *W, const float *bias,
                                   void *h1, void *g, int64_t ldg, const uint32_t *seed, uint32_t site, float p, void *stream) {

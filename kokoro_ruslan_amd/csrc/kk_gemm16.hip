@@ -49,6 +49,12 @@ struct G16Args {
     __bf16 *hn_y;
     int64_t hn_ldy;
     int hn_S, hn_H, hn_rope_mask;
+    // Delta epilogue (eight-wave 128x64 tile, bf16 C; the dgrad of an attention output projection): the tile's 64 columns are
+    // one head of dO = dY.W_o, so Delta[b, head, q] = sum_d dO * O (the attention backward's row term) leaves with it
+    const __bf16 *dl_o;
+    float *dl_out;
+    int64_t dl_ldo;
+    int dl_S, dl_heads;
 };
 
 constexpr int BK = 64;
@@ -420,7 +426,8 @@ __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char
     const bool lead = (ksl == 0);
     // bf16 C without accumulation or residual (most dgrads, linear2): the tile goes through LDS so that a lane stores 8
     // consecutive columns (16 bytes) of 2 rows instead of 16 two-byte values of one column
-    constexpr bool WIDE_OK = NS * STAGE >= WAVES * 32 * 36 * 4;      // the staging area holds one 32x32 fp32 tile per wave
+    constexpr bool WIDE_OK = NS * STAGE >= WAVES * 32 * 36 * 4 + 512;      // the staging area holds one 32x32 fp32 tile per wave (+ the Delta rows)
+    constexpr bool DELTA_OK = EPI == 0 && WAVES == 8 && WC == 2 && BM == 128 && BN == 64;      // one 32x32 tile per wave, a head per workgroup
     if (WIDE_OK && a.c_bf16 && a.residual == nullptr && (a.ldc & 7) == 0 && (a.N & 7) == 0 && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0) {
         constexpr int TP = 36;
         __builtin_amdgcn_s_barrier();                           // every wave is done with the last stage
@@ -435,6 +442,7 @@ __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char
                 for (int r = 0; r < 16; ++r) tile[frag_row(r, half) * TP + l31] = acc[i][j][r];
                 __builtin_amdgcn_wave_barrier();
                 const int col = n0 + wc * (BN / WC) + j * 32 + c8;
+                float dsum[2] = {0.f, 0.f};                   // Delta epilogue: this lane's 8 columns of its 2 rows
                 if (col < a.N) {
                     float bv[8];
 #pragma unroll
@@ -449,9 +457,42 @@ __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] = (__bf16)(a.alpha * v[e] + bv[e]);
                         *reinterpret_cast<bf16x8 *>(C + (int64_t)row * a.ldc + col) = o;
+                        if constexpr (DELTA_OK) {
+                            if (a.dl_out != nullptr) {              // (from the ROUNDED dO: what the attention kernels will read)
+                                const bf16x8 ov = *reinterpret_cast<const bf16x8 *>(a.dl_o + (int64_t)row * a.dl_ldo + col);
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) dsum[it] += (float)o[e] * (float)ov[e];
+                            }
+                        }
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
+                if constexpr (DELTA_OK) {
+                    if (a.dl_out != nullptr) {                      // (workgroup-uniform; N % 64 == 0 is checked by the entry point)
+                        // a row's 32 columns of this wave: the 4 lanes that share lane >> 2; its other 32 are in wave wc ^ 1
+                        float *red = reinterpret_cast<float *>(smem + WAVES * 32 * TP * 4);      // [WR][32] row sums of the wc = 1 waves
+#pragma unroll
+                        for (int it = 0; it < 2; ++it) {
+                            dsum[it] += __shfl_xor(dsum[it], 1, 64);
+                            dsum[it] += __shfl_xor(dsum[it], 2, 64);
+                        }
+                        if (wc == 1 && (lane & 3) == 0) {
+                            red[wr * 32 + (lane >> 2)] = dsum[0];
+                            red[wr * 32 + 16 + (lane >> 2)] = dsum[1];
+                        }
+                        __syncthreads();
+                        if (wc == 0 && (lane & 3) == 0) {
+#pragma unroll
+                            for (int it = 0; it < 2; ++it) {
+                                const int rl = it * 16 + (lane >> 2), row = m0 + wr * 32 + rl;
+                                if (row < a.M) {
+                                    const int bb = row / a.dl_S, q = row - bb * a.dl_S;
+                                    a.dl_out[((int64_t)bb * a.dl_heads + n0 / 64) * a.dl_S + q] = dsum[it] + red[wr * 32 + rl];
+                                }
+                            }
+                        }
+                    }
+                }
             }
         return;
     }
@@ -668,7 +709,7 @@ int kk_gemm16_launch(int ta, int tb, int64_t M, int64_t N, int64_t K, float alph
     int k_per_split = cd(ktiles, splits) * BK;
     splits = cd(K, k_per_split);
     const int split_major = (g16_split_major && splits > 1 && splits % 8 == 0) ? 1 : 0;
-    G16Args a;
+    G16Args a = {};
     a.M = (int)M; a.N = (int)N; a.K = (int)K;
     a.alpha = alpha; a.beta = beta;
     a.A = A; a.B = B; a.bias = bias; a.residual = residual; a.C = C; a.c_bf16 = c_bf16;
@@ -693,6 +734,32 @@ int kk_gemm16_launch(int ta, int tb, int64_t M, int64_t N, int64_t K, float alph
     else if (ns == 3) launch_tile<64, 64, 3>(ta, tb, a, grid, s);
     else launch_tile<64, 64, 2>(ta, tb, a, grid, s);
     KK_LAUNCH_CHECK("kk_gemm");
+    return 0;
+}
+
+// dX[M, N] = dY[M, K] . W[K, N] (bf16 everywhere) with Delta[b, head, q] = sum_d dX * O as the epilogue: the dgrad of an attention
+// output projection on the eight-wave 128x64 tile (a tile's 64 columns = one head).  `supported` mirrors kk_gemm16_launch's
+// tile choice: only launches that take that tile anyway get the epilogue.
+bool kk_gemm16_dgrad_delta_supported(int64_t M, int64_t N, int64_t K) {
+    auto cd = [](int64_t x, int64_t y) { return (int)((x + y - 1) / y); };
+    return g16_w8 != 0 && N % 64 == 0 && K % BK == 0 && cd(M, 128) * cd(N, 128) < g16_thr128 && cd(M, 128) * cd(N, 64) >= g16_thr12864;
+}
+int kk_gemm16_dgrad_delta(int64_t M, int64_t N, int64_t K, const void *dy, int64_t lddy, const void *W, int64_t ldw, void *dx,
+                          int64_t lddx, const void *O, int64_t ldo, float *delta, int S, int heads, int xcd_swizzle, hipStream_t s) {
+    auto cd = [](int64_t x, int64_t y) { return (int)((x + y - 1) / y); };
+    G16Args a = {};
+    a.M = (int)M; a.N = (int)N; a.K = (int)K;
+    a.alpha = 1.f; a.A = dy; a.B = W; a.C = dx; a.c_bf16 = 1;
+    a.lda = lddy; a.ldb = ldw; a.ldc = lddx;
+    a.k_per_split = cd(K, BK) * BK; a.splits = 1;
+    a.tiles_m = cd(M, 128); a.tiles_n = cd(N, 64); a.xcd_swizzle = xcd_swizzle;
+    a.a_bytes = (uint32_t)(((M - 1) * lddy + K) * 2);
+    a.b_bytes = (uint32_t)(((K - 1) * ldw + N) * 2);
+    a.dl_o = static_cast<const __bf16 *>(O); a.dl_out = delta; a.dl_ldo = ldo; a.dl_S = S; a.dl_heads = heads;
+    dim3 grid(a.tiles_m * a.tiles_n);
+    if (cd(K, BK) >= 3 && g16_stages >= 3 && g16_w8 >= 3) launch_w8<3>(0, 1, a, grid, s);
+    else launch_w8<2>(0, 1, a, grid, s);
+    KK_LAUNCH_CHECK("kk_gemm_dgrad_delta");
     return 0;
 }
 

@@ -196,6 +196,9 @@ class KokoroEngine:
         self.group_wgrads = os.environ.get("KK_GROUP_WGRADS", "1") != "0"     # A/B switches for tools/ and bench sweeps
         self.fuse_headnorm = os.environ.get("KK_FUSE_HEADNORM", "1") != "0"
         self.fuse_headnorm_bwd = os.environ.get("KK_FUSE_HEADNORM_BWD", "1") != "0"
+        # attention backward as ONE launch (kk_attn_bwd: the dQ and the dK/dV kernel as the two halves of a grid), Delta from the
+        # epilogue of the w_o dgrad GEMM (kk_gemm_dgrad_delta) — bf16 storage, shapes that take the eight-wave GEMM tile
+        self.attn_bwd_pair = os.environ.get("KK_ATTN_BWD_PAIR", "1") != "0"
         self._wgrad_queue = {}
         # The gradient arena was zeroed for THIS micro-batch (first of an accumulation cycle): a layer's grouped weight
         # gradients are each written exactly once per micro-batch, so they overwrite instead of read-modify-write (dW is
@@ -687,8 +690,16 @@ class KokoroEngine:
         # output and the column sums for w_o.bias
         d_out = self._buf("tmp.d_attn_proj" + ("" if xkv is None else ".x"), Nq, H, dtype=dt)
         self._wgrad(d_out, ctx, G[prefix + ".w_o.weight"], None)
-        self._dgrad(d_out, self._W(prefix + ".w_o.weight"), dctx)
-        # (Delta = rowsum(dctx * ctx) is computed by the dQ kernel from fragments it holds anyway, and read by the dK/dV kernel)
+        Wo = self._W(prefix + ".w_o.weight")
+        # Delta = rowsum(dctx * ctx): from the epilogue of this GEMM when the pair launch below takes it as an input, else computed
+        # by the dQ kernel from fragments it holds anyway (and read by the dK/dV kernel launched after it)
+        pair = bool(self.attn_bwd_pair and self.fuse_headnorm_bwd and i16 and _b16(d_out) and _b16(Wo) and (xkv is None or d_xkv is not None)
+                    and Sq > 64 and Sk > 64 and kk.load().kk_gemm_dgrad_delta_supported(Nq, H, H))
+        if pair:
+            kk.call("kk_gemm_dgrad_delta", Nq, H, H, d_out, d_out.stride(0), Wo, Wo.shape[1], dctx, dctx.stride(0), ctx, ctx.stride(0),
+                    delta, Sq, h)
+        else:
+            self._dgrad(d_out, Wo, dctx)
         if xkv is None:
             raw, nrm = self._buf(key + ".qkv_raw", Nq, 3 * H, dtype=dt), self._buf(key + ".qkv_n", Nq, 3 * H, dtype=dt)
             dn, draw = self._buf("tmp.dqkv_n", Nq, 3 * H, dtype=dt), self._buf("tmp.dqkv_raw", Nq, 3 * H, dtype=dt)
@@ -718,7 +729,12 @@ class KokoroEngine:
             return table
 
         if xkv is None:
-            if fuse:       # the head norms' backward is the epilogue of the two attention backward kernels
+            if pair:       # dQ | dK, dV in one launch, the head norms' backward as their epilogues
+                kk.call("kk_attn_bwd", q_n, k_n, v_n, dctx, lse, delta, dq_raw, dk_raw, dv_raw, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H,
+                        ld(dq_raw), ld(dk_raw), ld(dv_raw), key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16,
+                        hn_tables("q", Sq, [(q_raw, gq, dgq, cos, sin)]),
+                        hn_tables("kv", Sk, [(k_raw, gk, dgk, cos, sin), (v_raw, gv, dgv, None, None)]))
+            elif fuse:     # the head norms' backward is the epilogue of the two attention backward kernels
                 kk.call("kk_attn_bwd_dq", q_n, k_n, v_n, dctx, lse, delta, dq_raw, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H, ld(dq_raw),
                         key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16, ctx, H, hn_tables("q", Sq, [(q_raw, gq, dgq, cos, sin)]))
                 kk.call("kk_attn_bwd_dkv", q_n, k_n, v_n, dctx, lse, delta, dk_raw, dv_raw, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H,
@@ -734,7 +750,13 @@ class KokoroEngine:
             self._wgrad(draw, xq, a.fused(a.g, prefix + ".w_q.weight", 3))
             self._dgrad(draw, self._Wf(prefix + ".w_q.weight", 3), d_xq)
             return
-        if fuse:
+        if pair:
+            dkv_raw, _ = self._cross_kv(layer, Nk, dt, "d")
+            kk.call("kk_attn_bwd", q_n, k_n, v_n, dctx, lse, delta, dq_raw, dkv_raw, dkv_raw[:, H:], B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H,
+                    ld(dq_raw), ld(dkv_raw), ld(dkv_raw), key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16,
+                    hn_tables("q", Sq, [(q_raw, gq, dgq, None, None)]),
+                    hn_tables("kv", Sk, [(k_raw, gk, dgk, None, None), (v_raw, gv, dgv, None, None)]))
+        elif fuse:
             kk.call("kk_attn_bwd_dq", q_n, k_n, v_n, dctx, lse, delta, dq_raw, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H, ld(dq_raw),
                     key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16, ctx, H,
                     hn_tables("q", Sq, [(q_raw, gq, dgq, None, None)]))      # also writes delta

@@ -143,6 +143,9 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_attn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P],
     "kk_attn_delta": [_P, _P, _P, _I, _I, _I, _L, _L, _I, _P],
     "kk_attn_bwd_dq": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P, _L, _P, _P],
+    "kk_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P, _P, _P],
+    "kk_gemm_dgrad_delta": [_L, _L, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _I, _I, _P],
+    "kk_gemm_dgrad_delta_supported": [_L, _L, _L],
     "kk_attn_bwd_dkv": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P, _P],
     "kk_attn_bwd_blocks": [_I, _I, _I],
     "kk_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P],

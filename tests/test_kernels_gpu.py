@@ -1196,3 +1196,92 @@ def test_attention_backward_headnorm_epilogue(kk, B, h, Sq, Sk, causal, rope, bf
         assert float((dq_b == dq_a).float().mean()) > 0.99 and float((dkv_b == dkv_a).float().mean()) > 0.99, "almost all bits equal"
     for j, name in enumerate(("q", "k", "v")):
         close(dg_b[j], dg_a[j], 2e-3 * math.sqrt(B * max(Sq, Sk)), 2e-3, f"gain gradient {name}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,S,h,K", [(8, 512, 8, 512), (4, 1024, 8, 512), (3, 700, 8, 192), (16, 512, 4, 256)])
+def test_gemm_dgrad_delta_epilogue(kk, B, S, h, K):
+    """kk_gemm_dgrad_delta == kk_gemm (dgrad, bf16 result: bit-identical) + kk_attn_delta on that result (fp32 row sums of
+    the same rounded products, summed in a different order)."""
+    g = torch.Generator().manual_seed(B * S + K)
+    M, N = B * S, h * 64
+    assert kk.load().kk_gemm_dgrad_delta_supported(M, N, K) == 1
+    assert kk.load().kk_gemm_dgrad_delta_supported(512, N, K) == 0, "the encoder's 512-row GEMMs stay on 64x64 tiles"
+    dy = dev(torch.randn(M, K, generator=g)).bfloat16()
+    W = dev(torch.randn(K, N, generator=g) / math.sqrt(K)).bfloat16()
+    o = dev(torch.randn(M, N, generator=g)).bfloat16()
+    dx_ref, dx = torch.empty(M, N, device="cuda", dtype=torch.bfloat16), torch.full((M, N), 3.0, device="cuda", dtype=torch.bfloat16)
+    kk.call("kk_gemm", 0, 1, M, N, K, 1.0, dy, K, W, N, 0.0, dx_ref, N, None, None, 0, 0, 0, 1, 7)
+    d_ref, d_new = torch.empty(B, h, S, device="cuda"), torch.full((B, h, S), 9.0, device="cuda")
+    kk.call("kk_attn_delta", o, dx_ref, d_ref, B, h, S, N, N, 1)
+    kk.call("kk_gemm_dgrad_delta", M, N, K, dy, K, W, N, dx, N, o, N, d_new, S, h)
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx_ref), "the GEMM result must not change"
+    want = (dx_ref.float() * o.float()).view(B, S, h, 64).sum(-1).permute(0, 2, 1)
+    close(d_ref, want, 1e-4, 1e-4, "kk_attn_delta vs torch")
+    close(d_new, want, 1e-4, 1e-4, "delta from the GEMM epilogue")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,h,Sq,Sk,causal,rope,p,masked", [(1, 8, 512, 512, 1, 1, 0.1, 0), (2, 4, 512, 512, 0, 0, 0.2, 1), (1, 2, 1000, 1000, 1, 1, 0.2, 0),
+                                                            (1, 2, 900, 1000, 0, 1, 0.1, 1), (2, 2, 300, 384, 0, 0, 0.0, 0), (2, 2, 200, 200, 1, 1, 0.0, 0),
+                                                            (1, 2, 130, 400, 0, 0, 0.1, 0)])
+def test_attention_backward_pair_launch(kk, B, h, Sq, Sk, causal, rope, p, masked):
+    """kk_attn_bwd (dQ | dK, dV as the two halves of one grid, Delta an input) == kk_attn_bwd_dq + kk_attn_bwd_dkv given the
+    same Delta: bit-identical gradients and gain-gradient partial rows (same code, only the launch differs).  The last case
+    (different numbers of query and key blocks) takes the two-launch fall-back inside the entry point."""
+    g = torch.Generator().manual_seed(B * Sq + Sk + causal)
+    H = h * 64
+    dt = torch.bfloat16
+    raw_q = dev(torch.randn(B * Sq, H, generator=g)).to(dt)
+    raw_kv = dev(torch.randn(B * Sk, 2 * H, generator=g)).to(dt)
+    gains = [dev(1.0 + 0.2 * torch.randn(64, generator=g)) for _ in range(3)]
+    c, s = ((dev(t) for t in O.rope_tables(max(Sq, Sk), 64)) if rope else (None, None))
+    q_n, kv_n = torch.empty_like(raw_q), torch.empty_like(raw_kv)
+    kk.call("kk_headnorm_rope_fwd", raw_q, H, q_n, H, B * Sq, h, Sq, 1, gains[0], None, None, 1 if rope else 0, c, s, 1)
+    kk.call("kk_headnorm_rope_fwd", raw_kv, 2 * H, kv_n, 2 * H, B * Sk, h, Sk, 2, gains[1], gains[2], None, 1 if rope else 0, c, s, 1)
+    k_n, v_n = kv_n, kv_n[:, H:]
+    km = None
+    if masked:
+        km = torch.zeros(B, Sk, dtype=torch.uint8)
+        km[:, Sk - 37:] = 1
+        km[0, 5] = 1
+        km = dev(km)
+    do = dev(torch.randn(B * Sq, H, generator=g)).to(dt)
+    o, lse = torch.empty(B * Sq, H, device="cuda", dtype=dt), torch.empty(B, h, Sq, device="cuda")
+    seed = torch.tensor([91], dtype=torch.int32, device="cuda")
+    kk.call("kk_attn_fwd", q_n, k_n, v_n, o, lse, B, h, Sq, Sk, H, 2 * H, 2 * H, H, km, causal, 0.125, seed, 5, p, 1, 1)
+    delta = torch.empty(B, h, Sq, device="cuda")
+    kk.call("kk_attn_delta", o, do, delta, B, h, Sq, H, H, 1)
+    nbq, nbk = kk.load().kk_attn_bwd_blocks(B, h, Sq), kk.load().kk_attn_bwd_blocks(B, h, Sk)
+
+    def run(pair):
+        pq, pkv = torch.full((1, nbq, 64), 5.0, device="cuda"), torch.full((2, nbk, 64), 5.0, device="cuda")
+        dq, dkv = torch.full_like(raw_q, 7.0), torch.full_like(raw_kv, 7.0)
+        hq = kk.attn_headnorm([(raw_q, gains[0], pq[0], c, s)])
+        hkv = kk.attn_headnorm([(raw_kv, gains[1], pkv[0], c, s), (raw_kv[:, H:], gains[2], pkv[1], None, None)])
+        if pair:
+            kk.call("kk_attn_bwd", q_n, k_n, v_n, do, lse, delta, dq, dkv, dkv[:, H:], B, h, Sq, Sk, H, 2 * H, 2 * H, H, H, 2 * H, 2 * H, km,
+                    causal, 0.125, seed, 5, p, 1, 1, hq, hkv)
+        else:
+            kk.call("kk_attn_bwd_dq", q_n, k_n, v_n, do, lse, delta, dq, B, h, Sq, Sk, H, 2 * H, 2 * H, H, H, km, causal, 0.125, seed, 5, p,
+                    1, 1, None, 0, hq)
+            kk.call("kk_attn_bwd_dkv", q_n, k_n, v_n, do, lse, delta, dkv, dkv[:, H:], B, h, Sq, Sk, H, 2 * H, 2 * H, H, 2 * H, 2 * H, km,
+                    causal, 0.125, seed, 5, p, 1, 1, hkv)
+        torch.cuda.synchronize()
+        return dq, dkv, pq, pkv
+
+    ref, new = run(False), run(True)
+    for a_, b_, name in zip(ref, new, ("d raw q", "d raw k|v", "gain partials q", "gain partials k, v")):
+        assert torch.equal(a_, b_), f"{name}: the pair launch must reproduce the two launches bit for bit"
+    assert torch.isfinite(new[0].float()).all() and torch.isfinite(new[1].float()).all()
+    # without the head-norm epilogues
+    dq_a, dkv_a = torch.full_like(raw_q, 7.0), torch.full_like(raw_kv, 7.0)
+    dq_b, dkv_b = torch.full_like(raw_q, 7.0), torch.full_like(raw_kv, 7.0)
+    kk.call("kk_attn_bwd_dq", q_n, k_n, v_n, do, lse, delta, dq_a, B, h, Sq, Sk, H, 2 * H, 2 * H, H, H, km, causal, 0.125, seed, 5, p, 1, 1, None, 0, None)
+    kk.call("kk_attn_bwd_dkv", q_n, k_n, v_n, do, lse, delta, dkv_a, dkv_a[:, H:], B, h, Sq, Sk, H, 2 * H, 2 * H, H, 2 * H, 2 * H, km, causal, 0.125,
+            seed, 5, p, 1, 1, None)
+    kk.call("kk_attn_bwd", q_n, k_n, v_n, do, lse, delta, dq_b, dkv_b, dkv_b[:, H:], B, h, Sq, Sk, H, 2 * H, 2 * H, H, H, 2 * H, 2 * H, km, causal,
+            0.125, seed, 5, p, 1, 1, None, None)
+    torch.cuda.synchronize()
+    assert torch.equal(dq_a, dq_b) and torch.equal(dkv_a, dkv_b), "plain gradients: pair launch == two launches"
