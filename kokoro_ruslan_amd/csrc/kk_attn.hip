@@ -1423,9 +1423,15 @@ static int attn_pair() {                 // KK_ATTN_PAIR=0: kk_attn_bwd issues t
     static const int v = getenv("KK_ATTN_PAIR") ? atoi(getenv("KK_ATTN_PAIR")) : 1;
     return v;
 }
-static int attn_xcd_map() {
-    static const int v = getenv("KK_ATTN_XCD") ? atoi(getenv("KK_ATTN_XCD")) : 1;
+static int attn_xcd_env() {
+    static const int v = getenv("KK_ATTN_XCD") ? atoi(getenv("KK_ATTN_XCD")) : 2;
     return v;
+}
+// AttnArgs::xcd_map of a launch: 0 = launch order, 1 = a head's blocks on one XCD, 2 (default for causal launches) = that, with the
+// blocks of an XCD's heads longest first (attn_block).  KK_ATTN_XCD=1 keeps 1 for the single-kernel causal launches.
+static int attn_xcd_map(int causal = 0) {
+    const int v = attn_xcd_env();
+    return v == 2 ? (causal ? 2 : 1) : v;
 }
 
 // Launch KERNEL<BF16, ST16, G> with G*256 threads and its dynamic LDS (buffers x groups x NT tiles; above 64 KB the
@@ -1488,7 +1494,7 @@ extern "C" int kk_attn_fwd(const float *Q, const float *K, const float *V, float
     a.Q = Q; a.K = K; a.V = V; a.Out = O; a.LSEo = LSE; a.key_mask = key_mask;
     a.B = B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.causal = causal;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldout = ldo; a.scale = scale;
-    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(); a.dbg = attn_dbg();
+    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(causal); a.dbg = attn_dbg();
     dim3 grid(kk_cdiv(Sq, 128), B * heads);
     const int G = (Sk > 64 && g_attn_groups == 2) ? 2 : 1;          // one key tile: nothing to split
     // Four key groups (16 waves): the longest chain of key-tile steps of a 128-query block halves again — a causal block
@@ -1548,7 +1554,7 @@ extern "C" int kk_attn_bwd_dq(const float *Q, const float *K, const float *V, co
         KK_REQUIRE(ldo % 8 == 0 && ldo >= 64 * heads, "kk_attn_bwd_dq: row stride of O unsupported");
         a.O = O; a.ldo = ldo; a.DeltaOut = Delta;
     }
-    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(); a.dbg = attn_dbg();
+    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(causal); a.dbg = attn_dbg();
     if (hn) {
         if (int rc = check_headnorm("kk_attn_bwd_dq", hn, 1)) return rc;
         a.hn[0] = hn[0];
@@ -1581,7 +1587,7 @@ extern "C" int kk_attn_bwd_dkv(const float *Q, const float *K, const float *V, c
     a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.LSE = LSE; a.Delta = Delta; a.Out = dK; a.Out2 = dV; a.key_mask = key_mask;
     a.B = B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.causal = causal;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.lddo = lddo; a.ldout = lddk; a.ldout2 = lddv; a.scale = scale;
-    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(); a.dbg = attn_dbg();
+    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(causal); a.dbg = attn_dbg();
     if (hn) {
         if (int rc = check_headnorm("kk_attn_bwd_dkv", hn, 2)) return rc;
         a.hn[0] = hn[0]; a.hn[1] = hn[1];
@@ -1635,8 +1641,8 @@ extern "C" int kk_attn_bwd(const float *Q, const float *K, const float *V, const
     a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.LSE = LSE; a.Delta = Delta; a.Out = dQ; a.key_mask = key_mask;
     a.B = B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.causal = causal;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.lddo = lddo; a.ldout = lddq; a.scale = scale;
-    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(); a.dbg = attn_dbg();
-    if (a.xcd_map && causal) a.xcd_map = 2;
+    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(causal); a.dbg = attn_dbg();
+    if (a.xcd_map && causal) a.xcd_map = 2;                    // (the pair launch: always block-major when causal)
     p.dkv = a;
     p.dkv.Out = dK; p.dkv.Out2 = dV; p.dkv.ldout = lddk; p.dkv.ldout2 = lddv;
     if (hn_q) {

@@ -42,4 +42,5 @@ for S in (512, 1024):
         def dkv(): kk.call("kk_attn_bwd_dkv", q, k, v, do, lse, delta, dqkv[:, H:], dqkv[:, 2 * H:], B, h, S, S, 3 * H, 3 * H, 3 * H, H, 3 * H, 3 * H, km, causal, 0.125, seed, 3, p, 1, 1, hkv)
         def both(): dq(); dkv()
         def pair(): kk.call("kk_attn_bwd", q, k, v, do, lse, delta, dqkv, dqkv[:, H:], dqkv[:, 2 * H:], B, h, S, S, 3 * H, 3 * H, 3 * H, H, 3 * H, 3 * H, 3 * H, km, causal, 0.125, seed, 3, p, 1, 1, hq, hkv)
-        print(f"S={S} causal={causal}: dq {graph_time(dq):6.1f}  dkv {graph_time(dkv):6.1f}  dq+dkv {graph_time(both):6.1f}  pair {graph_time(pair):6.1f} us", flush=True)
+        def fwd(): kk.call("kk_attn_fwd", q, k, v, o, lse, B, h, S, S, 3 * H, 3 * H, 3 * H, H, km, causal, 0.125, seed, 3, p, 1, 1)
+        print(f"S={S} causal={causal}: fwd {graph_time(fwd):6.1f}  dq {graph_time(dq):6.1f}  dkv {graph_time(dkv):6.1f}  dq+dkv {graph_time(both):6.1f}  pair {graph_time(pair):6.1f} us", flush=True)
