@@ -191,6 +191,10 @@ class KokoroEngine:
         # one (630K -> 638K), but a per-layer fork for the cross-attention K/V backward lost 9 %, a stream per
         # weight-gradient GEMM 19 %, and moving the duration predictor's forward aside 2 %.
         self._kv = torch.cuda.Stream(device=self.device)
+        # KK_KV_SPLIT=1: the cross-attention K/V of decoder layer 0 on the main chain, those of layers 1.. in a second GEMM on
+        # a branch beside layer 0 (measured: see DESIGN)
+        self._kv2 = torch.cuda.Stream(device=self.device)
+        self.kv_split = os.environ.get("KK_KV_SPLIT", "0") == "1"
         self.dec_head_aside = True
         self.fuse_glu_fwd = os.environ.get("KK_FUSE_GLU_FWD", "1") != "0"
         self.group_wgrads = os.environ.get("KK_GROUP_WGRADS", "1") != "0"     # A/B switches for tools/ and bench sweeps
@@ -655,15 +659,18 @@ class KokoroEngine:
             kk.call("kk_headnorm_rope_fwd", raw[:, p0 * H:], raw.stride(0), nrm[:, p0 * H:], nrm.stride(0), rows, h, S, n,
                     g[0], g[1], g[2], (rope_mask >> p0) & 7, cos, sin, _b16(raw))
 
-    def _cross_kv_fwd_all(self, xkv, Nk, Sk, dt):
+    def _cross_kv_fwd_all(self, xkv, Nk, Sk, dt, first=0, last=None):
         """K/V projections of ALL decoder cross-attention layers in one GEMM (they depend on the memory alone and their
         weights are contiguous in the arena), then the per-head RMSNorm of each layer's slice (no RoPE:
         transformers.py:268-277 applies it to self-attention only)."""
         P, H, h, L = self.arena.P, self.dims.hidden, self.dims.heads, self.dims.dec_layers
         raw_all = self._buf("dec.ca.kv_raw_all", Nk, 2 * H * L, dtype=dt)
         nrm_all = self._buf("dec.ca.kv_n_all", Nk, 2 * H * L, dtype=dt)
-        gains = [P[f"decoder.layers.{l}.cross_attn.{kv}_norm.weight"] for l in range(L) for kv in ("k", "v")]
-        self._proj_headnorm(xkv, self._Wf("decoder.layers.0.cross_attn.w_k.weight", 2 * L), raw_all, nrm_all, Sk, gains, 0, None, None)
+        last = L if last is None else last                 # layers [first, last): a column slice of the all-layer buffers
+        gains = [P[f"decoder.layers.{l}.cross_attn.{kv}_norm.weight"] for l in range(first, last) for kv in ("k", "v")]
+        c0, c1 = 2 * H * first, 2 * H * last
+        self._proj_headnorm(xkv, self._Wf(f"decoder.layers.{first}.cross_attn.w_k.weight", 2 * (last - first)), raw_all[:, c0:c1],
+                            nrm_all[:, c0:c1], Sk, gains, 0, None, None)
 
     def _cross_kv_bwd_all(self, xkv, Nk, dt, d_xkv):
         """Weight gradient of all layers' K/V projections and the memory gradient: two GEMMs over the all-layer buffer."""
@@ -1086,7 +1093,13 @@ class KokoroEngine:
 
         # ---- decoder (model.py:519-531; transformers.py:543-583,660) ----
         self._mark("memory ready")
-        self._cross_kv_fwd_all(memory, Nd, T, ddt)        # every layer's cross-attention K/V in one GEMM
+        kv_split = bool(self.kv_split and self.overlap and not seg and d.dec_layers > 1)
+        if kv_split:                                      # layer 0's K/V here, the other layers' beside layer 0
+            self._cross_kv_fwd_all(memory, Nd, T, ddt, 0, 1)
+            with self._on_stream(self._kv2, "kv2."):
+                self._cross_kv_fwd_all(memory, Nd, T, ddt, 1, d.dec_layers)
+        else:
+            self._cross_kv_fwd_all(memory, Nd, T, ddt)    # every layer's cross-attention K/V in one GEMM
         self._mark("cross K/V fwd done")
         # Forked only here, after the K/V GEMM: started earlier (right after im2col3) the predictors' fp32 GEMMs compete
         # with the critical path into the decoder; 2.8 % of the step (729K -> 749K frames/s).
@@ -1124,6 +1137,8 @@ class KokoroEngine:
                 if n1 is None:
                     n1 = self._ln_fwd(key + ".ln1", y, pf + ".norm1", ddt)
                 ya, n2 = self_attn(i, y, n1)
+                if i == 1 and kv_split:
+                    self._join(self._kv2)
             yc = self._buf(key + ".xc", Nd, H)
             n3 = self._attn_fwd(key + ".ca", pf + ".cross_attn", n2, memory, B, T, T, False, False, fmask, ya, yc, st + 8, p_dec, dpr,
                                 next_ln=(key + ".ln3", pf + ".norm3", ddt), layer=i)
