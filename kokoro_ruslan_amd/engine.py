@@ -203,6 +203,7 @@ class KokoroEngine:
         # attention backward as ONE launch (kk_attn_bwd: the dQ and the dK/dV kernel as the two halves of a grid), Delta from the
         # epilogue of the w_o dgrad GEMM (kk_gemm_dgrad_delta) — bf16 storage, shapes that take the eight-wave GEMM tile
         self.attn_bwd_pair = os.environ.get("KK_ATTN_BWD_PAIR", "1") != "0"
+        self.attn_proj_bf16 = os.environ.get("KK_ATTN_PROJ_BF16", "1") != "0"      # decoder w_o output stored as bf16 (bf16 mode)
         self._wgrad_queue = {}
         # The gradient arena was zeroed for THIS micro-batch (first of an accumulation cycle): a layer's grouped weight
         # gradients are each written exactly once per micro-batch, so they overwrite instead of read-modify-write (dW is
@@ -630,7 +631,11 @@ class KokoroEngine:
         ctx, lse = self._buf(key + ".ctx", Nq, H, dtype=dt), self._buf(key + ".lse", B, h, Sq)
         kk.call("kk_attn_fwd", q_n, k_n, v_n, ctx, lse, B, h, Sq, Sk, q_n.stride(0), k_n.stride(0), v_n.stride(0), H, key_mask,
                 1 if causal else 0, 0.125, self.rng, site + 3, p, self.math, i16)
-        proj = self._buf("tmp.attn_proj", Nq, H)
+        # the projection output lives only until the tail two launches later: in the decoder's bf16 mode it is stored like every
+        # other GEMM result there (what autocast gives the reference's nn.Linear); the text encoder keeps fp32 (its persistent
+        # launch hands the tile over in fp32, and the per-kernel path must match it)
+        p16 = self.attn_proj_bf16 and i16 and key.startswith("dec")
+        proj = self._buf("tmp.attn_proj16" if p16 else "tmp.attn_proj", Nq, H, dtype=dt if p16 else torch.float32)
         self._linear(ctx, self._W(prefix + ".w_o.weight"), P[prefix + ".w_o.bias"], proj)
         return self._sublayer_tail(proj, x_res, x_out, Sq, site, p, dpr, 0.0, None, None, next_ln)   # (p = 0: masks are all ones)
 
