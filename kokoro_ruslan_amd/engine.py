@@ -1026,7 +1026,6 @@ class KokoroEngine:
         # ---- encoder (model.py:375-388) ----
         text_mask = self._buf("text_mask", B, Pn, dtype=torch.uint8)
         kk.call("kk_ids_eq_zero", ids, text_mask, Ne)
-        kk.call("kk_max_i64", dur, Ne, self.max_dur)
         x = self._buf("enc.x0", Ne, H)
         hp = self.hp
         if self.train_dropout:
@@ -1038,6 +1037,7 @@ class KokoroEngine:
         with self._on_stream(self._kv, "kv.", self.dec_head_aside):     # beside the encoder; joined before the first cross-attention
             if zero_grads and not self.zero_late:
                 self.zero_grad()
+            kk.call("kk_max_i64", dur, Ne, self.max_dur)  # (read by the losses only: not in front of the encoder)
             dec_head = decoder_head()                     # (includes the gradient zero-fill, see there)
             self._mark("kv: decoder head done")
         if seg and self.dec_head_aside:
