@@ -144,7 +144,7 @@ class KokoroEngine:
         # capture mode notwithstanding.
         self.capture_lock = threading.Lock()
         self._rope: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
-        self._reduce_lists = {"": [], "side.": [], "kv.": []}             # per stream namespace
+        self._reduce_lists = {"": [], "side.": [], "kv.": [], "kv2.": []}   # per stream namespace
         self.opt_state = torch.zeros(kk.OS["SIZE"], dtype=torch.float64, device=self.device)
         ns = self.arena.nseg
         f32 = lambda n: torch.zeros(n, dtype=torch.float32, device=self.device)
@@ -195,6 +195,9 @@ class KokoroEngine:
         # a branch beside layer 0 (measured: see DESIGN)
         self._kv2 = torch.cuda.Stream(device=self.device)
         self.kv_split = os.environ.get("KK_KV_SPLIT", "0") == "1"
+        # KK_SIDE_SPLIT=1: the backward's side branch as TWO branches — pitch / energy predictors and the output heads' weight
+        # gradients on one, duration predictor + text encoder on the other (they only meet in the optimizer)
+        self.side_split = os.environ.get("KK_SIDE_SPLIT", "0") == "1"
         self.dec_head_aside = True
         self.fuse_glu_fwd = os.environ.get("KK_FUSE_GLU_FWD", "1") != "0"
         self.group_wgrads = os.environ.get("KK_GROUP_WGRADS", "1") != "0"     # A/B switches for tools/ and bench sweeps
@@ -573,7 +576,7 @@ class KokoroEngine:
     def _reduce_partials(self, shape_key) -> None:
         """One launch that adds the column sums of every partial matrix written so far (by streams already joined into
         the current one) to its gradient vectors."""
-        todo = [e for ns in ("side.", "kv.", "") for e in self._reduce_lists[ns]]
+        todo = [e for ns in ("side.", "kv2.", "kv.", "") for e in self._reduce_lists[ns]]
         for ns in self._reduce_lists:
             self._reduce_lists[ns] = []
         if not todo:
@@ -1201,21 +1204,30 @@ class KokoroEngine:
         if seg:
             yield ("fork",)
 
+        side2 = bool(self.side_split and self.overlap and not seg and yield_at is None)
+
+        def heads_and_frame_predictors():
+            # the output heads' weight gradients have no consumer on the decoder chain (the stop head's input is
+            # detached, model.py:561-562): 50 us off the critical path
+            kk.call("kk_rowdot_bwd", dstop, dec_out, P["stop_token_predictor.weight"], None, None, G["stop_token_predictor.weight"],
+                    G["stop_token_predictor.bias"], Nd, H, T, 0, _b16(dec_out))
+            self._wgrad(dmel.view(Nd, M), dec_out, G["mel_projection_out.weight"], G["mel_projection_out.bias"])
+            dpitch_p, denergy_p = dpitch, denergy
+            if Tp != T:                               # frames past T carry no loss: zero gradient there
+                dpitch_p, denergy_p = self._buf("g.pitch_p", B, Tp), self._buf("g.energy_p", B, Tp)
+                kk.call("kk_pad2d_f32", dpitch, T, T, dpitch_p, Tp, Tp, B)
+                kk.call("kk_pad2d_f32", denergy, T, T, denergy_p, Tp, Tp, B)
+            self._varpred_bwd("vp.pitch", f"{VA}.pitch_predictor", dpitch_p, xf_p, col_f, B, Tp, fmask_p, None, p_var)
+            self._varpred_bwd("vp.energy", f"{VA}.energy_predictor", denergy_p, xf_p, col_f, B, Tp, fmask_p, None, p_var)
+
         def side_backward(after):                         # independent of the decoder backward (disjoint gradient segments)
+            if side2:
+                with self._on_stream(self._kv2, "kv2.", after=after):
+                    heads_and_frame_predictors()
             with self._on_side_stream(after=after):
                 self._mark("side: backward start")
-                # the output heads' weight gradients have no consumer on the decoder chain (the stop head's input is
-                # detached, model.py:561-562): 50 us off the critical path
-                kk.call("kk_rowdot_bwd", dstop, dec_out, P["stop_token_predictor.weight"], None, None, G["stop_token_predictor.weight"],
-                        G["stop_token_predictor.bias"], Nd, H, T, 0, _b16(dec_out))
-                self._wgrad(dmel.view(Nd, M), dec_out, G["mel_projection_out.weight"], G["mel_projection_out.bias"])
-                dpitch_p, denergy_p = dpitch, denergy
-                if Tp != T:                               # frames past T carry no loss: zero gradient there
-                    dpitch_p, denergy_p = self._buf("g.pitch_p", B, Tp), self._buf("g.energy_p", B, Tp)
-                    kk.call("kk_pad2d_f32", dpitch, T, T, dpitch_p, Tp, Tp, B)
-                    kk.call("kk_pad2d_f32", denergy, T, T, denergy_p, Tp, Tp, B)
-                self._varpred_bwd("vp.pitch", f"{VA}.pitch_predictor", dpitch_p, xf_p, col_f, B, Tp, fmask_p, None, p_var)
-                self._varpred_bwd("vp.energy", f"{VA}.energy_predictor", denergy_p, xf_p, col_f, B, Tp, fmask_p, None, p_var)
+                if not side2:
+                    heads_and_frame_predictors()
                 d_enc = self._buf("g.enc_out", Ne, H)
                 self._varpred_bwd("vp.dur", f"{VA}.duration_predictor", ddur, enc, col_e, B, Pn, text_mask, d_enc, p_var)
                 self._mark("side: predictors bwd done")
@@ -1314,6 +1326,8 @@ class KokoroEngine:
             yield ("join", "side")
         else:
             self._join(self._side)
+            if side2:
+                self._join(self._kv2)
         self._reduce_partials((B, T, Pn, Tp))
         self._comm_bucket("tail")                       # everything that was not a layer's weight matrix
         self._comm_join()
