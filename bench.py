@@ -82,6 +82,8 @@ def kernel_table(records, math_bf16: bool):
             T_, parts, heads, K_ = (int(x) for x in sc[:4])
             N_ = parts * heads * 64
             key = f"gemm16_kernel<false,false,64,64,{2 if K_ // 64 < 3 else 3},3> (q|k|v projection + head-norm epilogue)"
+            if K_ // 64 >= 3 and -(-T_ // 128) * -(-N_ // 64) >= 128 and os.environ.get("KK_G16_W8_HN", "1") != "0":
+                key = "gemm16_kernel_w8_hn (q|k|v projection + head-norm epilogue, 128x64 tiles)"
             flops, byts = 2.0 * T_ * N_ * K_, 2.0 * (T_ * K_ + N_ * K_ + 2 * T_ * N_)
         elif name == "kk_gemm_dgrad_delta":             # (M, N, K, ...): the w_o dgrad with the Delta epilogue, same instantiation as kk_gemm's
             M, N, K = (int(x) for x in sc[:3])

@@ -170,8 +170,8 @@ template <bool TA, bool TB, int BM, int BN, int NS, int EPI, int WAVES = 4, int 
 __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char *smem) {
     constexpr int WR = WAVES / WC;                              // waves along M x waves along N
     constexpr int MI = BM / (32 * WR), NI = BN / (32 * WC);     // 32x32 MFMA tiles per wave (wave tile = BM/WR x BN/WC)
-    static_assert(EPI == 0 || WAVES == 4 || ((EPI == 1 || EPI == 2) && WAVES == 8 && BM == 128 && BN == 64),
-                  "the epilogue variants are written for four waves (the two GLU ones also for the eight-wave 128x64 tile)");
+    static_assert(EPI == 0 || WAVES == 4 || (WAVES == 8 && BM == 128 && BN == 64),
+                  "the epilogue variants are written for four waves and for the eight-wave 128x64 tile");
     using OA = Operand<BM, TA, 64 * WAVES>;
     using OB = Operand<BN, TB, 64 * WAVES>;
     constexpr int NB = EPI == 2 ? 2 : 1;                        // EPI == 2 multiplies A with TWO 64-row panels of B (see below)
@@ -350,7 +350,7 @@ __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char
         return;
     }
     if constexpr (EPI == 3) {
-        static_assert(EPI != 3 || (BM == 64 && BN == 64), "the head-norm epilogue is written for the 64x64 tile");
+        static_assert(EPI != 3 || (BN == 64 && BM / WR == 32 && BN / WC == 32), "the head-norm epilogue expects one 32x32 MFMA tile per wave, 64 columns");
         constexpr int PITCH = 72;                               // bf16 per LDS row: 144 B, rows land on different banks
         __bf16 *tile = reinterpret_cast<__bf16 *>(smem);
         __builtin_amdgcn_s_barrier();                           // every wave is done with the last stage
@@ -365,9 +365,10 @@ __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char
         const bool rope = (a.hn_rope_mask >> part) & 1;
         const float4 g = ld4(a.hn_gain[part] + sub * 4);
         __bf16 *raw = static_cast<__bf16 *>(a.C);
+        constexpr int RPI = 4 * WAVES;                          // rows per pass: 16 threads per (row, head) vector
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int rl = it * 16 + (threadIdx.x >> 4), row = m0 + rl;
+        for (int it = 0; it < BM / RPI; ++it) {
+            const int rl = it * RPI + (threadIdx.x >> 4), row = m0 + rl;
             const bf16x4 r4 = *reinterpret_cast<const bf16x4 *>(tile + rl * PITCH + sub * 4);
             const float4 v = make_float4((float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]);
             const int pos = rope ? (row < a.M ? row : a.M - 1) % a.hn_S : 0;
@@ -554,8 +555,16 @@ __global__ __launch_bounds__(512) void gemm16_kernel_w8_glu(G16Args a) {
     __shared__ __attribute__((aligned(16))) char smem[NS * (128 + (EPI == 2 ? 2 : 1) * 64) * BK * 2];
     gemm16_body<false, TB, 128, 64, NS, EPI, 8, 2>(a, blockIdx.x, smem);
 }
+// EPI 3 on the eight-wave tile (KK_G16_W8_HN=0: the four-wave 64x64 form)
+template <int NS>
+__global__ __launch_bounds__(512) void gemm16_kernel_w8_hn(G16Args a) {
+    __shared__ __attribute__((aligned(16))) char smem[NS * (128 + 64) * BK * 2];
+    gemm16_body<false, false, 128, 64, NS, 3, 8, 2>(a, blockIdx.x, smem);
+}
+template __global__ void gemm16_kernel_w8_hn<3>(G16Args);
 template __global__ void gemm16_kernel_w8_glu<false, 3, 2>(G16Args);
 template __global__ void gemm16_kernel_w8_glu<true, 3, 1>(G16Args);
+int g16_w8_hn = getenv("KK_G16_W8_HN") ? atoi(getenv("KK_G16_W8_HN")) : 1;        // measured: +0.8 % on the step (interleaved A/B)
 int g16_w8_glu = getenv("KK_G16_W8_GLU") ? atoi(getenv("KK_G16_W8_GLU")) : 0;      // measured: -0.7 % on the step, left off
 
 template <int NS>
@@ -877,6 +886,12 @@ int kk_gemm16_qkv_headnorm(int64_t T, int parts, int heads, int64_t K, const voi
     for (int i = 0; i < parts; ++i) a.hn_gain[i] = gains[i];
     a.hn_cos = cos_t; a.hn_sin = sin_t; a.hn_y = static_cast<__bf16 *>(y); a.hn_ldy = ldy;
     a.hn_S = S; a.hn_H = heads * 64; a.hn_rope_mask = rope_mask;
+    if (g16_w8_hn && cd(K, BK) >= 3 && cd(T, 128) * cd(N, 64) >= g16_thr12864) {       // eight waves on 128x64 tiles, like the plain GEMMs
+        a.tiles_m = cd(T, 128);
+        hipLaunchKernelGGL((gemm16_kernel_w8_hn<3>), dim3(a.tiles_m * a.tiles_n), dim3(512), 0, s, a);
+        KK_LAUNCH_CHECK("kk_gemm_qkv_headnorm");
+        return 0;
+    }
     dim3 grid(a.tiles_m * a.tiles_n);
     if (cd(K, BK) < 3) hipLaunchKernelGGL((gemm16_kernel<false, false, 64, 64, 2, 3>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((gemm16_kernel<false, false, 64, 64, 3, 3>), grid, dim3(256), 0, s, a);
