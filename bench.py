@@ -77,6 +77,8 @@ def kernel_table(records, math_bf16: bool):
         elif name == "kk_gemm_dgrad_glu":               # (T, F, H, ...): dG = dY.W2 + gate backward
             T_, F_, H_ = (int(x) for x in sc[:3])
             key = f"gemm16_kernel<false,true,64,64,{2 if H_ // 64 < 3 else 3},1> (dY.W2 + GLU backward epilogue)"
+            if H_ // 64 >= 3 and -(-T_ // 128) * -(-F_ // 64) >= 128 and int(os.environ.get("KK_G16_W8_GLU", "1")) & 1:
+                key = "gemm16_kernel_w8_glu (dY.W2 + GLU backward epilogue, 128x64 tiles)"
             flops, byts = 2.0 * T_ * F_ * H_, 2.0 * (T_ * H_ + F_ * H_ + 4 * T_ * F_)
         elif name == "kk_gemm_qkv_headnorm":            # (T, parts, heads, K, ...)
             T_, parts, heads, K_ = (int(x) for x in sc[:4])

@@ -565,7 +565,7 @@ template __global__ void gemm16_kernel_w8_hn<3>(G16Args);
 template __global__ void gemm16_kernel_w8_glu<false, 3, 2>(G16Args);
 template __global__ void gemm16_kernel_w8_glu<true, 3, 1>(G16Args);
 int g16_w8_hn = getenv("KK_G16_W8_HN") ? atoi(getenv("KK_G16_W8_HN")) : 1;        // measured: +0.8 % on the step (interleaved A/B)
-int g16_w8_glu = getenv("KK_G16_W8_GLU") ? atoi(getenv("KK_G16_W8_GLU")) : 0;      // measured: -0.7 % on the step, left off
+int g16_w8_glu = getenv("KK_G16_W8_GLU") ? atoi(getenv("KK_G16_W8_GLU")) : 1;      // bit 0: dgrad + GLU backward, bit 1: linear1 + GLU; 4th part, interleaved: bit 0 +0.3 % (on), bit 1 -0.5 % (off)
 
 template <int NS>
 void launch_w8(int ta, int tb, const G16Args &a, dim3 grid, hipStream_t s) {
@@ -784,7 +784,7 @@ int kk_gemm16_dgrad_glu(int64_t T, int64_t F, int64_t H, const void *dy, int64_t
     a.b_bytes = (uint32_t)(((H - 1) * F + F) * 2);
     a.glu_h = static_cast<const __bf16 *>(h1); a.glu_dh = static_cast<__bf16 *>(dh1); a.glu_partials = partials;
     a.glu_seed = p > 0.f ? seed : nullptr; a.glu_site = site; a.glu_p = p;
-    if (g16_w8_glu && cd(H, BK) >= 3 && cd(T, 128) * cd(F, 64) >= g16_thr12864) {       // eight waves on 128x64 tiles, like the plain GEMMs
+    if ((g16_w8_glu & 1) && cd(H, BK) >= 3 && cd(T, 128) * cd(F, 64) >= g16_thr12864) {       // eight waves on 128x64 tiles, like the plain GEMMs
         a.tiles_m = cd(T, 128);
         hipLaunchKernelGGL((gemm16_kernel_w8_glu<true, 3, 1>), dim3(a.tiles_m * a.tiles_n), dim3(512), 0, s, a);
         KK_LAUNCH_CHECK("kk_gemm_dgrad_glu");
@@ -809,7 +809,7 @@ int kk_gemm16_linear_glu(int64_t T, int64_t F, int64_t K, const void *x, int64_t
     a.b_bytes = (uint32_t)(((2 * F - 1) * K + K) * 2);
     a.glu_dh = static_cast<__bf16 *>(h1);
     a.glu_seed = p > 0.f ? seed : nullptr; a.glu_site = site; a.glu_p = p;
-    if (g16_w8_glu && cd(K, BK) >= 3 && cd(T, 128) * cd(F, 64) >= g16_thr12864) {
+    if ((g16_w8_glu & 2) && cd(K, BK) >= 3 && cd(T, 128) * cd(F, 64) >= g16_thr12864) {
         a.tiles_m = cd(T, 128);
         hipLaunchKernelGGL((gemm16_kernel_w8_glu<false, 3, 2>), dim3(a.tiles_m * a.tiles_n), dim3(512), 0, s, a);
         KK_LAUNCH_CHECK("kk_gemm_linear_glu");
