@@ -663,7 +663,7 @@ struct G16EnvInit {
         }
     }
 } g16_env_init;
-int g16_group_tile = 1;                                         // grouped launches: 0 = 64x64, 1 = 128x64 (default: +1 % on the step), 2 = 128x128 tiles
+int g16_group_tile = getenv("KK_GROUP_TILE") ? atoi(getenv("KK_GROUP_TILE")) : 1;                                         // grouped launches: 0 = 64x64, 1 = 128x64 (default: +1 % on the step), 2 = 128x128 tiles
 int g16_group_waves = getenv("KK_GROUP_WAVES") ? atoi(getenv("KK_GROUP_WAVES")) : 8;   // 8-wave workgroups on the 128-row tiles (4: the old form)
 int g16_group_split = 0;                                        // grouped launches: 0 = by the split target, n = n k-slices
 
