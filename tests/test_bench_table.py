@@ -1,0 +1,43 @@
+"""CPU suite: bench.py's kernel table (the roofline leg's bookkeeping) — names and algorithmic FLOPs / bytes of the launches
+the engine makes at the bench shape, from synthetic profile records (no GPU)."""
+import importlib.util
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("kk_bench", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_kernel_table_accounts_for_the_attention_backward_pair_and_its_delta_gemm():
+    b = _bench()
+    B, h, S, H = 8, 8, 512, 512
+    recs = [
+        # kk_attn_bwd: (B, h, Sq, Sk, 7 row strides, causal, scale, site, p_drop, math, io_bf16)
+        ("kk_attn_bwd", (B, h, S, S, 1536, 1536, 1536, H, 1536, 1536, 1536, 1, 0.125, 2003, 0.2, 1, 1), 0.035),
+        ("kk_attn_bwd", (B, h, S, S, H, 6144, 6144, H, H, 6144, 6144, 0, 0.125, 2011, 0.2, 1, 1), 0.041),
+        # kk_gemm_dgrad_delta: (M, N, K, lddy, ldw, lddx, ldo, S, heads)
+        ("kk_gemm_dgrad_delta", (B * S, H, H, H, H, H, H, S, h), 0.008),
+        # the plain dgrad of the same shape lands on the same kernel instantiation
+        ("kk_gemm", (0, 1, B * S, H, H, 1.0, H, H, 0.0, H, 0, 0, 0, 1, 7), 0.0075),
+        ("kk_gemm_qkv_headnorm", (B * S, 3, h, H, H, 1536, 1536, S, 3), 0.020),
+        ("kk_gemm_qkv_headnorm", (512, 3, h, H, H, 1536, 1536, 64, 3), 0.010),
+        ("kk_gemm_dgrad_glu", (B * S, 1536, H, H, 2003, 0.2), 0.027),
+    ]
+    t = b.kernel_table(recs, True)
+    pair = t["attn_bwd_pair2_kernel (dQ | dK, dV in one launch)"]
+    full = 7 * 2.0 * B * h * S * S * 64
+    assert pair["launches"] == 2 and abs(pair["flops"] - (0.5 * full + full)) < 1.0          # causal = lower triangle
+    assert pair["bytes"] == 2 * 2.0 * B * h * 64 * 8 * S
+    w8 = [k for k in t if k.startswith("gemm16_kernel_w8<false,true,3>")]
+    assert len(w8) == 1 and t[w8[0]]["launches"] == 2 and t[w8[0]]["flops"] == 2 * 2.0 * B * S * H * H
+    assert t["gemm16_kernel_w8_hn (q|k|v projection + head-norm epilogue, 128x64 tiles)"]["launches"] == 1
+    assert t["gemm16_kernel<false,false,64,64,3,3> (q|k|v projection + head-norm epilogue)"]["launches"] == 1      # the encoder's 512 rows
+    assert t["gemm16_kernel_w8_glu (dY.W2 + GLU backward epilogue, 128x64 tiles)"]["flops"] == 2.0 * B * S * 1536 * H
+    shapes = [k for k in t if k.startswith("  shape")]
+    assert any("kk_attn_bwd B=8 h=8 Sq=512 Sk=512 causal=1" in k for k in shapes)
+    assert sum("ta=0 tb=1 M=4096 N=512 K=512" in k for k in shapes) == 1

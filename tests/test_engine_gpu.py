@@ -677,6 +677,36 @@ def test_bench_config_bf16_graph_replay_tracks_fp32_and_oracle(eng_mod):
     assert float(e2.losses[0]) != float(first[0])
 
 
+def test_bench_config_takes_the_pair_launch_and_it_changes_nothing(eng_mod):
+    """At the bench shape the decoder's 12 attention backwards are kk_gemm_dgrad_delta + ONE kk_attn_bwd launch each (the text
+    encoder's six, one key tile, keep the two first-generation launches), and the step computes what the two-launch form
+    computes: same losses, gradients equal to the rounding of Delta's summation order."""
+    from kokoro_ruslan_amd import lib as kk
+    from kokoro_ruslan_amd.synthetic import synthetic_batch
+    d = O.ModelDims()
+    P = O.init_params(d, 0)
+    b = _cuda(synthetic_batch(8, 512, 64, seed=1234))
+    e = _engine(eng_mod, d, P, math_mode="bf16", gradient_accumulation_steps=1)
+    assert e.attn_bwd_pair
+    e.zero_grad()
+    kk.profile_start()
+    l_pair = e.forward_backward(b)["losses"].clone()
+    names = [r[0] for r in kk.profile_stop()]
+    g_pair = e.arena.g.clone()
+    assert names.count("kk_attn_bwd") == 2 * d.dec_layers and names.count("kk_gemm_dgrad_delta") == 2 * d.dec_layers
+    assert names.count("kk_attn_bwd_dq") == d.enc_layers and names.count("kk_attn_bwd_dkv") == d.enc_layers
+    e.attn_bwd_pair = False
+    e.zero_grad()
+    kk.profile_start()
+    l_two = e.forward_backward(b)["losses"].clone()
+    names = [r[0] for r in kk.profile_stop()]
+    assert names.count("kk_attn_bwd") == 0 and names.count("kk_attn_bwd_dq") == d.enc_layers + 2 * d.dec_layers
+    torch.cuda.synchronize()
+    assert torch.equal(l_pair, l_two)                                  # (dropout off: the forward is deterministic)
+    a, r = g_pair.double(), e.arena.g.double()
+    assert float((a - r).norm() / r.norm()) < 2e-3 and float(a @ r / (a.norm() * r.norm())) > 0.99999
+
+
 def test_micro_batch_finite_guard_drops_the_cycle(eng_mod, golden_dir):
     """Reference guards per micro-batch (trainer.py:3233-3296, 2304-2314): an infinite mel-projection bias makes one
     output column infinite while every loss stays finite (non-finite elements are masked out of the means) and every
