@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One attention kernel, a few launches (for rocprofv3 --pmc passes):  attn_one.py fwd|dq|dkv S causal p [n]"""
+"""One attention kernel, a few launches (for rocprofv3 --pmc passes):  attn_one.py fwd|dq|dkv|pair S causal p [n]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from kokoro_ruslan_amd import lib as kk
@@ -23,6 +23,9 @@ for _ in range(n):
         kk.call("kk_attn_fwd", q, k, v, o, lse, B, h, S, S, 3 * H, 3 * H, 3 * H, H, km, causal, 0.125, seed, 3, p, 1, 1)
     elif which == "dq":
         kk.call("kk_attn_bwd_dq", q, k, v, do, lse, delta, dqkv, B, h, S, S, 3 * H, 3 * H, 3 * H, H, 3 * H, km, causal, 0.125, seed, 3, p, 1, 1, None, 0, None)
+    elif which == "pair":
+        kk.call("kk_attn_bwd", q, k, v, do, lse, delta, dqkv, dqkv[:, H:], dqkv[:, 2 * H:], B, h, S, S, 3 * H, 3 * H, 3 * H, H, 3 * H, 3 * H, 3 * H,
+                km, causal, 0.125, seed, 3, p, 1, 1, None, None)
     else:
         kk.call("kk_attn_bwd_dkv", q, k, v, do, lse, delta, dqkv[:, H:], dqkv[:, 2 * H:], B, h, S, S, 3 * H, 3 * H, 3 * H, H, 3 * H, 3 * H, km, causal, 0.125, seed, 3, p, 1, 1, None)
 torch.cuda.synchronize()
