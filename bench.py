@@ -241,6 +241,7 @@ def main():
     try:
         warm()
         if world > 1 or force:
+            torch.cuda.synchronize()            # (the step's own RCCL communicator is idle before torch.distributed's is used)
             replicas_ok = dp.replicas_in_step(eng.arena.p)
     except Exception as e:                     # (a hang cannot be caught; an error of the in-graph exchange can)
         if not dp_mode.startswith("in-graph"):
@@ -266,7 +267,9 @@ def main():
             dp_mode = "legacy (fallback)"
             step = lambda: eng.train_step_graphed(batch, sync)   # noqa: E731
             warm()
+            torch.cuda.synchronize()
             replicas_ok = dp.replicas_in_step(eng.arena.p)
+    torch.cuda.synchronize()
     dp.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
