@@ -447,6 +447,10 @@ int kk_timestamp(uint64_t *slot, void *stream);
 /* (replaces the per-tensor `.to(device)` / copy of a batch dict, trainer.py:2257-2290)  n <= 16 device-to-device copies (dst[i] <- src[i], bytes[i] each; host arrays of device pointers) as one launch:
  * the hand-over of a batch's tensors into the buffers the captured step reads. */
 int kk_copy_many(const void *const *src, void *const *dst, const int64_t *bytes, int n, void *stream);
+/* Zero-fill of up to 160 ranges (16-byte aligned, multiples of 16 bytes) in ONE launch: the gradient arena at the start of an
+ * accumulation cycle minus the weight-gradient matrices that the cycle's first kk_gemm_wgrad_group launches overwrite
+ * (optimizer.zero_grad(), trainer.py:2257-2262, without touching 89 % of the arena). */
+int kk_zero_many(void *const *dst, const int64_t *bytes, int n, void *stream);
 int kk_axpby(float a, const float *x, float b, float *y, int64_t n, void *stream); /* y = a*x + b*y */
 int kk_mfma_probe(float *out_f32 /*32*32*/, float *out_bf16 /*32*32*/, void *stream);
 

@@ -92,6 +92,46 @@ __global__ __launch_bounds__(256) void zero_words_kernel(uint32_t *p, size_t wor
     }
 }
 }  // namespace
+// Up to ZERO_MAX ranges zero-filled by ONE launch (the gradient arena minus what a step's grouped weight-gradient launches
+// overwrite anyway: ~100 small ranges between the weight matrices).  blockIdx.x walks 16 KiB chunks of the concatenation.
+namespace {
+constexpr int ZERO_MAX = 160, ZERO_CHUNK = 16384;
+struct ZeroMany {
+    int n;
+    int start[ZERO_MAX + 1];
+    char *dst[ZERO_MAX];
+    int64_t bytes[ZERO_MAX];
+};
+__global__ __launch_bounds__(256) void zero_many_kernel(ZeroMany z) {
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    int lo = 0, hi = z.n - 1;                                   // the range this chunk belongs to (start[] is ascending)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (z.start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const int64_t off = (int64_t)((int)blockIdx.x - z.start[lo]) * ZERO_CHUNK;
+    const int64_t left = z.bytes[lo] - off;
+    char *d = z.dst[lo] + off;
+    const u32x4_t zero = {0u, 0u, 0u, 0u};
+    for (int64_t i = (int64_t)threadIdx.x * 16; i < ZERO_CHUNK && i < left; i += 256 * 16) *reinterpret_cast<u32x4_t *>(d + i) = zero;
+}
+}  // namespace
+extern "C" int kk_zero_many(void *const *dst, const int64_t *bytes, int n, void *stream) {
+    KK_REQUIRE(dst && bytes && n >= 1 && n <= ZERO_MAX, "kk_zero_many: 1..%d ranges per call", ZERO_MAX);
+    ZeroMany z = {};
+    z.n = n;
+    for (int i = 0; i < n; ++i) {
+        KK_REQUIRE(dst[i] && bytes[i] > 0 && bytes[i] % 16 == 0 && ((uintptr_t)dst[i] & 15) == 0,
+                   "kk_zero_many: ranges must be 16-byte aligned multiples of 16 bytes");
+        z.dst[i] = static_cast<char *>(dst[i]);
+        z.bytes[i] = bytes[i];
+        z.start[i + 1] = z.start[i] + (int)((bytes[i] + ZERO_CHUNK - 1) / ZERO_CHUNK);
+    }
+    hipLaunchKernelGGL(zero_many_kernel, dim3(z.start[n]), dim3(256), 0, (hipStream_t)stream, z);
+    KK_LAUNCH_CHECK("kk_zero_many");
+    return 0;
+}
+
 int kk_zero_async(void *p, size_t bytes, hipStream_t s) {
     if (bytes == 0) return 0;
     if (!p || ((uintptr_t)p & 3) || (bytes & 3)) return kk_fail(KK_EINVAL, "kk_zero_async: needs a 4-byte aligned range");

@@ -207,6 +207,14 @@ class KokoroEngine:
         # epilogue of the w_o dgrad GEMM (kk_gemm_dgrad_delta) — bf16 storage, shapes that take the eight-wave GEMM tile
         self.attn_bwd_pair = os.environ.get("KK_ATTN_BWD_PAIR", "1") != "0"
         self.attn_proj_bf16 = os.environ.get("KK_ATTN_PROJ_BF16", "1") != "0"      # decoder w_o output stored as bf16 (bf16 mode)
+        # The zero-fill at the start of an accumulation cycle skips what the cycle's first grouped weight-gradient launches
+        # overwrite (89 % of the arena at default dims; the fill runs beside the latency-bound encoder launch: 20 us of the step).
+        # Which tensors those are is RECORDED from the launches of a step (per precision mode), never assumed, and a step that
+        # zeroed by the record checks at its end that it overwrote exactly that set (_zero_grad_step / _grouped_wgrads).
+        self.zero_skip_overwritten = os.environ.get("KK_ZERO_SKIP", "1") != "0"
+        self._ow_sets: Dict[Tuple, frozenset] = {}
+        self._ow_seen: Optional[set] = None
+        self._ow_expect: Optional[frozenset] = None
         self._wgrad_queue = {}
         # The gradient arena was zeroed for THIS micro-batch (first of an accumulation cycle): a layer's grouped weight
         # gradients are each written exactly once per micro-batch, so they overwrite instead of read-modify-write (dW is
@@ -517,6 +525,8 @@ class KokoroEngine:
             sig = ("wg",) + tuple((dy.data_ptr(), x.data_ptr(), dw.data_ptr(), tuple(dy.shape), tuple(x.shape)) for dy, x, dw in part)
             table = self._table(sig, lambda: kk.wgrad_table(part))
             kk.call("kk_gemm_wgrad_group", table, len(part), 0, 1 if self._grads_fresh else 0)
+            if self._grads_fresh and self._ow_seen is not None:
+                self._ow_seen.update((dw.data_ptr(), dw.numel()) for _, _, dw in part)
 
     def _ln_fwd(self, key, x, prefix, dtype=torch.float32):
         P = self.arena.P
@@ -977,6 +987,8 @@ class KokoroEngine:
         and leaves the stream switching to the driver, which captures every stretch as its own single-stream hipGraph."""
         d, a, P, G = self.dims, self.arena, self.arena.P, self.arena.G
         self._grads_fresh = bool(zero_grads) or self._first_micro
+        self._ow_seen = set() if (self._grads_fresh and backward) else None
+        self._ow_expect = None
         seg = self._segmented and self.overlap
         H, M, Fv = d.hidden, d.mel, d.var_filter
         ids, mel, dur = batch["phoneme_indices"], batch["mel_specs"], batch["phoneme_durations"]
@@ -1021,7 +1033,7 @@ class KokoroEngine:
             # the attention below cannot and follow the encoder — with the fill in front of the whole head, none of the
             # head ran early and it ended 46 us after the cross-attention K/V GEMM, on the critical path.
             if zero_grads and self.zero_late:
-                self.zero_grad()
+                self._zero_grad_step()
             self._mark("kv: zero_grad done")
             ya0, n20 = self_attn(0, y0, n10)
             return y0, ya0, n20
@@ -1039,7 +1051,7 @@ class KokoroEngine:
             yield ("begin", "kv")
         with self._on_stream(self._kv, "kv.", self.dec_head_aside):     # beside the encoder; joined before the first cross-attention
             if zero_grads and not self.zero_late:
-                self.zero_grad()
+                self._zero_grad_step()
             kk.call("kk_max_i64", dur, Ne, self.max_dur)  # (read by the losses only: not in front of the encoder)
             dec_head = decoder_head()                     # (includes the gradient zero-fill, see there)
             self._mark("kv: decoder head done")
@@ -1332,6 +1344,13 @@ class KokoroEngine:
         self._comm_bucket("tail")                       # everything that was not a layer's weight matrix
         self._comm_join()
         self._mark("backward joined, partials reduced")
+        if self._ow_seen is not None:                   # what this cycle's first micro-batch overwrote (see _zero_grad_step)
+            seen = frozenset(self._ow_seen)
+            if self._ow_expect is not None and seen != self._ow_expect:
+                raise RuntimeError("the step zero-filled the gradient arena by a stale overwrite record: "
+                                   f"{len(self._ow_expect - seen)} tensors were skipped but not overwritten")
+            self._ow_sets[self._ow_key()] = seen
+            self._ow_seen = None
         return out
 
     # ------------------------------------------------------------------ inference
@@ -1496,6 +1515,35 @@ class KokoroEngine:
 
     def zero_grad(self) -> None:
         self.arena.g.zero_()
+
+    def _ow_key(self) -> Tuple:
+        return (self.math, self.enc_dt, self.dec_dt, self.use_shadow, self.group_wgrads)
+
+    def _zero_grad_step(self) -> None:
+        """The zero-fill inside a step (forward_backward(zero_grads=True)): everything, or — once a step of this precision mode
+        has been seen — everything but the tensors its grouped weight-gradient launches overwrite, as ONE kk_zero_many launch."""
+        a = self.arena
+        rec = self._ow_sets.get(self._ow_key()) if self.zero_skip_overwritten else None
+        if not rec:
+            self._ow_expect = None
+            self.zero_grad()
+            return
+        self._ow_expect = rec
+
+        def build():
+            base, spans, pos = a.g.data_ptr(), [], 0
+            for ptr, n in sorted(rec):
+                b = (ptr - base) // 4
+                if b < pos or b % 4 or n % 4:
+                    raise RuntimeError("overlapping or misaligned weight-gradient tensors in the overwrite record")
+                if b > pos:
+                    spans.append(a.g[pos:b])
+                pos = b + n
+            if pos < a.total:
+                spans.append(a.g[pos:a.total])
+            return [kk.zero_table(spans[i:i + 160]) for i in range(0, len(spans), 160)]
+        for dst, nbytes, n in self._table(("zero", a.g.data_ptr(), rec), build):
+            kk.call("kk_zero_many", dst, nbytes, n)
 
     def optimizer_step(self, mel_length: int) -> None:
         """Pre-clip → total norm → non-finite skip / explosion tracker / adaptive + global clip → fused AdamW+EMA →

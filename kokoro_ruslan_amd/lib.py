@@ -123,6 +123,12 @@ def copy_many(pairs) -> None:
         call("kk_copy_many", src, dst, nbytes, n)
 
 
+def zero_table(views):
+    """(dst pointers, byte counts, n) host arrays for kk_zero_many from a list of contiguous device tensors (<= 160)."""
+    n = len(views)
+    return ((C.c_void_p * n)(*[v.data_ptr() for v in views]), (C.c_int64 * n)(*[v.numel() * v.element_size() for v in views]), n)
+
+
 def reduce_table(entries, device) -> "torch.Tensor":
     """Device copy of a KkReduceDesc array from [(src, dst0, dst1 | None, nblocks, ncols, split[, row stride])]."""
     arr = (KkReduceDesc * len(entries))()
@@ -143,6 +149,7 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_attn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P],
     "kk_attn_delta": [_P, _P, _P, _I, _I, _I, _L, _L, _I, _P],
     "kk_attn_bwd_dq": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P, _L, _P, _P],
+    "kk_zero_many": [_P, _P, _I, _P],
     "kk_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P, _P, _P],
     "kk_gemm_dgrad_delta": [_L, _L, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _I, _I, _P],
     "kk_gemm_dgrad_delta_supported": [_L, _L, _L],

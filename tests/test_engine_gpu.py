@@ -707,6 +707,56 @@ def test_bench_config_takes_the_pair_launch_and_it_changes_nothing(eng_mod):
     assert float((a - r).norm() / r.norm()) < 2e-3 and float(a @ r / (a.norm() * r.norm())) > 0.99999
 
 
+def test_step_zero_fill_skips_only_what_the_step_overwrites(eng_mod):
+    """forward_backward(zero_grads=True) clears the gradient arena minus the tensors the step's grouped weight-gradient launches
+    overwrite (recorded from a previous step of the same precision mode).  Poisoned with NaN before a step, every element of the
+    arena must come out finite — zeroed or overwritten — in the replayed graph, with accumulation, and after a mode change; and
+    the gradients are those of a full zero-fill."""
+    from kokoro_ruslan_amd import lib as kk
+    from kokoro_ruslan_amd.synthetic import synthetic_batch
+    d = O.ModelDims()
+    P = O.init_params(d, 0)
+    b = _cuda(synthetic_batch(4, 300, 40, seed=5))
+    e = _engine(eng_mod, d, P, math_mode="bf16", gradient_accumulation_steps=1)
+    assert e.zero_skip_overwritten
+    e.forward_backward(b, zero_grads=True)                                  # first step of this mode: full fill, records the set
+    rec = e._ow_sets[e._ow_key()]
+    skipped = sum(n for _, n in rec)
+    assert 0.8 < skipped / e.arena.total < 0.95, skipped / e.arena.total     # the weight matrices: 89 % of the arena
+    g_full = e.arena.g.clone()
+    e.arena.g.fill_(float("nan"))
+    kk.profile_start()
+    e.forward_backward(b, zero_grads=True)
+    names = [r[0] for r in kk.profile_stop()]
+    assert names.count("kk_zero_many") == 1
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(e.arena.g).all()), "an element was neither zeroed nor overwritten"
+    a, r = e.arena.g.double(), g_full.double()
+    assert float((a - r).norm() / r.norm()) < 2e-3                          # (two runs: scatter-add order)
+    # the fp32 parity mode groups nothing: its own (empty) record, full fill
+    with e.fp32_math():
+        e.arena.g.fill_(float("nan"))
+        e.forward_backward(b, zero_grads=True)
+        assert len(e._ow_sets[e._ow_key()]) == 0
+        assert bool(torch.isfinite(e.arena.g).all())
+    # graph replay with accumulation: the cycle's first micro-batch fills and overwrites, the second accumulates
+    e2 = _engine(eng_mod, d, P, math_mode="bf16", gradient_accumulation_steps=2)
+    for _ in range(6):
+        e2.train_step_graphed(b)
+    e2.arena.g.fill_(float("nan"))
+    for _ in range(4):
+        e2.train_step_graphed(b)
+    torch.cuda.synchronize()
+    st = e2.opt_stats()
+    assert st["skipped"] == 0 and st["attempt"] == 5 and bool(torch.isfinite(e2.arena.g).all()) and bool(torch.isfinite(e2.arena.p).all())
+    # a stale record is an error, not a silent stale gradient
+    key = e._ow_key()
+    e._ow_sets[key] = frozenset(list(e._ow_sets[key])[:-1] + [(e.arena.G["decoder.norm.weight"].data_ptr(), 512)])
+    e._tables.clear()
+    with pytest.raises(RuntimeError, match="stale overwrite record"):
+        e.forward_backward(b, zero_grads=True)
+
+
 def test_micro_batch_finite_guard_drops_the_cycle(eng_mod, golden_dir):
     """Reference guards per micro-batch (trainer.py:3233-3296, 2304-2314): an infinite mel-projection bias makes one
     output column infinite while every loss stays finite (non-finite elements are masked out of the means) and every
