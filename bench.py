@@ -303,9 +303,9 @@ def main():
         ach = v["flops"] / (v["ms"] * 1e-3) / 1e12
         traffic, traffic_note = None, None
         if os.path.exists(PMC_FILE):                 # HBM bytes per launch of this kernel from the committed PMC passes
-            shape_file = os.path.join(ROOT, "profiles", f"r02g_pmc_hbm_traffic_{B}x{T}x{P}.json")    # per workload shape (latest passes)
+            shape_file = os.path.join(ROOT, "profiles", f"r02h_pmc_hbm_traffic_{B}x{T}x{P}.json")    # per workload shape (latest passes)
             if not os.path.exists(shape_file):
-                shape_file = os.path.join(ROOT, "profiles", f"r02e_pmc_hbm_traffic_{B}x{T}x{P}.json")
+                shape_file = os.path.join(ROOT, "profiles", f"r02g_pmc_hbm_traffic_{B}x{T}x{P}.json")
             pmc = json.load(open(shape_file if os.path.exists(shape_file) else PMC_FILE))
             ent = pmc.get("kernels", {}).get(dom.split(" (")[0])
             if ent and pmc.get("workload") == [B, T, P, args.math]:
