@@ -248,10 +248,11 @@ def main():
             raise
         print(f"[bench] rank {rank}: in-graph exchange failed ({e}); falling back to the after-the-backward all-reduce", file=sys.stderr)
         replicas_ok = False
-    if dp_mode.startswith("in-graph") and world > 1:
+    if dp_mode.startswith("in-graph") and (world > 1 or force):
         # every rank must take the same branch: any rank that saw an error or diverged replicas sends all of them to the
         # round-1 form (one torch.distributed all-reduce between the backward graph and the optimizer graph)
-        bad = torch.tensor([0.0 if replicas_ok else 1.0], device="cuda")
+        # (KK_BENCH_TEST_FALLBACK=1 takes this path on purpose: it is rehearsed on one GPU with KK_DP_FORCE=1)
+        bad = torch.tensor([0.0 if (replicas_ok and os.environ.get("KK_BENCH_TEST_FALLBACK") != "1") else 1.0], device="cuda")
         dp.all_max(bad)
         if float(bad) > 0:
             if rank == 0:
@@ -262,9 +263,11 @@ def main():
             torch.distributed.broadcast(dist_p, src=0)          # re-align the replicas on rank 0's weights and state
             eng.arena.p.copy_(dist_p)
             for slab in (eng.arena.m, eng.arena.v, eng.arena.ema, eng.opt_state):
-                torch.distributed.broadcast(slab, src=0)
+                if slab is not None:
+                    torch.distributed.broadcast(slab, src=0)
             eng.sync_shadow()
             dp_mode = "legacy (fallback)"
+            use_sync = True
             step = lambda: eng.train_step_graphed(batch, sync)   # noqa: E731
             warm()
             torch.cuda.synchronize()
@@ -340,7 +343,8 @@ def main():
                       "grad_allreduce": (dp_mode if dp_mode.startswith("in-graph") else
                                          ("2 buckets, first overlapped with the backward of decoder layers < %d" % eng.dp_overlap_layer)
                                          if (use_sync and not args.no_graph and eng.dp_overlap_layer is not None) else
-                                         ("after the backward (torch.distributed)" if use_sync else "none (1 GPU)")),
+                                         (("after the backward (torch.distributed)" + (", fallback from the in-graph exchange" if dp_mode.endswith("(fallback)") else ""))
+                                          if use_sync else "none (1 GPU)")),
                       "replicas_in_step": replicas_ok,       # bit-identical weights on every rank after the warm-up (None: 1 GPU)
                       "grad_accumulation": 1,
                       "dropout": ("off (p=0 parity configuration)" if args.no_dropout else
