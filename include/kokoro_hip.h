@@ -435,6 +435,10 @@ int kk_comm_destroy(void);
 int kk_comm_reduce_bucket(void *ptr, int64_t count, int dtype, void *comm_stream);
 /* n in-place SUM all-reduces base[begin[i] .. end[i]) (element indices; HOST arrays) as one RCCL group */
 int kk_comm_reduce_ranges(void *base, const int64_t *begin, const int64_t *end, int n, int dtype, void *comm_stream);
+/* Loss normalisers of ragged data-parallel shards: acc[n_acc] (fp64 sums + valid-element counts of kk_losses_fwd;
+ * reference losses.py:40-46,82-105) SUM-reduced and *max_dur (trainer.py:2218-2242's inputs) MAX-reduced in place, one RCCL
+ * group on `stream`; kk_losses_finalize then normalises by the global counts.  Legal inside a hipGraph capture. */
+int kk_comm_loss_sync(double *acc, int n_acc, int64_t *max_dur, void *stream);
 /* the two halves of the ring all-reduce on their own (recv of rank r = block r of the sum / the concatenation) */
 int kk_comm_reduce_scatter(const void *send, void *recv, int64_t recv_count, int dtype, void *comm_stream);
 int kk_comm_all_gather(const void *send, void *recv, int64_t send_count, int dtype, void *comm_stream);

@@ -23,11 +23,27 @@ _TENSOR_KEYS = ("mel_spec", "phoneme_indices", "stress_indices", "phoneme_durati
 
 
 def clip_durations(dur: torch.Tensor, T: int) -> torch.Tensor:
-    """Durations of an utterance whose mel was cut to T frames: every phoneme keeps the frames that fall before the
-    cut, so sum(dur) == min(sum(dur), T) and the expansion is a prefix of the original one (the reference reconciles
-    sum(dur) with the clipped mel length when it builds a sample, data/dataset.py:704-707,769-776)."""
+    """Durations of an utterance whose mel THIS READER cut to T frames (a cache built with a larger max_seq_length than the
+    run's): every phoneme keeps the frames that fall before the cut, so sum(dur) == min(sum(dur), T) and the expansion is a
+    prefix of the original one; phonemes past the cut get duration 0 (the duration loss masks them: losses.py d > 0).
+
+    DELIBERATE DIVERGENCE, not the reference's rule.  The reference clips only when it BUILDS a sample (kokoro-precompute,
+    data/dataset.py:704-707) and reconciles there by `dur[-1] = max(1, dur[-1] + (T - sum))` followed by `clamp(min=1)`
+    (:769-776), which keeps every duration >= 1 and — when the last phoneme is shorter than the cut — leaves sum(dur) > T
+    (the model then expands to T' > T frames, model.py:607-628).  It never re-clips a cached file, so a cache whose files are
+    longer than the run's max_seq_length has no reference behaviour to copy; here the frames kept are exactly the frames whose
+    mel survives.  `reference_reconcile` below restates the reference's rule for the tests that pin the difference."""
     cum = torch.cumsum(dur.clamp(min=0), 0).clamp(max=T)
     return torch.diff(cum, prepend=cum.new_zeros(1))
+
+
+def reference_reconcile(dur: torch.Tensor, T: int) -> torch.Tensor:
+    """data/dataset.py:769-776 as written (used at precompute time by the reference; test infrastructure here)."""
+    d = dur.clone()
+    diff = int(T) - int(d.sum())
+    if diff != 0 and len(d) > 0:
+        d[-1] = max(1, int(d[-1]) + diff)
+    return d.clamp(min=1)
 
 
 def scan_cache(cache_dir: str) -> List[Dict]:
@@ -41,27 +57,29 @@ def scan_cache(cache_dir: str) -> List[Dict]:
     index_path = d / ".kk_index.json"
     known = {}
     try:
-        known = {e["name"]: e for e in json.loads(index_path.read_text())["entries"]}
+        idx = json.loads(index_path.read_text())
+        if idx.get("version") == FEATURE_CACHE_VERSION and idx.get("index_format") == 2:     # an index of another cache schema (or of
+            known = {e["name"]: e for e in idx["entries"]}                                  # second-resolution mtimes) is discarded
     except Exception:
         known = {}
     metas, entries, dirty = [], [], False
     for f in files:
         st = f.stat()
         e = known.get(f.name)
-        if e is None or e.get("size") != st.st_size or e.get("mtime") != int(st.st_mtime):
+        if e is None or e.get("size") != st.st_size or e.get("mtime_ns") != st.st_mtime_ns or e.get("cache_version") != FEATURE_CACHE_VERSION:
             it = torch.load(f, map_location="cpu", weights_only=False)
             ver = it.get("_cache_version")
             if ver != FEATURE_CACHE_VERSION:
                 raise RuntimeError(f"{f.name}: feature cache version {ver}, expected {FEATURE_CACHE_VERSION}")
-            e = {"name": f.name, "size": st.st_size, "mtime": int(st.st_mtime), "mel_length": int(it["mel_length"]),
-                 "phoneme_length": int(it["phoneme_length"])}
+            e = {"name": f.name, "size": st.st_size, "mtime_ns": st.st_mtime_ns, "cache_version": int(ver),
+                 "mel_length": int(it["mel_length"]), "phoneme_length": int(it["phoneme_length"])}
             dirty = True
         entries.append(e)
         metas.append({"file": f, "audio_length": e["mel_length"], "phoneme_length": e["phoneme_length"]})
     if dirty:
         try:
             tmp = index_path.with_suffix(".tmp%d" % os.getpid())
-            tmp.write_text(json.dumps({"version": FEATURE_CACHE_VERSION, "entries": entries}))
+            tmp.write_text(json.dumps({"version": FEATURE_CACHE_VERSION, "index_format": 2, "entries": entries}))
             os.replace(tmp, index_path)
         except OSError:
             pass                                                   # read-only cache directory: scan again next time

@@ -123,6 +123,7 @@ def assemble_checkpoint(*, model_sd: Dict[str, torch.Tensor], ema_sd: Optional[D
 
 def save_checkpoint(engine, config, epoch: int, loss: float, output_dir: str, val: Optional[Dict[str, float]] = None,
                     best_val_loss: Optional[float] = None, best_val_epoch: int = -1, early_stopping_counter: int = 0) -> str:
+    engine.check_encoder_stack()                   # never write weights trained through a timed-out encoder launch
     st = engine.opt_stats()
     done = int(st["attempt"] - st["skipped"])
     cpu = lambda sd: {k: v.detach().cpu().clone() for k, v in sd.items()}
@@ -177,6 +178,7 @@ def load_checkpoint(engine, path: str) -> Dict[str, Any]:
 def save_final_model(engine, config, output_dir: str) -> str:
     os.makedirs(output_dir, exist_ok=True)
     path = os.path.join(output_dir, "kokoro_russian_final.pth")
+    engine.check_encoder_stack()
     torch.save({"model_state_dict": {k: v.detach().cpu().clone() for k, v in engine.state_dict().items()},
                 "config": config, "model_metadata": build_model_metadata(config, engine.dims)}, path)
     return path

@@ -195,15 +195,19 @@ class KokoroTrainer:
         self.engine = KokoroEngine(dims, hp, math_mode=math_mode, total_steps=config.num_epochs * steps_per_epoch, seed=0)
         self.sync = dp.GradSync(self.world)
         if self.world > 1:
-            # real data = ragged shards: normalise every loss by the GLOBAL valid-element counts (dp.LossSync) instead of
-            # pre-scaling per-rank means by 1/world, and feed the batch-shape heuristics the global-batch mel length
-            self.engine.loss_sync = dp.LossSync(self.world)
+            # real data = ragged shards: normalise every loss by the GLOBAL valid-element counts instead of pre-scaling
+            # per-rank means by 1/world, and feed the batch-shape heuristics the global-batch mel length.
+            # Both collectives of a step — the gradient buckets inside the backward and the loss normalisers between the loss
+            # forward and the loss backward — go through ONE communicator behind the C ABI (kk_comm_*, RCCL) and are captured
+            # with the step, so ragged data-parallel steps replay from hipGraphs like single-GPU ones.  KK_DP_LEGACY=1 (or
+            # RCCL not bindable on some rank: dp.BucketedExchange.create agrees on that collectively) keeps the eager form:
+            # torch.distributed all-reduces between the kernels / after the backward.
             self.engine.dp_loss_scale = 1.0
-            # gradients: bucket by bucket inside the backward over the C ABI's kk_comm_* (RCCL); KK_DP_LEGACY=1 keeps the
-            # single torch.distributed all-reduce after the backward
-            if os.environ.get("KK_DP_LEGACY") != "1":
-                self.engine.dp_comm = dp.BucketedExchange.create(dims, self.rank, self.world, self.engine.device)
-                self.sync = None
+            comm = None if os.environ.get("KK_DP_LEGACY") == "1" else dp.BucketedExchange.create(dims, self.rank, self.world, self.engine.device)
+            if comm is not None and comm.capturable:
+                self.engine.dp_comm, self.engine.loss_sync, self.sync = comm, comm, None
+            else:
+                self.engine.loss_sync = dp.LossSync(self.world)
         self.start_epoch, self.best_val, self.best_epoch, self.patience = 0, float("inf"), -1, 0
         self.use_graphs = os.environ.get("KK_TRAINER_GRAPHS", "1") != "0"
         # Per-micro-batch non-finite guard (reference trainer.py:2304-2314): by default the device flags the micro-batch
@@ -267,6 +271,7 @@ class KokoroTrainer:
         finally:
             e.train_dropout = False
         avg = (losses / max(n, 1)).cpu().tolist()          # the only host sync of the epoch
+        e.check_encoder_stack()                            # (a second word read at the same sync point: raises on a timed-out barrier)
         if n == 0:
             logger.warning("epoch %d: no training batches", epoch + 1)
         logger.info("epoch %d train: total %.4f mel %.4f dur %.4f stop %.4f pitch %.4f energy %.4f", epoch + 1, *avg)
@@ -290,6 +295,7 @@ class KokoroTrainer:
         if not self.val_dataset or len(self.val_dataset) == 0:
             return None
         e = self.engine
+        e.check_encoder_stack()
         acc = torch.zeros(10, device=e.device, dtype=torch.float64)      # 6 losses, sc sum, sc batches, f0 sum, f0 batches
         n = 0
         saved_sync, saved_drop, e.loss_sync, e.train_dropout = e.loss_sync, e.train_dropout, None, False

@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256 * G) void attn_fwd_kernel(AttnArgs a) {
         __syncthreads();
         cur ^= 1;
     };
-    for (int kk0 = 0; kk0 < ((a.dbg & 32) ? 0 : kend); kk0 += 2 * STEP) {      // the bound is the same for both groups (barriers)
+    for (int kk0 = 0; kk0 < (KK_DBG(a, 32) ? 0 : kend); kk0 += 2 * STEP) {      // the bound is the same for both groups (barriers)
         tile_step(ra, kk0);
         if (kk0 + STEP < kend) tile_step(rb, kk0 + STEP);
     }
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(AttnArgs a) {
         nu = 2 * full + (rem > 32 ? 2 : (rem > 0 ? 1 : 0));
     }
     RowFrag<true> qf;
-    if (a.dbg & 64) return;                                // (timing probe: the launch alone)
+    if (KK_DBG(a, 64)) return;                                // (timing probe: the launch alone)
     char *qimg = smem_raw + 2 * GSZ + 512;                 // [128 queries][64] image (the oldest DMA: covered by every wait below)
     dma_rows128(static_cast<const T *>(a.Q) + ((int64_t)b * a.Sq + qblk) * a.ldq + hh * 64, a.ldq, a.Sq - qblk < 128 ? a.Sq - qblk : 128, qimg, wave8);
     const uint8_t *km = a.key_mask ? a.key_mask + (int64_t)b * a.Sk : nullptr;
@@ -767,14 +767,14 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(AttnArgs a) {
     s16x4 vlo[4], vhi[4];
     // (plain lambdas with literal offsets: inline-asm operands are not captured inside generic lambdas)
     auto read_k = [&](uint32_t img) {                      // img = LDS address of the unit's first K row
-        if (a.dbg & 16) return;
+        if (KK_DBG(a, 16)) return;
         asm volatile("ds_read_b128 %0, %1" : "=v"(kf[0]) : "v"(img + ka[0]));
         asm volatile("ds_read_b128 %0, %1" : "=v"(kf[1]) : "v"(img + ka[1]));
         asm volatile("ds_read_b128 %0, %1" : "=v"(kf[2]) : "v"(img + ka[2]));
         asm volatile("ds_read_b128 %0, %1" : "=v"(kf[3]) : "v"(img + ka[3]));
     };
     auto read_v = [&](uint32_t img) {                      // img = LDS address of the unit's first V row
-        if (a.dbg & 16) return;
+        if (KK_DBG(a, 16)) return;
         const uint32_t a0 = img + va[0], a1 = img + va[1];
         asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vlo[0]) : "v"(a0));
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(vhi[0]) : "v"(a0));
@@ -790,7 +790,7 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(AttnArgs a) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(kf[ks]));
         zero_acc(s);
-        if (a.dbg & 4) { s[0] = (float)kf[0][0] + (float)kf[1][1] + (float)kf[2][2] + (float)kf[3][3]; return; }
+        if (KK_DBG(a, 4)) { s[0] = (float)kf[0][0] + (float)kf[1][1] + (float)kf[2][2] + (float)kf[3][3]; return; }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf.v[ks], s, 0, 0, 0);
     };
@@ -802,7 +802,7 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(AttnArgs a) {
     pd.init(a, b, hh);
     // softmax (+ dropout) of one unit: s -> two B operands of the PV MFMAs; the arithmetic of attn_fwd_kernel
     auto softmax_unit = [&](const f32x16 &s, int kb, uint32_t kmsub, bf16x8 (&pb)[2]) {
-        if (a.dbg & 2) {
+        if (KK_DBG(a, 2)) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -856,14 +856,14 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(AttnArgs a) {
     auto pv = [&](const bf16x8 (&pb)[2]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(vlo[i]), "+v"(vhi[i]));
-        if (a.dbg & 4) { o[0][0] += (float)pb[0][0] + (float)pb[1][0] + (float)vlo[0][0] + (float)vhi[3][0]; return; }
+        if (KK_DBG(a, 4)) { o[0][0] += (float)pb[0][0] + (float)pb[1][0] + (float)vlo[0][0] + (float)vhi[3][0]; return; }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int db = 0; db < 2; ++db)
                 o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_pair(vlo[s2 * 2 + db], vhi[s2 * 2 + db]), pb[s2], o[db], 0, 0, 0);
     };
-    if (a.dbg & 128) return;                               // (timing probe: launch + DMA issue, nothing waited for)
+    if (KK_DBG(a, 128)) return;                               // (timing probe: launch + DMA issue, nothing waited for)
     // ---- prologue: tiles 0 and 1 landed (tile 2 may stay in flight), unit 0's scores, unit 1's K fragments
     if (NS >= 4 && nt >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (nt >= 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -878,15 +878,15 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(AttnArgs a) {
         if (nu > 1) read_k(gl + 4096);
     }
     int st = 0;
-    for (int t = 0; t < ((a.dbg & 32) ? 0 : nt0); ++t) {
+    for (int t = 0; t < (KK_DBG(a, 32) ? 0 : nt0); ++t) {
         const int st1 = st + 1 == NS ? 0 : st + 1;
         if (t > 0) {
             // tile t+1 landed: the only DMA younger than it is tile t+2 when NS == 4
             if (NS >= 4 && t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (!(a.dbg & 8)) __builtin_amdgcn_s_barrier();                  // ... for every wave, and every wave is done with tile t-1
+            if (!KK_DBG(a, 8)) __builtin_amdgcn_s_barrier();                  // ... for every wave, and every wave is done with tile t-1
             asm volatile("" ::: "memory");
-            if (t + NS - 1 < nt && !(a.dbg & 1)) issue_tile(t + NS - 1, st == 0 ? NS - 1 : st - 1);
+            if (t + NS - 1 < nt && !KK_DBG(a, 1)) issue_tile(t + NS - 1, st == 0 ? NS - 1 : st - 1);
         }
         const int u0 = 2 * t;
         if (u0 < nu) {
@@ -1067,7 +1067,7 @@ __global__ __launch_bounds__(256 * G) void attn_bwd_dq_kernel(AttnArgs a) {
         __syncthreads();
         cur ^= 1;
     };
-    for (int kk0 = 0; kk0 < ((a.dbg & 32) ? 0 : kend); kk0 += 2 * STEP) {      // the bound is the same for both groups (barriers)
+    for (int kk0 = 0; kk0 < (KK_DBG(a, 32) ? 0 : kend); kk0 += 2 * STEP) {      // the bound is the same for both groups (barriers)
         tile_step(ra, kk0);
         if (kk0 + STEP < kend) tile_step(rb, kk0 + STEP);
     }
@@ -1317,7 +1317,7 @@ __global__ __launch_bounds__(256 * G) void attn_bwd_dkv_kernel(AttnArgs a) {
         __syncthreads();
         cur ^= 1;
     };
-    for (int qq0 = qstart; qq0 < ((a.dbg & 32) ? 0 : a.Sq); qq0 += 2 * STEP) {              // the bound is the same for both groups (barriers)
+    for (int qq0 = qstart; qq0 < (KK_DBG(a, 32) ? 0 : a.Sq); qq0 += 2 * STEP) {              // the bound is the same for both groups (barriers)
         tile_step(ra, qq0);
         if (qq0 + STEP < a.Sq) tile_step(rb, qq0 + STEP);
     }
@@ -1411,20 +1411,20 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T *__restrict__ O
 
 int g_attn_groups = 2;
 static int attn_v2_mask() {              // bit 0: forward, bit 1: dQ, bit 2: dK/dV second-generation kernels
-    static const int v = getenv("KK_ATTN_V2") ? atoi(getenv("KK_ATTN_V2")) : 7;
+    static const int v = kk_tune_env("KK_ATTN_V2", 7);
     return v;
 }
-static int attn_dbg() {                  // timing probes of tools/probes (results are wrong when set)
-    static const int v = getenv("KK_ATTN_DBG") ? atoi(getenv("KK_ATTN_DBG")) : 0;
+static int attn_dbg() {                  // timing probes of tools/probes (tools build only: results are wrong when set)
+    static const int v = kk_tune_env("KK_ATTN_DBG", 0);
     return v;
 }
 static bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 static int attn_pair() {                 // KK_ATTN_PAIR=0: kk_attn_bwd issues the dQ and the dK/dV kernel as two launches
-    static const int v = getenv("KK_ATTN_PAIR") ? atoi(getenv("KK_ATTN_PAIR")) : 1;
+    static const int v = kk_tune_env("KK_ATTN_PAIR", 1);
     return v;
 }
 static int attn_xcd_env() {
-    static const int v = getenv("KK_ATTN_XCD") ? atoi(getenv("KK_ATTN_XCD")) : 2;
+    static const int v = kk_tune_env("KK_ATTN_XCD", 2);
     return v;
 }
 // AttnArgs::xcd_map of a launch: 0 = launch order, 1 = a head's blocks on one XCD, 2 (default for causal launches) = that, with the
@@ -1497,19 +1497,10 @@ extern "C" int kk_attn_fwd(const float *Q, const float *K, const float *V, float
     a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(causal); a.dbg = attn_dbg();
     dim3 grid(kk_cdiv(Sq, 128), B * heads);
     const int G = (Sk > 64 && g_attn_groups == 2) ? 2 : 1;          // one key tile: nothing to split
-    // Four key groups (16 waves): the longest chain of key-tile steps of a 128-query block halves again — a causal block
-    // near the end of the sequence sets the launch's duration, and at S = 512 the kernel is a chain of 4 dependent steps
-    static const int fwd_groups4 = getenv("KK_ATTN_FWD_G4") ? atoi(getenv("KK_ATTN_FWD_G4")) : 0;
-    if (io_bf16 && fwd_groups4 && G == 2 && Sk >= 256) {
-        int rc4 = launch_attn(attn_fwd_kernel<true, true, 4>, grid, 4, KK_ATTN_LDS(true, 4, 2, 0), (hipStream_t)stream, a);
-        if (rc4) return rc4;
-        KK_LAUNCH_CHECK("kk_attn_fwd");
-        return 0;
-    }
     // second-generation kernel (DMA-staged, software-pipelined): bf16 storage, two key groups, 16-byte aligned operands
     const int fwd_v2 = attn_v2_mask() & 1;
     if (io_bf16 && fwd_v2 && G == 2 && Sk <= 4096 && (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) == 0 && (int64_t)Sk * std::max(ldk, ldv) * 2 < (1ll << 31)) {
-        static const int ns2 = getenv("KK_ATTN_NS") ? atoi(getenv("KK_ATTN_NS")) : 3;
+        static const int ns2 = kk_tune_env("KK_ATTN_NS", 3);
         int rc2 = ns2 == 4 ? launch_attn(attn_fwd2_kernel<4>, grid, 2, (size_t)2 * 4 * 16384 + 512 + 16384, (hipStream_t)stream, a)
                            : launch_attn(attn_fwd2_kernel<3>, grid, 2, (size_t)2 * 3 * 16384 + 512 + 16384, (hipStream_t)stream, a);
         if (rc2) return rc2;

@@ -15,7 +15,7 @@ namespace {
 
 typedef struct ncclComm *ncclComm_t;
 typedef struct { char internal[128]; } ncclUniqueId;
-enum { ncclSum = 0, ncclFloat32 = 7, ncclBfloat16 = 9 };
+enum { ncclSum = 0, ncclMax = 2, ncclInt64 = 4, ncclFloat32 = 7, ncclFloat64 = 8, ncclBfloat16 = 9 };
 
 struct Rccl {
     void *handle = nullptr;
@@ -144,6 +144,20 @@ extern "C" int kk_comm_reduce_ranges(void *base, const int64_t *begin, const int
     const int rc_end = g_rccl.GroupEnd();
     if (first == KK_EINVAL) return kk_fail(KK_EINVAL, "kk_comm_reduce_ranges: empty range");
     return check(first ? first : rc_end, "kk_comm_reduce_ranges");
+}
+
+// The second collective of a data-parallel step with ragged shards: the loss normalisers.  The fp64 sums and
+// valid-element counts of kk_losses_fwd (reference losses.py:40-46,82-105 normalise by counts of the batch the process sees)
+// are SUM-reduced and the largest duration (the batch-shape heuristics of trainer.py:2218-2242) MAX-reduced, in place, as one
+// RCCL group on the caller's stream — between kk_losses_fwd and kk_losses_finalize, inside the captured step.
+extern "C" int kk_comm_loss_sync(double *acc, int n_acc, int64_t *max_dur, void *stream) {
+    KK_REQUIRE(g_comm != nullptr, "kk_comm_loss_sync: no communicator (kk_comm_init)");
+    KK_REQUIRE(acc && n_acc > 0 && max_dur, "kk_comm_loss_sync: bad arguments");
+    if (int rc = check(g_rccl.GroupStart(), "kk_comm_loss_sync")) return rc;
+    const int rc1 = g_rccl.AllReduce(acc, acc, (size_t)n_acc, ncclFloat64, ncclSum, g_comm, (hipStream_t)stream);
+    const int rc2 = g_rccl.AllReduce(max_dur, max_dur, 1, ncclInt64, ncclMax, g_comm, (hipStream_t)stream);
+    const int rc3 = g_rccl.GroupEnd();
+    return check(rc1 ? rc1 : (rc2 ? rc2 : rc3), "kk_comm_loss_sync");
 }
 
 // The two halves of the ring all-reduce as separate calls (reduce-scatter -> [optimizer on the shard] -> all-gather).

@@ -12,6 +12,18 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
 int kk_fail(int code, const char *fmt, ...);
 
+// Tuning switches.  The PRODUCT library reads no environment variable but KK_GEMM16_TUNE (one-time tile policy override, see
+// kk_gemm16.hip): every A/B switch and every result-changing timing probe below exists only in a tools build
+// (python -m kokoro_ruslan_amd.build --tuning, which defines KK_TUNING_HOOKS); in the product they fold to their defaults.
+#include <stdlib.h>
+#ifdef KK_TUNING_HOOKS
+static inline int kk_tune_env(const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; }
+#define KK_DBG(a, bits) (((a).dbg & (bits)) != 0)
+#else
+static inline int kk_tune_env(const char *, int dflt) { return dflt; }
+#define KK_DBG(a, bits) (false)
+#endif
+
 #define KK_REQUIRE(cond, ...)                                   \
     do {                                                        \
         if (!(cond)) return kk_fail(KK_EINVAL, __VA_ARGS__);    \

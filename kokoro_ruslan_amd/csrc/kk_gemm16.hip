@@ -564,8 +564,8 @@ __global__ __launch_bounds__(512) void gemm16_kernel_w8_hn(G16Args a) {
 template __global__ void gemm16_kernel_w8_hn<3>(G16Args);
 template __global__ void gemm16_kernel_w8_glu<false, 3, 2>(G16Args);
 template __global__ void gemm16_kernel_w8_glu<true, 3, 1>(G16Args);
-int g16_w8_hn = getenv("KK_G16_W8_HN") ? atoi(getenv("KK_G16_W8_HN")) : 1;        // measured: +0.8 % on the step (interleaved A/B)
-int g16_w8_glu = getenv("KK_G16_W8_GLU") ? atoi(getenv("KK_G16_W8_GLU")) : 1;      // bit 0: dgrad + GLU backward, bit 1: linear1 + GLU; 4th part, interleaved: bit 0 +0.3 % (on), bit 1 -0.5 % (off)
+int g16_w8_hn = kk_tune_env("KK_G16_W8_HN", 1);        // measured: +0.8 % on the step (interleaved A/B)
+int g16_w8_glu = kk_tune_env("KK_G16_W8_GLU", 1);      // bit 0: dgrad + GLU backward, bit 1: linear1 + GLU; 4th part, interleaved: bit 0 +0.3 % (on), bit 1 -0.5 % (off)
 
 template <int NS>
 void launch_w8(int ta, int tb, const G16Args &a, dim3 grid, hipStream_t s) {
@@ -576,7 +576,7 @@ void launch_w8(int ta, int tb, const G16Args &a, dim3 grid, hipStream_t s) {
 }
 // 8-wave 128x64 tiles, 3 stages, for single GEMMs with >= g16_thr12864 such tiles: +0.8 % on the 8x512 step, +2.2 % at 8x1024
 // (interleaved A/B, tools/probes/g16w8.sh); KK_G16_W8=0 restores the 4-wave form, =2 two stages.
-int g16_w8 = getenv("KK_G16_W8") ? atoi(getenv("KK_G16_W8")) : 3;
+int g16_w8 = kk_tune_env("KK_G16_W8", 3);
 
 // Several independent GEMMs of one operand layout in ONE launch (a layer's weight gradients: they have no consumer
 // before the optimizer, so they wait until the layer's backward is through and then fill the chip together — ~1000
@@ -663,8 +663,8 @@ struct G16EnvInit {
         }
     }
 } g16_env_init;
-int g16_group_tile = getenv("KK_GROUP_TILE") ? atoi(getenv("KK_GROUP_TILE")) : 1;                                         // grouped launches: 0 = 64x64, 1 = 128x64 (default: +1 % on the step), 2 = 128x128 tiles
-int g16_group_waves = getenv("KK_GROUP_WAVES") ? atoi(getenv("KK_GROUP_WAVES")) : 8;   // 8-wave workgroups on the 128-row tiles (4: the old form)
+int g16_group_tile = kk_tune_env("KK_GROUP_TILE", 1);                                         // grouped launches: 0 = 64x64, 1 = 128x64 (default: +1 % on the step), 2 = 128x128 tiles
+int g16_group_waves = kk_tune_env("KK_GROUP_WAVES", 8);   // 8-wave workgroups on the 128-row tiles (4: the old form)
 int g16_group_split = 0;                                        // grouped launches: 0 = by the split target, n = n k-slices
 
 }  // namespace

@@ -75,38 +75,23 @@ class GradSync:
         for o in range(0, n, self.bucket):
             dist.all_reduce(flat_grad[o:min(n, o + self.bucket)], op=dist.ReduceOp.SUM)
 
-    # Overlapped form (engine.train_step_graphed): `start` launches the exchange of the ranges that are already final
-    # asynchronously — RCCL runs on its own stream after the work queued so far, the caller keeps queueing the rest of
-    # the backward — and `finish` exchanges the remaining ranges and makes the current stream wait for everything.
-    def start(self, flat_grad: torch.Tensor, ranges):
-        works = []
-        if self._active():
-            for beg, end in ranges:
-                for o in range(beg, end, self.bucket):
-                    works.append(dist.all_reduce(flat_grad[o:min(end, o + self.bucket)], op=dist.ReduceOp.SUM, async_op=True))
-        return works
-
-    def finish(self, flat_grad: torch.Tensor, ranges, works) -> None:
-        if not self._active():
-            return
-        for beg, end in ranges:
-            for o in range(beg, end, self.bucket):
-                dist.all_reduce(flat_grad[o:min(end, o + self.bucket)], op=dist.ReduceOp.SUM)
-        for w in works:
-            w.wait()
-
 
 class LossSync:
-    """engine.loss_sync hook: global loss normalisers for ragged data-parallel shards (collective (2))."""
+    """engine.loss_sync over torch.distributed: global loss normalisers for ragged data-parallel shards (SURVEY §8e,
+    collective (2)).  Eager only (capturable = False) — the step's own communicator carries the same two collectives inside the
+    hipGraph: BucketedExchange.loss_sync over RCCL."""
+    capturable = False
 
     def __init__(self, world: int):
         self.world = world
 
-    def __call__(self, acc: torch.Tensor, max_dur: torch.Tensor) -> None:
+    def loss_sync(self, acc: torch.Tensor, max_dur: torch.Tensor) -> None:
         if self.world == 1:
             return
-        dist.all_reduce(acc, op=dist.ReduceOp.SUM)        # 5 numerators, 5 valid-element counts (fp64)
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)        # 5 numerators, 5 valid-element counts, non-finite count (fp64)
         dist.all_reduce(max_dur, op=dist.ReduceOp.MAX)    # adaptive loss scale / clip heuristics: same inputs on every rank
+
+    __call__ = loss_sync
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -170,6 +155,23 @@ class BucketedExchange:
     def begin_step(self) -> None:
         self.issued = []
 
+    @property
+    def capturable(self) -> bool:
+        """True when every collective of this exchange may be captured into the step's hipGraph (RCCL through the C ABI)."""
+        return self.backend == "rccl"
+
+    def loss_sync(self, acc: torch.Tensor, max_dur: torch.Tensor) -> None:
+        """engine.loss_sync: SUM of the loss sums / valid-element counts, MAX of the largest duration, in place, on the CURRENT
+        stream (they sit on the step's critical path between kk_losses_fwd and kk_losses_finalize) and through the SAME
+        communicator as the gradient buckets — one communicator per step, nothing a hipGraph cannot hold."""
+        if self.backend == "dist":
+            if dist.is_initialized() and dist.get_world_size() > 1:
+                dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+                dist.all_reduce(max_dur, op=dist.ReduceOp.MAX)
+            return
+        from . import lib as kk
+        kk.call("kk_comm_loss_sync", acc, acc.numel(), max_dur)
+
     def reduce(self, flat: torch.Tensor, tag: str) -> None:
         """Exchange bucket `tag` of the flat gradient arena in place (on the current stream)."""
         ranges = self.plan[tag]
@@ -198,29 +200,60 @@ class BucketedExchange:
     @classmethod
     def create(cls, dims, rank: int, world: int, device: torch.device, payload: Optional[str] = None) -> "BucketedExchange":
         """Communicator over RCCL through the C ABI: rank 0 draws the id, the torch.distributed group (already up for
-        the rendezvous) carries it to the others.  Falls back to the "dist" backend if RCCL cannot be bound."""
+        the rendezvous) carries it to the others.  The backend is agreed on COLLECTIVELY: every rank takes part in the
+        broadcast of the id whatever happened to it locally, then one MIN all-reduce of an "RCCL is up here" flag decides;
+        if any rank failed, the ranks that succeeded destroy their communicator and ALL ranks use the "dist" backend
+        (the same ranges over torch.distributed) — never a mix, which would hang or mismatch collectives."""
         import ctypes as C
+        import logging
         from . import lib as kk
+        log = logging.getLogger(__name__)
         payload = payload or os.environ.get("KK_DP_PAYLOAD", "f32")
         lib = kk.load()
-        try:
+        multi = world > 1 and dist.is_initialized()
+        err = None
+        buf = (C.c_char * 128)()
+        try:                                              # stage 1 (local): bind RCCL, rank 0 draws the id
             import torch as _t
             path = os.path.join(os.path.dirname(_t.__file__), "lib", "librccl.so")
             if lib.kk_comm_load(path.encode() if os.path.exists(path) else None) != 0:
                 raise RuntimeError(lib.kk_last_error().decode())
-            buf = (C.c_char * 128)()
             if rank == 0 and lib.kk_comm_unique_id(buf) != 0:
                 raise RuntimeError(lib.kk_last_error().decode())
-            box = [bytes(buf)]
-            if world > 1:
-                dist.broadcast_object_list(box, src=0)
-            if lib.kk_comm_world() == 0 and lib.kk_comm_init(rank, world, box[0]) != 0:
-                raise RuntimeError(lib.kk_last_error().decode())
-            return cls(dims, world, "rccl", payload, torch.cuda.Stream(device=device))
-        except Exception as e:                            # RCCL not bindable here: same ranges over torch.distributed
-            import logging
-            logging.getLogger(__name__).warning("kk_comm unavailable (%s); gradient buckets go through torch.distributed", e)
-            return cls(dims, world, "dist", "f32", torch.cuda.Stream(device=device))
+        except Exception as e:
+            err = e
+        box = [bytes(buf) if (rank == 0 and err is None) else None]
+        if multi:
+            dist.broadcast_object_list(box, src=0)         # every rank, always (None = rank 0 could not draw an id)
+        if err is None and box[0] is None:
+            err = RuntimeError("rank 0 could not create the RCCL id")
+        if multi:                                         # nobody enters ncclCommInitRank unless everybody will
+            err = cls._agree(err, device, "kk_comm unavailable on some rank (%s)", log)
+        if err is None:
+            try:                                          # stage 2: the communicator itself (collective inside RCCL)
+                if lib.kk_comm_world() == 0 and lib.kk_comm_init(rank, world, box[0]) != 0:
+                    raise RuntimeError(lib.kk_last_error().decode())
+            except Exception as e:
+                err = e
+            if multi:
+                err = cls._agree(err, device, "kk_comm_init failed on some rank (%s)", log)
+            if err is not None:
+                lib.kk_comm_destroy()                      # (no-op where no communicator exists)
+        stream = torch.cuda.Stream(device=device) if torch.cuda.is_available() else None
+        if err is None:
+            return cls(dims, world, "rccl", payload, stream)
+        log.warning("kk_comm unavailable (%s); gradient buckets go through torch.distributed on every rank", err)
+        return cls(dims, world, "dist", "f32", stream)
+
+    @staticmethod
+    def _agree(err, device, fmt, log):
+        """MIN all-reduce of a per-rank success flag: returns `err` unchanged when every rank succeeded or this rank failed,
+        and an error for the ranks that succeeded while another one did not."""
+        ok = torch.tensor([0.0 if err is not None else 1.0], device=device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok) < 1.0 and err is None:
+            err = RuntimeError(fmt % "another rank")
+        return err
 
 
 def all_max(x: torch.Tensor) -> torch.Tensor:

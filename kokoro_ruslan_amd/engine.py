@@ -144,7 +144,7 @@ class KokoroEngine:
         # capture mode notwithstanding.
         self.capture_lock = threading.Lock()
         self._rope: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
-        self._reduce_lists = {"": [], "side.": [], "kv.": [], "kv2.": []}   # per stream namespace
+        self._reduce_lists = {"": [], "side.": [], "kv.": []}   # per stream namespace
         self.opt_state = torch.zeros(kk.OS["SIZE"], dtype=torch.float64, device=self.device)
         ns = self.arena.nseg
         f32 = lambda n: torch.zeros(n, dtype=torch.float32, device=self.device)
@@ -158,16 +158,13 @@ class KokoroEngine:
         self.loss_coef = f32(5)
         self.micro_in_cycle = 0
         self.dp_loss_scale = 1.0                    # 1/world in data-parallel runs (dp.GradSync.loss_scale)
-        # Data parallel with ragged shards: callable(acc[10] f64, max_dur[1] i64) that SUM / MAX all-reduces them in
-        # place between the loss forward and the loss backward (dp.LossSync); the losses are then re-finalised with the
-        # global valid-element counts and dp_loss_scale stays 1.  None = per-rank normalisers (exact for equal shards).
+        # Data parallel with ragged shards: an object with .loss_sync(acc[12] f64, max_dur[1] i64) that SUM / MAX all-reduces
+        # them in place between the loss forward and the loss backward; the losses are then re-finalised with the global
+        # valid-element counts and dp_loss_scale stays 1.  dp.BucketedExchange over RCCL issues the two collectives through
+        # the C ABI (kk_comm_loss_sync) on the stream of the step, so they are captured with it: ONE communicator per step,
+        # graph replay for ragged shards too.  dp.LossSync (torch.distributed; the gloo tests) is eager only.
+        # None = per-rank normalisers (exact for equal shards).
         self.loss_sync = None
-        # Data-parallel graph replay, optional: pause the backward after this decoder layer and start the all-reduce of
-        # the gradients that are already final (early_late_ranges) beside the remaining layers.  None (default) = one
-        # exchange after the backward: a hipGraph branch cannot span two graphs, so pausing forces the encoder branch to
-        # be joined at the pause and costs 0.43 ms/step at 8x512 (measured with a 1-rank RCCL group: 6.50 vs 6.07 ms),
-        # about what hiding ~55 % of a ~1 ms all-reduce of 198 MB over xGMI would return.  Worth it for larger models.
-        self.dp_overlap_layer = None
         # Data-parallel exchange INSIDE the step (dp.BucketedExchange over the C ABI's kk_comm_*): every bucket of the
         # gradient arena is all-reduced on the exchange's stream as soon as the backward has finished it — after each
         # decoder / encoder layer's grouped weight gradients, the rest after the last launch — and the optimizer waits for
@@ -191,27 +188,22 @@ class KokoroEngine:
         # one (630K -> 638K), but a per-layer fork for the cross-attention K/V backward lost 9 %, a stream per
         # weight-gradient GEMM 19 %, and moving the duration predictor's forward aside 2 %.
         self._kv = torch.cuda.Stream(device=self.device)
-        # KK_KV_SPLIT=1: the cross-attention K/V of decoder layer 0 on the main chain, those of layers 1.. in a second GEMM on
-        # a branch beside layer 0 (measured: see DESIGN)
-        self._kv2 = torch.cuda.Stream(device=self.device)
-        self.kv_split = os.environ.get("KK_KV_SPLIT", "0") == "1"
-        # KK_SIDE_SPLIT=1: the backward's side branch as TWO branches — pitch / energy predictors and the output heads' weight
-        # gradients on one, duration predictor + text encoder on the other (they only meet in the optimizer)
-        self.side_split = os.environ.get("KK_SIDE_SPLIT", "0") == "1"
         self.dec_head_aside = True
-        self.fuse_glu_fwd = os.environ.get("KK_FUSE_GLU_FWD", "1") != "0"
-        self.group_wgrads = os.environ.get("KK_GROUP_WGRADS", "1") != "0"     # A/B switches for tools/ and bench sweeps
-        self.fuse_headnorm = os.environ.get("KK_FUSE_HEADNORM", "1") != "0"
-        self.fuse_headnorm_bwd = os.environ.get("KK_FUSE_HEADNORM_BWD", "1") != "0"
+        # Fusion switches: plain attributes (tests and tools/probes set them on the object for A/B runs; nothing reads the
+        # environment).  Each fused form is tested against the unfused one it replaces.
+        self.fuse_glu_fwd = True
+        self.group_wgrads = True
+        self.fuse_headnorm = True
+        self.fuse_headnorm_bwd = True
         # attention backward as ONE launch (kk_attn_bwd: the dQ and the dK/dV kernel as the two halves of a grid), Delta from the
         # epilogue of the w_o dgrad GEMM (kk_gemm_dgrad_delta) — bf16 storage, shapes that take the eight-wave GEMM tile
-        self.attn_bwd_pair = os.environ.get("KK_ATTN_BWD_PAIR", "1") != "0"
-        self.attn_proj_bf16 = os.environ.get("KK_ATTN_PROJ_BF16", "1") != "0"      # decoder w_o output stored as bf16 (bf16 mode)
+        self.attn_bwd_pair = True
+        self.attn_proj_bf16 = True                 # decoder w_o output stored as bf16 (bf16 mode)
         # The zero-fill at the start of an accumulation cycle skips what the cycle's first grouped weight-gradient launches
         # overwrite (89 % of the arena at default dims; the fill runs beside the latency-bound encoder launch: 20 us of the step).
         # Which tensors those are is RECORDED from the launches of a step (per precision mode), never assumed, and a step that
         # zeroed by the record checks at its end that it overwrote exactly that set (_zero_grad_step / _grouped_wgrads).
-        self.zero_skip_overwritten = os.environ.get("KK_ZERO_SKIP", "1") != "0"
+        self.zero_skip_overwritten = True
         self._ow_sets: Dict[Tuple, frozenset] = {}
         self._ow_seen: Optional[set] = None
         self._ow_expect: Optional[frozenset] = None
@@ -224,20 +216,14 @@ class KokoroEngine:
         # Text-encoder forward as one persistent launch (kk_encoder_stack_fwd): bf16 mode, phoneme sequences <= 128;
         # otherwise (and with KK_ENC_FUSED=0) the per-kernel sequence.  _enc_sync: its group-barrier words (word 0 != 0
         # = a barrier timed out; encoder_stack_error() reads it).
-        self.enc_fused = os.environ.get("KK_ENC_FUSED", "1") != "0"
-        self.zero_late = os.environ.get("KK_ZERO_LATE", "1") != "0"      # gradient zero-fill after the decoder head's first launches
-        self.enc_placement = int(os.environ.get("KK_ENC_PLACEMENT", "0"))
+        self.enc_fused = True
+        self.zero_late = True                       # gradient zero-fill after the decoder head's first launches
+        self.enc_placement = 0                      # (tests force the groups across XCDs with 1)
         self._enc_sync = torch.zeros(512, dtype=torch.int32, device=self.device)
         self.enc_trace, self.enc_trace_wg = None, 0      # tools/probes/enc_stack_phases.py: per-phase clock stamps of one workgroup
         self.spec_augment_active = True             # the trainer clears it for epochs < spec_augment_start_epoch
         # KK_TRACE=1: one-thread time-stamp launches at the marks of a step (also inside the captured graphs), read back by
         # timeline() — the real overlap of the graph's branches, which rocprofv3 cannot show (it serialises them)
-        self._segmented = False
-        # train_step_graphed: capture the step as a program of single-stream graphs (_capture_segments) instead of one
-        # graph with parallel branches.  Cuts the host cost of a step from 2.5 ms to ~0.2 ms, but the GPU time is 3 %
-        # worse (770K vs 794K frames/s: the kernels inside a stretch run no closer together, and every stretch boundary
-        # costs 10-20 us), so it is off unless the host is the bottleneck.
-        self.segmented_graphs = os.environ.get("KK_SEGMENTED", "0") == "1"
         self.trace = os.environ.get("KK_TRACE", "0") == "1"
         self._marks: Dict[str, int] = {}
         self._mark_buf = torch.zeros(512, dtype=torch.int64, device=self.device) if self.trace else None
@@ -329,9 +315,6 @@ class KokoroEngine:
             return
         saved, self._tmp_ns = self._tmp_ns, ns
         try:
-            if self._segmented:          # the capture driver switches graphs / streams at the generator's markers
-                yield
-                return
             if after is not None:
                 stream.wait_event(after)
             else:
@@ -346,7 +329,7 @@ class KokoroEngine:
 
     def _fork_point(self):
         """An event on the current stream that a later _on_stream(..., after=event) forks from."""
-        if not self.overlap or self._segmented:
+        if not self.overlap:
             return None
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
@@ -355,7 +338,7 @@ class KokoroEngine:
     def _comm_bucket(self, tag: str) -> None:
         """The gradients of bucket `tag` are final on the current stream from here on: exchange them on the comm stream."""
         c = self.dp_comm
-        if c is None or not self._exchange_now or self._segmented:
+        if c is None or not self._exchange_now:
             return
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
@@ -365,7 +348,7 @@ class KokoroEngine:
 
     def _comm_join(self) -> None:
         c = self.dp_comm
-        if c is not None and self._exchange_now and not self._segmented:
+        if c is not None and self._exchange_now:
             torch.cuda.current_stream().wait_stream(c.stream)
 
     def _mark(self, name: str) -> None:
@@ -586,7 +569,7 @@ class KokoroEngine:
     def _reduce_partials(self, shape_key) -> None:
         """One launch that adds the column sums of every partial matrix written so far (by streams already joined into
         the current one) to its gradient vectors."""
-        todo = [e for ns in ("side.", "kv2.", "kv.", "") for e in self._reduce_lists[ns]]
+        todo = [e for ns in ("side.", "kv.", "") for e in self._reduce_lists[ns]]
         for ns in self._reduce_lists:
             self._reduce_lists[ns] = []
         if not todo:
@@ -947,49 +930,14 @@ class KokoroEngine:
         decoder memory is the first T frames (model/model.py:607-613), the losses read the first T columns
         (losses.py:111,137).  T' < T: the reference fails in the pitch loss with a size-mismatch RuntimeError
         (losses.py:126: [B, T'] predictions against [B, T] targets) — the same error is raised here, before any launch."""
-        gen = self._fb_gen(batch, loss_scale, adaptive, backward, None, zero_grads, expanded_len)
-        while True:
-            try:
-                next(gen)
-            except StopIteration as stop:
-                return stop.value
+        return self._fb(batch, loss_scale, adaptive, backward, zero_grads, expanded_len)
 
-    def early_late_ranges(self, split_layer: int):
-        """Element ranges of the gradient arena that are final when _fb_gen pauses at `split_layer` ("early": decoder
-        layers >= split_layer, the heads, and everything the side stream computes) and the rest ("late": decoder layers
-        below, the batched cross-attention K/V weights, mel_projection_in, the pitch/energy embeddings).  Adjacent
-        segments are merged (segments are 1024-aligned and contiguous, the padding carries zero gradients)."""
-        a = self.arena
-        late_prefix = tuple(f"decoder.layers.{i}." for i in range(split_layer))
-
-        def late(n):
-            return (n.endswith(".cross_attn.w_k.weight") or n.endswith(".cross_attn.w_v.weight") or n.startswith("mel_projection_in.")
-                    or n.endswith("pitch_embedding.weight") or n.endswith("energy_embedding.weight") or n.startswith(late_prefix))
-        out = {False: [], True: []}
-        names = a.names                                  # physical order
-        for j, n in enumerate(names):
-            beg = a.offset[n]
-            end = a.offset[names[j + 1]] if j + 1 < len(names) else a.total
-            r = out[late(n) if n in a.G and n in a.param_names else False]
-            if r and r[-1][1] == beg:
-                r[-1][1] = end
-            else:
-                r.append([beg, end])
-        return [tuple(x) for x in out[False]], [tuple(x) for x in out[True]]
-
-    def _fb_gen(self, batch, loss_scale, adaptive, backward, split_layer, zero_grads=False, expanded_len=None):
-        """forward_backward as a generator: with split_layer = k it pauses once, after the backward of decoder layer k,
-        with the side stream joined and every gradient of early_late_ranges(k)[0] final — the data-parallel step
-        captures the two halves as separate hipGraphs and starts the all-reduce of the early ranges in between.
-
-        With self._segmented set (by _capture_segments) the generator also yields a marker wherever the work moves to
-        another stream or waits for one — ("begin", stream[, "fork"]), ("end", stream), ("join", stream), ("fork",) —
-        and leaves the stream switching to the driver, which captures every stretch as its own single-stream hipGraph."""
+    def _fb(self, batch, loss_scale, adaptive, backward, zero_grads=False, expanded_len=None):
+        """The launch sequence of forward_backward (also what train_step_graphed captures)."""
         d, a, P, G = self.dims, self.arena, self.arena.P, self.arena.G
         self._grads_fresh = bool(zero_grads) or self._first_micro
         self._ow_seen = set() if (self._grads_fresh and backward) else None
         self._ow_expect = None
-        seg = self._segmented and self.overlap
         H, M, Fv = d.hidden, d.mel, d.var_filter
         ids, mel, dur = batch["phoneme_indices"], batch["mel_specs"], batch["phoneme_durations"]
         stress = batch.get("stress_indices")
@@ -1047,16 +995,12 @@ class KokoroEngine:
             self.rng.add_(1)                              # fresh masks every micro-batch (captured in the hipGraph)
         pe_drop, p_enc, p_dec, p_var = self._p(hp.encoder_dropout), self._p(hp.encoder_dropout), self._p(hp.decoder_dropout), self._p(hp.variance_dropout)
         self._mark("step.start")
-        if seg and self.dec_head_aside:
-            yield ("begin", "kv")
         with self._on_stream(self._kv, "kv.", self.dec_head_aside):     # beside the encoder; joined before the first cross-attention
             if zero_grads and not self.zero_late:
                 self._zero_grad_step()
             kk.call("kk_max_i64", dur, Ne, self.max_dur)  # (read by the losses only: not in front of the encoder)
             dec_head = decoder_head()                     # (includes the gradient zero-fill, see there)
             self._mark("kv: decoder head done")
-        if seg and self.dec_head_aside:
-            yield ("end", "kv")
         kk.call("kk_embed_fwd", ids, stress, P["text_embedding.weight"], P["stress_embedding.weight"] if stress is not None else None,
                 pe, x, B, Pn, H, float(H ** 0.5), self.rng, 1, pe_drop)
         y1 = None                                         # LayerNorm outputs come from the previous sub-layer's fused tail
@@ -1113,18 +1057,10 @@ class KokoroEngine:
 
         # ---- decoder (model.py:519-531; transformers.py:543-583,660) ----
         self._mark("memory ready")
-        kv_split = bool(self.kv_split and self.overlap and not seg and d.dec_layers > 1)
-        if kv_split:                                      # layer 0's K/V here, the other layers' beside layer 0
-            self._cross_kv_fwd_all(memory, Nd, T, ddt, 0, 1)
-            with self._on_stream(self._kv2, "kv2."):
-                self._cross_kv_fwd_all(memory, Nd, T, ddt, 1, d.dec_layers)
-        else:
-            self._cross_kv_fwd_all(memory, Nd, T, ddt)    # every layer's cross-attention K/V in one GEMM
+        self._cross_kv_fwd_all(memory, Nd, T, ddt)        # every layer's cross-attention K/V in one GEMM
         self._mark("cross K/V fwd done")
         # Forked only here, after the K/V GEMM: started earlier (right after im2col3) the predictors' fp32 GEMMs compete
         # with the critical path into the decoder; 2.8 % of the step (729K -> 749K frames/s).
-        if seg:
-            yield ("begin", "side")
         with self._on_side_stream():                      # joined before the losses
             self._mark("side: predictors fwd start")
             kk.call("kk_im2col3_fwd", enc, col_e, B, Pn, H, CHUNK, _b16(col_e))
@@ -1141,24 +1077,17 @@ class KokoroEngine:
                 kk.call("kk_pad2d_f32", pitch_pred, Tp, Tp, pitch_l, T, T, B)
                 kk.call("kk_pad2d_f32", energy_pred, Tp, Tp, energy_l, T, T, B)
             self._mark("side: predictors fwd done")
-        if seg:
-            yield ("end", "side")
         n1 = None
         for i in range(d.dec_layers):
             pf, key, st = f"decoder.layers.{i}", f"dec{i}", 2000 + 32 * i
             dpr = self._dpr(i, d.dec_layers)
             if i == 0:                                    # input projection + layer-0 self-attention ran beside the encoder
-                if seg and self.dec_head_aside:
-                    yield ("join", "kv")
-                else:
-                    self._join(self._kv)
+                self._join(self._kv)
                 y, ya, n2 = dec_head
             else:
                 if n1 is None:
                     n1 = self._ln_fwd(key + ".ln1", y, pf + ".norm1", ddt)
                 ya, n2 = self_attn(i, y, n1)
-                if i == 1 and kv_split:
-                    self._join(self._kv2)
             yc = self._buf(key + ".xc", Nd, H)
             n3 = self._attn_fwd(key + ".ca", pf + ".cross_attn", n2, memory, B, T, T, False, False, fmask, ya, yc, st + 8, p_dec, dpr,
                                 next_ln=(key + ".ln3", pf + ".norm3", ddt), layer=i)
@@ -1178,10 +1107,7 @@ class KokoroEngine:
                 _b16(dec_out))
 
         # ---- losses (losses.py) ----
-        if seg:
-            yield ("join", "side")
-        else:
-            self._join_side()
+        self._join_side()
         lcfg = kk.KkLossCfg(hp.duration_loss_weight, hp.stop_token_loss_weight, hp.pitch_loss_weight, hp.energy_loss_weight,
                             hp.duration_huber_delta, hp.pitch_huber_delta, hp.energy_huber_delta, hp.stop_token_pos_weight,
                             float(loss_scale), 1 if adaptive else 0)
@@ -1193,15 +1119,14 @@ class KokoroEngine:
         guard = self.opt_state[kk.OS["MICRO_BAD"]:] if backward else None
         kk.call("kk_losses_fwd", *largs, self.max_dur, self.loss_acc, self.losses, self.loss_coef,
                 guard if self.loss_sync is None else None)
-        if self.loss_sync is not None:
-            self.loss_sync(self.loss_acc, self.max_dur)
+        if self.loss_sync is not None:                    # global normalisers for ragged shards (one more collective of the step)
+            self.loss_sync.loss_sync(self.loss_acc, self.max_dur)
             kk.call("kk_losses_finalize", self.loss_acc, lcfg, self.max_dur, int(self.global_mel_length or T), self.losses,
                     self.loss_coef, guard)
         out = {"losses": self.losses, "mel": mel_pred, "log_dur": dur_pred, "stop": stop, "pitch": pitch_pred,
                "energy": energy_pred, "lr_idx": idx, "lr_lens": lens, "memory": memory.view(B, T, H)}
         if not backward:
             return out
-        yield_at = split_layer if (split_layer is not None and 0 < split_layer < d.dec_layers) else None
 
         # =========================== backward ===========================
         for ns in self._reduce_lists:
@@ -1213,10 +1138,6 @@ class KokoroEngine:
         kk.call("kk_losses_bwd", *largs, self.loss_coef, dmel, ddur, dstop, dpitch, denergy)
         self._mark("losses + loss gradients done")
         fork = self._fork_point()
-        if seg:
-            yield ("fork",)
-
-        side2 = bool(self.side_split and self.overlap and not seg and yield_at is None)
 
         def heads_and_frame_predictors():
             # the output heads' weight gradients have no consumer on the decoder chain (the stop head's input is
@@ -1233,13 +1154,9 @@ class KokoroEngine:
             self._varpred_bwd("vp.energy", f"{VA}.energy_predictor", denergy_p, xf_p, col_f, B, Tp, fmask_p, None, p_var)
 
         def side_backward(after):                         # independent of the decoder backward (disjoint gradient segments)
-            if side2:
-                with self._on_stream(self._kv2, "kv2.", after=after):
-                    heads_and_frame_predictors()
             with self._on_side_stream(after=after):
                 self._mark("side: backward start")
-                if not side2:
-                    heads_and_frame_predictors()
+                heads_and_frame_predictors()
                 d_enc = self._buf("g.enc_out", Ne, H)
                 self._varpred_bwd("vp.dur", f"{VA}.duration_predictor", ddur, enc, col_e, B, Pn, text_mask, d_enc, p_var)
                 self._mark("side: predictors bwd done")
@@ -1271,10 +1188,7 @@ class KokoroEngine:
                 self._mark("side: backward done")
 
         # The decoder backward is the critical path, so it is captured first and the predictors' + encoder's backward
-        # after it, forked from the point right after the loss gradients (see _on_stream).  With a split backward
-        # (data-parallel overlap) the early ranges must be final at the pause, so there the side branch goes first.
-        if yield_at is not None:
-            side_backward(None)
+        # after it, forked from the point right after the loss gradients (see _on_stream).
         # heads: only the mel projection's input gradient continues down the decoder (the two heads' weight gradients are
         # on the side branch, see side_backward)
         d_dec_out = self._buf("tmp.d_dec_out", Nd, H, dtype=ddt)
@@ -1306,10 +1220,6 @@ class KokoroEngine:
             else:
                 self._ln_bwd(key + ".ln1", dn, x_in, pf + ".norm1", dy, accumulate=True)
             self._mark(f"dec{i} bwd done")
-            if yield_at == i:                           # everything the early ranges hold is final from here on
-                self._join(self._side)
-                self._reduce_partials((B, T, Pn, Tp, "early"))
-                yield "split"
         # decoder input projection (the PE add and the shift are parameter-free; mel is data)
         if self.train_dropout and (p_din > 0.0 or pe_drop > 0.0):
             t1, dlin = self._buf("tmp.d_dec_t1", Nd, H), self._buf("tmp.d_dec_lin", Nd, H)
@@ -1328,18 +1238,8 @@ class KokoroEngine:
         kk.call("kk_bucket_embed_add_bwd", dmem, pidx, eidx, fmask, G[f"{VA}.pitch_embedding.weight"],
                 G[f"{VA}.energy_embedding.weight"], B, T, H, d.var_bins)
         self._mark("main: backward tail done")
-        if yield_at is None:
-            if seg:
-                yield ("begin", "side", "fork")
-            side_backward(fork)
-            if seg:
-                yield ("end", "side")
-        if seg:
-            yield ("join", "side")
-        else:
-            self._join(self._side)
-            if side2:
-                self._join(self._kv2)
+        side_backward(fork)
+        self._join(self._side)
         self._reduce_partials((B, T, Pn, Tp))
         self._comm_bucket("tail")                       # everything that was not a layer's weight matrix
         self._comm_join()
@@ -1595,7 +1495,7 @@ class KokoroEngine:
         max_graphs shapes are kept (least recently used first out)."""
         B, T = batch["mel_specs"].shape[:2]
         key = (B, T, batch["phoneme_indices"].shape[1], T if expanded_len is None else int(expanded_len))
-        if self.loss_sync is None:              # (the loss-count exchange of ragged data-parallel shards runs between kernels)
+        if self.loss_sync is None or getattr(self.loss_sync, "capturable", False):     # (a torch.distributed loss exchange is eager)
             if key in self._graphs:
                 return self.train_step_graphed(batch, grad_sync, accumulation_divisor, boundary, expanded_len)
             n = self._shape_seen.get(key, 0) + 1
@@ -1608,110 +1508,15 @@ class KokoroEngine:
         return self.train_step(batch, accumulation_divisor, boundary, grad_sync, expanded_len)
 
     # ------------------------------------------------------------------ hipGraph replay of a whole step
-    def _capture_segments(self, static, scale=None, first=True, expanded_len=None):
-        """Capture forward+backward as a PROGRAM of single-stream hipGraphs instead of one graph with parallel branches.
-
-        A hipGraph that forks onto several streams is launched node by node through the runtime's multi-queue path:
-        2.5 ms of host time per step here and 2.4 us between dependent kernels.  A single-stream graph takes the
-        packet-capture fast path: ~0.02 ms to launch, 1.5 us between dependent kernels (tools/probes/graph_gap_probe.py)
-        — 0.9 us less for each of the ~330 kernels of the main chain.  So every stretch of the step that runs on one
-        stream becomes its own graph, launched on that stream, and the edges between the branches (fork after the
-        cross K/V GEMM, join before the losses, ...) are ordinary events between graph launches.  The program is the
-        list of ("launch", stream, graph) / ("record", stream, event) / ("wait", stream, event) replayed every step;
-        the dependencies are exactly the ones the one-graph capture had."""
-        prog, graphs = [], []
-        last = {}                                   # stream name -> event after its latest graph
-        state = {"name": "main", "ctx": None, "g": None, "n0": 0, "fork": None}
-
-        def open_graph(name):
-            g = torch.cuda.CUDAGraph()
-            ctx = torch.cuda.graph(g, capture_error_mode="thread_local")
-            ctx.__enter__()
-            state.update(name=name, ctx=ctx, g=g, n0=kk.launches)
-
-        def close_graph():
-            state["ctx"].__exit__(None, None, None)
-            name = state["name"]
-            graphs.append(state["g"])              # (kept alive even when empty: a graph must not be destroyed during a capture)
-            if kk.launches > state["n0"]:
-                prog.append(("launch", name, state["g"]))
-            ev = torch.cuda.Event()
-            prog.append(("record", name, ev))
-            last[name] = ev
-            state["ctx"] = None
-
-        ev0 = torch.cuda.Event()                    # everything queued before this step (the previous optimizer pass)
-        prog.append(("record", "main", ev0))
-        last["main"] = ev0
-        self._segmented = True
-        try:
-            gen = self._fb_gen(static, self.dp_loss_scale if scale is None else scale, True, True, None, first, expanded_len)
-            open_graph("main")
-            for msg in gen:
-                kind = msg[0]
-                if kind == "begin":
-                    close_graph()
-                    dep = state["fork"] if len(msg) > 2 else last["main"]
-                    prog.append(("wait", msg[1], dep))
-                    open_graph(msg[1])
-                elif kind == "end":
-                    close_graph()
-                    open_graph("main")
-                elif kind == "join":
-                    close_graph()
-                    prog.append(("wait", "main", last[msg[1]]))
-                    open_graph("main")
-                elif kind == "fork":
-                    close_graph()
-                    state["fork"] = last["main"]
-                    open_graph("main")
-                else:
-                    raise RuntimeError(f"unexpected pause {msg!r} in a segmented capture")
-            close_graph()
-        finally:
-            self._segmented = False
-            if state["ctx"] is not None:
-                state["ctx"].__exit__(None, None, None)
-        self._segment_graphs = getattr(self, "_segment_graphs", []) + graphs
-        return prog
-
-    def _run_program(self, prog) -> None:
-        main = torch.cuda.current_stream()
-        streams = {"main": main, "kv": self._kv, "side": self._side}
-        for op, name, obj in prog:
-            st = streams[name]
-            if op == "launch":
-                if st is main:
-                    obj.replay()
-                else:
-                    with torch.cuda.stream(st):
-                        obj.replay()
-            elif op == "record":
-                obj.record(st)
-            else:
-                st.wait_event(obj)
-
-    def _capture_fb(self, static, scale, first, expanded_len, overlap, plain) -> Dict:
+    def _capture_fb(self, static, scale, first, expanded_len) -> "torch.cuda.CUDAGraph":
         """Capture one micro-batch variant (forward + losses + backward) of a batch shape; called under capture_lock."""
         torch.cuda.synchronize()
-        fb = {"g1": torch.cuda.CUDAGraph(), "g2": None, "prog": None}
+        g = torch.cuda.CUDAGraph()
         # thread_local: with an RCCL process group alive, its watchdog thread polls events while we capture; only
         # this thread's calls must be capture-safe
-        if overlap:     # two graphs: the all-reduce of the gradients that are final at the split runs beside the second
-            gen = self._fb_gen(static, scale, True, True, self.dp_overlap_layer, first, expanded_len)
-            with torch.cuda.graph(fb["g1"], capture_error_mode="thread_local"):
-                assert next(gen) == "split"
-            fb["g2"] = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(fb["g2"], capture_error_mode="thread_local"):
-                for _ in gen:
-                    raise RuntimeError("forward_backward paused twice")
-            fb["ranges"] = self.early_late_ranges(self.dp_overlap_layer)
-        elif plain and self.segmented_graphs and self.overlap:
-            fb["prog"] = self._capture_segments(static, scale, first, expanded_len)
-        else:
-            with torch.cuda.graph(fb["g1"], capture_error_mode="thread_local"):
-                self.forward_backward(static, loss_scale=scale, adaptive=True, zero_grads=first, expanded_len=expanded_len)
-        return fb
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            self.forward_backward(static, loss_scale=scale, adaptive=True, zero_grads=first, expanded_len=expanded_len)
+        return g
 
     def train_step_graphed(self, batch: Dict[str, torch.Tensor], grad_sync=None, accumulation_divisor: Optional[int] = None,
                            boundary: Optional[bool] = None, expanded_len: Optional[int] = None) -> torch.Tensor:
@@ -1724,24 +1529,21 @@ class KokoroEngine:
         B, T = batch["mel_specs"].shape[:2]
         Tp = T if expanded_len is None else int(expanded_len)
         key = (B, T, batch["phoneme_indices"].shape[1], Tp)
-        if self.loss_sync is not None:
-            raise RuntimeError("train_step_graphed: the loss-count exchange (loss_sync) runs between kernels of the step; "
-                               "use train_step for ragged data-parallel shards")
+        if self.loss_sync is not None and not getattr(self.loss_sync, "capturable", False):
+            raise RuntimeError("train_step_graphed: this loss_sync exchanges the loss counts through torch.distributed between "
+                               "kernels of the step, which a hipGraph cannot hold; use train_step, or the RCCL exchange "
+                               "(dp.BucketedExchange, backend 'rccl'), whose collectives are captured with the step")
         G = max(1, int(self.hp.gradient_accumulation_steps))
         div = int(accumulation_divisor) if accumulation_divisor is not None else G
         first = self.micro_in_cycle == 0
         is_boundary = bool(boundary) if boundary is not None else self.micro_in_cycle + 1 >= G
         scale = self.dp_loss_scale / div
         mel_length = int(self.global_mel_length or T)
-        plain = G == 1 and div == 1                   # the split-backward / segmented forms exist for the one-micro-batch step
-        overlap = plain and grad_sync is not None and self.dp_overlap_layer is not None and hasattr(grad_sync, "start")
         ent = self._graphs.get(key)
         self._exchange_now = is_boundary
         if ent is None:                               # first sight of a shape: eager (allocates the workspaces and the
             static = {k: v.clone() for k, v in batch.items()}      # reduction tables — host-to-device copies, illegal in a capture)
-            gen = self._fb_gen(static, scale, True, True, self.dp_overlap_layer if overlap else None, first, expanded_len)
-            for _ in gen:                             # same pause point as the captured form, so the same tables get built
-                pass
+            self._fb(static, scale, True, True, first, expanded_len)
             self._exchange_now = True
             # (registered only now: growing a buffer during the eager pass drops every graph entry)
             if len(self._graphs) >= self.max_graphs:
@@ -1768,23 +1570,16 @@ class KokoroEngine:
                 d.copy_(v, non_blocking=True)
         if moved:
             kk.copy_many(moved)                        # one launch for the whole batch
-        fkey = (div, first, self.train_dropout, self.spec_augment_active, self.math, overlap, self.dp_comm is not None and is_boundary)
+        fkey = (div, first, self.train_dropout, self.spec_augment_active, self.math, self.dp_comm is not None and is_boundary,
+                self.loss_sync is not None)
         fb = ent["fb"].get(fkey)
         if fb is None:
             with self.capture_lock:
-                fb = ent["fb"][fkey] = self._capture_fb(static, scale, first, expanded_len, overlap, plain)
+                fb = ent["fb"][fkey] = self._capture_fb(static, scale, first, expanded_len)
         self._exchange_now = True
-        if fb["prog"] is not None:
-            self._run_program(fb["prog"])
-        else:
-            fb["g1"].replay()
+        fb.replay()
         self.micro_in_cycle += 1
-        if fb["g2"] is not None:
-            early, late = fb["ranges"]
-            works = grad_sync.start(self.arena.g, early)      # asynchronous, on the collective stream
-            fb["g2"].replay()                                 # ... while the rest of the backward runs
-            grad_sync.finish(self.arena.g, late, works)
-        elif grad_sync is not None and is_boundary:
+        if grad_sync is not None and is_boundary:
             grad_sync(self.arena.g)
         if is_boundary:
             opt = ent["opt"].get(mel_length)
@@ -1799,8 +1594,27 @@ class KokoroEngine:
         return self.losses
 
     def encoder_stack_error(self) -> int:
-        """Non-zero when a group barrier of kk_encoder_stack_fwd has ever timed out (host read: synchronises)."""
+        """Non-zero when a group barrier of kk_encoder_stack_fwd has timed out since the last reset (host read: synchronises)."""
         return int(self._enc_sync[0].item())
+
+    def check_encoder_stack(self) -> None:
+        """Raise if a group barrier of the persistent encoder launch has timed out.  kk_encoder_stack_fwd is a plain launch whose
+        256 workgroups must be co-resident; every spin is bounded, and a workgroup that gives up sets word 0 of the sync buffer
+        and carries on with stale activations — the step (and every later one: the word makes later barriers fall through) is
+        then garbage that no finite-value guard sees.  The trainer calls this wherever it synchronises anyway (end of an epoch,
+        before validation, before a checkpoint is written).  Handling it = clear the word (so later launches wait again), fall
+        back to the per-kernel encoder for the rest of the run, drop the graphs that hold the launch, and fail the caller: the
+        weights since the last check cannot be trusted."""
+        if not self.enc_fused:
+            return
+        code = self.encoder_stack_error()
+        if code:
+            self._enc_sync.zero_()
+            self.enc_fused = False
+            self._graphs.clear()
+            raise RuntimeError(f"kk_encoder_stack_fwd: a group barrier timed out (code {code}); the activations of at least one "
+                               "step were stale.  The fused encoder launch is now off for this engine (per-kernel sequence); "
+                               "reload the last checkpoint before continuing.")
 
     def opt_stats(self) -> Dict[str, float]:
         """Host read-back of the device optimizer state (synchronises; for logging/tests only)."""

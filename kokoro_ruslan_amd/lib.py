@@ -207,6 +207,7 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_comm_destroy": [],
     "kk_comm_reduce_bucket": [_P, _L, _I, _P],
     "kk_comm_reduce_ranges": [_P, _P, _P, _I, _I, _P],
+    "kk_comm_loss_sync": [_P, _I, _P, _P],
     "kk_comm_reduce_scatter": [_P, _P, _L, _I, _P],
     "kk_comm_all_gather": [_P, _P, _L, _I, _P],
     "kk_cast_bf16_f32": [_P, _P, _L, _F, _P],

@@ -18,11 +18,16 @@ def stop_targets(T: int, tail: int = 6, decay: float = 0.5) -> torch.Tensor:
 
 
 def synthetic_batch(B: int, T: int, P: int, vocab: int = 59, mel: int = 80, seed: int = 1234,
-                    ragged: bool = False) -> Dict[str, torch.Tensor]:
+                    ragged: bool = False, lengths=None) -> Dict[str, torch.Tensor]:
+    """lengths = (mel lengths [B], phoneme lengths [B]): a batch padded to T x P with those valid lengths (what collate_fn makes of
+    B utterances); ragged=True draws them in [0.6, 1] x (T, P) with sample 0 full length."""
     g = torch.Generator().manual_seed(seed)
     mel_len = torch.full((B,), T, dtype=torch.long)
     ph_len = torch.full((B,), P, dtype=torch.long)
-    if ragged and B > 1:
+    if lengths is not None:
+        mel_len, ph_len = torch.as_tensor(lengths[0], dtype=torch.long), torch.as_tensor(lengths[1], dtype=torch.long)
+        assert mel_len.shape == (B,) and ph_len.shape == (B,) and int(mel_len.max()) <= T and int(ph_len.max()) <= P
+    elif ragged and B > 1:
         mel_len[1:] = (T * (0.6 + 0.4 * torch.rand(B - 1, generator=g))).long().clamp(min=4)
         ph_len[1:] = (P * (0.6 + 0.4 * torch.rand(B - 1, generator=g))).long().clamp(min=2)
     out = {"phoneme_indices": torch.zeros(B, P, dtype=torch.long), "stress_indices": torch.zeros(B, P, dtype=torch.long),

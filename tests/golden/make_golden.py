@@ -621,11 +621,68 @@ def section_expanded_length(d: O.ModelDims):
     np.savez_compressed(os.path.join(HERE, "expanded_length.npz"), **save)
 
 
+def section_autocast(d: O.ModelDims, B, T, Pn, seed, ragged):
+    """The reference's OWN bf16 mode (trainer.py:3181-3232: the model forward under torch.autocast(dtype=bfloat16), losses and
+    backward outside it) on the `full_dims` batch and weights, next to its fp32 run: how far the reference's mixed precision
+    moves losses, outputs and every gradient away from its fp32 numbers.  The MI355X engine's bf16 mode (bf16 MFMA operands and
+    operand storage, fp32 accumulate / residual streams / statistics) is held to that yardstick on the GPU
+    (tests/test_engine_gpu.py::test_bf16_mode_against_the_references_own_autocast)."""
+    print(f"== autocast_bf16: dims={d} batch=({B},{T},{Pn})")
+    cfg = TrainingConfig()
+    model = ref_model(d)
+    # The reference enters autocast on CUDA only (trainer.py:935-956); here its model runs under the CPU autocast of the same dtype,
+    # the one emulation this container allows.  The bf16 predictions are widened to fp32 before the losses (exact): the CPU
+    # HuberLoss backward refuses a bf16 prediction against an fp32 target ("Found dtype Float but expected BFloat16"), where the CUDA
+    # kernel promotes to fp32 internally — the same arithmetic.
+    missing, unexpected = model.load_state_dict(seeded_params(d, seed), strict=False)
+    assert not unexpected
+    names = [n for n, _ in model.named_parameters()]
+    batch = O.synthetic_batch(B, T, Pn, d, seed=seed, ragged=ragged)
+    if ragged:
+        batch["phoneme_indices"][0, 2] = 0
+    res = {}
+    for mode in ("fp32", "autocast"):
+        model.zero_grad()
+        if mode == "autocast":
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                out = model(batch["phoneme_indices"], batch["mel_specs"], batch["phoneme_durations"], batch["stop_token_targets"],
+                            pitch_targets=batch["pitches"], energy_targets=batch["energies"], stress_indices=batch["stress_indices"])
+        else:
+            out = model(batch["phoneme_indices"], batch["mel_specs"], batch["phoneme_durations"], batch["stop_token_targets"],
+                        pitch_targets=batch["pitches"], energy_targets=batch["energies"], stress_indices=batch["stress_indices"])
+        ls = ref_losses(model, cfg, [o.float() for o in out], batch)
+        ls[0].backward()
+        res[mode] = ([o.detach().float().clone() for o in out], [float(x) for x in ls],
+                     {n: (p.grad.detach().float().clone() if p.grad is not None else torch.zeros_like(p)) for n, p in model.named_parameters()})
+        print(f"  {mode:8s} output dtype {out[0].dtype}, losses {[round(float(x), 5) for x in ls]}")
+    (o32, l32, g32), (o16, l16, g16) = res["fp32"], res["autocast"]
+    cos, ratio = [], []
+    for n in names:
+        a, b = g16[n].double().flatten(), g32[n].double().flatten()
+        nb = float(b.norm())
+        cos.append(float(a @ b / (a.norm() * b.norm() + 1e-300)) if nb > 1e-12 else 1.0)
+        ratio.append(float(a.norm()) / nb if nb > 1e-12 else 1.0)
+    valid = (torch.arange(T)[None, :] < batch["mel_lengths"][:, None])[:, :, None].float()
+    mel_l1 = float(((o16[0] - o32[0]).abs() * valid).sum() / (valid.sum() * d.mel))
+    print(f"  autocast vs fp32: loss deltas {[round(a - b, 5) for a, b in zip(l16, l32)]}; mel-L1 between the two mel outputs {mel_l1:.4e}; "
+          f"gradient cosine min {min(cos):.4f} mean {float(np.mean(cos)):.5f}; norm ratio {min(ratio):.3f}..{max(ratio):.3f}")
+    np.savez_compressed(os.path.join(HERE, "autocast_bf16.npz"), seed=np.array(seed), shape=np.array([B, T, Pn]),
+                        losses_fp32=np.array(l32), losses_autocast=np.array(l16), grad_cos=np.array(cos), grad_norm_ratio=np.array(ratio),
+                        grad_norms_autocast=np.array([float(g16[n].double().norm()) for n in names]),
+                        grad_norms_fp32=np.array([float(g32[n].double().norm()) for n in names]),
+                        mel_l1_between=np.array(mel_l1), mel_autocast=o16[0].numpy(), mel_fp32=o32[0].numpy(),
+                        **{f"batch/{k}": v.numpy() for k, v in batch.items()})
+    print("  wrote autocast_bf16.npz")
+
+
 if __name__ == "__main__":
     tiny = O.ModelDims(vocab=59, mel=20, hidden=128, heads=2, enc_layers=2, dec_layers=2, enc_ff=96,
                        dec_ff=96, var_filter=32, var_kernel=3, var_bins=16, max_len=700)
     if sys.argv[1:] == ["inference"]:                            # only the decode fixture
         section_inference(tiny, seed=21)
+        sys.exit(0)
+    if sys.argv[1:] == ["autocast"]:                             # only the reference-autocast fixture
+        section_autocast(O.ModelDims(), B=2, T=96, Pn=12, seed=14, ragged=True)
         sys.exit(0)
     if sys.argv[1:] == ["step"]:                                 # only the step-driver / expanded-length fixtures
         section_step_driver()
@@ -648,4 +705,5 @@ if __name__ == "__main__":
     section_step_driver()
     section_expanded_length(mid)
     section_inference(tiny, seed=21)
+    section_autocast(O.ModelDims(), B=2, T=96, Pn=12, seed=14, ragged=True)
     print("ALL REFERENCE CHECKS PASSED")

@@ -30,7 +30,7 @@ def test_kernel_table_accounts_for_the_attention_backward_pair_and_its_delta_gem
     ]
     t = b.kernel_table(recs, True)
     pair = t["attn_bwd_pair2_kernel (dQ | dK, dV in one launch)"]
-    full = 7 * 2.0 * B * h * S * S * 64
+    full = 4 * 2.0 * B * h * S * S * 64            # the backward of a 2-matmul forward is 4 matmuls; recomputation earns nothing
     assert pair["launches"] == 2 and abs(pair["flops"] - (0.5 * full + full)) < 1.0          # causal = lower triangle
     assert pair["bytes"] == 2 * 2.0 * B * h * 64 * 8 * S
     w8 = [k for k in t if k.startswith("gemm16_kernel_w8<false,true,3>")]
@@ -41,3 +41,25 @@ def test_kernel_table_accounts_for_the_attention_backward_pair_and_its_delta_gem
     shapes = [k for k in t if k.startswith("  shape")]
     assert any("kk_attn_bwd B=8 h=8 Sq=512 Sk=512 causal=1" in k for k in shapes)
     assert sum("ta=0 tb=1 M=4096 N=512 K=512" in k for k in shapes) == 1
+
+
+def test_train_flops_formula_reproduces_the_survey_table():
+    """SURVEY 8d / BASELINE.md section 4: 870.1 GFLOP per step at 8x512x64, 1974.4 GFLOP at 8x1024x128."""
+    b = _bench()
+    assert abs(b.train_flops(8, 512, 64) / 1e9 - 870.1) < 0.1
+    assert abs(b.train_flops(8, 1024, 128) / 1e9 - 1974.4) < 0.1
+    assert abs(b.train_flops(8, 512, 64) / (8 * 512) / 1e6 - 212.4) < 0.1
+
+
+def test_ragged_workload_respects_the_frame_budget(monkeypatch):
+    """configs[2]'s resident workload: every batch B * T <= 16384, 4 <= B <= 32, ragged lengths, durations summing to the lengths."""
+    import torch
+    b = _bench()
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    batches = b.ragged_workload(n_utts=120)
+    assert len(batches) >= 8
+    for x in batches:
+        B, T = x["mel_specs"].shape[:2]
+        assert B * T <= 16384 and 4 <= B <= 32 and int(x["mel_lengths"].max()) == T
+        assert torch.equal(x["phoneme_durations"].sum(1), x["mel_lengths"])
+    assert len({tuple(x["mel_specs"].shape[:2]) for x in batches}) >= 6

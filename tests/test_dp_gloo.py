@@ -71,11 +71,15 @@ def _ragged(batch, seed):
 def _worker_ragged(rank, world, port, q):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(2)
-    from kokoro_ruslan_amd import dp
+    from kokoro_ruslan_amd import dp, spec
     from oracle import kokoro_oracle as O
     dp.init("gloo")
-    d = O.ModelDims(vocab=59, mel=20, hidden=128, heads=2, enc_layers=1, dec_layers=1, enc_ff=96, dec_ff=96, var_filter=32,
-                    var_bins=16, max_len=300)
+    dkw = dict(vocab=59, mel=20, hidden=128, heads=2, enc_layers=1, dec_layers=1, enc_ff=96, dec_ff=96, var_filter=32, var_bins=16, max_len=300)
+    d = O.ModelDims(**dkw)
+    # the engine-side objects of a ragged data-parallel step: ONE exchange carries both collectives (the loss normalisers
+    # between the loss forward and the loss backward, the gradient buckets in backward order over the arena layout)
+    ex = dp.BucketedExchange(spec.ModelDims(**dkw), world, backend="dist")
+    names, shapes, offset, total = spec.arena_layout(spec.ModelDims(**dkw))
     P, Bf, hp = O.init_params(d, 7), O.make_buffers(d), O.StepHyper()
     glob = _ragged(O.synthetic_batch(4, 32, 6, d, seed=21), 5)
     shard = dp.shard_batch(glob, rank, world)
@@ -84,11 +88,19 @@ def _worker_ragged(rank, world, port, q):
     acc = torch.stack([s.detach().double() for s in sums] + [c.double() for c in counts])        # the engine's loss_acc
     local_counts = acc[5:].clone()
     max_dur = shard["phoneme_durations"].max().reshape(1)
-    dp.LossSync(world)(acc, max_dur)                                    # global sums / counts, global max duration
-    total = O.losses_from_sums(sums, list(acc[5:]), hp)[0]              # local sums over GLOBAL counts, no 1/world
-    total.backward()
-    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in Pg.values()])
-    dp.GradSync(world)(flat)
+    assert not ex.capturable                                            # (torch.distributed backend: eager; RCCL: captured)
+    ex.loss_sync(acc, max_dur)                                          # global sums / counts, global max duration
+    total_loss = O.losses_from_sums(sums, list(acc[5:]), hp)[0]         # local sums over GLOBAL counts, no 1/world
+    total_loss.backward()
+    arena = torch.zeros(total)                                          # the gradient arena as the engine lays it out
+    for n, p in Pg.items():
+        if p.grad is not None:
+            arena[offset[n]:offset[n] + p.numel()] = p.grad.reshape(-1)
+    ex.begin_step()
+    for tag in ex.plan:                                                  # bucket by bucket, in the order the backward releases them
+        ex.reduce(arena, tag)
+    assert ex.issued == list(ex.plan)
+    flat = torch.cat([arena[offset[n]:offset[n] + p.numel()] for n, p in Pg.items()])
     if rank == 0:
         Gf, lf, _ = O.grads_of(P, Bf, glob, d, hp)
         ref = torch.cat([g.reshape(-1) for g in Gf.values()])
@@ -212,3 +224,78 @@ def test_bucketed_exchange_two_ranks_equals_one_all_reduce():
     assert same, "bucket by bucket must give exactly the sum of the whole arena"
     assert in_step and diverged_seen, "replicas_in_step must accept equal arenas and flag one differing element"
     assert issued == ["dec1", "dec0", "enc1", "enc0", "tail"]
+
+
+# ---- the backend of the in-step exchange is agreed on collectively (a rank that cannot bind RCCL must not leave the
+# others in a broadcast or with a communicator nobody else joined) -----------------------------------------------------------------
+def _create_worker(rank, world, port, q, scenario):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from kokoro_ruslan_amd import dp, spec, lib as kk
+    dp.init("gloo")
+
+    class FakeLib:                                       # stands in for libkokoro_hip.so's kk_comm_* on a box without GPUs
+        def __init__(self):
+            self.calls, self.world = [], 0
+
+        def kk_comm_load(self, path):
+            return 1 if (scenario == "load_fails_on_rank1" and rank == 1) else 0
+
+        def kk_comm_unique_id(self, buf):
+            self.calls.append("id")
+            return 1 if scenario == "id_fails_on_rank0" else 0
+
+        def kk_comm_world(self):
+            return self.world
+
+        def kk_comm_init(self, r, w, uid):
+            self.calls.append("init")
+            if scenario == "init_fails_on_rank1" and rank == 1:
+                return 1
+            self.world = w
+            return 0
+
+        def kk_comm_destroy(self):
+            self.calls.append("destroy")
+            self.world = 0
+            return 0
+
+        def kk_last_error(self):
+            return b"injected failure"
+    fake = FakeLib()
+    kk.load = lambda: fake
+    dims = spec.ModelDims(hidden=128, heads=2, enc_layers=1, dec_layers=1, enc_ff=96, dec_ff=96, var_filter=32, var_bins=16, mel=20, max_len=300)
+    ex = dp.BucketedExchange.create(dims, rank, world, torch.device("cpu"))
+    # whatever was agreed on must work as a collective on every rank
+    x = torch.ones(4) * (rank + 1)
+    if ex.backend == "dist":
+        dist.all_reduce(x)
+    q.put((rank, ex.backend, list(fake.calls), fake.world, x.tolist()))
+    dp.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scenario,backend", [("all_ok", "rccl"), ("load_fails_on_rank1", "dist"), ("id_fails_on_rank0", "dist"),
+                                              ("init_fails_on_rank1", "dist")])
+def test_exchange_backend_is_agreed_on_by_all_ranks(scenario, backend):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_create_worker, args=(r, 2, port, q, scenario)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [g[1] for g in got] == [backend, backend], got                # never a mix
+    for rank, be, calls, live, x in got:
+        if backend == "rccl":
+            assert "init" in calls and live == 2
+        else:
+            assert live == 0, "no rank may keep a communicator the others never joined"
+            assert x == [3.0] * 4
+        if scenario == "load_fails_on_rank1":
+            assert "init" not in calls, "nobody enters ncclCommInitRank unless everybody will"
+        if scenario == "init_fails_on_rank1" and rank == 0:
+            assert calls[-1] == "destroy"

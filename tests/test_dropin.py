@@ -145,6 +145,51 @@ def test_clip_durations_keeps_the_prefix():
         assert (idx_clip[0, :n] == idx_full[0, :n]).all()               # the expansion is a prefix of the original one
 
 
+def test_clip_durations_differs_from_the_reference_rule_on_purpose():
+    """The reader's own clip (a cache longer than the run's max_seq_length) keeps sum(dur) == T; the reference's precompute-time
+    reconciliation (dataset.py:769-776) keeps every duration >= 1 and may leave sum(dur) > T.  Both pinned, so nobody takes one
+    for the other."""
+    import torch
+    from kokoro.data.cached import clip_durations, reference_reconcile
+    dur = torch.tensor([3, 0, 5, 2, 7, 1])                            # sums to 18
+    assert reference_reconcile(dur, 18).tolist() == [3, 1, 5, 2, 7, 1]       # clamp(min=1) alone: T' = 19 > T
+    assert reference_reconcile(dur, 12).tolist() == [3, 1, 5, 2, 7, 1]       # last = max(1, 1 - 6) = 1: T' = 19 > T = 12
+    assert reference_reconcile(dur, 25).tolist() == [3, 1, 5, 2, 7, 8]       # last += 7
+    assert clip_durations(dur, 12).tolist() == [3, 0, 5, 2, 2, 0] and int(clip_durations(dur, 12).sum()) == 12
+
+
+def test_scan_cache_discards_a_stale_index(tmp_path):
+    """An index written for another FEATURE_CACHE_VERSION (or by the round-2 reader: second-resolution mtimes, no per-file
+    version) is not trusted: every file is re-read, and a file of the wrong version is refused."""
+    import json
+    import pytest
+    import torch
+    from kokoro.data import cached
+    from kokoro_ruslan_amd.synthetic import synthetic_batch
+    d = tmp_path / ".feature_cache"
+    d.mkdir()
+    b = synthetic_batch(1, 40, 5, seed=0)
+    item = {"mel_spec": b["mel_specs"][0].T.contiguous(), "phoneme_indices": b["phoneme_indices"][0], "stress_indices": b["stress_indices"][0],
+            "phoneme_durations": b["phoneme_durations"][0], "stop_token_targets": b["stop_token_targets"][0], "pitch": b["pitches"][0],
+            "energy": b["energies"][0], "text": "x", "audio_file": "u0", "mel_length": 40, "phoneme_length": 5, "_cache_version": 6}
+    torch.save(item, d / "u0.pt")
+    st = (d / "u0.pt").stat()
+    # a round-2 style index vouching for the old file with a wrong length
+    (d / ".kk_index.json").write_text(json.dumps({"version": 7, "entries": [
+        {"name": "u0.pt", "size": st.st_size, "mtime": int(st.st_mtime), "mel_length": 999, "phoneme_length": 5}]}))
+    with pytest.raises(RuntimeError, match="feature cache version 6"):
+        cached.scan_cache(str(d))
+    item["_cache_version"] = 7
+    torch.save(item, d / "u0.pt")
+    assert cached.scan_cache(str(d))[0]["audio_length"] == 40
+    idx = json.loads((d / ".kk_index.json").read_text())
+    assert idx["index_format"] == 2 and idx["entries"][0]["cache_version"] == 7 and "mtime_ns" in idx["entries"][0]
+    idx["version"] = 6                                                 # an index of another schema version
+    idx["entries"][0]["mel_length"] = 123
+    (d / ".kk_index.json").write_text(json.dumps(idx))
+    assert cached.scan_cache(str(d))[0]["audio_length"] == 40
+
+
 def test_cached_dataset_scans_once_and_clips_durations(tmp_path):
     import torch
     from kokoro.data import cached
