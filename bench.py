@@ -296,6 +296,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-shapes", action="store_true", help="skip the 8x1024x128 and dyn16384 measurements after the headline region")
     ap.add_argument("--no-roofline", action="store_true", help="skip the eager event-timed roofline leg (A/B runs)")
+    ap.add_argument("--lib", default="product", help="tools: 'tuning' = the flavour of the library that reads the KK_* A/B switches from "
+                    "the environment (python -m kokoro_ruslan_amd.build --tuning), or the name of a --variant build")
+    ap.add_argument("--set", action="append", default=[], metavar="ATTR=VALUE", help="tools: set an engine attribute (a fusion switch such "
+                    "as attn_bwd_pair=0) for an A/B run; the line records it under config.engine_overrides")
     ap.add_argument("--kernel-table", default="")
     ap.add_argument("--gemm16", default="", help="tuning sweep hook: enable,thr128,thr12864,split_target for the bf16 GEMM core")
     args = ap.parse_args()
@@ -305,6 +309,8 @@ def main():
     from kokoro_ruslan_amd.spec import ModelDims, StepHyper
     from kokoro_ruslan_amd.synthetic import synthetic_batch
 
+    if args.lib != "product":
+        kk.use_library(args.lib)
     if args.gemm16:                    # A/B of the GEMM tile policy: read once when the library loads (no tuning calls in the ABI)
         os.environ["KK_GEMM16_TUNE"] = ",".join(args.gemm16.split(",")[-3:])
     rank, world, local = dp.init()
@@ -316,6 +322,11 @@ def main():
     eng = KokoroEngine(ModelDims(), hp, math_mode=args.math, total_steps=20000, seed=0,
                        storage=args.storage)                           # same seed ⇒ identical replicas
     eng.train_dropout = not args.no_dropout          # reference-faithful: dropout, stochastic depth, SpecAugment on
+    for kv in args.set:
+        name, val = kv.split("=", 1)
+        if not hasattr(eng, name):
+            raise SystemExit(f"--set {kv}: KokoroEngine has no attribute {name}")
+        setattr(eng, name, type(getattr(eng, name))(int(val)) if isinstance(getattr(eng, name), (bool, int)) else float(val))
     force = os.environ.get("KK_DP_FORCE") == "1"       # run the data-parallel code path (1-rank group) on a single GPU
     sync = dp.GradSync(world, force=force)
     eng.dp_loss_scale = sync.loss_scale
@@ -475,7 +486,7 @@ def main():
                       "grad_accumulation": 1,
                       "dropout": ("off (p=0 parity configuration)" if args.no_dropout else
                                   "on: enc 0.15 / dec 0.20 / dec-input 0.15 / variance 0.10, stochastic depth 0.1, SpecAugment (config.py defaults)"),
-                      "hipgraph": not args.no_graph},
+                      "hipgraph": not args.no_graph, "engine_overrides": args.set or None},
            "final_losses": [round(x, 5) for x in losses], "optimizer_steps": stats["attempt"], "skipped": stats["skipped"],
            "roofline": roof,
            "model_tflops": round(frames / dt * fl / (B * T) / 1e12, 2),

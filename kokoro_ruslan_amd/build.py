@@ -34,22 +34,27 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False, tuning: bool = False) -> str:
-    """tuning=True also exports the tools-only tuning hooks (include/kokoro_hip_tuning.h); the product build does not."""
-    os.makedirs(OBJ, exist_ok=True)
+def build(force: bool = False, verbose: bool = False, tuning: bool = False, variant: str = "", defs=()) -> str:
+    """tuning=True builds the TOOLS flavour next to the product library (libkokoro_hip_tuning.so, objects under _obj_tuning): it
+    also exports the tuning hooks of include/kokoro_hip_tuning.h and reads the KK_* A/B switches and timing probes from the
+    environment (kk_common.h: kk_tune_env / KK_DBG), which the product build folds to their defaults.  Tools pick it with
+    `bench.py --lib tuning` / kokoro_ruslan_amd.lib.use_library().
+    variant="name", defs=["-DX=1", ...]: a tools flavour compiled with extra definitions as libkokoro_hip_<name>.so (compile-time
+    A/B of a kernel change on one box: `bench.py --lib <name>`, tools/probes/ab.sh)."""
+    if variant:
+        tuning = True
+    tag = variant or ("tuning" if tuning else "")
+    obj_dir = OBJ + (f"_{tag}" if tag else "")
+    lib_path = LIB.replace(".so", f"_{tag}.so") if tag else LIB
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
-    stamp = os.path.join(OBJ, ".tuning")
-    was = os.path.exists(stamp)
-    if was != tuning:                                   # switching flavours recompiles everything
-        force = True
-        (open(stamp, "w").close() if tuning else os.remove(stamp))
-    flags = FLAGS + (["-DKK_TUNING_HOOKS"] if tuning else [])
+    flags = FLAGS + (["-DKK_TUNING_HOOKS"] if tuning else []) + list(defs)
     headers = [os.path.join(CSRC, "kk_common.h"), os.path.join(os.path.dirname(HERE), "include", "kokoro_hip.h")]
     headers += [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".inc")]      # kernel bodies included by kk_attn.hip
 
     def compile_one(src: str) -> str:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        o = os.path.join(obj_dir, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + headers):
             cmd = [hipcc] + flags + ["-c", s, "-o", o]
             r = subprocess.run(cmd, capture_output=True, text=True)
@@ -61,13 +66,15 @@ def build(force: bool = False, verbose: bool = False, tuning: bool = False) -> s
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    if force or _stale(LIB, objs):
-        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"],
+    if force or _stale(lib_path, objs):
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs + ["-ldl"],
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")
-    return LIB
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, tuning="--tuning" in sys.argv))
+    av = sys.argv[1:]
+    var = av[av.index("--variant") + 1] if "--variant" in av else ""
+    print(build(force="--force" in av, verbose=True, tuning="--tuning" in av, variant=var, defs=[a for a in av if a.startswith("-D")]))

@@ -182,9 +182,13 @@ struct SubInArgs {
     DropArgs d;
 };
 
-// SIB_WAVES waves x 2 rows per workgroup; 8 waves (two per SIMD hide each other's load latency) while the per-wave
-// column-sum slabs fit 64 KB of LDS (H <= 512), fewer above.
-template <typename TN, typename TY, int NV, int SIB_WAVES>
+// SIB_WAVES waves per workgroup, RIF rows IN FLIGHT per wave; 8 waves (two per SIMD hide each other's load latency) while the
+// per-wave column-sum slabs fit 64 KB of LDS (H <= 512), fewer above.
+// The column reductions want few, fat workgroups (one partial row each for kk_partials_reduce), so a wave walks several rows —
+// and a row is one dependent round trip to HBM (loads -> two wave reductions -> stores).  Walking them one after the other
+// made the launch a chain of round trips: 10.4 us for 23.5 MB at 4096 x 512 (2.3 TB/s, profiles/r02h).  RIF = 2: the loads of
+// BOTH rows of a wave are issued before anything is reduced, so the launch is one round trip with twice the bytes in flight.
+template <typename TN, typename TY, int NV, int SIB_WAVES, int RIF>
 __global__ __launch_bounds__(64 * SIB_WAVES) void sublayer_in_bwd_kernel(SubInArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [waves][4][H]: per-wave column sums, no LDS atomics
     const int lane = threadIdx.x & 63, H = a.H;
@@ -204,65 +208,81 @@ __global__ __launch_bounds__(64 * SIB_WAVES) void sublayer_in_bwd_kernel(SubInAr
     const TN *dn = static_cast<const TN *>(a.dn);
     const TY *yy = static_cast<const TY *>(a.y);
     TY *dy = static_cast<TY *>(a.dy);
-    for (int64_t row = (int64_t)blockIdx.x * SIB_WAVES + (threadIdx.x >> 6); row < a.rows; row += (int64_t)gridDim.x * SIB_WAVES) {
-        const float mu = a.mean[row], rs = a.rstd[row], rsf = ffn ? a.rstd_f[row] : 0.f;
-        float4 xh[NV], dg[NV], old[NV], yv[NV];
-        float s1 = 0.f, s2 = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * SIB_WAVES;
+    for (int64_t row0 = (int64_t)blockIdx.x * SIB_WAVES + (threadIdx.x >> 6); row0 < a.rows; row0 += stride * RIF) {
+        float4 xh[RIF][NV], dg[RIF][NV], old[RIF][NV], yv[RIF][NV];
+        float mu[RIF], rs[RIF], rsf[RIF];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {                     // all loads of the row first
-            const int c = lane * 4 + 256 * i;
-            const bool ok = c < H;
-            xh[i] = ok ? ld4(a.x_out + row * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            dg[i] = ok ? ldv4<TN>(dn + row * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            old[i] = (ok && a.accumulate) ? ld4(a.dres + row * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            yv[i] = (ok && ffn) ? ldv4<TY>(yy + row * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int r = 0; r < RIF; ++r) {                    // all loads of all rows in flight first
+            const int64_t row = row0 + r * stride;
+            const bool live = row < a.rows;
+            mu[r] = live ? a.mean[row] : 0.f;
+            rs[r] = live ? a.rstd[row] : 0.f;
+            rsf[r] = (live && ffn) ? a.rstd_f[row] : 0.f;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const float4 d = dg[i];
-            float4 &x = xh[i];
-            x = make_float4((x.x - mu) * rs, (x.y - mu) * rs, (x.z - mu) * rs, (x.w - mu) * rs);
-            if (lane * 4 + 256 * i >= H) x = make_float4(0.f, 0.f, 0.f, 0.f);
-            ag[i].x += d.x * x.x; ag[i].y += d.y * x.y; ag[i].z += d.z * x.z; ag[i].w += d.w * x.w;
-            ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
-            dg[i] = make_float4(d.x * gm[i].x, d.y * gm[i].y, d.z * gm[i].z, d.w * gm[i].w);
-            s1 += dg[i].x + dg[i].y + dg[i].z + dg[i].w;
-            s2 += dg[i].x * x.x + dg[i].y * x.y + dg[i].z * x.z + dg[i].w * x.w;
-        }
-        s1 = wave_sum(s1) * invH;
-        s2 = wave_sum(s2) * invH;
-        const float dp = row_scale(a.d, seed, row);
-        float sk = 0.f;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = lane * 4 + 256 * i;
-            if (c < H) {
-                float g[4] = {old[i].x + rs * (dg[i].x - s1 - xh[i].x * s2), old[i].y + rs * (dg[i].y - s1 - xh[i].y * s2),
-                              old[i].z + rs * (dg[i].z - s1 - xh[i].z * s2), old[i].w + rs * (dg[i].w - s1 - xh[i].w * s2)};
-                st4(a.dres + row * H + c, make_float4(g[0], g[1], g[2], g[3]));
-                float m1[4], m2[4];
-                kk_drop_mul4(seed, a.d.site1, (uint64_t)row * H + c, t1, k1, m1);
-                kk_drop_mul4(seed, a.d.site2, (uint64_t)row * H + c, t2, k2, m2);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) g[e] *= dp * m1[e] * m2[e];
-                if (ffn) {                                  // dz -> RMSNorm backward (second pass below needs the row sum)
-                    const float4 y4 = yv[i];
-                    an[i].x += g[0] * y4.x * rsf; an[i].y += g[1] * y4.y * rsf; an[i].z += g[2] * y4.z * rsf; an[i].w += g[3] * y4.w * rsf;
-                    g[0] *= gn[i].x; g[1] *= gn[i].y; g[2] *= gn[i].z; g[3] *= gn[i].w;
-                    sk += g[0] * y4.x + g[1] * y4.y + g[2] * y4.z + g[3] * y4.w;
-                }
-                dg[i] = make_float4(g[0], g[1], g[2], g[3]);     // reuse: dz (attention) or dz*gain (FFN)
+            for (int i = 0; i < NV; ++i) {
+                const int c = lane * 4 + 256 * i;
+                const bool ok = live && c < H;
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                xh[r][i] = ok ? ld4(a.x_out + row * H + c) : z;
+                dg[r][i] = ok ? ldv4<TN>(dn + row * H + c) : z;
+                old[r][i] = (ok && a.accumulate) ? ld4(a.dres + row * H + c) : z;
+                yv[r][i] = (ok && ffn) ? ldv4<TY>(yy + row * H + c) : z;
             }
         }
-        const float k = ffn ? wave_sum(sk) * invH * rsf * rsf * rsf : 0.f;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = lane * 4 + 256 * i;
-            if (c < H) {
-                float4 o = dg[i];
-                if (ffn) o = make_float4(rsf * o.x - yv[i].x * k, rsf * o.y - yv[i].y * k, rsf * o.z - yv[i].z * k, rsf * o.w - yv[i].w * k);
-                stv4<TY>(dy + row * H + c, o);
-                ac[i].x += o.x; ac[i].y += o.y; ac[i].z += o.z; ac[i].w += o.w;
+        for (int r = 0; r < RIF; ++r) {
+            const int64_t row = row0 + r * stride;
+            if (row >= a.rows) break;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const float4 d = dg[r][i];
+                float4 &x = xh[r][i];
+                x = make_float4((x.x - mu[r]) * rs[r], (x.y - mu[r]) * rs[r], (x.z - mu[r]) * rs[r], (x.w - mu[r]) * rs[r]);
+                if (lane * 4 + 256 * i >= H) x = make_float4(0.f, 0.f, 0.f, 0.f);
+                ag[i].x += d.x * x.x; ag[i].y += d.y * x.y; ag[i].z += d.z * x.z; ag[i].w += d.w * x.w;
+                ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+                dg[r][i] = make_float4(d.x * gm[i].x, d.y * gm[i].y, d.z * gm[i].z, d.w * gm[i].w);
+                s1 += dg[r][i].x + dg[r][i].y + dg[r][i].z + dg[r][i].w;
+                s2 += dg[r][i].x * x.x + dg[r][i].y * x.y + dg[r][i].z * x.z + dg[r][i].w * x.w;
+            }
+            s1 = wave_sum(s1) * invH;
+            s2 = wave_sum(s2) * invH;
+            const float dp = row_scale(a.d, seed, row);
+            float sk = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = lane * 4 + 256 * i;
+                if (c < H) {
+                    const float4 dgi = dg[r][i], xi = xh[r][i], oi = old[r][i];
+                    float g[4] = {oi.x + rs[r] * (dgi.x - s1 - xi.x * s2), oi.y + rs[r] * (dgi.y - s1 - xi.y * s2),
+                                  oi.z + rs[r] * (dgi.z - s1 - xi.z * s2), oi.w + rs[r] * (dgi.w - s1 - xi.w * s2)};
+                    st4(a.dres + row * H + c, make_float4(g[0], g[1], g[2], g[3]));
+                    float m1[4], m2[4];
+                    kk_drop_mul4(seed, a.d.site1, (uint64_t)row * H + c, t1, k1, m1);
+                    kk_drop_mul4(seed, a.d.site2, (uint64_t)row * H + c, t2, k2, m2);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[e] *= dp * m1[e] * m2[e];
+                    if (ffn) {                                  // dz -> RMSNorm backward (second pass below needs the row sum)
+                        const float4 y4 = yv[r][i];
+                        an[i].x += g[0] * y4.x * rsf[r]; an[i].y += g[1] * y4.y * rsf[r]; an[i].z += g[2] * y4.z * rsf[r]; an[i].w += g[3] * y4.w * rsf[r];
+                        g[0] *= gn[i].x; g[1] *= gn[i].y; g[2] *= gn[i].z; g[3] *= gn[i].w;
+                        sk += g[0] * y4.x + g[1] * y4.y + g[2] * y4.z + g[3] * y4.w;
+                    }
+                    dg[r][i] = make_float4(g[0], g[1], g[2], g[3]);     // reuse: dz (attention) or dz*gain (FFN)
+                }
+            }
+            const float k = ffn ? wave_sum(sk) * invH * rsf[r] * rsf[r] * rsf[r] : 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = lane * 4 + 256 * i;
+                if (c < H) {
+                    float4 o = dg[r][i];
+                    if (ffn) o = make_float4(rsf[r] * o.x - yv[r][i].x * k, rsf[r] * o.y - yv[r][i].y * k, rsf[r] * o.z - yv[r][i].z * k, rsf[r] * o.w - yv[r][i].w * k);
+                    stv4<TY>(dy + row * H + c, o);
+                    ac[i].x += o.x; ac[i].y += o.y; ac[i].z += o.z; ac[i].w += o.w;
+                }
             }
         }
     }
@@ -290,11 +310,14 @@ template <typename TN, typename TY>
 void launch_subin(const SubInArgs &a, int blocks, hipStream_t s) {
     const dim3 grid(blocks);
     const int nv = kk_cdiv(a.H, 256);
-#define KK_SIB(NV, WV) hipLaunchKernelGGL((sublayer_in_bwd_kernel<TN, TY, NV, WV>), grid, dim3(64 * WV), (size_t)WV * 4 * a.H * sizeof(float), s, a)
-    if (nv <= 1) KK_SIB(1, 8);
-    else if (nv <= 2) KK_SIB(2, 8);
-    else if (nv <= 4) KK_SIB(4, 4);
-    else KK_SIB(8, 2);
+#define KK_SIB(NV, WV, RIF) hipLaunchKernelGGL((sublayer_in_bwd_kernel<TN, TY, NV, WV, RIF>), grid, dim3(64 * WV), (size_t)WV * 4 * a.H * sizeof(float), s, a)
+    // RIF = 2 (both rows of a wave in flight at once, 213 registers) was measured on one box, interleaved, against RIF = 1:
+    // 4.165 vs 4.145 ms per step — the shorter, burstier launch costs the chains around it more than it saves
+    static const int rif2 = kk_tune_env("KK_SIB_RIF", 1);
+    if (nv <= 1) { if (rif2 == 2) KK_SIB(1, 8, 2); else KK_SIB(1, 8, 1); }
+    else if (nv <= 2) { if (rif2 == 2) KK_SIB(2, 8, 2); else KK_SIB(2, 8, 1); }
+    else if (nv <= 4) KK_SIB(4, 4, 1);
+    else KK_SIB(8, 2, 1);
 #undef KK_SIB
 }
 

@@ -35,6 +35,7 @@ struct G16Args {
     int64_t lda, ldb, ldc, ldr, res_mod;
     int k_per_split, atomic, splits, split_major;
     int tiles_m, tiles_n, xcd_swizzle;
+    int m_fast;                                                 // tile order inside an XCD's run: 0 = n fastest, 1 = m fastest (see gemm16_body)
     uint32_t a_bytes, b_bytes;
     // EPI == 1 (GLU backward epilogue): C is not written; see gemm16_kernel
     const __bf16 *glu_h;
@@ -197,7 +198,12 @@ __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char
             tid_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + in;
         }
     }
-    const int m0 = (tid_lin / a.tiles_n) * BM, n0 = (tid_lin % a.tiles_n) * BN;
+    // An XCD's contiguous run of tiles covers a few rows of the tile grid in the FAST direction completely: it streams the whole
+    // operand of that direction through its private L2 (all eight L2s do) and a slice of the other one.  n fastest: B re-read 8x,
+    // A once; m fastest: the other way round.  The grouped weight gradients pick the direction that replicates the SMALLER
+    // operand (linear2's dW is 512 x 1536: m fastest re-reads dY 8x = 32 MB instead of the gated activations 8x = 100 MB).
+    const int m0 = (a.m_fast ? tid_lin % a.tiles_m : tid_lin / a.tiles_n) * BM;
+    const int n0 = (a.m_fast ? tid_lin / a.tiles_m : tid_lin % a.tiles_n) * BN;
     const int kbeg = ksl * a.k_per_split;
     const int kend = min(a.K, kbeg + a.k_per_split);
     const int nk = (kend - kbeg + BK - 1) / BK, kt0 = kbeg / BK;
@@ -665,6 +671,7 @@ struct G16EnvInit {
 } g16_env_init;
 int g16_group_tile = kk_tune_env("KK_GROUP_TILE", 1);                                         // grouped launches: 0 = 64x64, 1 = 128x64 (default: +1 % on the step), 2 = 128x128 tiles
 int g16_group_waves = kk_tune_env("KK_GROUP_WAVES", 8);   // 8-wave workgroups on the 128-row tiles (4: the old form)
+int g16_group_mfast = kk_tune_env("KK_GROUP_MFAST", 1);  // grouped launches: sweep direction by operand size (0: always n fastest)
 int g16_group_split = 0;                                        // grouped launches: 0 = by the split target, n = n k-slices
 
 }  // namespace
@@ -855,6 +862,7 @@ int kk_gemm16_wgrad_group(const KkWgradDesc *d, int n, int split_k, int overwrit
         a.lda = d[i].lddy; a.ldb = d[i].ldx; a.ldc = d[i].lddw;
         a.k_per_split = kps; a.splits = sp; a.atomic = sp > 1 ? 1 : 0;
         a.tiles_m = cd(M, BM); a.tiles_n = cd(N, BN); a.xcd_swizzle = xcd_swizzle;
+        a.m_fast = (g16_group_mfast && xcd_swizzle && M < N) ? 1 : 0;
         a.a_bytes = (uint32_t)(((K - 1) * a.lda + M) * 2);
         a.b_bytes = (uint32_t)(((K - 1) * a.ldb + N) * 2);
         g.start[i + 1] = g.start[i] + a.tiles_m * a.tiles_n * sp;

@@ -630,9 +630,10 @@ class KokoroEngine:
         # the projection output lives only until the tail two launches later: in the decoder's bf16 mode it is stored like every
         # other GEMM result there (what autocast gives the reference's nn.Linear); the text encoder keeps fp32 (its persistent
         # launch hands the tile over in fp32, and the per-kernel path must match it)
+        Wo = self._W(prefix + ".w_o.weight")
         p16 = self.attn_proj_bf16 and i16 and key.startswith("dec")
         proj = self._buf("tmp.attn_proj16" if p16 else "tmp.attn_proj", Nq, H, dtype=dt if p16 else torch.float32)
-        self._linear(ctx, self._W(prefix + ".w_o.weight"), P[prefix + ".w_o.bias"], proj)
+        self._linear(ctx, Wo, P[prefix + ".w_o.bias"], proj)
         return self._sublayer_tail(proj, x_res, x_out, Sq, site, p, dpr, 0.0, None, None, next_ln)   # (p = 0: masks are all ones)
 
     def _cross_kv(self, layer, Nk, dt, which=""):

@@ -234,6 +234,15 @@ def profile_stop():
     return [(n, a, s.elapsed_time(e)) for n, a, s, e in rec]
 
 
+def use_library(flavour: str) -> None:
+    """Tools only: select the library flavour before the first call — "tuning" = libkokoro_hip_tuning.so (python -m
+    kokoro_ruslan_amd.build --tuning: A/B switches and timing probes readable from the environment), "product" = the default."""
+    global LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("use_library() must be called before the library is loaded")
+    LIB_PATH = os.path.join(HERE, "libkokoro_hip.so" if flavour == "product" else f"libkokoro_hip_{flavour}.so")
+
+
 def load() -> C.CDLL:
     """Load the shared library (once).  Raises RuntimeError if it has not been built."""
     global _lib

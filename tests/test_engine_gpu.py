@@ -323,12 +323,12 @@ def test_global_loss_normalisers_two_shards_on_one_gpu(eng_mod, golden_dir):
         e.loss_sync = fake_all_reduce
         e.train_step_graphed(_cuda(glob))
     # ... one whose collectives go through the step's own communicator is captured with the step: replay == eager
-    e2 = _engine(eng_mod, d, P)
+    e2 = _engine(eng_mod, d, P, gradient_accumulation_steps=1)
     e2.loss_sync, e2.dp_loss_scale = FakeAllReduce(True), 1.0
     sh = _cuda(shards[0])
     for _ in range(3):                                  # eager, capture, replay
         e2.train_step_graphed(sh)
-    e3 = _engine(eng_mod, d, P)
+    e3 = _engine(eng_mod, d, P, gradient_accumulation_steps=1)
     e3.loss_sync, e3.dp_loss_scale = FakeAllReduce(False), 1.0
     for _ in range(3):
         e3.train_step(sh)
@@ -791,6 +791,31 @@ def test_in_graph_bucket_exchange_over_rccl_one_rank(eng_mod, golden_dir):
     assert torch.equal(x, torch.arange(1000, dtype=torch.float32, device="cuda")) and torch.equal(z, x)
     with pytest.raises(RuntimeError, match="dtype"):
         kk.call("kk_comm_reduce_bucket", x, 1000, 7)
+    # the step's second collective through the same communicator: the loss normalisers of ragged shards (kk_comm_loss_sync: fp64 SUM
+    # + int64 MAX as one RCCL group on the step's stream).  One rank: identity — so a graph-replayed step with the exchange AND the
+    # global normalisers on (what kokoro-train runs on 8 GPUs) must train exactly like the plain engine.
+    acc = torch.arange(12, dtype=torch.float64, device="cuda") * 1.5
+    md = torch.tensor([41], dtype=torch.int64, device="cuda")
+    comm.payload = "f32"
+    assert comm.capturable
+    comm.loss_sync(acc, md)
+    torch.cuda.synchronize()
+    assert torch.equal(acc, torch.arange(12, dtype=torch.float64, device="cuda") * 1.5) and int(md) == 41
+
+    def run_ragged(graphed):
+        e = _engine(eng_mod, d, P, math_mode="bf16", gradient_accumulation_steps=1)
+        e.train_dropout = True
+        e.dp_comm, e.loss_sync, e.dp_loss_scale = comm, comm, 1.0
+        for it in range(4):
+            (e.train_step_auto if graphed else e.train_step)(batches[it % 2])
+        torch.cuda.synchronize()
+        assert e.opt_stats()["attempt"] == 4 and e.opt_stats()["skipped"] == 0
+        if graphed:
+            assert len(e._graphs) == 1 and any(k[-1] for ent in e._graphs.values() for k in ent["fb"]), "the ragged step must replay from a graph"
+        return e.arena.p.clone()
+    got_e, got_g = run_ragged(False), run_ragged(True)
+    assert float((got_e - ref1).abs().max()) <= 2e-5 * float(ref1.abs().max())
+    assert float((got_g - ref1).abs().max()) <= 2e-5 * float(ref1.abs().max())
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -1285,3 +1285,4 @@ def test_attention_backward_pair_launch(kk, B, h, Sq, Sk, causal, rope, p, maske
             0.125, seed, 5, p, 1, 1, None, None)
     torch.cuda.synchronize()
     assert torch.equal(dq_a, dq_b) and torch.equal(dkv_a, dkv_b), "plain gradients: pair launch == two launches"
+
