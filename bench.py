@@ -228,7 +228,7 @@ def ragged_workload(max_frames=16384, n_utts=600, seed=7):
     return out
 
 
-def extra_shapes(eng, steps_1024=30, passes=2, n_batches=24):
+def extra_shapes(eng, steps_1024=30, passes=3, n_batches=24):
     """The two other shapes the verdict asks the driver-run record to carry, measured in this process after the headline region:
     8x1024x128 (BASELINE configs[3]'s per-GPU shape: the north-star shape) replayed from hipGraphs, and configs[2] (dynamic
     batching, B*T <= 16384) over resident ragged batches through train_step_auto (graphs from the second sight of a shape).
@@ -252,10 +252,9 @@ def extra_shapes(eng, steps_1024=30, passes=2, n_batches=24):
                 "value": round(8 * 1024 / ms * 1e3, 1), "unit": "mel-frames/s", "steps": steps_1024, "repeats_ms": [round(x * 1e3, 3) for x in reps],
                 "model_tflops": round(fl / ms / 1e9, 2), "model_mfma_frac": round(fl / ms / 1e9 / PEAK_BF16_TFLOPS, 4)})
     batches = ragged_workload()[:n_batches]
-    for b in batches:                                  # first sight: eager (sizes the workspace); second: capture
-        eng.train_step_auto(b)
-    for b in batches:
-        eng.train_step_auto(b)
+    for _ in range(3):                                 # a shape's 1st sight runs eagerly, the 2nd is train_step_graphed's own eager pass
+        for b in batches:                              # (it sizes the workspace), the 3rd captures: the 4th pass replays graphs
+            eng.train_step_auto(b)
     reps = []
     for _ in range(passes):
         torch.cuda.synchronize()
@@ -290,6 +289,9 @@ def main():
     ap.add_argument("--math", choices=["bf16", "f32"], default="bf16")
     ap.add_argument("--storage", choices=["auto", "f32", "bf16", "bf16-dec"], default="auto",
                     help="GEMM/attention operand storage in HBM (auto: bf16 in the bf16 mode)")
+    ap.add_argument("--workload", choices=["fixed", "dyn16384"], default="fixed", help="dyn16384: BASELINE configs[2] (dynamic batching, "
+                    "B*T <= 16384, resident ragged batches) as the timed workload of a 1-GPU run instead of the fixed --batch x --frames shape "
+                    "(profiling / A-B runs; the default line carries it under extra_shapes)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="also time the CPU baseline at 8x1024x128 (minutes of CPU time)")
     ap.add_argument("--no-dropout", action="store_true", help="parity configuration (p = 0 everywhere)")
@@ -342,6 +344,18 @@ def main():
         dp_mode += f" ({eng.dp_comm.backend}, {eng.dp_comm.payload} payload, {len(eng.dp_comm.plan)} buckets)"
         use_sync = False
     step = (lambda: eng.train_step(batch)) if args.no_graph else (lambda: eng.train_step_graphed(batch, sync if use_sync else None))
+    dyn = None
+    if args.workload == "dyn16384":
+        if world != 1:
+            raise SystemExit("--workload dyn16384 is a 1-GPU measurement")
+        dyn = {"batches": ragged_workload()[:24], "i": 0}
+
+        def step():   # noqa: F811
+            b = dyn["batches"][dyn["i"] % len(dyn["batches"])]
+            dyn["i"] += 1
+            (eng.train_step if args.no_graph else eng.train_step_auto)(b)
+        args.warmup = max(args.warmup, 3 * len(dyn["batches"]))        # eager, eager (graphed's own), capture: then replays
+        args.steps = max(len(dyn["batches"]), args.steps // len(dyn["batches"]) * len(dyn["batches"]))     # whole passes
     if args.no_graph and world > 1:
         def step():   # noqa: F811
             eng.zero_grad()
@@ -410,7 +424,7 @@ def main():
         raise RuntimeError("a group barrier of the fused encoder launch timed out during the timed region: the number is void")
 
     roof, table = None, {}
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and dyn is None:
         # Roofline leg: the same step, eager, every launch bracketed by events on the launch stream.
         kk.profile_start()
         for _ in range(2):
@@ -454,7 +468,7 @@ def main():
                 srows = sorted(shapes.items(), key=lambda kv: -kv[1]["ms"])
                 json.dump({"total_ms_2_steps": tot, "kernels": {k: v for k, v in rows}, "shapes": {k: v for k, v in srows}}, f, indent=1)
     extra = None
-    if rank == 0 and world == 1 and not args.no_extra_shapes and not args.no_graph and args.math == "bf16":
+    if rank == 0 and world == 1 and not args.no_extra_shapes and not args.no_graph and args.math == "bf16" and dyn is None:
         extra = extra_shapes(eng)
         if eng.encoder_stack_error():
             raise RuntimeError("a group barrier of the fused encoder launch timed out during the extra shapes")
@@ -464,6 +478,12 @@ def main():
         return
     frames = world * B * T * args.steps
     fl = train_flops(B, T, P)
+    if dyn is not None:                                  # valid frames and algorithmic FLOPs of the passes that were timed
+        nb, passes = len(dyn["batches"]), args.steps // len(dyn["batches"])
+        frames = passes * sum(int(b["mel_lengths"].sum()) for b in dyn["batches"])
+        fl_pass = sum(train_flops(b["mel_specs"].shape[0], b["mel_specs"].shape[1], b["phoneme_indices"].shape[1]) for b in dyn["batches"])
+        B, T = 1, frames // args.steps                   # (so that model_tflops below = FLOPs of the passes / time)
+        fl = fl_pass * passes / args.steps
     ms_regions = [round(x / args.steps * 1e3, 3) for x in regions]
     out = {"metric": "mel-frames/sec (full train step)", "value": round(frames / dt, 1), "unit": "mel-frames/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -472,7 +492,9 @@ def main():
                              "min": min(ms_regions), "max": max(ms_regions)},
            "storage": eng.storage,
            "per_gpu": round(frames / dt / world, 1),
-           "config": {"workload": f"kokoro acoustic-model train step, {B}x{T} mel frames x {P} phonemes per GPU "
+           "config": {"workload": ("dyn16384: BASELINE configs[2], dynamic batching B*T <= 16384 over 24 resident ragged batches, value = VALID mel frames/s, "
+                                   "49.4M params, fwd+loss+bwd+clip+AdamW+EMA every step") if dyn is not None else
+                                  f"kokoro acoustic-model train step, {B}x{T} mel frames x {P} phonemes per GPU "
                                   f"({'BASELINE configs[1]' if (B, T, P) == (8, 512, 64) else 'configs[3] per-GPU shape' if (B, T, P) == (8, 1024, 128) else 'non-baseline shape'}), "
                                   f"49.4M params, fwd+loss+bwd+clip+AdamW+EMA every step",
                       "global_batch": world * B, "frames": T, "phonemes": P, "parallelism": f"dp{world}",

@@ -217,6 +217,7 @@ class KokoroEngine:
         # otherwise (and with KK_ENC_FUSED=0) the per-kernel sequence.  _enc_sync: its group-barrier words (word 0 != 0
         # = a barrier timed out; encoder_stack_error() reads it).
         self.enc_fused = True
+        self.enc_fused_max_batch = 8                # one item per workgroup group (see _encoder_stack_ok)
         self.zero_late = True                       # gradient zero-fill after the decoder head's first launches
         self.enc_placement = 0                      # (tests force the groups across XCDs with 1)
         self._enc_sync = torch.zeros(512, dtype=torch.int32, device=self.device)
@@ -790,8 +791,12 @@ class KokoroEngine:
 
     # ------------------------------------------------------------------ text encoder: all layers in one launch
     def _encoder_stack_ok(self, B: int, Pn: int) -> bool:
+        """The persistent launch carries batch item b on workgroup group b % 8: up to 8 items it is one pass (265-290 us against 545 us
+        as 48 launches at 8 x 64 phonemes); a group walks further items one after the other, and from two passes on the 48 launches —
+        whose kernels grow with the batch instead — are level or faster (dynamic batching, B up to 32: 9.50 against 9.69 ms per
+        step on the configs[2] workload), so larger batches take the per-kernel sequence."""
         d = self.dims
-        return bool(self.enc_fused and self.enc_dt == torch.bfloat16 and self.use_shadow and self.math == kk.KK_MATH_BF16 and
+        return bool(self.enc_fused and B <= self.enc_fused_max_batch and self.enc_dt == torch.bfloat16 and self.use_shadow and self.math == kk.KK_MATH_BF16 and
                     kk.load().kk_encoder_stack_supported(B, Pn, d.hidden, d.enc_ff, d.heads, d.enc_layers))
 
     def _encoder_stack_fwd(self, x0, B, Pn, text_mask, p_enc):
