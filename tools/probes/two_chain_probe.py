@@ -2,8 +2,8 @@
 
 Two engines (own arenas, workspaces, streams), each with half of the 8x512 batch, replay their captured forward+backward
 concurrently from two host threads; compared with one engine replaying the whole batch.  forward+backward only (the
-optimizer pass is HBM-bound and would run once either way).  KK_SEGMENTED=1 replays each step as a program of
-single-stream graphs (low host cost); GPU_MAX_HW_QUEUES decides how many streams get their own hardware queue."""
+optimizer pass is HBM-bound and would run once either way).  GPU_MAX_HW_QUEUES decides how many streams get their own hardware queue.
+(Round 2 result: 5.6-7.4 ms for the two half-batch chains against 4.46 ms for one chain of the whole batch.)"""
 import os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
