@@ -1419,6 +1419,13 @@ static int attn_dbg() {                  // timing probes of tools/probes (tools
     return v;
 }
 static bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+// The second-generation BACKWARD kernels also take sequences of ONE 64-row tile (33..64 queries and keys: the text encoder): wave
+// group 1 then has no tile and only joins the barriers and the merge, but the DMA prologue, the LDS-transposed epilogues and the
+// one-launch form (kk_attn_bwd) beat the first generation's 13 + 17 us there (KK_ATTN_V2_SMALL=0 in the tools build: old dispatch)
+static bool attn_v2_small(int Sq, int Sk) {
+    static const int v = kk_tune_env("KK_ATTN_V2_SMALL", 1);
+    return v != 0 && Sq > 32 && Sk > 32;
+}
 static int attn_pair() {                 // KK_ATTN_PAIR=0: kk_attn_bwd issues the dQ and the dK/dV kernel as two launches
     static const int v = kk_tune_env("KK_ATTN_PAIR", 1);
     return v;
@@ -1552,7 +1559,7 @@ extern "C" int kk_attn_bwd_dq(const float *Q, const float *K, const float *V, co
     }
     dim3 grid(kk_cdiv(Sq, 128), B * heads);
     const int G = (Sk > 64 && g_attn_groups == 2) ? 2 : 1;
-    if (io_bf16 && (attn_v2_mask() & 2) && G == 2 && Sk <= 4096 && al16(Q) && al16(K) && al16(V) && al16(dO) && al16(dQ) && (!O || al16(O)) &&
+    if (io_bf16 && (attn_v2_mask() & 2) && (G == 2 || attn_v2_small(Sq, Sk)) && g_attn_groups == 2 && Sk <= 4096 && al16(Q) && al16(K) && al16(V) && al16(dO) && al16(dQ) && (!O || al16(O)) &&
         (!hn || (al16(hn->raw) && (!hn->rope || (al16(hn->cos_t) && al16(hn->sin_t))))) && (int64_t)Sk * std::max(ldk, ldv) * 2 < (1ll << 31)) {
         int rc2 = launch_attn(attn_bwd_dq2_kernel, grid, 2, (size_t)2 * 3 * 16384 + 512 + 3 * 16384, (hipStream_t)stream, a);
         if (rc2) return rc2;
@@ -1585,7 +1592,7 @@ extern "C" int kk_attn_bwd_dkv(const float *Q, const float *K, const float *V, c
     }
     dim3 grid(kk_cdiv(Sk, 128), B * heads);
     const int G = (Sq > 64 && g_attn_groups == 2) ? 2 : 1;          // one query tile: nothing to split
-    if (io_bf16 && (attn_v2_mask() & 4) && G == 2 && al16(Q) && al16(K) && al16(V) && al16(dO) && al16(dK) && al16(dV) &&
+    if (io_bf16 && (attn_v2_mask() & 4) && (G == 2 || attn_v2_small(Sq, Sk)) && g_attn_groups == 2 && al16(Q) && al16(K) && al16(V) && al16(dO) && al16(dK) && al16(dV) &&
         (!hn || (al16(hn[0].raw) && al16(hn[1].raw) && !hn[1].rope && (!hn[0].rope || (al16(hn[0].cos_t) && al16(hn[0].sin_t))))) &&
         (int64_t)Sq * std::max(ldq, lddo) * 2 < (1ll << 31)) {
         int rc2 = launch_attn(attn_bwd_dkv2_kernel, grid, 2, (size_t)2 * 3 * (16384 + 512) + 3 * 16384, (hipStream_t)stream, a);
@@ -1611,7 +1618,8 @@ extern "C" int kk_attn_bwd(const float *Q, const float *K, const float *V, const
     KK_REQUIRE(Delta != nullptr, "kk_attn_bwd: Delta is an input of this call");
     KK_REQUIRE((hn_q == nullptr) == (hn_kv == nullptr), "kk_attn_bwd: head-norm epilogues for both kernels or for neither");
     const int G = (Sk > 64 && Sq > 64 && g_attn_groups == 2) ? 2 : 1;
-    const bool pair = io_bf16 && math == KK_MATH_BF16 && (attn_v2_mask() & 6) == 6 && attn_pair() && G == 2 && Sk <= 4096 &&
+    const bool pair = io_bf16 && math == KK_MATH_BF16 && (attn_v2_mask() & 6) == 6 && attn_pair() && (G == 2 || attn_v2_small(Sq, Sk)) &&
+                      g_attn_groups == 2 && Sk <= 4096 &&
                       kk_cdiv(Sq, 128) == kk_cdiv(Sk, 128) && al16(Q) && al16(K) && al16(V) && al16(dO) && al16(dQ) && al16(dK) && al16(dV) &&
                       (!hn_q || (al16(hn_q->raw) && (!hn_q->rope || (al16(hn_q->cos_t) && al16(hn_q->sin_t))))) &&
                       (!hn_kv || (al16(hn_kv[0].raw) && al16(hn_kv[1].raw) && !hn_kv[1].rope &&

@@ -754,11 +754,12 @@ int kk_gemm16_launch(int ta, int tb, int64_t M, int64_t N, int64_t K, float alph
 }
 
 // dX[M, N] = dY[M, K] . W[K, N] (bf16 everywhere) with Delta[b, head, q] = sum_d dX * O as the epilogue: the dgrad of an attention
-// output projection on the eight-wave 128x64 tile (a tile's 64 columns = one head).  `supported` mirrors kk_gemm16_launch's
-// tile choice: only launches that take that tile anyway get the epilogue.
+// output projection on the eight-wave 128x64 tile (a tile's 64 columns = one head).  `supported`: the shapes the epilogue is written
+// for.  The decoder's 4096-row launches take that tile anyway; the text encoder's 512-row ones (32 tiles, a 64x64 launch otherwise)
+// take it FOR the epilogue: Delta is what lets the attention backward run as one launch (kk_attn_bwd).
 bool kk_gemm16_dgrad_delta_supported(int64_t M, int64_t N, int64_t K) {
     auto cd = [](int64_t x, int64_t y) { return (int)((x + y - 1) / y); };
-    return g16_w8 != 0 && N % 64 == 0 && K % BK == 0 && cd(M, 128) * cd(N, 128) < g16_thr128 && cd(M, 128) * cd(N, 64) >= g16_thr12864;
+    return g16_w8 != 0 && M >= 1 && N % 64 == 0 && K % BK == 0 && cd(M, 128) * cd(N, 128) < g16_thr128;
 }
 int kk_gemm16_dgrad_delta(int64_t M, int64_t N, int64_t K, const void *dy, int64_t lddy, const void *W, int64_t ldw, void *dx,
                           int64_t lddx, const void *O, int64_t ldo, float *delta, int S, int heads, int xcd_swizzle, hipStream_t s) {

@@ -198,6 +198,7 @@ class KokoroEngine:
         # attention backward as ONE launch (kk_attn_bwd: the dQ and the dK/dV kernel as the two halves of a grid), Delta from the
         # epilogue of the w_o dgrad GEMM (kk_gemm_dgrad_delta) — bf16 storage, shapes that take the eight-wave GEMM tile
         self.attn_bwd_pair = True
+        self.attn_pair_min_seq = 32                # (one-tile sequences included: the text encoder's 33..64 phonemes; 64 = the round-2 dispatch)
         self.attn_proj_bf16 = True                 # decoder w_o output stored as bf16 (bf16 mode)
         # The zero-fill at the start of an accumulation cycle skips what the cycle's first grouped weight-gradient launches
         # overwrite (89 % of the arena at default dims; the fill runs beside the latency-bound encoder launch: 20 us of the step).
@@ -704,7 +705,7 @@ class KokoroEngine:
         # Delta = rowsum(dctx * ctx): from the epilogue of this GEMM when the pair launch below takes it as an input, else computed
         # by the dQ kernel from fragments it holds anyway (and read by the dK/dV kernel launched after it)
         pair = bool(self.attn_bwd_pair and self.fuse_headnorm_bwd and i16 and _b16(d_out) and _b16(Wo) and (xkv is None or d_xkv is not None)
-                    and Sq > 64 and Sk > 64 and kk.load().kk_gemm_dgrad_delta_supported(Nq, H, H))
+                    and min(Sq, Sk) > self.attn_pair_min_seq and kk.load().kk_gemm_dgrad_delta_supported(Nq, H, H))
         if pair:
             kk.call("kk_gemm_dgrad_delta", Nq, H, H, d_out, d_out.stride(0), Wo, Wo.shape[1], dctx, dctx.stride(0), ctx, ctx.stride(0),
                     delta, Sq, h)

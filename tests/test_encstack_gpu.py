@@ -64,6 +64,8 @@ def _rel(a, b):
 def test_fused_encoder_matches_the_per_kernel_sequence(mods, B, T, P, dropout):
     _, _, synthetic = mods
     e = _engine(mods)
+    assert e._encoder_stack_ok(B, P) == (B <= 8), "the engine takes the fused launch for up to 8 items (one per workgroup group)"
+    e.enc_fused_max_batch = 64                           # (the launch itself serves any batch: a group walks its items in turn)
     assert e._encoder_stack_ok(B, P), "the shape must be served by the fused launch"
     e.train_dropout = dropout
     batch = {k: v.cuda() for k, v in synthetic.synthetic_batch(B, T, P, seed=5, ragged=B in (3, 5, 16)).items()}     # ragged: padded keys

@@ -616,9 +616,10 @@ def test_bench_config_bf16_graph_replay_tracks_fp32_and_oracle(eng_mod):
 
 
 def test_bench_config_takes_the_pair_launch_and_it_changes_nothing(eng_mod):
-    """At the bench shape the decoder's 12 attention backwards are kk_gemm_dgrad_delta + ONE kk_attn_bwd launch each (the text
-    encoder's six, one key tile, keep the two first-generation launches), and the step computes what the two-launch form
-    computes: same losses, gradients equal to the rounding of Delta's summation order."""
+    """At the bench shape every attention backward — the decoder's 12 and, since round 3, the text encoder's six (one 64-row tile:
+    wave group 1 of the second-generation kernels idles) — is kk_gemm_dgrad_delta + ONE kk_attn_bwd launch, and the step computes
+    what the two-launch form computes: same losses, gradients equal to the rounding of Delta's summation order.  With
+    attn_pair_min_seq = 64 (the round-2 dispatch) the encoder keeps two launches."""
     from kokoro_ruslan_amd import lib as kk
     from kokoro_ruslan_amd.synthetic import synthetic_batch
     d = O.ModelDims()
@@ -631,8 +632,16 @@ def test_bench_config_takes_the_pair_launch_and_it_changes_nothing(eng_mod):
     l_pair = e.forward_backward(b)["losses"].clone()
     names = [r[0] for r in kk.profile_stop()]
     g_pair = e.arena.g.clone()
-    assert names.count("kk_attn_bwd") == 2 * d.dec_layers and names.count("kk_gemm_dgrad_delta") == 2 * d.dec_layers
-    assert names.count("kk_attn_bwd_dq") == d.enc_layers and names.count("kk_attn_bwd_dkv") == d.enc_layers
+    n_attn = 2 * d.dec_layers + d.enc_layers
+    assert names.count("kk_attn_bwd") == n_attn and names.count("kk_gemm_dgrad_delta") == n_attn
+    assert "kk_attn_bwd_dkv" not in names and "kk_attn_bwd_dq" not in names
+    e.attn_pair_min_seq = 64                                           # the round-2 dispatch: the encoder keeps two launches
+    e.zero_grad()
+    kk.profile_start()
+    e.forward_backward(b)
+    names64 = [r[0] for r in kk.profile_stop()]
+    assert names64.count("kk_attn_bwd") == 2 * d.dec_layers and names64.count("kk_attn_bwd_dkv") == d.enc_layers
+    e.attn_pair_min_seq = 32
     e.attn_bwd_pair = False
     e.zero_grad()
     kk.profile_start()

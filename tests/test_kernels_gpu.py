@@ -671,7 +671,8 @@ def _r16(t):
 BF = (2e-2, 1e-2)   # (atol, rtol): one bf16 rounding (2^-8 relative) of O(1) outputs, with slack for re-associated sums
 
 
-@pytest.mark.parametrize("B,h,Sq,Sk,causal,masked,strided", [(2, 2, 64, 64, 0, 1, 0), (1, 2, 200, 200, 1, 0, 1),
+@pytest.mark.parametrize("B,h,Sq,Sk,causal,masked,strided", [(2, 2, 64, 64, 0, 1, 0), (8, 8, 64, 64, 0, 1, 1), (3, 2, 47, 47, 0, 1, 1), (2, 2, 33, 64, 1, 0, 0),
+                                                              (1, 2, 200, 200, 1, 0, 1),
                                                               (2, 1, 37, 150, 0, 1, 0), (1, 8, 300, 300, 1, 0, 1),
                                                               (1, 2, 1100, 1100, 1, 1, 1), (1, 2, 777, 1030, 0, 1, 0)])
 def test_attention_bf16_storage(kk, B, h, Sq, Sk, causal, masked, strided):
@@ -1199,14 +1200,14 @@ def test_attention_backward_headnorm_epilogue(kk, B, h, Sq, Sk, causal, rope, bf
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,S,h,K", [(8, 512, 8, 512), (4, 1024, 8, 512), (3, 700, 8, 192), (16, 512, 4, 256)])
+@pytest.mark.parametrize("B,S,h,K", [(8, 512, 8, 512), (4, 1024, 8, 512), (3, 700, 8, 192), (16, 512, 4, 256), (8, 64, 8, 512), (5, 41, 8, 512)])
 def test_gemm_dgrad_delta_epilogue(kk, B, S, h, K):
     """kk_gemm_dgrad_delta == kk_gemm (dgrad, bf16 result: bit-identical) + kk_attn_delta on that result (fp32 row sums of
     the same rounded products, summed in a different order)."""
     g = torch.Generator().manual_seed(B * S + K)
     M, N = B * S, h * 64
     assert kk.load().kk_gemm_dgrad_delta_supported(M, N, K) == 1
-    assert kk.load().kk_gemm_dgrad_delta_supported(512, N, K) == 0, "the encoder's 512-row GEMMs stay on 64x64 tiles"
+    assert kk.load().kk_gemm_dgrad_delta_supported(512, N, K) == 1, "the encoder's 512-row output projections take the tile for the epilogue"
     dy = dev(torch.randn(M, K, generator=g)).bfloat16()
     W = dev(torch.randn(K, N, generator=g) / math.sqrt(K)).bfloat16()
     o = dev(torch.randn(M, N, generator=g)).bfloat16()
@@ -1225,7 +1226,8 @@ def test_gemm_dgrad_delta_epilogue(kk, B, S, h, K):
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,h,Sq,Sk,causal,rope,p,masked", [(1, 8, 512, 512, 1, 1, 0.1, 0), (2, 4, 512, 512, 0, 0, 0.2, 1), (1, 2, 1000, 1000, 1, 1, 0.2, 0),
                                                             (1, 2, 900, 1000, 0, 1, 0.1, 1), (2, 2, 300, 384, 0, 0, 0.0, 0), (2, 2, 200, 200, 1, 1, 0.0, 0),
-                                                            (1, 2, 130, 400, 0, 0, 0.1, 0)])
+                                                            (1, 2, 130, 400, 0, 0, 0.1, 0), (8, 8, 64, 64, 0, 1, 0.15, 1), (3, 4, 41, 41, 0, 1, 0.15, 1),
+                                                            (2, 2, 64, 50, 0, 0, 0.0, 0)])
 def test_attention_backward_pair_launch(kk, B, h, Sq, Sk, causal, rope, p, masked):
     """kk_attn_bwd (dQ | dK, dV as the two halves of one grid, Delta an input) == kk_attn_bwd_dq + kk_attn_bwd_dkv given the
     same Delta: bit-identical gradients and gain-gradient partial rows (same code, only the launch differs).  The last case
