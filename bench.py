@@ -113,6 +113,10 @@ def kernel_table(records, math_bf16: bool):
             off = 1 if name == "kk_attn_bwd_dq" else 0       # (..., causal, scale, site, p_drop, math, io_bf16[, ldo])
             causal = int(sc[-6 - off])
             mm = {"kk_attn_fwd": 2, "kk_attn_bwd_dq": 1, "kk_attn_bwd_dkv": 3}[name]   # ALGORITHMIC matmuls of Sq x Sk x 64 (dQ | dV, dP, dK)
+            v2 = int(sc[-1 - off]) and Sk > (64 if name == "kk_attn_fwd" else 32)       # (mirrors the dispatch in kk_attn.hip)
+            key = {"kk_attn_fwd": "attn_fwd2_kernel (flash forward, DMA-staged)" if v2 else "attn_fwd_kernel (flash forward, first generation)",
+                   "kk_attn_bwd_dq": "attn_bwd_dq2_kernel (dQ)" if v2 else "attn_bwd_dq_kernel (dQ, first generation)",
+                   "kk_attn_bwd_dkv": "attn_bwd_dkv2_kernel (dK, dV)" if v2 else "attn_bwd_dkv_kernel (dK, dV, first generation)"}[name]
             flops = mm * 2.0 * B * h * Sq * Sk * 64 * (0.5 if causal else 1.0)
             byts = (2.0 if int(sc[-1 - off]) else 4.0) * B * h * 64 * (2 * Sq + 2 * Sk)
         keys = [key]
