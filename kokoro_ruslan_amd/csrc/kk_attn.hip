@@ -44,6 +44,7 @@ struct AttnArgs {
     uint32_t site;
     float p_drop;
     int xcd_map;
+    int wt;                              // write-through stores of the [rows, 64] outputs (kk_common.h: kk_write_through(B * S))
     int dbg;                             // timing probes (KK_ATTN_DBG; results are wrong when set)
     // backward kernels: the gradient of the per-head RMSNorm (+ RoPE) that produced Q (dQ kernel) / K and V (dK/dV
     // kernel: hn[0], hn[1]) as the epilogue — Out / Out2 then receive the gradient of the RAW projection
@@ -658,7 +659,7 @@ __device__ __forceinline__ void rowfrag_from_image(RowFrag<true> &f, const char 
 // Store the wave's transposed accumulator pair (acc[db][r]: d = db*32 + 8(r>>2) + 4 half + (r&3), row = lane&31) times mul
 // as 32 bf16 rows of 64 through a wave-private 4608-byte LDS tile: 16-byte global stores, eight lanes per 128-byte row.
 __device__ __forceinline__ void store_rows_via_lds(__bf16 *dst_row0, int64_t ld, int nvalid, const f32x16 (&acc)[2], float mul,
-                                                   char *tile, int lane) {
+                                                   char *tile, int lane, int wt) {
     const int l31 = lane & 31, half = lane >> 5;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -674,7 +675,7 @@ __device__ __forceinline__ void store_rows_via_lds(__bf16 *dst_row0, int64_t ld,
     for (int j = 0; j < 4; ++j) {
         const int row = (lane >> 3) + 8 * j, c = lane & 7;
         const u32x4 v = *reinterpret_cast<const u32x4 *>(tile + row * 144 + c * 16);
-        if (row < nvalid) *reinterpret_cast<u32x4 *>(dst_row0 + (int64_t)row * ld + c * 8) = v;
+        if (row < nvalid) kk_store16(dst_row0 + (int64_t)row * ld + c * 8, v, wt);
     }
 }
 
@@ -937,7 +938,7 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(AttnArgs a) {
     }
     const float inv = l > 0.f ? pd.inv_keep / l : 0.f;
     store_rows_via_lds(static_cast<T *>(a.Out) + ((int64_t)b * a.Sq + qmin) * a.ldout + hh * 64, a.ldout, a.Sq - qmin, o, inv,
-                       smem_raw + 36864 + wave * 4608, lane);
+                       smem_raw + 36864 + wave * 4608, lane, a.wt);
     if (qvalid && half == 0) a.LSEo[((int64_t)b * a.heads + hh) * a.Sq + q] = l > 0.f ? (m + __builtin_amdgcn_logf(l)) * 0.6931471805599453f : INFINITY;
 }
 
@@ -1501,7 +1502,7 @@ extern "C" int kk_attn_fwd(const float *Q, const float *K, const float *V, float
     a.Q = Q; a.K = K; a.V = V; a.Out = O; a.LSEo = LSE; a.key_mask = key_mask;
     a.B = B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.causal = causal;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldout = ldo; a.scale = scale;
-    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(causal); a.dbg = attn_dbg();
+    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(causal); a.dbg = attn_dbg(); a.wt = kk_write_through((int64_t)B * std::max(Sq, Sk));
     dim3 grid(kk_cdiv(Sq, 128), B * heads);
     const int G = (Sk > 64 && g_attn_groups == 2) ? 2 : 1;          // one key tile: nothing to split
     // second-generation kernel (DMA-staged, software-pipelined): bf16 storage, two key groups, 16-byte aligned operands
@@ -1552,7 +1553,7 @@ extern "C" int kk_attn_bwd_dq(const float *Q, const float *K, const float *V, co
         KK_REQUIRE(ldo % 8 == 0 && ldo >= 64 * heads, "kk_attn_bwd_dq: row stride of O unsupported");
         a.O = O; a.ldo = ldo; a.DeltaOut = Delta;
     }
-    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(causal); a.dbg = attn_dbg();
+    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(causal); a.dbg = attn_dbg(); a.wt = kk_write_through((int64_t)B * std::max(Sq, Sk));
     if (hn) {
         if (int rc = check_headnorm("kk_attn_bwd_dq", hn, 1)) return rc;
         a.hn[0] = hn[0];
@@ -1585,7 +1586,7 @@ extern "C" int kk_attn_bwd_dkv(const float *Q, const float *K, const float *V, c
     a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.LSE = LSE; a.Delta = Delta; a.Out = dK; a.Out2 = dV; a.key_mask = key_mask;
     a.B = B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.causal = causal;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.lddo = lddo; a.ldout = lddk; a.ldout2 = lddv; a.scale = scale;
-    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(causal); a.dbg = attn_dbg();
+    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(causal); a.dbg = attn_dbg(); a.wt = kk_write_through((int64_t)B * std::max(Sq, Sk));
     if (hn) {
         if (int rc = check_headnorm("kk_attn_bwd_dkv", hn, 2)) return rc;
         a.hn[0] = hn[0]; a.hn[1] = hn[1];
@@ -1640,7 +1641,7 @@ extern "C" int kk_attn_bwd(const float *Q, const float *K, const float *V, const
     a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.LSE = LSE; a.Delta = Delta; a.Out = dQ; a.key_mask = key_mask;
     a.B = B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.causal = causal;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.lddo = lddo; a.ldout = lddq; a.scale = scale;
-    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(causal); a.dbg = attn_dbg();
+    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(causal); a.dbg = attn_dbg(); a.wt = kk_write_through((int64_t)B * std::max(Sq, Sk));
     if (a.xcd_map && causal) a.xcd_map = 2;                    // (the pair launch: always block-major when causal)
     p.dkv = a;
     p.dkv.Out = dK; p.dkv.Out2 = dV; p.dkv.ldout = lddk; p.dkv.ldout2 = lddv;

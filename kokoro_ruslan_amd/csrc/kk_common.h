@@ -101,6 +101,39 @@ __device__ __forceinline__ double block_sum_256_d(double v, double *red) {
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 
+// Write-through (sc1) stores of a kernel's BIG outputs.  A kernel boundary writes the XCD L2s' dirty lines back before the next kernel
+// may start (its readers sit on other XCDs): ~B / 6 TB/s behind B dirty bytes (MI355X_MICROARCH "boundary") — serial time on a chain of
+// dependent launches.  A write-through store sends the bytes to memory while the kernel is still running.  Measured in-step, interleaved
+// on one box (tools build, KK_WT_MAX_ROWS=0 against the default): 4.054 -> 3.994 ms (-1.5 %) at 8 x 512, 6.909 -> 6.837
+// (-1.0 %) at 8 x 1024, 9.117 -> 9.112 (+-0) under dynamic batching at ~11 K rows per launch (long launches hide their write-back).
+// Applied to the outputs of the sub-layer tails, every epilogue of the bf16 GEMM core (fp32 weight gradients through the same LDS
+// transposition as the bf16 tiles, so that they too leave as 16-byte stores) and the second-generation attention kernels; NOT to the
+// optimizer / norm / element-wise kernels (measured: no gain at 8 x 512, +0.9 % step time under dynamic batching).  Every entry point
+// decides from its OWN shape (kk_write_through(rows of the launch)): no state, no switch in the product.
+constexpr int KK_WT_MAX_ROWS = 16384;
+static inline int kk_write_through(int64_t rows) {             // (tools build: KK_WT_MAX_ROWS=0 restores plain stores everywhere)
+    static const int max_rows = kk_tune_env("KK_WT_MAX_ROWS", KK_WT_MAX_ROWS);
+    return rows <= max_rows ? 1 : 0;
+}
+typedef unsigned int kk_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int kk_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void kk_st16_wt(void *p, kk_u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void kk_st8_wt(void *p, kk_u32x2 v) {
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+// 16- / 8-byte GLOBAL output stores; wt is wave-uniform (a kernel argument)
+__device__ __forceinline__ void kk_store16(void *p, kk_u32x4 v, int wt) {
+    if (wt) kk_st16_wt(p, v);
+    else *reinterpret_cast<kk_u32x4 *>(p) = v;
+}
+__device__ __forceinline__ void kk_store8(void *p, kk_u32x2 v, int wt) {
+    if (wt) kk_st8_wt(p, v);
+    else *reinterpret_cast<kk_u32x2 *>(p) = v;
+}
+__device__ __forceinline__ void st4_out(float *p, float4 v, int wt) { kk_store16(p, __builtin_bit_cast(kk_u32x4, v), wt); }
+
 // Storage-type generic 4-element access: activations are fp32 in the parity mode and bf16 in the bf16 mode.
 template <typename T> __device__ __forceinline__ float4 ldv4(const T *p);
 template <> __device__ __forceinline__ float4 ldv4<float>(const float *p) { return ld4(p); }
@@ -114,6 +147,13 @@ template <> __device__ __forceinline__ void stv4<__bf16>(__bf16 *p, float4 v) {
     bf16x4 o;
     o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
     *reinterpret_cast<bf16x4 *>(p) = o;
+}
+template <typename T> __device__ __forceinline__ void stv4_out(T *p, float4 v, int wt);
+template <> __device__ __forceinline__ void stv4_out<float>(float *p, float4 v, int wt) { st4_out(p, v, wt); }
+template <> __device__ __forceinline__ void stv4_out<__bf16>(__bf16 *p, float4 v, int wt) {
+    bf16x4 o;
+    o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+    kk_store8(p, __builtin_bit_cast(kk_u32x2, o), wt);
 }
 template <typename T> __device__ __forceinline__ float ldv1(const T *p) { return (float)(*p); }
 template <typename T> __device__ __forceinline__ void stv1(T *p, float v) { *p = (T)v; }

@@ -67,6 +67,7 @@ struct SubOutArgs {
     float *mean, *rstd;
     int64_t rows;
     int H;
+    int wt;                        // write-through output stores (kk_write_through(rows))
     DropArgs d;
 };
 
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void sublayer_out_fwd_kernel(SubOutArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = o[e] * (dp * m1[e] * m2[e]) + rr[e];
             v[i] = make_float4(o[0], o[1], o[2], o[3]);
-            st4(a.x_out + row * H + c, v[i]);
+            st4_out(a.x_out + row * H + c, v[i], a.wt);
             s += o[0] + o[1] + o[2] + o[3];
         }
     }
@@ -140,8 +141,8 @@ __global__ __launch_bounds__(256) void sublayer_out_fwd_kernel(SubOutArgs a) {
         const int c = lane * 4 + 256 * i;
         if (c < H) {
             const float4 g = lg[i], b = lb[i];
-            stv4<TN>(nr + c, make_float4((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
-                                         (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w));
+            stv4_out<TN>(nr + c, make_float4((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
+                                         (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w), a.wt);
         }
     }
     if (lane == 0) {
@@ -179,6 +180,7 @@ struct SubInArgs {
     float *partials;               // [gridDim.x][4][H]
     int64_t rows;
     int H;
+    int wt;                        // write-through output stores (kk_write_through(rows))
     DropArgs d;
 };
 
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(64 * SIB_WAVES) void sublayer_in_bwd_kernel(SubInAr
                     const float4 dgi = dg[r][i], xi = xh[r][i], oi = old[r][i];
                     float g[4] = {oi.x + rs[r] * (dgi.x - s1 - xi.x * s2), oi.y + rs[r] * (dgi.y - s1 - xi.y * s2),
                                   oi.z + rs[r] * (dgi.z - s1 - xi.z * s2), oi.w + rs[r] * (dgi.w - s1 - xi.w * s2)};
-                    st4(a.dres + row * H + c, make_float4(g[0], g[1], g[2], g[3]));
+                    st4_out(a.dres + row * H + c, make_float4(g[0], g[1], g[2], g[3]), a.wt);
                     float m1[4], m2[4];
                     kk_drop_mul4(seed, a.d.site1, (uint64_t)row * H + c, t1, k1, m1);
                     kk_drop_mul4(seed, a.d.site2, (uint64_t)row * H + c, t2, k2, m2);
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(64 * SIB_WAVES) void sublayer_in_bwd_kernel(SubInAr
                 if (c < H) {
                     float4 o = dg[r][i];
                     if (ffn) o = make_float4(rsf[r] * o.x - yv[r][i].x * k, rsf[r] * o.y - yv[r][i].y * k, rsf[r] * o.z - yv[r][i].z * k, rsf[r] * o.w - yv[r][i].w * k);
-                    stv4<TY>(dy + row * H + c, o);
+                    stv4_out<TY>(dy + row * H + c, o, a.wt);
                     ac[i].x += o.x; ac[i].y += o.y; ac[i].z += o.z; ac[i].w += o.w;
                 }
             }
@@ -391,7 +393,7 @@ extern "C" int kk_sublayer_out_fwd(const float *y, int y_bf16, const float *gain
     KK_REQUIRE(p1 >= 0.f && p1 < 1.f && p2 >= 0.f && p2 < 1.f && dp_rate >= 0.f && dp_rate < 1.f, "kk_sublayer_out_fwd: probabilities must be in [0,1)");
     SubOutArgs a;
     a.y = y; a.gain = gain; a.rstd_f = rstd_f; a.res = res; a.x_out = x_out; a.ln_gamma = ln_gamma; a.ln_beta = ln_beta; a.n = n;
-    a.mean = mean; a.rstd = rstd; a.rows = rows; a.H = H;
+    a.mean = mean; a.rstd = rstd; a.rows = rows; a.H = H; a.wt = kk_write_through(rows);
     a.d = {seed, site1, site2, site_dp, p1, p2, dp_rate, S};
     hipStream_t s = (hipStream_t)stream;
     if (y_bf16) { if (n_bf16) launch_subout<__bf16, __bf16>(a, s); else launch_subout<__bf16, float>(a, s); }
@@ -415,7 +417,7 @@ extern "C" int kk_sublayer_in_bwd(const float *dn, int dn_bf16, const float *x_o
     KK_REQUIRE(!gain || (y && rstd_f), "kk_sublayer_in_bwd: the RMSNorm backward needs y and rstd_f");
     SubInArgs a;
     a.dn = dn; a.x_out = x_out; a.ln_gamma = ln_gamma; a.mean = mean; a.rstd = rstd; a.dres = dres; a.accumulate = accumulate;
-    a.y = y; a.gain = gain; a.rstd_f = rstd_f; a.dy = dy; a.partials = partials; a.rows = rows; a.H = H;
+    a.y = y; a.gain = gain; a.rstd_f = rstd_f; a.dy = dy; a.partials = partials; a.rows = rows; a.H = H; a.wt = kk_write_through(rows);
     a.d = {seed, site1, site2, site_dp, p1, p2, dp_rate, S};
     hipStream_t s = (hipStream_t)stream;
     const int blocks = kk_sublayer_in_bwd_blocks(rows);

@@ -36,6 +36,7 @@ struct G16Args {
     int k_per_split, atomic, splits, split_major;
     int tiles_m, tiles_n, xcd_swizzle;
     int m_fast;                                                 // tile order inside an XCD's run: 0 = n fastest, 1 = m fastest (see gemm16_body)
+    int wt;                                                     // write-through stores of C and the epilogues' outputs (kk_common.h: kk_write_through)
     uint32_t a_bytes, b_bytes;
     // EPI == 1 (GLU backward epilogue): C is not written; see gemm16_kernel
     const __bf16 *glu_h;
@@ -335,8 +336,8 @@ __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char
                     sa[j] += da;
                     sb[j] += db;
                 }
-                *reinterpret_cast<bf16x8 *>(a.glu_dh + o) = oa;
-                *reinterpret_cast<bf16x8 *>(a.glu_dh + o + F) = ob;
+                kk_store16(a.glu_dh + o, __builtin_bit_cast(kk_u32x4, oa), a.wt);
+                kk_store16(a.glu_dh + o + F, __builtin_bit_cast(kk_u32x4, ob), a.wt);
             }
         }
         // column sums over the wave's 32 rows: the 16 lanes that share (lane & 3)
@@ -380,8 +381,10 @@ __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char
             const int pos = rope ? (row < a.M ? row : a.M - 1) % a.hn_S : 0;
             const float4 n = kk_headnorm_rope(v, g, rope, a.hn_cos + pos * 64, a.hn_sin + pos * 64, sub);
             if (row < a.M) {
-                *reinterpret_cast<bf16x4 *>(raw + (int64_t)row * a.ldc + n0 + sub * 4) = r4;
-                stv4<__bf16>(a.hn_y + (int64_t)row * a.hn_ldy + n0 + sub * 4, n);
+                kk_store8(raw + (int64_t)row * a.ldc + n0 + sub * 4, __builtin_bit_cast(kk_u32x2, r4), a.wt);
+                bf16x4 n4;
+                n4[0] = (__bf16)n.x; n4[1] = (__bf16)n.y; n4[2] = (__bf16)n.z; n4[3] = (__bf16)n.w;
+                kk_store8(a.hn_y + (int64_t)row * a.hn_ldy + n0 + sub * 4, __builtin_bit_cast(kk_u32x2, n4), a.wt);
             }
         }
         return;
@@ -424,9 +427,9 @@ __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char
                 og[j] = (__bf16)(kk_gelu_fast((float)oa[j]) * (float)ob[j] * mk[j]);
             }
             const int64_t o = (int64_t)row * 2 * F + col;
-            *reinterpret_cast<bf16x8 *>(h + o) = oa;
-            *reinterpret_cast<bf16x8 *>(h + o + F) = ob;
-            *reinterpret_cast<bf16x8 *>(g + (int64_t)row * a.ldc + col) = og;
+            kk_store16(h + o, __builtin_bit_cast(kk_u32x4, oa), a.wt);
+            kk_store16(h + o + F, __builtin_bit_cast(kk_u32x4, ob), a.wt);
+            kk_store16(g + (int64_t)row * a.ldc + col, __builtin_bit_cast(kk_u32x4, og), a.wt);
         }
         return;
     }
@@ -463,7 +466,7 @@ __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char
                         bf16x8 o;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] = (__bf16)(a.alpha * v[e] + bv[e]);
-                        *reinterpret_cast<bf16x8 *>(C + (int64_t)row * a.ldc + col) = o;
+                        kk_store16(C + (int64_t)row * a.ldc + col, __builtin_bit_cast(kk_u32x4, o), a.wt);
                         if constexpr (DELTA_OK) {
                             if (a.dl_out != nullptr) {              // (from the ROUNDED dO: what the attention kernels will read)
                                 const bf16x8 ov = *reinterpret_cast<const bf16x8 *>(a.dl_o + (int64_t)row * a.dl_ldo + col);
@@ -500,6 +503,49 @@ __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char
                         }
                     }
                 }
+            }
+        return;
+    }
+    // fp32 C written (or accumulated into) exactly once per element — the weight gradients — in a write-through launch: the same
+    // transposition, so that a lane stores 8 consecutive columns of 2 rows as 16-byte write-through stores (a launch leaves up to
+    // 31 MB of dW behind; as plain 4-byte stores they sit dirty in the L2s until the kernel boundary writes them back)
+    if (a.wt && WIDE_OK && !a.c_bf16 && !a.atomic && a.residual == nullptr && (a.ldc & 3) == 0 && (a.N & 7) == 0 &&
+        (reinterpret_cast<uintptr_t>(a.C) & 15) == 0) {
+        constexpr int TP = 36;
+        __builtin_amdgcn_s_barrier();                           // every wave is done with the last stage
+        float *tile = reinterpret_cast<float *>(smem) + wave * 32 * TP;
+        float *C = static_cast<float *>(a.C);
+        const int c8 = (lane & 3) * 8;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tile[frag_row(r, half) * TP + l31] = acc[i][j][r];
+                __builtin_amdgcn_wave_barrier();
+                const int col = n0 + wc * (BN / WC) + j * 32 + c8;
+                if (col < a.N) {
+                    float bv[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bv[e] = (a.bias != nullptr && lead) ? a.bias[col + e] : 0.f;
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        const int rl = it * 16 + (lane >> 2), row = m0 + wr * (BM / WR) + i * 32 + rl;
+                        if (row >= a.M) continue;
+                        float *dst = C + (int64_t)row * a.ldc + col;
+                        const float4 v0 = ld4(tile + rl * TP + c8), v1 = ld4(tile + rl * TP + c8 + 4);
+                        float4 o0 = make_float4(a.alpha * v0.x + bv[0], a.alpha * v0.y + bv[1], a.alpha * v0.z + bv[2], a.alpha * v0.w + bv[3]);
+                        float4 o1 = make_float4(a.alpha * v1.x + bv[4], a.alpha * v1.y + bv[5], a.alpha * v1.z + bv[6], a.alpha * v1.w + bv[7]);
+                        if (a.beta != 0.f) {
+                            const float4 d0 = ld4(dst), d1 = ld4(dst + 4);
+                            o0 = make_float4(o0.x + a.beta * d0.x, o0.y + a.beta * d0.y, o0.z + a.beta * d0.z, o0.w + a.beta * d0.w);
+                            o1 = make_float4(o1.x + a.beta * d1.x, o1.y + a.beta * d1.y, o1.z + a.beta * d1.z, o1.w + a.beta * d1.w);
+                        }
+                        kk_st16_wt(dst, __builtin_bit_cast(kk_u32x4, o0));
+                        kk_st16_wt(dst + 4, __builtin_bit_cast(kk_u32x4, o1));
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
             }
         return;
     }
@@ -727,6 +773,7 @@ int kk_gemm16_launch(int ta, int tb, int64_t M, int64_t N, int64_t K, float alph
     const int split_major = (g16_split_major && splits > 1 && splits % 8 == 0) ? 1 : 0;
     G16Args a = {};
     a.M = (int)M; a.N = (int)N; a.K = (int)K;
+    a.wt = kk_write_through(ta ? K : M);                       // (ta: a weight gradient — its launch length is the reduction)
     a.alpha = alpha; a.beta = beta;
     a.A = A; a.B = B; a.bias = bias; a.residual = residual; a.C = C; a.c_bf16 = c_bf16;
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.res_mod = res_mod;
@@ -766,6 +813,7 @@ int kk_gemm16_dgrad_delta(int64_t M, int64_t N, int64_t K, const void *dy, int64
     auto cd = [](int64_t x, int64_t y) { return (int)((x + y - 1) / y); };
     G16Args a = {};
     a.M = (int)M; a.N = (int)N; a.K = (int)K;
+    a.wt = kk_write_through(M);
     a.alpha = 1.f; a.A = dy; a.B = W; a.C = dx; a.c_bf16 = 1;
     a.lda = lddy; a.ldb = ldw; a.ldc = lddx;
     a.k_per_split = cd(K, BK) * BK; a.splits = 1;
@@ -785,6 +833,7 @@ int kk_gemm16_dgrad_glu(int64_t T, int64_t F, int64_t H, const void *dy, int64_t
     auto cd = [](int64_t x, int64_t y) { return (int)((x + y - 1) / y); };
     G16Args a = {};
     a.M = (int)T; a.N = (int)F; a.K = (int)H;
+    a.wt = kk_write_through(T);
     a.alpha = 1.f; a.A = dy; a.B = W; a.lda = lddy; a.ldb = F;
     a.k_per_split = cd(H, BK) * BK; a.splits = 1;
     a.tiles_m = cd(T, 64); a.tiles_n = cd(F, 64); a.xcd_swizzle = xcd_swizzle;
@@ -810,6 +859,7 @@ int kk_gemm16_linear_glu(int64_t T, int64_t F, int64_t K, const void *x, int64_t
     auto cd = [](int64_t a_, int64_t b_) { return (int)((a_ + b_ - 1) / b_); };
     G16Args a = {};
     a.M = (int)T; a.N = (int)F; a.K = (int)K;          // N = F: a workgroup covers columns n and F + n of the [T, 2F] product
+    a.wt = kk_write_through(T);
     a.alpha = 1.f; a.A = x; a.B = W; a.lda = ldx; a.ldb = K; a.bias = bias; a.C = g; a.ldc = ldg; a.c_bf16 = 1;
     a.k_per_split = cd(K, BK) * BK; a.splits = 1;
     a.tiles_m = cd(T, 64); a.tiles_n = cd(F, 64); a.xcd_swizzle = xcd_swizzle;
@@ -858,6 +908,7 @@ int kk_gemm16_wgrad_group(const KkWgradDesc *d, int n, int split_k, int overwrit
         min_per = std::min(min_per, kps / BK);
         G16Args &a = g.p[i];
         a.M = (int)M; a.N = (int)N; a.K = (int)K;
+        a.wt = kk_write_through(K);                                // (a weight gradient's launch length is its reduction: the tokens)
         a.alpha = 1.f; a.beta = overwrite ? 0.f : 1.f;
         a.A = d[i].dy; a.B = d[i].x; a.C = d[i].dw;
         a.lda = d[i].lddy; a.ldb = d[i].ldx; a.ldc = d[i].lddw;
@@ -887,6 +938,7 @@ int kk_gemm16_qkv_headnorm(int64_t T, int parts, int heads, int64_t K, const voi
     const int64_t N = (int64_t)parts * heads * 64;
     G16Args a = {};
     a.M = (int)T; a.N = (int)N; a.K = (int)K;
+    a.wt = kk_write_through(T);
     a.alpha = 1.f; a.A = x; a.B = W; a.lda = ldx; a.ldb = K; a.bias = bias; a.C = raw; a.ldc = ldraw; a.c_bf16 = 1;
     a.k_per_split = cd(K, BK) * BK; a.splits = 1;
     a.tiles_m = cd(T, 64); a.tiles_n = cd(N, 64); a.xcd_swizzle = xcd_swizzle;
