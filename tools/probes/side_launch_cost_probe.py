@@ -12,6 +12,18 @@ import torch
 from kokoro_ruslan_amd import lib as kk
 
 x = torch.ones(1 << 22, device="cuda")
+MAIN = os.environ.get("MAIN", "stream")      # stream: a 32 MB read-modify-write; gemm: a 4096 x 512 x 512 bf16 GEMM (cache-resident operands)
+ga, gb = torch.randn(4096, 512, device="cuda").bfloat16(), torch.randn(512, 512, device="cuda").bfloat16()
+gc = torch.empty(4096, 512, device="cuda", dtype=torch.bfloat16)
+
+
+def main_op():
+    if MAIN == "gemm":
+        torch.matmul(ga, gb.t(), out=gc)
+    else:
+        x.mul_(1.0)
+
+
 y = torch.ones(1 << 14, device="cuda")
 buf = torch.zeros(1024, dtype=torch.int64, device="cuda")
 side = torch.cuda.Stream()
@@ -20,7 +32,7 @@ NMAIN = 200
 
 def step(n_side, kind):
     for _ in range(10):
-        x.mul_(1.0)
+        main_op()
     if n_side:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -30,7 +42,7 @@ def step(n_side, kind):
                 else:
                     y.mul_(1.0)
     for _ in range(NMAIN - 10):
-        x.mul_(1.0)
+        main_op()
     if n_side:
         torch.cuda.current_stream().wait_stream(side)
 
@@ -58,6 +70,6 @@ def measure(n_side, kind):
 base = measure(0, "stamp")
 print(f"main chain alone (single-stream graph): {base:8.1f} us = {base / NMAIN:.2f} us per launch")
 for kind in ("stamp", "small"):
-    for n in (1, 25, 50, 100, 200):
+    for n in (1, 50, 100, 200, 400):
         t = measure(n, kind)
         print(f"branch of {n:3d} {kind:5s} launches: {t:8.1f} us  (+{t - base:7.1f} us, {(t - base) / n:6.2f} us per branch launch)")
