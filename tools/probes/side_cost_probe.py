@@ -15,11 +15,20 @@ batch = {k: v.cuda() for k, v in synthetic_batch(8, T, P, seed=1).items()}
 orig_call = kk.call
 
 
-def run(tag, skip_side_bwd=False, overlap=True, skip_fwd_side=False):
+def run(tag, skip_side_bwd=False, overlap=True, skip_fwd_side=False, only=None):
     eng = E.KokoroEngine(ModelDims(), StepHyper(gradient_accumulation_steps=1), math_mode="bf16", total_steps=20000, seed=0)
     eng.train_dropout = True
     eng.overlap = overlap
-    state = {"bwd": False, "side": False}
+    state = {"bwd": False, "side": False, "part": "pred"}
+    orig_mark = eng._mark
+
+    def mark(name):                      # the side backward = predictors + heads, then the text encoder
+        if name == "side: predictors bwd done":
+            state["part"] = "enc"
+        elif name == "side: backward start":
+            state["part"] = "pred"
+        orig_mark(name)
+    eng._mark = mark
     import contextlib
     orig_on = eng._on_stream
 
@@ -38,7 +47,7 @@ def run(tag, skip_side_bwd=False, overlap=True, skip_fwd_side=False):
             state["bwd"] = True
         elif name == "kk_seg_sumsq":
             state["bwd"] = False
-        if skip_side_bwd and state["bwd"] and state["side"]:
+        if skip_side_bwd and state["bwd"] and state["side"] and (only is None or state["part"] == only):
             return
         if skip_fwd_side and not state["bwd"] and state["side"]:
             return
@@ -64,6 +73,8 @@ def run(tag, skip_side_bwd=False, overlap=True, skip_fwd_side=False):
 
 
 run("as shipped")
+run("side backward: predictors + heads skipped (timing only)", skip_side_bwd=True, only="pred")
+run("side backward: text encoder skipped (timing only)", skip_side_bwd=True, only="enc")
 run("side branch's backward launches skipped (timing only)", skip_side_bwd=True)
 run("side branch skipped in forward AND backward (timing only)", skip_side_bwd=True, skip_fwd_side=True)
 run("no overlap (one stream)", overlap=False)
