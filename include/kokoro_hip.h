@@ -249,6 +249,20 @@ int kk_ids_eq_zero(const int64_t *ids, uint8_t *mask, int64_t n, void *stream);
 /* decoder input shift-right (model.py:519): out[b,0,:]=0, out[b,t,:]=mel[b,t-1,:]. */
 int kk_shift_right(const float *mel, float *out, int B, int T, int M, void *stream);
 
+/* ---- autoregressive decode (KokoroGenerator.generate, model/generator.py:24-127; incremental attention with a KV cache,
+ * transformers.py:237-253): the per-frame launches take the frame index t from DEVICE memory (*t_dev), so that ONE captured
+ * hipGraph of a decoder step is replayed for every frame.
+ * prologue: frame_in[B,M] = mel_all[:, t, :] (mel_all [B, L1, M]: row 0 = the all-zero first input, row t+1 = frame t's output),
+ *   pe_row[H] = pe[t], cos_row / sin_row [64] = the RoPE tables' row t (the step's K is rotated by its absolute position,
+ *   transformers.py:268-277), key_mask[t] = 0 (the self-attention runs over the whole cache under a key mask).
+ * cache_append: nrm [B, 3H] (normalised q | k | v of the step) -> q [B*H], kcache[t] and vcache[t] ([L][B*H], time-major).
+ * epilogue: mel_all[:, t+1, :] = frame_out [B,M]; stop_all[t, :] = stop [B]; *t_dev = t + 1. */
+int kk_decode_prologue(const float *mel_all, float *frame_in, const float *pe, float *pe_row, const float *cos_t, const float *sin_t,
+                       float *cos_row, float *sin_row, uint8_t *key_mask, const int *t_dev, int B, int L1, int M, int H, void *stream);
+int kk_decode_cache_append(const void *nrm, void *q, void *kcache, void *vcache, const int *t_dev, int B, int H, int bf16, void *stream);
+int kk_decode_epilogue(const float *frame_out, const float *stop, float *mel_all, float *stop_all, int *t_dev, int B, int L1, int M,
+                       void *stream);
+
 /* ---- dropout / DropPath / SpecAugment (p > 0 training paths; masks from an in-kernel counter RNG) ----
  * out = (res ? res[row % res_mod (0: row)] : 0) + x * m1 * m2 * droppath(sample(row)), m_i in {0, 1/(1-p_i)}
  * (transformers.py:16-40,482-487,569-581; the FFN has two dropouts in series, :111).  *seed is read on the device. */

@@ -360,6 +360,57 @@ __global__ __launch_bounds__(256) void shift_right_kernel(const float *__restric
     }
 }
 
+// ---- autoregressive decode (model/generator.py:24-127, the KV-cache path of transformers.py:237-253) ------------------------------
+// The launches of one decoder step read the frame index t from DEVICE memory, so that one captured hipGraph of the step is replayed
+// for every frame of an utterance (the step's ~100 launches are otherwise host-bound: ~1 ms per frame through eager launches).
+// prologue: the step's input frame, its positional-encoding row and RoPE rows into fixed buffers; key t of the self-attention
+// caches becomes visible (the attention runs over the whole cache with a key mask, so its arguments do not change with t).
+__global__ __launch_bounds__(256) void decode_prologue_kernel(const float *__restrict__ mel_all, float *__restrict__ frame_in,
+                                                              const float *__restrict__ pe, float *__restrict__ pe_row,
+                                                              const float *__restrict__ cos_t, const float *__restrict__ sin_t,
+                                                              float *__restrict__ cos_row, float *__restrict__ sin_row,
+                                                              uint8_t *__restrict__ key_mask, const int *__restrict__ t_dev, int B, int L1,
+                                                              int M, int H) {
+    const int t = *t_dev;
+    for (int i = threadIdx.x; i < B * M; i += 256) {
+        const int b = i / M, c = i - b * M;
+        frame_in[i] = mel_all[((int64_t)b * L1 + t) * M + c];
+    }
+    for (int i = threadIdx.x; i < H; i += 256) pe_row[i] = pe[(int64_t)t * H + i];
+    for (int i = threadIdx.x; i < 64; i += 256) {
+        cos_row[i] = cos_t[(int64_t)t * 64 + i];
+        sin_row[i] = sin_t[(int64_t)t * 64 + i];
+    }
+    if (threadIdx.x == 0) key_mask[t] = 0;
+}
+// the step's normalised q | k | v [B, 3H] -> the query buffer [B*H] and row t of the time-major K and V caches [L][B*H]
+template <typename T>
+__global__ __launch_bounds__(256) void decode_cache_append_kernel(const T *__restrict__ nrm, T *__restrict__ q, T *__restrict__ kc,
+                                                                  T *__restrict__ vc, const int *__restrict__ t_dev, int B, int H) {
+    const int t = *t_dev;
+    const int64_t row = (int64_t)t * B * H;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < B * H; i += gridDim.x * 256) {
+        const int b = i / H, c = i - b * H;
+        const T *src = nrm + (int64_t)b * 3 * H + c;
+        q[i] = src[0];
+        kc[row + i] = src[H];
+        vc[row + i] = src[2 * H];
+    }
+}
+// epilogue: the step's mel frame -> row t+1 of the output (= the next step's input), its stop logits -> row t; t += 1
+__global__ __launch_bounds__(256) void decode_epilogue_kernel(const float *__restrict__ frame_out, const float *__restrict__ stop,
+                                                              float *__restrict__ mel_all, float *__restrict__ stop_all,
+                                                              int *__restrict__ t_dev, int B, int L1, int M) {
+    const int t = *t_dev;
+    for (int i = threadIdx.x; i < B * M; i += 256) {
+        const int b = i / M, c = i - b * M;
+        mel_all[((int64_t)b * L1 + t + 1) * M + c] = frame_out[i];
+    }
+    for (int i = threadIdx.x; i < B; i += 256) stop_all[(int64_t)t * B + i] = stop[i];
+    __syncthreads();
+    if (threadIdx.x == 0) *t_dev = t + 1;
+}
+
 inline int grid_for(int64_t n, int cap = 4096) {
     int b = kk_cdiv(n, 256);
     return b > cap ? cap : (b < 1 ? 1 : b);
@@ -527,6 +578,39 @@ extern "C" int kk_bucket_embed_add_bwd(const float *dout, const int32_t *pidx, c
     hipLaunchKernelGGL(bucket_embed_add_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, pidx, eidx,
                        frame_mask, dpemb, deemb, rows, H);
     KK_LAUNCH_CHECK("kk_bucket_embed_add_bwd");
+    return 0;
+}
+
+extern "C" int kk_decode_prologue(const float *mel_all, float *frame_in, const float *pe, float *pe_row, const float *cos_t,
+                                  const float *sin_t, float *cos_row, float *sin_row, uint8_t *key_mask, const int *t_dev, int B, int L1,
+                                  int M, int H, void *stream) {
+    KK_REQUIRE(mel_all && frame_in && pe && pe_row && cos_t && sin_t && cos_row && sin_row && key_mask && t_dev && B > 0 && L1 > 1 && M > 0 && H > 0,
+               "kk_decode_prologue: bad args");
+    hipLaunchKernelGGL(decode_prologue_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mel_all, frame_in, pe, pe_row, cos_t, sin_t,
+                       cos_row, sin_row, key_mask, t_dev, B, L1, M, H);
+    KK_LAUNCH_CHECK("kk_decode_prologue");
+    return 0;
+}
+extern "C" int kk_decode_cache_append(const void *nrm, void *q, void *kcache, void *vcache, const int *t_dev, int B, int H, int bf16,
+                                      void *stream) {
+    KK_REQUIRE(nrm && q && kcache && vcache && t_dev && B > 0 && H > 0, "kk_decode_cache_append: bad args");
+    const int blocks = grid_for((int64_t)B * H, 64);
+    if (bf16)
+        hipLaunchKernelGGL(decode_cache_append_kernel<uint16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           static_cast<const uint16_t *>(nrm), static_cast<uint16_t *>(q), static_cast<uint16_t *>(kcache),
+                           static_cast<uint16_t *>(vcache), t_dev, B, H);
+    else
+        hipLaunchKernelGGL(decode_cache_append_kernel<uint32_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           static_cast<const uint32_t *>(nrm), static_cast<uint32_t *>(q), static_cast<uint32_t *>(kcache),
+                           static_cast<uint32_t *>(vcache), t_dev, B, H);
+    KK_LAUNCH_CHECK("kk_decode_cache_append");
+    return 0;
+}
+extern "C" int kk_decode_epilogue(const float *frame_out, const float *stop, float *mel_all, float *stop_all, int *t_dev, int B, int L1,
+                                  int M, void *stream) {
+    KK_REQUIRE(frame_out && stop && mel_all && stop_all && t_dev && B > 0 && L1 > 1 && M > 0, "kk_decode_epilogue: bad args");
+    hipLaunchKernelGGL(decode_epilogue_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, frame_out, stop, mel_all, stop_all, t_dev, B, L1, M);
+    KK_LAUNCH_CHECK("kk_decode_epilogue");
     return 0;
 }
 

@@ -1265,7 +1265,7 @@ class KokoroEngine:
     def generate(self, ids: torch.Tensor, stress: Optional[torch.Tensor] = None, max_len: int = 4000,
                  stop_threshold: float = 0.5, min_len_ratio: float = 0.7, min_len_floor: int = 12,
                  max_len_ratio: float = 3.0, max_len_cap: int = 1600, post_expected_stop_threshold: float = 0.2,
-                 check_every: int = 16) -> torch.Tensor:
+                 check_every: int = 16, decode_graph: bool = True) -> torch.Tensor:
         """KokoroModel.forward_inference (model/model.py:676-790) + KokoroGenerator.generate (model/generator.py:24-127):
         encode, expand by the model's own durations, pick the pitch / energy embeddings from its own (clamped)
         predictions (variance_predictor.py:338-439 without targets), then decode one mel frame at a time against a KV
@@ -1278,7 +1278,8 @@ class KokoroEngine:
         the reference, the single query of a step is rotated by position 0 (RoPE offsets default to 0 in its
         incremental path, transformers.py:276).  The stop decision needs the host; the reference syncs every frame,
         here the frames of `check_every` steps are decoded before the host looks (frames past the stop are dropped, so
-        the result is the same)."""
+        the result is the same).  decode_graph: frames 1.. are replays of ONE hipGraph of the step, captured after frame 0 ran
+        eagerly (the step's launches index everything by a device-side frame counter); False issues the same launches one by one."""
         d, P, H, M, h = self.dims, self.arena.P, self.dims.hidden, self.dims.mel, self.dims.heads
         VA = "duration_adaptor.variance_adaptor"
         ids = ids.to(self.device, torch.int64).contiguous()
@@ -1344,33 +1345,42 @@ class KokoroEngine:
                 max_expected = min(max_len, min_expected + 1)
             if max_expected > d.max_len:
                 raise ValueError(f"generation bound {max_expected} exceeds the positional table ({d.max_len})")
-            cos, sin = self._rope_tables(max_expected)
-            BH = B * H
+            cos, sin = self._rope_tables(d.max_len)                                # (the whole tables: the step indexes them by t)
+            BH, L1 = B * H, max_expected + 1
             Kc = [self._buf(f"gen.dec{i}.kcache", max_expected, BH, dtype=ddt) for i in range(d.dec_layers)]
             Vc = [self._buf(f"gen.dec{i}.vcache", max_expected, BH, dtype=ddt) for i in range(d.dec_layers)]
-            mel_out = self._buf("gen.mel", B, max_expected + 1, M)                 # row 0 = the all-zero first input
+            for c_ in Kc + Vc:
+                c_.zero_()                                                         # (rows >= t are masked, but 0 * garbage must stay 0)
+            mel_out = self._buf("gen.mel", B, L1, M)                               # row 0 = the all-zero first input
             mel_out.zero_()
             stop_logit = self._buf("gen.stop", max_expected, B)
             y = self._buf("gen.y", B, H)
-            frames = max_expected
-            done = 0
-            for t in range(max_expected):
+            # The step's launches take the frame index from device memory (kk_decode_*): their arguments are the same for every
+            # frame, so ONE captured hipGraph of the step serves the whole utterance (decode_graph; ~100 launches per frame are
+            # host-bound when issued one by one).  The self-attention runs over the whole cache under a key mask that opens key t.
+            t_dev = self._buf("gen.t", 1, dtype=torch.int32)
+            t_dev.zero_()
+            kmask = self._buf("gen.kmask", 1, max_expected, dtype=torch.uint8)
+            kmask.fill_(1)
+            frame_in, frame_out, stop_now = self._buf("gen.frame_in", B, M), self._buf("gen.frame_out", B, M), self._buf("gen.stop_now", B)
+            pe_row, cos_row, sin_row = self._buf("gen.pe_row", 1, H), self._buf("gen.cos_row", 1, 64), self._buf("gen.sin_row", 1, 64)
+
+            def decode_step():
+                kk.call("kk_decode_prologue", mel_out, frame_in, pe, pe_row, cos, sin, cos_row, sin_row, kmask, t_dev, B, L1, M, H)
                 # mel_projection_in + positional encoding at offset t (model.py:541-545)
-                self._linear(mel_out[:, t], self._W("mel_projection_in.weight"), P["mel_projection_in.bias"], y, res=pe[t:t + 1], res_mod=1)
+                self._linear(frame_in, self._W("mel_projection_in.weight"), P["mel_projection_in.bias"], y, res=pe_row, res_mod=1)
                 n1 = self._ln_fwd("gen.dec0.ln1", y, "decoder.layers.0.norm1", ddt)
                 yl = y
                 for i in range(d.dec_layers):
                     pf, key = f"decoder.layers.{i}", f"gen.dec{i}"
                     gq, gk, gv = P[pf + ".self_attn.q_norm.weight"], P[pf + ".self_attn.k_norm.weight"], P[pf + ".self_attn.v_norm.weight"]
                     raw, nrm = self._buf(key + ".qkv_raw", B, 3 * H, dtype=ddt), self._buf(key + ".qkv_n", B, 3 * H, dtype=ddt)
-                    self._proj_headnorm(n1, self._Wf(pf + ".self_attn.w_q.weight", 3), raw, nrm, 1, (gq, gk, gv), 2, cos[t:t + 1], sin[t:t + 1])
+                    self._proj_headnorm(n1, self._Wf(pf + ".self_attn.w_q.weight", 3), raw, nrm, 1, (gq, gk, gv), 2, cos_row, sin_row)
                     qb = self._buf(key + ".q", 1, BH, dtype=ddt)
-                    qb.view(B, H).copy_(nrm[:, :H])
-                    Kc[i][t].view(B, H).copy_(nrm[:, H:2 * H])
-                    Vc[i][t].view(B, H).copy_(nrm[:, 2 * H:])
+                    kk.call("kk_decode_cache_append", nrm, qb, Kc[i], Vc[i], t_dev, B, H, _b16(nrm))
                     ctx, lse = self._buf(key + ".ctx", 1, BH, dtype=ddt), self._buf(key + ".lse", 1, B * h, 1)
-                    kk.call("kk_attn_fwd", qb, Kc[i], Vc[i], ctx, lse, 1, B * h, 1, t + 1, BH, BH, BH, BH, None, 0, 0.125, self.rng, 0, 0.0,
-                            self.math, _b16(qb))
+                    kk.call("kk_attn_fwd", qb, Kc[i], Vc[i], ctx, lse, 1, B * h, 1, max_expected, BH, BH, BH, BH, kmask, 0, 0.125, self.rng,
+                            0, 0.0, self.math, _b16(qb))
                     proj = self._buf("tmp.gen_proj", B, H)
                     self._linear(ctx.view(B, H), self._W(pf + ".self_attn.w_o.weight"), P[pf + ".self_attn.w_o.bias"], proj)
                     ya = self._buf(key + ".xa", B, H)
@@ -1384,9 +1394,25 @@ class KokoroEngine:
                     n1 = self._ffn_fwd(key + ".ff", pf + ".ff", n3, yc, yo, d.dec_ff, 1, next_ln=nxt)
                     yl = yo
                 dec_out = n1
-                self._linear(dec_out, self._W("mel_projection_out.weight"), P["mel_projection_out.bias"], mel_out[:, t + 1])
-                kk.call("kk_rowdot_fwd", dec_out, P["stop_token_predictor.weight"], P["stop_token_predictor.bias"], None, stop_logit[t],
+                self._linear(dec_out, self._W("mel_projection_out.weight"), P["mel_projection_out.bias"], frame_out)
+                kk.call("kk_rowdot_fwd", dec_out, P["stop_token_predictor.weight"], P["stop_token_predictor.bias"], None, stop_now,
                         B, H, 1, 0, _b16(dec_out))
+                kk.call("kk_decode_epilogue", frame_out, stop_now, mel_out, stop_logit, t_dev, B, L1, M)
+
+            frames = max_expected
+            done = 0
+            step_graph = None
+            for t in range(max_expected):
+                if step_graph is not None:
+                    step_graph.replay()
+                else:
+                    decode_step()                          # frame 0 eagerly: it sizes the workspaces a capture may not allocate
+                    if decode_graph and max_expected > 1:
+                        with self.capture_lock:
+                            torch.cuda.synchronize()
+                            step_graph = torch.cuda.CUDAGraph()
+                            with torch.cuda.graph(step_graph, capture_error_mode="thread_local"):
+                                decode_step()
                 if (t + 1) % check_every == 0 or t + 1 == max_expected:
                     sp = torch.sigmoid(stop_logit[done:t + 1]).mean(dim=1).cpu().tolist()
                     mel_host = mel_out[:, 1:t + 2].float().cpu() if t + 1 >= 30 else None

@@ -192,6 +192,9 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_specaug": [_P, _I, _I, _I, _P, _U, _I, _I, _I, _I, _I, _P],
     "kk_ids_eq_zero": [_P, _P, _L, _P],
     "kk_shift_right": [_P, _P, _I, _I, _I, _P],
+    "kk_decode_prologue": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "kk_decode_cache_append": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "kk_decode_epilogue": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "kk_losses_fwd": [_P] * 12 + [_I, _I, _I, _I, C.POINTER(KkLossCfg), _P, _P, _P, _P, _P, _P],
     "kk_losses_finalize": [_P, C.POINTER(KkLossCfg), _P, _I, _P, _P, _P, _P],
     "kk_losses_bwd": [_P] * 12 + [_I, _I, _I, _I, C.POINTER(KkLossCfg), _P, _P, _P, _P, _P, _P, _P],

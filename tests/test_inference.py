@@ -61,15 +61,15 @@ def test_oracle_stop_rules():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", CASES)
-@pytest.mark.parametrize("check_every", [1, 16])
-def test_engine_generate_matches_the_reference(golden_dir, name, check_every):
+@pytest.mark.parametrize("check_every,decode_graph", [(1, False), (16, False), (1, True), (16, True)])
+def test_engine_generate_matches_the_reference(golden_dir, name, check_every, decode_graph):
     from kokoro_ruslan_amd import engine as eng_mod
     from kokoro_ruslan_amd.spec import ModelDims, StepHyper
     fx, d, P = _fixture(golden_dir)
     ids, stress, kw, ref = _case(fx, name)
     e = eng_mod.KokoroEngine(ModelDims(**d.__dict__), StepHyper(), math_mode="f32", init=False, total_steps=100)
     e.load_params(P)
-    mel = e.generate(ids.cuda(), stress.cuda() if stress is not None else None, check_every=check_every, **kw)
+    mel = e.generate(ids.cuda(), stress.cuda() if stress is not None else None, check_every=check_every, decode_graph=decode_graph, **kw)
     assert tuple(mel.shape) == tuple(ref.shape), "same number of frames: same stop decision"
     torch.testing.assert_close(mel.cpu(), ref, atol=1e-4, rtol=0)          # the mel-L1 bar of the train step (fp32 mode)
     e.train_dropout = True
@@ -89,3 +89,25 @@ def test_engine_generate_bf16_mode(golden_dir):
     mel = e.generate(ids.cuda(), stress.cuda(), **kw).cpu()
     assert tuple(mel.shape) == tuple(ref.shape) and bool(torch.isfinite(mel).all())
     assert float((mel - ref).abs().mean()) < 0.08 * float(ref.abs().mean()) + 0.02
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_engine_generate_graph_replay_equals_eager_launches(golden_dir, mode):
+    """The decoder step replayed from ONE hipGraph (its launches index the frame by a device-side counter: kk_decode_prologue /
+    kk_decode_cache_append / kk_decode_epilogue) gives what the same launches give when issued one by one — default model size, 90
+    frames, batch of 2 with padding.  (Not bit for bit: one-row GEMMs slice their reduction and add the slices with fp32 atomics, whose
+    order differs from run to run; the error does not grow over the 90 autoregressive steps.)"""
+    from kokoro_ruslan_amd import engine as eng_mod
+    from kokoro_ruslan_amd.spec import ModelDims, StepHyper
+    e = eng_mod.KokoroEngine(ModelDims(), StepHyper(), math_mode=mode, total_steps=100, seed=3)
+    ids = torch.randint(1, 59, (2, 40), generator=torch.Generator().manual_seed(1))
+    ids[1, 33:] = 0
+    kw = dict(max_len=90, stop_threshold=2.0, min_len_ratio=0.0, min_len_floor=1)
+    a = e.generate(ids.cuda(), decode_graph=False, **kw)
+    b = e.generate(ids.cuda(), decode_graph=True, check_every=7, **kw)
+    c = e.generate(ids.cuda(), decode_graph=True, **kw)
+    assert a.shape[1] >= 30 and bool(torch.isfinite(a).all())
+    tol = 1e-3 if mode == "f32" else 0.05
+    for other in (b, c):
+        assert other.shape == a.shape and float((other - a).abs().max()) <= tol * max(1.0, float(a.abs().max()))
