@@ -942,6 +942,95 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(AttnArgs a) {
     if (qvalid && half == 0) a.LSEo[((int64_t)b * a.heads + hh) * a.Sq + q] = l > 0.f ? (m + __builtin_amdgcn_logf(l)) * 0.6931471805599453f : INFINITY;
 }
 
+// ------------------------------------------------------------------ decode: one query per (batch, head)
+// Sq == 1 (the incremental path of transformers.py:237-253: a decoder step against the KV cache / against the memory), no dropout.
+// The tiled kernels above would run one live row of a 128-row block; here a workgroup is one (batch, head): 16 waves = 256 key groups
+// x 4 lanes (16 of the 64 dims each), scores kept in LDS between the two passes (max, then exp / sum / P.V), fp32 throughout.
+template <typename T>
+__global__ __launch_bounds__(1024) void attn_decode_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];          // [Sk] scores | [16 waves][64] partial outputs | [32] reductions
+    float *sc = dsm, *part = dsm + ((a.Sk + 3) & ~3), *red = part + 16 * 64;
+    const int b = blockIdx.x / a.heads, hh = blockIdx.x % a.heads;
+    const int tid = threadIdx.x, kg = tid >> 2, dq = (tid & 3) * 16, lane = tid & 63, wave = tid >> 6;
+    const T *Q = static_cast<const T *>(a.Q) + (int64_t)b * a.ldq + hh * 64 + dq;
+    const T *Kb = static_cast<const T *>(a.K) + (int64_t)b * a.Sk * a.ldk + hh * 64 + dq;
+    const T *Vb = static_cast<const T *>(a.V) + (int64_t)b * a.Sk * a.ldv + hh * 64 + dq;
+    const uint8_t *km = a.key_mask ? a.key_mask + (int64_t)b * a.Sk : nullptr;
+    float qv[16];
+#pragma unroll
+    for (int i = 0; i < 16; i += 4) {
+        const float4 t = ldv4<T>(Q + i);
+        qv[i] = t.x; qv[i + 1] = t.y; qv[i + 2] = t.z; qv[i + 3] = t.w;
+    }
+    const float c2 = a.scale * 1.4426950408889634f;
+    float mx = -INFINITY;
+#pragma unroll 2
+    for (int j = kg; j < a.Sk; j += 256) {                                // 256 key groups x 4 lanes (16 of the 64 dims each)
+        const bool masked = km && km[j];
+        float d = 0.f;
+        if (!masked) {
+            const T *kr = Kb + (int64_t)j * a.ldk;
+            float4 t[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t[i] = ldv4<T>(kr + 4 * i);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d += qv[4 * i] * t[i].x + qv[4 * i + 1] * t[i].y + qv[4 * i + 2] * t[i].z + qv[4 * i + 3] * t[i].w;
+        }
+        d += __shfl_xor(d, 1, 64);
+        d += __shfl_xor(d, 2, 64);
+        d = masked ? -INFINITY : d * c2;
+        if ((tid & 3) == 0) sc[j] = d;
+        mx = fmaxf(mx, d);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    float m = red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+    const float mm = fmaxf(m, -1e30f);
+    float acc[16], l = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll 2
+    for (int j = kg; j < a.Sk; j += 256) {
+        const float s = sc[j];
+        if (s == -INFINITY) continue;
+        const T *vr = Vb + (int64_t)j * a.ldv;
+        float4 t[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = ldv4<T>(vr + 4 * i);
+        const float pj = __builtin_amdgcn_exp2f(s - mm);
+        l += pj;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[4 * i] += pj * t[i].x; acc[4 * i + 1] += pj * t[i].y; acc[4 * i + 2] += pj * t[i].z; acc[4 * i + 3] += pj * t[i].w;
+        }
+    }
+    // the 16 key groups of a wave (lanes with the same dims: lane ^ 4, 8, 16, 32), then the 16 waves through LDS
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) acc[i] += __shfl_xor(acc[i], o, 64);
+    }
+    if (lane < 4) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) part[wave * 64 + dq + i] = acc[i];
+    }
+    l = wave_sum(l) * 0.25f;                                              // (the 4 lanes of a key group hold the same p)
+    if (lane == 0) red[16 + wave] = l;
+    __syncthreads();
+    if (tid < 64) {
+        float lt = 0.f, o = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { lt += red[16 + w]; o += part[w * 64 + tid]; }
+        o = lt > 0.f ? o / lt : 0.f;
+        T *out = static_cast<T *>(a.Out) + (int64_t)b * a.ldout + hh * 64 + tid;
+        *out = (T)o;
+        if (tid == 0) a.LSEo[(int64_t)b * a.heads + hh] = lt > 0.f ? (mm + __builtin_amdgcn_logf(lt)) * 0.6931471805599453f : INFINITY;
+    }
+}
+
 // ------------------------------------------------------------------ backward: dQ
 // Same decomposition as the forward: a lane owns a query, wave group g sweeps the key tiles g, g+G, ...; with G = 2
 // group 1's partial dQ is added to group 0's through LDS at the end.  Two register sets (prefetch distance 2).
@@ -1503,6 +1592,14 @@ extern "C" int kk_attn_fwd(const float *Q, const float *K, const float *V, float
     a.B = B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.causal = causal;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldout = ldo; a.scale = scale;
     a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(causal); a.dbg = attn_dbg(); a.wt = kk_write_through((int64_t)B * std::max(Sq, Sk));
+    if (Sq == 1 && a.seed == nullptr && !causal && Sk <= 8192 && ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 &&
+        (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) == 0) {  // a decoder step of the incremental path: one (batch, head) per workgroup
+        const size_t lds = (size_t)(((Sk + 3) & ~3) + 16 * 64 + 32) * sizeof(float);
+        if (io_bf16) hipLaunchKernelGGL(attn_decode_kernel<__bf16>, dim3(B * heads), dim3(1024), lds, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(attn_decode_kernel<float>, dim3(B * heads), dim3(1024), lds, (hipStream_t)stream, a);
+        KK_LAUNCH_CHECK("kk_attn_fwd");
+        return 0;
+    }
     dim3 grid(kk_cdiv(Sq, 128), B * heads);
     const int G = (Sk > 64 && g_attn_groups == 2) ? 2 : 1;          // one key tile: nothing to split
     // second-generation kernel (DMA-staged, software-pipelined): bf16 storage, two key groups, 16-byte aligned operands

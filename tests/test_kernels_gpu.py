@@ -1092,6 +1092,41 @@ def test_gemm_wgrad_group(kk, T, shapes, split):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("B,h,Sk,time_major", [(2, 8, 600, False), (1, 16, 37, True), (3, 8, 1, False), (1, 8, 1500, True)])
+def test_attention_decode_step(kk, bf16, B, h, Sk, time_major):
+    """kk_attn_fwd at Sq = 1 (the incremental path of transformers.py:237-253: one decoder step against the KV cache / the memory) takes
+    the decode kernel — one (batch, head) per workgroup — and equals a float64 softmax(q.K^T / 8).V under a key mask, for both layouts
+    generate() uses: batch-major K|V rows (cross-attention) and the time-major cache [t][B*H] seen as ONE batch of B*h heads."""
+    g = torch.Generator().manual_seed(Sk + B)
+    H = h * 64
+    dt = torch.bfloat16 if bf16 else torch.float32
+    q = dev(torch.randn(B, H, generator=g)).to(dt)
+    K, V = dev(torch.randn(B, Sk, H, generator=g)).to(dt), dev(torch.randn(B, Sk, H, generator=g)).to(dt)
+    mask = torch.rand(B, Sk, generator=g) < 0.3
+    mask[:, 0] = False
+    if B > 1:
+        mask[B - 1] = True                                     # a fully masked batch item: zero output, lse = inf
+    if time_major:                                             # ONE batch, B*h heads, rows = time steps; the mask is per time step
+        assert B == 1
+    out, lse = torch.empty(B, H, device="cuda", dtype=dt), torch.empty(B, h, 1, device="cuda")
+    kk.call("kk_attn_fwd", q, K, V, out, lse, B, h, 1, Sk, H, H, H, H, dev(mask.to(torch.uint8)), 0, 0.125, _seed(), 0, 0.0,
+            1 if bf16 else 0, 1 if bf16 else 0)
+    torch.cuda.synchronize()
+    qd, Kd, Vd = q.double().cpu().view(B, h, 64), K.double().cpu().view(B, Sk, h, 64), V.double().cpu().view(B, Sk, h, 64)
+    s = torch.einsum("bhd,bkhd->bhk", qd, Kd) * 0.125
+    s = s.masked_fill(mask[:, None, :], float("-inf"))
+    p = torch.softmax(s, dim=-1).nan_to_num(0.0)
+    ref = torch.einsum("bhk,bkhd->bhd", p, Vd).reshape(B, H)
+    close(out.float(), ref.float(), 2e-2 if bf16 else 2e-5, 1e-2 if bf16 else 1e-5, "decode attention")
+    ref_lse = torch.logsumexp(s, dim=-1)
+    live = ~mask.all(dim=1)
+    close(lse.view(B, h)[live.cuda()], ref_lse[live].float(), 1e-4, 1e-5, "decode attention log-sum-exp")
+    if B > 1:
+        assert bool((out[B - 1] == 0).all()) and bool(torch.isinf(lse[B - 1]).all())
+
+
+@pytest.mark.gpu
 def test_copy_many(kk):
     g = torch.Generator().manual_seed(5)
     srcs = [dev(torch.randn(n, generator=g)) for n in (1, 7, 4096, 5000, 40000)] + \
