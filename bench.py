@@ -428,6 +428,10 @@ def main():
         raise RuntimeError("a group barrier of the fused encoder launch timed out during the timed region: the number is void")
 
     roof, table = None, {}
+    # From here on rank 0 works ALONE (roofline leg, extra shapes, baselines) while the other ranks wait at the barrier below: the
+    # in-step exchange must be detached first — an eager forward_backward with eng.dp_comm set would issue RCCL collectives that no
+    # other rank matches (a hang, not an error).  The timed numbers are already taken.
+    eng.dp_comm = None
     if rank == 0 and not args.no_roofline and dyn is None:
         # Roofline leg: the same step, eager, every launch bracketed by events on the launch stream.
         kk.profile_start()
