@@ -103,7 +103,8 @@ def kernel_table(records, math_bf16: bool):
         elif name == "kk_attn_bwd":                     # (B, h, Sq, Sk, 7 row strides, causal, scale, site, p_drop, math, io_bf16)
             B, h, Sq, Sk = (int(x) for x in sc[:4])
             causal = int(sc[-6])
-            key = "attn_bwd_pair2_kernel (dQ | dK, dV in one launch)"
+            # (the text encoder's one-tile launches, S <= 64, are a different regime from the decoder's: listed apart)
+            key = "attn_bwd_pair2_kernel (dQ | dK, dV in one launch)" + (", one-tile sequences (text encoder)" if max(Sq, Sk) <= 64 else "")
             # §8d: training = 3 x forward, no credit for recomputation — the backward of the forward's 2 matmuls is 4 (dV, dP, dQ, dK);
             # the launch EXECUTES 7 (S and dP are computed by both halves): executed work is not algorithmic work
             flops = 4 * 2.0 * B * h * Sq * Sk * 64 * (0.5 if causal else 1.0)
@@ -460,6 +461,8 @@ def main():
         dom = entry(ranked[0])
         roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": dom["frac"],
                 "traffic": dom["traffic"], "traffic_unit": "bytes/launch", "traffic_source": dom["pmc_method"],
+                "traffic_scope": "mean over ALL launches of the kernel symbol in the PMC pass (for the attention pair launch that includes the "
+                                 "text encoder's six one-tile launches per step, which the rate above lists apart)",
                 "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "launches_per_step": dom["launches_per_step"],
                 "avg_launch_us": dom["avg_launch_us"], "algorithmic_gflop_per_launch": dom["algorithmic_gflop_per_launch"],
                 "mfma_busy": dom["mfma_busy"],
