@@ -63,3 +63,15 @@ def test_ragged_workload_respects_the_frame_budget(monkeypatch):
         assert B * T <= 16384 and 4 <= B <= 32 and int(x["mel_lengths"].max()) == T
         assert torch.equal(x["phoneme_durations"].sum(1), x["mel_lengths"])
     assert len({tuple(x["mel_specs"].shape[:2]) for x in batches}) >= 6
+
+
+def test_bench_detaches_the_in_step_exchange_before_rank0_only_legs():
+    """After the timed region rank 0 runs the eager roofline leg ALONE while the other ranks wait at a barrier: with eng.dp_comm still
+    set, its forward_backward would issue RCCL collectives that no other rank matches (a hang at N > 1 that a 1-rank rehearsal cannot
+    show).  bench.py must drop the exchange before anything rank-0-only launches kernels — checked on the source, in order."""
+    import os
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
+    timed = src.index("regions.append(float(dt_r))")
+    detach = src.index("eng.dp_comm = None", timed)
+    first_alone = min(src.index("kk.profile_start()", timed), src.index("extra_shapes(eng)", timed))
+    assert timed < detach < first_alone
