@@ -10,6 +10,7 @@ extern "C" {
 int kk_gemm_tune(int tm_threshold, int xcd_swizzle);
 int kk_gemm_tune16(int enable, int thr128, int thr12864, int split_target);
 int kk_gemm_tune_group(int split);
+int kk_gemm_tune16x(int on, int force, int dbg);   /* large-tile family (csrc/kk_gemm16x.hip): enable bits, forced tile, probe bits */
 #ifdef __cplusplus
 }
 #endif

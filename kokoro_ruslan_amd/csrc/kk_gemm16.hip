@@ -15,7 +15,7 @@
 //     with a function of k; fragments (8 consecutive k per lane) come from two ds_read_b64_tr_b16 — the hardware
 //     4x16 transpose read — so no software transpose exists anywhere.
 // Out-of-range rows (tile edges, the K tail of a k-strided operand) are zero-filled by the buffer bounds check.
-#include "kk_common.h"
+#include "kk_gemm16.h"
 #include <algorithm>
 #include <stdlib.h>
 
@@ -25,41 +25,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
 
-struct G16Args {
-    int M, N, K;
-    float alpha, beta;
-    const void *A, *B;
-    const float *bias, *residual;
-    void *C;
-    int c_bf16;
-    int64_t lda, ldb, ldc, ldr, res_mod;
-    int k_per_split, atomic, splits, split_major;
-    int tiles_m, tiles_n, xcd_swizzle;
-    int m_fast;                                                 // tile order inside an XCD's run: 0 = n fastest, 1 = m fastest (see gemm16_body)
-    int wt;                                                     // write-through stores of C and the epilogues' outputs (kk_common.h: kk_write_through)
-    uint32_t a_bytes, b_bytes;
-    // EPI == 1 (GLU backward epilogue): C is not written; see gemm16_kernel
-    const __bf16 *glu_h;
-    __bf16 *glu_dh;
-    float *glu_partials;
-    const uint32_t *glu_seed;
-    uint32_t glu_site;
-    float glu_p;
-    // EPI == 3 (per-head RMSNorm + RoPE epilogue): C receives the raw projection, hn_y the normalised one
-    const float *hn_gain[12];                                   // one gain vector per part (a part = hn_H columns: q | k | v | ...)
-    const float *hn_cos, *hn_sin;
-    __bf16 *hn_y;
-    int64_t hn_ldy;
-    int hn_S, hn_H, hn_rope_mask;
-    // Delta epilogue (eight-wave 128x64 tile, bf16 C; the dgrad of an attention output projection): the tile's 64 columns are
-    // one head of dO = dY.W_o, so Delta[b, head, q] = sum_d dO * O (the attention backward's row term) leaves with it
-    const __bf16 *dl_o;
-    float *dl_out;
-    int64_t dl_ldo;
-    int dl_S, dl_heads;
-};
 
-constexpr int BK = 64;
 
 // One operand tile of ROWS x 64: DMA issue + fragment reads.
 template <int ROWS, bool KS, int NT = 256> struct Operand {
@@ -633,12 +599,6 @@ int g16_w8 = kk_tune_env("KK_G16_W8", 3);
 // Several independent GEMMs of one operand layout in ONE launch (a layer's weight gradients: they have no consumer
 // before the optimizer, so they wait until the layer's backward is through and then fill the chip together — ~1000
 // 64x64 tiles with the full reduction length each, no split-K atomics, one launch instead of four to six).
-constexpr int GROUP_MAX = 8;
-struct G16Group {
-    int n;
-    int start[GROUP_MAX + 1];                                   // first workgroup of each problem
-    G16Args p[GROUP_MAX];
-};
 template <bool TA, bool TB, int BM, int BN, int NS, int WAVES = 4, int WC = 2>
 __global__ __launch_bounds__(64 * WAVES) void gemm16_group_kernel(G16Group g) {
     __shared__ __attribute__((aligned(16))) char smem[NS * (BM + BN) * BK * 2];
@@ -720,6 +680,27 @@ int g16_group_waves = kk_tune_env("KK_GROUP_WAVES", 8);   // 8-wave workgroups o
 int g16_group_mfast = kk_tune_env("KK_GROUP_MFAST", 1);  // grouped launches: sweep direction by operand size (0: always n fastest)
 int g16_group_split = 0;                                        // grouped launches: 0 = by the split target, n = n k-slices
 
+// ---- the large-tile family (kk_gemm16x.hip) ------------------------------------------------------------------------------------
+// A CU's L2 -> LDS stream runs at ~20 B/clk whatever a kernel does, so a launch's floor is the bytes that pass
+// through its BUSIEST CU: rounds of workgroups x (BM + BN) x K x 2.  Every candidate tile is priced by that number (in units of
+// K x 2 bytes) and the cheapest one runs; ties go to the smaller tile (more workgroups in flight, shorter prologue / epilogue).
+int g16x_on = kk_tune_env("KK_G16X", 15);              // tools: bit 0 plain, 1 head-norm, 2 GLU forward / backward, 3 grouped weight gradients
+int g16x_min_k_group = kk_tune_env("KK_G16X_GROUP_MIN_K", 1024);
+int g16x_min_k_plain = kk_tune_env("KK_G16X_PLAIN_MIN_K", 1024);
+int g16x_min_n_hn = kk_tune_env("KK_G16X_HN_MIN_N", 1024);
+int g16x_dbg = kk_tune_env("KK_G16X_DBG", 0);         // tools: probe bits of g16x_body (1 no epilogue, 4 no MFMAs, 8 DMA + barriers only)
+int g16x_force = kk_tune_env("KK_G16X_FORCE", -1);
+void *g16x_trace = nullptr;                            // tools: destination of probe bit 32    // tools: this tile for every head-norm / plain launch of the family
+int g16_cus() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) return v;
+        return 256;
+    }();
+    return n;
+}
+long g16_cost(int64_t tiles, int bm, int bn) { return (long)((tiles + g16_cus() - 1) / g16_cus()) * (bm + bn); }
+
 }  // namespace
 
 // Tuning hook used by tools/ (not part of the C ABI).
@@ -731,6 +712,13 @@ void kk_gemm16_tune(int thr128, int thr12864, int split_target) {
     g16_split_target = split_target % 10000;
 }
 void kk_gemm16_tune_group(int split) { g16_group_split = split % 100; g16_group_tile = split / 100; }
+#ifdef KK_TUNING_HOOKS
+// tools: large-tile family on/off bits, forced tile (-1 = by cost), probe bits
+extern int g16x_lw;
+extern "C" int kk_gemm_tune16x(int on, int force, int dbg) { g16x_on = on & 255; g16x_lw = (on >> 8) & 1 ? 0 : ((on >> 9) & 1 ? 2 : 1); g16x_force = force; g16x_dbg = dbg; return 0; }
+void kk_g16x_probe(int bits, void *buf);
+extern "C" int kk_gemm_trace16x(void *buf) { g16x_trace = buf; kk_g16x_probe(g16x_dbg, buf); return 0; }      // probe bit 32: 8 waves x 64 stamps (uint64) of workgroup 0
+#endif
 
 // True when this core can run the problem (both operands bf16 assumed by the caller).
 bool kk_gemm16_eligible(int ta, int tb, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda, const void *B, int64_t ldb) {
@@ -784,6 +772,27 @@ int kk_gemm16_launch(int ta, int tb, int64_t M, int64_t N, int64_t K, float alph
     a.xcd_swizzle = xcd_swizzle;
     a.a_bytes = (uint32_t)(((ta ? (K - 1) * lda + M : (M - 1) * lda + K)) * 2);
     a.b_bytes = (uint32_t)(((tb ? (K - 1) * ldb + N : (N - 1) * ldb + K)) * 2);
+    // (long reductions only: at K = 512 a one-workgroup-per-CU launch shows its whole prologue and epilogue, two 128x64 workgroups per CU
+    // hide each other's — measured 9.5 against 10.3 us at 8192 x 512 x 512, 46 against 37 us at K = 3072; weight-gradient layouts: grouped launches only)
+    if ((g16x_on & 1) && splits == 1 && !ta && K >= g16x_min_k_plain) {
+        const long cost_old = g16_cost(tiles, BM, BN);
+        int best = -1;
+        long best_cost = cost_old;
+        for (int cfg : {G16X_128x128, G16X_256x128}) {
+            int bm, bn;
+            kk_g16x_tile(cfg, &bm, &bn);
+            const long c = g16_cost((int64_t)cd(M, bm) * cd(N, bn), bm, bn);
+            if (c < best_cost) { best = cfg; best_cost = c; }
+        }
+        if (g16x_force == G16X_128x128 || g16x_force == G16X_256x128) best = g16x_force;
+        if (best >= 0) {
+            int bm, bn;
+            kk_g16x_tile(best, &bm, &bn);
+            a.tiles_m = cd(M, bm); a.tiles_n = cd(N, bn); a.dbg = g16x_dbg;
+            a.k_per_split = ktiles * BK; a.atomic = 0; a.splits = 1; a.split_major = 0;
+            return kk_g16x_plain(best, ta, tb, a, s);
+        }
+    }
     if (splits > 1 && beta == 0.f) {
         const int e = kk_zero_async(C, (size_t)M * N * sizeof(float), s);
         if (e != 0) return e;
@@ -821,6 +830,13 @@ int kk_gemm16_dgrad_delta(int64_t M, int64_t N, int64_t K, const void *dy, int64
     a.a_bytes = (uint32_t)(((M - 1) * lddy + K) * 2);
     a.b_bytes = (uint32_t)(((K - 1) * ldw + N) * 2);
     a.dl_o = static_cast<const __bf16 *>(O); a.dl_out = delta; a.dl_ldo = ldo; a.dl_S = S; a.dl_heads = heads;
+    if ((g16x_on & 1) && K >= g16x_min_k_plain) {
+        const long c_old = g16_cost((int64_t)a.tiles_m * a.tiles_n, 128, 64), c_new = g16_cost((int64_t)cd(M, 128) * cd(N, 128), 128, 128);
+        if (c_new < c_old) {
+            a.tiles_m = cd(M, 128); a.tiles_n = cd(N, 128);
+            return kk_g16x_plain(G16X_128x128, 0, 1, a, s);
+        }
+    }
     dim3 grid(a.tiles_m * a.tiles_n);
     if (cd(K, BK) >= 3 && g16_stages >= 3 && g16_w8 >= 3) launch_w8<3>(0, 1, a, grid, s);
     else launch_w8<2>(0, 1, a, grid, s);
@@ -841,6 +857,13 @@ int kk_gemm16_dgrad_glu(int64_t T, int64_t F, int64_t H, const void *dy, int64_t
     a.b_bytes = (uint32_t)(((H - 1) * F + F) * 2);
     a.glu_h = static_cast<const __bf16 *>(h1); a.glu_dh = static_cast<__bf16 *>(dh1); a.glu_partials = partials;
     a.glu_seed = p > 0.f ? seed : nullptr; a.glu_site = site; a.glu_p = p;
+    if ((g16x_on & 4) && cd(H, BK) >= 3) {
+        const long c_old = g16_cost((int64_t)cd(T, 128) * cd(F, 64), 128, 64), c_new = g16_cost((int64_t)cd(T, 128) * cd(F, 192), 128, 192);
+        if (c_new < c_old) {
+            a.tiles_m = cd(T, 128); a.tiles_n = cd(F, 192);
+            return kk_g16x_glu_bwd(a, s);
+        }
+    }
     if ((g16_w8_glu & 1) && cd(H, BK) >= 3 && cd(T, 128) * cd(F, 64) >= g16_thr12864) {       // eight waves on 128x64 tiles, like the plain GEMMs
         a.tiles_m = cd(T, 128);
         hipLaunchKernelGGL((gemm16_kernel_w8_glu<true, 3, 1>), dim3(a.tiles_m * a.tiles_n), dim3(512), 0, s, a);
@@ -867,6 +890,13 @@ int kk_gemm16_linear_glu(int64_t T, int64_t F, int64_t K, const void *x, int64_t
     a.b_bytes = (uint32_t)(((2 * F - 1) * K + K) * 2);
     a.glu_dh = static_cast<__bf16 *>(h1);
     a.glu_seed = p > 0.f ? seed : nullptr; a.glu_site = site; a.glu_p = p;
+    if ((g16x_on & 4) && cd(K, BK) >= 3) {               // 256 rows x (96 + 96) columns per workgroup against 64 x (64 + 64)
+        const long c_old = g16_cost((int64_t)cd(T, 64) * cd(F, 64), 64, 128), c_new = g16_cost((int64_t)cd(T, 256) * cd(F, 96), 256, 192);
+        if (c_new < c_old) {
+            a.tiles_m = cd(T, 256); a.tiles_n = cd(F, 96);
+            return kk_g16x_glu_fwd(a, s);
+        }
+    }
     if ((g16_w8_glu & 2) && cd(K, BK) >= 3 && cd(T, 128) * cd(F, 64) >= g16_thr12864) {
         a.tiles_m = cd(T, 128);
         hipLaunchKernelGGL((gemm16_kernel_w8_glu<false, 3, 2>), dim3(a.tiles_m * a.tiles_n), dim3(512), 0, s, a);
@@ -892,6 +922,33 @@ int kk_gemm16_wgrad_group(const KkWgradDesc *d, int n, int split_k, int overwrit
         total += cd(d[i].M, BM) * cd(d[i].N, BN);
     }
     int splits = 1;
+    {   // 128x128 tiles of the large-tile family: full reductions only, long ones (short launches sit on the side branch, where
+        // a 96 KB workgroup keeps the main chain's workgroups waiting)
+        int total_x = 0;
+        int64_t kmin = 1ll << 40;
+        for (int i = 0; i < n; ++i) { total_x += cd(d[i].M, 128) * cd(d[i].N, 128); kmin = std::min<int64_t>(kmin, d[i].T); }
+        const bool old_splits = split_k > 1 || g16_group_split > 1 || (split_k <= 0 && !overwrite && total * 2 <= g16_split_target);
+        if ((g16x_on & 8) && !old_splits && kmin >= g16x_min_k_group && g16_cost(total_x, 128, 128) < g16_cost(total, BM, BN)) {
+            G16Group g = {};
+            g.n = n;
+            for (int i = 0; i < n; ++i) {
+                const int64_t M = d[i].M, N = d[i].N, K = d[i].T;
+                G16Args &a = g.p[i];
+                a.M = (int)M; a.N = (int)N; a.K = (int)K;
+                a.wt = kk_write_through(K);
+                a.alpha = 1.f; a.beta = overwrite ? 0.f : 1.f;
+                a.A = d[i].dy; a.B = d[i].x; a.C = d[i].dw;
+                a.lda = d[i].lddy; a.ldb = d[i].ldx; a.ldc = d[i].lddw;
+                a.k_per_split = cd(K, BK) * BK; a.splits = 1;
+                a.tiles_m = cd(M, 128); a.tiles_n = cd(N, 128); a.xcd_swizzle = xcd_swizzle;
+                a.m_fast = (g16_group_mfast && xcd_swizzle && M < N) ? 1 : 0;
+                a.a_bytes = (uint32_t)(((K - 1) * a.lda + M) * 2);
+                a.b_bytes = (uint32_t)(((K - 1) * a.ldb + N) * 2);
+                g.start[i + 1] = g.start[i] + a.tiles_m * a.tiles_n;
+            }
+            return kk_g16x_group(g, g.start[n], s);
+        }
+    }
     if (split_k > 0) splits = split_k;                            // the caller's k-slice count (0 = by the split target)
     else if (g16_group_split > 0) splits = g16_group_split;
     else if (total * 2 <= g16_split_target) splits = cd(g16_split_target, total);
@@ -947,6 +1004,24 @@ int kk_gemm16_qkv_headnorm(int64_t T, int parts, int heads, int64_t K, const voi
     for (int i = 0; i < parts; ++i) a.hn_gain[i] = gains[i];
     a.hn_cos = cos_t; a.hn_sin = sin_t; a.hn_y = static_cast<__bf16 *>(y); a.hn_ldy = ldy;
     a.hn_S = S; a.hn_H = heads * 64; a.hn_rope_mask = rope_mask;
+    if ((g16x_on & 2) && cd(K, BK) >= 3 && N >= g16x_min_n_hn && ldraw % 8 == 0 && ldy % 8 == 0 && (((uintptr_t)raw | (uintptr_t)y) & 15) == 0) {      // (16-byte stores)
+        const bool w8 = g16_w8_hn && cd(T, 128) * cd(N, 64) >= g16_thr12864;
+        int best = -1;
+        long best_cost = w8 ? g16_cost((int64_t)cd(T, 128) * cd(N, 64), 128, 64) : g16_cost((int64_t)cd(T, 64) * cd(N, 64), 64, 64);
+        for (int cfg : {G16X_128x128, G16X_128x192, G16X_256x128, G16X_256x192}) {
+            int bm, bn;
+            kk_g16x_tile(cfg, &bm, &bn);
+            const long c = g16_cost((int64_t)cd(T, bm) * cd(N, bn), bm, bn);
+            if (c < best_cost) { best = cfg; best_cost = c; }
+        }
+        if (g16x_force >= 0) best = g16x_force;
+        if (best >= 0) {
+            int bm, bn;
+            kk_g16x_tile(best, &bm, &bn);
+            a.tiles_m = cd(T, bm); a.tiles_n = cd(N, bn); a.dbg = g16x_dbg;
+            return kk_g16x_headnorm(best, a, s);
+        }
+    }
     if (g16_w8_hn && cd(K, BK) >= 3 && cd(T, 128) * cd(N, 64) >= g16_thr12864) {       // eight waves on 128x64 tiles, like the plain GEMMs
         a.tiles_m = cd(T, 128);
         hipLaunchKernelGGL((gemm16_kernel_w8_hn<3>), dim3(a.tiles_m * a.tiles_n), dim3(512), 0, s, a);
