@@ -39,67 +39,153 @@ def train_flops(B: int, T: int, P: int, H=512, F=1536, Le=6, Ld=6, M=80, Fv=256)
     return 6.0 * macs
 
 GEMM_ROLE = {(0, 0): "X.W^T fwd", (0, 1): "dY.W dgrad", (1, 1): "dY^T.X wgrad", (1, 0): "X^T.W"}
-PMC_ROUNDS = ("r03", "r02h", "r02g")       # profiles/<round>_pmc_hbm_traffic_BxTxP.json, newest first (tools/rocprof_pmc.sh: separate --pmc passes)
+PMC_ROUNDS = ("r04", "r03", "r02h", "r02g")       # profiles/<round>_pmc_hbm_traffic_BxTxP.json, newest first (tools/rocprof_pmc.sh: separate --pmc passes)
+
+
+CUS = 256                                  # MI355X; the tile policy prices a launch by the bytes through its busiest CU
+L2_LDS_BPS = 256 * 46e9                    # the chip's L2 -> LDS stream as DESIGN section 9 measured it (46 GB/s per CU)
+
+
+def _cd(x, y):
+    return -(-x // y)
+
+
+def _cost(tiles, bm, bn):
+    return _cd(tiles, CUS) * (bm + bn)
+
+
+def x_tile(kind, M, N, K):
+    """(BM, BN, name) of the large-tile family's kernel for this launch, or None when kk_gemm16.hip keeps its 64x64 / 128x64 tiles
+    (mirrors g16_cost / the thresholds of kk_gemm16.hip: plain and Delta launches need K >= 1024, head-norm ones N >= 1024)."""
+    if kind in ("plain0", "plain1", "delta"):                    # X.W^T / dY.W; Delta = dY.W on 128x128 only
+        if K < 1024:
+            return None
+        bm0, bn0 = (128, 64) if _cd(M, 128) * _cd(N, 64) >= 128 else (64, 64)
+        best, bc = None, _cost(_cd(M, bm0) * _cd(N, bn0), bm0, bn0)
+        for bm, bn in ((128, 128),) if kind == "delta" else ((128, 128), (256, 128)):
+            c = _cost(_cd(M, bm) * _cd(N, bn), bm, bn)
+            if c < bc:
+                best, bc = (bm, bn), c
+        if best is None:
+            return None
+        tb = "false" if kind == "plain0" else "true"
+        return best + (f"g16x_kernel<false,{tb},{best[0]},{best[1]},3,0,2,2,4>",)
+    if kind == "hn":
+        if N < 1024 or K < 192:
+            return None
+        bm0, bn0 = (128, 64) if _cd(M, 128) * _cd(N, 64) >= 128 else (64, 64)
+        best, bc = None, _cost(_cd(M, bm0) * _cd(N, bn0), bm0, bn0)
+        for bm, bn in ((128, 128), (128, 192), (256, 128), (256, 192)):
+            c = _cost(_cd(M, bm) * _cd(N, bn), bm, bn)
+            if c < bc:
+                best, bc = (bm, bn), c
+        if best is None:
+            return None
+        cfg = "2,3,4,2,0" if best == (256, 192) else "3,3,2,2,4"
+        return best + (f"g16x_kernel<false,false,{best[0]},{best[1]},{cfg}>",)
+    if kind == "glu_fwd":                                        # N = F: 256 rows x (96 + 96) columns against 64 x (64 + 64)
+        if K < 192 or _cost(_cd(M, 256) * _cd(N, 96), 256, 192) >= _cost(_cd(M, 64) * _cd(N, 64), 64, 128):
+            return None
+        return (256, 192, "g16x_kernel<false,false,256,192,2,2,8,1,0>")
+    if kind == "glu_bwd":
+        if K < 192 or _cost(_cd(M, 128) * _cd(N, 192), 128, 192) >= _cost(_cd(M, 128) * _cd(N, 64), 128, 64):
+            return None
+        return (128, 192, "g16x_kernel<false,true,128,192,3,1,2,2,4>")
+    return None
+
+
+def lds_floor_us(macs, bm, bn):
+    """The launch's L2 -> LDS floor: 2 B x MACs x (1 / BM + 1 / BN) through 256 CUs at 46 GB/s each."""
+    return 2.0 * macs * (1.0 / bm + 1.0 / bn) / L2_LDS_BPS * 1e6
 
 
 def gemm_symbol(ta, tb, M, N, K, math_bf16, dtypes):
-    """Name of the kernel instantiation kk_gemm launches for this call (mirrors the dispatch in kk_gemm.hip / kk_gemm16.hip)."""
+    """(kernel instantiation kk_gemm launches for this call, BM, BN) — mirrors the dispatch in kk_gemm.hip / kk_gemm16.hip."""
     b = lambda v: "true" if v else "false"
-    if math_bf16 and (dtypes & 3) == 3 and (K % 64 == 0 or (ta and tb)):      # DMA-staged bf16 x bf16 core, 64x64 tiles here
-        cd = lambda x, y: -(-x // y)
+    if math_bf16 and (dtypes & 3) == 3 and (K % 64 == 0 or (ta and tb)):      # DMA-staged bf16 x bf16 core
+        cd = _cd
+        if not ta:
+            x = x_tile("plain1" if tb else "plain0", M, N, K)
+            if x is not None:
+                return f"{x[2]} ({GEMM_ROLE[(ta, tb)]}, {x[0]}x{x[1]} tiles, loader waves)", x[0], x[1]
         if cd(M, 128) * cd(N, 64) >= 128 and os.environ.get("KK_G16_W8", "3") != "0":      # eight waves on 128x64 tiles
-            return f"gemm16_kernel_w8<{b(ta)},{b(tb)},{3 if cd(K, 64) >= 3 else 2}> ({GEMM_ROLE[(ta, tb)]}, 128x64 tiles)"
+            return f"gemm16_kernel_w8<{b(ta)},{b(tb)},{3 if cd(K, 64) >= 3 else 2}> ({GEMM_ROLE[(ta, tb)]}, 128x64 tiles)", 128, 64
         tiles, ktiles = cd(M, 64) * cd(N, 64), cd(K, 64)
         splits = 1
         if tiles * 2 <= 384 and not (dtypes & 4):
             splits = max(1, min(cd(384, tiles), max(ktiles // 2, 1)))
         ns = 2 if ktiles // splits < 3 else 3
-        return f"gemm16_kernel<{b(ta)},{b(tb)},64,64,{ns}> ({GEMM_ROLE[(ta, tb)]})"
+        return f"gemm16_kernel<{b(ta)},{b(tb)},64,64,{ns}> ({GEMM_ROLE[(ta, tb)]})", 64, 64
     tile = 128 if -(-M // 128) * -(-N // 128) >= 512 else 64
-    return f"gemm_kernel<{b(ta)},{b(tb)},{b(math_bf16)},{tile}> ({GEMM_ROLE[(ta, tb)]})"
+    return f"gemm_kernel<{b(ta)},{b(tb)},{b(math_bf16)},{tile}> ({GEMM_ROLE[(ta, tb)]})", tile, tile
 
 
 def kernel_table(records, math_bf16: bool):
     """Aggregate per-launch event timings into {kernel: {launches, ms, flops, bytes}}."""
     agg = {}
     for name, sc, ms in records:
-        flops = byts = 0.0
+        flops = byts = floor = 0.0
         key = name
         if name == "kk_gemm":
             ta, tb, M, N, K = (int(x) for x in sc[:5])
             dt = int(sc[-1])               # storage bits: A, B, C bf16
-            key = gemm_symbol(ta, tb, M, N, K, math_bf16, dt)
+            key, bm_, bn_ = gemm_symbol(ta, tb, M, N, K, math_bf16, dt)
             flops = 2.0 * M * N * K
+            floor = lds_floor_us(M * N * K, bm_, bn_)
             byts = (2.0 if dt & 1 else 4.0) * M * K + (2.0 if dt & 2 else 4.0) * N * K + (2.0 if dt & 4 else 4.0) * M * N
         elif name == "kk_gemm_wgrad_group":             # (n, split_k, overwrite, then M, N, T of every problem); 128x64 tiles, see kk_gemm16.hip
             dims = [int(x) for x in sc[3:]]
             overwrite = int(sc[2])
             probs = [dims[i:i + 3] for i in range(0, len(dims), 3)]
-            key = "gemm16_group_kernel<true,true,128,64,2,8> (a layer's dY^T.X wgrads, one launch)"
+            key, bm_, bn_ = "gemm16_group_kernel<true,true,128,64,2,8> (a layer's dY^T.X wgrads, one launch)", 128, 64
+            # (mirrors kk_gemm16_wgrad_group: 128x128 tiles of the large-tile family for long reductions that fill the chip without k-slices)
+            t_old = sum(_cd(M, 128) * _cd(N, 64) for M, N, _ in probs)
+            t_new = sum(_cd(M, 128) * _cd(N, 128) for M, N, _ in probs)
+            if min(T_ for _, _, T_ in probs) >= 1024 and (overwrite or t_old * 2 > 384) and _cost(t_new, 128, 128) < _cost(t_old, 128, 64):
+                key, bm_, bn_ = "g16x_group_kernel<true,true,128,128,3,2,2,4> (a layer's dY^T.X wgrads, one launch, 128x128 tiles, loader waves)", 128, 128
             flops = sum(2.0 * M * N * T_ for M, N, T_ in probs)
+            floor = lds_floor_us(sum(M * N * T_ for M, N, T_ in probs), bm_, bn_)
             byts = sum(2.0 * T_ * (M + N) + (4.0 if overwrite else 8.0) * M * N for M, N, T_ in probs)   # bf16 operands, fp32 dW (read +) written
         elif name == "kk_gemm_linear_glu":              # (T, F, K, ...): h1 = x.W1^T (2F columns) + gate
             T_, F_, K_ = (int(x) for x in sc[:3])
-            key = "gemm16_kernel<false,false,64,64,2,2> (X.W1^T + GLU gate epilogue)"
+            key, bm_, bn_ = "gemm16_kernel<false,false,64,64,2,2> (X.W1^T + GLU gate epilogue)", 64, 128
+            x = x_tile("glu_fwd", T_, F_, K_)
+            if x is not None:
+                key, bm_, bn_ = f"{x[2]} (X.W1^T + GLU gate epilogue, 256 x (96 + 96) tiles)", x[0], x[1]
             flops, byts = 2.0 * T_ * 2 * F_ * K_, 2.0 * (T_ * K_ + 2 * F_ * K_ + 3 * T_ * F_)
+            floor = lds_floor_us(T_ * 2 * F_ * K_, bm_, bn_)
         elif name == "kk_gemm_dgrad_glu":               # (T, F, H, ...): dG = dY.W2 + gate backward
             T_, F_, H_ = (int(x) for x in sc[:3])
             key = f"gemm16_kernel<false,true,64,64,{2 if H_ // 64 < 3 else 3},1> (dY.W2 + GLU backward epilogue)"
             if H_ // 64 >= 3 and -(-T_ // 128) * -(-F_ // 64) >= 128 and int(os.environ.get("KK_G16_W8_GLU", "1")) & 1:
                 key = "gemm16_kernel_w8_glu (dY.W2 + GLU backward epilogue, 128x64 tiles)"
+            bm_, bn_ = (128, 64) if "w8" in key else (64, 64)
+            x = x_tile("glu_bwd", T_, F_, H_)
+            if x is not None:
+                key, bm_, bn_ = f"{x[2]} (dY.W2 + GLU backward epilogue, 128x192 tiles, loader waves)", x[0], x[1]
             flops, byts = 2.0 * T_ * F_ * H_, 2.0 * (T_ * H_ + F_ * H_ + 4 * T_ * F_)
+            floor = lds_floor_us(T_ * F_ * H_, bm_, bn_)
         elif name == "kk_gemm_qkv_headnorm":            # (T, parts, heads, K, ...)
             T_, parts, heads, K_ = (int(x) for x in sc[:4])
             N_ = parts * heads * 64
             key = f"gemm16_kernel<false,false,64,64,{2 if K_ // 64 < 3 else 3},3> (q|k|v projection + head-norm epilogue)"
             if K_ // 64 >= 3 and -(-T_ // 128) * -(-N_ // 64) >= 128 and os.environ.get("KK_G16_W8_HN", "1") != "0":
                 key = "gemm16_kernel_w8_hn (q|k|v projection + head-norm epilogue, 128x64 tiles)"
+            bm_, bn_ = (128, 64) if "w8" in key else (64, 64)
+            x = x_tile("hn", T_, N_, K_)
+            if x is not None:
+                key, bm_, bn_ = f"{x[2]} (q|k|v projection + head-norm epilogue, {x[0]}x{x[1]} tiles)", x[0], x[1]
             flops, byts = 2.0 * T_ * N_ * K_, 2.0 * (T_ * K_ + N_ * K_ + 2 * T_ * N_)
+            floor = lds_floor_us(T_ * N_ * K_, bm_, bn_)
         elif name == "kk_gemm_dgrad_delta":             # (M, N, K, ...): the w_o dgrad with the Delta epilogue, same instantiation as kk_gemm's
             M, N, K = (int(x) for x in sc[:3])
             ta, tb = 0, 1
-            key = gemm_symbol(0, 1, M, N, K, math_bf16, 7)
+            key, bm_, bn_ = gemm_symbol(0, 1, M, N, K, math_bf16, 7)
+            x = x_tile("delta", M, N, K)
+            if x is not None:
+                key, bm_, bn_ = f"{x[2]} (dY.W dgrad + Delta epilogue, 128x128 tiles, loader waves)", x[0], x[1]
             flops, byts = 2.0 * M * N * K, 2.0 * (M * K + N * K + 2 * M * N)
+            floor = lds_floor_us(M * N * K, bm_, bn_)
         elif name == "kk_attn_bwd":                     # (B, h, Sq, Sk, 7 row strides, causal, scale, site, p_drop, math, io_bf16)
             B, h, Sq, Sk = (int(x) for x in sc[:4])
             causal = int(sc[-6])
@@ -126,11 +212,12 @@ def kernel_table(records, math_bf16: bool):
         elif name.startswith("kk_attn_") and name != "kk_attn_delta":
             keys.append(f"  shape {name} B={B} h={h} Sq={Sq} Sk={Sk} causal={causal}")
         for kq in keys:
-            a = agg.setdefault(kq, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            a = agg.setdefault(kq, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "floor_us": 0.0})
             a["launches"] += 1
             a["ms"] += ms
             a["flops"] += flops
             a["bytes"] += byts
+            a["floor_us"] += floor
     return agg
 
 
@@ -160,7 +247,7 @@ def oracle_steps(B, T, P, device, dropout, steps, warmup=1):
     return times
 
 
-def cpu_baseline(B, T, P, steps=2, full=False):
+def cpu_baseline(B, T, P, steps=3, full=False):
     """The oracle (CPU restatement of the reference, proven equal to it by tests/golden/make_golden.py) timed on this box's
     host cores: a bounded sample — 1 warm-up + `steps` timed steps of the bench batch with dropout off, then ONE timed step with
     the reference's training-time dropout on (SURVEY §8d asks for both: half of the reference's CPU step is dropout-mask
@@ -206,6 +293,93 @@ def pmc_entry(B, T, P, math, kernel):
     return None, None, None, None
 
 
+def attn_ffn_flops(B: int, T: int, P: int, H=512, F=1536, Le=6, Ld=6) -> float:
+    """SURVEY 8d's attention + FFN subset of train_flops(): the Cv (variance predictors) and 2MH + H (mel projections, stop head)
+    terms dropped — the FLOPs of the encoder and decoder FFT-block stacks, which is what `north_star`'s 40 % target is quoted on."""
+    macs = (B * P * (Le * (4 * H * H + 3 * H * F) + Le * 2 * P * H)
+            + B * T * (Ld * (8 * H * H + 3 * H * F) + Ld * (2 * T * H + (T + 1) * H)))
+    return 6.0 * macs
+
+
+def roofline_leg(eng, kk, batches, math, pmc_shape):
+    """The dominant-kernel roofline of a workload: its step(s) run eagerly with every launch bracketed by events on the launch stream
+    (kk.profile_start), algorithmic FLOPs per SURVEY 8d.  batches: the workload's batches (one eager step each, two passes)."""
+    kk.profile_start()
+    for _ in range(2):
+        for b in batches:
+            eng.zero_grad()
+            eng._first_micro = True              # like the timed step: the first micro-batch of a cycle (weight gradients overwrite)
+            eng.forward_backward(b, loss_scale=eng.dp_loss_scale, adaptive=True)
+            eng._first_micro = False
+            eng.optimizer_step(b["mel_specs"].shape[1])
+    table = kernel_table(kk.profile_stop(), math == "bf16")
+    shapes = {k: v for k, v in table.items() if k.startswith("  shape")}
+    table = {k: v for k, v in table.items() if not k.startswith("  shape")}
+    mfma = {k: v for k, v in table.items() if v["flops"] > 0}
+    peak = PEAK_BF16_TFLOPS if math == "bf16" else PEAK_F32_TFLOPS
+    nsteps = 2 * len(batches)
+
+    def entry(name):
+        v = mfma[name]
+        ach = v["flops"] / (v["ms"] * 1e-3) / 1e12
+        traffic, busy, note, src = pmc_entry(*pmc_shape, math, name) if pmc_shape else (None, None, None, None)
+        e = {"kernel": name, "achieved": round(ach, 2), "frac": round(ach / peak, 4), "launches_per_step": round(v["launches"] / nsteps, 2),
+             "avg_launch_us": round(v["ms"] * 1e3 / v["launches"], 2),
+             "algorithmic_gflop_per_launch": round(v["flops"] / v["launches"] / 1e9, 3),
+             "algorithmic_bytes_per_launch": round(v["bytes"] / v["launches"]), "traffic": traffic, "mfma_busy": busy,
+             "pmc_source": src, "pmc_method": note}
+        if v["floor_us"] > 0:                    # GEMMs: the tile's L2 -> LDS floor (2 B x MACs x (1/BM + 1/BN) at 256 x 46 GB/s), per launch
+            e["l2_to_lds_floor_us"] = round(v["floor_us"] / v["launches"], 2)
+        return e
+    ranked = sorted(mfma, key=lambda k: -mfma[k]["ms"])
+    dom = entry(ranked[0])
+    roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": dom["frac"],
+            "traffic": dom["traffic"], "traffic_unit": "bytes/launch", "traffic_source": dom["pmc_method"],
+            "traffic_scope": "mean over ALL launches of the kernel symbol in the PMC pass (for the attention pair launch that includes the "
+                             "text encoder's six one-tile launches per step, which the rate above lists apart)",
+            "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "launches_per_step": dom["launches_per_step"],
+            "avg_launch_us": dom["avg_launch_us"], "algorithmic_gflop_per_launch": dom["algorithmic_gflop_per_launch"],
+            "mfma_busy": dom["mfma_busy"],
+            "flop_convention": "SURVEY 8d: 2 FLOP/MAC, causal = lower triangle, attention backward = 4 matmuls (no credit for the "
+                               "recomputed S / dP), event-timed on the launch stream in 2 eager steps",
+            # the other MFMA kernels by time, same accounting (mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x SIMDs), from
+            # the committed PMC pass of this shape; null where the pass has no entry)
+            "top_kernels": [{k: e[k] for k in ("kernel", "achieved", "frac", "launches_per_step", "avg_launch_us", "traffic", "mfma_busy",
+                                               "l2_to_lds_floor_us") if k in e} for e in (entry(n) for n in ranked[:8])]}
+    return roof, table, shapes
+
+
+def stack_fraction(eng, batch):
+    """`north_star`'s own number: the attention + FFN FLOP subset over the time the encoder and decoder stacks occupy in a
+    replayed step, from device time stamps captured into the step's graphs (one-thread kk_timestamp launches at the marks of the step:
+    they cost the traced step ~1 %).  Stack time = step start .. last decoder layer's forward, minus the length regulator / variance
+    adaptor segment, plus loss gradients .. backward joined (decoder backward with the text encoder's backward beside it)."""
+    B, T, P = batch["mel_specs"].shape[0], batch["mel_specs"].shape[1], batch["phoneme_indices"].shape[1]
+    was = eng.trace
+    eng.trace, eng._marks = True, {}
+    eng._mark_buf = torch.zeros(512, dtype=torch.int64, device=eng.device)
+    eng._graphs.clear()
+    try:
+        for _ in range(6):
+            eng.train_step_graphed(batch)
+        torch.cuda.synchronize()
+        rows = {n: t for t, n in eng.timeline()}
+    finally:
+        eng.trace = was
+        eng._graphs.clear()
+    last_dec = max(int(n[3:n.index(" ")]) for n in rows if n.startswith("dec") and n.endswith("fwd done"))
+    last_enc = max(int(n[3:n.index(" ")]) for n in rows if n.startswith("enc") and n.endswith("fwd done"))
+    fwd = rows[f"dec{last_dec} fwd done"] - rows["step.start"] - (rows["memory ready"] - rows[f"enc{last_enc} fwd done"])
+    bwd = rows["backward joined, partials reduced"] - rows["losses + loss gradients done"]
+    us = fwd + bwd
+    fl = attn_ffn_flops(B, T, P)
+    return {"attn_ffn_gflop": round(fl / 1e9, 1), "stack_us": round(us, 1), "forward_us": round(fwd, 1), "backward_us": round(bwd, 1),
+            "step_us": round(rows["optimizer done"] - rows["step.start"], 1),
+            "attn_ffn_tflops": round(fl / us / 1e6, 1), "attn_ffn_mfma_frac": round(fl / us / 1e6 / PEAK_BF16_TFLOPS, 4),
+            "definition": "SURVEY 8d attention + FFN FLOPs (train_flops without the Cv and 2MH + H terms) / device time between the step's "
+                          "marks: [start .. last decoder layer forward] - [length regulator + variance adaptor] + [loss gradients .. backward joined]"}
+
+
 def median(xs):
     ys = sorted(xs)
     n = len(ys)
@@ -233,7 +407,7 @@ def ragged_workload(max_frames=16384, n_utts=600, seed=7):
     return out
 
 
-def extra_shapes(eng, steps_1024=30, passes=3, n_batches=24):
+def extra_shapes(eng, kk, math, steps_1024=30, passes=3, n_batches=24):
     """The two other shapes the verdict asks the driver-run record to carry, measured in this process after the headline region:
     8x1024x128 (BASELINE configs[3]'s per-GPU shape: the north-star shape) replayed from hipGraphs, and configs[2] (dynamic
     batching, B*T <= 16384) over resident ragged batches through train_step_auto (graphs from the second sight of a shape).
@@ -256,6 +430,8 @@ def extra_shapes(eng, steps_1024=30, passes=3, n_batches=24):
     out.append({"workload": "8x1024 mel frames x 128 phonemes (configs[3] per-GPU shape), hipGraph replay", "ms_per_step": round(ms, 3),
                 "value": round(8 * 1024 / ms * 1e3, 1), "unit": "mel-frames/s", "steps": steps_1024, "repeats_ms": [round(x * 1e3, 3) for x in reps],
                 "model_tflops": round(fl / ms / 1e9, 2), "model_mfma_frac": round(fl / ms / 1e9 / PEAK_BF16_TFLOPS, 4)})
+    out[-1]["stacks"] = stack_fraction(eng, b)
+    out[-1]["roofline"] = roofline_leg(eng, kk, [b], math, (8, 1024, 128))[0]
     batches = ragged_workload()[:n_batches]
     for _ in range(3):                                 # a shape's 1st sight runs eagerly, the 2nd is train_step_graphed's own eager pass
         for b in batches:                              # (it sizes the workspace), the 3rd captures: the 4th pass replays graphs
@@ -278,6 +454,7 @@ def extra_shapes(eng, steps_1024=30, passes=3, n_batches=24):
                 "padded_frames_per_s": round(padded / dt, 1), "padded_tokens_per_step": round(padded / len(batches)),
                 "passes_s": [round(x, 4) for x in reps],
                 "model_tflops": round(fl / dt / 1e12, 2), "model_mfma_frac": round(fl / dt / 1e12 / PEAK_BF16_TFLOPS, 4)})
+    out[-1]["roofline"] = roofline_leg(eng, kk, batches, math, None)[0]        # (one eager pass over the 24 shapes, twice)
     return out
 
 
@@ -435,52 +612,18 @@ def main():
     eng.dp_comm = None
     if rank == 0 and not args.no_roofline and dyn is None:
         # Roofline leg: the same step, eager, every launch bracketed by events on the launch stream.
-        kk.profile_start()
-        for _ in range(2):
-            eng.zero_grad()
-            eng._first_micro = True              # like the timed step: the first micro-batch of a cycle (weight gradients overwrite)
-            eng.forward_backward(batch, loss_scale=eng.dp_loss_scale, adaptive=True)
-            eng._first_micro = False
-            eng.optimizer_step(T)
-        table = kernel_table(kk.profile_stop(), args.math == "bf16")
-        shapes = {k: v for k, v in table.items() if k.startswith("  shape")}
-        table = {k: v for k, v in table.items() if not k.startswith("  shape")}
-        mfma = {k: v for k, v in table.items() if v["flops"] > 0}
-        peak = PEAK_BF16_TFLOPS if args.math == "bf16" else PEAK_F32_TFLOPS
-
-        def entry(name):
-            v = mfma[name]
-            ach = v["flops"] / (v["ms"] * 1e-3) / 1e12
-            traffic, busy, note, src = pmc_entry(B, T, P, args.math, name)
-            return {"kernel": name, "achieved": round(ach, 2), "frac": round(ach / peak, 4), "launches_per_step": v["launches"] // 2,
-                    "avg_launch_us": round(v["ms"] * 1e3 / v["launches"], 2),
-                    "algorithmic_gflop_per_launch": round(v["flops"] / v["launches"] / 1e9, 3),
-                    "algorithmic_bytes_per_launch": round(v["bytes"] / v["launches"]), "traffic": traffic, "mfma_busy": busy,
-                    "pmc_source": src, "pmc_method": note}
-        ranked = sorted(mfma, key=lambda k: -mfma[k]["ms"])
-        dom = entry(ranked[0])
-        roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": dom["frac"],
-                "traffic": dom["traffic"], "traffic_unit": "bytes/launch", "traffic_source": dom["pmc_method"],
-                "traffic_scope": "mean over ALL launches of the kernel symbol in the PMC pass (for the attention pair launch that includes the "
-                                 "text encoder's six one-tile launches per step, which the rate above lists apart)",
-                "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "launches_per_step": dom["launches_per_step"],
-                "avg_launch_us": dom["avg_launch_us"], "algorithmic_gflop_per_launch": dom["algorithmic_gflop_per_launch"],
-                "mfma_busy": dom["mfma_busy"],
-                "flop_convention": "SURVEY 8d: 2 FLOP/MAC, causal = lower triangle, attention backward = 4 matmuls (no credit for the "
-                                   "recomputed S / dP), event-timed on the launch stream in 2 eager steps",
-                # the other MFMA kernels by time, same accounting (mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x SIMDs), from
-                # the committed PMC pass of this shape; null where the pass has no entry)
-                "top_kernels": [{k: e[k] for k in ("kernel", "achieved", "frac", "launches_per_step", "avg_launch_us", "traffic", "mfma_busy")}
-                                for e in (entry(n) for n in ranked[:6])]}
+        roof, table, shapes = roofline_leg(eng, kk, [batch], args.math, (B, T, P))
         if args.kernel_table:
             tot = sum(x["ms"] for x in table.values())
             rows = sorted(table.items(), key=lambda kv: -kv[1]["ms"])
             with open(args.kernel_table, "w") as f:
                 srows = sorted(shapes.items(), key=lambda kv: -kv[1]["ms"])
                 json.dump({"total_ms_2_steps": tot, "kernels": {k: v for k, v in rows}, "shapes": {k: v for k, v in srows}}, f, indent=1)
-    extra = None
+    extra = stacks = None
+    if rank == 0 and not args.no_roofline and not args.no_graph and dyn is None:
+        stacks = stack_fraction(eng, batch)
     if rank == 0 and world == 1 and not args.no_extra_shapes and not args.no_graph and args.math == "bf16" and dyn is None:
-        extra = extra_shapes(eng)
+        extra = extra_shapes(eng, kk, args.math)
         if eng.encoder_stack_error():
             raise RuntimeError("a group barrier of the fused encoder launch timed out during the extra shapes")
     dp.barrier()
@@ -522,6 +665,7 @@ def main():
                       "hipgraph": not args.no_graph, "engine_overrides": args.set or None},
            "final_losses": [round(x, 5) for x in losses], "optimizer_steps": stats["attempt"], "skipped": stats["skipped"],
            "roofline": roof,
+           "stacks": stacks,
            "model_tflops": round(frames / dt * fl / (B * T) / 1e12, 2),
            "model_mfma_frac": round(frames / dt * fl / (B * T) / 1e12 / world / (PEAK_BF16_TFLOPS if args.math == "bf16" else PEAK_F32_TFLOPS), 4)}
     if extra is not None:

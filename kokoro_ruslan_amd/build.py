@@ -49,6 +49,14 @@ def build(force: bool = False, verbose: bool = False, tuning: bool = False, vari
     os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
     flags = FLAGS + (["-DKK_TUNING_HOOKS"] if tuning else []) + list(defs)
+    # the objects of a flavour are only as good as the flags they were built with: a stamp of the flags forces a rebuild when the
+    # same --variant name comes back with other -D definitions (an A/B could otherwise compare identical code)
+    stamp = os.path.join(obj_dir, "flags.stamp")
+    want = " ".join(flags)
+    if not os.path.exists(stamp) or open(stamp).read() != want:
+        force = True
+        with open(stamp, "w") as f:
+            f.write(want)
     headers = [os.path.join(CSRC, "kk_common.h"), os.path.join(os.path.dirname(HERE), "include", "kokoro_hip.h")]
     headers += [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".inc") or (f.endswith(".h") and f != "kk_common.h")]      # kernel bodies included by kk_attn.hip
 

@@ -708,6 +708,10 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(AttnArgs a) {
     }
     RowFrag<true> qf;
     if (KK_DBG(a, 64)) return;                                // (timing probe: the launch alone)
+    // probe (tools builds, bit 256): shader-clock stamps of workgroup 0's waves into the buffer at a.DeltaOut
+    unsigned long long *trace = (KK_DBG(a, 256) && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) ? reinterpret_cast<unsigned long long *>(a.DeltaOut) + wave8 * 64 : nullptr;
+    auto stamp = [&](int slot) { if (KK_DBG(a, 256) && trace != nullptr && slot < 64) trace[slot] = __builtin_amdgcn_s_memtime(); };
+    stamp(0);
     char *qimg = smem_raw + 2 * GSZ + 512;                 // [128 queries][64] image (the oldest DMA: covered by every wait below)
     dma_rows128(static_cast<const T *>(a.Q) + ((int64_t)b * a.Sq + qblk) * a.ldq + hh * 64, a.ldq, a.Sq - qblk < 128 ? a.Sq - qblk : 128, qimg, wave8);
     const uint8_t *km = a.key_mask ? a.key_mask + (int64_t)b * a.Sk : nullptr;
@@ -865,11 +869,13 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(AttnArgs a) {
                 o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_pair(vlo[s2 * 2 + db], vhi[s2 * 2 + db]), pb[s2], o[db], 0, 0, 0);
     };
     if (KK_DBG(a, 128)) return;                               // (timing probe: launch + DMA issue, nothing waited for)
+    stamp(1);
     // ---- prologue: tiles 0 and 1 landed (tile 2 may stay in flight), unit 0's scores, unit 1's K fragments
     if (NS >= 4 && nt >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (nt >= 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    stamp(2);
     rowfrag_from_image(qf, qimg, wave * 32, l31, half);
     f32x16 sa, sb;
     if (nu > 0) {
@@ -878,16 +884,21 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(AttnArgs a) {
         qk(sa);
         if (nu > 1) read_k(gl + 4096);
     }
+    stamp(3);
     int st = 0;
     for (int t = 0; t < (KK_DBG(a, 32) ? 0 : nt0); ++t) {
         const int st1 = st + 1 == NS ? 0 : st + 1;
+        stamp(4 + 6 * t);
         if (t > 0) {
             // tile t+1 landed: the only DMA younger than it is tile t+2 when NS == 4
             if (NS >= 4 && t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stamp(5 + 6 * t);
             if (!KK_DBG(a, 8)) __builtin_amdgcn_s_barrier();                  // ... for every wave, and every wave is done with tile t-1
             asm volatile("" ::: "memory");
+            stamp(6 + 6 * t);
             if (t + NS - 1 < nt && !KK_DBG(a, 1)) issue_tile(t + NS - 1, st == 0 ? NS - 1 : st - 1);
+            stamp(7 + 6 * t);
         }
         const int u0 = 2 * t;
         if (u0 < nu) {
@@ -903,6 +914,7 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(AttnArgs a) {
             wait_lds();
             pv(pb);
             __builtin_amdgcn_sched_barrier(0);
+            stamp(8 + 6 * t);
             if (u0 + 2 < nu) read_k(nxt);
             if (u0 + 1 < nu) {
                 // unit (t, 1): scores in sb; next unit (t+1, 0) -> sa
@@ -913,13 +925,16 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(AttnArgs a) {
                 wait_lds();
                 pv(pb);
                 __builtin_amdgcn_sched_barrier(0);
+                stamp(9 + 6 * t);
                 if (u0 + 3 < nu) read_k(nxt + 4096);
             }
         }
         st = st1;
     }
+    stamp(58);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    stamp(59);
     {                                // merge the two key groups' partial softmaxes: group 1 -> LDS -> group 0
         float *mb = reinterpret_cast<float *>(smem_raw) + (wave * 64 + lane) * 34;
         if (grp == 1) {
@@ -936,10 +951,12 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o[0][r] = o[0][r] * a0 + mb[2 + r] * a1; o[1][r] = o[1][r] * a0 + mb[18 + r] * a1; }
     }
+    stamp(60);
     const float inv = l > 0.f ? pd.inv_keep / l : 0.f;
     store_rows_via_lds(static_cast<T *>(a.Out) + ((int64_t)b * a.Sq + qmin) * a.ldout + hh * 64, a.ldout, a.Sq - qmin, o, inv,
                        smem_raw + 36864 + wave * 4608, lane, a.wt);
     if (qvalid && half == 0) a.LSEo[((int64_t)b * a.heads + hh) * a.Sq + q] = l > 0.f ? (m + __builtin_amdgcn_logf(l)) * 0.6931471805599453f : INFINITY;
+    stamp(61);
 }
 
 // ------------------------------------------------------------------ decode: one query per (batch, head)
@@ -1504,6 +1521,10 @@ static int attn_v2_mask() {              // bit 0: forward, bit 1: dQ, bit 2: dK
     static const int v = kk_tune_env("KK_ATTN_V2", 7);
     return v;
 }
+#ifdef KK_TUNING_HOOKS
+static void *g_attn_trace = nullptr;
+extern "C" int kk_attn_trace(void *buf) { g_attn_trace = buf; return 0; }      // tools: destination of the stamps of probe bit 256
+#endif
 static int attn_dbg() {                  // timing probes of tools/probes (tools build only: results are wrong when set)
     static const int v = kk_tune_env("KK_ATTN_DBG", 0);
     return v;
@@ -1592,6 +1613,9 @@ extern "C" int kk_attn_fwd(const float *Q, const float *K, const float *V, float
     a.B = B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.causal = causal;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldout = ldo; a.scale = scale;
     a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(causal); a.dbg = attn_dbg(); a.wt = kk_write_through((int64_t)B * std::max(Sq, Sk));
+#ifdef KK_TUNING_HOOKS
+    if (a.dbg & 256) a.DeltaOut = static_cast<float *>(g_attn_trace);
+#endif
     if (Sq == 1 && a.seed == nullptr && !causal && Sk <= 8192 && ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 &&
         (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) == 0) {  // a decoder step of the incremental path: one (batch, head) per workgroup
         const size_t lds = (size_t)(((Sk + 3) & ~3) + 16 * 64 + 32) * sizeof(float);

@@ -21,6 +21,7 @@
 // barrier, the next chunk's loads in flight under the current chunk's MFMAs) and runs the epilogue (head norm + RoPE,
 // bias, GLU gate + dropout) on its own row-major LDS tile; units are dealt workgroup-first, so a phase is one pass.
 #include "kk_common.h"
+#include <algorithm>
 #include <float.h>
 #include <math.h>
 
@@ -730,6 +731,14 @@ extern "C" int kk_encoder_stack_workgroups(void) {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
         wgs = cus >= 256 ? 256 : (cus / 8) * 8;
+        // Residency: the launch is a plain one whose workgroups spin on each other, so every one of them must be
+        // resident at once.  The grid never exceeds one workgroup per CU; ask the runtime that a CU admits one (registers, 160 KB of
+        // LDS) for BOTH instantiations, and refuse the fused launch otherwise (the engine then takes the per-kernel sequence).  The
+        // bounded spins + the error word remain the net for what the query cannot see (CU masks, a partitioned device).
+        int nb0 = 0, nb1 = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb0, enc_stack_fwd_kernel<512, 1536>, NTHREADS, 0) != hipSuccess) nb0 = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, enc_stack_fwd_kernel<0, 0>, NTHREADS, 0) != hipSuccess) nb1 = 0;
+        if (nb0 < 1 || nb1 < 1 || (int64_t)std::min(nb0, nb1) * cus < wgs) wgs = 0;
     }
     return wgs;
 }

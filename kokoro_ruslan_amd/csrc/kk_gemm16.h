@@ -44,6 +44,7 @@ constexpr int BK = 64;
 constexpr int GROUP_MAX = 8;
 struct G16Group {
     int n;
+    int xcd_chunks;                                             // kk_gemm16x.hip: XCD x takes the x-th contiguous eighth of ALL problems' tiles (see g16x_group_kernel)
     int start[GROUP_MAX + 1];                                   // first workgroup of each problem
     G16Args p[GROUP_MAX];
 };

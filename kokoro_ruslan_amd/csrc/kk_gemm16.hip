@@ -687,6 +687,7 @@ int g16_group_split = 0;                                        // grouped launc
 int g16x_on = kk_tune_env("KK_G16X", 15);              // tools: bit 0 plain, 1 head-norm, 2 GLU forward / backward, 3 grouped weight gradients
 int g16x_min_k_group = kk_tune_env("KK_G16X_GROUP_MIN_K", 1024);
 int g16x_min_k_plain = kk_tune_env("KK_G16X_PLAIN_MIN_K", 1024);
+int g16x_group_chunks = kk_tune_env("KK_G16X_GROUP_CHUNKS", 1);      // grouped launches: an XCD takes a contiguous eighth of ALL tiles (0: of every problem)
 int g16x_min_n_hn = kk_tune_env("KK_G16X_HN_MIN_N", 1024);
 int g16x_dbg = kk_tune_env("KK_G16X_DBG", 0);         // tools: probe bits of g16x_body (1 no epilogue, 4 no MFMAs, 8 DMA + barriers only)
 int g16x_force = kk_tune_env("KK_G16X_FORCE", -1);
@@ -715,7 +716,7 @@ void kk_gemm16_tune_group(int split) { g16_group_split = split % 100; g16_group_
 #ifdef KK_TUNING_HOOKS
 // tools: large-tile family on/off bits, forced tile (-1 = by cost), probe bits
 extern int g16x_lw;
-extern "C" int kk_gemm_tune16x(int on, int force, int dbg) { g16x_on = on & 255; g16x_lw = (on >> 8) & 1 ? 0 : ((on >> 9) & 1 ? 2 : 1); g16x_force = force; g16x_dbg = dbg; return 0; }
+extern "C" int kk_gemm_tune16x(int on, int force, int dbg) { g16x_on = on & 255; g16x_lw = (on >> 8) & 1 ? 0 : ((on >> 9) & 1 ? 2 : 1); g16x_group_chunks = (on >> 10) & 1 ? 0 : 1; g16x_force = force; g16x_dbg = dbg; return 0; }
 void kk_g16x_probe(int bits, void *buf);
 extern "C" int kk_gemm_trace16x(void *buf) { g16x_trace = buf; kk_g16x_probe(g16x_dbg, buf); return 0; }      // probe bit 32: 8 waves x 64 stamps (uint64) of workgroup 0
 #endif
@@ -931,6 +932,7 @@ int kk_gemm16_wgrad_group(const KkWgradDesc *d, int n, int split_k, int overwrit
         if ((g16x_on & 8) && !old_splits && kmin >= g16x_min_k_group && g16_cost(total_x, 128, 128) < g16_cost(total, BM, BN)) {
             G16Group g = {};
             g.n = n;
+            g.xcd_chunks = (xcd_swizzle && g16x_group_chunks) ? 1 : 0;
             for (int i = 0; i < n; ++i) {
                 const int64_t M = d[i].M, N = d[i].N, K = d[i].T;
                 G16Args &a = g.p[i];
@@ -940,7 +942,7 @@ int kk_gemm16_wgrad_group(const KkWgradDesc *d, int n, int split_k, int overwrit
                 a.A = d[i].dy; a.B = d[i].x; a.C = d[i].dw;
                 a.lda = d[i].lddy; a.ldb = d[i].ldx; a.ldc = d[i].lddw;
                 a.k_per_split = cd(K, BK) * BK; a.splits = 1;
-                a.tiles_m = cd(M, 128); a.tiles_n = cd(N, 128); a.xcd_swizzle = xcd_swizzle;
+                a.tiles_m = cd(M, 128); a.tiles_n = cd(N, 128); a.xcd_swizzle = g.xcd_chunks ? 0 : xcd_swizzle;
                 a.m_fast = (g16_group_mfast && xcd_swizzle && M < N) ? 1 : 0;
                 a.a_bytes = (uint32_t)(((K - 1) * a.lda + M) * 2);
                 a.b_bytes = (uint32_t)(((K - 1) * a.ldb + N) * 2);

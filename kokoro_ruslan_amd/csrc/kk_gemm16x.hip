@@ -670,11 +670,21 @@ __global__ __launch_bounds__(64 * (WR * WC + LW)) void g16x_kernel(G16Args a) {
 template <bool TA, bool TB, int BM, int BN, int NS, int WR, int WC, int LW>
 __global__ __launch_bounds__(64 * (WR * WC + LW)) void g16x_group_kernel(G16Group g) {
     __shared__ __attribute__((aligned(16))) char smem[NS * (BM + BN) * BK * 2 + BN * 4];
+    // Which tiles share an XCD's L2.  The dispatcher places workgroup w on XCD w % 8; with xcd_chunks set, XCD x works on the x-th
+    // contiguous eighth of the concatenation of ALL problems' tile lists (each in its own sweep order), not on an eighth of every
+    // problem: the 30 tiles it runs side by side then come from one or two problems and share operand panels — 115 instead of 188
+    // panel fetches per decoder-layer launch from the Infinity Cache into the eight L2s (these launches are bound by the latency of
+    // the L2 misses: ~64 requests in flight per CU).
+    int w = (int)blockIdx.x;
+    if (g.xcd_chunks) {
+        const int total = g.start[g.n], q = total >> 3, r = total & 7, xcd = w & 7, in = w >> 3;
+        w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + in;
+    }
     int i = 0;
-    while (i + 1 < g.n && (int)blockIdx.x >= g.start[i + 1]) ++i;
+    while (i + 1 < g.n && w >= g.start[i + 1]) ++i;
     // (hipcc's host pass rejects a g16x_body specialization named by two kernels when TA = TB = true: the weight-gradient layout is
     // instantiated here only; single weight-gradient GEMMs are groups of one)
-    g16x_body<TA, TB, BM, BN, NS, 0, WR, WC, LW>(g.p[i], (int)blockIdx.x - g.start[i], smem);
+    g16x_body<TA, TB, BM, BN, NS, 0, WR, WC, LW>(g.p[i], w - g.start[i], smem);
 }
 
 #ifdef KK_TUNING_HOOKS
@@ -735,6 +745,8 @@ int kk_g16x_glu_fwd(const G16Args &a0, hipStream_t s) {
         return launch_x<false, false, 128, 192, 3, 2, 4, 1, 4>(a, "kk_gemm_linear_glu", s);
     }
     a.tiles_m = kk_cdiv(a.M, 256);
+    // (eight compute waves of 32 x 192 + four loaders, 3 waves per SIMD at 166 registers, measured level: 24.2 against 25.3 us at 4096
+    // rows, 51.9 against 50.6 at 8192 — the epilogue's 38 MB of stores is most of this launch; not instantiated)
     return launch_x<false, false, 256, 192, 2, 2, 8, 1, 0>(a, "kk_gemm_linear_glu", s);
 }
 int kk_g16x_glu_bwd(const G16Args &a, hipStream_t s) {

@@ -1603,8 +1603,10 @@ class KokoroEngine:
                 d.copy_(v, non_blocking=True)
         if moved:
             kk.copy_many(moved)                        # one launch for the whole batch
+        # (kk_losses_finalize takes the GLOBAL mel length by value — the adaptive loss scale depends on it above 1400 frames — so a
+        # graph captured under one value must not be replayed under another: ADVICE r3)
         fkey = (div, first, self.train_dropout, self.spec_augment_active, self.math, self.dp_comm is not None and is_boundary,
-                self.loss_sync is not None)
+                int(self.global_mel_length or 0) if self.loss_sync is not None else 0, self.loss_sync is not None)
         fb = ent["fb"].get(fkey)
         if fb is None:
             with self.capture_lock:
@@ -1641,6 +1643,13 @@ class KokoroEngine:
         if not self.enc_fused:
             return
         code = self.encoder_stack_error()
+        # data parallel: the ranks decide TOGETHER — a rank that raised alone would leave the others waiting in the next
+        # collective.  The check sits at the trainer's sync points (epoch end, validation, checkpoint), which every rank reaches.
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            word = torch.tensor([code], dtype=torch.int64, device=self.device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(word, op=dist.ReduceOp.MAX)
+            code = int(word.item())
         if code:
             self._enc_sync.zero_()
             self.enc_fused = False

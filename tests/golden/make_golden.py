@@ -621,13 +621,13 @@ def section_expanded_length(d: O.ModelDims):
     np.savez_compressed(os.path.join(HERE, "expanded_length.npz"), **save)
 
 
-def section_autocast(d: O.ModelDims, B, T, Pn, seed, ragged):
+def section_autocast(d: O.ModelDims, B, T, Pn, seed, ragged, name="autocast_bf16", keep_autocast_mel=True):
     """The reference's OWN bf16 mode (trainer.py:3181-3232: the model forward under torch.autocast(dtype=bfloat16), losses and
     backward outside it) on the `full_dims` batch and weights, next to its fp32 run: how far the reference's mixed precision
     moves losses, outputs and every gradient away from its fp32 numbers.  The MI355X engine's bf16 mode (bf16 MFMA operands and
     operand storage, fp32 accumulate / residual streams / statistics) is held to that yardstick on the GPU
     (tests/test_engine_gpu.py::test_bf16_mode_against_the_references_own_autocast)."""
-    print(f"== autocast_bf16: dims={d} batch=({B},{T},{Pn})")
+    print(f"== {name}: dims={d} batch=({B},{T},{Pn})")
     cfg = TrainingConfig()
     model = ref_model(d)
     # The reference enters autocast on CUDA only (trainer.py:935-956); here its model runs under the CPU autocast of the same dtype,
@@ -666,13 +666,15 @@ def section_autocast(d: O.ModelDims, B, T, Pn, seed, ragged):
     mel_l1 = float(((o16[0] - o32[0]).abs() * valid).sum() / (valid.sum() * d.mel))
     print(f"  autocast vs fp32: loss deltas {[round(a - b, 5) for a, b in zip(l16, l32)]}; mel-L1 between the two mel outputs {mel_l1:.4e}; "
           f"gradient cosine min {min(cos):.4f} mean {float(np.mean(cos)):.5f}; norm ratio {min(ratio):.3f}..{max(ratio):.3f}")
-    np.savez_compressed(os.path.join(HERE, "autocast_bf16.npz"), seed=np.array(seed), shape=np.array([B, T, Pn]),
+    extra = {"mel_autocast": o16[0].numpy()} if keep_autocast_mel else {}      # (the T = 512 fixture keeps the fp32 output only: size)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), seed=np.array(seed), shape=np.array([B, T, Pn]),
+                        dims=np.array(list(d.__dict__.values())),
                         losses_fp32=np.array(l32), losses_autocast=np.array(l16), grad_cos=np.array(cos), grad_norm_ratio=np.array(ratio),
                         grad_norms_autocast=np.array([float(g16[n].double().norm()) for n in names]),
                         grad_norms_fp32=np.array([float(g32[n].double().norm()) for n in names]),
-                        mel_l1_between=np.array(mel_l1), mel_autocast=o16[0].numpy(), mel_fp32=o32[0].numpy(),
+                        mel_l1_between=np.array(mel_l1), mel_fp32=o32[0].numpy(), **extra,
                         **{f"batch/{k}": v.numpy() for k, v in batch.items()})
-    print("  wrote autocast_bf16.npz")
+    print(f"  wrote {name}.npz")
 
 
 if __name__ == "__main__":
@@ -681,8 +683,9 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["inference"]:                            # only the decode fixture
         section_inference(tiny, seed=21)
         sys.exit(0)
-    if sys.argv[1:] == ["autocast"]:                             # only the reference-autocast fixture
+    if sys.argv[1:] == ["autocast"]:                             # only the reference-autocast fixtures
         section_autocast(O.ModelDims(), B=2, T=96, Pn=12, seed=14, ragged=True)
+        section_autocast(O.ModelDims(), B=2, T=512, Pn=64, seed=15, ragged=True, name="autocast_bf16_t512", keep_autocast_mel=False)
         sys.exit(0)
     if sys.argv[1:] == ["step"]:                                 # only the step-driver / expanded-length fixtures
         section_step_driver()
@@ -706,4 +709,6 @@ if __name__ == "__main__":
     section_expanded_length(mid)
     section_inference(tiny, seed=21)
     section_autocast(O.ModelDims(), B=2, T=96, Pn=12, seed=14, ragged=True)
+    # ... and at the bench's frame count (T = 512: the decoder's attention and the 512-frame GroupNorm chunk at full length)
+    section_autocast(O.ModelDims(), B=2, T=512, Pn=64, seed=15, ragged=True, name="autocast_bf16_t512", keep_autocast_mel=False)
     print("ALL REFERENCE CHECKS PASSED")

@@ -35,9 +35,16 @@ def test_kernel_table_accounts_for_the_attention_backward_pair_and_its_delta_gem
     assert pair["bytes"] == 2 * 2.0 * B * h * 64 * 8 * S
     w8 = [k for k in t if k.startswith("gemm16_kernel_w8<false,true,3>")]
     assert len(w8) == 1 and t[w8[0]]["launches"] == 2 and t[w8[0]]["flops"] == 2 * 2.0 * B * S * H * H
-    assert t["gemm16_kernel_w8_hn (q|k|v projection + head-norm epilogue, 128x64 tiles)"]["launches"] == 1
+    # the decoder's q|k|v projection and the linear2 dgrad + GLU' take the large-tile family (kk_gemm16x.hip) at 4096 rows ...
+    hn = t["g16x_kernel<false,false,128,192,3,3,2,2,4> (q|k|v projection + head-norm epilogue, 128x192 tiles)"]
+    assert hn["launches"] == 1 and abs(hn["floor_us"] - 2.0 * B * S * 1536 * H * (1 / 128 + 1 / 192) / (256 * 46e9) * 1e6) < 1e-6
     assert t["gemm16_kernel<false,false,64,64,3,3> (q|k|v projection + head-norm epilogue)"]["launches"] == 1      # the encoder's 512 rows
-    assert t["gemm16_kernel_w8_glu (dY.W2 + GLU backward epilogue, 128x64 tiles)"]["flops"] == 2.0 * B * S * 1536 * H
+    assert t["g16x_kernel<false,true,128,192,3,1,2,2,4> (dY.W2 + GLU backward epilogue, 128x192 tiles, loader waves)"]["flops"] == 2.0 * B * S * 1536 * H
+    # ... the K = 512 plain GEMMs do not (long reductions only), and the formulas mirror kk_gemm16.hip's policy
+    assert b.x_tile("plain1", 4096, 512, 512) is None and b.x_tile("plain1", 4096, 512, 3072) is None
+    assert b.x_tile("plain1", 8192, 512, 3072)[:2] == (128, 128) and b.x_tile("hn", 8192, 1536, 512)[:2] == (256, 192)
+    assert b.x_tile("hn", 4096, 512, 512) is None and b.x_tile("glu_fwd", 4096, 1536, 512)[:2] == (256, 192)
+    assert abs(b.attn_ffn_flops(8, 1024, 128) / b.train_flops(8, 1024, 128) - 0.967) < 2e-3          # 96.7 % of the total at cfg-4
     shapes = [k for k in t if k.startswith("  shape")]
     assert any("kk_attn_bwd B=8 h=8 Sq=512 Sk=512 causal=1" in k for k in shapes)
     assert sum("ta=0 tb=1 M=4096 N=512 K=512" in k for k in shapes) == 1
@@ -73,5 +80,6 @@ def test_bench_detaches_the_in_step_exchange_before_rank0_only_legs():
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
     timed = src.index("regions.append(float(dt_r))")
     detach = src.index("eng.dp_comm = None", timed)
-    first_alone = min(src.index("kk.profile_start()", timed), src.index("extra_shapes(eng)", timed))
+    first_alone = min(src.index("roofline_leg(eng, kk, [batch]", timed), src.index("stack_fraction(eng, batch)", timed),
+                      src.index("extra_shapes(eng, kk, args.math)", timed))
     assert timed < detach < first_alone

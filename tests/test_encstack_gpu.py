@@ -59,7 +59,7 @@ def _rel(a, b):
     return float((a[fin] - b[fin]).norm() / (b[fin].norm() + 1e-30))
 
 
-@pytest.mark.parametrize("B,T,P", [(8, 512, 64), (8, 256, 128), (3, 96, 50), (16, 128, 64), (2, 64, 33), (5, 160, 97)])
+@pytest.mark.parametrize("B,T,P", [(8, 512, 64), (8, 256, 128), (8, 1024, 128), (3, 96, 50), (16, 128, 64), (2, 64, 33), (5, 160, 97)])
 @pytest.mark.parametrize("dropout", [True, False])
 def test_fused_encoder_matches_the_per_kernel_sequence(mods, B, T, P, dropout):
     _, _, synthetic = mods

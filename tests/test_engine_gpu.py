@@ -555,15 +555,17 @@ def test_graphed_accumulation_matches_eager(eng_mod, golden_dir):
     assert len(e._graphs) == 1
 
 
-def test_bench_config_bf16_graph_replay_tracks_fp32_and_oracle(eng_mod):
-    """The configuration bench.py times — 8 x 512 frames x 64 phonemes, default 49.4 M-parameter model, bf16, hipGraph
-    replay — checked for what it computes: (1) losses against the CPU oracle and the fp32 engine, (2) every gradient's
-    direction against the fp32 engine, (3) with all dropout on, a replayed step is the eager step (same seed, same
-    masks), (4) 12 replayed optimizer steps: no skips, finite, the loss moves."""
+@pytest.mark.parametrize("B,T,Pn", [(8, 512, 64), (8, 1024, 128)])
+def test_bench_config_bf16_graph_replay_tracks_fp32_and_oracle(eng_mod, B, T, Pn):
+    """The configurations bench.py times — 8 x 512 frames x 64 phonemes (configs[1], the headline) and 8 x 1024 x 128 (configs[3]'s
+    per-GPU shape), default 49.4 M-parameter model, bf16, hipGraph replay — checked for what they compute: (1) losses against the
+    CPU oracle and the fp32 engine (mel-L1 within 1e-4), (2) every gradient's direction against the fp32 engine, (3) with all
+    dropout on, a replayed step is the eager step (same seed, same masks), (4) 12 replayed optimizer steps: no skips, finite,
+    the loss moves."""
     from kokoro_ruslan_amd.synthetic import synthetic_batch
     d = O.ModelDims()
     P = O.init_params(d, 0)
-    cpu = synthetic_batch(8, 512, 64, seed=1234)
+    cpu = synthetic_batch(B, T, Pn, seed=1234)
     b = _cuda(cpu)
     f32 = _engine(eng_mod, d, P, gradient_accumulation_steps=1)
     f32.zero_grad()
@@ -826,25 +828,54 @@ def test_in_graph_bucket_exchange_over_rccl_one_rank(eng_mod, golden_dir):
     assert float((got_e - ref1).abs().max()) <= 2e-5 * float(ref1.abs().max())
     assert float((got_g - ref1).abs().max()) <= 2e-5 * float(ref1.abs().max())
 
+    # kk_losses_finalize takes the GLOBAL mel length by value (the adaptive loss scale above 1400 frames), so a graph captured
+    # under one value must not be replayed under another: one local shape, two global lengths, replayed = eager; and the length matters
+    def run_global_t(graphed, lengths):
+        e = _engine(eng_mod, d, P, math_mode="bf16", gradient_accumulation_steps=1)
+        e.train_dropout = True
+        e.dp_comm, e.loss_sync, e.dp_loss_scale = comm, comm, 1.0
+        for g_t in lengths:
+            e.global_mel_length = g_t
+            (e.train_step_auto if graphed else e.train_step)(batches[0])
+        torch.cuda.synchronize()
+        return e.arena.p.clone(), e.opt_stats()["last_grad_norm"]
+    # (AdamW normalises the gradient scale away, so the parameters barely see the loss scale; the gradient norm of the last step does:
+    #  scale = 1400 / T above 1400 frames.  The sequence ends on a length other than the one its graph was first captured under.)
+    seq = (1500, 1500, 2000, 2000, 1500)
+    (p_e, n_e), (p_g, n_g) = run_global_t(False, seq), run_global_t(True, seq)
+    assert float((p_g - p_e).abs().max()) <= 2e-5 * float(p_e.abs().max())
+    assert abs(n_g / n_e - 1.0) < 2e-3, f"a replayed graph must not keep the global mel length of its capture: |g| {n_g} (replayed) vs {n_e} (eager)"
+    _, n_c = run_global_t(True, (2000,) * len(seq))
+    assert abs(n_c / n_e - 1.0) > 0.1, "the test must be sensitive to the global mel length"
+
 
 # ---------------------------------------------------------------------------------------------------------------------
 # round 3: the bf16 mode against the reference's OWN mixed precision, and a long bf16 trajectory
 # ---------------------------------------------------------------------------------------------------------------------
-def test_bf16_mode_against_the_references_own_autocast(eng_mod, golden_dir):
-    """tests/golden/autocast_bf16.npz = the reference run twice on the `full_dims` batch and weights: fp32, and its model under
+@pytest.mark.parametrize("fixture", ["autocast_bf16", "autocast_bf16_t512"])
+def test_bf16_mode_against_the_references_own_autocast(eng_mod, golden_dir, fixture):
+    """tests/golden/autocast_bf16*.npz = the reference run twice on one batch and set of weights: fp32, and its model under
     torch.autocast(bfloat16) (what `use_mixed_precision` does, trainer.py:3181-3232) — losses of both, the L1 distance between the
     two mel outputs, and per-tensor cosine / norm ratio between the two sets of gradients.  The engine's bf16 mode (the mode
     bench.py times) must stay as close to the reference's fp32 numbers as the reference's own bf16 mode does (x1.5 slack: two
-    different roundings of the same computation are not closer to each other than each is to the truth)."""
-    ac = np.load(os.path.join(golden_dir, "autocast_bf16.npz"))
-    fx, d, batch, P = _load(golden_dir, "full_dims")
-    for k, v in batch.items():
-        assert np.array_equal(v.numpy(), ac[f"batch/{k}"]), "the autocast fixture was made on the full_dims batch"
-    np.testing.assert_allclose(ac["losses_fp32"], fx["losses"], rtol=1e-6, atol=1e-7)       # same reference fp32 run
+    different roundings of the same computation are not closer to each other than each is to the truth).  Two batches: the
+    `full_dims` one (2 x 96 frames) and one at the bench's frame count (2 x 512 frames x 64 phonemes, ragged: the decoder's
+    attention over 512 keys, the predictors' 512-frame GroupNorm chunk at full length)."""
+    ac = np.load(os.path.join(golden_dir, fixture + ".npz"))
+    if fixture == "autocast_bf16":
+        fx, d, batch, P = _load(golden_dir, "full_dims")
+        for k, v in batch.items():
+            assert np.array_equal(v.numpy(), ac[f"batch/{k}"]), "the autocast fixture was made on the full_dims batch"
+        np.testing.assert_allclose(ac["losses_fp32"], fx["losses"], rtol=1e-6, atol=1e-7)       # same reference fp32 run
+    else:
+        _, d, batch, P = _load(golden_dir, fixture)                 # dims, batch and the seed of the weights travel in the fixture
     names = list(O.param_shapes(d))
     ref32 = _engine(eng_mod, d, P)                                  # pinned to the reference's fp32 numbers (test_train_step_parity_fp32)
     ref32.zero_grad()
     o32 = ref32.forward_backward(_cuda(batch))
+    # the fp32 engine against the REFERENCE's fp32 losses of this batch (total, mel, dur, stop, pitch, energy): mel-L1 within 1e-4
+    np.testing.assert_allclose(o32["losses"].cpu().double().numpy(), ac["losses_fp32"], rtol=2e-4, atol=2e-4)
+    assert abs(float(o32["losses"][1]) - float(ac["losses_fp32"][1])) < 1e-4
     e = _engine(eng_mod, d, P, math_mode="bf16")
     assert e.storage == "bf16"
     e.zero_grad()
@@ -857,7 +888,8 @@ def test_bf16_mode_against_the_references_own_autocast(eng_mod, golden_dir):
     B, T = batch["mel_specs"].shape[:2]
     valid = (torch.arange(T)[None, :] < batch["mel_lengths"][:, None])[:, :, None].float()
     mel_l1 = float(((o16["mel"].cpu() - torch.from_numpy(ac["mel_fp32"])).abs() * valid).sum() / (valid.sum() * d.mel))
-    mel_l1_cross = float(((o16["mel"].cpu() - torch.from_numpy(ac["mel_autocast"])).abs() * valid).sum() / (valid.sum() * d.mel))
+    mel_l1_cross = (float(((o16["mel"].cpu() - torch.from_numpy(ac["mel_autocast"])).abs() * valid).sum() / (valid.sum() * d.mel))
+                    if "mel_autocast" in ac.files else float("nan"))
     print(f"mel-L1 of the bf16 engine's mel output: vs reference fp32 {mel_l1:.3e}, vs reference autocast {mel_l1_cross:.3e}; "
           f"reference autocast vs reference fp32 {float(ac['mel_l1_between']):.3e}; mel-loss delta {d_eng[1]:.3e} (reference's own: {d_ref[1]:.3e})")
     assert mel_l1 <= 1.5 * float(ac["mel_l1_between"]), (mel_l1, float(ac["mel_l1_between"]))

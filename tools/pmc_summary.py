@@ -18,7 +18,12 @@ out = {"workload": [B, T, P, math], "method": "rocprofv3 --pmc FETCH_SIZE / --pm
 for mangled, c in raw.items():
     w8 = re.search(r"gemm16_kernel_w8ILb(\d)ELb(\d)ELi(\d+)E", mangled)
     m = re.search(r"gemm16_(group_)?kernelILb(\d)ELb(\d)ELi(\d+)ELi(\d+)ELi(\d+)E(?:Li(\d+)E)?", mangled)
-    if w8:
+    gx = re.search(r"g16x_(group_)?kernelILb(\d)ELb(\d)E((?:Li\d+E)+)", mangled)
+    if gx:                                                        # large-tile family (kk_gemm16x.hip): every template argument, as bench.py names it
+        b = lambda v: "true" if v == "1" else "false"
+        ints = ",".join(re.findall(r"Li(\d+)E", gx.group(4)))
+        name = f"g16x_{gx.group(1) or ''}kernel<{b(gx.group(2))},{b(gx.group(3))},{ints}>"
+    elif w8:
         b = lambda v: "true" if v == "1" else "false"
         name = f"gemm16_kernel_w8<{b(w8.group(1))},{b(w8.group(2))},{w8.group(3)}>"
     elif m:

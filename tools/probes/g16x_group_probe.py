@@ -34,7 +34,7 @@ for name, shapes in (("decoder layer", dec), ("cross k|v x6", [(12 * H, H)])):
     fns = group(shapes)
     fl = sum(2.0 * T * m * n for m, n in shapes)
     row = []
-    for label, on in (("old 128x64", 0), ("x no loaders", 15 | 256), ("x 4+4", 15), ("x 8+4", 15 | 512)):
+    for label, on in (("old 128x64", 0), ("x 4+4 per-problem XCD runs", 15 | 1024), ("x 4+4 global XCD chunks", 15), ("x 8+4 chunks", 15 | 512)):
         tune(on, -1, 0)
         t = gtime(fns)
         row.append(f"{label}: {t:6.1f} us {fl / t / 1e6:4.0f} TF")
