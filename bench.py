@@ -201,7 +201,12 @@ def kernel_table(records, math_bf16: bool):
             causal = int(sc[-6 - off])
             mm = {"kk_attn_fwd": 2, "kk_attn_bwd_dq": 1, "kk_attn_bwd_dkv": 3}[name]   # ALGORITHMIC matmuls of Sq x Sk x 64 (dQ | dV, dP, dK)
             v2 = int(sc[-1 - off]) and Sk > (64 if name == "kk_attn_fwd" else 32)       # (mirrors the dispatch in kk_attn.hip)
-            key = {"kk_attn_fwd": "attn_fwd2_kernel (flash forward, DMA-staged)" if v2 else "attn_fwd_kernel (flash forward, first generation)",
+            fwd_name = "attn_fwd_kernel (flash forward, first generation)"
+            if v2:                                               # (mirrors kk_attn_fwd: the third generation above 128 keys, 128- or 64-query blocks)
+                fwd_name = ("attn_fwd2_kernel (flash forward, DMA-staged)" if Sk <= 128 else
+                            "attn_fwd3_q128_kernel (flash forward, 2 workgroups per CU, 128-query blocks x 2 key slots)" if _cd(Sq, 128) * B * h >= 512 else
+                            "attn_fwd3_q64_kernel (flash forward, 2 workgroups per CU, 64-query blocks x 4 key slots)")
+            key = {"kk_attn_fwd": fwd_name,
                    "kk_attn_bwd_dq": "attn_bwd_dq2_kernel (dQ)" if v2 else "attn_bwd_dq_kernel (dQ, first generation)",
                    "kk_attn_bwd_dkv": "attn_bwd_dkv2_kernel (dK, dV)" if v2 else "attn_bwd_dkv_kernel (dK, dV, first generation)"}[name]
             flops = mm * 2.0 * B * h * Sq * Sk * 64 * (0.5 if causal else 1.0)

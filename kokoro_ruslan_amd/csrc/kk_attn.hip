@@ -959,6 +959,242 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(AttnArgs a) {
     stamp(61);
 }
 
+// ------------------------------------------------------------------ forward, third generation (bf16 storage): two workgroups per CU
+// What the stamps of attn_fwd2 said (tools/probes/attn_trace.py): the loop is VALU-bound — a wave64 VALU instruction occupies its
+// SIMD for 4 clocks, ~250 of them per 32 x 32 score unit against 8 MFMAs — and its two waves per SIMD, phase-locked by the per-tile
+// barrier of the two key groups, keep the VALU ~60 % busy; one 112 KB workgroup fits a CU, so the 512 workgroups of a 1024-frame
+// launch run as two rounds, each with its own prologue, group imbalance and merge.  Here a workgroup needs <= 74 KB of LDS and <= 128
+// registers, so TWO are resident per CU (four waves per SIMD, from independent workgroups: no common barrier), and the work is dealt
+// so that every wave does the same amount: the 8 waves are QW query waves x KG key slots over ONE shared K/V ring whose tile is
+// KT = 32 KG keys — in a tile step wave (qw, kg) computes exactly one 32 x 32 unit (queries 32 qw.., keys 32 kg.. of the tile).  No
+// software pipelining inside a wave (the other three waves of the SIMD are the overlap), Q fragments re-read from LDS per unit.
+// Same arithmetic per unit as attn_fwd2 (softmax per 32-key unit, same dropout function): the results differ from it only by the
+// order in which the key slots' partial softmaxes are merged.
+template <int QW, int KG, int NS>
+__device__ __forceinline__ void attn_fwd3_body(const AttnArgs &a) {
+    typedef __bf16 T;
+    constexpr int QB = 32 * QW, KT = 32 * KG, KIMG = KT * 128, STAGE = 2 * KIMG, RING = NS * STAGE;
+    constexpr int KP = KT / 64, NPT = 2 * KP;                 // 16-byte pieces per thread: per operand, per tile
+    static_assert(QW * KG == 8 && (QB * 8) % 512 == 0, "eight waves; whole Q pieces per thread");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];        // [stage][K image | V image] | key-mask words | Q image
+    uint64_t *kmb = reinterpret_cast<uint64_t *>(smem_raw + RING);         // [64] one word per 64 keys
+    char *qimg = smem_raw + RING + 512;                                    // [QB queries][64] image
+    int bx_, by_;
+    attn_block(a, bx_, by_, true);
+    const int b = by_ / a.heads, hh = by_ % a.heads;
+    const int qblk = bx_ * QB;
+    const int lane = threadIdx.x & 63, wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, l31 = lane & 31;
+    const int qw = wave8 % QW, kg = wave8 / QW;
+    const int qmin = qblk + 32 * qw, q = qmin + l31;
+    const bool qvalid = q < a.Sq;
+    int kend = a.Sk;
+    if (a.causal && qblk + QB < kend) kend = qblk + QB;
+    int klim = kend;                                           // this wave multiplies the keys [0, klim)
+    if (a.causal && qmin + 32 < klim) klim = qmin + 32;
+    const int nt = (kend + KT - 1) / KT;
+    // ---- Q rows of the block (the oldest DMA: covered by every wait below)
+    {
+        const int nrows = a.Sq - qblk < QB ? a.Sq - qblk : QB;
+        const T *qb = static_cast<const T *>(a.Q) + ((int64_t)b * a.Sq + qblk) * a.ldq + hh * 64;
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(qb), 0, nrows > 0 ? (int)((((int64_t)nrows - 1) * a.ldq + 64) * 2) : 0, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < QB * 8 / 512; ++j) {
+            const int p = threadIdx.x + 512 * j, row = p >> 3, pc = p & 7;
+            const uint32_t vo = (uint32_t)(((int64_t)row * a.ldq + ((pc ^ ((row >> 1) & 7)) * 8)) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, KK_LDS_PTR(qimg + wave8 * 1024 + j * 8192), 16, vo, 0, 0, 0);
+        }
+    }
+    const uint8_t *km = a.key_mask ? a.key_mask + (int64_t)b * a.Sk : nullptr;
+    uint32_t kmv[8];
+    if (km) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int key = (wave8 + 8 * i) * 64 + lane;
+            kmv[i] = key < kend ? km[key] : 0u;
+        }
+    }
+    // ---- K / V tiles: every thread issues KP pieces of each
+    const T *Kb = static_cast<const T *>(a.K) + (int64_t)b * a.Sk * a.ldk + hh * 64;
+    const T *Vb = static_cast<const T *>(a.V) + (int64_t)b * a.Sk * a.ldv + hh * 64;
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(Kb), 0, (int)((((int64_t)a.Sk - 1) * a.ldk + 64) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(Vb), 0, (int)((((int64_t)a.Sk - 1) * a.ldv + 64) * 2), 0x00020000);
+    uint32_t kvo[KP], vvo[KP];
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+        const int p = threadIdx.x + 512 * j, row = p >> 3, pc = p & 7;
+        kvo[j] = (uint32_t)(((int64_t)row * a.ldk + ((pc ^ ((row >> 1) & 7)) * 8)) * 2);
+        const int sw = 2 * ((row >> 1) & 1), g = (((pc >> 1) ^ sw) << 1) | (pc & 1);
+        vvo[j] = (uint32_t)(((int64_t)row * a.ldv + g * 8) * 2);
+    }
+    const uint32_t ktile = (uint32_t)(KT * a.ldk * 2), vtile = (uint32_t)(KT * a.ldv * 2);
+    auto issue_tile = [&](int t, int st) {
+        char *dst = smem_raw + st * STAGE + wave8 * 1024;
+#pragma unroll
+        for (int j = 0; j < KP; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, KK_LDS_PTR(dst + j * 8192), 16, kvo[j] + (uint32_t)t * ktile, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < KP; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, KK_LDS_PTR(dst + KIMG + j * 8192), 16, vvo[j] + (uint32_t)t * vtile, 0, 0, 0);
+    };
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < nt) issue_tile(t, t);
+    if (km) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint64_t bits = __ballot(kmv[i] != 0u);
+            if (lane == 0) kmb[wave8 + 8 * i] = bits;
+        }
+    }
+    // ---- fragment addresses (bytes inside an image)
+    const uint32_t sl = (uint32_t)(uintptr_t)KK_LDS_PTR(smem_raw);
+    const uint32_t ql = (uint32_t)(uintptr_t)KK_LDS_PTR(qimg) + (uint32_t)((32 * qw + l31) * 128);
+    uint32_t ka[4], va[2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) ka[ks] = (uint32_t)(l31 * 128 + (((2 * ks + half) ^ ((l31 >> 1) & 7)) * 16));
+    {
+        const int L = lane & 15, kq = L >> 2, gi = (lane >> 4) & 1, sw = 2 * ((kq >> 1) & 1);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) va[db] = (uint32_t)((4 * half + kq) * 128 + (((2 * db + gi) ^ sw) * 32) + 8 * (L & 3));
+    }
+    f32x16 o[2];
+    zero_acc(o[0]); zero_acc(o[1]);
+    float m = -1e30f, l = 0.f;
+    const float c2 = a.scale * 1.4426950408889634f;
+    ProbDrop pd;
+    pd.init(a, b, hh);
+    for (int t = 0; t < nt; ++t) {
+        // tile t landed once at most the younger tiles' DMAs are outstanding (tile t + NS - 1 goes out behind this step's barrier)
+        const int younger = min(nt - 1 - t, NS - 2);
+        if (NS >= 3 && younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                         // ... for every wave, and every wave is done with tile t - 1
+        asm volatile("" ::: "memory");
+        if (t + NS - 1 < nt) issue_tile(t + NS - 1, (t + NS - 1) % NS);
+        const int k0 = t * KT + 32 * kg;
+        if (k0 >= klim) continue;                             // (causal: nothing of this unit is visible to these queries)
+        const uint32_t kimg = sl + (uint32_t)((t % NS) * STAGE + kg * 4096), vimg = kimg + KIMG;
+        // S^T = K . Q^T
+        bf16x8 kf[4], qf[4];
+        asm volatile("ds_read_b128 %0, %1" : "=v"(kf[0]) : "v"(kimg + ka[0]));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(qf[0]) : "v"(ql + (ka[0] & 127)));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(kf[1]) : "v"(kimg + ka[1]));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(qf[1]) : "v"(ql + (ka[1] & 127)));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(kf[2]) : "v"(kimg + ka[2]));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(qf[2]) : "v"(ql + (ka[2] & 127)));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(kf[3]) : "v"(kimg + ka[3]));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(qf[3]) : "v"(ql + (ka[3] & 127)));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(kf[ks]), "+v"(qf[ks]));
+        f32x16 s;
+        zero_acc(s);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // V^T fragments in flight under the softmax
+        s16x4 vlo[4], vhi[4];
+        {
+            const uint32_t a0 = vimg + va[0], a1 = vimg + va[1];
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vlo[0]) : "v"(a0));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(vhi[0]) : "v"(a0));
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vlo[1]) : "v"(a1));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(vhi[1]) : "v"(a1));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(vlo[2]) : "v"(a0));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:3072" : "=v"(vhi[2]) : "v"(a0));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(vlo[3]) : "v"(a1));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:3072" : "=v"(vhi[3]) : "v"(a1));
+        }
+        // softmax (+ dropout) of the unit, in place: the arithmetic of attn_fwd2's softmax_unit
+        const uint32_t kmsub = km ? (uint32_t)(kmb[k0 >> 6] >> (k0 & 32)) : 0u;
+        const bool edge = k0 + 32 > a.Sk || (a.causal && k0 + 31 > qmin) || kmsub != 0u;
+        if (edge) {
+            const uint32_t kml = kmsub >> (4 * half);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + frag_row(r, half);
+                const bool ok = key < a.Sk && !(a.causal && key > q) && !((kml >> frag_row(r, 0)) & 1u);
+                s[r] = ok ? s[r] : -INFINITY;
+            }
+        }
+        float mx = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+        mx = xor32_max(mx) * c2;
+        const float mn = fmaxf(m, mx);
+        if (__ballot(mn > m) != 0ull) {
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);
+            l *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+            m = mn;
+        }
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -m)); rs += s[r]; }
+        rs = xor32_sum(rs);
+        l += rs;
+        if (pd.thr) {
+            const uint32_t xb = pd.row(q, k0 + 4 * half);
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const uint32_t hsh = pd.hash(xb + (uint32_t)(frag_row(r, 0) >> 1));
+                s[r] = pd.keep_lo(hsh) ? s[r] : 0.f;
+                s[r + 1] = pd.keep_hi(hsh) ? s[r + 1] : 0.f;
+            }
+        }
+        bf16x8 pb[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pb[s2][j] = (__bf16)s[8 * s2 + j];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(vlo[i]), "+v"(vhi[i]));
+        // O^T += V^T . P^T
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_pair(vlo[s2 * 2 + db], vhi[s2 * 2 + db]), pb[s2], o[db], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                           // the ring is free: the key slots' partial softmaxes meet in it
+    {
+        float *mb = reinterpret_cast<float *>(smem_raw);       // [(kg - 1) * QW + qw][lane][34]
+        if (kg > 0) {
+            float *w = mb + (((kg - 1) * QW + qw) * 64 + lane) * 34;
+            w[0] = m; w[1] = l;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { w[2 + r] = o[0][r]; w[18 + r] = o[1][r]; }
+        }
+        __syncthreads();
+        if (kg > 0) return;
+#pragma unroll
+        for (int g = 1; g < KG; ++g) {
+            const float *w = mb + (((g - 1) * QW + qw) * 64 + lane) * 34;
+            const float m1 = w[0], l1 = w[1], mn = fmaxf(m, m1);
+            const float a0 = __builtin_amdgcn_exp2f(m - mn), a1 = __builtin_amdgcn_exp2f(m1 - mn);
+            l = l * a0 + l1 * a1;
+            m = mn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o[0][r] = o[0][r] * a0 + w[2 + r] * a1; o[1][r] = o[1][r] * a0 + w[18 + r] * a1; }
+        }
+    }
+    __syncthreads();                                           // (the QW remaining waves: everyone has read the merge area — the store tiles reuse it)
+    const float inv = l > 0.f ? pd.inv_keep / l : 0.f;
+    static_assert(RING >= (KG - 1) * QW * 64 * 34 * 4 && RING >= QW * 4608, "merge area / store tiles fit the ring");
+    store_rows_via_lds(static_cast<T *>(a.Out) + ((int64_t)b * a.Sq + qmin) * a.ldout + hh * 64, a.ldout, a.Sq - qmin, o, inv,
+                       smem_raw + qw * 4608, lane, a.wt);
+    if (qvalid && half == 0) a.LSEo[((int64_t)b * a.heads + hh) * a.Sq + q] = l > 0.f ? (m + __builtin_amdgcn_logf(l)) * 0.6931471805599453f : INFINITY;
+}
+
+// (plain kernels around the template body: hipcc's host pass did not emit the stub of the kernel TEMPLATE named in kk_attn_fwd, and
+// rejected its explicit instantiation — the same host-pass trouble as g16x_group_kernel in kk_gemm16x.hip)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd3_q128_kernel(AttnArgs a) { attn_fwd3_body<4, 2, 3>(a); }
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd3_q64_kernel(AttnArgs a) { attn_fwd3_body<2, 4, 2>(a); }
+
 // ------------------------------------------------------------------ decode: one query per (batch, head)
 // Sq == 1 (the incremental path of transformers.py:237-253: a decoder step against the KV cache / against the memory), no dropout.
 // The tiled kernels above would run one live row of a 128-row block; here a workgroup is one (batch, head): 16 waves = 256 key groups
@@ -1629,6 +1865,19 @@ extern "C" int kk_attn_fwd(const float *Q, const float *K, const float *V, float
     // second-generation kernel (DMA-staged, software-pipelined): bf16 storage, two key groups, 16-byte aligned operands
     const int fwd_v2 = attn_v2_mask() & 1;
     if (io_bf16 && fwd_v2 && G == 2 && Sk <= 4096 && (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) == 0 && (int64_t)Sk * std::max(ldk, ldv) * 2 < (1ll << 31)) {
+        // third generation: two 74 KB / 128-register workgroups per CU.  128-query blocks x 2 key slots when that gives two workgroups
+        // per CU, else 64-query blocks x 4 key slots (a 512-frame launch: 512 workgroups instead of 256)
+        static const int fwd3 = kk_tune_env("KK_ATTN_FWD3", 1);
+        if (fwd3 && Sk > 128) {
+            const bool big = (int64_t)kk_cdiv(Sq, 128) * B * heads >= 512;
+            // (a conditional expression: hipcc does not emit the host stub of a kernel template named only inside an if / else chain)
+            const int rc3 = (big || fwd3 == 2)
+                ? launch_attn(attn_fwd3_q128_kernel, dim3(kk_cdiv(Sq, 128), B * heads), 2, (size_t)3 * 16384 + 512 + 16384, (hipStream_t)stream, a)
+                : launch_attn(attn_fwd3_q64_kernel, dim3(kk_cdiv(Sq, 64), B * heads), 2, (size_t)2 * 32768 + 512 + 8192, (hipStream_t)stream, a);
+            if (rc3) return rc3;
+            KK_LAUNCH_CHECK("kk_attn_fwd");
+            return 0;
+        }
         static const int ns2 = kk_tune_env("KK_ATTN_NS", 3);
         int rc2 = ns2 == 4 ? launch_attn(attn_fwd2_kernel<4>, grid, 2, (size_t)2 * 4 * 16384 + 512 + 16384, (hipStream_t)stream, a)
                            : launch_attn(attn_fwd2_kernel<3>, grid, 2, (size_t)2 * 3 * 16384 + 512 + 16384, (hipStream_t)stream, a);

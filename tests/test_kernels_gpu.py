@@ -1230,7 +1230,9 @@ def test_attention_backward_headnorm_epilogue(kk, B, h, Sq, Sk, causal, rope, bf
     torch.cuda.synchronize()
     tol = (2e-2, 2e-2) if bf16 else (2e-5, 2e-5)
     close(dq_b, dq_a, *tol, "d raw q")
-    close(dkv_b, dkv_a, *tol, "d raw k|v")
+    bad = ((dkv_b.float() - dkv_a.float()).abs() > tol[0] + tol[1] * dkv_a.float().abs()).nonzero().tolist()
+    where = [(i, j, float(dkv_b[i, j]), float(dkv_a[i, j]), float(dkv_n[i, j])) for i, j in bad[:8]]      # (a one-off failure was seen once: say where)
+    close(dkv_b, dkv_a, *tol, f"d raw k|v (row, column, fused, unfused, d normalised: {where})")
     if bf16:
         assert float((dq_b == dq_a).float().mean()) > 0.99 and float((dkv_b == dkv_a).float().mean()) > 0.99, "almost all bits equal"
     for j, name in enumerate(("q", "k", "v")):
