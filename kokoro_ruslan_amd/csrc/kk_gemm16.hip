@@ -691,7 +691,9 @@ int g16x_group_chunks = kk_tune_env("KK_G16X_GROUP_CHUNKS", 1);      // grouped 
 int g16x_min_n_hn = kk_tune_env("KK_G16X_HN_MIN_N", 1024);
 int g16x_dbg = kk_tune_env("KK_G16X_DBG", 0);         // tools: probe bits of g16x_body (1 no epilogue, 4 no MFMAs, 8 DMA + barriers only)
 int g16x_force = kk_tune_env("KK_G16X_FORCE", -1);
-void *g16x_trace = nullptr;                            // tools: destination of probe bit 32    // tools: this tile for every head-norm / plain launch of the family
+#ifdef KK_TUNING_HOOKS
+void *g16x_trace = nullptr;                            // tools: destination of probe bit 32
+#endif
 int g16_cus() {
     static const int n = [] {
         int dev = 0, v = 0;
