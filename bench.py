@@ -195,6 +195,12 @@ def kernel_table(records, math_bf16: bool):
             # the launch EXECUTES 7 (S and dP are computed by both halves): executed work is not algorithmic work
             flops = 4 * 2.0 * B * h * Sq * Sk * 64 * (0.5 if causal else 1.0)
             byts = (2.0 if int(sc[-1]) else 4.0) * B * h * 64 * (4 * Sq + 4 * Sk)
+        elif name == "kk_attn_bwd_ws":                  # (... as kk_attn_bwd ..., ws_bytes): two kernels behind one entry point, event-timed together
+            B, h, Sq, Sk = (int(x) for x in sc[:4])
+            causal = int(sc[-7])
+            key = "attn_bwd_dkv2s_kernel + attn_bwd_dqpass_kernel (dK, dV and the dS tiles, then dQ = dS.K)"
+            flops = 4 * 2.0 * B * h * Sq * Sk * 64 * (0.5 if causal else 1.0)        # executes 5: S is the only recomputation left
+            byts = 2.0 * B * h * 64 * (4 * Sq + 4 * Sk) + 2 * 2.0 * B * h * Sq * Sk * (0.5 if causal else 1.0)   # + dS written and read once
         elif name in ("kk_attn_fwd", "kk_attn_bwd_dq", "kk_attn_bwd_dkv"):
             B, h, Sq, Sk = (int(x) for x in sc[:4])
             off = 1 if name == "kk_attn_bwd_dq" else 0       # (..., causal, scale, site, p_drop, math, io_bf16[, ldo])

@@ -147,6 +147,21 @@ int kk_attn_bwd(const float *Q, const float *K, const float *V, const float *dO,
                 int64_t ldv, int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, const uint8_t *key_mask,
                 int causal, float scale, const uint32_t *seed, uint32_t site, float p_drop, int math, int io_bf16,
                 const KkAttnHeadNorm *hn_q, const KkAttnHeadNorm *hn_kv, void *stream);
+/* The same backward in two passes through a caller-owned workspace (same call sites; `ws` of at least kk_attn_bwd_ws_bytes(...)
+ * bytes, 16-byte aligned, private to the stream for the duration of the call): the dK/dV kernel also stores dS = P o (dP - Delta)
+ * as bf16 tiles (2 bytes per score), and dQ = dS . K is a pass without softmax work (+ the head-norm epilogue) — the pair launch
+ * above computes the scores, exponentials and dropout masks once per kernel.  Identical dK, dV and gain partials of hn_kv; dQ and
+ * hn_q's partials differ by the order of the sum over key units.  ws == NULL, a workspace that is too small or a launch the two-pass
+ * kernels do not serve (fp32 storage, one key tile, causal with Sq != Sk, unaligned operands): kk_attn_bwd runs.
+ * kk_attn_bwd_two_pass(): whether the two passes are the faster form of a shape (the extra 2 bytes per score against the second
+ * softmax: full attention from 1024 x 1024 scores per head up) — the caller's policy for handing over a workspace. */
+int64_t kk_attn_bwd_ws_bytes(int B, int heads, int Sq, int Sk);
+int kk_attn_bwd_two_pass(int B, int heads, int Sq, int Sk, int causal);
+int kk_attn_bwd_ws(const float *Q, const float *K, const float *V, const float *dO, const float *LSE, const float *Delta,
+                   float *dQ, float *dK, float *dV, int B, int heads, int Sq, int Sk, int64_t ldq, int64_t ldk,
+                   int64_t ldv, int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, const uint8_t *key_mask,
+                   int causal, float scale, const uint32_t *seed, uint32_t site, float p_drop, int math, int io_bf16,
+                   const KkAttnHeadNorm *hn_q, const KkAttnHeadNorm *hn_kv, void *ws, int64_t ws_bytes, void *stream);
 
 /* ---- norms ----
  * LayerNorm (nn.LayerNorm eps 1e-5; transformers.py:461-462,518-520,612; model.py:122). */

@@ -46,6 +46,7 @@ struct AttnArgs {
     int xcd_map;
     int wt;                              // write-through stores of the [rows, 64] outputs (kk_common.h: kk_write_through(B * S))
     int dbg;                             // timing probes (KK_ATTN_DBG; results are wrong when set)
+    void *dS;                            // kk_attn_bwd_ws: bf16 dS tiles, written by the dK/dV kernel, read by the dQ pass (kk_attn_bwd_dkv2.inc)
     // backward kernels: the gradient of the per-head RMSNorm (+ RoPE) that produced Q (dQ kernel) / K and V (dK/dV
     // kernel: hn[0], hn[1]) as the epilogue — Out / Out2 then receive the gradient of the RAW projection
     KkAttnHeadNorm hn[2];
@@ -637,13 +638,14 @@ __device__ __forceinline__ float xor32_max(float v) {
 // per lane: the RowFrag loads, store_row) touches 32 lines per wave instruction and is bound by requests, not bytes
 // (4 us of a 13 us forward launch were the Q loads and the O stores).
 // DMA of a [128 rows][64] bf16 head tile into a 16 KB LDS image with XOR-ed 16-byte chunks, by 512 threads (two pieces each).
+template <int NT = 512>                 // threads of the workgroup (512: two pieces each, 256: four)
 __device__ __forceinline__ void dma_rows128(const __bf16 *base, int64_t ld, int nrows, char *img, int wave8) {
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(base), 0, nrows > 0 ? (int)((((int64_t)nrows - 1) * ld + 64) * 2) : 0, 0x00020000);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int p = threadIdx.x + 512 * j, row = p >> 3, pc = p & 7;
+    for (int j = 0; j < 1024 / NT; ++j) {
+        const int p = threadIdx.x + NT * j, row = p >> 3, pc = p & 7;
         const uint32_t vo = (uint32_t)(((int64_t)row * ld + ((pc ^ ((row >> 1) & 7)) * 8)) * 2);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, KK_LDS_PTR(img + wave8 * 1024 + j * 8192), 16, vo, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, KK_LDS_PTR(img + wave8 * 1024 + j * (NT * 16)), 16, vo, 0, 0, 0);
     }
 }
 // this lane's row (row0 + lane&31, row0 a multiple of 16) of such an image as an MFMA operand with k = d (RowFrag layout)
@@ -1451,9 +1453,11 @@ __device__ __forceinline__ int kk_xb(int r) { return (((r >> 1) & 1) << 1) | ((r
 // latency and no row-per-lane requests.  rawimg: [128][64] bf16, cosimg / sinimg: columns 0..31 of the table rows as
 // [128][32] fp32 (rotate-half RoPE tables have identical halves, positional_encoding.py:129-150), all with the chunk XOR
 // of dma_rows128.  The gradient of the raw projection comes back in the accumulator layout (out), for store_rows_via_lds.
-__device__ __forceinline__ void hn_bwd_row2(const f32x16 (&acc)[2], float mul, bool valid, const char *rawimg, const char *cosimg,
-                                            const char *sinimg, int row, bool rope, const float *gain, int half, float *colred_row,
-                                            f32x16 (&out)[2]) {
+// (core: the per-column contributions to the gain gradient come back in cr[32], accumulator order, for a caller whose colred buffer
+//  shares LDS with the images and can only be written behind a barrier)
+__device__ __forceinline__ void hn_bwd_row2_core(const f32x16 (&acc)[2], float mul, bool valid, const char *rawimg, const char *cosimg,
+                                                 const char *sinimg, int row, bool rope, const float *gain, int half, float (&cr)[32],
+                                                 f32x16 (&out)[2]) {
     float dn[32], v[32];
     const int swz = (row >> 1) & 7;
 #pragma unroll
@@ -1496,7 +1500,7 @@ __device__ __forceinline__ void hn_bwd_row2(const f32x16 (&acc)[2], float mul, b
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int i = db * 16 + 4 * g + e;
-                colred_row[db * 32 + 8 * g + 4 * half + e] = dn[i] * v[i] * rs;
+                cr[i] = dn[i] * v[i] * rs;
                 dn[i] *= gg[e];
                 kdot += dn[i] * v[i];
             }
@@ -1508,12 +1512,27 @@ __device__ __forceinline__ void hn_bwd_row2(const f32x16 (&acc)[2], float mul, b
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[db][r] = rs * dn[db * 16 + r] - v[db * 16 + r] * k;
 }
+__device__ __forceinline__ void hn_colred_store(const float (&cr)[32], int half, float *colred_row) {
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) colred_row[db * 32 + 8 * g + 4 * half + e] = cr[db * 16 + 4 * g + e];
+}
+__device__ __forceinline__ void hn_bwd_row2(const f32x16 (&acc)[2], float mul, bool valid, const char *rawimg, const char *cosimg,
+                                            const char *sinimg, int row, bool rope, const float *gain, int half, float *colred_row,
+                                            f32x16 (&out)[2]) {
+    float cr[32];
+    hn_bwd_row2_core(acc, mul, valid, rawimg, cosimg, sinimg, row, rope, gain, half, cr, out);
+    hn_colred_store(cr, half, colred_row);
+}
 // the three epilogue images of a 128-row block (rows row0 .. of a sequence of S rows, position = row): raw | cos | sin
-template <typename HN> __device__ __forceinline__ void hn_dma_inputs(HN &h, int64_t seq_row0, int pos0, int nrows, int hh, char *img, int wave8) {
-    dma_rows128(static_cast<const __bf16 *>(h.raw) + seq_row0 * h.ldraw + hh * 64, h.ldraw, nrows, img, wave8);
+template <int NT = 512, typename HN> __device__ __forceinline__ void hn_dma_inputs(HN &h, int64_t seq_row0, int pos0, int nrows, int hh, char *img, int wave8) {
+    dma_rows128<NT>(static_cast<const __bf16 *>(h.raw) + seq_row0 * h.ldraw + hh * 64, h.ldraw, nrows, img, wave8);
     if (h.rope) {       // (fp32 rows of 64 = 128 bf16-sized elements; the first 128 bytes of each)
-        dma_rows128(reinterpret_cast<const __bf16 *>(h.cos_t + (int64_t)pos0 * 64), 128, nrows, img + 16384, wave8);
-        dma_rows128(reinterpret_cast<const __bf16 *>(h.sin_t + (int64_t)pos0 * 64), 128, nrows, img + 32768, wave8);
+        dma_rows128<NT>(reinterpret_cast<const __bf16 *>(h.cos_t + (int64_t)pos0 * 64), 128, nrows, img + 16384, wave8);
+        dma_rows128<NT>(reinterpret_cast<const __bf16 *>(h.sin_t + (int64_t)pos0 * 64), 128, nrows, img + 32768, wave8);
     }
 }
 
@@ -1733,6 +1752,136 @@ __global__ __launch_bounds__(512) void attn_bwd_pair2_kernel(AttnArgs a_dq, Attn
 #include "kk_attn_bwd_dkv2.inc"
 #undef a
     }
+}
+
+// ------------------------------------------------------------------ backward in two passes (kk_attn_bwd_ws)
+// The pair launch computes the scores, the exponentials, the dropout masks and dS TWICE (once per kernel: 7 S x S x 64 matmuls and
+// ~560 vector instructions per 32 x 32 unit where the algorithm needs 5 and ~330), because dQ is a sum over keys and dK / dV sums
+// over queries.  Here the dK/dV kernel — the same body — also stores dS as it feeds it to its dK MFMAs (bf16, [32 keys][32
+// queries] tiles of 2 KB: 2 bytes per score, 32 MB per launch at 8 x 8 x 512^2, mostly served back by the Infinity Cache), and dQ =
+// dS . K becomes a pass with NO vector work: four waves (one per 32 queries) stream K tiles and their dS tiles through a three-stage
+// DMA ring and issue 4 MFMAs per unit, both operands by transpose reads (K^T as in the dQ kernel; dS^T [key][query] the same way: a
+// 512-byte span of a tile per instruction, conflict free without a swizzle); the head-norm epilogue of the dQ kernel follows.
+// dS is bit-identical to what the dQ kernel computes for itself (same MFMA sums, same rounding), so dQ differs from the pair
+// launch's only by the order in which the key units are added (all of them in sequence here; two interleaved halves there).
+__global__ __launch_bounds__(512) void attn_bwd_dkv2s_kernel(AttnArgs a) {
+#define KK_DKV_STORE_DS 1
+#include "kk_attn_bwd_dkv2.inc"
+#undef KK_DKV_STORE_DS
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dqpass_kernel(AttnArgs a) {
+    typedef __bf16 T;
+    constexpr int NS = 3, KIMG = 64 * 64 * 2, DIMG = 2 * 4 * 2048, STAGE = KIMG + DIMG, NPT = 6;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];        // [stage][K image | 2 key units x 4 query units of dS]
+    int bx_, by_;
+    attn_block(a, bx_, by_, true);
+    const int b = by_ / a.heads, hh = by_ % a.heads;
+    const int qblk = bx_ * 128;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, l31 = lane & 31;
+    const int qmin = qblk + 32 * wave;
+    const bool qvalid = qmin + l31 < a.Sq;
+    int kend = a.Sk;
+    if (a.causal && qblk + 128 < kend) kend = qblk + 128;
+    int klim = kend;
+    if (a.causal && qmin + 32 < klim) klim = qmin + 32;
+    const int nt = (kend + 63) >> 6;
+    const int nqu4 = ((a.Sq + 127) >> 7) << 2, nku = (a.Sk + 31) >> 5;
+    const T *Kb = static_cast<const T *>(a.K) + (int64_t)b * a.Sk * a.ldk + hh * 64;
+    const char *dsb = static_cast<const char *>(a.dS) + (int64_t)(b * a.heads + hh) * nku * nqu4 * 2048;
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(Kb), 0, (int)((((int64_t)a.Sk - 1) * a.ldk + 64) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(dsb), 0, (int)((int64_t)nku * nqu4 * 2048), 0x00020000);
+    uint32_t kvo[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = threadIdx.x + 256 * j, row = p >> 3, pc = p & 7;
+        kvo[j] = (uint32_t)(((int64_t)row * a.ldk + ((pc ^ (kk_xb(row) << 1)) * 8)) * 2);
+    }
+    const uint32_t ktile = (uint32_t)(64 * a.ldk * 2);
+    const uint32_t drow = (uint32_t)(nqu4 * 2048), dq0 = (uint32_t)((qblk >> 5) * 2048 + threadIdx.x * 16);
+    auto issue_tile = [&](int t, int st) {
+        char *dst = smem_raw + st * STAGE + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, KK_LDS_PTR(dst + j * 4096), 16, kvo[j] + (uint32_t)t * ktile, 0, 0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)           // the four query units' tiles of a key unit are one 8 KB run
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, KK_LDS_PTR(dst + KIMG + kk * 8192 + j * 4096), 16,
+                                                         (uint32_t)(2 * t + kk) * drow + dq0 + (uint32_t)j * 4096, 0, 0, 0);
+    };
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < nt) issue_tile(t, t);
+    const uint32_t sl = (uint32_t)(uintptr_t)KK_LDS_PTR(smem_raw);
+    uint32_t ta[2], da;
+    {
+        const int L = lane & 15, kq = L >> 2, gi = (lane >> 4) & 1, xb = (((kq >> 1) & 1) << 1) | half;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) ta[db] = (uint32_t)((4 * half + kq) * 128 + (((2 * db + gi) ^ xb) * 32) + 8 * (L & 3));
+        da = (uint32_t)(KIMG + wave * 2048 + (4 * half + kq) * 64 + gi * 32 + 8 * (L & 3));
+    }
+    f32x16 dq[2];
+    zero_acc(dq[0]); zero_acc(dq[1]);
+    for (int t = 0; t < nt; ++t) {
+        const int younger = min(nt - 1 - t, NS - 2);
+        if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + NS - 1 < nt) issue_tile(t + NS - 1, (t + NS - 1) % NS);
+        const uint32_t stg = sl + (uint32_t)((t % NS) * STAGE);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if (t * 64 + 32 * kk >= klim) continue;
+            s16x4 tlo[4], thi[4], dlo[2], dhi[2];
+            const uint32_t a0 = stg + kk * 4096 + ta[0], a1 = stg + kk * 4096 + ta[1], d0 = stg + kk * 8192 + da;
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dlo[0]) : "v"(d0));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:512" : "=v"(dhi[0]) : "v"(d0));
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(tlo[0]) : "v"(a0));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(thi[0]) : "v"(a0));
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(tlo[1]) : "v"(a1));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(thi[1]) : "v"(a1));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(dlo[1]) : "v"(d0));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1536" : "=v"(dhi[1]) : "v"(d0));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(tlo[2]) : "v"(a0));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:3072" : "=v"(thi[2]) : "v"(a0));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(tlo[3]) : "v"(a1));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:3072" : "=v"(thi[3]) : "v"(a1));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(tlo[i]), "+v"(thi[i]));
+#pragma unroll
+            for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(dlo[i]), "+v"(dhi[i]));
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_pair(tlo[s2 * 2 + db], thi[s2 * 2 + db]), tr_pair(dlo[s2], dhi[s2]), dq[db], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                           // the ring is free
+    T *out0 = static_cast<T *>(a.Out) + ((int64_t)b * a.Sq + qmin) * a.ldout + hh * 64;
+    char *otile = smem_raw + 36864 + wave * 4608;
+    if (a.hn[0].raw == nullptr) {
+        store_rows_via_lds(out0, a.ldout, a.Sq - qmin, dq, a.scale, otile, lane, a.wt);
+        return;
+    }
+    const int nrows = a.Sq - qblk < 128 ? a.Sq - qblk : 128;
+    hn_dma_inputs<256>(a.hn[0], (int64_t)b * a.Sq + qblk, qblk, nrows, hh, smem_raw, wave);       // raw | cos | sin: 48 KB
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16 dx[2];
+    float cr[32];
+    hn_bwd_row2_core(dq, a.scale, qvalid, smem_raw, smem_raw + 16384, smem_raw + 32768, wave * 32 + l31, a.hn[0].rope != 0, a.hn[0].gain, half, cr, dx);
+    __syncthreads();                                           // every wave has read its image rows: colred and the store tiles lie over them
+    float *colred = reinterpret_cast<float *>(smem_raw);       // [128 rows][65]
+    hn_colred_store(cr, half, colred + (wave * 32 + l31) * 65);
+    store_rows_via_lds(out0, a.ldout, a.Sq - qmin, dx, 1.f, otile, lane, a.wt);
+    __syncthreads();
+    hn_colsum(colred, a.hn[0].partials);
 }
 
 // Delta[b,h,q] = sum_d dO*O : one wave per (row, head).
@@ -2030,5 +2179,73 @@ extern "C" int kk_attn_bwd(const float *Q, const float *K, const float *V, const
     }
     hipLaunchKernelGGL(attn_bwd_pair2_kernel, dim3(kk_cdiv(Sq, 128), B * heads, 2), dim3(512), lds_bytes, (hipStream_t)stream, p.dq, p.dkv);
     KK_LAUNCH_CHECK("kk_attn_bwd");
+    return 0;
+}
+
+// Backward in two passes through a caller-owned workspace (see attn_bwd_dkv2s_kernel): the same contract and fall-backs as
+// kk_attn_bwd, which is what runs when ws is null / too small or the launch is not eligible for the pair launch either.
+extern "C" int64_t kk_attn_bwd_ws_bytes(int B, int heads, int Sq, int Sk) {
+    if (B <= 0 || heads <= 0 || Sq <= 0 || Sk <= 0) return 0;
+    return (int64_t)B * heads * kk_cdiv(Sk, 32) * (kk_cdiv(Sq, 128) * 4) * 2048;
+}
+// Whether the two passes are the faster form for this shape (advice to the caller, who hands kk_attn_bwd_ws a workspace only then;
+// the entry point itself takes the two passes whenever it gets an adequate workspace and the kernels serve the launch).  The dQ
+// pass streams the dS tiles at ~3.5 TB/s (a CU keeps ~64 lines in flight whatever issues them), 17 us of a 37-47 us launch at
+// 8 x 8 x 512^2 — so the two passes lose there and win where the pair launch is long and not lopsided: full attention from 1024^2 up
+// (146 -> 128 us; causal 92 -> 90: left to the pair launch, whose halves balance each other).  KK_ATTN_BWD_TWO_PASS=2: always, 0: never.
+static int attn_two_pass_mode() {
+    static const int v = kk_tune_env("KK_ATTN_BWD_TWO_PASS", 1);
+    return v;
+}
+extern "C" int kk_attn_bwd_two_pass(int B, int heads, int Sq, int Sk, int causal) {
+    const int mode = attn_two_pass_mode();
+    if (mode == 0 || B <= 0 || heads <= 0 || Sq <= 64 || Sk <= 64 || Sk > 4096 || (causal && Sq != Sk)) return 0;
+    if (mode == 2) return 1;
+    return !causal && (int64_t)Sq * Sk >= (1ll << 20);
+}
+
+extern "C" int kk_attn_bwd_ws(const float *Q, const float *K, const float *V, const float *dO, const float *LSE, const float *Delta,
+                              float *dQ, float *dK, float *dV, int B, int heads, int Sq, int Sk, int64_t ldq, int64_t ldk,
+                              int64_t ldv, int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, const uint8_t *key_mask,
+                              int causal, float scale, const uint32_t *seed, uint32_t site, float p_drop, int math, int io_bf16,
+                              const KkAttnHeadNorm *hn_q, const KkAttnHeadNorm *hn_kv, void *ws, int64_t ws_bytes, void *stream) {
+    KK_REQUIRE(Delta != nullptr, "kk_attn_bwd_ws: Delta is an input of this call");
+    KK_REQUIRE((hn_q == nullptr) == (hn_kv == nullptr), "kk_attn_bwd_ws: head-norm epilogues for both kernels or for neither");
+    const int two_pass = attn_two_pass_mode() != 0;             // (the shape policy is the caller's: kk_attn_bwd_two_pass)
+    const int64_t per_head = (int64_t)kk_cdiv(Sk, 32) * (kk_cdiv(Sq, 128) * 4) * 2048;
+    const bool ok = two_pass && ws && al16(ws) && ws_bytes >= kk_attn_bwd_ws_bytes(B, heads, Sq, Sk) && per_head < (1ll << 31) &&
+                    io_bf16 && math == KK_MATH_BF16 && (attn_v2_mask() & 6) == 6 && g_attn_groups == 2 && Sk > 64 && Sq > 64 && Sk <= 4096 &&
+                    (!causal || Sq == Sk) && al16(Q) && al16(K) && al16(V) && al16(dO) && al16(dQ) && al16(dK) && al16(dV) &&
+                    (!hn_q || (al16(hn_q->raw) && (!hn_q->rope || (al16(hn_q->cos_t) && al16(hn_q->sin_t))))) &&
+                    (!hn_kv || (al16(hn_kv[0].raw) && al16(hn_kv[1].raw) && !hn_kv[1].rope &&
+                                (!hn_kv[0].rope || (al16(hn_kv[0].cos_t) && al16(hn_kv[0].sin_t))))) &&
+                    (int64_t)Sk * std::max(ldk, ldv) * 2 < (1ll << 31) && (int64_t)Sq * std::max(ldq, lddo) * 2 < (1ll << 31);
+    if (!ok)
+        return kk_attn_bwd(Q, K, V, dO, LSE, Delta, dQ, dK, dV, B, heads, Sq, Sk, ldq, ldk, ldv, lddo, lddq, lddk, lddv, key_mask, causal,
+                           scale, seed, site, p_drop, math, io_bf16, hn_q, hn_kv, stream);
+    KK_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "kk_attn_bwd_ws: dropout probability must be in [0,1)");
+    const int64_t lds[7] = {ldq, ldk, ldv, lddo, lddq, lddk, lddv};
+    if (int rc = check_common("kk_attn_bwd_ws", B, heads, Sq, Sk, math, lds, 7)) return rc;
+    AttnArgs a = {};
+    a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.LSE = LSE; a.Delta = Delta; a.Out = dK; a.Out2 = dV; a.key_mask = key_mask;
+    a.B = B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.causal = causal;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.lddo = lddo; a.ldout = lddk; a.ldout2 = lddv; a.scale = scale;
+    a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(causal); a.dbg = attn_dbg();
+    a.wt = kk_write_through((int64_t)B * std::max(Sq, Sk));
+    a.dS = ws;
+    if (hn_q) {
+        if (int rc = check_headnorm("kk_attn_bwd_ws", hn_q, 1)) return rc;
+        if (int rc = check_headnorm("kk_attn_bwd_ws", hn_kv, 2)) return rc;
+        a.hn[0] = hn_kv[0]; a.hn[1] = hn_kv[1];
+    }
+    if (int rc = launch_attn(attn_bwd_dkv2s_kernel, dim3(kk_cdiv(Sk, 128), B * heads), 2, (size_t)2 * 3 * (16384 + 512) + 3 * 16384, (hipStream_t)stream, a))
+        return rc;
+    KK_LAUNCH_CHECK("kk_attn_bwd_ws (dK, dV, dS)");
+    a.Out = dQ; a.Out2 = nullptr; a.ldout = lddq; a.ldout2 = 0;
+    a.hn[0] = KkAttnHeadNorm{}; a.hn[1] = KkAttnHeadNorm{};
+    if (hn_q) a.hn[0] = hn_q[0];
+    if (int rc = launch_attn(attn_bwd_dqpass_kernel, dim3(kk_cdiv(Sq, 128), B * heads), 1, (size_t)3 * (8192 + 16384), (hipStream_t)stream, a))
+        return rc;
+    KK_LAUNCH_CHECK("kk_attn_bwd_ws (dQ pass)");
     return 0;
 }

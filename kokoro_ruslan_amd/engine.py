@@ -198,6 +198,9 @@ class KokoroEngine:
         # attention backward as ONE launch (kk_attn_bwd: the dQ and the dK/dV kernel as the two halves of a grid), Delta from the
         # epilogue of the w_o dgrad GEMM (kk_gemm_dgrad_delta) — bf16 storage, shapes that take the eight-wave GEMM tile
         self.attn_bwd_pair = True
+        # ... or, where the library prices it cheaper (kk_attn_bwd_two_pass: full attention from 1024 x 1024 scores per head), as the
+        # dK/dV kernel that also stores dS + a dQ pass without softmax work (kk_attn_bwd_ws; workspace of 2 bytes per score per stream)
+        self.attn_two_pass = True
         self.attn_pair_min_seq = 32                # (one-tile sequences included: the text encoder's 33..64 phonemes; 64 = the round-2 dispatch)
         self.attn_proj_bf16 = True                 # decoder w_o output stored as bf16 (bf16 mode)
         # The zero-fill at the start of an accumulation cycle skips what the cycle's first grouped weight-gradient launches
@@ -739,12 +742,21 @@ class KokoroEngine:
                 self._reduce_lists[self._tmp_ns].append((part[j], dg_, None, nb, 64, 64))
             return table
 
+        def bwd_one_call(*args):
+            """kk_attn_bwd, or — where the library says the shape pays (kk_attn_bwd_two_pass: full attention from 1024 x 1024 scores per
+            head up) — kk_attn_bwd_ws with this stream's dS workspace (2 bytes per score; "tmp.": private to the stream)."""
+            if self.attn_two_pass and kk.load().kk_attn_bwd_two_pass(B, h, Sq, Sk, cz):
+                need = kk.load().kk_attn_bwd_ws_bytes(B, h, Sq, Sk)
+                kk.call("kk_attn_bwd_ws", *args, self._buf("tmp.attn_dS", need, dtype=torch.uint8), need)
+            else:
+                kk.call("kk_attn_bwd", *args)
+
         if xkv is None:
             if pair:       # dQ | dK, dV in one launch, the head norms' backward as their epilogues
-                kk.call("kk_attn_bwd", q_n, k_n, v_n, dctx, lse, delta, dq_raw, dk_raw, dv_raw, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H,
-                        ld(dq_raw), ld(dk_raw), ld(dv_raw), key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16,
-                        hn_tables("q", Sq, [(q_raw, gq, dgq, cos, sin)]),
-                        hn_tables("kv", Sk, [(k_raw, gk, dgk, cos, sin), (v_raw, gv, dgv, None, None)]))
+                bwd_one_call(q_n, k_n, v_n, dctx, lse, delta, dq_raw, dk_raw, dv_raw, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H,
+                             ld(dq_raw), ld(dk_raw), ld(dv_raw), key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16,
+                             hn_tables("q", Sq, [(q_raw, gq, dgq, cos, sin)]),
+                             hn_tables("kv", Sk, [(k_raw, gk, dgk, cos, sin), (v_raw, gv, dgv, None, None)]))
             elif fuse:     # the head norms' backward is the epilogue of the two attention backward kernels
                 kk.call("kk_attn_bwd_dq", q_n, k_n, v_n, dctx, lse, delta, dq_raw, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H, ld(dq_raw),
                         key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16, ctx, H, hn_tables("q", Sq, [(q_raw, gq, dgq, cos, sin)]))
@@ -763,10 +775,10 @@ class KokoroEngine:
             return
         if pair:
             dkv_raw, _ = self._cross_kv(layer, Nk, dt, "d")
-            kk.call("kk_attn_bwd", q_n, k_n, v_n, dctx, lse, delta, dq_raw, dkv_raw, dkv_raw[:, H:], B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H,
-                    ld(dq_raw), ld(dkv_raw), ld(dkv_raw), key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16,
-                    hn_tables("q", Sq, [(q_raw, gq, dgq, None, None)]),
-                    hn_tables("kv", Sk, [(k_raw, gk, dgk, None, None), (v_raw, gv, dgv, None, None)]))
+            bwd_one_call(q_n, k_n, v_n, dctx, lse, delta, dq_raw, dkv_raw, dkv_raw[:, H:], B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H,
+                         ld(dq_raw), ld(dkv_raw), ld(dkv_raw), key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16,
+                         hn_tables("q", Sq, [(q_raw, gq, dgq, None, None)]),
+                         hn_tables("kv", Sk, [(k_raw, gk, dgk, None, None), (v_raw, gv, dgv, None, None)]))
         elif fuse:
             kk.call("kk_attn_bwd_dq", q_n, k_n, v_n, dctx, lse, delta, dq_raw, B, h, Sq, Sk, ld(q_n), ld(k_n), ld(v_n), H, ld(dq_raw),
                     key_mask, cz, 0.125, self.rng, site + 3, p, self.math, i16, ctx, H,

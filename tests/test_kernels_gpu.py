@@ -1240,6 +1240,83 @@ def test_attention_backward_headnorm_epilogue(kk, B, h, Sq, Sk, causal, rope, bf
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,h,Sq,Sk,causal,rope,p,masked", [(8, 8, 512, 512, 1, 1, 0.2, 0), (8, 8, 512, 512, 0, 0, 0.2, 1), (2, 8, 1024, 1024, 1, 1, 0.2, 0),
+                                                            (1, 2, 900, 1000, 0, 1, 0.1, 1), (2, 2, 300, 384, 0, 0, 0.0, 0), (2, 4, 200, 200, 1, 1, 0.0, 0),
+                                                            (1, 2, 130, 400, 0, 0, 0.1, 0), (1, 2, 1000, 1000, 1, 1, 0.2, 1), (3, 4, 41, 41, 0, 1, 0.15, 1)])
+def test_attention_backward_two_pass(kk, B, h, Sq, Sk, causal, rope, p, masked):
+    """kk_attn_bwd_ws (the dK/dV kernel also stores dS; dQ = dS . K as a pass without softmax work) against kk_attn_bwd given the same
+    Delta: dK, dV and the k / v gain partials bit for bit (the same kernel body), dQ and the q gain partials within the rounding of
+    a different summation order over the key units (same bf16 dS, same K: fp32 sums of the same products) — and against the
+    workspace being poisoned beforehand (every tile the pass reads must have been written by this call).  The last case (one key
+    tile) takes kk_attn_bwd inside the entry point."""
+    g = torch.Generator().manual_seed(B * Sq + Sk + causal + 17)
+    H = h * 64
+    dt = torch.bfloat16
+    raw_q = dev(torch.randn(B * Sq, H, generator=g)).to(dt)
+    raw_kv = dev(torch.randn(B * Sk, 2 * H, generator=g)).to(dt)
+    gains = [dev(1.0 + 0.2 * torch.randn(64, generator=g)) for _ in range(3)]
+    c, s = ((dev(t) for t in O.rope_tables(max(Sq, Sk), 64)) if rope else (None, None))
+    q_n, kv_n = torch.empty_like(raw_q), torch.empty_like(raw_kv)
+    kk.call("kk_headnorm_rope_fwd", raw_q, H, q_n, H, B * Sq, h, Sq, 1, gains[0], None, None, 1 if rope else 0, c, s, 1)
+    kk.call("kk_headnorm_rope_fwd", raw_kv, 2 * H, kv_n, 2 * H, B * Sk, h, Sk, 2, gains[1], gains[2], None, 1 if rope else 0, c, s, 1)
+    k_n, v_n = kv_n, kv_n[:, H:]
+    km = None
+    if masked:
+        km = torch.zeros(B, Sk, dtype=torch.uint8)
+        km[:, Sk - 37:] = 1
+        km[0, 5] = 1
+        km = dev(km)
+    do = dev(torch.randn(B * Sq, H, generator=g)).to(dt)
+    o, lse = torch.empty(B * Sq, H, device="cuda", dtype=dt), torch.empty(B, h, Sq, device="cuda")
+    seed = torch.tensor([91], dtype=torch.int32, device="cuda")
+    kk.call("kk_attn_fwd", q_n, k_n, v_n, o, lse, B, h, Sq, Sk, H, 2 * H, 2 * H, H, km, causal, 0.125, seed, 5, p, 1, 1)
+    delta = torch.empty(B, h, Sq, device="cuda")
+    kk.call("kk_attn_delta", o, do, delta, B, h, Sq, H, H, 1)
+    nbq, nbk = kk.load().kk_attn_bwd_blocks(B, h, Sq), kk.load().kk_attn_bwd_blocks(B, h, Sk)
+    need = kk.load().kk_attn_bwd_ws_bytes(B, h, Sq, Sk)
+    assert need == B * h * ((Sk + 31) // 32) * ((Sq + 127) // 128) * 4 * 2048
+    pol = kk.load().kk_attn_bwd_two_pass
+    assert pol(8, 8, 1024, 1024, 0) == 1 and pol(8, 8, 512, 512, 0) == 0 and pol(8, 8, 1024, 1024, 1) == 0 and pol(8, 8, 64, 64, 0) == 0
+    ws = torch.full((need // 2,), float("nan"), device="cuda", dtype=torch.bfloat16)
+
+    def run(two_pass, hn):
+        pq, pkv = torch.full((1, nbq, 64), 5.0, device="cuda"), torch.full((2, nbk, 64), 5.0, device="cuda")
+        dq, dkv = torch.full_like(raw_q, 7.0), torch.full_like(raw_kv, 7.0)
+        hq = kk.attn_headnorm([(raw_q, gains[0], pq[0], c, s)]) if hn else None
+        hkv = kk.attn_headnorm([(raw_kv, gains[1], pkv[0], c, s), (raw_kv[:, H:], gains[2], pkv[1], None, None)]) if hn else None
+        args = (q_n, k_n, v_n, do, lse, delta, dq, dkv, dkv[:, H:], B, h, Sq, Sk, H, 2 * H, 2 * H, H, H, 2 * H, 2 * H, km, causal, 0.125, seed, 5, p,
+                1, 1, hq, hkv)
+        if two_pass:
+            ws.fill_(float("nan"))
+            kk.call("kk_attn_bwd_ws", *args, ws, need)
+        else:
+            kk.call("kk_attn_bwd", *args)
+        torch.cuda.synchronize()
+        return dq, dkv, pq, pkv
+
+    for hn in (True, False):
+        ref, new = run(False, hn), run(True, hn)
+        assert torch.equal(ref[1], new[1]) and torch.equal(ref[3], new[3]), f"hn={hn}: dK, dV (and the k / v gain partials): the same kernel body"
+        assert torch.isfinite(new[0].float()).all(), "every dS tile the pass read was written by this call"
+        close(new[0], ref[0], 4e-2, 2e-2, f"hn={hn}: dQ")
+        if hn:
+            gq_new, gq_ref = new[2][0].sum(0), ref[2][0].sum(0)
+            # (the epilogue rounds dQ to bf16 before the norm's backward, as the unfused path stores it: a different summation order flips
+            #  the last bit of about half the elements, and the gain gradient sums B * Sq * h such rows per column)
+            close(gq_new, gq_ref, 5e-3 * math.sqrt(B * Sq * h), 1e-2, "gain gradient q")
+    # a workspace that is too small (or none): the pair launch runs, bit for bit
+    ref = run(False, True)
+    dq, dkv = torch.full_like(raw_q, 7.0), torch.full_like(raw_kv, 7.0)
+    pq, pkv = torch.full((1, nbq, 64), 5.0, device="cuda"), torch.full((2, nbk, 64), 5.0, device="cuda")
+    hq = kk.attn_headnorm([(raw_q, gains[0], pq[0], c, s)])
+    hkv = kk.attn_headnorm([(raw_kv, gains[1], pkv[0], c, s), (raw_kv[:, H:], gains[2], pkv[1], None, None)])
+    kk.call("kk_attn_bwd_ws", q_n, k_n, v_n, do, lse, delta, dq, dkv, dkv[:, H:], B, h, Sq, Sk, H, 2 * H, 2 * H, H, H, 2 * H, 2 * H, km, causal, 0.125,
+            seed, 5, p, 1, 1, hq, hkv, ws, need - 2048)
+    torch.cuda.synchronize()
+    assert torch.equal(dq, ref[0]) and torch.equal(dkv, ref[1]) and torch.equal(pq, ref[2])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,S,h,K", [(8, 512, 8, 512), (4, 1024, 8, 512), (3, 700, 8, 192), (16, 512, 4, 256), (8, 64, 8, 512), (5, 41, 8, 512),
                                      (8, 1024, 8, 512), (11, 777, 8, 256)])      # (the last two: 128x128 tiles, a head per wave)
 def test_gemm_dgrad_delta_epilogue(kk, B, S, h, K):
