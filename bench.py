@@ -297,9 +297,10 @@ def pmc_entry(B, T, P, math, kernel):
         if not os.path.exists(f):
             continue
         pmc = json.load(open(f))
-        ent = pmc.get("kernels", {}).get(kernel.split(" (")[0])
-        if ent and pmc.get("workload") == [B, T, P, math]:
-            return (round(ent["fetch_bytes_per_launch"] + ent["write_bytes_per_launch"]), ent.get("mfma_busy"), pmc.get("method"),
+        parts = [pmc.get("kernels", {}).get(sym) for sym in kernel.split(" (")[0].split(" + ")]      # (an entry point of two kernels: both)
+        if all(parts) and pmc.get("workload") == [B, T, P, math]:
+            busy = parts[0].get("mfma_busy") if len(parts) == 1 else None
+            return (round(sum(e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"] for e in parts)), busy, pmc.get("method"),
                     os.path.basename(f))
     return None, None, None, None
 

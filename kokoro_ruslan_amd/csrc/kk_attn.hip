@@ -1459,6 +1459,7 @@ __device__ __forceinline__ void hn_bwd_row2_core(const f32x16 (&acc)[2], float m
                                                  const char *sinimg, int row, bool rope, const float *gain, int half, float (&cr)[32],
                                                  f32x16 (&out)[2]) {
     float dn[32], v[32];
+    asm volatile("" : "+v"(row));          // (or the image addresses below are computed in the prologue and spilled across the main loop)
     const int swz = (row >> 1) & 7;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
