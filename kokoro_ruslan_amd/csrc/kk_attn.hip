@@ -2191,7 +2191,7 @@ extern "C" int64_t kk_attn_bwd_ws_bytes(int B, int heads, int Sq, int Sk) {
 }
 // Whether the two passes are the faster form for this shape (advice to the caller, who hands kk_attn_bwd_ws a workspace only then;
 // the entry point itself takes the two passes whenever it gets an adequate workspace and the kernels serve the launch).  The dQ
-// pass streams the dS tiles at ~3.5 TB/s (a CU keeps ~64 lines in flight whatever issues them), 17 us of a 37-47 us launch at
+// pass reads the dS tiles back from the Infinity Cache (~11 B/clk/CU with every CU streaming), 17 us of a 37-47 us launch at
 // 8 x 8 x 512^2 — so the two passes lose there and win where the pair launch is long and not lopsided: full attention from 1024^2 up
 // (146 -> 128 us; causal 92 -> 90: left to the pair launch, whose halves balance each other).  KK_ATTN_BWD_TWO_PASS=2: always, 0: never.
 static int attn_two_pass_mode() {
