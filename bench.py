@@ -190,7 +190,7 @@ def kernel_table(records, math_bf16: bool):
             B, h, Sq, Sk = (int(x) for x in sc[:4])
             causal = int(sc[-6])
             # (the text encoder's one-tile launches, S <= 64, are a different regime from the decoder's: listed apart)
-            key = "attn_bwd_pair2_kernel (dQ | dK, dV in one launch)" + (", one-tile sequences (text encoder)" if max(Sq, Sk) <= 64 else "")
+            key = "attn_bwd_pair3_kernel (dQ | dK, dV in one launch, two workgroups per CU)" + (", one-tile sequences (text encoder)" if max(Sq, Sk) <= 64 else "")
             # §8d: training = 3 x forward, no credit for recomputation — the backward of the forward's 2 matmuls is 4 (dV, dP, dQ, dK);
             # the launch EXECUTES 7 (S and dP are computed by both halves): executed work is not algorithmic work
             flops = 4 * 2.0 * B * h * Sq * Sk * 64 * (0.5 if causal else 1.0)
@@ -198,7 +198,7 @@ def kernel_table(records, math_bf16: bool):
         elif name == "kk_attn_bwd_ws":                  # (... as kk_attn_bwd ..., ws_bytes): two kernels behind one entry point, event-timed together
             B, h, Sq, Sk = (int(x) for x in sc[:4])
             causal = int(sc[-7])
-            key = "attn_bwd_dkv2s_kernel + attn_bwd_dqpass_kernel (dK, dV and the dS tiles, then dQ = dS.K)"
+            key = "attn_bwd_dkv3s_kernel + attn_bwd_dqpass_kernel (dK, dV and the dS tiles, then dQ = dS.K)"
             flops = 4 * 2.0 * B * h * Sq * Sk * 64 * (0.5 if causal else 1.0)        # executes 5: S is the only recomputation left
             byts = 2.0 * B * h * 64 * (4 * Sq + 4 * Sk) + 2 * 2.0 * B * h * Sq * Sk * (0.5 if causal else 1.0)   # + dS written and read once
         elif name in ("kk_attn_fwd", "kk_attn_bwd_dq", "kk_attn_bwd_dkv"):
@@ -213,8 +213,8 @@ def kernel_table(records, math_bf16: bool):
                             "attn_fwd3_q128_kernel (flash forward, 2 workgroups per CU, 128-query blocks x 2 key slots)" if _cd(Sq, 128) * B * h >= 512 else
                             "attn_fwd3_q64_kernel (flash forward, 2 workgroups per CU, 64-query blocks x 4 key slots)")
             key = {"kk_attn_fwd": fwd_name,
-                   "kk_attn_bwd_dq": "attn_bwd_dq2_kernel (dQ)" if v2 else "attn_bwd_dq_kernel (dQ, first generation)",
-                   "kk_attn_bwd_dkv": "attn_bwd_dkv2_kernel (dK, dV)" if v2 else "attn_bwd_dkv_kernel (dK, dV, first generation)"}[name]
+                   "kk_attn_bwd_dq": "attn_bwd_dq3_kernel (dQ)" if v2 else "attn_bwd_dq_kernel (dQ, first generation)",
+                   "kk_attn_bwd_dkv": "attn_bwd_dkv3_kernel (dK, dV)" if v2 else "attn_bwd_dkv_kernel (dK, dV, first generation)"}[name]
             flops = mm * 2.0 * B * h * Sq * Sk * 64 * (0.5 if causal else 1.0)
             byts = (2.0 if int(sc[-1 - off]) else 4.0) * B * h * 64 * (2 * Sq + 2 * Sk)
         keys = [key]

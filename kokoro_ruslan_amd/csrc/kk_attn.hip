@@ -46,6 +46,7 @@ struct AttnArgs {
     int xcd_map;
     int wt;                              // write-through stores of the [rows, 64] outputs (kk_common.h: kk_write_through(B * S))
     int dbg;                             // timing probes (KK_ATTN_DBG; results are wrong when set)
+    int short_first;                     // attn_bwd_pair3: the dK/dV half of a causal launch hands out its SHORT blocks first (see there)
     void *dS;                            // kk_attn_bwd_ws: bf16 dS tiles, written by the dK/dV kernel, read by the dQ pass (kk_attn_bwd_dkv2.inc)
     // backward kernels: the gradient of the per-head RMSNorm (+ RoPE) that produced Q (dQ kernel) / K and V (dK/dV
     // kernel: hn[0], hn[1]) as the epilogue — Out / Out2 then receive the gradient of the RAW projection
@@ -1755,6 +1756,31 @@ __global__ __launch_bounds__(512) void attn_bwd_pair2_kernel(AttnArgs a_dq, Attn
     }
 }
 
+// ------------------------------------------------------------------ backward, third generation: one wave group, two workgroups per CU
+// The second-generation bodies as ONE 256-thread group each (kk_attn_bwd_dq3.inc / kk_attn_bwd_dkv3.inc): <= 70 KB of LDS, so two
+// workgroups share a CU.  The waves per SIMD stay two (256 registers: the dK/dV half holds 64 accumulator registers per wave,
+// DESIGN section 9) but they now belong to INDEPENDENT workgroups: no common barrier, one's prologue / epilogue under the other's
+// loop, no merge of group partials, and the 2 x 256 workgroups of an 8 x 8 x 512^2 launch are resident at once (one round).  In the
+// pair launch the dK/dV half of a causal launch hands out its SHORT blocks first: the i-th workgroup of each half land on the same
+// CU, so every CU holds a long block of one kernel beside a short block of the other, concurrently.
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq3_kernel(AttnArgs a) {
+#include "kk_attn_bwd_dq3.inc"
+}
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(AttnArgs a) {
+#include "kk_attn_bwd_dkv3.inc"
+}
+__global__ __launch_bounds__(256, 2) void attn_bwd_pair3_kernel(AttnArgs a_dq, AttnArgs a_dkv) {
+    if (blockIdx.z == 0) {
+#define a a_dq
+#include "kk_attn_bwd_dq3.inc"
+#undef a
+    } else {
+#define a a_dkv
+#include "kk_attn_bwd_dkv3.inc"
+#undef a
+    }
+}
+
 // ------------------------------------------------------------------ backward in two passes (kk_attn_bwd_ws)
 // The pair launch computes the scores, the exponentials, the dropout masks and dS TWICE (once per kernel: 7 S x S x 64 matmuls and
 // ~560 vector instructions per 32 x 32 unit where the algorithm needs 5 and ~330), because dQ is a sum over keys and dK / dV sums
@@ -1768,6 +1794,11 @@ __global__ __launch_bounds__(512) void attn_bwd_pair2_kernel(AttnArgs a_dq, Attn
 __global__ __launch_bounds__(512) void attn_bwd_dkv2s_kernel(AttnArgs a) {
 #define KK_DKV_STORE_DS 1
 #include "kk_attn_bwd_dkv2.inc"
+#undef KK_DKV_STORE_DS
+}
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv3s_kernel(AttnArgs a) {      // (the one-group body: what kk_attn_bwd's dK/dV half runs)
+#define KK_DKV_STORE_DS 1
+#include "kk_attn_bwd_dkv3.inc"
 #undef KK_DKV_STORE_DS
 }
 
@@ -1927,6 +1958,18 @@ static int attn_pair() {                 // KK_ATTN_PAIR=0: kk_attn_bwd issues t
     static const int v = kk_tune_env("KK_ATTN_PAIR", 1);
     return v;
 }
+static int attn_gen3() {                 // KK_ATTN_BWD3: bit 0 the one-group backward kernels (two workgroups per CU), bit 1 short-first dK/dV half
+    static const int v = kk_tune_env("KK_ATTN_BWD3", 3);
+    return v;
+}
+static int g_attn_cus() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) return v;
+        return 256;
+    }();
+    return n;
+}
 static int attn_xcd_env() {
     static const int v = kk_tune_env("KK_ATTN_XCD", 2);
     return v;
@@ -2082,7 +2125,8 @@ extern "C" int kk_attn_bwd_dq(const float *Q, const float *K, const float *V, co
     const int G = (Sk > 64 && g_attn_groups == 2) ? 2 : 1;
     if (io_bf16 && (attn_v2_mask() & 2) && (G == 2 || attn_v2_small(Sq, Sk)) && g_attn_groups == 2 && Sk <= 4096 && al16(Q) && al16(K) && al16(V) && al16(dO) && al16(dQ) && (!O || al16(O)) &&
         (!hn || (al16(hn->raw) && (!hn->rope || (al16(hn->cos_t) && al16(hn->sin_t))))) && (int64_t)Sk * std::max(ldk, ldv) * 2 < (1ll << 31)) {
-        int rc2 = launch_attn(attn_bwd_dq2_kernel, grid, 2, (size_t)2 * 3 * 16384 + 512 + 3 * 16384, (hipStream_t)stream, a);
+        int rc2 = (!O && (attn_gen3() & 1)) ? launch_attn(attn_bwd_dq3_kernel, grid, 1, (size_t)3 * 16384 + 512 + 16384, (hipStream_t)stream, a)
+                                            : launch_attn(attn_bwd_dq2_kernel, grid, 2, (size_t)2 * 3 * 16384 + 512 + 3 * 16384, (hipStream_t)stream, a);
         if (rc2) return rc2;
         KK_LAUNCH_CHECK("kk_attn_bwd_dq");
         return 0;
@@ -2116,7 +2160,8 @@ extern "C" int kk_attn_bwd_dkv(const float *Q, const float *K, const float *V, c
     if (io_bf16 && (attn_v2_mask() & 4) && (G == 2 || attn_v2_small(Sq, Sk)) && g_attn_groups == 2 && al16(Q) && al16(K) && al16(V) && al16(dO) && al16(dK) && al16(dV) &&
         (!hn || (al16(hn[0].raw) && al16(hn[1].raw) && !hn[1].rope && (!hn[0].rope || (al16(hn[0].cos_t) && al16(hn[0].sin_t))))) &&
         (int64_t)Sq * std::max(ldq, lddo) * 2 < (1ll << 31)) {
-        int rc2 = launch_attn(attn_bwd_dkv2_kernel, grid, 2, (size_t)2 * 3 * (16384 + 512) + 3 * 16384, (hipStream_t)stream, a);
+        int rc2 = (attn_gen3() & 1) ? launch_attn(attn_bwd_dkv3_kernel, grid, 1, (size_t)71680, (hipStream_t)stream, a)
+                                    : launch_attn(attn_bwd_dkv2_kernel, grid, 2, (size_t)2 * 3 * (16384 + 512) + 3 * 16384, (hipStream_t)stream, a);
         if (rc2) return rc2;
         KK_LAUNCH_CHECK("kk_attn_bwd_dkv");
         return 0;
@@ -2171,6 +2216,21 @@ extern "C" int kk_attn_bwd(const float *Q, const float *K, const float *V, const
         p.dq.hn[0] = hn_q[0];
         p.dkv.hn[0] = hn_kv[0]; p.dkv.hn[1] = hn_kv[1];
     }
+    if (attn_gen3() & 1) {                                     // one wave group per workgroup: two workgroups per CU
+        const size_t lds3 = 71680;
+        static thread_local bool raised3 = false;
+        if (!raised3) {
+            hipError_t e = hipFuncSetAttribute((const void *)attn_bwd_pair3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+            if (e != hipSuccess) return kk_fail((int)e, "kk_attn_bwd: cannot reserve %zu bytes of LDS: %s", lds3, hipGetErrorString(e));
+            raised3 = true;
+        }
+        // (short blocks first only when both halves are resident at once — 2 workgroups per CU; with more rounds the longest-first
+        //  order of the second generation is the faster one: 8 x 8 x 1024^2 causal 79 against 96 us)
+        p.dkv.short_first = (causal && (attn_gen3() & 2) && (int64_t)kk_cdiv(Sq, 128) * B * heads <= g_attn_cus()) ? 1 : 0;
+        hipLaunchKernelGGL(attn_bwd_pair3_kernel, dim3(kk_cdiv(Sq, 128), B * heads, 2), dim3(256), lds3, (hipStream_t)stream, p.dq, p.dkv);
+        KK_LAUNCH_CHECK("kk_attn_bwd");
+        return 0;
+    }
     const size_t lds_bytes = std::max((size_t)2 * 3 * 16384 + 512 + 3 * 16384, (size_t)2 * 3 * (16384 + 512) + 3 * 16384);
     static thread_local bool raised = false;
     if (!raised) {
@@ -2202,7 +2262,9 @@ extern "C" int kk_attn_bwd_two_pass(int B, int heads, int Sq, int Sk, int causal
     const int mode = attn_two_pass_mode();
     if (mode == 0 || B <= 0 || heads <= 0 || Sq <= 64 || Sk <= 64 || Sk > 4096 || (causal && Sq != Sk)) return 0;
     if (mode == 2) return 1;
-    return !causal && (int64_t)Sq * Sk >= (1ll << 20);
+    // (against the second-generation pair launch the two passes won for full attention from 1024^2 up: 142 -> 125 us; the
+    //  third-generation pair launch runs that shape in 118 us, so with it the advice is "never")
+    return !(attn_gen3() & 1) && !causal && (int64_t)Sq * Sk >= (1ll << 20);
 }
 
 extern "C" int kk_attn_bwd_ws(const float *Q, const float *K, const float *V, const float *dO, const float *LSE, const float *Delta,
@@ -2239,7 +2301,8 @@ extern "C" int kk_attn_bwd_ws(const float *Q, const float *K, const float *V, co
         if (int rc = check_headnorm("kk_attn_bwd_ws", hn_kv, 2)) return rc;
         a.hn[0] = hn_kv[0]; a.hn[1] = hn_kv[1];
     }
-    if (int rc = launch_attn(attn_bwd_dkv2s_kernel, dim3(kk_cdiv(Sk, 128), B * heads), 2, (size_t)2 * 3 * (16384 + 512) + 3 * 16384, (hipStream_t)stream, a))
+    if (int rc = (attn_gen3() & 1) ? launch_attn(attn_bwd_dkv3s_kernel, dim3(kk_cdiv(Sk, 128), B * heads), 1, (size_t)71680, (hipStream_t)stream, a)
+                                   : launch_attn(attn_bwd_dkv2s_kernel, dim3(kk_cdiv(Sk, 128), B * heads), 2, (size_t)2 * 3 * (16384 + 512) + 3 * 16384, (hipStream_t)stream, a))
         return rc;
     KK_LAUNCH_CHECK("kk_attn_bwd_ws (dK, dV, dS)");
     a.Out = dQ; a.Out2 = nullptr; a.ldout = lddq; a.ldout2 = 0;

@@ -1,4 +1,4 @@
-"""GPU suite: the kernels the bf16 bench path ACTUALLY runs — attn_fwd2, attn_bwd_pair2 (kk_attn_bwd), kk_gemm_dgrad_delta — against
+"""GPU suite: the kernels the bf16 bench path ACTUALLY runs — attn_fwd3 (attn_fwd2 up to 128 keys), attn_bwd_pair3 (kk_attn_bwd), kk_gemm_dgrad_delta — against
 direct fp64 torch references at the bench shapes (8 x 8 heads x 512^2 and 1024^2), with everything the step turns on: attention-
 probability dropout, causal or key-padding masks, RoPE, and the head-norm backward epilogues.  (until now these kernels
 were compared with the repository's own first-generation kernels only.)

@@ -29,7 +29,7 @@ def test_kernel_table_accounts_for_the_attention_backward_pair_and_its_delta_gem
         ("kk_gemm_dgrad_glu", (B * S, 1536, H, H, 2003, 0.2), 0.027),
     ]
     t = b.kernel_table(recs, True)
-    pair = t["attn_bwd_pair2_kernel (dQ | dK, dV in one launch)"]
+    pair = t["attn_bwd_pair3_kernel (dQ | dK, dV in one launch, two workgroups per CU)"]
     full = 4 * 2.0 * B * h * S * S * 64            # the backward of a 2-matmul forward is 4 matmuls; recomputation earns nothing
     assert pair["launches"] == 2 and abs(pair["flops"] - (0.5 * full + full)) < 1.0          # causal = lower triangle
     assert pair["bytes"] == 2 * 2.0 * B * h * 64 * 8 * S

@@ -7,6 +7,8 @@ import torch
 from kokoro_ruslan_amd import lib as kk
 from oracle import kokoro_oracle as O
 
+if "--lib" in sys.argv:
+    kk.use_library(sys.argv[sys.argv.index("--lib") + 1])
 R = 6
 def graph_time(fn, reps=20):
     fn(); torch.cuda.synchronize()
