@@ -154,7 +154,7 @@ int kk_attn_bwd(const float *Q, const float *K, const float *V, const float *dO,
  * hn_q's partials differ by the order of the sum over key units.  ws == NULL, a workspace that is too small or a launch the two-pass
  * kernels do not serve (fp32 storage, one key tile, causal with Sq != Sk, unaligned operands): kk_attn_bwd runs.
  * kk_attn_bwd_two_pass(): whether the two passes are the faster form of a shape (the extra 2 bytes per score against the second
- * softmax: full attention from 1024 x 1024 scores per head up) — the caller's policy for handing over a workspace. */
+ * softmax) — the caller's policy for handing over a workspace; 0 for every shape beside the present kk_attn_bwd kernels. */
 int64_t kk_attn_bwd_ws_bytes(int B, int heads, int Sq, int Sk);
 int kk_attn_bwd_two_pass(int B, int heads, int Sq, int Sk, int causal);
 int kk_attn_bwd_ws(const float *Q, const float *K, const float *V, const float *dO, const float *LSE, const float *Delta,

@@ -198,8 +198,8 @@ class KokoroEngine:
         # attention backward as ONE launch (kk_attn_bwd: the dQ and the dK/dV kernel as the two halves of a grid), Delta from the
         # epilogue of the w_o dgrad GEMM (kk_gemm_dgrad_delta) — bf16 storage, shapes that take the eight-wave GEMM tile
         self.attn_bwd_pair = True
-        # ... or, where the library prices it cheaper (kk_attn_bwd_two_pass: full attention from 1024 x 1024 scores per head), as the
-        # dK/dV kernel that also stores dS + a dQ pass without softmax work (kk_attn_bwd_ws; workspace of 2 bytes per score per stream)
+        # ... or, where the library prices it cheaper (kk_attn_bwd_two_pass: nowhere beside the present pair launch), as the dK/dV
+        # kernel that also stores dS + a dQ pass without softmax work (kk_attn_bwd_ws; workspace of 2 bytes per score per stream)
         self.attn_two_pass = True
         self.attn_pair_min_seq = 32                # (one-tile sequences included: the text encoder's 33..64 phonemes; 64 = the round-2 dispatch)
         self.attn_proj_bf16 = True                 # decoder w_o output stored as bf16 (bf16 mode)
