@@ -344,7 +344,13 @@ def roofline_leg(eng, kk, batches, math, pmc_shape):
             e["l2_to_lds_floor_us"] = round(v["floor_us"] / v["launches"], 2)
         return e
     ranked = sorted(mfma, key=lambda k: -mfma[k]["ms"])
-    dom = entry(ranked[0])
+    # dominant = the kernel SYMBOL with the most time (what a rocprofv3 summary ranks by: the rows of one symbol — the pair launch's
+    # decoder and one-tile text-encoder launches — count together), reported through that symbol's largest row
+    sym_ms = {}
+    for k in ranked:
+        sym_ms[k.split(" (")[0]] = sym_ms.get(k.split(" (")[0], 0.0) + mfma[k]["ms"]
+    top_sym = max(sym_ms, key=sym_ms.get)
+    dom = entry(next(k for k in ranked if k.split(" (")[0] == top_sym))
     roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": dom["frac"],
             "traffic": dom["traffic"], "traffic_unit": "bytes/launch", "traffic_source": dom["pmc_method"],
             "traffic_scope": "mean over ALL launches of the kernel symbol in the PMC pass (for the attention pair launch that includes the "
