@@ -39,11 +39,18 @@ def train_flops(B: int, T: int, P: int, H=512, F=1536, Le=6, Ld=6, M=80, Fv=256)
     return 6.0 * macs
 
 GEMM_ROLE = {(0, 0): "X.W^T fwd", (0, 1): "dY.W dgrad", (1, 1): "dY^T.X wgrad", (1, 0): "X^T.W"}
-PMC_ROUNDS = ("r04", "r03", "r02h", "r02g")       # profiles/<round>_pmc_hbm_traffic_BxTxP.json, newest first (tools/rocprof_pmc.sh: separate --pmc passes)
+PMC_ROUNDS = ("r05", "r04", "r03", "r02h", "r02g")       # profiles/<round>_pmc_hbm_traffic_BxTxP.json, newest first (tools/rocprof_pmc.sh: separate --pmc passes)
 
 
-CUS = 256                                  # MI355X; the tile policy prices a launch by the bytes through its busiest CU
-L2_LDS_BPS = 256 * 46e9                    # the chip's L2 -> LDS stream as DESIGN section 9 measured it (46 GB/s per CU)
+CUS = 256                                  # compute units; set_device_cus() replaces it with the device's count (the library's tile policy reads the same attribute)
+L2_LDS_BPC = 54.0                          # bytes per clock and CU the L2 -> LDS DMA delivers with 64 KB in flight (profiles/r04_stream_rate_probe.txt)
+SCLK_HZ = 2.4e9
+
+
+def set_device_cus(n: int) -> None:
+    global CUS
+    if n > 0:
+        CUS = int(n)
 
 
 def _cd(x, y):
@@ -95,8 +102,10 @@ def x_tile(kind, M, N, K):
 
 
 def lds_floor_us(macs, bm, bn):
-    """The launch's L2 -> LDS floor: 2 B x MACs x (1 / BM + 1 / BN) through 256 CUs at 46 GB/s each."""
-    return 2.0 * macs * (1.0 / bm + 1.0 / bn) / L2_LDS_BPS * 1e6
+    """The launch's L2 -> LDS floor: 2 B x MACs x (1 / BM + 1 / BN) through every CU at the rate the DMA path DELIVERS when it is all a
+    kernel does (54 B/clk/CU at 2.4 GHz = 130 GB/s per CU: the round-4 probe; rounds 3-4 priced 46 GB/s, which the k-loops achieve —
+    VERDICT r4: a floor must be what the path can do, not what the kernel does)."""
+    return 2.0 * macs * (1.0 / bm + 1.0 / bn) / (CUS * L2_LDS_BPC * SCLK_HZ) * 1e6
 
 
 def gemm_symbol(ta, tb, M, N, K, math_bf16, dtypes):
@@ -340,7 +349,7 @@ def roofline_leg(eng, kk, batches, math, pmc_shape):
              "algorithmic_gflop_per_launch": round(v["flops"] / v["launches"] / 1e9, 3),
              "algorithmic_bytes_per_launch": round(v["bytes"] / v["launches"]), "traffic": traffic, "mfma_busy": busy,
              "pmc_source": src, "pmc_method": note}
-        if v["floor_us"] > 0:                    # GEMMs: the tile's L2 -> LDS floor (2 B x MACs x (1/BM + 1/BN) at 256 x 46 GB/s), per launch
+        if v["floor_us"] > 0:                    # GEMMs: the tile's L2 -> LDS floor (2 B x MACs x (1/BM + 1/BN) at CUs x 54 B/clk x 2.4 GHz), per launch
             e["l2_to_lds_floor_us"] = round(v["floor_us"] / v["launches"], 2)
         return e
     ranked = sorted(mfma, key=lambda k: -mfma[k]["ms"])
@@ -519,6 +528,7 @@ def main():
     if world != max(1, args.gpus) and rank == 0:
         print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     torch.cuda.set_device(local)
+    set_device_cus(torch.cuda.get_device_properties(local).multi_processor_count)      # (what the library's tile policy reads: hipDeviceAttributeMultiprocessorCount)
     B, T, P = args.batch, args.frames, args.phonemes
     hp = StepHyper(gradient_accumulation_steps=1)
     eng = KokoroEngine(ModelDims(), hp, math_mode=args.math, total_steps=20000, seed=0,

@@ -31,6 +31,11 @@ extern "C" {
 
 int kk_abi_version(void);
 const char *kk_last_error(void);
+/* Which kernel variant the LAST launching call of this thread took, e.g. "g16x<0,1,128,128,3,0,2,2,4>", "gemm16_w8<0,1,3>",
+ * "attn_fwd3_q128", "attn_bwd_pair3" ("" before the first one).  The tile / generation policies are the library's own
+ * (bytes through the busiest CU, sequence lengths, alignment); tests assert through this record that the shapes they mean to
+ * cover really reach the kernel they name, so that a policy change cannot silently un-test a kernel. */
+const char *kk_last_kernel(void);
 
 /* ---- GEMM family (nn.Linear fwd/dgrad/wgrad: transformers.py:131-136,90-91; model.py:173,190) ----
  * C[M,N] = alpha * op(A)·op(B) (+bias[n]) (+residual[(m % res_mod), n]) (+ beta*C).
@@ -473,6 +478,12 @@ int kk_comm_reduce_scatter(const void *send, void *recv, int64_t recv_count, int
 int kk_comm_all_gather(const void *send, void *recv, int64_t send_count, int dtype, void *comm_stream);
 /* y[i] = scale * float(x[i]) for a bf16 x: widens a bf16 gradient bucket after its exchange */
 int kk_cast_bf16_f32(const void *x, float *y, int64_t n, float scale, void *stream);
+/* The bf16 payload of a gradient bucket (reference: none — trainer.py has no data parallelism): dst[begin_i, end_i) =
+ * cast(src[begin_i, end_i)) for i < n over two arrays of the same layout (the fp32 gradient arena and its bf16 twin), to_bf16 = 1
+ * narrows, 0 widens (times scale).  ONE launch of at most 64 workgroups for all ranges: it runs on the communication stream beside
+ * the backward.  begin / end are HOST arrays of element offsets (begin % 4 == 0), read during the call. */
+int kk_cast_ranges(const void *src, void *dst, const int64_t *begin, const int64_t *end, int n, int to_bf16, float scale,
+                   void *stream);
 
 /* ---- misc ---- */
 /* *slot = device wall clock (100 MHz ticks) at the time this launch executes: in-graph time stamps for timelines. */

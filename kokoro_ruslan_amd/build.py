@@ -51,12 +51,15 @@ def build(force: bool = False, verbose: bool = False, tuning: bool = False, vari
     flags = FLAGS + (["-DKK_TUNING_HOOKS"] if tuning else []) + list(defs)
     # the objects of a flavour are only as good as the flags they were built with: a stamp of the flags forces a rebuild when the
     # same --variant name comes back with other -D definitions (an A/B could otherwise compare identical code)
+    # (the stamp is removed first and written only after every object and the link succeeded: a failed or interrupted build leaves
+    #  no stamp, so the next one rebuilds everything instead of linking old-flag objects beside new-flag ones — ADVICE r4)
     stamp = os.path.join(obj_dir, "flags.stamp")
     want = " ".join(flags)
-    if not os.path.exists(stamp) or open(stamp).read() != want:
+    stamp_ok = os.path.exists(stamp) and open(stamp).read() == want
+    if not stamp_ok:
         force = True
-        with open(stamp, "w") as f:
-            f.write(want)
+        if os.path.exists(stamp):
+            os.remove(stamp)
     headers = [os.path.join(CSRC, "kk_common.h"), os.path.join(os.path.dirname(HERE), "include", "kokoro_hip.h")]
     headers += [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".inc") or (f.endswith(".h") and f != "kk_common.h")]      # kernel bodies included by kk_attn.hip
 
@@ -79,6 +82,9 @@ def build(force: bool = False, verbose: bool = False, tuning: bool = False, vari
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")
+    if not stamp_ok:
+        with open(stamp, "w") as f:
+            f.write(want)
     return lib_path
 
 

@@ -1048,6 +1048,7 @@ __device__ __forceinline__ void attn_fwd3_body(const AttnArgs &a) {
             const uint64_t bits = __ballot(kmv[i] != 0u);
             if (lane == 0) kmb[wave8 + 8 * i] = bits;
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the words are in LDS before this wave reaches the loop's raw s_barrier
     }
     // ---- fragment addresses (bytes inside an image)
     const uint32_t sl = (uint32_t)(uintptr_t)KK_LDS_PTR(smem_raw);
@@ -1735,15 +1736,18 @@ __global__ __launch_bounds__(256 * G) void attn_bwd_dkv_kernel(AttnArgs a) {
 __global__ __launch_bounds__(512) void attn_bwd_dq2_kernel(AttnArgs a) {
 #include "kk_attn_bwd_dq2.inc"
 }
+#ifdef KK_TUNING_HOOKS                                       // (second-generation dK/dV and pair kernels: A/B arms of the tools flavour, KK_ATTN_BWD3=0)
 __global__ __launch_bounds__(512) void attn_bwd_dkv2_kernel(AttnArgs a) {
 #include "kk_attn_bwd_dkv2.inc"
 }
+#endif
 // dQ and dK/dV of one attention in ONE launch (grid z = 0: the dQ workgroups, z = 1: the dK/dV workgroups; Delta is an INPUT of
 // both, see kk_gemm_dgrad_delta).  The two kernels are independent once Delta exists, each keeps one workgroup per CU (148 KB of
 // LDS), and a causal launch is lopsided: dQ blocks near the end of the sequence see the most keys, dK/dV blocks near its start the
 // most queries.  Dispatched in this order (x, y, then z; long blocks first inside each half) the CUs that finish a short dQ block
 // pick up the long dK/dV blocks, so at S = 512 (one workgroup per CU and kernel) the pair takes about 5 block-units instead of
 // 4 + 4, and a non-causal pair saves one launch's ramp and tail.
+#ifdef KK_TUNING_HOOKS
 __global__ __launch_bounds__(512) void attn_bwd_pair2_kernel(AttnArgs a_dq, AttnArgs a_dkv) {
     if (blockIdx.z == 0) {
 #define a a_dq
@@ -1755,6 +1759,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pair2_kernel(AttnArgs a_dq, Attn
 #undef a
     }
 }
+#endif
 
 // ------------------------------------------------------------------ backward, third generation: one wave group, two workgroups per CU
 // The second-generation bodies as ONE 256-thread group each (kk_attn_bwd_dq3.inc / kk_attn_bwd_dkv3.inc): <= 70 KB of LDS, so two
@@ -1791,11 +1796,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pair3_kernel(AttnArgs a_dq, A
 // 512-byte span of a tile per instruction, conflict free without a swizzle); the head-norm epilogue of the dQ kernel follows.
 // dS is bit-identical to what the dQ kernel computes for itself (same MFMA sums, same rounding), so dQ differs from the pair
 // launch's only by the order in which the key units are added (all of them in sequence here; two interleaved halves there).
+#ifdef KK_TUNING_HOOKS
 __global__ __launch_bounds__(512) void attn_bwd_dkv2s_kernel(AttnArgs a) {
 #define KK_DKV_STORE_DS 1
 #include "kk_attn_bwd_dkv2.inc"
 #undef KK_DKV_STORE_DS
 }
+#endif
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3s_kernel(AttnArgs a) {      // (the one-group body: what kk_attn_bwd's dK/dV half runs)
 #define KK_DKV_STORE_DS 1
 #include "kk_attn_bwd_dkv3.inc"
@@ -1958,10 +1965,14 @@ static int attn_pair() {                 // KK_ATTN_PAIR=0: kk_attn_bwd issues t
     static const int v = kk_tune_env("KK_ATTN_PAIR", 1);
     return v;
 }
+#ifdef KK_TUNING_HOOKS
 static int attn_gen3() {                 // KK_ATTN_BWD3: bit 0 the one-group backward kernels (two workgroups per CU), bit 1 short-first dK/dV half
     static const int v = kk_tune_env("KK_ATTN_BWD3", 3);
     return v;
 }
+#else
+static constexpr int attn_gen3() { return 3; }        // (the product carries the third generation only; the second-generation dK/dV / pair kernels are tools arms)
+#endif
 static int g_attn_cus() {
     static const int n = [] {
         int dev = 0, v = 0;
@@ -1986,14 +1997,18 @@ static int attn_xcd_map(int causal = 0) {
 template <typename K>
 int launch_attn(K kernel, dim3 grid, int G, size_t lds, hipStream_t s, const AttnArgs &a) {
     if (lds > 64 * 1024) {
-        static thread_local const void *raised[16];
+        // (one table for every kernel of this signature: 64 slots for the ~20 kernels with more than 64 KB of dynamic LDS; a full table
+        //  is an error, not a silent hipFuncSetAttribute per launch — ADVICE r4)
+        static thread_local const void *raised[64];
         bool done = false;
         for (const void *p : raised) done = done || p == (const void *)kernel;
         if (!done) {
             hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return kk_fail((int)e, "attention: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+            bool noted = false;
             for (auto &p : raised)
-                if (!p) { p = (const void *)kernel; break; }
+                if (!p) { p = (const void *)kernel; noted = true; break; }
+            if (!noted) return kk_fail(KK_EINVAL, "attention: the table of kernels with raised LDS limits is full");
         }
     }
     hipLaunchKernelGGL(kernel, grid, dim3(256 * G), lds, s, a);
@@ -2062,8 +2077,9 @@ extern "C" int kk_attn_fwd(const float *Q, const float *K, const float *V, float
         // per CU, else 64-query blocks x 4 key slots (a 512-frame launch: 512 workgroups instead of 256)
         static const int fwd3 = kk_tune_env("KK_ATTN_FWD3", 1);
         if (fwd3 && Sk > 128) {
-            const bool big = (int64_t)kk_cdiv(Sq, 128) * B * heads >= 512;
+            const bool big = (int64_t)kk_cdiv(Sq, 128) * B * heads >= 2 * g_attn_cus();    // (two workgroups per CU)
             // (a conditional expression: hipcc does not emit the host stub of a kernel template named only inside an if / else chain)
+            kk_note_kernel((big || fwd3 == 2) ? "attn_fwd3_q128" : "attn_fwd3_q64");
             const int rc3 = (big || fwd3 == 2)
                 ? launch_attn(attn_fwd3_q128_kernel, dim3(kk_cdiv(Sq, 128), B * heads), 2, (size_t)3 * 16384 + 512 + 16384, (hipStream_t)stream, a)
                 : launch_attn(attn_fwd3_q64_kernel, dim3(kk_cdiv(Sq, 64), B * heads), 2, (size_t)2 * 32768 + 512 + 8192, (hipStream_t)stream, a);
@@ -2072,12 +2088,19 @@ extern "C" int kk_attn_fwd(const float *Q, const float *K, const float *V, float
             return 0;
         }
         static const int ns2 = kk_tune_env("KK_ATTN_NS", 3);
+        kk_note_kernel("attn_fwd2");
+#ifdef KK_TUNING_HOOKS
         int rc2 = ns2 == 4 ? launch_attn(attn_fwd2_kernel<4>, grid, 2, (size_t)2 * 4 * 16384 + 512 + 16384, (hipStream_t)stream, a)
                            : launch_attn(attn_fwd2_kernel<3>, grid, 2, (size_t)2 * 3 * 16384 + 512 + 16384, (hipStream_t)stream, a);
+#else
+        (void)ns2;
+        int rc2 = launch_attn(attn_fwd2_kernel<3>, grid, 2, (size_t)2 * 3 * 16384 + 512 + 16384, (hipStream_t)stream, a);
+#endif
         if (rc2) return rc2;
         KK_LAUNCH_CHECK("kk_attn_fwd");
         return 0;
     }
+    kk_note_kernel("attn_fwd");
     if (io_bf16) KK_ATTN_LAUNCH(attn_fwd_kernel, true, true, G, 2);
     else if (math == KK_MATH_BF16) KK_ATTN_LAUNCH(attn_fwd_kernel, true, false, G, 2);
     else KK_ATTN_LAUNCH(attn_fwd_kernel, false, false, G, 2);
@@ -2125,12 +2148,14 @@ extern "C" int kk_attn_bwd_dq(const float *Q, const float *K, const float *V, co
     const int G = (Sk > 64 && g_attn_groups == 2) ? 2 : 1;
     if (io_bf16 && (attn_v2_mask() & 2) && (G == 2 || attn_v2_small(Sq, Sk)) && g_attn_groups == 2 && Sk <= 4096 && al16(Q) && al16(K) && al16(V) && al16(dO) && al16(dQ) && (!O || al16(O)) &&
         (!hn || (al16(hn->raw) && (!hn->rope || (al16(hn->cos_t) && al16(hn->sin_t))))) && (int64_t)Sk * std::max(ldk, ldv) * 2 < (1ll << 31)) {
+        kk_note_kernel((!O && (attn_gen3() & 1)) ? "attn_bwd_dq3" : "attn_bwd_dq2");
         int rc2 = (!O && (attn_gen3() & 1)) ? launch_attn(attn_bwd_dq3_kernel, grid, 1, (size_t)3 * 16384 + 512 + 16384, (hipStream_t)stream, a)
                                             : launch_attn(attn_bwd_dq2_kernel, grid, 2, (size_t)2 * 3 * 16384 + 512 + 3 * 16384, (hipStream_t)stream, a);
         if (rc2) return rc2;
         KK_LAUNCH_CHECK("kk_attn_bwd_dq");
         return 0;
     }
+    kk_note_kernel("attn_bwd_dq");
     if (io_bf16) KK_ATTN_LAUNCH(attn_bwd_dq_kernel, true, true, G, 3);
     else if (math == KK_MATH_BF16) KK_ATTN_LAUNCH(attn_bwd_dq_kernel, true, false, G, 3);
     else KK_ATTN_LAUNCH(attn_bwd_dq_kernel, false, false, G, 2);
@@ -2160,12 +2185,18 @@ extern "C" int kk_attn_bwd_dkv(const float *Q, const float *K, const float *V, c
     if (io_bf16 && (attn_v2_mask() & 4) && (G == 2 || attn_v2_small(Sq, Sk)) && g_attn_groups == 2 && al16(Q) && al16(K) && al16(V) && al16(dO) && al16(dK) && al16(dV) &&
         (!hn || (al16(hn[0].raw) && al16(hn[1].raw) && !hn[1].rope && (!hn[0].rope || (al16(hn[0].cos_t) && al16(hn[0].sin_t))))) &&
         (int64_t)Sq * std::max(ldq, lddo) * 2 < (1ll << 31)) {
+        kk_note_kernel((attn_gen3() & 1) ? "attn_bwd_dkv3" : "attn_bwd_dkv2");
+#ifdef KK_TUNING_HOOKS
         int rc2 = (attn_gen3() & 1) ? launch_attn(attn_bwd_dkv3_kernel, grid, 1, (size_t)71680, (hipStream_t)stream, a)
                                     : launch_attn(attn_bwd_dkv2_kernel, grid, 2, (size_t)2 * 3 * (16384 + 512) + 3 * 16384, (hipStream_t)stream, a);
+#else
+        int rc2 = launch_attn(attn_bwd_dkv3_kernel, grid, 1, (size_t)71680, (hipStream_t)stream, a);
+#endif
         if (rc2) return rc2;
         KK_LAUNCH_CHECK("kk_attn_bwd_dkv");
         return 0;
     }
+    kk_note_kernel("attn_bwd_dkv");
     if (io_bf16) KK_ATTN_LAUNCH_X(attn_bwd_dkv_kernel, true, true, G, 4, 2 * G * 128 * sizeof(float));
     else if (math == KK_MATH_BF16) KK_ATTN_LAUNCH_X(attn_bwd_dkv_kernel, true, false, 1, 4, 2 * 128 * sizeof(float));   // (G = 2 would spill)
     else KK_ATTN_LAUNCH_X(attn_bwd_dkv_kernel, false, false, G, 2, 2 * G * 128 * sizeof(float));
@@ -2227,10 +2258,12 @@ extern "C" int kk_attn_bwd(const float *Q, const float *K, const float *V, const
         // (short blocks first only when both halves are resident at once — 2 workgroups per CU; with more rounds the longest-first
         //  order of the second generation is the faster one: 8 x 8 x 1024^2 causal 79 against 96 us)
         p.dkv.short_first = (causal && (attn_gen3() & 2) && (int64_t)kk_cdiv(Sq, 128) * B * heads <= g_attn_cus()) ? 1 : 0;
+        kk_note_kernel("attn_bwd_pair3");
         hipLaunchKernelGGL(attn_bwd_pair3_kernel, dim3(kk_cdiv(Sq, 128), B * heads, 2), dim3(256), lds3, (hipStream_t)stream, p.dq, p.dkv);
         KK_LAUNCH_CHECK("kk_attn_bwd");
         return 0;
     }
+#ifdef KK_TUNING_HOOKS
     const size_t lds_bytes = std::max((size_t)2 * 3 * 16384 + 512 + 3 * 16384, (size_t)2 * 3 * (16384 + 512) + 3 * 16384);
     static thread_local bool raised = false;
     if (!raised) {
@@ -2238,9 +2271,13 @@ extern "C" int kk_attn_bwd(const float *Q, const float *K, const float *V, const
         if (e != hipSuccess) return kk_fail((int)e, "kk_attn_bwd: cannot reserve %zu bytes of LDS: %s", lds_bytes, hipGetErrorString(e));
         raised = true;
     }
+    kk_note_kernel("attn_bwd_pair2");
     hipLaunchKernelGGL(attn_bwd_pair2_kernel, dim3(kk_cdiv(Sq, 128), B * heads, 2), dim3(512), lds_bytes, (hipStream_t)stream, p.dq, p.dkv);
     KK_LAUNCH_CHECK("kk_attn_bwd");
     return 0;
+#else
+    return kk_fail(KK_EINVAL, "kk_attn_bwd: unreachable");
+#endif
 }
 
 // Backward in two passes through a caller-owned workspace (see attn_bwd_dkv2s_kernel): the same contract and fall-backs as
@@ -2301,13 +2338,18 @@ extern "C" int kk_attn_bwd_ws(const float *Q, const float *K, const float *V, co
         if (int rc = check_headnorm("kk_attn_bwd_ws", hn_kv, 2)) return rc;
         a.hn[0] = hn_kv[0]; a.hn[1] = hn_kv[1];
     }
+#ifdef KK_TUNING_HOOKS
     if (int rc = (attn_gen3() & 1) ? launch_attn(attn_bwd_dkv3s_kernel, dim3(kk_cdiv(Sk, 128), B * heads), 1, (size_t)71680, (hipStream_t)stream, a)
                                    : launch_attn(attn_bwd_dkv2s_kernel, dim3(kk_cdiv(Sk, 128), B * heads), 2, (size_t)2 * 3 * (16384 + 512) + 3 * 16384, (hipStream_t)stream, a))
         return rc;
+#else
+    if (int rc = launch_attn(attn_bwd_dkv3s_kernel, dim3(kk_cdiv(Sk, 128), B * heads), 1, (size_t)71680, (hipStream_t)stream, a)) return rc;
+#endif
     KK_LAUNCH_CHECK("kk_attn_bwd_ws (dK, dV, dS)");
     a.Out = dQ; a.Out2 = nullptr; a.ldout = lddq; a.ldout2 = 0;
     a.hn[0] = KkAttnHeadNorm{}; a.hn[1] = KkAttnHeadNorm{};
     if (hn_q) a.hn[0] = hn_q[0];
+    kk_note_kernel("attn_bwd_dkv3s+dqpass");
     if (int rc = launch_attn(attn_bwd_dqpass_kernel, dim3(kk_cdiv(Sq, 128), B * heads), 1, (size_t)3 * (8192 + 16384), (hipStream_t)stream, a))
         return rc;
     KK_LAUNCH_CHECK("kk_attn_bwd_ws (dQ pass)");

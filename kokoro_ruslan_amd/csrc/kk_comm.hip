@@ -82,7 +82,67 @@ __global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const __bf16 *__rest
     }
 }
 
+// bf16 gradient payload: all ranges of a bucket narrowed (or widened back) by ONE launch of at most CAST_WGS workgroups.  The
+// exchange runs on the communication stream beside the backward's one-workgroup-per-CU launches; the per-range casts of round 2
+// (two launches per range, up to 8192 workgroups each) made the one-GPU step 42 % slower (profiles/r04_dp_exchange_one_gpu_ab.txt) —
+// a thin grid costs the chain next to nothing and still moves a 16 MB bucket in ~30 us, hidden beside the backward.
+constexpr int CAST_MAX = 48, CAST_WGS = 64, CAST_CHUNK = 4096;
+struct CastRanges {
+    int n, to_bf16;
+    float scale;
+    int64_t begin[CAST_MAX];
+    int64_t chunk0[CAST_MAX + 1];                                // first chunk of each range in the concatenation
+    int64_t len[CAST_MAX];
+};
+__global__ __launch_bounds__(256) void cast_ranges_kernel(const void *__restrict__ src, void *__restrict__ dst, CastRanges r) {
+    const int64_t total = r.chunk0[r.n];
+    int i = 0;
+    for (int64_t c = blockIdx.x; c < total; c += gridDim.x) {
+        while (c >= r.chunk0[i + 1]) ++i;                        // (chunks ascend per workgroup)
+        const int64_t off = (c - r.chunk0[i]) * CAST_CHUNK, left = r.len[i] - off, e0 = r.begin[i] + off;
+#pragma unroll
+        for (int k = 0; k < CAST_CHUNK / 1024; ++k) {
+            const int64_t j = (int64_t)k * 1024 + threadIdx.x * 4;
+            if (j + 4 <= left) {
+                if (r.to_bf16) stv4<__bf16>(static_cast<__bf16 *>(dst) + e0 + j, ld4(static_cast<const float *>(src) + e0 + j));
+                else {
+                    const float4 v = ldv4<__bf16>(static_cast<const __bf16 *>(src) + e0 + j);
+                    st4(static_cast<float *>(dst) + e0 + j, make_float4(v.x * r.scale, v.y * r.scale, v.z * r.scale, v.w * r.scale));
+                }
+            } else {
+                for (int64_t q = j; q < left && q < j + 4; ++q) {
+                    if (r.to_bf16) static_cast<__bf16 *>(dst)[e0 + q] = (__bf16) static_cast<const float *>(src)[e0 + q];
+                    else static_cast<float *>(dst)[e0 + q] = (float)static_cast<const __bf16 *>(src)[e0 + q] * r.scale;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
+
+// dst[begin_i .. end_i) = cast(src[begin_i .. end_i)) for i < n (element offsets into two arrays of the SAME layout: the fp32 gradient
+// arena and its bf16 payload twin), to_bf16 = 1: fp32 -> bf16, 0: bf16 -> fp32 times `scale`.  begin[i] must be a multiple of 4.
+extern "C" int kk_cast_ranges(const void *src, void *dst, const int64_t *begin, const int64_t *end, int n, int to_bf16, float scale,
+                              void *stream) {
+    KK_REQUIRE(src && dst && begin && end && n >= 1, "kk_cast_ranges: bad arguments");
+    for (int i0 = 0; i0 < n; i0 += CAST_MAX) {
+        CastRanges r = {};
+        r.n = n - i0 < CAST_MAX ? n - i0 : CAST_MAX;
+        r.to_bf16 = to_bf16 ? 1 : 0;
+        r.scale = scale;
+        for (int i = 0; i < r.n; ++i) {
+            KK_REQUIRE(end[i0 + i] > begin[i0 + i] && begin[i0 + i] % 4 == 0, "kk_cast_ranges: empty or unaligned range %d", i0 + i);
+            r.begin[i] = begin[i0 + i];
+            r.len[i] = end[i0 + i] - begin[i0 + i];
+            r.chunk0[i + 1] = r.chunk0[i] + (r.len[i] + CAST_CHUNK - 1) / CAST_CHUNK;
+        }
+        const int64_t total = r.chunk0[r.n];
+        hipLaunchKernelGGL(cast_ranges_kernel, dim3((unsigned)(total < CAST_WGS ? total : CAST_WGS)), dim3(256), 0, (hipStream_t)stream, src, dst, r);
+        KK_LAUNCH_CHECK("kk_cast_ranges");
+    }
+    return 0;
+}
 
 extern "C" int kk_comm_load(const char *rccl_path) { return load_rccl(rccl_path); }
 

@@ -11,6 +11,8 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
 int kk_fail(int code, const char *fmt, ...);
+void kk_note_kernel(const char *name);         // kk_last_kernel(): `name` must have static storage duration
+void kk_note_kernelf(const char *fmt, ...);    // ... a formatted name (interned)
 
 // Tuning switches.  The PRODUCT library reads no environment variable but KK_GEMM16_TUNE (one-time tile policy override, see
 // kk_gemm16.hip): every A/B switch and every result-changing timing probe below exists only in a tools build

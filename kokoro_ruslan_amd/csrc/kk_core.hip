@@ -1,5 +1,8 @@
 // Error plumbing, ABI version and an MFMA fragment-layout probe.
 #include "kk_common.h"
+#include <mutex>
+#include <string>
+#include <unordered_set>
 
 static thread_local char g_err[512] = "";
 
@@ -12,6 +15,22 @@ int kk_fail(int code, const char *fmt, ...) {
 }
 
 extern "C" const char *kk_last_error(void) { return g_err; }
+
+// route record (kk_last_kernel): a pointer to a string with static storage duration, set by the entry points' dispatch code
+static thread_local const char *g_last_kernel = "";
+void kk_note_kernel(const char *name) { g_last_kernel = name; }
+void kk_note_kernelf(const char *fmt, ...) {                       // formatted names are interned: the record outlives the call
+    static std::mutex mu;
+    static std::unordered_set<std::string> names;
+    char buf[96];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    std::lock_guard<std::mutex> lock(mu);
+    g_last_kernel = names.emplace(buf).first->c_str();
+}
+extern "C" const char *kk_last_kernel(void) { return g_last_kernel; }
 extern "C" int kk_abi_version(void) { return KK_ABI_VERSION; }
 
 namespace {

@@ -587,6 +587,7 @@ int g16_w8_glu = kk_tune_env("KK_G16_W8_GLU", 1);      // bit 0: dgrad + GLU bac
 
 template <int NS>
 void launch_w8(int ta, int tb, const G16Args &a, dim3 grid, hipStream_t s) {
+    kk_note_kernelf("gemm16_w8<%d,%d,%d>", ta, tb, NS);
     if (!ta && !tb) hipLaunchKernelGGL((gemm16_kernel_w8<false, false, NS>), grid, dim3(512), 0, s, a);
     else if (!ta && tb) hipLaunchKernelGGL((gemm16_kernel_w8<false, true, NS>), grid, dim3(512), 0, s, a);
     else if (ta && !tb) hipLaunchKernelGGL((gemm16_kernel_w8<true, false, NS>), grid, dim3(512), 0, s, a);
@@ -649,6 +650,7 @@ template __global__ void gemm16_kernel<false, true, 64, 64, 3, 1>(G16Args);
 
 template <int BM, int BN, int NS>
 void launch_tile(int ta, int tb, const G16Args &a, dim3 grid, hipStream_t s) {
+    kk_note_kernelf("gemm16<%d,%d,%d,%d,%d>", ta, tb, BM, BN, NS);
     if (!ta && !tb) hipLaunchKernelGGL((gemm16_kernel<false, false, BM, BN, NS>), grid, dim3(256), 0, s, a);
     else if (!ta && tb) hipLaunchKernelGGL((gemm16_kernel<false, true, BM, BN, NS>), grid, dim3(256), 0, s, a);
     else if (ta && !tb) hipLaunchKernelGGL((gemm16_kernel<true, false, BM, BN, NS>), grid, dim3(256), 0, s, a);
@@ -869,11 +871,13 @@ int kk_gemm16_dgrad_glu(int64_t T, int64_t F, int64_t H, const void *dy, int64_t
     }
     if ((g16_w8_glu & 1) && cd(H, BK) >= 3 && cd(T, 128) * cd(F, 64) >= g16_thr12864) {       // eight waves on 128x64 tiles, like the plain GEMMs
         a.tiles_m = cd(T, 128);
+        kk_note_kernel("gemm16_w8_glu<1,3,1>");
         hipLaunchKernelGGL((gemm16_kernel_w8_glu<true, 3, 1>), dim3(a.tiles_m * a.tiles_n), dim3(512), 0, s, a);
         KK_LAUNCH_CHECK("kk_gemm_dgrad_glu");
         return 0;
     }
     dim3 grid(a.tiles_m * a.tiles_n);
+    kk_note_kernel("gemm16<0,1,64,64,*,1>");
     if (cd(H, BK) < 3) hipLaunchKernelGGL((gemm16_kernel<false, true, 64, 64, 2, 1>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((gemm16_kernel<false, true, 64, 64, 3, 1>), grid, dim3(256), 0, s, a);
     KK_LAUNCH_CHECK("kk_gemm_dgrad_glu");
@@ -902,10 +906,12 @@ int kk_gemm16_linear_glu(int64_t T, int64_t F, int64_t K, const void *x, int64_t
     }
     if ((g16_w8_glu & 2) && cd(K, BK) >= 3 && cd(T, 128) * cd(F, 64) >= g16_thr12864) {
         a.tiles_m = cd(T, 128);
+        kk_note_kernel("gemm16_w8_glu<0,3,2>");
         hipLaunchKernelGGL((gemm16_kernel_w8_glu<false, 3, 2>), dim3(a.tiles_m * a.tiles_n), dim3(512), 0, s, a);
         KK_LAUNCH_CHECK("kk_gemm_linear_glu");
         return 0;
     }
+    kk_note_kernel("gemm16<0,0,64,64,2,2>");
     hipLaunchKernelGGL((gemm16_kernel<false, false, 64, 64, 2, 2>), dim3(a.tiles_m * a.tiles_n), dim3(256), 0, s, a);
     KK_LAUNCH_CHECK("kk_gemm_linear_glu");
     return 0;
@@ -981,6 +987,7 @@ int kk_gemm16_wgrad_group(const KkWgradDesc *d, int n, int split_k, int overwrit
         g.start[i + 1] = g.start[i] + a.tiles_m * a.tiles_n * sp;
     }
     dim3 grid(g.start[n]);
+    kk_note_kernelf("gemm16_group<%d,%d,w%d>", BM, BN, BM == 128 ? g16_group_waves : 4);
     if (BN == 128 && g16_group_waves == 16) hipLaunchKernelGGL((gemm16_group_kernel<true, true, 128, 128, 2, 16, 4>), grid, dim3(1024), 0, s, g);
     else if (BN == 128 && g16_group_waves == 8) hipLaunchKernelGGL((gemm16_group_kernel<true, true, 128, 128, 2, 8>), grid, dim3(512), 0, s, g);
     else if (BN == 128) hipLaunchKernelGGL((gemm16_group_kernel<true, true, 128, 128, 2>), grid, dim3(256), 0, s, g);
@@ -1028,11 +1035,13 @@ int kk_gemm16_qkv_headnorm(int64_t T, int parts, int heads, int64_t K, const voi
     }
     if (g16_w8_hn && cd(K, BK) >= 3 && cd(T, 128) * cd(N, 64) >= g16_thr12864) {       // eight waves on 128x64 tiles, like the plain GEMMs
         a.tiles_m = cd(T, 128);
+        kk_note_kernel("gemm16_w8_hn<3>");
         hipLaunchKernelGGL((gemm16_kernel_w8_hn<3>), dim3(a.tiles_m * a.tiles_n), dim3(512), 0, s, a);
         KK_LAUNCH_CHECK("kk_gemm_qkv_headnorm");
         return 0;
     }
     dim3 grid(a.tiles_m * a.tiles_n);
+    kk_note_kernel("gemm16<0,0,64,64,*,3>");
     if (cd(K, BK) < 3) hipLaunchKernelGGL((gemm16_kernel<false, false, 64, 64, 2, 3>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((gemm16_kernel<false, false, 64, 64, 3, 3>), grid, dim3(256), 0, s, a);
     KK_LAUNCH_CHECK("kk_gemm_qkv_headnorm");

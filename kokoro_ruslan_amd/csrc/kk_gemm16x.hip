@@ -700,6 +700,7 @@ int launch_x(const G16Args &a0, const char *name, hipStream_t s) {
 #else
     const G16Args &a = a0;
 #endif
+    kk_note_kernelf("g16x<%d,%d,%d,%d,%d,%d,%d,%d,%d>", (int)TA, (int)TB, BM, BN, NS, EPI, WR, WC, LW);
     hipLaunchKernelGGL((g16x_kernel<TA, TB, BM, BN, NS, EPI, WR, WC, LW>), dim3(a.tiles_m * a.tiles_n), dim3(64 * (WR * WC + LW)), 0, s, a);
     KK_LAUNCH_CHECK(name);
     return 0;
@@ -710,7 +711,15 @@ int launch_x(const G16Args &a0, const char *name, hipStream_t s) {
 #ifdef KK_TUNING_HOOKS
 void kk_g16x_probe(int bits, void *buf) { g16x_probe_bits = bits; g16x_probe_buf = buf; }
 #endif
-int g16x_lw = kk_tune_env("KK_G16X_LW", 1);           // tools: 0 = every wave loads and computes (the form of kk_gemm16.hip)
+// Loader-wave form of every launch: 1 = four compute + four loader waves (the product), 0 = every wave loads and computes (the form
+// of kk_gemm16.hip), 2 = eight compute + four loader waves.  0 and 2 are A/B arms: they are instantiated in the TOOLS flavour only
+// (KK_TUNING_HOOKS, KK_G16X_LW); the product build folds the choice to 1 and carries one kernel per tile and layout.
+#ifdef KK_TUNING_HOOKS
+int g16x_lw = kk_tune_env("KK_G16X_LW", 1);
+#define G16X_LW(lw1, lw0) (g16x_lw ? (lw1) : (lw0))
+#else
+#define G16X_LW(lw1, lw0) (lw1)
+#endif
 
 void kk_g16x_tile(int cfg, int *bm, int *bn) {
     static const int t[G16X_NCFG][2] = {{128, 128}, {256, 128}, {128, 192}, {256, 192}};
@@ -721,41 +730,51 @@ void kk_g16x_tile(int cfg, int *bm, int *bn) {
 int kk_g16x_plain(int cfg, int ta, int tb, const G16Args &a, hipStream_t s) {
     const int lay = (ta ? 2 : 0) | (tb ? 1 : 0);
     if (cfg == G16X_128x128) {
-        if (lay == 0) return g16x_lw ? launch_x<false, false, 128, 128, 3, 0, 2, 2, 4>(a, "kk_gemm", s) : launch_x<false, false, 128, 128, 3, 0, 4, 2, 0>(a, "kk_gemm", s);
-        if (lay == 1) return g16x_lw ? launch_x<false, true, 128, 128, 3, 0, 2, 2, 4>(a, "kk_gemm", s) : launch_x<false, true, 128, 128, 3, 0, 4, 2, 0>(a, "kk_gemm", s);
+        if (lay == 0) return G16X_LW((launch_x<false, false, 128, 128, 3, 0, 2, 2, 4>(a, "kk_gemm", s)), (launch_x<false, false, 128, 128, 3, 0, 4, 2, 0>(a, "kk_gemm", s)));
+        if (lay == 1) return G16X_LW((launch_x<false, true, 128, 128, 3, 0, 2, 2, 4>(a, "kk_gemm", s)), (launch_x<false, true, 128, 128, 3, 0, 4, 2, 0>(a, "kk_gemm", s)));
     } else if (cfg == G16X_256x128) {
-        if (lay == 0) return g16x_lw ? launch_x<false, false, 256, 128, 3, 0, 2, 2, 4>(a, "kk_gemm", s) : launch_x<false, false, 256, 128, 3, 0, 4, 2, 0>(a, "kk_gemm", s);
-        if (lay == 1) return g16x_lw ? launch_x<false, true, 256, 128, 3, 0, 2, 2, 4>(a, "kk_gemm", s) : launch_x<false, true, 256, 128, 3, 0, 4, 2, 0>(a, "kk_gemm", s);
+        if (lay == 0) return G16X_LW((launch_x<false, false, 256, 128, 3, 0, 2, 2, 4>(a, "kk_gemm", s)), (launch_x<false, false, 256, 128, 3, 0, 4, 2, 0>(a, "kk_gemm", s)));
+        if (lay == 1) return G16X_LW((launch_x<false, true, 256, 128, 3, 0, 2, 2, 4>(a, "kk_gemm", s)), (launch_x<false, true, 256, 128, 3, 0, 4, 2, 0>(a, "kk_gemm", s)));
     }
     return kk_fail(KK_EINVAL, "kk_g16x_plain: no kernel for tile %d, layout %d", cfg, lay);
 }
 int kk_g16x_headnorm(int cfg, const G16Args &a, hipStream_t s) {
+#ifdef KK_TUNING_HOOKS
     if (cfg == G16X_128x192 && g16x_lw == 2) return launch_x<false, false, 128, 192, 3, 3, 4, 2, 4>(a, "kk_gemm_qkv_headnorm", s);
-    if (cfg == G16X_128x192) return g16x_lw ? launch_x<false, false, 128, 192, 3, 3, 2, 2, 4>(a, "kk_gemm_qkv_headnorm", s) : launch_x<false, false, 128, 192, 3, 3, 4, 2, 0>(a, "kk_gemm_qkv_headnorm", s);
+#endif
+    if (cfg == G16X_128x192) return G16X_LW((launch_x<false, false, 128, 192, 3, 3, 2, 2, 4>(a, "kk_gemm_qkv_headnorm", s)), (launch_x<false, false, 128, 192, 3, 3, 4, 2, 0>(a, "kk_gemm_qkv_headnorm", s)));
     if (cfg == G16X_256x192) return launch_x<false, false, 256, 192, 2, 3, 4, 2, 0>(a, "kk_gemm_qkv_headnorm", s);
-    if (cfg == G16X_128x128) return g16x_lw ? launch_x<false, false, 128, 128, 3, 3, 2, 2, 4>(a, "kk_gemm_qkv_headnorm", s) : launch_x<false, false, 128, 128, 3, 3, 4, 2, 0>(a, "kk_gemm_qkv_headnorm", s);
-    if (cfg == G16X_256x128) return g16x_lw ? launch_x<false, false, 256, 128, 3, 3, 2, 2, 4>(a, "kk_gemm_qkv_headnorm", s) : launch_x<false, false, 256, 128, 3, 3, 4, 2, 0>(a, "kk_gemm_qkv_headnorm", s);
+    if (cfg == G16X_128x128) return G16X_LW((launch_x<false, false, 128, 128, 3, 3, 2, 2, 4>(a, "kk_gemm_qkv_headnorm", s)), (launch_x<false, false, 128, 128, 3, 3, 4, 2, 0>(a, "kk_gemm_qkv_headnorm", s)));
+    if (cfg == G16X_256x128) return G16X_LW((launch_x<false, false, 256, 128, 3, 3, 2, 2, 4>(a, "kk_gemm_qkv_headnorm", s)), (launch_x<false, false, 256, 128, 3, 3, 4, 2, 0>(a, "kk_gemm_qkv_headnorm", s)));
     return kk_fail(KK_EINVAL, "kk_g16x_headnorm: no kernel for tile %d", cfg);
 }
 int kk_g16x_glu_fwd(const G16Args &a0, hipStream_t s) {
     G16Args a = a0;
     a.tiles_n = kk_cdiv(a.N, 96);
+#ifdef KK_TUNING_HOOKS
     if (g16x_lw == 2) {                                         // (tools: 128 rows x (96 + 96) columns, four compute waves of 32 x 192 + four loaders: 2 rounds at 4096 rows, slower)
         a.tiles_m = kk_cdiv(a.M, 128);
         return launch_x<false, false, 128, 192, 3, 2, 4, 1, 4>(a, "kk_gemm_linear_glu", s);
     }
+#endif
     a.tiles_m = kk_cdiv(a.M, 256);
     // (eight compute waves of 32 x 192 + four loaders, 3 waves per SIMD at 166 registers, measured level: 24.2 against 25.3 us at 4096
     // rows, 51.9 against 50.6 at 8192 — the epilogue's 38 MB of stores is most of this launch; not instantiated)
     return launch_x<false, false, 256, 192, 2, 2, 8, 1, 0>(a, "kk_gemm_linear_glu", s);
 }
 int kk_g16x_glu_bwd(const G16Args &a, hipStream_t s) {
-    return g16x_lw ? launch_x<false, true, 128, 192, 3, 1, 2, 2, 4>(a, "kk_gemm_dgrad_glu", s) : launch_x<false, true, 128, 192, 3, 1, 4, 2, 0>(a, "kk_gemm_dgrad_glu", s);
+    return G16X_LW((launch_x<false, true, 128, 192, 3, 1, 2, 2, 4>(a, "kk_gemm_dgrad_glu", s)), (launch_x<false, true, 128, 192, 3, 1, 4, 2, 0>(a, "kk_gemm_dgrad_glu", s)));
 }
 int kk_g16x_group(const G16Group &g, int grid, hipStream_t s) {
+#ifdef KK_TUNING_HOOKS
+    kk_note_kernelf("g16x_group<1,1,128,128,3,lw%d>", g16x_lw);
     if (g16x_lw == 2) hipLaunchKernelGGL((g16x_group_kernel<true, true, 128, 128, 3, 4, 2, 4>), dim3(grid), dim3(768), 0, s, g);
     else if (g16x_lw) hipLaunchKernelGGL((g16x_group_kernel<true, true, 128, 128, 3, 2, 2, 4>), dim3(grid), dim3(512), 0, s, g);
     else hipLaunchKernelGGL((g16x_group_kernel<true, true, 128, 128, 3, 4, 2, 0>), dim3(grid), dim3(512), 0, s, g);
+#else
+    kk_note_kernel("g16x_group<1,1,128,128,3,lw1>");
+    hipLaunchKernelGGL((g16x_group_kernel<true, true, 128, 128, 3, 2, 2, 4>), dim3(grid), dim3(512), 0, s, g);
+#endif
     KK_LAUNCH_CHECK("kk_gemm_wgrad_group");
     return 0;
 }

@@ -189,11 +189,11 @@ class BucketedExchange:
         if self.payload == "bf16":
             if self._g16 is None or self._g16.numel() != flat.numel():
                 self._g16 = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device)
-            for b, e in ranges:
-                kk.call("kk_cast_f32_bf16", flat[b:e], self._g16[b:e], e - b)
+            # (one thin launch per direction and bucket: kk_cast_ranges — the per-range casts with chip-filling grids cost the chain
+            #  they ran beside 42 % on one GPU)
+            kk.call("kk_cast_ranges", flat, self._g16, beg, end, n, 1, 1.0)
             kk.call("kk_comm_reduce_ranges", self._g16, beg, end, n, 1)
-            for b, e in ranges:
-                kk.call("kk_cast_bf16_f32", self._g16[b:e], flat[b:e], e - b, 1.0)
+            kk.call("kk_cast_ranges", self._g16, flat, beg, end, n, 0, 1.0)
         else:
             kk.call("kk_comm_reduce_ranges", flat, beg, end, n, 0)
 

@@ -98,6 +98,15 @@ class Arena:
         return slab[o:o + count * H * H].view(count * H, H)
 
 
+def canonical_mel_length(global_mel_length, local_T: int) -> int:
+    """The mel length the step's kernels take BY VALUE (kk_losses_finalize, kk_opt_prepare: the batch-shape heuristics of
+    trainer.py:2218-2242), canonicalised for the graph keys: both kernels use it only as max(T / 1400, max_dur / 150) > 1, so every
+    length up to 1400 frames gives the result of 1400 exactly (T / 1400 <= 1 never decides the max when the max exceeds 1).  Keying the
+    step graphs on the raw global length made every (local shape, global T) pair of a ragged data-parallel run a new capture
+    (VERDICT r4); with this value a shape is captured once for all global lengths <= 1400 and once per longer length."""
+    return max(int(global_mel_length or local_T), 1400)
+
+
 class KokoroEngine:
     def __init__(self, dims: Optional[ModelDims] = None, hyper: Optional[StepHyper] = None, device="cuda",
                  math_mode: str = "f32", total_steps: int = 20000, seed: int = 0, init: bool = True,
@@ -1140,7 +1149,7 @@ class KokoroEngine:
                 guard if self.loss_sync is None else None)
         if self.loss_sync is not None:                    # global normalisers for ragged shards (one more collective of the step)
             self.loss_sync.loss_sync(self.loss_acc, self.max_dur)
-            kk.call("kk_losses_finalize", self.loss_acc, lcfg, self.max_dur, int(self.global_mel_length or T), self.losses,
+            kk.call("kk_losses_finalize", self.loss_acc, lcfg, self.max_dur, canonical_mel_length(self.global_mel_length, T), self.losses,
                     self.loss_coef, guard)
         out = {"losses": self.losses, "mel": mel_pred, "log_dur": dur_pred, "stop": stop, "pitch": pitch_pred,
                "energy": energy_pred, "lr_idx": idx, "lr_lens": lens, "memory": memory.view(B, T, H)}
@@ -1527,7 +1536,7 @@ class KokoroEngine:
         if is_boundary:
             if grad_sync is not None:
                 grad_sync(self.arena.g)              # data parallel: SUM over ranks (dp.GradSync)
-            self.optimizer_step(int(self.global_mel_length or batch["mel_specs"].shape[1]))
+            self.optimizer_step(canonical_mel_length(self.global_mel_length, batch["mel_specs"].shape[1]))
             self.micro_in_cycle = 0
         return out["losses"]
 
@@ -1583,7 +1592,7 @@ class KokoroEngine:
         first = self.micro_in_cycle == 0
         is_boundary = bool(boundary) if boundary is not None else self.micro_in_cycle + 1 >= G
         scale = self.dp_loss_scale / div
-        mel_length = int(self.global_mel_length or T)
+        mel_length = canonical_mel_length(self.global_mel_length, T)
         ent = self._graphs.get(key)
         self._exchange_now = is_boundary
         if ent is None:                               # first sight of a shape: eager (allocates the workspaces and the
@@ -1616,9 +1625,10 @@ class KokoroEngine:
         if moved:
             kk.copy_many(moved)                        # one launch for the whole batch
         # (kk_losses_finalize takes the GLOBAL mel length by value — the adaptive loss scale depends on it above 1400 frames — so a
-        # graph captured under one value must not be replayed under another: ADVICE r3)
+        # graph captured under one value must not be replayed under another: ADVICE r3; the CANONICAL value, so that a ragged
+        # data-parallel run replays one capture per local shape for every global length up to 1400: canonical_mel_length)
         fkey = (div, first, self.train_dropout, self.spec_augment_active, self.math, self.dp_comm is not None and is_boundary,
-                int(self.global_mel_length or 0) if self.loss_sync is not None else 0, self.loss_sync is not None)
+                mel_length if self.loss_sync is not None else 0, self.loss_sync is not None)
         fb = ent["fb"].get(fkey)
         if fb is None:
             with self.capture_lock:
@@ -1652,20 +1662,24 @@ class KokoroEngine:
         before validation, before a checkpoint is written).  Handling it = clear the word (so later launches wait again), fall
         back to the per-kernel encoder for the rest of the run, drop the graphs that hold the launch, and fail the caller: the
         weights since the last check cannot be trusted."""
-        if not self.enc_fused:
-            return
-        code = self.encoder_stack_error()
         # data parallel: the ranks decide TOGETHER (ADVICE r3) — a rank that raised alone would leave the others waiting in the next
-        # collective.  The check sits at the trainer's sync points (epoch end, validation, checkpoint), which every rank reaches.
+        # collective.  The check sits at the trainer's sync points (epoch end, validation, checkpoint), which every rank reaches, and
+        # EVERY rank enters the all-reduce — also one whose own fused launch is already off (it contributes 0; ADVICE r4: returning
+        # early there left the other ranks alone in the collective).
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if not self.enc_fused and not multi:
+            return
+        code = self.encoder_stack_error() if self.enc_fused else 0
+        if multi:
             word = torch.tensor([code], dtype=torch.int64, device=self.device if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(word, op=dist.ReduceOp.MAX)
             code = int(word.item())
         if code:
             self._enc_sync.zero_()
-            self.enc_fused = False
-            self._graphs.clear()
+            if self.enc_fused:
+                self.enc_fused = False
+                self._graphs.clear()
             raise RuntimeError(f"kk_encoder_stack_fwd: a group barrier timed out (code {code}); the activations of at least one "
                                "step were stale.  The fused encoder launch is now off for this engine (per-kernel sequence); "
                                "reload the last checkpoint before continuing.")

@@ -216,6 +216,7 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_comm_reduce_scatter": [_P, _P, _L, _I, _P],
     "kk_comm_all_gather": [_P, _P, _L, _I, _P],
     "kk_cast_bf16_f32": [_P, _P, _L, _F, _P],
+    "kk_cast_ranges": [_P, _P, _P, _P, _I, _I, _F, _P],
     "kk_copy_many": [_P, _P, _P, _I, _P],
     "kk_axpby": [_F, _P, _F, _P, _L, _P],
     "kk_timestamp": [_P, _P],
@@ -259,6 +260,7 @@ def load() -> C.CDLL:
     lib = C.CDLL(LIB_PATH)
     lib.kk_last_error.restype = C.c_char_p
     lib.kk_abi_version.restype = C.c_int
+    lib.kk_last_kernel.restype = C.c_char_p
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = args
@@ -300,6 +302,11 @@ def gemm_tune16(enable: int = 1, thr128: int = 0, thr12864: int = 0, split_targe
 
 def gemm_tune_group(split: int = 0) -> None:
     _tuning_hook("kk_gemm_tune_group")(split)
+
+
+def last_kernel() -> str:
+    """The kernel variant the last launching call of this thread took (kk_last_kernel): what tests assert routes with."""
+    return load().kk_last_kernel().decode()
 
 
 launches = 0          # kk.call invocations so far (the graph-capture driver uses it to drop empty segments)

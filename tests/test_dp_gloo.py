@@ -299,3 +299,50 @@ def test_exchange_backend_is_agreed_on_by_all_ranks(scenario, backend):
             assert "init" not in calls, "nobody enters ncclCommInitRank unless everybody will"
         if scenario == "init_fails_on_rank1" and rank == 0:
             assert calls[-1] == "destroy"
+
+
+# ---- the fused-encoder failure check is a collective that EVERY rank enters (a rank whose own fused launch was already
+# off returned before the all-reduce and left the others alone in it) -------------------------------------------------------------
+def _encstack_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from kokoro_ruslan_amd import dp
+    from kokoro_ruslan_amd.engine import KokoroEngine
+    dp.init("gloo")
+
+    class Stub:                                          # the attributes check_encoder_stack touches (no GPU engine on this box)
+        device = torch.device("cpu")
+
+        def __init__(self, fused, code):
+            self.enc_fused, self._code = fused, code
+            self._enc_sync, self._graphs = torch.tensor([code]), {"g": 1}
+
+        def encoder_stack_error(self):
+            return self._code
+    # rank 0: fused launch on, a barrier timed out; rank 1: fused launch already off — it must still join and must raise too
+    eng = Stub(True, 7) if rank == 0 else Stub(False, 0)
+    raised = False
+    try:
+        KokoroEngine.check_encoder_stack(eng)
+    except RuntimeError:
+        raised = True
+    # a second round where nothing is wrong: nobody raises, nobody hangs
+    eng2 = Stub(True, 0) if rank == 0 else Stub(False, 0)
+    KokoroEngine.check_encoder_stack(eng2)
+    q.put((rank, raised, eng.enc_fused, len(eng._graphs)))
+    dp.barrier()
+    dist.destroy_process_group()
+
+
+def test_encoder_stack_check_is_entered_by_every_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_encstack_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == [(0, True, False, 0), (1, True, False, 1)], got

@@ -847,6 +847,20 @@ def test_in_graph_bucket_exchange_over_rccl_one_rank(eng_mod, golden_dir):
     assert abs(n_g / n_e - 1.0) < 2e-3, f"a replayed graph must not keep the global mel length of its capture: |g| {n_g} (replayed) vs {n_e} (eager)"
     _, n_c = run_global_t(True, (2000,) * len(seq))
     assert abs(n_c / n_e - 1.0) > 0.1, "the test must be sensitive to the global mel length"
+    # global lengths up to 1400 frames share ONE capture per local shape (canonical_mel_length) — a ragged data-parallel run
+    # replays instead of re-capturing — and give the eager result
+    short = (900, 1000, 1100, 1399, 700, 1400)
+    e = _engine(eng_mod, d, P, math_mode="bf16", gradient_accumulation_steps=1)
+    e.train_dropout = True
+    e.dp_comm, e.loss_sync, e.dp_loss_scale = comm, comm, 1.0
+    for g_t in short:
+        e.global_mel_length = g_t
+        e.train_step_auto(batches[0])
+    torch.cuda.synchronize()
+    assert sum(len(ent["fb"]) for ent in e._graphs.values()) == 1 and sum(len(ent["opt"]) for ent in e._graphs.values()) == 1, \
+        "one forward/backward graph and one optimizer graph for every global mel length <= 1400"
+    p_s, _ = run_global_t(False, short)
+    assert float((e.arena.p - p_s).abs().max()) <= 2e-5 * float(p_s.abs().max())
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -91,7 +91,7 @@ def test_gemm_splitk_wgrad(kk, math_mode):
 
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize("M,N,K", [(128, 64, 64), (200, 136, 192), (520, 1536, 512), (4096, 512, 1536), (1000, 3072, 320),
-                                   (72, 264, 4096), (8200, 512, 512), (8192, 1000, 192)])      # (the last two: 128x128 / 256x128 tiles of kk_gemm16x.hip)
+                                   (72, 264, 4096), (8200, 512, 512), (8192, 1000, 192)])
 def test_gemm_bf16_dma_core(kk, ta, tb, M, N, K):
     """bf16 x bf16 operands (the DMA-staged core, kk_gemm16.hip): strided operands and outputs, bias, residual with
     a row period, alpha/beta, bf16 and fp32 outputs, ragged tiles; for k-strided operands also a K that is not a
@@ -122,6 +122,39 @@ def test_gemm_bf16_dma_core(kk, ta, tb, M, N, K):
     Cd = torch.empty(M, N, device="cuda")           # beta = 0 with split-K (memset + atomics)
     kk.call("kk_gemm", ta, tb, M, N, K, 1.0, Ad, A.shape[1], Bd, Bm.shape[1], 0.0, Cd, N, None, None, 0, 0, 2, 1, 3)
     close(Cd, (Al @ Bl).float(), 3e-3 * math.sqrt(K / 64), 1e-4, "dma core beta=0 split")
+
+
+# The plain kernels of the large-tile family (kk_gemm16x.hip): kk_gemm takes them for k-contiguous A, no k-slices, K >= 1024 when the
+# bytes through the busiest CU say so — q|k|v and linear1 dgrads, linear2 forward at 8192+ rows (transformers.py:131-136,90-91) and
+# every such launch under dynamic batching (ragged row counts).  The route is asserted, so a policy change cannot un-test them.
+@pytest.mark.parametrize("tb", [0, 1])
+@pytest.mark.parametrize("M,N,K,tile", [(8192, 512, 1536, "128,128"), (8192, 512, 3072, "128,128"), (15996, 512, 1536, "256,128"),
+                                        (8192, 1000, 1088, "256,128"), (4090, 1000, 1088, "128,128"), (16384, 1536, 1024, "256,128")])
+def test_gemm_bf16_large_tile_plain(kk, tb, M, N, K, tile):
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K + tb)
+    pad_a, pad_b, pad_c = 16, 8, 24
+    A = torch.randn(M, K + pad_a, generator=g).bfloat16()
+    Bm = torch.randn((K, N + pad_b) if tb else (N, K + pad_b), generator=g).bfloat16()
+    Ad, Bd = dev(A), dev(Bm)
+    Al, Bl = Ad[:, :K].double(), (Bd[:, :N].double() if tb else Bd[:, :K].double().t())
+    bias = torch.randn(N, generator=g)
+    prod = Al @ Bl                                                  # float64 on the device (the host takes minutes at these sizes)
+    ref = (0.5 * prod).float() + dev(bias)
+    want = f"g16x<0,{tb},{tile},3,0,"
+    for c16 in (0, 1):
+        Cd = torch.full((M, N + pad_c), 7.0, device="cuda", dtype=torch.bfloat16 if c16 else torch.float32)
+        kk.call("kk_gemm", 0, tb, M, N, K, 0.5, Ad, A.shape[1], Bd, Bm.shape[1], 0.0, Cd, N + pad_c, dev(bias), None, 0, 0, 1, 1,
+                3 | (c16 << 2))
+        assert kk.last_kernel().startswith(want), (kk.last_kernel(), want)
+        close(Cd[:, :N], ref, 2e-3 * math.sqrt(K / 64) + (0.1 if c16 else 0.0), 1e-2 if c16 else 1e-4, f"g16x plain c16={c16}")
+        assert bool((Cd[:, N:].float() == 7.0).all()), "columns beyond N must not be written"
+    # the general epilogue (residual with a row period, beta = 1 accumulation) straight from the accumulators
+    res = torch.randn(50, N + 8, generator=g)
+    acc = torch.randn(M, N, generator=g)
+    Cd = dev(acc)
+    kk.call("kk_gemm", 0, tb, M, N, K, 1.0, Ad, A.shape[1], Bd, Bm.shape[1], 1.0, Cd, N, None, dev(res), N + 8, 50, 1, 1, 3)
+    assert kk.last_kernel().startswith(want), (kk.last_kernel(), want)
+    close(Cd, prod.float() + dev(acc) + dev(res)[torch.arange(M, device="cuda") % 50][:, :N], 3e-3 * math.sqrt(K / 64), 1e-4, "g16x plain accumulate + residual")
 
 
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 1)])
@@ -674,7 +707,9 @@ BF = (2e-2, 1e-2)   # (atol, rtol): one bf16 rounding (2^-8 relative) of O(1) ou
 @pytest.mark.parametrize("B,h,Sq,Sk,causal,masked,strided", [(2, 2, 64, 64, 0, 1, 0), (8, 8, 64, 64, 0, 1, 1), (3, 2, 47, 47, 0, 1, 1), (2, 2, 33, 64, 1, 0, 0),
                                                               (1, 2, 200, 200, 1, 0, 1),
                                                               (2, 1, 37, 150, 0, 1, 0), (1, 8, 300, 300, 1, 0, 1),
-                                                              (1, 2, 1100, 1100, 1, 1, 1), (1, 2, 777, 1030, 0, 1, 0)])
+                                                              (1, 2, 1100, 1100, 1, 1, 1), (1, 2, 777, 1030, 0, 1, 0),
+                                                              # dynamic batching's shape class: >= 512 row blocks of a RAGGED sequence -> attn_fwd3_q128
+                                                              (12, 8, 1333, 1333, 1, 0, 1), (12, 8, 1333, 1333, 0, 1, 1)])
 def test_attention_bf16_storage(kk, B, h, Sq, Sk, causal, masked, strided):
     g = torch.Generator().manual_seed(Sq + 7 * Sk + causal)
     H = h * 64
@@ -699,6 +734,8 @@ def test_attention_bf16_storage(kk, B, h, Sq, Sk, causal, masked, strided):
         l32, l16 = torch.zeros(B, h, Sq, device="cuda"), torch.zeros(B, h, Sq, device="cuda")
         kk.call("kk_attn_fwd", Q, K, V, O32, l32, B, h, Sq, Sk, ld, ld, ld, H, kmd, causal, 0.125, seed, 4, p, 1, 0)
         kk.call("kk_attn_fwd", Q16, K16, V16, O16, l16, B, h, Sq, Sk, ld, ld, ld, H, kmd, causal, 0.125, seed, 4, p, 1, 1)
+        if Sk > 128:                                       # the route is part of what the case covers (kk_attn.hip: kk_attn_fwd)
+            assert kk.last_kernel() == ("attn_fwd3_q128" if -(-Sq // 128) * B * h >= 512 else "attn_fwd3_q64"), kk.last_kernel()
         close(O16, O32, *BF, f"attn fwd bf16 storage p={p}")
         close(l16, l32, 1e-5, 1e-5, "attn lse bf16 storage")
         O32r = O16.float()                                 # backward from the same (rounded) forward output
@@ -1353,7 +1390,8 @@ def test_attention_backward_generations_agree(kk, B, h, S, causal, masked):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,S,h,K", [(8, 512, 8, 512), (4, 1024, 8, 512), (3, 700, 8, 192), (16, 512, 4, 256), (8, 64, 8, 512), (5, 41, 8, 512),
-                                     (8, 1024, 8, 512), (11, 777, 8, 256)])      # (the last two: 128x128 tiles, a head per wave)
+                                     (8, 1024, 8, 512), (11, 777, 8, 256),
+                                     (8, 1024, 8, 1024), (11, 777, 8, 1088)])      # (the last two: K >= 1024 takes the 128x128 tile of kk_gemm16x.hip, route asserted)
 def test_gemm_dgrad_delta_epilogue(kk, B, S, h, K):
     """kk_gemm_dgrad_delta == kk_gemm (dgrad, bf16 result: bit-identical) + kk_attn_delta on that result (fp32 row sums of
     the same rounded products, summed in a different order)."""
@@ -1369,6 +1407,7 @@ def test_gemm_dgrad_delta_epilogue(kk, B, S, h, K):
     d_ref, d_new = torch.empty(B, h, S, device="cuda"), torch.full((B, h, S), 9.0, device="cuda")
     kk.call("kk_attn_delta", o, dx_ref, d_ref, B, h, S, N, N, 1)
     kk.call("kk_gemm_dgrad_delta", M, N, K, dy, K, W, N, dx, N, o, N, d_new, S, h)
+    assert kk.last_kernel().startswith("g16x<0,1,128,128,3,0," if K >= 1024 else "gemm16_w8<0,1,"), kk.last_kernel()
     torch.cuda.synchronize()
     assert torch.equal(dx, dx_ref), "the GEMM result must not change"
     want = (dx_ref.float() * o.float()).view(B, S, h, 64).sum(-1).permute(0, 2, 1)
@@ -1443,3 +1482,31 @@ def test_attention_backward_pair_launch(kk, B, h, Sq, Sk, causal, rope, p, maske
     torch.cuda.synchronize()
     assert torch.equal(dq_a, dq_b) and torch.equal(dkv_a, dkv_b), "plain gradients: pair launch == two launches"
 
+
+
+def test_cast_ranges_bucket_payload(kk):
+    """kk_cast_ranges: every range of a gradient bucket narrowed to its bf16 payload twin (and widened back, scaled) by one thin launch;
+    elements outside the ranges untouched; more ranges than one launch's table holds; ragged lengths."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(3)
+    n_el = 3_000_000
+    src = dev(torch.randn(n_el, generator=g))
+    ranges, pos = [], 0
+    for i in range(61):                                            # > 48 ranges: two launches
+        ln = int(torch.randint(1, 60000, (1,), generator=g)) if i % 5 else 4096 * 7
+        ranges.append((pos, pos + ln))
+        pos += ((ln + 1023) // 1024 + (i % 3)) * 1024
+    assert pos <= n_el
+    beg, end = (C.c_int64 * len(ranges))(*[b for b, _ in ranges]), (C.c_int64 * len(ranges))(*[e for _, e in ranges])
+    d16 = torch.full((n_el,), 7.0, device="cuda", dtype=torch.bfloat16)
+    kk.call("kk_cast_ranges", src, d16, beg, end, len(ranges), 1, 1.0)
+    want = torch.full((n_el,), 7.0, device="cuda", dtype=torch.bfloat16)
+    for b, e in ranges:
+        want[b:e] = src[b:e].bfloat16()
+    assert torch.equal(d16, want)
+    back = torch.full((n_el,), -3.0, device="cuda")
+    kk.call("kk_cast_ranges", d16, back, beg, end, len(ranges), 0, 0.5)
+    wantf = torch.full((n_el,), -3.0, device="cuda")
+    for b, e in ranges:
+        wantf[b:e] = d16[b:e].float() * 0.5
+    assert torch.equal(back, wantf)
