@@ -152,6 +152,22 @@ int kk_attn_bwd(const float *Q, const float *K, const float *V, const float *dO,
                 int64_t ldv, int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, const uint8_t *key_mask,
                 int causal, float scale, const uint32_t *seed, uint32_t site, float p_drop, int math, int io_bf16,
                 const KkAttnHeadNorm *hn_q, const KkAttnHeadNorm *hn_kv, void *stream);
+/* Stored dropout keep decisions (round 5).  The probabilities' dropout mask (SDPA dropout_p, transformers.py:393-398) is a counter hash
+ * that every kernel can regenerate; in the third-generation backward the regeneration was ~40 % of the vector instructions.
+ * kk_attn_fwd_kb = kk_attn_fwd that ALSO stores the keep decisions as packed bits (one per score: the 16 lane masks of every 32 x 32
+ * unit the kernel computes, 128 bytes per unit at (((b * heads + head) * ceil(Sq / 32) + qu) * ceil(Sk / 32) + ku) * 128);
+ * kk_attn_bwd_kb = kk_attn_bwd whose pair launch reads them instead of hashing (bit-identical gradients).  `keep` = a 16-byte aligned
+ * device buffer of kk_attn_keep_bytes(B, heads, Sq, Sk) bytes (0 = this shape's forward stores none: pass NULL); same seed value,
+ * site, p_drop, shape and masks in both calls.  NULL keep = exactly kk_attn_fwd / kk_attn_bwd. */
+int64_t kk_attn_keep_bytes(int B, int heads, int Sq, int Sk);
+int kk_attn_fwd_kb(const float *Q, const float *K, const float *V, float *O, float *LSE, int B, int heads, int Sq, int Sk,
+                   int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, const uint8_t *key_mask, int causal, float scale,
+                   const uint32_t *seed, uint32_t site, float p_drop, int math, int io_bf16, void *keep, void *stream);
+int kk_attn_bwd_kb(const float *Q, const float *K, const float *V, const float *dO, const float *LSE, const float *Delta,
+                   float *dQ, float *dK, float *dV, int B, int heads, int Sq, int Sk, int64_t ldq, int64_t ldk, int64_t ldv,
+                   int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, const uint8_t *key_mask, int causal, float scale,
+                   const uint32_t *seed, uint32_t site, float p_drop, int math, int io_bf16, const KkAttnHeadNorm *hn_q,
+                   const KkAttnHeadNorm *hn_kv, const void *keep, void *stream);
 /* The same backward in two passes through a caller-owned workspace (same call sites; `ws` of at least kk_attn_bwd_ws_bytes(...)
  * bytes, 16-byte aligned, private to the stream for the duration of the call): the dK/dV kernel also stores dS = P o (dP - Delta)
  * as bf16 tiles (2 bytes per score), and dQ = dS . K is a pass without softmax work (+ the head-norm epilogue) — the pair launch

@@ -48,6 +48,12 @@ struct AttnArgs {
     int dbg;                             // timing probes (KK_ATTN_DBG; results are wrong when set)
     int short_first;                     // attn_bwd_pair3: the dK/dV half of a causal launch hands out its SHORT blocks first (see there)
     void *dS;                            // kk_attn_bwd_ws: bf16 dS tiles, written by the dK/dV kernel, read by the dQ pass (kk_attn_bwd_dkv2.inc)
+    // Packed keep decisions of the probability dropout (kk_attn_fwd_kb / kk_attn_bwd_kb): one bit per score, written by the
+    // third-generation forward as the 16 ballots of every 32 x 32 unit it computes, read by the third-generation backward instead of
+    // re-hashing — the hash was ~40 % of the backward's vector instructions.  Unit (qu, ku) of (b, head): 128 bytes at
+    // (((b * heads + head) * nQU + qu) * nKU + ku) * 128, nQU = ceil(Sq / 32), nKU = ceil(Sk / 32); dword 2 r + h of a unit = bits over
+    // the unit's 32 queries (bit = query) for key frag_row(r, h): the forward's ballot of accumulator register r, half h.
+    void *keep;
     // backward kernels: the gradient of the per-head RMSNorm (+ RoPE) that produced Q (dQ kernel) / K and V (dK/dV
     // kernel: hn[0], hn[1]) as the epilogue — Out / Out2 then receive the gradient of the RAW projection
     KkAttnHeadNorm hn[2];
@@ -84,6 +90,17 @@ struct ProbDrop {
     __device__ __forceinline__ bool keep_lo(uint32_t h) const { return (h & 0xFFFFu) >= thr; }   // even key
     __device__ __forceinline__ bool keep_hi(uint32_t h) const { return (h >> 16) >= thr; }       // odd key
 };
+
+// Edge sub-tiles without branches: bits 0 .. rel of a 32-bit word (rel < 0: none, rel >= 31: all).  A unit's visibility word is
+// kk_low_bits(last visible element - first element of the unit) & ~(masked elements); a score is kept with v_bfe_i32 + v_and.
+__device__ __forceinline__ uint32_t kk_low_bits(int rel) { return rel < 0 ? 0u : (rel >= 31 ? 0xFFFFFFFFu : (2u << rel) - 1u); }
+// x with its bits ANDed by m (m = 0 or -1: v_bfe_i32 of a visibility / keep word).  Takes the value BY VALUE on purpose:
+// __builtin_bit_cast applied directly to an element of an ext_vector (`bit_cast(int, acc[r])`) reads element 0 whatever r is (clang
+// 19 / ROCm 7.2, seen in the disassembly: every select used the first accumulator register).
+__device__ __forceinline__ float kk_andf(float x, int m) { return __builtin_bit_cast(float, __builtin_bit_cast(int, x) & m); }
+__device__ __forceinline__ float kk_bfif(float x, int m, int other) { return __builtin_bit_cast(float, (__builtin_bit_cast(int, x) & m) | (~m & other)); }
+typedef unsigned long long kk_u64x8 __attribute__((ext_vector_type(8)));
+typedef const kk_u64x8 __attribute__((address_space(4))) kk_cu64x8;      // constant address space: a wave-uniform address gives s_load_dwordx16
 
 // Workgroup -> (128-row block, batch*head).  The dispatcher places workgroup i (x fastest) on XCD i % 8, each with a private
 // L2: in launch order the row blocks of one (batch, head) land on up to eight XCDs and every one of those L2s fetches that
@@ -1065,8 +1082,24 @@ __device__ __forceinline__ void attn_fwd3_body(const AttnArgs &a) {
     zero_acc(o[0]); zero_acc(o[1]);
     float m = -1e30f, l = 0.f;
     const float c2 = a.scale * 1.4426950408889634f;
+    const int klast = a.causal ? min(a.Sk - 1, q) : a.Sk - 1;  // the last key this lane's query sees
     ProbDrop pd;
     pd.init(a, b, hh);
+    // keep bits (AttnArgs::keep): the unit's 32 ballot dwords are gathered into lanes 0..31 of ONE register (v_writelane) and stored
+    // at the top of the NEXT tile step, BEFORE that step's tile DMAs are issued: the counted vmcnt waits above stay exact — the only
+    // operations younger than the tile a step waits for are the DMAs of the tile after it (CDNA4 counts stores in vmcnt too).
+    const int nKU = (a.Sk + 31) >> 5;
+    uint32_t *kbh = (a.keep != nullptr && pd.thr != 0u && qmin < a.Sq)         // (a wave whose 32 rows lie beyond Sq has no unit row in the array)
+        ? reinterpret_cast<uint32_t *>(static_cast<char *>(a.keep) + ((int64_t)(b * a.heads + hh) * ((a.Sq + 31) >> 5) + (qmin >> 5)) * nKU * 128) : nullptr;
+    uint32_t kw_pend = 0u;
+    int kw_unit = -1;                                          // (wave-uniform) key unit whose words are pending in kw_pend
+    auto flush_keep = [&]() {
+        if (kw_unit >= 0) {
+            if (lane < 32) kbh[kw_unit * 32 + lane] = kw_pend;
+            kw_unit = -1;
+        }
+        asm volatile("" ::: "memory");
+    };
     for (int t = 0; t < nt; ++t) {
         // tile t landed once at most the younger tiles' DMAs are outstanding (tile t + NS - 1 goes out behind this step's barrier)
         const int younger = min(nt - 1 - t, NS - 2);
@@ -1074,6 +1107,7 @@ __device__ __forceinline__ void attn_fwd3_body(const AttnArgs &a) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                         // ... for every wave, and every wave is done with tile t - 1
         asm volatile("" ::: "memory");
+        flush_keep();
         if (t + NS - 1 < nt) issue_tile(t + NS - 1, (t + NS - 1) % NS);
         const int k0 = t * KT + 32 * kg;
         if (k0 >= klim) continue;                             // (causal: nothing of this unit is visible to these queries)
@@ -1112,13 +1146,12 @@ __device__ __forceinline__ void attn_fwd3_body(const AttnArgs &a) {
         // softmax (+ dropout) of the unit, in place: the arithmetic of attn_fwd2's softmax_unit
         const uint32_t kmsub = km ? (uint32_t)(kmb[k0 >> 6] >> (k0 & 32)) : 0u;
         const bool edge = k0 + 32 > a.Sk || (a.causal && k0 + 31 > qmin) || kmsub != 0u;
-        if (edge) {
-            const uint32_t kml = kmsub >> (4 * half);
+        if (edge) {                                            // bit c of the word = key c of the unit is visible: no branches (kk_low_bits)
+            const uint32_t aw = (kk_low_bits(klast - k0) & ~kmsub) >> (4 * half);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = k0 + frag_row(r, half);
-                const bool ok = key < a.Sk && !(a.causal && key > q) && !((kml >> frag_row(r, 0)) & 1u);
-                s[r] = ok ? s[r] : -INFINITY;
+                const int m = __builtin_amdgcn_sbfe((int)aw, frag_row(r, 0), 1);
+                s[r] = kk_bfif(s[r], m, (int)0xff800000);     // (v_bfi_b32: s or -inf)
             }
         }
         float mx = s[0];
@@ -1140,11 +1173,24 @@ __device__ __forceinline__ void attn_fwd3_body(const AttnArgs &a) {
         l += rs;
         if (pd.thr) {
             const uint32_t xb = pd.row(q, k0 + 4 * half);
+            uint64_t mk[16];                                   // the comparisons' lane masks = the unit's ballots
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 const uint32_t hsh = pd.hash(xb + (uint32_t)(frag_row(r, 0) >> 1));
-                s[r] = pd.keep_lo(hsh) ? s[r] : 0.f;
-                s[r + 1] = pd.keep_hi(hsh) ? s[r + 1] : 0.f;
+                mk[r] = __builtin_amdgcn_uicmp(hsh & 0xFFFFu, pd.thr, 35);          // >= : keep_lo
+                mk[r + 1] = __builtin_amdgcn_uicmp(hsh >> 16, pd.thr, 35);          //      keep_hi
+                s[r] = __builtin_amdgcn_inverse_ballot_w64(mk[r]) ? s[r] : 0.f;
+                s[r + 1] = __builtin_amdgcn_inverse_ballot_w64(mk[r + 1]) ? s[r + 1] : 0.f;
+            }
+            if (kbh != nullptr) {
+                uint32_t kw = 0u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(kw) : "s"((uint32_t)mk[r]), "n"(2 * r));
+                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(kw) : "s"((uint32_t)(mk[r] >> 32)), "n"(2 * r + 1));
+                }
+                kw_pend = kw;
+                kw_unit = __builtin_amdgcn_readfirstlane(k0 >> 5);
             }
         }
         bf16x8 pb[2];
@@ -1163,6 +1209,7 @@ __device__ __forceinline__ void attn_fwd3_body(const AttnArgs &a) {
                 o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_pair(vlo[s2 * 2 + db], vhi[s2 * 2 + db]), pb[s2], o[db], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
+    flush_keep();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                           // the ring is free: the key slots' partial softmaxes meet in it
     {
@@ -1785,6 +1832,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pair3_kernel(AttnArgs a_dq, A
 #undef a
     }
 }
+// The pair launch that READS the dropout keep decisions the forward stored (AttnArgs::keep) instead of hashing them again: the same
+// bodies compiled with KK_KEEP_BITS — same arithmetic on the same decisions, bit-identical outputs (tests), ~100 vector instructions
+// per 32 x 32 unit less in each half.
+#define KK_KEEP_BITS 1
+__global__ __launch_bounds__(256, 2) void attn_bwd_pair3k_kernel(AttnArgs a_dq, AttnArgs a_dkv) {
+    if (blockIdx.z == 0) {
+#define a a_dq
+#include "kk_attn_bwd_dq3.inc"
+#undef a
+    } else {
+#define a a_dkv
+#include "kk_attn_bwd_dkv3.inc"
+#undef a
+    }
+}
+#undef KK_KEEP_BITS
 
 // ------------------------------------------------------------------ backward in two passes (kk_attn_bwd_ws)
 // The pair launch computes the scores, the exponentials, the dropout masks and dS TWICE (once per kernel: 7 S x S x 64 matmuls and
@@ -2044,10 +2107,17 @@ int check_headnorm(const char *name, const KkAttnHeadNorm *hn, int n) {
 // rows of the [workgroups][64] partial gain-gradient matrix a backward launch with a head-norm epilogue writes
 extern "C" int kk_attn_bwd_blocks(int B, int heads, int S) { return kk_cdiv(S, 128) * B * heads; }
 
-extern "C" int kk_attn_fwd(const float *Q, const float *K, const float *V, float *O, float *LSE, int B, int heads,
-                           int Sq, int Sk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
-                           const uint8_t *key_mask, int causal, float scale, const uint32_t *seed, uint32_t site,
-                           float p_drop, int math, int io_bf16, void *stream) {
+// Whether a forward launch of this shape stores keep bits (the third-generation kernels) and how many bytes they take; 0 = no.
+extern "C" int64_t kk_attn_keep_bytes(int B, int heads, int Sq, int Sk) {
+    if (B <= 0 || heads <= 0 || Sq <= 0 || Sk <= 128 || Sk > 4096 || g_attn_groups != 2 || !(attn_v2_mask() & 1)) return 0;
+    const int64_t per_head = (int64_t)kk_cdiv(Sq, 32) * kk_cdiv(Sk, 32) * 128;
+    return per_head < (1ll << 31) ? (int64_t)B * heads * per_head : 0;
+}
+
+static int attn_fwd_impl(const float *Q, const float *K, const float *V, float *O, float *LSE, int B, int heads,
+                         int Sq, int Sk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                         const uint8_t *key_mask, int causal, float scale, const uint32_t *seed, uint32_t site,
+                         float p_drop, int math, int io_bf16, void *keep, void *stream) {
     KK_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "kk_attn_fwd: dropout probability must be in [0,1)");
     KK_REQUIRE(!io_bf16 || math == KK_MATH_BF16, "kk_attn_fwd: bf16 storage needs KK_MATH_BF16");
     const int64_t lds[4] = {ldq, ldk, ldv, ldo};
@@ -2057,6 +2127,7 @@ extern "C" int kk_attn_fwd(const float *Q, const float *K, const float *V, float
     a.B = B; a.heads = heads; a.Sq = Sq; a.Sk = Sk; a.causal = causal;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldout = ldo; a.scale = scale;
     a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(causal); a.dbg = attn_dbg(); a.wt = kk_write_through((int64_t)B * std::max(Sq, Sk));
+    a.keep = keep;
 #ifdef KK_TUNING_HOOKS
     if (a.dbg & 256) a.DeltaOut = static_cast<float *>(g_attn_trace);
 #endif
@@ -2087,6 +2158,7 @@ extern "C" int kk_attn_fwd(const float *Q, const float *K, const float *V, float
             KK_LAUNCH_CHECK("kk_attn_fwd");
             return 0;
         }
+        KK_REQUIRE(keep == nullptr, "kk_attn_fwd_kb: only the third-generation forward stores keep bits (ask kk_attn_keep_bytes)");
         static const int ns2 = kk_tune_env("KK_ATTN_NS", 3);
         kk_note_kernel("attn_fwd2");
 #ifdef KK_TUNING_HOOKS
@@ -2100,12 +2172,30 @@ extern "C" int kk_attn_fwd(const float *Q, const float *K, const float *V, float
         KK_LAUNCH_CHECK("kk_attn_fwd");
         return 0;
     }
+    KK_REQUIRE(keep == nullptr, "kk_attn_fwd_kb: this launch (storage, alignment or shape) does not take the third-generation forward, which alone stores keep bits");
     kk_note_kernel("attn_fwd");
     if (io_bf16) KK_ATTN_LAUNCH(attn_fwd_kernel, true, true, G, 2);
     else if (math == KK_MATH_BF16) KK_ATTN_LAUNCH(attn_fwd_kernel, true, false, G, 2);
     else KK_ATTN_LAUNCH(attn_fwd_kernel, false, false, G, 2);
     KK_LAUNCH_CHECK("kk_attn_fwd");
     return 0;
+}
+
+extern "C" int kk_attn_fwd(const float *Q, const float *K, const float *V, float *O, float *LSE, int B, int heads,
+                           int Sq, int Sk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                           const uint8_t *key_mask, int causal, float scale, const uint32_t *seed, uint32_t site,
+                           float p_drop, int math, int io_bf16, void *stream) {
+    return attn_fwd_impl(Q, K, V, O, LSE, B, heads, Sq, Sk, ldq, ldk, ldv, ldo, key_mask, causal, scale, seed, site, p_drop, math, io_bf16,
+                         nullptr, stream);
+}
+// kk_attn_fwd that also stores the dropout keep decisions (AttnArgs::keep; kk_attn_keep_bytes(B, heads, Sq, Sk) bytes, > 0 required)
+extern "C" int kk_attn_fwd_kb(const float *Q, const float *K, const float *V, float *O, float *LSE, int B, int heads,
+                              int Sq, int Sk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                              const uint8_t *key_mask, int causal, float scale, const uint32_t *seed, uint32_t site,
+                              float p_drop, int math, int io_bf16, void *keep, void *stream) {
+    KK_REQUIRE(keep == nullptr || (al16(keep) && kk_attn_keep_bytes(B, heads, Sq, Sk) > 0), "kk_attn_fwd_kb: no keep bits for this shape (kk_attn_keep_bytes) or unaligned buffer");
+    return attn_fwd_impl(Q, K, V, O, LSE, B, heads, Sq, Sk, ldq, ldk, ldv, ldo, key_mask, causal, scale, seed, site, p_drop, math, io_bf16,
+                         keep, stream);
 }
 
 extern "C" int kk_attn_delta(const float *O, const float *dO, float *Delta, int B, int heads, int Sq, int64_t ldo,
@@ -2207,11 +2297,11 @@ extern "C" int kk_attn_bwd_dkv(const float *Q, const float *K, const float *V, c
 // dQ, dK and dV in one launch (attn_bwd_pair2_kernel) when both second-generation kernels apply; otherwise the two launches
 // above, in order.  Delta[b, head, q] = sum_d dO * O is an INPUT here (kk_gemm_dgrad_delta writes it with dO, or kk_attn_delta).
 // hn_q / hn_kv: the head-norm backward epilogues of kk_attn_bwd_dq / kk_attn_bwd_dkv (both or neither).
-extern "C" int kk_attn_bwd(const float *Q, const float *K, const float *V, const float *dO, const float *LSE, const float *Delta,
-                           float *dQ, float *dK, float *dV, int B, int heads, int Sq, int Sk, int64_t ldq, int64_t ldk,
-                           int64_t ldv, int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, const uint8_t *key_mask,
-                           int causal, float scale, const uint32_t *seed, uint32_t site, float p_drop, int math, int io_bf16,
-                           const KkAttnHeadNorm *hn_q, const KkAttnHeadNorm *hn_kv, void *stream) {
+static int attn_bwd_impl(const float *Q, const float *K, const float *V, const float *dO, const float *LSE, const float *Delta,
+                         float *dQ, float *dK, float *dV, int B, int heads, int Sq, int Sk, int64_t ldq, int64_t ldk,
+                         int64_t ldv, int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, const uint8_t *key_mask,
+                         int causal, float scale, const uint32_t *seed, uint32_t site, float p_drop, int math, int io_bf16,
+                         const KkAttnHeadNorm *hn_q, const KkAttnHeadNorm *hn_kv, const void *keep, void *stream) {
     KK_REQUIRE(Delta != nullptr, "kk_attn_bwd: Delta is an input of this call");
     KK_REQUIRE((hn_q == nullptr) == (hn_kv == nullptr), "kk_attn_bwd: head-norm epilogues for both kernels or for neither");
     const int G = (Sk > 64 && Sq > 64 && g_attn_groups == 2) ? 2 : 1;
@@ -2257,7 +2347,20 @@ extern "C" int kk_attn_bwd(const float *Q, const float *K, const float *V, const
         }
         // (short blocks first only when both halves are resident at once — 2 workgroups per CU; with more rounds the longest-first
         //  order of the second generation is the faster one: 8 x 8 x 1024^2 causal 79 against 96 us)
-        p.dkv.short_first = (causal && (attn_gen3() & 2) && (int64_t)kk_cdiv(Sq, 128) * B * heads <= g_attn_cus()) ? 1 : 0;
+        p.dkv.short_first = (causal && (attn_gen3() & 2) != 0 && (int64_t)kk_cdiv(Sq, 128) * B * heads <= g_attn_cus()) ? 1 : 0;
+        if (keep != nullptr && p_drop > 0.f && Sk > 128 && kk_attn_keep_bytes(B, heads, Sq, Sk) > 0) {      // (exactly the launches whose forward stored the bits)
+            static thread_local bool raised3k = false;
+            if (!raised3k) {
+                hipError_t e = hipFuncSetAttribute((const void *)attn_bwd_pair3k_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+                if (e != hipSuccess) return kk_fail((int)e, "kk_attn_bwd: cannot reserve %zu bytes of LDS: %s", lds3, hipGetErrorString(e));
+                raised3k = true;
+            }
+            p.dq.keep = p.dkv.keep = const_cast<void *>(keep);
+            kk_note_kernel("attn_bwd_pair3k");
+            hipLaunchKernelGGL(attn_bwd_pair3k_kernel, dim3(kk_cdiv(Sq, 128), B * heads, 2), dim3(256), lds3, (hipStream_t)stream, p.dq, p.dkv);
+            KK_LAUNCH_CHECK("kk_attn_bwd");
+            return 0;
+        }
         kk_note_kernel("attn_bwd_pair3");
         hipLaunchKernelGGL(attn_bwd_pair3_kernel, dim3(kk_cdiv(Sq, 128), B * heads, 2), dim3(256), lds3, (hipStream_t)stream, p.dq, p.dkv);
         KK_LAUNCH_CHECK("kk_attn_bwd");
@@ -2278,6 +2381,26 @@ extern "C" int kk_attn_bwd(const float *Q, const float *K, const float *V, const
 #else
     return kk_fail(KK_EINVAL, "kk_attn_bwd: unreachable");
 #endif
+}
+
+extern "C" int kk_attn_bwd(const float *Q, const float *K, const float *V, const float *dO, const float *LSE, const float *Delta,
+                           float *dQ, float *dK, float *dV, int B, int heads, int Sq, int Sk, int64_t ldq, int64_t ldk,
+                           int64_t ldv, int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, const uint8_t *key_mask,
+                           int causal, float scale, const uint32_t *seed, uint32_t site, float p_drop, int math, int io_bf16,
+                           const KkAttnHeadNorm *hn_q, const KkAttnHeadNorm *hn_kv, void *stream) {
+    return attn_bwd_impl(Q, K, V, dO, LSE, Delta, dQ, dK, dV, B, heads, Sq, Sk, ldq, ldk, ldv, lddo, lddq, lddk, lddv, key_mask, causal,
+                         scale, seed, site, p_drop, math, io_bf16, hn_q, hn_kv, nullptr, stream);
+}
+// kk_attn_bwd reading the keep decisions kk_attn_fwd_kb stored for the SAME launch parameters (seed value, site, p_drop, shape): the
+// pair launch then reads bits where it would hash (bit-identical results); every fall-back path ignores `keep` and hashes.
+extern "C" int kk_attn_bwd_kb(const float *Q, const float *K, const float *V, const float *dO, const float *LSE, const float *Delta,
+                              float *dQ, float *dK, float *dV, int B, int heads, int Sq, int Sk, int64_t ldq, int64_t ldk,
+                              int64_t ldv, int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, const uint8_t *key_mask,
+                              int causal, float scale, const uint32_t *seed, uint32_t site, float p_drop, int math, int io_bf16,
+                              const KkAttnHeadNorm *hn_q, const KkAttnHeadNorm *hn_kv, const void *keep, void *stream) {
+    KK_REQUIRE(keep == nullptr || al16(keep), "kk_attn_bwd_kb: unaligned keep buffer");
+    return attn_bwd_impl(Q, K, V, dO, LSE, Delta, dQ, dK, dV, B, heads, Sq, Sk, ldq, ldk, ldv, lddo, lddq, lddk, lddv, key_mask, causal,
+                         scale, seed, site, p_drop, math, io_bf16, hn_q, hn_kv, keep, stream);
 }
 
 // Backward in two passes through a caller-owned workspace (see attn_bwd_dkv2s_kernel): the same contract and fall-backs as

@@ -950,7 +950,7 @@ int kk_gemm16_wgrad_group(const KkWgradDesc *d, int n, int split_k, int overwrit
                 a.A = d[i].dy; a.B = d[i].x; a.C = d[i].dw;
                 a.lda = d[i].lddy; a.ldb = d[i].ldx; a.ldc = d[i].lddw;
                 a.k_per_split = cd(K, BK) * BK; a.splits = 1;
-                a.tiles_m = cd(M, 128); a.tiles_n = cd(N, 128); a.xcd_swizzle = g.xcd_chunks ? 0 : xcd_swizzle;
+                a.tiles_m = cd(M, 128); a.tiles_n = cd(N, 128); a.xcd_swizzle = g.xcd_chunks ? 0 : xcd_swizzle; a.dbg = g16x_dbg;
                 a.m_fast = (g16_group_mfast && xcd_swizzle && M < N) ? 1 : 0;
                 a.a_bytes = (uint32_t)(((K - 1) * a.lda + M) * 2);
                 a.b_bytes = (uint32_t)(((K - 1) * a.ldb + N) * 2);

@@ -716,6 +716,7 @@ void kk_g16x_probe(int bits, void *buf) { g16x_probe_bits = bits; g16x_probe_buf
 // (KK_TUNING_HOOKS, KK_G16X_LW); the product build folds the choice to 1 and carries one kernel per tile and layout.
 #ifdef KK_TUNING_HOOKS
 int g16x_lw = kk_tune_env("KK_G16X_LW", 1);
+int g16x_ns4 = kk_tune_env("KK_G16X_NS4", 0);          // tools: four stages (three k-tiles in flight) on the 128 x 128 tile
 #define G16X_LW(lw1, lw0) (g16x_lw ? (lw1) : (lw0))
 #else
 #define G16X_LW(lw1, lw0) (lw1)
@@ -730,6 +731,10 @@ void kk_g16x_tile(int cfg, int *bm, int *bn) {
 int kk_g16x_plain(int cfg, int ta, int tb, const G16Args &a, hipStream_t s) {
     const int lay = (ta ? 2 : 0) | (tb ? 1 : 0);
     if (cfg == G16X_128x128) {
+#ifdef KK_TUNING_HOOKS
+        if (g16x_ns4 && lay == 0) return launch_x<false, false, 128, 128, 4, 0, 2, 2, 4>(a, "kk_gemm", s);
+        if (g16x_ns4 && lay == 1) return launch_x<false, true, 128, 128, 4, 0, 2, 2, 4>(a, "kk_gemm", s);
+#endif
         if (lay == 0) return G16X_LW((launch_x<false, false, 128, 128, 3, 0, 2, 2, 4>(a, "kk_gemm", s)), (launch_x<false, false, 128, 128, 3, 0, 4, 2, 0>(a, "kk_gemm", s)));
         if (lay == 1) return G16X_LW((launch_x<false, true, 128, 128, 3, 0, 2, 2, 4>(a, "kk_gemm", s)), (launch_x<false, true, 128, 128, 3, 0, 4, 2, 0>(a, "kk_gemm", s)));
     } else if (cfg == G16X_256x128) {
@@ -768,7 +773,8 @@ int kk_g16x_glu_bwd(const G16Args &a, hipStream_t s) {
 int kk_g16x_group(const G16Group &g, int grid, hipStream_t s) {
 #ifdef KK_TUNING_HOOKS
     kk_note_kernelf("g16x_group<1,1,128,128,3,lw%d>", g16x_lw);
-    if (g16x_lw == 2) hipLaunchKernelGGL((g16x_group_kernel<true, true, 128, 128, 3, 4, 2, 4>), dim3(grid), dim3(768), 0, s, g);
+    if (g16x_ns4) hipLaunchKernelGGL((g16x_group_kernel<true, true, 128, 128, 4, 2, 2, 4>), dim3(grid), dim3(512), 0, s, g);
+    else if (g16x_lw == 2) hipLaunchKernelGGL((g16x_group_kernel<true, true, 128, 128, 3, 4, 2, 4>), dim3(grid), dim3(768), 0, s, g);
     else if (g16x_lw) hipLaunchKernelGGL((g16x_group_kernel<true, true, 128, 128, 3, 2, 2, 4>), dim3(grid), dim3(512), 0, s, g);
     else hipLaunchKernelGGL((g16x_group_kernel<true, true, 128, 128, 3, 4, 2, 0>), dim3(grid), dim3(512), 0, s, g);
 #else

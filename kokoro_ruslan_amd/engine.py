@@ -210,6 +210,9 @@ class KokoroEngine:
         # ... or, where the library prices it cheaper (kk_attn_bwd_two_pass: nowhere beside the present pair launch), as the dK/dV
         # kernel that also stores dS + a dQ pass without softmax work (kk_attn_bwd_ws; workspace of 2 bytes per score per stream)
         self.attn_two_pass = True
+        # the attention forward stores its dropout keep decisions as packed bits (kk_attn_fwd_kb) and the backward's pair launch reads
+        # them (kk_attn_bwd_kb) instead of hashing them again: ~40 % of the backward kernels' vector instructions (round 5)
+        self.attn_keep_bits = True
         self.attn_pair_min_seq = 32                # (one-tile sequences included: the text encoder's 33..64 phonemes; 64 = the round-2 dispatch)
         self.attn_proj_bf16 = True                 # decoder w_o output stored as bf16 (bf16 mode)
         # The zero-fill at the start of an accumulation cycle skips what the cycle's first grouped weight-gradient launches
@@ -639,8 +642,13 @@ class KokoroEngine:
             self._proj_headnorm(xq, self._W(prefix + ".w_q.weight"), q_raw, q_n, Sq, (gq,), 0, None, None)
             k_raw, v_raw, k_n, v_n = kv_raw, kv_raw[:, H:], kv_n, kv_n[:, H:]
         ctx, lse = self._buf(key + ".ctx", Nq, H, dtype=dt), self._buf(key + ".lse", B, h, Sq)
-        kk.call("kk_attn_fwd", q_n, k_n, v_n, ctx, lse, B, h, Sq, Sk, q_n.stride(0), k_n.stride(0), v_n.stride(0), H, key_mask,
-                1 if causal else 0, 0.125, self.rng, site + 3, p, self.math, i16)
+        keep = self._attn_keep(key, B, Sq, Sk, p, i16)
+        if keep is not None:      # the forward also stores the dropout keep decisions (1 bit per score) for the backward's pair launch
+            kk.call("kk_attn_fwd_kb", q_n, k_n, v_n, ctx, lse, B, h, Sq, Sk, q_n.stride(0), k_n.stride(0), v_n.stride(0), H, key_mask,
+                    1 if causal else 0, 0.125, self.rng, site + 3, p, self.math, i16, keep)
+        else:
+            kk.call("kk_attn_fwd", q_n, k_n, v_n, ctx, lse, B, h, Sq, Sk, q_n.stride(0), k_n.stride(0), v_n.stride(0), H, key_mask,
+                    1 if causal else 0, 0.125, self.rng, site + 3, p, self.math, i16)
         # the projection output lives only until the tail two launches later: in the decoder's bf16 mode it is stored like every
         # other GEMM result there (what autocast gives the reference's nn.Linear); the text encoder keeps fp32 (its persistent
         # launch hands the tile over in fp32, and the per-kernel path must match it)
@@ -649,6 +657,15 @@ class KokoroEngine:
         proj = self._buf("tmp.attn_proj16" if p16 else "tmp.attn_proj", Nq, H, dtype=dt if p16 else torch.float32)
         self._linear(ctx, Wo, P[prefix + ".w_o.bias"], proj)
         return self._sublayer_tail(proj, x_res, x_out, Sq, site, p, dpr, 0.0, None, None, next_ln)   # (p = 0: masks are all ones)
+
+    def _attn_keep(self, key, B, Sq, Sk, p, i16):
+        """Buffer of the attention sub-layer's packed dropout keep decisions (kk_attn_fwd_kb writes, kk_attn_bwd_kb reads: the backward
+        then spends no vector instructions on the mask hash), or None where the library stores none (short sequences, fp32 storage,
+        no dropout) or the switch is off."""
+        if not (self.attn_keep_bits and i16 and p > 0.0):
+            return None
+        n = kk.load().kk_attn_keep_bytes(B, self.dims.heads, Sq, Sk)
+        return self._buf(key + ".keep", n, dtype=torch.uint8) if n > 0 else None
 
     def _cross_kv(self, layer, Nk, dt, which=""):
         """(raw, normed) K|V of cross-attention layer `layer`: column slices [.., 2H] of the all-layer buffers (row stride
@@ -757,6 +774,10 @@ class KokoroEngine:
             if self.attn_two_pass and kk.load().kk_attn_bwd_two_pass(B, h, Sq, Sk, cz):
                 need = kk.load().kk_attn_bwd_ws_bytes(B, h, Sq, Sk)
                 kk.call("kk_attn_bwd_ws", *args, self._buf("tmp.attn_dS", need, dtype=torch.uint8), need)
+                return
+            keep = self._attn_keep(key, B, Sq, Sk, p, i16)          # (the buffer the forward of this sub-layer filled)
+            if keep is not None:
+                kk.call("kk_attn_bwd_kb", *args, keep)
             else:
                 kk.call("kk_attn_bwd", *args)
 

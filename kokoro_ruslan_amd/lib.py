@@ -147,10 +147,12 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_gemm_wgrad_group": [_P, _I, _I, _I, _P],
     "kk_colsum_acc": [_P, _L, _L, _L, _P, _I, _P],
     "kk_attn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P],
+    "kk_attn_fwd_kb": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P, _P],
     "kk_attn_delta": [_P, _P, _P, _I, _I, _I, _L, _L, _I, _P],
     "kk_attn_bwd_dq": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P, _L, _P, _P],
     "kk_zero_many": [_P, _P, _I, _P],
     "kk_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P, _P, _P],
+    "kk_attn_bwd_kb": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P, _P, _P, _P],
     "kk_attn_bwd_ws": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P, _P, _P, _L, _P],
     "kk_attn_bwd_two_pass": [_I, _I, _I, _I, _I],
     "kk_gemm_dgrad_delta": [_L, _L, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _I, _I, _P],
@@ -267,6 +269,8 @@ def load() -> C.CDLL:
         fn.restype = C.c_int
     lib.kk_attn_bwd_ws_bytes.argtypes = [_I, _I, _I, _I]
     lib.kk_attn_bwd_ws_bytes.restype = C.c_int64
+    lib.kk_attn_keep_bytes.argtypes = [_I, _I, _I, _I]
+    lib.kk_attn_keep_bytes.restype = C.c_int64
     if lib.kk_abi_version() != 1:
         raise RuntimeError("libkokoro_hip.so ABI version mismatch")
     _lib = lib

@@ -40,6 +40,20 @@ def _cos(got, ref):
     return float(got @ ref / (got.norm() * ref.norm()).clamp(min=1e-30))
 
 
+def decode_keep_bits(buf, B, h, Sq, Sk):
+    """[B, h, Sq', Sk'] bool from the packed keep decisions of kk_attn_fwd_kb (include/kokoro_hip.h: 128 bytes per 32 x 32 unit,
+    dword 2 r + hf = bits over the unit's queries for key (r & 3) + 8 (r >> 2) + 4 hf), Sq' / Sk' rounded up to 32."""
+    nq, nk = -(-Sq // 32), -(-Sk // 32)
+    w = buf.view(torch.int32).view(B, h, nq, nk, 32)
+    bits = ((w.unsqueeze(-1) >> torch.arange(32, device=buf.device, dtype=torch.int32)) & 1).bool()      # [.., dword, query]
+    d = torch.arange(32, device=buf.device)
+    r, hf = d >> 1, d & 1
+    key_of = (r & 3) + 8 * (r >> 2) + 4 * hf
+    by_key = torch.empty_like(bits)
+    by_key[..., key_of, :] = bits                                                                        # [.., key, query]
+    return by_key.permute(0, 1, 2, 5, 3, 4).reshape(B, h, nq * 32, nk * 32)[:, :, :Sq, :Sk]
+
+
 def _headnorm64(raw, gain, cos, sin, B, S, h):
     """fp64 per-head RMSNorm (eps of fp32, as nn.RMSNorm(eps=None) on fp32 activations) * gain, then RoPE (rotate-half)."""
     x = raw.view(B, S, h, 64)
@@ -111,6 +125,17 @@ def test_v2_attention_forward_and_pair_backward_against_fp64(kk, S, causal, mask
     mask = torch.where(keep, inv_keep, 0.0).double()
     mask = torch.where(known, mask, torch.full_like(mask, 1.0))     # (P0 == 0: masked or underflowed, contributes nothing)
 
+    # ---- round 5: the forward that STORES the keep decisions (kk_attn_fwd_kb): the stored bits are the recovered mask, and the launch
+    # changes nothing else
+    nbytes = kk.load().kk_attn_keep_bytes(B, h, S, S)
+    assert nbytes == B * h * (S // 32) ** 2 * 128
+    keep_buf = torch.full((nbytes,), 0x5A, dtype=torch.uint8, device="cuda")
+    o_kb, lse_kb = torch.empty(B * S, H, device="cuda", dtype=bf), torch.empty(B, h, S, device="cuda")
+    kk.call("kk_attn_fwd_kb", q_n, k_n, v_n, o_kb, lse_kb, B, h, S, S, H, 2 * H, v_n.stride(0), H, km, causal, 0.125, seed, site, p, 1, 1, keep_buf)
+    assert kk.last_kernel() == ("attn_fwd3_q128" if (S // 128) * B * h >= 512 else "attn_fwd3_q64")
+    stored = decode_keep_bits(keep_buf, B, h, S, S)
+    assert bool((stored == keep)[known].all()), "stored keep bits == the mask the kernel applied"
+
     # ---- fp64 reference of the attention proper, on the kernel's own (bf16) inputs
     hd = lambda x: x.view(B, S, h, 64).transpose(1, 2)
     qr, kr_, vr = (t.double().clone().requires_grad_(True) for t in (q_n, k_n[:, :H], v_n[:, :H]))
@@ -129,6 +154,7 @@ def test_v2_attention_forward_and_pair_backward_against_fp64(kk, S, causal, mask
     o = torch.empty(B * S, H, device="cuda", dtype=bf)
     lse = torch.empty(B, h, S, device="cuda")
     fwd(v_n, p, o, lse)
+    assert torch.equal(o, o_kb) and torch.equal(lse, lse_kb), "storing the keep bits must not change the forward"
     assert _rel(o, out_ref.detach()) < 8e-3 and _cos(o, out_ref.detach()) > 0.9999, ("attention output", _rel(o, out_ref.detach()))
     assert float((o.double() - out_ref.detach()).abs().max()) < 6e-2
     assert float((lse.double() - lse_ref.detach()).abs().max()) < 2e-3, "log-sum-exp rows"
@@ -182,3 +208,15 @@ def test_v2_attention_forward_and_pair_backward_against_fp64(kk, S, causal, mask
         assert float((got.double() - want).abs().max()) < 0.05 * float(want.abs().max()) + 1e-3, name
     for name, got, want in zip("qkv", dgs, want_gain):
         assert _rel(got, want) < 1e-2, (f"gain gradient {name}", _rel(got, want))
+    # ---- round 5: the pair launch that READS the stored decisions (kk_attn_bwd_kb -> attn_bwd_pair3k): bit-identical to the hashing one
+    assert kk.last_kernel() != "attn_bwd_pair3k"
+    pq2, pkv2 = torch.zeros(1, nb, 64, device="cuda"), torch.zeros(2, nb, 64, device="cuda")
+    dq2, dkv2 = torch.full_like(raw_q, 7.0), torch.full_like(raw_kv, 7.0)
+    hq2 = kk.attn_headnorm([(raw_q, gains[0], pq2[0], cos, sin)])
+    hkv2 = kk.attn_headnorm([(raw_kv, gains[1], pkv2[0], cos, sin), (raw_kv[:, H:], gains[2], pkv2[1], None, None)])
+    kk.call("kk_attn_bwd_kb", q_n, k_n, v_n, do, lse, delta, dq2, dkv2, dkv2[:, H:], B, h, S, S, H, 2 * H, 2 * H, H, H, 2 * H, 2 * H, km,
+            causal, 0.125, seed, site, p, 1, 1, hq2, hkv2, keep_buf)
+    assert kk.last_kernel() == "attn_bwd_pair3k"
+    torch.cuda.synchronize()
+    assert torch.equal(dq2, dq) and torch.equal(dkv2, dkv), "reading the keep bits == hashing them again"
+    assert torch.equal(pq2, pq) and torch.equal(pkv2, pkv)

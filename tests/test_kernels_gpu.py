@@ -1419,7 +1419,8 @@ def test_gemm_dgrad_delta_epilogue(kk, B, S, h, K):
 @pytest.mark.parametrize("B,h,Sq,Sk,causal,rope,p,masked", [(1, 8, 512, 512, 1, 1, 0.1, 0), (2, 4, 512, 512, 0, 0, 0.2, 1), (1, 2, 1000, 1000, 1, 1, 0.2, 0),
                                                             (1, 2, 900, 1000, 0, 1, 0.1, 1), (2, 2, 300, 384, 0, 0, 0.0, 0), (2, 2, 200, 200, 1, 1, 0.0, 0),
                                                             (1, 2, 130, 400, 0, 0, 0.1, 0), (8, 8, 64, 64, 0, 1, 0.15, 1), (3, 4, 41, 41, 0, 1, 0.15, 1),
-                                                            (2, 2, 64, 50, 0, 0, 0.0, 0)])
+                                                            (2, 2, 64, 50, 0, 0, 0.0, 0),
+                                                            (12, 8, 1333, 1333, 1, 1, 0.2, 0), (12, 8, 1333, 1333, 0, 0, 0.2, 1), (4, 8, 1024, 1024, 1, 1, 0.2, 1)])
 def test_attention_backward_pair_launch(kk, B, h, Sq, Sk, causal, rope, p, masked):
     """kk_attn_bwd (dQ | dK, dV as the two halves of one grid, Delta an input) == kk_attn_bwd_dq + kk_attn_bwd_dkv given the
     same Delta: bit-identical gradients and gain-gradient partial rows (same code, only the launch differs).  The last case
@@ -1481,6 +1482,31 @@ def test_attention_backward_pair_launch(kk, B, h, Sq, Sk, causal, rope, p, maske
             0.125, seed, 5, p, 1, 1, None, None)
     torch.cuda.synchronize()
     assert torch.equal(dq_a, dq_b) and torch.equal(dkv_a, dkv_b), "plain gradients: pair launch == two launches"
+    # round 5: the forward that stores the keep decisions + the pair launch that reads them (kk_attn_fwd_kb / kk_attn_bwd_kb): the same
+    # output, log-sum-exp rows and gradients bit for bit — with and without the head-norm epilogues, ragged sequences included
+    nbytes = kk.load().kk_attn_keep_bytes(B, h, Sq, Sk)
+    assert (nbytes > 0) == (Sk > 128)
+    if nbytes > 0 and p > 0.0:
+        keep = torch.full((nbytes,), 0xA5, dtype=torch.uint8, device="cuda")
+        o2, lse2 = torch.empty_like(o), torch.empty_like(lse)
+        kk.call("kk_attn_fwd_kb", q_n, k_n, v_n, o2, lse2, B, h, Sq, Sk, H, 2 * H, 2 * H, H, km, causal, 0.125, seed, 5, p, 1, 1, keep)
+        assert kk.last_kernel().startswith("attn_fwd3_q")
+        assert torch.equal(o2, o) and torch.equal(lse2, lse)
+        pair_ok = -(-Sq // 128) == -(-Sk // 128)
+        dq_k, dkv_k = torch.full_like(raw_q, 7.0), torch.full_like(raw_kv, 7.0)
+        kk.call("kk_attn_bwd_kb", q_n, k_n, v_n, do, lse, delta, dq_k, dkv_k, dkv_k[:, H:], B, h, Sq, Sk, H, 2 * H, 2 * H, H, H, 2 * H, 2 * H, km,
+                causal, 0.125, seed, 5, p, 1, 1, None, None, keep)
+        assert kk.last_kernel() == ("attn_bwd_pair3k" if pair_ok else "attn_bwd_dkv3"), kk.last_kernel()
+        pq, pkv = torch.full((1, nbq, 64), 5.0, device="cuda"), torch.full((2, nbk, 64), 5.0, device="cuda")
+        dq_h, dkv_h = torch.full_like(raw_q, 7.0), torch.full_like(raw_kv, 7.0)
+        hq = kk.attn_headnorm([(raw_q, gains[0], pq[0], c, s)])
+        hkv = kk.attn_headnorm([(raw_kv, gains[1], pkv[0], c, s), (raw_kv[:, H:], gains[2], pkv[1], None, None)])
+        kk.call("kk_attn_bwd_kb", q_n, k_n, v_n, do, lse, delta, dq_h, dkv_h, dkv_h[:, H:], B, h, Sq, Sk, H, 2 * H, 2 * H, H, H, 2 * H, 2 * H, km,
+                causal, 0.125, seed, 5, p, 1, 1, hq, hkv, keep)
+        torch.cuda.synchronize()
+        assert torch.equal(dq_k, dq_b) and torch.equal(dkv_k, dkv_b), "plain gradients: reading the keep bits == hashing"
+        assert torch.equal(dq_h, new[0]) and torch.equal(dkv_h, new[1]), "head-norm epilogues: reading the keep bits == hashing"
+        assert torch.equal(pq, new[2]) and torch.equal(pkv, new[3])
 
 
 
