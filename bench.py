@@ -195,22 +195,26 @@ def kernel_table(records, math_bf16: bool):
                 key, bm_, bn_ = f"{x[2]} (dY.W dgrad + Delta epilogue, 128x128 tiles, loader waves)", x[0], x[1]
             flops, byts = 2.0 * M * N * K, 2.0 * (M * K + N * K + 2 * M * N)
             floor = lds_floor_us(M * N * K, bm_, bn_)
-        elif name == "kk_attn_bwd":                     # (B, h, Sq, Sk, 7 row strides, causal, scale, site, p_drop, math, io_bf16)
+        elif name in ("kk_attn_bwd", "kk_attn_bwd_kb"):  # (B, h, Sq, Sk, 7 row strides, causal, scale, site, p_drop, math, io_bf16); _kb: + the keep-bit buffer (a tensor)
             B, h, Sq, Sk = (int(x) for x in sc[:4])
             causal = int(sc[-6])
+            kb = name == "kk_attn_bwd_kb" and Sk > 128 and float(sc[-3]) > 0.0      # (mirrors kk_attn_bwd_kb: the launches whose forward stored bits)
             # (the text encoder's one-tile launches, S <= 64, are a different regime from the decoder's: listed apart)
-            key = "attn_bwd_pair3_kernel (dQ | dK, dV in one launch, two workgroups per CU)" + (", one-tile sequences (text encoder)" if max(Sq, Sk) <= 64 else "")
+            key = ("attn_bwd_pair3k_kernel (dQ | dK, dV in one launch, two workgroups per CU, stored dropout keep bits)" if kb else
+                   "attn_bwd_pair3_kernel (dQ | dK, dV in one launch, two workgroups per CU)" + (", one-tile sequences (text encoder)" if max(Sq, Sk) <= 64 else ""))
             # §8d: training = 3 x forward, no credit for recomputation — the backward of the forward's 2 matmuls is 4 (dV, dP, dQ, dK);
             # the launch EXECUTES 7 (S and dP are computed by both halves): executed work is not algorithmic work
             flops = 4 * 2.0 * B * h * Sq * Sk * 64 * (0.5 if causal else 1.0)
-            byts = (2.0 if int(sc[-1]) else 4.0) * B * h * 64 * (4 * Sq + 4 * Sk)
+            byts = (2.0 if int(sc[-1]) else 4.0) * B * h * 64 * (4 * Sq + 4 * Sk) + (2 * B * h * Sq * Sk / 8.0 * (0.5 if causal else 1.0) if kb else 0.0)   # (both halves read the bits)
         elif name == "kk_attn_bwd_ws":                  # (... as kk_attn_bwd ..., ws_bytes): two kernels behind one entry point, event-timed together
             B, h, Sq, Sk = (int(x) for x in sc[:4])
             causal = int(sc[-7])
             key = "attn_bwd_dkv3s_kernel + attn_bwd_dqpass_kernel (dK, dV and the dS tiles, then dQ = dS.K)"
             flops = 4 * 2.0 * B * h * Sq * Sk * 64 * (0.5 if causal else 1.0)        # executes 5: S is the only recomputation left
             byts = 2.0 * B * h * 64 * (4 * Sq + 4 * Sk) + 2 * 2.0 * B * h * Sq * Sk * (0.5 if causal else 1.0)   # + dS written and read once
-        elif name in ("kk_attn_fwd", "kk_attn_bwd_dq", "kk_attn_bwd_dkv"):
+        elif name in ("kk_attn_fwd", "kk_attn_fwd_kb", "kk_attn_bwd_dq", "kk_attn_bwd_dkv"):
+            kb_fwd = name == "kk_attn_fwd_kb"                    # (the same kernels, also storing one bit per score)
+            name = "kk_attn_fwd" if kb_fwd else name
             B, h, Sq, Sk = (int(x) for x in sc[:4])
             off = 1 if name == "kk_attn_bwd_dq" else 0       # (..., causal, scale, site, p_drop, math, io_bf16[, ldo])
             causal = int(sc[-6 - off])
@@ -225,7 +229,7 @@ def kernel_table(records, math_bf16: bool):
                    "kk_attn_bwd_dq": "attn_bwd_dq3_kernel (dQ)" if v2 else "attn_bwd_dq_kernel (dQ, first generation)",
                    "kk_attn_bwd_dkv": "attn_bwd_dkv3_kernel (dK, dV)" if v2 else "attn_bwd_dkv_kernel (dK, dV, first generation)"}[name]
             flops = mm * 2.0 * B * h * Sq * Sk * 64 * (0.5 if causal else 1.0)
-            byts = (2.0 if int(sc[-1 - off]) else 4.0) * B * h * 64 * (2 * Sq + 2 * Sk)
+            byts = (2.0 if int(sc[-1 - off]) else 4.0) * B * h * 64 * (2 * Sq + 2 * Sk) + (B * h * Sq * Sk / 8.0 * (0.5 if causal else 1.0) if kb_fwd else 0.0)
         keys = [key]
         if name in ("kk_gemm", "kk_gemm_dgrad_delta"):
             keys.append(f"  shape ta={ta} tb={tb} M={M} N={N} K={K}")

@@ -27,12 +27,21 @@ def test_kernel_table_accounts_for_the_attention_backward_pair_and_its_delta_gem
         ("kk_gemm_qkv_headnorm", (B * S, 3, h, H, H, 1536, 1536, S, 3), 0.020),
         ("kk_gemm_qkv_headnorm", (512, 3, h, H, H, 1536, 1536, 64, 3), 0.010),
         ("kk_gemm_dgrad_glu", (B * S, 1536, H, H, 2003, 0.2), 0.027),
+        # round 5: the entry points with the stored dropout keep bits (the buffer is a tensor: same scalars as the plain ones)
+        ("kk_attn_bwd_kb", (B, h, S, S, 1536, 1536, 1536, H, 1536, 1536, 1536, 1, 0.125, 2003, 0.2, 1, 1), 0.030),
+        ("kk_attn_fwd_kb", (B, h, S, S, 1536, 1536, 1536, H, 1, 0.125, 2003, 0.2, 1, 1), 0.012),
+        ("kk_attn_bwd_kb", (B, h, 64, 64, 1536, 1536, 1536, H, 1536, 1536, 1536, 0, 0.125, 2003, 0.15, 1, 1), 0.013),      # one tile: no bits, the hashing kernel
     ]
     t = b.kernel_table(recs, True)
     pair = t["attn_bwd_pair3_kernel (dQ | dK, dV in one launch, two workgroups per CU)"]
     full = 4 * 2.0 * B * h * S * S * 64            # the backward of a 2-matmul forward is 4 matmuls; recomputation earns nothing
     assert pair["launches"] == 2 and abs(pair["flops"] - (0.5 * full + full)) < 1.0          # causal = lower triangle
     assert pair["bytes"] == 2 * 2.0 * B * h * 64 * 8 * S
+    pk = t["attn_bwd_pair3k_kernel (dQ | dK, dV in one launch, two workgroups per CU, stored dropout keep bits)"]
+    assert pk["launches"] == 1 and abs(pk["flops"] - 0.5 * full) < 1.0 and pk["bytes"] == 2.0 * B * h * 64 * 8 * S + 2 * B * h * S * S / 8 * 0.5
+    fk = t["attn_fwd3_q64_kernel (flash forward, 2 workgroups per CU, 64-query blocks x 4 key slots)"]
+    assert fk["launches"] == 1 and abs(fk["flops"] - 0.25 * full) < 1.0
+    assert t["attn_bwd_pair3_kernel (dQ | dK, dV in one launch, two workgroups per CU), one-tile sequences (text encoder)"]["launches"] == 1
     w8 = [k for k in t if k.startswith("gemm16_kernel_w8<false,true,3>")]
     assert len(w8) == 1 and t[w8[0]]["launches"] == 2 and t[w8[0]]["flops"] == 2 * 2.0 * B * S * H * H
     # the decoder's q|k|v projection and the linear2 dgrad + GLU' take the large-tile family (kk_gemm16x.hip) at 4096 rows ...
