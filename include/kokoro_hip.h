@@ -496,7 +496,7 @@ int kk_comm_all_gather(const void *send, void *recv, int64_t send_count, int dty
 int kk_cast_bf16_f32(const void *x, float *y, int64_t n, float scale, void *stream);
 /* The bf16 payload of a gradient bucket (reference: none — trainer.py has no data parallelism): dst[begin_i, end_i) =
  * cast(src[begin_i, end_i)) for i < n over two arrays of the same layout (the fp32 gradient arena and its bf16 twin), to_bf16 = 1
- * narrows, 0 widens (times scale).  ONE launch of at most 64 workgroups for all ranges: it runs on the communication stream beside
+ * narrows, 0 widens (times scale).  ONE launch of at most 128 thin workgroups for all ranges: it runs on the communication stream beside
  * the backward.  begin / end are HOST arrays of element offsets (begin % 4 == 0), read during the call. */
 int kk_cast_ranges(const void *src, void *dst, const int64_t *begin, const int64_t *end, int n, int to_bf16, float scale,
                    void *stream);

@@ -2348,6 +2348,9 @@ static int attn_bwd_impl(const float *Q, const float *K, const float *V, const f
         // (short blocks first only when both halves are resident at once — 2 workgroups per CU; with more rounds the longest-first
         //  order of the second generation is the faster one: 8 x 8 x 1024^2 causal 79 against 96 us)
         p.dkv.short_first = (causal && (attn_gen3() & 2) != 0 && (int64_t)kk_cdiv(Sq, 128) * B * heads <= g_attn_cus()) ? 1 : 0;
+#ifdef KK_TUNING_HOOKS
+        if (a.dbg & 256) { p.dq.DeltaOut = static_cast<float *>(g_attn_trace); p.dkv.DeltaOut = static_cast<float *>(g_attn_trace); }      // (stamp buffer: 8 rows x 64)
+#endif
         if (keep != nullptr && p_drop > 0.f && Sk > 128 && kk_attn_keep_bytes(B, heads, Sq, Sk) > 0) {      // (exactly the launches whose forward stored the bits)
             static thread_local bool raised3k = false;
             if (!raised3k) {

@@ -82,11 +82,11 @@ __global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const __bf16 *__rest
     }
 }
 
-// bf16 gradient payload: all ranges of a bucket narrowed (or widened back) by ONE launch of at most CAST_WGS workgroups.  The
+// bf16 gradient payload: all ranges of a bucket narrowed (or widened back) by ONE launch of at most CAST_WGS (128) workgroups.  The
 // exchange runs on the communication stream beside the backward's one-workgroup-per-CU launches; the per-range casts of round 2
 // (two launches per range, up to 8192 workgroups each) made the one-GPU step 42 % slower (profiles/r04_dp_exchange_one_gpu_ab.txt) —
 // a thin grid costs the chain next to nothing and still moves a 16 MB bucket in ~30 us, hidden beside the backward.
-constexpr int CAST_MAX = 48, CAST_WGS = 64, CAST_CHUNK = 4096;
+constexpr int CAST_MAX = 48, CAST_WGS = 128, CAST_CHUNK = 8192;
 struct CastRanges {
     int n, to_bf16;
     float scale;
@@ -100,21 +100,30 @@ __global__ __launch_bounds__(256) void cast_ranges_kernel(const void *__restrict
     for (int64_t c = blockIdx.x; c < total; c += gridDim.x) {
         while (c >= r.chunk0[i + 1]) ++i;                        // (chunks ascend per workgroup)
         const int64_t off = (c - r.chunk0[i]) * CAST_CHUNK, left = r.len[i] - off, e0 = r.begin[i] + off;
+        if (left >= CAST_CHUNK) {
+            // whole chunk: the four 16-byte loads of a thread are in flight together (a thin grid lives on bytes in flight per thread:
+            // one load per round trip made a 16 MB bucket take ~90 us on 64 workgroups, and the 26 casts of a step longer than its backward)
+            if (r.to_bf16) {
+                const float *sp = static_cast<const float *>(src) + e0 + threadIdx.x * 4;
+                float4 v[CAST_CHUNK / 1024];
 #pragma unroll
-        for (int k = 0; k < CAST_CHUNK / 1024; ++k) {
-            const int64_t j = (int64_t)k * 1024 + threadIdx.x * 4;
-            if (j + 4 <= left) {
-                if (r.to_bf16) stv4<__bf16>(static_cast<__bf16 *>(dst) + e0 + j, ld4(static_cast<const float *>(src) + e0 + j));
-                else {
-                    const float4 v = ldv4<__bf16>(static_cast<const __bf16 *>(src) + e0 + j);
-                    st4(static_cast<float *>(dst) + e0 + j, make_float4(v.x * r.scale, v.y * r.scale, v.z * r.scale, v.w * r.scale));
-                }
+                for (int k = 0; k < CAST_CHUNK / 1024; ++k) v[k] = ld4(sp + k * 1024);
+#pragma unroll
+                for (int k = 0; k < CAST_CHUNK / 1024; ++k) stv4<__bf16>(static_cast<__bf16 *>(dst) + e0 + k * 1024 + threadIdx.x * 4, v[k]);
             } else {
-                for (int64_t q = j; q < left && q < j + 4; ++q) {
-                    if (r.to_bf16) static_cast<__bf16 *>(dst)[e0 + q] = (__bf16) static_cast<const float *>(src)[e0 + q];
-                    else static_cast<float *>(dst)[e0 + q] = (float)static_cast<const __bf16 *>(src)[e0 + q] * r.scale;
-                }
+                const __bf16 *sp = static_cast<const __bf16 *>(src) + e0 + threadIdx.x * 4;
+                float4 v[CAST_CHUNK / 1024];
+#pragma unroll
+                for (int k = 0; k < CAST_CHUNK / 1024; ++k) v[k] = ldv4<__bf16>(sp + k * 1024);
+#pragma unroll
+                for (int k = 0; k < CAST_CHUNK / 1024; ++k)
+                    st4(static_cast<float *>(dst) + e0 + k * 1024 + threadIdx.x * 4, make_float4(v[k].x * r.scale, v[k].y * r.scale, v[k].z * r.scale, v[k].w * r.scale));
             }
+            continue;
+        }
+        for (int64_t q = threadIdx.x; q < left; q += 256) {      // ragged tail of a range
+            if (r.to_bf16) static_cast<__bf16 *>(dst)[e0 + q] = (__bf16) static_cast<const float *>(src)[e0 + q];
+            else static_cast<float *>(dst)[e0 + q] = (float)static_cast<const __bf16 *>(src)[e0 + q] * r.scale;
         }
     }
 }

@@ -130,6 +130,22 @@ def bucket_plan(dims) -> "List[Tuple[str, List[Tuple[int, int]]]]":
     return [(t, [tuple(x) for x in ranges[t]]) for t in order if t in ranges]
 
 
+def group_buckets(plan, n_groups: int) -> "List[List[str]]":
+    """The plan's buckets (issue order) as n_groups consecutive groups of about equal bytes; the last bucket ("tail": final only when
+    the whole backward is) closes the last group.  Deterministic in (plan, n_groups): every rank forms the same groups."""
+    tags = list(plan.keys()) if hasattr(plan, "keys") else [t for t, _ in plan]
+    size = {t: sum(e - b for b, e in (plan[t] if hasattr(plan, "keys") else dict(plan)[t])) for t in tags}
+    n_groups = min(n_groups, len(tags))
+    total, groups, acc = sum(size.values()), [[]], 0
+    for i, t in enumerate(tags):
+        groups[-1].append(t)
+        acc += size[t]
+        left, need = len(tags) - 1 - i, n_groups - len(groups)        # buckets left / groups still to open
+        if need > 0 and left >= need and (acc >= total * len(groups) / n_groups or left == need):
+            groups.append([])
+    return [g for g in groups if g]
+
+
 def _prod(shape) -> int:
     n = 1
     for v in shape:
@@ -145,15 +161,41 @@ class BucketedExchange:
     bound).  payload "bf16" narrows each range into a bf16 staging arena before the exchange and widens it back
     (half the xGMI bytes; sums of bf16-rounded gradients)."""
 
-    def __init__(self, dims, world: int, backend: str = "dist", payload: str = "f32", stream=None):
+    def __init__(self, dims, world: int, backend: str = "dist", payload: str = "f32", stream=None, groups: Optional[int] = None):
         self.plan = OrderedDict(bucket_plan(dims))
         self.world, self.backend, self.payload, self.stream = world, backend, payload, stream
         self.issued: List[str] = []
         self._tables: Dict[str, tuple] = {}
         self._g16: Optional[torch.Tensor] = None
+        # Exchange GROUPS: consecutive buckets of the plan that travel as ONE exchange, issued when the last of them is final.  On this
+        # runtime a kernel on the communication branch of the step's hipGraph costs the step +0.85 ms as soon as its group is closed by a
+        # bucket of the MAIN chain (a decoder layer) — whatever the kernel, one group or thirteen — and +0.08 ms when the group is closed
+        # on the side branch or by the tail (profiles/r05_dp_exchange_one_gpu_ab.txt; a one-rank fp32 all-reduce enqueues no kernel, which
+        # hid this until round 5).  Default: TWO groups of about equal bytes, {dec5..dec0, enc5} and {enc4..enc0, tail} at default dims
+        # (KK_DP_GROUPS = a count, or "dec3,enc0" = explicit closing buckets for probes).
+        g = groups if groups is not None else os.environ.get("KK_DP_GROUPS", "2")
+        if isinstance(g, str) and not g.strip().isdigit():      # "dec3,dec0": explicit groups, each closed by the named bucket (probes)
+            ends, self.groups = set(g.split(",")), [[]]
+            for t in self.plan:
+                self.groups[-1].append(t)
+                if t in ends and t != list(self.plan)[-1]:
+                    self.groups.append([])
+        else:
+            self.groups = group_buckets(self.plan, max(1, int(g)))
+        self._group_of = {t: gi for gi, tags in enumerate(self.groups) for t in tags}
+        self._seen: Dict[int, List[str]] = {}
 
     def begin_step(self) -> None:
         self.issued = []
+        self._seen = {}
+
+    def arrive(self, tag: str) -> Optional[List[str]]:
+        """Bucket `tag` is final.  Returns the tags of its group when the group is complete (exchange them now, in one call of
+        reduce_tags), else None.  Host-side bookkeeping in issue order: identical on every rank."""
+        gi = self._group_of[tag]
+        seen = self._seen.setdefault(gi, [])
+        seen.append(tag)
+        return list(self.groups[gi]) if len(seen) == len(self.groups[gi]) else None
 
     @property
     def capturable(self) -> bool:
@@ -172,10 +214,26 @@ class BucketedExchange:
         from . import lib as kk
         kk.call("kk_comm_loss_sync", acc, acc.numel(), max_dur)
 
-    def reduce(self, flat: torch.Tensor, tag: str) -> None:
+    def reduce_tags(self, flat: torch.Tensor, tags: List[str]) -> None:
+        """Exchange the buckets `tags` as ONE exchange (one RCCL group, one cast launch per direction)."""
+        key = "+".join(tags)
+        if key not in self.plan:
+            merged: List[List[int]] = []
+            for b, e in sorted(r for t in tags for r in self.plan[t]):
+                if merged and merged[-1][1] == b:
+                    merged[-1][1] = e
+                else:
+                    merged.append([b, e])
+            self.plan_merged = getattr(self, "plan_merged", {})
+            self.plan_merged[key] = [tuple(x) for x in merged]
+        self.issued.extend(tags[:-1])
+        self.reduce(flat, tags[-1], _ranges=self.plan_merged[key] if key not in self.plan else self.plan[key], _key=key)
+
+    def reduce(self, flat: torch.Tensor, tag: str, _ranges=None, _key=None) -> None:
         """Exchange bucket `tag` of the flat gradient arena in place (on the current stream)."""
-        ranges = self.plan[tag]
+        ranges = self.plan[tag] if _ranges is None else _ranges
         self.issued.append(tag)
+        tag = tag if _key is None else _key
         if self.backend == "dist":
             for b, e in ranges:
                 dist.all_reduce(flat[b:e], op=dist.ReduceOp.SUM)
@@ -196,6 +254,10 @@ class BucketedExchange:
             kk.call("kk_cast_ranges", self._g16, flat, beg, end, n, 0, 1.0)
         else:
             kk.call("kk_comm_reduce_ranges", flat, beg, end, n, 0)
+            if os.environ.get("KK_DP_PROBE_KERNEL"):           # probe: a one-rank fp32 exchange enqueues NO kernel; this stands in for a collective's
+                if getattr(self, "_probe_slot", None) is None:
+                    self._probe_slot = torch.zeros(2, dtype=torch.int64, device=flat.device)
+                kk.call("kk_timestamp", self._probe_slot)
 
     @classmethod
     def create(cls, dims, rank: int, world: int, device: torch.device, payload: Optional[str] = None) -> "BucketedExchange":

@@ -181,6 +181,7 @@ class KokoroEngine:
         # split, nothing between the backward graph and the optimizer graph).  With gradient accumulation only the
         # boundary micro-batch exchanges (_exchange_now).
         self.dp_comm = None
+        self._comm_events = {}
         self._exchange_now = True
         self.global_mel_length = None               # batch-max T over all ranks (adaptive loss scale / clip heuristics)
         # dropout / DropPath / SpecAugment: off = the parity configuration (reference with p = 0)
@@ -357,11 +358,24 @@ class KokoroEngine:
         c = self.dp_comm
         if c is None or not self._exchange_now:
             return
+        # buckets travel in GROUPS (dp.BucketedExchange.groups): the bucket's event is recorded where it becomes final; when the last
+        # bucket of a group has arrived the communication branch waits for all of the group's events and carries ONE exchange
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
-        c.stream.wait_event(ev)
+        self._comm_events.setdefault(c._group_of[tag], []).append(ev)
+        tags = c.arrive(tag)
+        if tags is None:
+            return
+        events = self._comm_events.pop(c._group_of[tag])
+        if os.environ.get("KK_DP_STREAM", "comm") == "main":   # run-mode choice (probes): on the chain itself, no extra branch
+            for e in events:
+                torch.cuda.current_stream().wait_event(e)
+            c.reduce_tags(self.arena.g, tags)
+            return
+        for e in events:
+            c.stream.wait_event(e)
         with torch.cuda.stream(c.stream):
-            c.reduce(self.arena.g, tag)
+            c.reduce_tags(self.arena.g, tags)
 
     def _comm_join(self) -> None:
         c = self.dp_comm
@@ -1182,6 +1196,7 @@ class KokoroEngine:
             self._reduce_lists[ns] = []
         if self.dp_comm is not None and self._exchange_now:
             self.dp_comm.begin_step()
+            self._comm_events = {}
         dmel, ddur = self._buf("g.mel", B, T, M), self._buf("g.dur", B, Pn)
         dstop, dpitch, denergy = self._buf("g.stop", B, T), self._buf("g.pitch", B, T), self._buf("g.energy", B, T)
         kk.call("kk_losses_bwd", *largs, self.loss_coef, dmel, ddur, dstop, dpitch, denergy)

@@ -205,8 +205,23 @@ def _bucket_worker(rank, world, port, q):
     if rank == 1:
         other[total // 2] += 1e-3
     diverged_seen = not dp.replicas_in_step(other)
+    # round 5: the buckets travel in GROUPS (one exchange per group, issued when its last bucket is final) — the engine's arrival
+    # order may differ from the plan's (encoder buckets come from the side branch): any order must give the sum of the whole arena
+    grouped_ok = True
+    for n_groups, order in ((2, list(ex.plan)), (3, ["enc1", "dec1", "enc0", "dec0", "tail"]), (1, list(ex.plan)[::-1]), (13, list(ex.plan))):
+        g2 = torch.Generator().manual_seed(100 + rank)
+        f2 = torch.randn(total, generator=g2)
+        ex2 = dp.BucketedExchange(dims, world, backend="dist", groups=n_groups)
+        ex2.begin_step()
+        calls = 0
+        for tag in order:
+            tags = ex2.arrive(tag)
+            if tags is not None:
+                ex2.reduce_tags(f2, tags)
+                calls += 1
+        grouped_ok = grouped_ok and bool(torch.equal(f2, whole)) and calls == min(n_groups, len(ex.plan)) and sorted(ex2.issued) == sorted(ex.plan)
     if rank == 0:
-        q.put((bool(torch.equal(flat, whole)), list(ex.issued), in_step, diverged_seen))
+        q.put((bool(torch.equal(flat, whole)) and grouped_ok, list(ex.issued), in_step, diverged_seen))
     dist.destroy_process_group()
 
 

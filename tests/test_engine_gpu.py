@@ -763,13 +763,13 @@ def test_in_graph_bucket_exchange_over_rccl_one_rank(eng_mod, golden_dir):
         e.dp_comm = comm
         log = []
         if comm is not None:
-            orig = comm.reduce
-            comm.reduce = lambda flat, tag: (log.append(tag), orig(flat, tag))[1]
+            orig = comm.reduce_tags                          # (one exchange per GROUP of buckets: dp.BucketedExchange.groups)
+            comm.reduce_tags = lambda flat, tags: (log.extend(tags), orig(flat, tags))[1]
         for it in range(4 * G):
             (e.train_step_graphed if graphed else e.train_step)(batches[it % 2])
         torch.cuda.synchronize()
         if comm is not None:
-            comm.reduce = orig
+            comm.reduce_tags = orig
         assert e.opt_stats()["attempt"] == 4 and e.opt_stats()["skipped"] == 0
         return e.arena.p.clone(), log
     from kokoro_ruslan_amd.spec import ModelDims
