@@ -367,11 +367,6 @@ class KokoroEngine:
         if tags is None:
             return
         events = self._comm_events.pop(c._group_of[tag])
-        if os.environ.get("KK_DP_STREAM", "comm") == "main":   # run-mode choice (probes): on the chain itself, no extra branch
-            for e in events:
-                torch.cuda.current_stream().wait_event(e)
-            c.reduce_tags(self.arena.g, tags)
-            return
         for e in events:
             c.stream.wait_event(e)
         with torch.cuda.stream(c.stream):
