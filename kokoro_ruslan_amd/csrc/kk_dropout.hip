@@ -313,9 +313,12 @@ void launch_subin(const SubInArgs &a, int blocks, hipStream_t s) {
     const dim3 grid(blocks);
     const int nv = kk_cdiv(a.H, 256);
 #define KK_SIB(NV, WV, RIF) hipLaunchKernelGGL((sublayer_in_bwd_kernel<TN, TY, NV, WV, RIF>), grid, dim3(64 * WV), (size_t)WV * 4 * a.H * sizeof(float), s, a)
-    // RIF = 2 (both rows of a wave in flight at once, 213 registers) was measured on one box, interleaved, against RIF = 1:
-    // 4.165 vs 4.145 ms per step — the shorter, burstier launch costs the chains around it more than it saves
-    static const int rif2 = kk_tune_env("KK_SIB_RIF", 1);
+    // RIF = 2 (both rows of a wave in flight at once, 213 registers): when a wave walks exactly two rows the launch becomes ONE round trip
+    // to HBM.  Round 3 measured it slower in-step (4.165 vs 4.145 ms); re-measured in round 5 (interleaved, tools flavour): 8 x 512 (4096
+    // rows, two per wave) 3.794 / 3.776 -> 3.746 / 3.759 ms, 8 x 1024 (four per wave: two trips either way, more registers) 6.217 -> 6.268 ms.
+    // Taken where it is one trip; KK_SIB_RIF (tools) forces 1 or 2.
+    static const int rif_env = kk_tune_env("KK_SIB_RIF", 0);
+    const int rif2 = rif_env ? rif_env : (a.rows <= (int64_t)2 * blocks * 8 ? 2 : 1);
     if (nv <= 1) { if (rif2 == 2) KK_SIB(1, 8, 2); else KK_SIB(1, 8, 1); }
     else if (nv <= 2) { if (rif2 == 2) KK_SIB(2, 8, 2); else KK_SIB(2, 8, 1); }
     else if (nv <= 4) KK_SIB(4, 4, 1);
