@@ -313,6 +313,19 @@ int kk_sublayer_out_fwd(const float *y, int y_bf16, const float *gain, float *rs
                         const float *ln_gamma, const float *ln_beta, float *n, int n_bf16, float *mean, float *rstd,
                         int64_t rows, int H, int S, const uint32_t *seed, uint32_t site1, float p1, uint32_t site2,
                         float p2, uint32_t site_dp, float dp_rate, void *stream);
+/* y = x.W^T + bias (x bf16 [rows, K] with pitch ldx, W bf16 [512, K]: the attention output projection transformers.py:131-136 /
+ * :437, or the feed-forward's linear2 :105-111) AND kk_sublayer_out_fwd of that y in ONE launch: a workgroup owns 32 whole rows, the
+ * [rows, 512] projection never reaches HBM.  y_round != 0: y is rounded to bf16 before the tail (what kk_gemm with a bf16 C followed
+ * by kk_sublayer_out_fwd(y_bf16 = 1) computes: the results are bit-identical to those two launches); y_out (optional, bf16
+ * [rows, 512]): y itself, for a backward that needs it (the RMSNorm of the feed-forward).  The other arguments are
+ * kk_sublayer_out_fwd's.  H must be 512 and K a multiple of 64: ask kk_linear_tail_supported() first. */
+int kk_linear_tail_supported(int64_t rows, int H, int K);
+int kk_linear_tail_pays(int64_t rows, int H, int K);   /* 1 where the one launch measured faster than the two (K = 512, whole rounds of workgroups) */
+int kk_linear_tail_fwd(const void *x, int64_t ldx, const void *W, const float *bias, int K, void *y_out, int y_round,
+                       const float *gain, float *rstd_f, const float *res, float *x_out, const float *ln_gamma,
+                       const float *ln_beta, float *n, int n_bf16, float *mean, float *rstd, int64_t rows, int H, int S,
+                       const uint32_t *seed, uint32_t site1, float p1, uint32_t site2, float p2, uint32_t site_dp,
+                       float dp_rate, void *stream);
 /* Backward of kk_sublayer_out_fwd, fused with what follows it in the backward pass: dres (+)= LayerNorm_bwd(dn); dz = dres *
  * masks; dy = RMSNorm_bwd(dz) (gain != NULL, FFN) or dz (attention output projection).  The column reductions go to
  * partials[kk_sublayer_in_bwd_blocks(rows)][4][H] = (dgamma | dbeta | column sums of dy | dgain) for kk_partials_reduce

@@ -161,6 +161,309 @@ void launch_subout(const SubOutArgs &a, hipStream_t s) {
     else hipLaunchKernelGGL((sublayer_out_fwd_kernel<TY, TN, 8>), grid, blk, 0, s, a);
 }
 
+// ---- a Linear with H = 512 outputs AND the sub-layer tail behind it as ONE launch (row ownership) -------------------------------
+//   y = x.W^T + b  (bf16 x bf16 -> fp32, [rounded to bf16 as the two-launch path stores it]);  then exactly sublayer_out_fwd_kernel.
+// Replaces kk_gemm + kk_sublayer_out_fwd behind an attention output projection (K = 512) or a feed-forward's linear2 (K = F): the
+// [rows, 512] projection never exists in HBM (-2 KB per row of traffic, one launch and its ~3 us of dependent-launch gap less).
+//
+// A LayerNorm needs whole rows, so a workgroup owns 32 rows x all 512 columns and the WHOLE weight matrix streams through every CU:
+// 512 K bytes per CU out of the XCD's L2 (it is the same matrix for every workgroup: L2 hits) — that stream is the launch time, so
+// the loop is built around keeping it busy, not around MFMA duty:
+//   * wave w owns output columns [64 w, 64 w + 64): its 64 weight rows are read by nobody else, so each wave runs a PRIVATE ring of
+//     two 8 KB slots (64 rows x 64 k) with its own DMA issue and counted vmcnt — no workgroup barrier anywhere in the k-loop.  A slot
+//     is refilled as soon as the wave's own fragment reads of it have returned (two k-tiles of every wave in flight: 64-128 KB per CU);
+//   * the 32-row x panel (shared by the eight waves) sits in two 16 KB buffers of 256 k each; for K <= 512 it is resident and the
+//     loop has no barrier at all, beyond that the waves meet once per 256 k;
+//   * everything the tail reads from HBM (residual rows, bias, gains) is fetched into registers BEFORE the loop.
+// LDS: 32 KB (x) + 8 x 16 KB (weight rings) = the CU's 160 KB; the epilogue's fp32 tile [32][512] overlays it.
+// Same accumulation order as the 128x64 GEMM tile (32x32x16 MFMAs, ascending k) and the tail's own arithmetic: bit-identical to the
+// two launches it replaces (tests/test_kernels_gpu.py::test_linear_tail_fwd_matches_two_launches).
+#define KK_LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
+constexpr int RT_BK = 64, RT_BM = 32, RT_H = 512, RT_WAVES = 8;
+constexpr int RT_SLOT = 64 * RT_BK * 2;                        // a wave's 64 weight rows x 64 k
+constexpr int RT_ACH = 4;                                      // k-tiles per x chunk
+constexpr int RT_A_KT = RT_BM * RT_BK * 2;                     // 4 KB: one k-tile of the x panel
+constexpr int RT_A_CHUNK = RT_ACH * RT_A_KT;
+constexpr int RT_LDS = 2 * RT_A_CHUNK + RT_WAVES * 2 * RT_SLOT;
+constexpr int RT_TP = 520;                                     // floats per row of the epilogue tile (4 rows apart = 32 banks apart)
+static_assert(RT_LDS == 163840 && RT_BM * RT_TP * 4 <= RT_LDS, "the fused Linear + tail launch takes the CU's whole LDS");
+
+struct RowTailArgs {
+    const void *x, *W;             // bf16 [rows, K] (pitch ldx), bf16 [512, K]
+    int64_t ldx;
+    uint32_t x_bytes, w_bytes;
+    int K, y_round, rot;
+    uint64_t *trace;               // tools: [8 waves][8] wall-clock stamps of workgroup 0
+    const float *bias;
+    void *y_out;                   // optional (bf16): y as the backward wants it (the feed-forward's f2)
+    SubOutArgs t;                  // the tail's own arguments (y unused)
+};
+
+template <int N> __device__ __forceinline__ void rt_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename TN>
+__global__ __launch_bounds__(512) void linear_tail_fwd_kernel(RowTailArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[RT_LDS];
+    const SubOutArgs &t = a.t;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * RT_BM;
+    const int nk = a.K / RT_BK, nch = (nk + RT_ACH - 1) / RT_ACH;
+    constexpr int H = RT_H;
+#ifdef KK_TUNING_HOOKS
+    uint64_t *tr = (a.trace && blockIdx.x == 0 && lane == 0) ? a.trace + wave * 8 : nullptr;
+#define RT_STAMP() do { if (tr) *tr++ = wall_clock64(); } while (0)
+#else
+#define RT_STAMP() do { } while (0)
+#endif
+    RT_STAMP();
+
+    // ---- the tail's operands: this wave finishes rows m0 + 4 wave + {0..3}, a lane columns 4 lane + {0, 256} ----
+    float4 rres[4][2], bia[2], gg[2], lg[2], lb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = lane * 4 + 256 * i;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        bia[i] = a.bias ? ld4(a.bias + c) : z;
+        gg[i] = t.gain ? ld4(t.gain + c) : z;
+        lg[i] = t.ln_gamma ? ld4(t.ln_gamma + c) : z;
+        lb[i] = t.ln_gamma ? ld4(t.ln_beta + c) : z;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = m0 + 4 * wave + r;
+            rres[r][i] = row < t.rows ? ld4(t.res + row * H + c) : z;
+        }
+    }
+
+    // ---- DMA plumbing ----
+    const __amdgpu_buffer_rsrc_t RX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.x), 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t RW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.W), 0, (int)a.w_bytes, 0x00020000);
+    const int c8 = lane & 7, r8 = lane >> 3;
+    // x: wave w moves k-tile (w >> 1) of a chunk, rows 16 (w & 1) + 8 e + r8
+    uint32_t voa[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int row = 16 * (wave & 1) + 8 * e + r8;
+        voa[e] = (uint32_t)(((m0 + row) * a.ldx + (wave >> 1) * RT_BK + ((c8 ^ ((row >> 1) & 7)) << 3)) * 2);
+    }
+    char *adst = smem + (wave >> 1) * RT_A_KT + (wave & 1) * 2048;
+    auto issue_x = [&](int ch) {
+        const uint32_t so = (uint32_t)ch * (RT_ACH * RT_BK * 2);
+        char *d = adst + (ch & 1) * RT_A_CHUNK;
+        if (ch * RT_ACH + (wave >> 1) < nk) {                   // (wave-uniform; a K that is not a multiple of 256 has a short last chunk)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(RX, KK_LDS_PTR(d), 16, voa[0], so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(RX, KK_LDS_PTR(d + 1024), 16, voa[1], so, 0, 0);
+        } else {                                                // keep the wave's count of outstanding operations uniform
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(RX, KK_LDS_PTR(d), 16, 0xFFFFFFF0u, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(RX, KK_LDS_PTR(d + 1024), 16, 0xFFFFFFF0u, 0, 0, 0);
+        }
+    };
+    // W: this wave's rows 64 w + 8 j + r8, j = 0..7
+    uint32_t vob[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row = 8 * j + r8;
+        vob[j] = (uint32_t)(((int64_t)(64 * wave + row) * a.K + ((c8 ^ ((row >> 1) & 7)) << 3)) * 2);
+    }
+    char *ring = smem + 2 * RT_A_CHUNK + wave * (2 * RT_SLOT);
+    // resident x panel (K <= 512): the k order is a free choice per wave.  Rotated by workgroup and wave, the CUs of an XCD are NOT all
+    // asking the L2 for the same k-tile of the weight rows (lines 2 K bytes apart: a handful of channels) at the same moment.
+    const int rot = (a.rot && nch <= 2) ? (int)((blockIdx.x * 3u + (uint32_t)wave) % (uint32_t)nk) : 0;
+    auto ktile = [&](int kt) { const int k = kt + rot; return k >= nk ? k - nk : k; };
+    auto issue_w = [&](int kt) {
+        const uint32_t so = (uint32_t)ktile(kt) * (RT_BK * 2);
+        char *d = ring + (kt & 1) * RT_SLOT;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(RW, KK_LDS_PTR(d + j * 1024), 16, vob[j], so, 0, 0);
+    };
+    // fragment reads (k-contiguous images, 128-byte rows, chunk ^ (row >> 1) & 7)
+    const uint32_t fbase = (uint32_t)(l31 * (RT_BK * 2));
+    uint32_t fx[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fx[ks] = fbase + (uint32_t)(((2 * ks + half) ^ ((l31 >> 1) & 7)) << 4);
+    const uint32_t a_lds = (uint32_t)(uintptr_t)KK_LDS_PTR(smem), w_lds = (uint32_t)(uintptr_t)KK_LDS_PTR(ring);
+
+    issue_x(0);
+    if (nch > 1) issue_x(1);
+    issue_w(0);
+    if (nk > 1) issue_w(1);
+    if (nk > 1) rt_wait_vm<8>(); else rt_wait_vm<0>();
+    RT_STAMP();
+    __builtin_amdgcn_s_barrier();                               // the x chunks of every wave have landed
+    asm volatile("" ::: "memory");
+    RT_STAMP();
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    bool x_issued = false;                                      // an x chunk was issued in the previous iteration (2 operations in the FIFO)
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt > 0) {                                           // this wave's tile kt has landed: only younger operations may be outstanding
+            const bool more = kt + 1 < nk;
+            if (x_issued) { if (more) rt_wait_vm<10>(); else rt_wait_vm<2>(); }
+            else { if (more) rt_wait_vm<8>(); else rt_wait_vm<0>(); }
+        }
+        x_issued = false;
+        const int ch = kt / RT_ACH;
+        if (kt > 0 && kt % RT_ACH == 0 && (ch >= 2 || ch + 1 < nch)) {
+            __builtin_amdgcn_s_barrier();                       // chunk ch has landed for everyone; everyone is done with chunk ch - 1
+            asm volatile("" ::: "memory");
+            if (ch + 1 < nch) { issue_x(ch + 1); x_issued = true; }
+        }
+        const int kx = ktile(kt);
+        const uint32_t ai = a_lds + (uint32_t)(((kx / RT_ACH) & 1) * RT_A_CHUNK + (kx % RT_ACH) * RT_A_KT);
+        const uint32_t bi = w_lds + (uint32_t)((kt & 1) * RT_SLOT);
+        bf16x8 af[4], bf[4][2];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            asm volatile("ds_read_b128 %0, %1" : "=v"(af[ks]) : "v"(ai + fx[ks]));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(bf[ks][0]) : "v"(bi + fx[ks]));
+            asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(bf[ks][1]) : "v"(bi + fx[ks]));
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks == 0) asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");
+            else if (ks == 1) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            else if (ks == 2) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+            else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (kt + 2 < nk) issue_w(kt + 2);               // the slot is free: every read of it has returned
+            }
+            asm volatile("" : "+v"(af[ks]), "+v"(bf[ks][0]), "+v"(bf[ks][1]));
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], bf[ks][0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], bf[ks][1], acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- the tile goes through LDS: accumulator layout (a lane = one column) -> a wave per row ----
+    RT_STAMP();
+    __builtin_amdgcn_s_barrier();                               // every wave is through with the panels
+    asm volatile("" ::: "memory");
+    float *tile = reinterpret_cast<float *>(smem);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tile[frag_row(r, half) * RT_TP + 64 * wave + 32 * j + l31] = acc[j][r];
+    __syncthreads();
+    RT_STAMP();
+
+    // The wave's four rows side by side: every step below is four independent chains (a row is three dependent wave reductions —
+    // one after the other they were 6 us of this launch, 1.5 us per row at two waves per SIMD).  Rows past the end compute on zeros
+    // and store nothing.
+    const uint32_t seed = *t.d.seed;
+    const uint32_t t1 = kk_drop_threshold(t.d.p1), t2 = kk_drop_threshold(t.d.p2);
+    const float k1 = t.d.p1 > 0.f ? 1.f / (1.f - t.d.p1) : 1.f, k2 = t.d.p2 > 0.f ? 1.f / (1.f - t.d.p2) : 1.f;
+    auto wave_sum4 = [](float (&x)[4]) {                        // wave_sum of each (same order of additions), interleaved
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            float y[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = __shfl_xor(x[r], o, 64);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] += y[r];
+        }
+    };
+    const int64_t row0 = m0 + 4 * wave;
+    float4 v[4][2];
+    float q[4], rs[4], dp[4], sm[4], mean[4], qq[4], rstd[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t row = row0 + r;
+        q[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = lane * 4 + 256 * i;
+            const float4 s4 = ld4(tile + (4 * wave + r) * RT_TP + c);
+            float o[4] = {s4.x + bia[i].x, s4.y + bia[i].y, s4.z + bia[i].z, s4.w + bia[i].w};
+            if (a.y_round) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (float)(__bf16)o[e];
+            }
+            v[r][i] = make_float4(o[0], o[1], o[2], o[3]);
+            if (a.y_out && row < t.rows) stv4_out<__bf16>(static_cast<__bf16 *>(a.y_out) + row * H + c, v[r][i], t.wt);
+            q[r] += o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
+        }
+        rs[r] = 1.f;
+        dp[r] = row_scale(t.d, seed, row);
+    }
+    if (t.gain) {
+        wave_sum4(q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            rs[r] = 1.f / sqrtf(q[r] / (float)t.H + FLT_EPSILON);
+            if (lane == 0 && row0 + r < t.rows) t.rstd_f[row0 + r] = rs[r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t row = row0 + r;
+        sm[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = lane * 4 + 256 * i;
+            float o[4] = {v[r][i].x, v[r][i].y, v[r][i].z, v[r][i].w};
+            if (t.gain) {
+                const float4 g = gg[i];
+                o[0] = o[0] * rs[r] * g.x; o[1] = o[1] * rs[r] * g.y; o[2] = o[2] * rs[r] * g.z; o[3] = o[3] * rs[r] * g.w;
+            }
+            const float rr[4] = {rres[r][i].x, rres[r][i].y, rres[r][i].z, rres[r][i].w};
+            float m1[4], m2[4];
+            kk_drop_mul4(seed, t.d.site1, (uint64_t)row * H + c, t1, k1, m1);
+            kk_drop_mul4(seed, t.d.site2, (uint64_t)row * H + c, t2, k2, m2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = o[e] * (dp[r] * m1[e] * m2[e]) + rr[e];
+            v[r][i] = make_float4(o[0], o[1], o[2], o[3]);
+            if (row < t.rows) st4_out(t.x_out + row * H + c, v[r][i], t.wt);
+            sm[r] += o[0] + o[1] + o[2] + o[3];
+        }
+    }
+    if (t.ln_gamma) {
+        wave_sum4(sm);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            mean[r] = sm[r] / (float)t.H;
+            qq[r] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float e0 = v[r][i].x - mean[r], e1 = v[r][i].y - mean[r], e2 = v[r][i].z - mean[r], e3 = v[r][i].w - mean[r];
+                qq[r] += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+            }
+        }
+        wave_sum4(qq);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + r;
+            rstd[r] = 1.f / sqrtf(qq[r] / (float)t.H + 1e-5f);
+            if (row >= t.rows) continue;
+            TN *nr = static_cast<TN *>(t.n) + row * H;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = lane * 4 + 256 * i;
+                const float4 g = lg[i], b = lb[i];
+                stv4_out<TN>(nr + c, make_float4((v[r][i].x - mean[r]) * rstd[r] * g.x + b.x, (v[r][i].y - mean[r]) * rstd[r] * g.y + b.y,
+                                             (v[r][i].z - mean[r]) * rstd[r] * g.z + b.z, (v[r][i].w - mean[r]) * rstd[r] * g.w + b.w), t.wt);
+            }
+            if (lane == 0) {
+                t.mean[row] = mean[r];
+                t.rstd[row] = rstd[r];
+            }
+        }
+    }
+    RT_STAMP();
+#ifdef KK_TUNING_HOOKS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RT_STAMP();
+#endif
+#undef RT_STAMP
+}
+#ifdef KK_TUNING_HOOKS
+uint64_t *g_rt_trace = nullptr;
+#endif
+
 // ---- fused sub-layer tail (backward) ------------------------------------------------------------------------------
 // The exact reverse of sublayer_out_fwd_kernel, one wave per row:
 //   g   = (accumulate ? dres : 0) + LayerNorm_backward(dn; x_out, gamma, mean, rstd)      -> dres (gradient of the stream)
@@ -402,6 +705,61 @@ extern "C" int kk_sublayer_out_fwd(const float *y, int y_bf16, const float *gain
     if (y_bf16) { if (n_bf16) launch_subout<__bf16, __bf16>(a, s); else launch_subout<__bf16, float>(a, s); }
     else { if (n_bf16) launch_subout<float, __bf16>(a, s); else launch_subout<float, float>(a, s); }
     KK_LAUNCH_CHECK("kk_sublayer_out_fwd");
+    return 0;
+}
+
+#ifdef KK_TUNING_HOOKS
+extern "C" int kk_linear_tail_trace(void *buf) { g_rt_trace = static_cast<uint64_t *>(buf); return 0; }      // tools: 64 uint64 stamps of workgroup 0
+#endif
+extern "C" int kk_linear_tail_supported(int64_t rows, int H, int K) {
+    static const int on = kk_tune_env("KK_LINEAR_TAIL", 1);
+    return on && rows > 0 && rows <= (int64_t)1 << 21 && H == RT_H && K >= RT_BK && K % RT_BK == 0 && K <= 8192;
+}
+
+// Does the one-launch form beat kk_gemm + kk_sublayer_out_fwd at this shape?  Measured on MI355X (tools/probes/linear_tail_bench.py,
+// dependent chains in a replayed graph; profiles/r05_linear_tail_bench.txt): a round of <= one workgroup per CU takes ~18.5 us at
+// K = 512 whatever its row count (the weight matrix streams through every CU at ~54 B/clk, then every CU writes its rows at once),
+// the two launches 4.5 us + 2.44 us per 1000 rows; K >= 1536 streams 3-4 x the bytes per CU and always loses (x 1.15 - 1.45).
+extern "C" int kk_linear_tail_pays(int64_t rows, int H, int K) {
+    if (!kk_linear_tail_supported(rows, H, K) || K != 512) return 0;
+    int dev = 0, cus = 0;
+    static const int ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) ? cus : 256;
+    const int64_t rounds = (kk_cdiv(rows, RT_BM) + ncu - 1) / ncu;
+    return 18.5 * (double)rounds + 0.5 < 4.5 + 2.44e-3 * (double)rows;
+}
+
+extern "C" int kk_linear_tail_fwd(const void *x, int64_t ldx, const void *W, const float *bias, int K, void *y_out, int y_round,
+                                  const float *gain, float *rstd_f, const float *res, float *x_out, const float *ln_gamma,
+                                  const float *ln_beta, float *n, int n_bf16, float *mean, float *rstd, int64_t rows, int H, int S,
+                                  const uint32_t *seed, uint32_t site1, float p1, uint32_t site2, float p2, uint32_t site_dp,
+                                  float dp_rate, void *stream) {
+    KK_REQUIRE(kk_linear_tail_supported(rows, H, K), "kk_linear_tail_fwd: unsupported shape rows=%lld H=%d K=%d (H = 512, K a multiple of 64)",
+               (long long)rows, H, K);
+    KK_REQUIRE(x && W && res && x_out && seed && S > 0 && ldx >= K && ldx % 8 == 0, "kk_linear_tail_fwd: bad args");
+    KK_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0, "kk_linear_tail_fwd: operands must be 16-byte aligned");
+    KK_REQUIRE(!gain || rstd_f, "kk_linear_tail_fwd: the RMSNorm needs rstd_f");
+    KK_REQUIRE(!ln_gamma || (ln_beta && n && mean && rstd), "kk_linear_tail_fwd: the LayerNorm needs beta, n, mean, rstd");
+    KK_REQUIRE(p1 >= 0.f && p1 < 1.f && p2 >= 0.f && p2 < 1.f && dp_rate >= 0.f && dp_rate < 1.f, "kk_linear_tail_fwd: probabilities must be in [0,1)");
+    const int64_t xb = ((rows - 1) * ldx + K) * 2;
+    KK_REQUIRE(xb < ((int64_t)1 << 31), "kk_linear_tail_fwd: x spans more than 2 GB");
+    RowTailArgs a;
+    a.x = x; a.W = W; a.ldx = ldx; a.x_bytes = (uint32_t)xb; a.w_bytes = (uint32_t)((int64_t)RT_H * K * 2); a.K = K; a.y_round = y_round;
+    static const int rot = kk_tune_env("KK_RT_ROT", 0);
+    a.rot = rot;
+    a.trace = nullptr;
+#ifdef KK_TUNING_HOOKS
+    a.trace = g_rt_trace;
+#endif
+    a.bias = bias; a.y_out = y_out;
+    SubOutArgs &t = a.t;
+    t.y = nullptr; t.gain = gain; t.rstd_f = rstd_f; t.res = res; t.x_out = x_out; t.ln_gamma = ln_gamma; t.ln_beta = ln_beta; t.n = n;
+    t.mean = mean; t.rstd = rstd; t.rows = rows; t.H = H; t.wt = kk_write_through(rows);
+    t.d = {seed, site1, site2, site_dp, p1, p2, dp_rate, S};
+    const dim3 grid(kk_cdiv(rows, RT_BM));
+    kk_note_kernel("linear_tail_fwd");
+    if (n_bf16) hipLaunchKernelGGL((linear_tail_fwd_kernel<__bf16>), grid, dim3(512), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((linear_tail_fwd_kernel<float>), grid, dim3(512), 0, (hipStream_t)stream, a);
+    KK_LAUNCH_CHECK("kk_linear_tail_fwd");
     return 0;
 }
 

@@ -216,6 +216,9 @@ class KokoroEngine:
         self.attn_keep_bits = True
         self.attn_pair_min_seq = 32                # (one-tile sequences included: the text encoder's 33..64 phonemes; 64 = the round-2 dispatch)
         self.attn_proj_bf16 = True                 # decoder w_o output stored as bf16 (bf16 mode)
+        # the decoder's attention output projection and the sub-layer tail behind it as ONE row-owner launch (kk_linear_tail_fwd) where
+        # the library measured it faster (kk_linear_tail_pays: whole rounds of workgroups at >= ~6 K rows); bit-identical results
+        self.fuse_linear_tail = True
         # The zero-fill at the start of an accumulation cycle skips what the cycle's first grouped weight-gradient launches
         # overwrite (89 % of the arena at default dims; the fill runs beside the latency-bound encoder launch: 20 us of the step).
         # Which tensors those are is RECORDED from the launches of a step (per precision mode), never assumed, and a step that
@@ -663,6 +666,16 @@ class KokoroEngine:
         # launch hands the tile over in fp32, and the per-kernel path must match it)
         Wo = self._W(prefix + ".w_o.weight")
         p16 = self.attn_proj_bf16 and i16 and key.startswith("dec")
+        if (p16 and self.fuse_linear_tail and _b16(Wo) and self.math == kk.KK_MATH_BF16 and kk.load().kk_linear_tail_pays(Nq, H, H)):
+            # projection + tail as ONE row-owner launch (kk_linear_tail_fwd: same bits as the two launches below)
+            n = mean = rstd = g = b = None
+            if next_ln is not None:
+                lkey, lprefix, ldt = next_ln
+                n, mean, rstd = self._buf(lkey + ".y", Nq, H, dtype=ldt), self._buf(lkey + ".mean", Nq), self._buf(lkey + ".rstd", Nq)
+                g, b = P[lprefix + ".weight"], P[lprefix + ".bias"]
+            kk.call("kk_linear_tail_fwd", ctx, ctx.stride(0), Wo, P[prefix + ".w_o.bias"], H, None, 1, None, None, x_res, x_out, g, b, n,
+                    _b16(n), mean, rstd, Nq, H, Sq, self.rng, site, p, site + 1, 0.0, site + 2, dpr)
+            return n
         proj = self._buf("tmp.attn_proj16" if p16 else "tmp.attn_proj", Nq, H, dtype=dt if p16 else torch.float32)
         self._linear(ctx, Wo, P[prefix + ".w_o.bias"], proj)
         return self._sublayer_tail(proj, x_res, x_out, Sq, site, p, dpr, 0.0, None, None, next_ln)   # (p = 0: masks are all ones)

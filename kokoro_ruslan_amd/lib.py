@@ -187,6 +187,9 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_bucket_embed_add_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "kk_dropout_fwd": [_P, _P, _L, _P, _L, _I, _I, _P, _U, _F, _U, _F, _U, _F, _P],
     "kk_sublayer_out_fwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _I, _I, _P, _U, _F, _U, _F, _U, _F, _P],
+    "kk_linear_tail_supported": [_L, _I, _I],
+    "kk_linear_tail_pays": [_L, _I, _I],
+    "kk_linear_tail_fwd": [_P, _L, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _I, _I, _P, _U, _F, _U, _F, _U, _F, _P],
     "kk_sublayer_in_bwd": [_P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _L, _I, _I, _P, _U, _F, _U, _F, _U, _F, _P],
     "kk_sublayer_in_bwd_blocks": [_L],
     "kk_encoder_stack_supported": [_I, _I, _I, _I, _I, _I],

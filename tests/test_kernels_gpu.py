@@ -963,6 +963,60 @@ def test_sublayer_tail_equals_separate_kernels(kk, ffn, ln, bf):
         close(nb, na, 2e-2 if bf else 1e-5, 1e-2 if bf else 1e-5, "fused tail: LN output")
 
 
+@pytest.mark.parametrize("rows,K,ffn,ln,nbf", [(4096, 512, 0, 1, 1), (203, 512, 0, 1, 1), (8192, 512, 0, 1, 1), (1333, 1536, 1, 1, 1),
+                                               (4096, 2048, 1, 0, 0), (77, 64, 0, 1, 0), (2100, 576, 1, 1, 1), (4096, 1280, 0, 0, 1)])
+def test_linear_tail_fwd_matches_two_launches(kk, rows, K, ffn, ln, nbf):
+    """kk_linear_tail_fwd (row-owner Linear + sub-layer tail in one launch) against (a) the two launches it replaces — kk_gemm with a
+    bf16 C, then kk_sublayer_out_fwd: BIT-identical (same MFMA shape and k order, same tail arithmetic, same masks) — and (b) a
+    float64 evaluation of y = x.W^T + b from the same bf16 operands.  K = 512: resident x panel, no barrier in the k-loop; 1536 /
+    2048 / 1280: the chunked panel with its per-256-k meetings; 576 / 64: a short last chunk / a single k-tile; ragged rows."""
+    g = torch.Generator().manual_seed(rows + K)
+    H, S = 512, 29
+    x = dev(torch.randn(rows, K, generator=g)).bfloat16()
+    W = dev(torch.randn(H, K, generator=g) / K ** 0.5).bfloat16()
+    bias = dev(0.1 * torch.randn(H, generator=g))
+    res, gain = dev(torch.randn(rows, H, generator=g)), dev(1 + 0.1 * torch.randn(H, generator=g))
+    gam, bet = dev(1 + 0.1 * torch.randn(H, generator=g)), dev(0.1 * torch.randn(H, generator=g))
+    seed = torch.tensor([91], dtype=torch.int32, device="cuda")
+    p1, p2, dpr = 0.2, (0.2 if ffn else 0.0), 0.1
+    ndt = torch.bfloat16 if nbf else torch.float32
+    assert kk.load().kk_linear_tail_supported(rows, H, K) == 1
+    # the two launches
+    ya = torch.empty(rows, H, device="cuda", dtype=torch.bfloat16)
+    kk.call("kk_gemm", 0, 0, rows, H, K, 1.0, x, K, W, K, 0.0, ya, H, bias, None, 0, 0, 0, kk.KK_MATH_BF16, 1 | 2 | 4)
+    xa, rs_a = torch.empty(rows, H, device="cuda"), torch.zeros(rows, device="cuda")
+    na, ma, ra = torch.zeros(rows, H, device="cuda", dtype=ndt), torch.zeros(rows, device="cuda"), torch.zeros(rows, device="cuda")
+    kk.call("kk_sublayer_out_fwd", ya, 1, gain if ffn else None, rs_a if ffn else None, res, xa, gam if ln else None, bet if ln else None,
+            na if ln else None, nbf, ma if ln else None, ra if ln else None, rows, H, S, seed, 40, p1, 41, p2, 42, dpr)
+    # one launch
+    yb = torch.zeros(rows, H, device="cuda", dtype=torch.bfloat16)
+    xb, rs_b = torch.empty(rows, H, device="cuda"), torch.zeros(rows, device="cuda")
+    nb, mb, rb = torch.zeros_like(na), torch.zeros_like(ma), torch.zeros_like(ra)
+    kk.call("kk_linear_tail_fwd", x, K, W, bias, K, yb if ffn else None, 1, gain if ffn else None, rs_b if ffn else None, res, xb,
+            gam if ln else None, bet if ln else None, nb if ln else None, nbf, mb if ln else None, rb if ln else None,
+            rows, H, S, seed, 40, p1, 41, p2, 42, dpr)
+    torch.cuda.synchronize()
+    assert kk.last_kernel() == "linear_tail_fwd"
+    assert torch.equal(xb, xa), f"residual stream differs: {float((xb - xa).abs().max())}"
+    if ffn:
+        assert torch.equal(yb, ya) and torch.equal(rs_b, rs_a)
+    if ln:
+        assert torch.equal(mb, ma), f"LN mean differs: {float((mb - ma).abs().max())}"
+        assert torch.equal(rb, ra), f"LN rstd differs: {float((rb - ra).abs().max())}"
+        assert torch.equal(nb, na), f"LN output differs: {float((nb.float() - na.float()).abs().max())}"
+    # float64 anchor of the projection under the masks: where nothing was dropped, x_out - res = y * scale
+    y64 = x.double() @ W.double().t() + bias.double()
+    if ffn:
+        y64 = y64 / torch.sqrt((y64 ** 2).mean(1, keepdim=True) + torch.finfo(torch.float32).eps) * gain.double()
+    d = (xb - res).double()
+    kept = d != 0
+    assert 0.3 < float(kept.float().mean()) < 0.9
+    ratio = (d / y64)[kept & (y64.abs() > 0.05)]
+    scales = torch.tensor([1 / (0.8 * 0.9), 1 / (0.8 * 0.8 * 0.9)] if ffn else [1 / (0.8 * 0.9)], device="cuda", dtype=torch.float64)
+    err = (ratio[:, None] / scales[None, :] - 1).abs().min(1).values
+    assert float(err.max()) < 2e-2, f"projection under the masks: {float(err.max())}"        # bf16 rounding of y: 2^-8
+
+
 @pytest.mark.parametrize("ffn,bf,acc", [(1, 1, 1), (0, 1, 1), (1, 0, 0), (0, 0, 1)])
 def test_sublayer_tail_backward_equals_separate_kernels(kk, ffn, bf, acc):
     """kk_sublayer_in_bwd == kk_layernorm_bwd -> kk_dropout_bwd -> (kk_rmsnorm_bwd) -> kk_colsum_acc, same masks."""
