@@ -192,7 +192,7 @@ struct RowTailArgs {
     const void *x, *W;             // bf16 [rows, K] (pitch ldx), bf16 [512, K]
     int64_t ldx;
     uint32_t x_bytes, w_bytes;
-    int K, y_round, rot;
+    int K, y_round;
     uint64_t *trace;               // tools: [8 waves][8] wall-clock stamps of workgroup 0
     const float *bias;
     void *y_out;                   // optional (bf16): y as the backward wants it (the feed-forward's f2)
@@ -266,12 +266,8 @@ __global__ __launch_bounds__(512) void linear_tail_fwd_kernel(RowTailArgs a) {
         vob[j] = (uint32_t)(((int64_t)(64 * wave + row) * a.K + ((c8 ^ ((row >> 1) & 7)) << 3)) * 2);
     }
     char *ring = smem + 2 * RT_A_CHUNK + wave * (2 * RT_SLOT);
-    // resident x panel (K <= 512): the k order is a free choice per wave.  Rotated by workgroup and wave, the CUs of an XCD are NOT all
-    // asking the L2 for the same k-tile of the weight rows (lines 2 K bytes apart: a handful of channels) at the same moment.
-    const int rot = (a.rot && nch <= 2) ? (int)((blockIdx.x * 3u + (uint32_t)wave) % (uint32_t)nk) : 0;
-    auto ktile = [&](int kt) { const int k = kt + rot; return k >= nk ? k - nk : k; };
     auto issue_w = [&](int kt) {
-        const uint32_t so = (uint32_t)ktile(kt) * (RT_BK * 2);
+        const uint32_t so = (uint32_t)kt * (RT_BK * 2);
         char *d = ring + (kt & 1) * RT_SLOT;
 #pragma unroll
         for (int j = 0; j < 8; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(RW, KK_LDS_PTR(d + j * 1024), 16, vob[j], so, 0, 0);
@@ -313,8 +309,7 @@ __global__ __launch_bounds__(512) void linear_tail_fwd_kernel(RowTailArgs a) {
             asm volatile("" ::: "memory");
             if (ch + 1 < nch) { issue_x(ch + 1); x_issued = true; }
         }
-        const int kx = ktile(kt);
-        const uint32_t ai = a_lds + (uint32_t)(((kx / RT_ACH) & 1) * RT_A_CHUNK + (kx % RT_ACH) * RT_A_KT);
+        const uint32_t ai = a_lds + (uint32_t)((ch & 1) * RT_A_CHUNK + (kt % RT_ACH) * RT_A_KT);
         const uint32_t bi = w_lds + (uint32_t)((kt & 1) * RT_SLOT);
         bf16x8 af[4], bf[4][2];
 #pragma unroll
@@ -744,8 +739,6 @@ extern "C" int kk_linear_tail_fwd(const void *x, int64_t ldx, const void *W, con
     KK_REQUIRE(xb < ((int64_t)1 << 31), "kk_linear_tail_fwd: x spans more than 2 GB");
     RowTailArgs a;
     a.x = x; a.W = W; a.ldx = ldx; a.x_bytes = (uint32_t)xb; a.w_bytes = (uint32_t)((int64_t)RT_H * K * 2); a.K = K; a.y_round = y_round;
-    static const int rot = kk_tune_env("KK_RT_ROT", 0);
-    a.rot = rot;
     a.trace = nullptr;
 #ifdef KK_TUNING_HOOKS
     a.trace = g_rt_trace;

@@ -56,7 +56,7 @@ print("KK_G16X_NS4 =", os.environ.get("KK_G16X_NS4", "0"))
 for name, fns, flops in cases:
     row = []
     for dbg in (0, 1, 5, 9):
-        tune(15, -1, dbg)
+        tune(15, -1, dbg | int(os.environ.get('KK_PROBE_OR', '0')))
         t = gtime(fns)
         row.append(f"dbg{dbg}: {t:7.2f}")
         if dbg == 0: full = t
