@@ -408,11 +408,18 @@ int kk_losses_fwd(const float *mel_pred, const float *mel_tgt, const float *dur_
                   const float *pitch_tgt, const float *energy_pred, const float *energy_tgt,
                   const int64_t *mel_len, const int64_t *ph_len, int B, int T, int P, int M,
                   const KkLossCfg *cfg, const int64_t *max_dur /* device scalar or null */, double *acc,
-                  float *losses, float *coef, double *guard, void *stream);
+                  float *losses, float *coef, double *guard, int flags, void *stream);
+/* flags of kk_losses_fwd — the 12-double accumulator costs a zero-fill launch on the step's critical chain unless it is handed
+ * round: bit 0 = acc is zero on entry (the call launches no zero-fill), bit 1 = the call's own finalize leaves acc zero.  A
+ * single-GPU step passes 3 on a buffer allocated zero; a data-parallel step passes 1 and lets kk_losses_finalize(clear = 1) — the
+ * last reader — clear it.  0 is the self-contained form (zero-fill inside, acc kept). */
+#define KK_LOSS_ACC_ZEROED 1
+#define KK_LOSS_ACC_CLEAR 2
 /* Recompute losses[6] and coef[5] from acc (see kk_losses_fwd) — used by data-parallel runs after acc has been
- * SUM-reduced and *max_dur MAX-reduced over the ranks: normalisers become the global valid-element counts. */
-int kk_losses_finalize(const double *acc, const KkLossCfg *cfg, const int64_t *max_dur, int T, float *losses,
-                       float *coef, double *guard, void *stream);
+ * SUM-reduced and *max_dur MAX-reduced over the ranks: normalisers become the global valid-element counts.
+ * clear != 0: acc is zero afterwards. */
+int kk_losses_finalize(double *acc, const KkLossCfg *cfg, const int64_t *max_dur, int T, float *losses,
+                       float *coef, double *guard, int clear, void *stream);
 int kk_losses_bwd(const float *mel_pred, const float *mel_tgt, const float *dur_pred, const int64_t *dur,
                   const float *stop_logit, const float *stop_tgt, const float *pitch_pred,
                   const float *pitch_tgt, const float *energy_pred, const float *energy_tgt,
@@ -457,23 +464,28 @@ typedef struct KkOptCfg {
 #define KK_OS_MICRO_BAD 14    /* set by kk_losses_*: a micro-batch of the current cycle had non-finite outputs / losses */
 #define KK_OS_MICRO_BAD_TOTAL 15 /* micro-batches flagged so far */
 #define KK_OS_SIZE 16
-/* sumsq[seg] (double, zeroed by the call) = sum of squares of each arena segment of `buf`. */
-int kk_seg_sumsq(const float *buf, const int32_t *block_seg, int64_t nblocks, double *sumsq, int nseg,
+/* sumsq[seg] (double) = sum of squares of each arena segment of `buf`.  zeroed == 0: the call zero-fills sumsq first (one more
+ * launch); zeroed != 0: the caller guarantees sumsq is zero on entry (kk_opt_prepare, its only reader, can leave it so). */
+int kk_seg_sumsq(const float *buf, const int32_t *block_seg, int64_t nblocks, double *sumsq, int nseg, int zeroed,
                  void *stream);
 /* One-thread-block kernel: per-parameter pre-clip, total norm, non-finite check, explosion tracker,
  * adaptive + global clip, LR schedule -> per-segment gradient scale / lr / step-size constants. */
 int kk_opt_prepare(const double *grad_sumsq, const float *seg_preclip, const float *seg_lr_mult,
                    const float *seg_wd, int nseg, const int64_t *max_dur, const KkOptCfg *cfg,
                    double *opt_state, float *seg_gscale, float *seg_decay, float *seg_stepsize,
-                   float *step_consts /* [4]: skip, sqrt(1-beta2^t), eps, base_lr */, void *stream);
+                   float *step_consts /* [4]: skip, sqrt(1-beta2^t), eps, base_lr */,
+                   double *clear_a, double *clear_b /* nullable: per-segment accumulators [nseg] left zero by this launch — grad_sumsq
+                   itself (read before it is cleared) for the next kk_seg_sumsq(zeroed = 1), p_sumsq for the kk_adamw_ema(zeroed = 1)
+                   that follows */, void *stream);
 /* Fused single pass: p,g,m,v,(ema) -> p,m,v,(ema).  seg_flags bit0: AdamW-updated, bit1: EMA-tracked,
- * bit2: weight-norm target (its post-step sum of squares is accumulated into p_sumsq, zeroed by the call).
+ * bit2: weight-norm target (its post-step sum of squares is accumulated into p_sumsq; zeroed == 0: zero-filled by the call first,
+ * zeroed != 0: zero on entry, e.g. cleared by the kk_opt_prepare in front of it).
  * p_bf16 (optional): bf16 shadow of the arena, same element offsets, rewritten wherever p is (the bf16 mode's
  * GEMMs read weights from it). */
 int kk_adamw_ema(float *p, const float *g, float *m, float *v, float *ema, const int32_t *block_seg,
                  int64_t nblocks, const float *seg_gscale, const float *seg_decay, const float *seg_stepsize,
                  const int32_t *seg_flags, const float *step_consts, float beta1, float beta2,
-                 float ema_decay, double *p_sumsq, int nseg, void *p_bf16, void *stream);
+                 float ema_decay, double *p_sumsq, int nseg, void *p_bf16, int zeroed, void *stream);
 /* FFN weight-norm projection: for flagged segments with ||W|| > max: W *= max/||W||. */
 int kk_weight_norm_project(float *p, const int32_t *block_seg, int64_t nblocks, const double *p_sumsq,
                            const int32_t *seg_flags, const float *step_consts, double max_norm, void *p_bf16,

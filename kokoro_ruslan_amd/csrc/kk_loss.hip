@@ -76,8 +76,8 @@ __global__ __launch_bounds__(256) void losses_fwd_kernel(LossArgs a, double *__r
 // guard (nullable): 2 doubles of the step driver's state — [0] "a micro-batch of the current accumulation cycle had
 // non-finite outputs or losses" (the reference then drops the cycle's gradients and takes no optimizer step,
 // trainer.py:2304-2314; kk_opt_prepare honours and clears it), [1] how many micro-batches were flagged so far.
-__global__ void losses_finalize_kernel(const double *__restrict__ acc, KkLossCfg cfg, const int64_t *__restrict__ max_dur,
-                                       int T, float *__restrict__ losses, float *__restrict__ coef, double *__restrict__ guard) {
+__global__ void losses_finalize_kernel(double *__restrict__ acc, KkLossCfg cfg, const int64_t *__restrict__ max_dur,
+                                       int T, float *__restrict__ losses, float *__restrict__ coef, double *__restrict__ guard, int clear) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double scale = (double)cfg.loss_scale;
     if (cfg.adaptive) {                               // trainer.py:2218-2242 (second branch overrides the first)
@@ -106,6 +106,8 @@ __global__ void losses_finalize_kernel(const double *__restrict__ acc, KkLossCfg
         guard[0] = 1.0;
         guard[1] += 1.0;
     }
+    if (clear)                   // the accumulator leaves the step zero: the next kk_losses_fwd needs no zero-fill launch in front of it
+        for (int k = 0; k < 12; ++k) acc[k] = 0.0;
 }
 
 __global__ __launch_bounds__(256) void losses_bwd_kernel(LossArgs a, const float *__restrict__ coef, float *__restrict__ dmel,
@@ -167,17 +169,19 @@ extern "C" int kk_losses_fwd(const float *mel_pred, const float *mel_tgt, const 
                              const float *pitch_tgt, const float *energy_pred, const float *energy_tgt,
                              const int64_t *mel_len, const int64_t *ph_len, int B, int T, int P, int M,
                              const KkLossCfg *cfg, const int64_t *max_dur, double *acc, float *losses, float *coef,
-                             double *guard, void *stream) {
+                             double *guard, int flags, void *stream) {
     KK_REQUIRE(B > 0 && T > 0 && P > 0 && M > 0 && cfg, "kk_losses_fwd: bad args");
     hipStream_t s = (hipStream_t)stream;
-    const int e = kk_zero_async(acc, 12 * sizeof(double), s);
-    if (e != 0) return e;
+    if (!(flags & 1)) {                                         // bit 0: acc[0..12) == 0 on entry (a finalize with `clear` left it so)
+        const int e = kk_zero_async(acc, 12 * sizeof(double), s);
+        if (e != 0) return e;
+    }
     LossArgs a = pack(mel_pred, mel_tgt, dur_pred, dur, stop_logit, stop_tgt, pitch_pred, pitch_tgt, energy_pred,
                       energy_tgt, mel_len, ph_len, B, T, P, M, cfg);
     int blocks = kk_cdiv((int64_t)B * T * M, 256 * 8);
     blocks = blocks > 1024 ? 1024 : (blocks < 1 ? 1 : blocks);
     hipLaunchKernelGGL(losses_fwd_kernel, dim3(blocks), dim3(256), 0, s, a, acc);
-    hipLaunchKernelGGL(losses_finalize_kernel, dim3(1), dim3(64), 0, s, acc, *cfg, max_dur, T, losses, coef, guard);
+    hipLaunchKernelGGL(losses_finalize_kernel, dim3(1), dim3(64), 0, s, acc, *cfg, max_dur, T, losses, coef, guard, (flags >> 1) & 1);
     KK_LAUNCH_CHECK("kk_losses_fwd");
     return 0;
 }
@@ -185,10 +189,10 @@ extern "C" int kk_losses_fwd(const float *mel_pred, const float *mel_tgt, const 
 // Finish the scalars again from `acc` — data parallel: after the 5 sums + 5 counts have been SUM-all-reduced (and
 // max_dur MAX-all-reduced), every rank normalises by the GLOBAL valid-element counts, so the summed gradients are the
 // global-batch gradients also when the shards are ragged.  T = the global-batch mel length.
-extern "C" int kk_losses_finalize(const double *acc, const KkLossCfg *cfg, const int64_t *max_dur, int T, float *losses,
-                                  float *coef, double *guard, void *stream) {
+extern "C" int kk_losses_finalize(double *acc, const KkLossCfg *cfg, const int64_t *max_dur, int T, float *losses,
+                                  float *coef, double *guard, int clear, void *stream) {
     KK_REQUIRE(acc && cfg && losses && coef && T > 0, "kk_losses_finalize: bad args");
-    hipLaunchKernelGGL(losses_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, acc, *cfg, max_dur, T, losses, coef, guard);
+    hipLaunchKernelGGL(losses_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, acc, *cfg, max_dur, T, losses, coef, guard, clear);
     KK_LAUNCH_CHECK("kk_losses_finalize");
     return 0;
 }

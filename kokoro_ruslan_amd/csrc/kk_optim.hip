@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void opt_prepare_kernel(const double *__restri
                                                           int nseg, const int64_t *__restrict__ max_dur, KkOptCfg c,
                                                           double *__restrict__ st, float *__restrict__ seg_gscale,
                                                           float *__restrict__ seg_decay, float *__restrict__ seg_stepsize,
-                                                          float *__restrict__ step_consts) {
+                                                          float *__restrict__ step_consts, double *clear_a, double *clear_b) {
     __shared__ double red[4];
     __shared__ double sh[4];   // coef, base_lr, bc1, skip
     double part = 0.0, bad = 0.0;
@@ -154,6 +154,10 @@ __global__ __launch_bounds__(256) void opt_prepare_kernel(const double *__restri
         seg_gscale[i] = (float)((double)seg_gscale[i] * coef);
         seg_decay[i] = (float)(1.0 - lr * (double)seg_wd[i]);
         seg_stepsize[i] = (float)(lr / bc1);
+        // the per-segment accumulators of the launches around this one leave it zero (every read of grad_sumsq lies before the first
+        // block reduction above): no zero-fill launch on the optimizer's chain
+        if (clear_a) clear_a[i] = 0.0;
+        if (clear_b) clear_b[i] = 0.0;
     }
 }
 
@@ -250,12 +254,14 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float *__restrict_
 
 }  // namespace
 
-extern "C" int kk_seg_sumsq(const float *buf, const int32_t *block_seg, int64_t nblocks, double *sumsq, int nseg,
+extern "C" int kk_seg_sumsq(const float *buf, const int32_t *block_seg, int64_t nblocks, double *sumsq, int nseg, int zeroed,
                             void *stream) {
     KK_REQUIRE(buf && block_seg && sumsq && nblocks > 0 && nseg > 0, "kk_seg_sumsq: bad args");
     hipStream_t s = (hipStream_t)stream;
-    const int e = kk_zero_async(sumsq, sizeof(double) * nseg, s);
-    if (e != 0) return e;
+    if (!zeroed) {                                              // (zeroed: the caller guarantees sumsq[0..nseg) == 0 on entry)
+        const int e = kk_zero_async(sumsq, sizeof(double) * nseg, s);
+        if (e != 0) return e;
+    }
     int wgs = 2048;
     const int per = kk_cdiv(nblocks, wgs);
     wgs = kk_cdiv(nblocks, per);
@@ -267,10 +273,10 @@ extern "C" int kk_seg_sumsq(const float *buf, const int32_t *block_seg, int64_t 
 extern "C" int kk_opt_prepare(const double *grad_sumsq, const float *seg_preclip, const float *seg_lr_mult,
                               const float *seg_wd, int nseg, const int64_t *max_dur, const KkOptCfg *cfg,
                               double *opt_state, float *seg_gscale, float *seg_decay, float *seg_stepsize,
-                              float *step_consts, void *stream) {
+                              float *step_consts, double *clear_a, double *clear_b, void *stream) {
     KK_REQUIRE(grad_sumsq && seg_preclip && seg_lr_mult && seg_wd && cfg && opt_state && nseg > 0, "kk_opt_prepare: bad args");
     hipLaunchKernelGGL(opt_prepare_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, grad_sumsq, seg_preclip, seg_lr_mult,
-                       seg_wd, nseg, max_dur, *cfg, opt_state, seg_gscale, seg_decay, seg_stepsize, step_consts);
+                       seg_wd, nseg, max_dur, *cfg, opt_state, seg_gscale, seg_decay, seg_stepsize, step_consts, clear_a, clear_b);
     KK_LAUNCH_CHECK("kk_opt_prepare");
     return 0;
 }
@@ -279,10 +285,10 @@ extern "C" int kk_adamw_ema(float *p, const float *g, float *m, float *v, float 
                             int64_t nblocks, const float *seg_gscale, const float *seg_decay,
                             const float *seg_stepsize, const int32_t *seg_flags, const float *step_consts,
                             float beta1, float beta2, float ema_decay, double *p_sumsq, int nseg, void *p_bf16,
-                            void *stream) {
+                            int zeroed, void *stream) {
     KK_REQUIRE(p && g && m && v && block_seg && nblocks > 0 && nblocks < (1ll << 31), "kk_adamw_ema: bad args");
     hipStream_t s = (hipStream_t)stream;
-    if (p_sumsq) {
+    if (p_sumsq && !zeroed) {                                   // (zeroed: p_sumsq[0..nseg) == 0 on entry, e.g. cleared by kk_opt_prepare)
         const int e = kk_zero_async(p_sumsq, sizeof(double) * nseg, s);
         if (e != 0) return e;
     }

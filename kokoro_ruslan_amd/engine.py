@@ -219,6 +219,9 @@ class KokoroEngine:
         # the decoder's attention output projection and the sub-layer tail behind it as ONE row-owner launch (kk_linear_tail_fwd) where
         # the library measured it faster (kk_linear_tail_pays: whole rounds of workgroups at >= ~6 K rows); bit-identical results
         self.fuse_linear_tail = True
+        # the step's small fp64 accumulators (loss sums, per-segment gradient / parameter norms) are kept zero by their last readers
+        # instead of a zero-fill launch in front of every writer (three dependent launches of the critical chain)
+        self.self_cleaning_acc = True
         # The zero-fill at the start of an accumulation cycle skips what the cycle's first grouped weight-gradient launches
         # overwrite (89 % of the arena at default dims; the fill runs beside the latency-bound encoder launch: 20 us of the step).
         # Which tensors those are is RECORDED from the launches of a step (per precision mode), never assumed, and a step that
@@ -1188,12 +1191,14 @@ class KokoroEngine:
         # back-propagates nothing and its accumulation cycle takes no optimizer step; forward-only calls (validation) do
         # not touch the training cycle's flag
         guard = self.opt_state[kk.OS["MICRO_BAD"]:] if backward else None
+        # (loss_acc is handed round zero: allocated zero, cleared by its last reader — no zero-fill launch on the critical chain)
+        sc = 1 if self.self_cleaning_acc else 0
         kk.call("kk_losses_fwd", *largs, self.max_dur, self.loss_acc, self.losses, self.loss_coef,
-                guard if self.loss_sync is None else None)
+                guard if self.loss_sync is None else None, sc * (1 if self.loss_sync is not None else 3))
         if self.loss_sync is not None:                    # global normalisers for ragged shards (one more collective of the step)
             self.loss_sync.loss_sync(self.loss_acc, self.max_dur)
             kk.call("kk_losses_finalize", self.loss_acc, lcfg, self.max_dur, canonical_mel_length(self.global_mel_length, T), self.losses,
-                    self.loss_coef, guard)
+                    self.loss_coef, guard, sc)
         out = {"losses": self.losses, "mel": mel_pred, "log_dur": dur_pred, "stop": stop, "pitch": pitch_pred,
                "energy": energy_pred, "lr_idx": idx, "lr_lens": lens, "memory": memory.view(B, T, H)}
         if not backward:
@@ -1549,12 +1554,16 @@ class KokoroEngine:
         a, hp = self.arena, self.hp
         cfg = self._opt_cfg(mel_length)
         self._mark("optimizer start")
-        kk.call("kk_seg_sumsq", a.g, a.block_seg, a.nblocks, self.grad_sumsq, a.nseg)
+        # grad_sumsq / p_sumsq are private to this sequence: kk_opt_prepare, the one-workgroup launch between their writers, leaves
+        # both zero (grad_sumsq after reading it, for the next step) — two zero-fill launches less on the optimizer's chain
+        sc = 1 if self.self_cleaning_acc else 0
+        kk.call("kk_seg_sumsq", a.g, a.block_seg, a.nblocks, self.grad_sumsq, a.nseg, sc)
         kk.call("kk_opt_prepare", self.grad_sumsq, a.seg_preclip, a.seg_lr_mult, a.seg_wd, a.nseg, self.max_dur, cfg,
-                self.opt_state, self.seg_gscale, self.seg_decay, self.seg_stepsize, self.step_consts)
+                self.opt_state, self.seg_gscale, self.seg_decay, self.seg_stepsize, self.step_consts,
+                self.grad_sumsq if sc else None, self.p_sumsq if sc else None)
         kk.call("kk_adamw_ema", a.p, a.g, a.m, a.v, a.ema, a.block_seg, a.nblocks, self.seg_gscale, self.seg_decay,
                 self.seg_stepsize, a.seg_flags, self.step_consts, hp.adam_betas[0], hp.adam_betas[1], hp.ema_decay,
-                self.p_sumsq, a.nseg, a.p16)
+                self.p_sumsq, a.nseg, a.p16, sc)
         kk.call("kk_weight_norm_project", a.p, a.block_seg, a.nblocks, self.p_sumsq, a.seg_flags, self.step_consts,
                 float(hp.dec_ffn_max_weight_norm), a.p16)
         self._mark("optimizer done")

@@ -202,12 +202,12 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_decode_prologue": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "kk_decode_cache_append": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "kk_decode_epilogue": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
-    "kk_losses_fwd": [_P] * 12 + [_I, _I, _I, _I, C.POINTER(KkLossCfg), _P, _P, _P, _P, _P, _P],
-    "kk_losses_finalize": [_P, C.POINTER(KkLossCfg), _P, _I, _P, _P, _P, _P],
+    "kk_losses_fwd": [_P] * 12 + [_I, _I, _I, _I, C.POINTER(KkLossCfg), _P, _P, _P, _P, _P, _I, _P],
+    "kk_losses_finalize": [_P, C.POINTER(KkLossCfg), _P, _I, _P, _P, _P, _I, _P],
     "kk_losses_bwd": [_P] * 12 + [_I, _I, _I, _I, C.POINTER(KkLossCfg), _P, _P, _P, _P, _P, _P, _P],
-    "kk_seg_sumsq": [_P, _P, _L, _P, _I, _P],
-    "kk_opt_prepare": [_P, _P, _P, _P, _I, _P, C.POINTER(KkOptCfg), _P, _P, _P, _P, _P, _P],
-    "kk_adamw_ema": [_P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _F, _F, _F, _P, _I, _P, _P],
+    "kk_seg_sumsq": [_P, _P, _L, _P, _I, _I, _P],
+    "kk_opt_prepare": [_P, _P, _P, _P, _I, _P, C.POINTER(KkOptCfg), _P, _P, _P, _P, _P, _P, _P, _P],
+    "kk_adamw_ema": [_P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _F, _F, _F, _P, _I, _P, _I, _P],
     "kk_weight_norm_project": [_P, _P, _L, _P, _P, _P, _D, _P, _P],
     "kk_cast_f32_bf16": [_P, _P, _L, _P],
     "kk_comm_load": [C.c_char_p],

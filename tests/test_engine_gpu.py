@@ -291,10 +291,13 @@ def test_global_loss_normalisers_two_shards_on_one_gpu(eng_mod, golden_dir):
     shards = [{k: v[i:i + 2].contiguous() for k, v in glob.items()} for i in (0, 2)]
     e = _engine(eng_mod, d, P)
     accs, mds = [], []
+    e.self_cleaning_acc = False                         # (the accumulator is normally left zero by its last reader: keep it to look at it)
     for sh in shards:                                   # what the ranks' loss forward kernels accumulate
         e.forward_backward(_cuda(sh), backward=False)
         accs.append(e.loss_acc.clone())
         mds.append(e.max_dur.clone())
+    e.self_cleaning_acc = True
+    e.loss_acc.zero_()
     assert not torch.equal(accs[0][5:], accs[1][5:]), "shards must have different valid counts"
     g_acc, g_md = accs[0] + accs[1], torch.maximum(mds[0], mds[1])
 
@@ -456,7 +459,7 @@ def test_device_step_driver_against_reference_sequences(eng_mod, golden_dir):
             e.grad_sumsq[seg] = float(nv) ** 2
             cfg = e._opt_cfg(64)
             kk.call("kk_opt_prepare", e.grad_sumsq, a.seg_preclip, a.seg_lr_mult, a.seg_wd, a.nseg, e.max_dur, cfg, e.opt_state,
-                    e.seg_gscale, e.seg_decay, e.seg_stepsize, e.step_consts)
+                    e.seg_gscale, e.seg_decay, e.seg_stepsize, e.step_consts, None, None)
             check(k, e.opt_stats(), e)
     # ---- explosion tracker: 520 steps ----
     e = _engine(eng_mod, d, P, gradient_accumulation_steps=1)

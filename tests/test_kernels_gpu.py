@@ -527,13 +527,66 @@ def test_losses_fwd_bwd(kk, ragged):
     bd = {k: dev(v) for k, v in b.items()}
     args = (dv["mel"], bd["mel_specs"], dv["log_dur"], bd["phoneme_durations"], dv["stop"], bd["stop_token_targets"], dv["pitch"],
             bd["pitches"], dv["energy"], bd["energies"], bd["mel_lengths"], bd["phoneme_lengths"], B, T, Pn, 80, cfg)
-    kk.call("kk_losses_fwd", *args, None, acc, losses, coef, None)
+    kk.call("kk_losses_fwd", *args, None, acc, losses, coef, None, 0)
     close(losses, torch.stack([x.detach() for x in ls]), 1e-5, 1e-5, "losses")
     grads = [torch.empty_like(dv[k]) for k in ("mel", "log_dur", "stop", "pitch", "energy")]
     kk.call("kk_losses_bwd", *args, coef, *grads)
     for k, gd in zip(("mel", "log_dur", "stop", "pitch", "energy"), grads):
         ref = torch.nan_to_num(outr[k].grad, nan=0.0, posinf=0.0, neginf=0.0)
         close(gd, ref, 1e-7, 1e-4, f"loss grad {k}")
+    # the accumulator handed round zero (KK_LOSS_ACC_ZEROED | KK_LOSS_ACC_CLEAR): same scalars, acc zero again afterwards; and the
+    # data-parallel order: forward leaves acc for the collective, the explicit finalize clears it
+    assert float(acc.abs().sum()) > 0
+    l0, c0 = losses.clone(), coef.clone()
+    acc.zero_(); losses.zero_(); coef.zero_()
+    for _ in range(2):
+        kk.call("kk_losses_fwd", *args, None, acc, losses, coef, None, 3)
+        assert torch.equal(losses, l0) and torch.equal(coef, c0) and float(acc.abs().sum()) == 0.0
+    kk.call("kk_losses_fwd", *args, None, acc, losses, coef, None, 1)
+    assert float(acc.abs().sum()) > 0
+    losses.zero_()
+    kk.call("kk_losses_finalize", acc, cfg, None, T, losses, coef, None, 1)
+    assert torch.equal(losses, l0) and torch.equal(coef, c0) and float(acc.abs().sum()) == 0.0
+
+
+def test_optimizer_accumulators_handed_round_zero(kk):
+    """kk_seg_sumsq(zeroed = 1) / kk_opt_prepare(clear_a, clear_b) / kk_adamw_ema(zeroed = 1): the per-segment fp64 accumulators
+    kept zero by the one-workgroup launch between their writers give the same numbers as the zero-fill launches they replace."""
+    g = torch.Generator().manual_seed(5)
+    BLK, nblocks, nseg = 1024, 96, 7
+    seg_of = torch.tensor(sorted([int(v) for v in torch.randint(0, nseg, (nblocks,), generator=g)]), dtype=torch.int32, device="cuda")
+    n = nblocks * BLK
+    grad = dev(torch.randn(n, generator=g) * 0.01)
+    ref = torch.zeros(nseg, dtype=torch.float64, device="cuda")
+    ref.index_add_(0, seg_of.long().repeat_interleave(BLK), grad.double() ** 2)
+    ss = torch.full((nseg,), 7.0, dtype=torch.float64, device="cuda")
+    kk.call("kk_seg_sumsq", grad, seg_of, nblocks, ss, nseg, 0)              # self-contained form: zero-fills the garbage itself
+    close(ss, ref, 1e-6, 1e-9, "seg_sumsq (zero-fill inside)")
+    ss.zero_()
+    kk.call("kk_seg_sumsq", grad, seg_of, nblocks, ss, nseg, 1)
+    close(ss, ref, 1e-6, 1e-9, "seg_sumsq (zero on entry)")
+    f = lambda v: torch.full((nseg,), v, device="cuda")
+    cfg = kk.KkOptCfg()
+    cfg.learning_rate, cfg.max_lr, cfg.warmup_start_lr, cfg.warmup_target_lr, cfg.use_warmup = 1e-3, 1e-3, 1e-4, 1e-3, 0
+    cfg.pct_start, cfg.div_factor, cfg.final_div_factor, cfg.warmup_steps, cfg.onecycle_steps = 0.3, 25.0, 1e4, 10, 1000
+    cfg.max_grad_norm, cfg.beta1, cfg.beta2, cfg.eps, cfg.mel_length = 1.0, 0.9, 0.999, 1e-8, 64
+    cfg.expl_abs_floor, cfg.expl_warmup_floor, cfg.expl_multiplier, cfg.expl_alpha = 1e9, 1e9, 10.0, 0.9
+    cfg.expl_warmup_steps, cfg.expl_min_ema_steps, cfg.ema_decay, cfg.max_weight_norm = 0, 5, 0.999, 0.0
+    st = torch.zeros(16, dtype=torch.float64, device="cuda")
+    gs, dec, stp, consts = f(0.0), f(0.0), f(0.0), torch.zeros(4, device="cuda")
+    psq = torch.full((nseg,), 3.0, dtype=torch.float64, device="cuda")
+    kk.call("kk_opt_prepare", ss, f(0.0), f(1.0), f(0.01), nseg, None, cfg, st, gs, dec, stp, consts, ss, psq)
+    assert float(ss.abs().sum()) == 0.0 and float(psq.abs().sum()) == 0.0, "kk_opt_prepare leaves both accumulators zero"
+    total = float(ref.sum().sqrt())
+    close(torch.tensor(float(st[kk.OS["LAST_GRAD_NORM"]])), torch.tensor(total), 1e-6, 1e-9, "total norm read before the clear")
+    p, m, v, ema = dev(torch.randn(n, generator=g)), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    flags = torch.full((nseg,), 1 | 4, dtype=torch.int32, device="cuda")
+    pa, pb = p.clone(), p.clone()
+    psa = torch.full((nseg,), 9.0, dtype=torch.float64, device="cuda")
+    kk.call("kk_adamw_ema", pa, grad, m.clone(), v.clone(), ema.clone(), seg_of, nblocks, gs, dec, stp, flags, consts, 0.9, 0.999, 0.999, psa, nseg, None, 0)
+    kk.call("kk_adamw_ema", pb, grad, m.clone(), v.clone(), ema.clone(), seg_of, nblocks, gs, dec, stp, flags, consts, 0.9, 0.999, 0.999, psq, nseg, None, 1)
+    assert torch.equal(pa, pb) and not torch.equal(pa, p)
+    close(psq, psa, 1e-12, 1e-12, "p_sumsq (zero on entry == zero-fill inside)")
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -31,7 +31,7 @@ for frac in (0.0, 0.55, 1.0):
         if nb:
             with torch.cuda.stream(side):
                 kk.call("kk_adamw_ema", dummy[0], dummy[1], dummy[2], dummy[3], dummy[4], a.block_seg, nb, eng.seg_gscale, eng.seg_decay,
-                        eng.seg_stepsize, a.seg_flags, eng.step_consts, hp.adam_betas[0], hp.adam_betas[1], hp.ema_decay, psq, a.nseg, d16)
+                        eng.seg_stepsize, a.seg_flags, eng.step_consts, hp.adam_betas[0], hp.adam_betas[1], hp.ema_decay, psq, a.nseg, d16, 0)
         eng.train_step_graphed(batch)
         torch.cuda.synchronize()
         t = dict((n, v) for v, n in eng.timeline())
