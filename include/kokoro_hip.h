@@ -234,6 +234,12 @@ int kk_glu_bwd(const float *dg, const float *h, float *dh, int64_t rows, int F, 
 int kk_embed_fwd(const int64_t *ids, const int64_t *stress, const float *emb, const float *stress_emb,
                  const float *pe, float *out, int B, int P, int H, float scale, const uint32_t *seed,
                  uint32_t site, float p, void *stream);
+/* kk_embed_fwd + the key-padding mask (key_mask[tok] = ids[tok] == 0, nullable; model.py:372) + kk_layernorm_fwd of the result (the
+ * first encoder layer's pre-norm, transformers.py:468) in ONE launch, a wave per token; same bits as the separate launches. */
+int kk_embed_ln_fwd(const int64_t *ids, const int64_t *stress, const float *emb, const float *stress_emb, const float *pe,
+                    float *out, int B, int P, int H, float scale, const uint32_t *seed, uint32_t site, float p,
+                    uint8_t *key_mask, const float *ln_gamma, const float *ln_beta, void *y, int y_bf16, float *mean,
+                    float *rstd, void *stream);
 int kk_embed_bwd(const int64_t *ids, const int64_t *stress, const float *dout, float *demb,
                  float *dstress_emb, int B, int P, int H, float scale, const uint32_t *seed, uint32_t site, float p,
                  void *stream);

@@ -87,6 +87,73 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t *__restric
     }
 }
 
+// The encoder's whole prologue as ONE launch, a wave per token: the embedding row above (same expressions, same bits), the key-padding
+// mask (ids == 0, model.py:372) and the first layer's pre-LayerNorm (the arithmetic of layernorm_fwd_kernel, kk_norm.hip).  These were
+// three dependent launches in front of the encoder forward — the head of the step's critical path, ~7 us each with their gaps.
+template <typename TY, int NV>
+__global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t *__restrict__ ids, const int64_t *__restrict__ stress,
+                                                           const float *__restrict__ emb, const float *__restrict__ semb,
+                                                           const float *__restrict__ pe, float *__restrict__ out, int64_t ntok, int P, int H,
+                                                           float scale, Drop1 d, uint8_t *__restrict__ key_mask,
+                                                           const float *__restrict__ gamma, const float *__restrict__ beta, TY *__restrict__ y,
+                                                           float *__restrict__ mean_o, float *__restrict__ rstd_o) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= ntok) return;
+    const uint32_t thr = d.seed ? kk_drop_threshold(d.p) : 0u, seed = thr ? *d.seed : 0u;
+    const float ik = thr ? 1.f / (1.f - d.p) : 1.f;
+    const int64_t id = ids[tok], sid = stress ? stress[tok] : 0;
+    const int p = (int)(tok % P);
+    if (key_mask && lane == 0) key_mask[tok] = id == 0 ? 1 : 0;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < H) {
+            const float4 e = ld4(emb + id * H + c), pv = ld4(pe + (int64_t)p * H + c);
+            float4 o = make_float4(e.x * scale, e.y * scale, e.z * scale, e.w * scale);
+            if (stress) { const float4 sv = ld4(semb + sid * H + c); o.x += sv.x; o.y += sv.y; o.z += sv.z; o.w += sv.w; }
+            o.x += pv.x; o.y += pv.y; o.z += pv.z; o.w += pv.w;
+            const float4 m = drop4(d, seed, thr, ik, (uint64_t)tok * H + c);
+            o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w;
+            st4(out + tok * H + c, o);
+            v[i] = o;
+        }
+        s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+    const float mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < H) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, dd = v[i].w - mean;
+            q += a * a + b * b + cc * cc + dd * dd;
+        }
+    }
+    const float rstd = 1.f / sqrtf(wave_sum(q) / (float)H + 1e-5f);
+    TY *yr = y + tok * H;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < H) {
+            const float4 g = ld4(gamma + c), b = ld4(beta + c);
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * g.x + b.x;
+            o.y = (v[i].y - mean) * rstd * g.y + b.y;
+            o.z = (v[i].z - mean) * rstd * g.z + b.z;
+            o.w = (v[i].w - mean) * rstd * g.w + b.w;
+            stv4<TY>(yr + c, o);
+        }
+    }
+    if (lane == 0) {
+        mean_o[tok] = mean;
+        rstd_o[tok] = rstd;
+    }
+}
+
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t *__restrict__ ids, const int64_t *__restrict__ stress,
                                                         const float *__restrict__ dout, float *__restrict__ demb,
                                                         float *__restrict__ dsemb, int64_t total, int H, float scale, Drop1 dr) {
@@ -454,6 +521,24 @@ extern "C" int kk_embed_fwd(const int64_t *ids, const int64_t *stress, const flo
     hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, ids, stress, emb,
                        stress_emb, pe, out, total4, P, H, scale, d);
     KK_LAUNCH_CHECK("kk_embed_fwd");
+    return 0;
+}
+extern "C" int kk_embed_ln_fwd(const int64_t *ids, const int64_t *stress, const float *emb, const float *stress_emb, const float *pe,
+                               float *out, int B, int P, int H, float scale, const uint32_t *seed, uint32_t site, float p,
+                               uint8_t *key_mask, const float *ln_gamma, const float *ln_beta, void *y, int y_bf16, float *mean,
+                               float *rstd, void *stream) {
+    KK_REQUIRE(B > 0 && P > 0 && H > 0 && H % 4 == 0 && H <= 2048 && p >= 0.f && p < 1.f, "kk_embed_ln_fwd: bad shape (H %% 4 == 0, H <= 2048)");
+    KK_REQUIRE(ids && emb && pe && out && ln_gamma && ln_beta && y && mean && rstd, "kk_embed_ln_fwd: null pointer");
+    const int64_t ntok = (int64_t)B * P;
+    Drop1 d = {p > 0.f ? seed : nullptr, site, p};
+    const dim3 grid(kk_cdiv(ntok, 4));
+    const int nv = kk_cdiv(H, 256);
+#define KK_EL(TY, NV) hipLaunchKernelGGL((embed_ln_fwd_kernel<TY, NV>), grid, dim3(256), 0, (hipStream_t)stream, ids, stress, emb, stress_emb, \
+                                         pe, out, ntok, P, H, scale, d, key_mask, ln_gamma, ln_beta, static_cast<TY *>(y), mean, rstd)
+    if (y_bf16) { if (nv <= 1) KK_EL(__bf16, 1); else if (nv <= 2) KK_EL(__bf16, 2); else if (nv <= 4) KK_EL(__bf16, 4); else KK_EL(__bf16, 8); }
+    else { if (nv <= 1) KK_EL(float, 1); else if (nv <= 2) KK_EL(float, 2); else if (nv <= 4) KK_EL(float, 4); else KK_EL(float, 8); }
+#undef KK_EL
+    KK_LAUNCH_CHECK("kk_embed_ln_fwd");
     return 0;
 }
 extern "C" int kk_embed_bwd(const int64_t *ids, const int64_t *stress, const float *dout, float *demb,

@@ -222,6 +222,9 @@ class KokoroEngine:
         # the step's small fp64 accumulators (loss sums, per-segment gradient / parameter norms) are kept zero by their last readers
         # instead of a zero-fill launch in front of every writer (three dependent launches of the critical chain)
         self.self_cleaning_acc = True
+        # key-padding mask + embedding (+ PE, dropout) + the first encoder layer's pre-LayerNorm as one launch (kk_embed_ln_fwd): the
+        # head of the critical path in front of the encoder forward is 3 dependent launches instead of 5
+        self.fuse_enc_prologue = True
         # The zero-fill at the start of an accumulation cycle skips what the cycle's first grouped weight-gradient launches
         # overwrite (89 % of the arena at default dims; the fill runs beside the latency-bound encoder launch: 20 us of the step).
         # Which tensors those are is RECORDED from the launches of a step (per precision mode), never assumed, and a step that
@@ -1062,7 +1065,8 @@ class KokoroEngine:
 
         # ---- encoder (model.py:375-388) ----
         text_mask = self._buf("text_mask", B, Pn, dtype=torch.uint8)
-        kk.call("kk_ids_eq_zero", ids, text_mask, Ne)
+        if not self.fuse_enc_prologue:
+            kk.call("kk_ids_eq_zero", ids, text_mask, Ne)
         x = self._buf("enc.x0", Ne, H)
         hp = self.hp
         if self.train_dropout:
@@ -1075,12 +1079,19 @@ class KokoroEngine:
             kk.call("kk_max_i64", dur, Ne, self.max_dur)  # (read by the losses only: not in front of the encoder)
             dec_head = decoder_head()                     # (includes the gradient zero-fill, see there)
             self._mark("kv: decoder head done")
-        kk.call("kk_embed_fwd", ids, stress, P["text_embedding.weight"], P["stress_embedding.weight"] if stress is not None else None,
-                pe, x, B, Pn, H, float(H ** 0.5), self.rng, 1, pe_drop)
         y1 = None                                         # LayerNorm outputs come from the previous sub-layer's fused tail
+        if self.fuse_enc_prologue:                        # key mask + embedding + layer 0's pre-norm: ONE launch in front of the encoder
+            y1, m1, r1 = self._buf("enc0.ln1.y", Ne, H, dtype=edt), self._buf("enc0.ln1.mean", Ne), self._buf("enc0.ln1.rstd", Ne)
+            kk.call("kk_embed_ln_fwd", ids, stress, P["text_embedding.weight"], P["stress_embedding.weight"] if stress is not None else None,
+                    pe, x, B, Pn, H, float(H ** 0.5), self.rng, 1, pe_drop, text_mask, P["transformer_encoder_layers.0.norm1.weight"],
+                    P["transformer_encoder_layers.0.norm1.bias"], y1, _b16(y1), m1, r1)
+        else:
+            kk.call("kk_embed_fwd", ids, stress, P["text_embedding.weight"], P["stress_embedding.weight"] if stress is not None else None,
+                    pe, x, B, Pn, H, float(H ** 0.5), self.rng, 1, pe_drop)
         stack = self._encoder_stack_ok(B, Pn)
         if stack:                                         # all layers in ONE persistent launch (csrc/kk_encstack.hip)
-            y1 = self._ln_fwd("enc0.ln1", x, "transformer_encoder_layers.0.norm1", edt)
+            if y1 is None:
+                y1 = self._ln_fwd("enc0.ln1", x, "transformer_encoder_layers.0.norm1", edt)
             x, y1 = self._encoder_stack_fwd(x, B, Pn, text_mask, p_enc)
             self._mark(f"enc{d.enc_layers - 1} fwd done")
         for i in range(0 if not stack else d.enc_layers, d.enc_layers):      # when dropout is on, from _ln_fwd otherwise

@@ -171,6 +171,7 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_glu_fwd": [_P, _P, _L, _I, _P, _U, _F, _I, _P],
     "kk_glu_bwd": [_P, _P, _P, _L, _I, _P, _U, _F, _I, _P],
     "kk_embed_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _U, _F, _P],
+    "kk_embed_ln_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _U, _F, _P, _P, _P, _P, _I, _P, _P, _P],
     "kk_embed_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _U, _F, _P],
     "kk_length_regulate_index": [_P, _P, _P, _P, _I, _I, _I, _P],
     "kk_length_regulate_gather": [_P, _P, _P, _I, _I, _I, _I, _P],

@@ -361,6 +361,35 @@ def test_embed(kk):
     close(ds, sr.grad, 1e-4, 1e-5, "embed dstress")
 
 
+@pytest.mark.parametrize("H,bf,p", [(512, 1, 0.15), (512, 0, 0.0), (64, 0, 0.15), (768, 1, 0.1)])
+def test_embed_ln_fwd_equals_three_launches(kk, H, bf, p):
+    """kk_embed_ln_fwd == kk_ids_eq_zero + kk_embed_fwd + kk_layernorm_fwd, bit for bit (same seed and call site: same dropout masks),
+    and against the float64 LayerNorm of the embedding sum without dropout."""
+    B, P, V = 5, 67, 59
+    g = torch.Generator().manual_seed(H + bf)
+    ids, stress = dev(torch.randint(0, V, (B, P), generator=g)), dev(torch.randint(0, 3, (B, P), generator=g))
+    ids[1, 40:] = 0
+    emb, semb, pe = dev(torch.randn(V, H, generator=g)), dev(torch.randn(3, H, generator=g)), dev(torch.randn(80, H, generator=g))
+    gam, bet = dev(1 + 0.1 * torch.randn(H, generator=g)), dev(0.1 * torch.randn(H, generator=g))
+    ydt = torch.bfloat16 if bf else torch.float32
+    seed = _seed(77) if p > 0 else None
+    xa, ma = torch.empty(B * P, H, device="cuda"), torch.empty(B, P, dtype=torch.uint8, device="cuda")
+    ya, mea, rsa = torch.empty(B * P, H, device="cuda", dtype=ydt), torch.empty(B * P, device="cuda"), torch.empty(B * P, device="cuda")
+    kk.call("kk_ids_eq_zero", ids, ma, B * P)
+    kk.call("kk_embed_fwd", ids, stress, emb, semb, pe, xa, B, P, H, float(H ** 0.5), seed, 1, p)
+    kk.call("kk_layernorm_fwd", xa, gam, bet, ya, mea, rsa, B * P, H, bf)
+    xb, mb = torch.zeros_like(xa), torch.full_like(ma, 7)
+    yb, meb, rsb = torch.zeros_like(ya), torch.zeros_like(mea), torch.zeros_like(rsa)
+    kk.call("kk_embed_ln_fwd", ids, stress, emb, semb, pe, xb, B, P, H, float(H ** 0.5), seed, 1, p, mb, gam, bet, yb, bf, meb, rsb)
+    torch.cuda.synchronize()
+    assert torch.equal(xb, xa) and torch.equal(mb, ma) and int(mb.sum()) >= 27
+    assert torch.equal(meb, mea) and torch.equal(rsb, rsa) and torch.equal(yb, ya)
+    if p == 0.0:
+        x64 = emb.double()[ids.view(-1)] * float(H ** 0.5) + semb.double()[stress.view(-1)] + pe.double()[:P].repeat(B, 1)
+        y64 = (x64 - x64.mean(1, keepdim=True)) / torch.sqrt(x64.var(1, unbiased=False, keepdim=True) + 1e-5) * gam.double() + bet.double()
+        close(yb, y64, 2e-5, 2e-5, "embed + LayerNorm vs float64")
+
+
 def test_length_regulator_golden_bit_exact(kk, golden_dir):
     fx = np.load(os.path.join(golden_dir, "length_regulator.npz"))
     for i in range(int(fx["n"])):
