@@ -276,8 +276,13 @@ int kk_groupnorm_relu_bwd(const float *dy, const float *x, const float *y, const
 /* out[r] = mask[r] ? 0 : dot(x[r,:], w) + b  (Linear(C->1) + masked_fill; also the stop head, model.py:562). */
 int kk_rowdot_fwd(const float *x, const float *w, const float *b, const uint8_t *mask, float *out,
                   int64_t rows, int C, int L, int chunk, int x_bf16, void *stream);
+/* partials == NULL: dw[C] and db[1] are ACCUMULATED with atomics (every workgroup adds to the same C + 1 addresses: ~15 us of
+ * same-address serialisation at 256 workgroups).  partials != NULL (C % 4 == 0): nothing is added; workgroup g writes the plain row
+ * partials[g][C + 4] = (dw | db | pad) and kk_partials_reduce (nblocks = kk_rowdot_bwd_blocks(rows), ncols = C + 1, split = C,
+ * stride = C + 4) sums the rows into dw / db. */
+int kk_rowdot_bwd_blocks(int64_t rows);
 int kk_rowdot_bwd(const float *dout, const float *x, const float *w, const uint8_t *mask, float *dx,
-                  float *dw, float *db, int64_t rows, int C, int L, int chunk, int x_bf16, void *stream);
+                  float *dw, float *db, int64_t rows, int C, int L, int chunk, int x_bf16, float *partials, void *stream);
 /* frame_mask[b,f] = f >= lens[b]; bucketize(right=False) + two embedding adds + masked_fill. */
 int kk_bucket_embed_add_fwd(const float *x, const float *pitch, const float *energy, const float *pbins,
                             const float *ebins, const float *pemb, const float *eemb, const int64_t *lens,

@@ -323,6 +323,101 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float *__restrict
     if (threadIdx.x == 0) atomicAdd(db, ab);
 }
 
+// The same backward, a wave per row and 16-byte accesses: the form above walks its rows one after the other with one 4-byte load in
+// flight per thread behind the row's mask / dout round trip (22 us for 4096 x 256 on the side branch).  Here a wave takes RB rows per
+// trip — their mask bytes, dout scalars and x rows are all in flight together — a lane owns 4 NV columns, and the four waves' weight
+// gradient sums meet in LDS before the workgroup's C atomics.  Same grid (one workgroup per 16 rows): thinner, not burstier.
+template <typename TX, int NV>
+__global__ __launch_bounds__(256) void rowdot_bwd_rows_kernel(const float *__restrict__ dout, const TX *__restrict__ x,
+                                                              const float *__restrict__ w, const uint8_t *__restrict__ mask,
+                                                              float *__restrict__ dx, float *__restrict__ dw, float *__restrict__ db,
+                                                              int64_t rows, int C, int L, int chunk, int rows_per_block,
+                                                              float *__restrict__ partials) {
+    constexpr int RB = 4;
+    __shared__ float red[3][NV * 256 + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t rbeg = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t rend = rbeg + rows_per_block < rows ? rbeg + rows_per_block : rows;
+    float4 wv[NV], aw[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane * 4 + 256 * i;
+        wv[i] = c < C ? ld4(w + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        aw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float ab = 0.f;
+    for (int64_t r0 = rbeg + wave; r0 < rend; r0 += 4 * RB) {
+        float d[RB];
+        float4 xv[RB][NV];
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {                            // every load of the trip first
+            const int64_t r = r0 + 4 * u;
+            const bool in = r < rend;
+            const int64_t rr = in ? r : rbeg;
+            bool dead = !in || (mask && mask[rr]);
+            if (chunk > 0) {
+                const int l = (int)(rr % L), cb = (l / chunk) * chunk;
+                dead = dead || (L - cb < chunk ? L - cb : chunk) < 2;
+            }
+            d[u] = dout[rr];
+            if (dead) d[u] = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = lane * 4 + 256 * i;
+                xv[u][i] = c < C ? ldv4<TX>(x + rr * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const int64_t r = r0 + 4 * u;
+            if (r >= rend) continue;                              // (wave-uniform)
+            ab += d[u];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = lane * 4 + 256 * i;
+                if (c < C) {
+                    aw[i].x += d[u] * xv[u][i].x; aw[i].y += d[u] * xv[u][i].y; aw[i].z += d[u] * xv[u][i].z; aw[i].w += d[u] * xv[u][i].w;
+                    if (dx) st4(dx + r * C + c, make_float4(d[u] * wv[i].x, d[u] * wv[i].y, d[u] * wv[i].z, d[u] * wv[i].w));
+                }
+            }
+        }
+    }
+    // waves 1..3 hand their sums to wave 0
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            float *p = &red[wave - 1][lane * 4 + 256 * i];
+            p[0] = aw[i].x; p[1] = aw[i].y; p[2] = aw[i].z; p[3] = aw[i].w;
+        }
+        if (lane == 0) red[wave - 1][NV * 256] = ab;
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane * 4 + 256 * i;
+            if (c < C) {
+                float t[4] = {aw[i].x, aw[i].y, aw[i].z, aw[i].w};
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] += red[k][c + e];
+                if (partials) {                                   // one plain row per workgroup for kk_partials_reduce: [dw (C) | db | pad]
+                    st4(partials + (int64_t)blockIdx.x * (C + 4) + c, make_float4(t[0], t[1], t[2], t[3]));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) atomicAdd(&dw[c + e], t[e]);
+                }
+            }
+        }
+        if (lane == 0) {
+            const float tb = ab + red[0][NV * 256] + red[1][NV * 256] + red[2][NV * 256];
+            if (partials) partials[(int64_t)blockIdx.x * (C + 4) + C] = tb;
+            else atomicAdd(db, tb);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ bucketize + embedding adds + frame mask (wave per frame)
 __device__ __forceinline__ int bucketize_left(const float *__restrict__ bins, int n, float v) {
     int lo = 0, hi = n;                                  // #{i : bins[i] < v}   (torch.bucketize right=False)
@@ -384,17 +479,18 @@ __global__ __launch_bounds__(256) void bucket_embed_add_bwd_lds_kernel(const flo
     const int c0 = blockIdx.x * BE_CW, col = threadIdx.x & (BE_CW - 1), rsub = threadIdx.x / BE_CW;
     const int64_t per = (rows + gridDim.y - 1) / gridDim.y, r0 = blockIdx.y * per, r1 = r0 + per < rows ? r0 + per : rows;
     if (c0 + col < H) {
-        constexpr int RS = 256 / BE_CW, U = 4;            // U rows in flight per thread: the loop is load-latency bound
+        constexpr int RS = 256 / BE_CW, U = 8;            // U rows in flight per thread: the loop is load-latency bound
         for (int64_t rb = r0 + rsub; rb < r1; rb += RS * U) {
             float d[U];
             int pi[U], ei[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int64_t r = rb + u * RS;
-                const bool ok = r < r1 && !fmask[r];
-                d[u] = ok ? dout[r * H + c0 + col] : 0.f;
-                pi[u] = ok ? pidx[r] : -1;
-                ei[u] = ok ? eidx[r] : 0;
+            for (int u = 0; u < U; ++u) {                     // (four INDEPENDENT loads per row: behind `!fmask[r] ? ... :` they were two round trips)
+                const int64_t r = rb + u * RS, rr = r < r1 ? r : r0;
+                const uint8_t fm = fmask[rr];
+                d[u] = dout[rr * H + c0 + col];
+                pi[u] = pidx[rr];
+                ei[u] = eidx[rr];
+                if (r >= r1 || fm) pi[u] = -1;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -612,13 +708,35 @@ extern "C" int kk_rowdot_fwd(const float *x, const float *w, const float *b, con
     KK_LAUNCH_CHECK("kk_rowdot_fwd");
     return 0;
 }
-extern "C" int kk_rowdot_bwd(const float *dout, const float *x, const float *w, const uint8_t *mask, float *dx,
-                             float *dw, float *db, int64_t rows, int C, int L, int chunk, int x_bf16, void *stream) {
-    KK_REQUIRE(rows > 0 && C > 0 && C <= 1024 && L > 0, "kk_rowdot_bwd: bad shape (C <= 1024)");
+// workgroups (= rows of the partial matrix [blocks][C + 4]: dw | db | pad) of a kk_rowdot_bwd launch over `rows` rows
+extern "C" int kk_rowdot_bwd_blocks(int64_t rows) {
     int blocks = kk_cdiv(rows, 16);
     if (blocks > 1024) blocks = 1024;
+    return kk_cdiv(rows, kk_cdiv(rows, blocks < 1 ? 1 : blocks));
+}
+extern "C" int kk_rowdot_bwd(const float *dout, const float *x, const float *w, const uint8_t *mask, float *dx,
+                             float *dw, float *db, int64_t rows, int C, int L, int chunk, int x_bf16, float *partials, void *stream) {
+    KK_REQUIRE(rows > 0 && C > 0 && C <= 1024 && L > 0, "kk_rowdot_bwd: bad shape (C <= 1024)");
+    const int blocks = kk_rowdot_bwd_blocks(rows);
     const int rpb = kk_cdiv(rows, blocks);
-    blocks = kk_cdiv(rows, rpb);
+    static const int vec = kk_tune_env("KK_ROWDOT_VEC", 1);
+    KK_REQUIRE(!partials || (vec && C % 4 == 0 && (reinterpret_cast<uintptr_t>(partials) & 15) == 0),
+               "kk_rowdot_bwd: partial rows need C %% 4 == 0 and a 16-byte aligned matrix");
+    if (vec && C % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (!dx || (reinterpret_cast<uintptr_t>(dx) & 15) == 0) &&
+        (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+        hipStream_t s = (hipStream_t)stream;
+        const __bf16 *xb = reinterpret_cast<const __bf16 *>(x);
+        const int nv = kk_cdiv(C, 256);
+#define KK_RD(NV)                                                                                                                              \
+    do {                                                                                                                                       \
+        if (x_bf16) hipLaunchKernelGGL((rowdot_bwd_rows_kernel<__bf16, NV>), dim3(blocks), dim3(256), 0, s, dout, xb, w, mask, dx, dw, db, rows, C, L, chunk, rpb, partials); \
+        else hipLaunchKernelGGL((rowdot_bwd_rows_kernel<float, NV>), dim3(blocks), dim3(256), 0, s, dout, x, w, mask, dx, dw, db, rows, C, L, chunk, rpb, partials);          \
+    } while (0)
+        if (nv <= 1) KK_RD(1); else if (nv <= 2) KK_RD(2); else KK_RD(4);
+#undef KK_RD
+        KK_LAUNCH_CHECK("kk_rowdot_bwd");
+        return 0;
+    }
     if (x_bf16)
         hipLaunchKernelGGL(rowdot_bwd_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout,
                            reinterpret_cast<const __bf16 *>(x), w, mask, dx, dw, db, rows, C, L, chunk, rpb);

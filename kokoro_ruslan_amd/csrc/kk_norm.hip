@@ -488,6 +488,67 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float *__rest
     }
 }
 
+// The same pass with 16-byte loads: a thread owns 4 channels, the workgroup's 1024 / C frame lanes walk the slab with every load of
+// four frames in flight (the scalar form above keeps 12 four-byte loads in flight per thread: 25-33 us per launch on the side branch at
+// 4096 x 256).  Same grid — the launch stays as thin as the comment at its call site wants it, it just holds its CUs for less time.
+__global__ __launch_bounds__(256) void gn_bwd_partial_v4_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                                const float *__restrict__ y, const float *__restrict__ gamma,
+                                                                const float *__restrict__ stats, double *__restrict__ scratch,
+                                                                float *__restrict__ dgamma, float *__restrict__ dbeta, int L, int C,
+                                                                int chunk, int nch, int slabs, float inv_keep) {
+    __shared__ double red[4];
+    __shared__ float colred[2][1024];                           // [dgamma | dbeta][frame lane][C]: lanes * C = 1024
+    const int bc = blockIdx.y, b = bc / nch, ci = bc % nch;
+    const int nf = chunk_frames(L, chunk, ci);
+    const int C4 = C >> 2, lanes = 256 / C4, c = (threadIdx.x % C4) * 4, fl = threadIdx.x / C4;
+    const int per = (nf + slabs - 1) / slabs;
+    const int fbeg = blockIdx.x * per, fend = fbeg + per < nf ? fbeg + per : nf;
+    const float mu = stats[bc * 2], rs = stats[bc * 2 + 1];
+    const float4 g = ld4(gamma + c);
+    const int64_t base = ((int64_t)b * L + (int64_t)ci * chunk) * C;
+    float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+    float s1 = 0.f, s2 = 0.f;
+    if (nf >= 2) {
+        constexpr int U = 4;
+        for (int f0 = fbeg + fl; f0 < fend; f0 += lanes * U) {
+            float4 dv[U], xv[U], yv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int f = f0 + u * lanes, ff = f < fend ? f : fbeg;
+                const int64_t o = base + (int64_t)ff * C + c;
+                dv[u] = ld4(dy + o); xv[u] = ld4(x + o); yv[u] = ld4(y + o);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (f0 + u * lanes >= fend) continue;
+                const float dd[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w}, xx[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+                const float yy[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w}, gg[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = yy[e] > 0.f ? dd[e] * inv_keep : 0.f;
+                    const float xh = (xx[e] - mu) * rs;
+                    ag[e] += d * xh; ab[e] += d;
+                    s1 += d * gg[e]; s2 += d * gg[e] * xh;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { colred[0][fl * C + c + e] = ag[e]; colred[1][fl * C + c + e] = ab[e]; }
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+        float tg = 0.f, tb = 0.f;
+        for (int l = 0; l < lanes; ++l) { tg += colred[0][l * C + threadIdx.x]; tb += colred[1][l * C + threadIdx.x]; }
+        if (tg != 0.f || tb != 0.f) { atomicAdd(&dgamma[threadIdx.x], tg); atomicAdd(&dbeta[threadIdx.x], tb); }
+    }
+    const double d1 = block_sum_256_d((double)s1, red);
+    const double d2 = block_sum_256_d((double)s2, red);
+    if (threadIdx.x == 0 && fbeg < fend) {
+        atomicAdd(&scratch[bc * 2], d1);
+        atomicAdd(&scratch[bc * 2 + 1], d2);
+    }
+}
+
 template <typename TO>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                            const float *__restrict__ y, const float *__restrict__ gamma,
@@ -682,8 +743,13 @@ extern "C" int kk_groupnorm_relu_bwd(const float *dy, const float *x, const floa
     // 128 slabs the kernel itself is 4x faster and the train step 1 % SLOWER (796K -> 790K -> 786K frames/s) — a burst of
     // workgroups disturbs the critical chain more than a long thin launch does; 8 and 4 slabs are slower again.
     const int slabs = 16;
-    hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(slabs, total), dim3(256), 0, s, dy, x, y, gamma, stats, scratch, dgamma,
-                       dbeta, L, C, chunk, nch, slabs, inv_keep);
+    static const int v4 = kk_tune_env("KK_GN_BWD_V4", 1);
+    if (v4 && C >= 4 && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gamma)) & 15) == 0)
+        hipLaunchKernelGGL(gn_bwd_partial_v4_kernel, dim3(slabs, total), dim3(256), 0, s, dy, x, y, gamma, stats, scratch, dgamma,
+                           dbeta, L, C, chunk, nch, slabs, inv_keep);
+    else
+        hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(slabs, total), dim3(256), 0, s, dy, x, y, gamma, stats, scratch, dgamma,
+                           dbeta, L, C, chunk, nch, slabs, inv_keep);
     const int64_t total4 = (int64_t)B * L * C / 4;
     int blocks = kk_cdiv(total4, 256);
     if (blocks > 4096) blocks = 4096;

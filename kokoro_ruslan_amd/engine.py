@@ -225,6 +225,9 @@ class KokoroEngine:
         # key-padding mask + embedding (+ PE, dropout) + the first encoder layer's pre-LayerNorm as one launch (kk_embed_ln_fwd): the
         # head of the critical path in front of the encoder forward is 3 dependent launches instead of 5
         self.fuse_enc_prologue = True
+        # kk_rowdot_bwd (the predictors' / stop head's Linear(C -> 1) backward) leaves its weight-gradient sums as one plain row per
+        # workgroup for the backward's single kk_partials_reduce instead of 256 workgroups' atomics on the same C + 1 addresses
+        self.rowdot_partials = True
         # The zero-fill at the start of an accumulation cycle skips what the cycle's first grouped weight-gradient launches
         # overwrite (89 % of the arena at default dims; the fill runs beside the latency-bound encoder launch: 20 us of the step).
         # Which tensors those are is RECORDED from the launches of a step (per precision mode), never assumed, and a step that
@@ -559,6 +562,16 @@ class KokoroEngine:
         nb = kk.load().kk_norm_bwd_blocks(rows, H)
         part = self._buf(key + ".part", nb, ncols)
         self._reduce_lists[self._tmp_ns].append((part, dst0, dst1, nb, ncols, split))
+        return part
+
+    def _rowdot_partials(self, key, rows, C, dw, db):
+        """[blocks][C + 4] partial (dw | db) rows of one kk_rowdot_bwd launch, summed by the backward's kk_partials_reduce — or None
+        (same-address atomics inside the launch) when C is not a multiple of 4."""
+        if C % 4 or not self.rowdot_partials:
+            return None
+        nb = kk.load().kk_rowdot_bwd_blocks(rows)
+        part = self._buf(key + ".rdpart", nb, C + 4)
+        self._reduce_lists[self._tmp_ns].append((part, dw.view(-1), db.view(-1), nb, C + 1, C, C + 4))
         return part
 
     def _headnorm_partials(self, key, rows, dgains):
@@ -977,7 +990,8 @@ class KokoroEngine:
         dy, dc = self._buf("tmp.vp_dy", rows, Fv), self._buf("tmp.vp_dc", rows, Fv, dtype=dc_dt)
         y1 = self._buf(f"{key}.y1", rows, Fv)
         kk.call("kk_rowdot_bwd", dout, y1, P[f"{prefix}.linear.weight"], mask, dy, G[f"{prefix}.linear.weight"],
-                G[f"{prefix}.linear.bias"], rows, Fv, L, CHUNK, 0)
+                G[f"{prefix}.linear.bias"], rows, Fv, L, CHUNK, 0,
+                self._rowdot_partials(key, rows, Fv, G[f"{prefix}.linear.weight"], G[f"{prefix}.linear.bias"]))
         for li in (1, 0):
             c, y, stats = self._buf(f"{key}.c{li}", rows, Fv), self._buf(f"{key}.y{li}", rows, Fv), self._buf(f"{key}.st{li}", B * nch, 2)
             cin = Fv if li == 1 else H
@@ -1231,7 +1245,8 @@ class KokoroEngine:
             # the output heads' weight gradients have no consumer on the decoder chain (the stop head's input is
             # detached, model.py:561-562): 50 us off the critical path
             kk.call("kk_rowdot_bwd", dstop, dec_out, P["stop_token_predictor.weight"], None, None, G["stop_token_predictor.weight"],
-                    G["stop_token_predictor.bias"], Nd, H, T, 0, _b16(dec_out))
+                    G["stop_token_predictor.bias"], Nd, H, T, 0, _b16(dec_out),
+                    self._rowdot_partials("stop", Nd, H, G["stop_token_predictor.weight"], G["stop_token_predictor.bias"]))
             self._wgrad(dmel.view(Nd, M), dec_out, G["mel_projection_out.weight"], G["mel_projection_out.bias"])
             dpitch_p, denergy_p = dpitch, denergy
             if Tp != T:                               # frames past T carry no loss: zero gradient there

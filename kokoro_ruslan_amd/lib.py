@@ -183,7 +183,8 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_groupnorm_relu_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _U, _F, _P],
     "kk_groupnorm_relu_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "kk_rowdot_fwd": [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
-    "kk_rowdot_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
+    "kk_rowdot_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P],
+    "kk_rowdot_bwd_blocks": [_L],
     "kk_bucket_embed_add_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "kk_bucket_embed_add_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "kk_dropout_fwd": [_P, _P, _L, _P, _L, _I, _I, _P, _U, _F, _U, _F, _U, _F, _P],

@@ -473,7 +473,7 @@ def test_variance_predictor_chain(kk, L):
     close(out.view(B, L), ref, 2e-4, 2e-4, "varpred fwd")
     dy = torch.empty(rows, Fv, device="cuda")
     kk.call("kk_rowdot_bwd", dev(dout), inp, Pd["vp.linear.weight"], md, dy, Gd["vp.linear.weight"], Gd["vp.linear.bias"],
-            rows, Fv, L, 512, 0)
+            rows, Fv, L, 512, 0, None)
     for li in (1, 0):
         col, c, y, stats, cin = acts[li]
         dc = torch.empty(rows, Fv, device="cuda")
@@ -518,6 +518,78 @@ def test_bucket_embed_add(kk):
     kk.call("kk_bucket_embed_add_bwd", dev(dout), pi, ei, fmd, dp, de, B, T, H, nb)
     close(dp, pr.grad, 1e-4, 1e-5, "bucket-embed dpitch_emb")
     close(de, er.grad, 1e-4, 1e-5, "bucket-embed denergy_emb")
+
+
+@pytest.mark.parametrize("B,L,C,chunk,xbf", [(8, 512, 256, 0, 0), (8, 512, 256, 0, 1), (8, 64, 256, 0, 0), (3, 437, 256, 128, 0),
+                                              (5, 99, 512, 0, 1), (2, 33, 100, 0, 0)])
+def test_side_branch_backward_kernels_model_shapes(kk, B, L, C, chunk, xbf):
+    """The predictors' three backward kernels of the side branch at the model's shapes against float64: kk_rowdot_bwd (wave-per-row
+    16-byte form; C = 100 takes... the scalar form's column ownership stays for C % 4 != 0 only), kk_groupnorm_relu_bwd (16-byte partial
+    sums) and kk_bucket_embed_add_bwd (independent loads)."""
+    g = torch.Generator().manual_seed(B * L + C)
+    rows = B * L
+    # ---- rowdot backward: dx = d w, dw = sum_r d x, db = sum_r d with masked / dead rows
+    x = dev(_r16(torch.randn(rows, C, generator=g)))
+    w, dout = dev(torch.randn(C, generator=g)), dev(torch.randn(rows, generator=g))
+    mask = dev((torch.rand(rows, generator=g) < 0.2).to(torch.uint8))
+    dx, dw, db = torch.full((rows, C), 9.0, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(1, device="cuda")
+    kk.call("kk_rowdot_bwd", dout, x.bfloat16() if xbf else x, w, mask, dx, dw, db, rows, C, L, chunk, xbf, None)
+    d64 = dout.double() * (mask == 0).double()
+    if chunk > 0:
+        l = torch.arange(rows, device="cuda") % L
+        cb = (l // chunk) * chunk
+        d64 = d64 * (torch.minimum(torch.tensor(chunk, device="cuda"), L - cb) >= 2).double()
+    close(dx, d64[:, None] * w.double()[None], 1e-6, 1e-6, "rowdot dx")
+    close(dw, (d64[:, None] * x.double()).sum(0), 2e-4, 2e-5, "rowdot dw")
+    close(db, d64.sum().view(1), 2e-4, 2e-5, "rowdot db")
+    if C % 4 == 0:      # ... and with one partial row per workgroup + kk_partials_reduce instead of the atomics: added onto what is there
+        nb = kk.load().kk_rowdot_bwd_blocks(rows)
+        part = torch.full((nb, C + 4), 7.0, device="cuda")
+        dw2, db2, dx2 = torch.full((C,), 0.5, device="cuda"), torch.full((1,), 0.25, device="cuda"), torch.empty(rows, C, device="cuda")
+        kk.call("kk_rowdot_bwd", dout, x.bfloat16() if xbf else x, w, mask, dx2, dw2, db2, rows, C, L, chunk, xbf, part)
+        assert float(dw2[0]) == 0.5 and float(db2[0]) == 0.25, "with partial rows the launch must not touch the gradient vectors"
+        kk.call("kk_partials_reduce", kk.reduce_table([(part, dw2, db2, nb, C + 1, C, C + 4)], "cuda"), 1, C + 1)
+        assert torch.equal(dx2, dx)
+        close(dw2 - 0.5, (d64[:, None] * x.double()).sum(0), 2e-4, 2e-5, "rowdot dw through partial rows")
+        close(db2 - 0.25, d64.sum().view(1), 2e-4, 2e-5, "rowdot db through partial rows")
+    # ---- GroupNorm + ReLU backward (one group per (batch item, chunk of frames))
+    if C <= 256 and 256 % C == 0:
+        ck = chunk if chunk > 0 else 512
+        xg, gam, bet = dev(torch.randn(rows, C, generator=g)), dev(torch.rand(C, generator=g) + 0.5), dev(torch.randn(C, generator=g) * 0.1)
+        nch = (L + ck - 1) // ck
+        y, st = torch.empty(rows, C, device="cuda"), torch.empty(B * nch, 2, device="cuda")
+        scr = torch.zeros(2 * B * nch, dtype=torch.float64, device="cuda")
+        kk.call("kk_groupnorm_relu_fwd", xg, gam, bet, y, st, scr, B, L, C, ck, None, 0, 0.0)
+        dy = dev(torch.randn(rows, C, generator=g))
+        dxg, dg, dbt = torch.empty(rows, C, device="cuda"), torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        kk.call("kk_groupnorm_relu_bwd", dy, xg, y, gam, st, dxg, dg, dbt, scr, B, L, C, ck, 0.0, 0)
+        x64 = xg.double().view(B, L, C).requires_grad_(True)
+        g64, b64 = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+        outs = []
+        for c0 in range(0, L, ck):
+            xc = x64[:, c0:c0 + ck]
+            if xc.shape[1] < 2:
+                outs.append(torch.zeros_like(xc))
+                continue
+            mu, var = xc.mean((1, 2), keepdim=True), xc.var((1, 2), unbiased=False, keepdim=True)
+            outs.append(torch.relu((xc - mu) / torch.sqrt(var + 1e-5) * g64 + b64))
+        torch.cat(outs, 1).backward(dy.double().view(B, L, C))
+        close(dxg, x64.grad.view(rows, C), 2e-4, 2e-4, "groupnorm dx")
+        close(dg, g64.grad, 2e-3, 2e-4, "groupnorm dgamma")
+        close(dbt, b64.grad, 2e-3, 2e-4, "groupnorm dbeta")
+    # ---- bucket embedding backward: scatter-add of the unmasked frames' gradient rows into the pitch / energy tables
+    H, nb = 512, 256
+    dout2 = dev(torch.randn(rows, H, generator=g))
+    pi, ei = dev(torch.randint(0, nb, (rows,), generator=g).int()), dev(torch.randint(0, nb, (rows,), generator=g).int())
+    fm = dev((torch.rand(rows, generator=g) < 0.25).to(torch.uint8))
+    dp, de = torch.zeros(nb, H, device="cuda"), torch.zeros(nb, H, device="cuda")
+    kk.call("kk_bucket_embed_add_bwd", dout2, pi, ei, fm, dp, de, B, L, H, nb)
+    d2 = dout2.double() * (fm == 0).double()[:, None]
+    rp, re = torch.zeros(nb, H, dtype=torch.float64, device="cuda"), torch.zeros(nb, H, dtype=torch.float64, device="cuda")
+    rp.index_add_(0, pi.long(), d2)
+    re.index_add_(0, ei.long(), d2)
+    close(dp, rp, 2e-4, 2e-5, "bucket-embed dpitch_emb")
+    close(de, re, 2e-4, 2e-5, "bucket-embed denergy_emb")
 
 
 def test_small_helpers(kk):
@@ -938,8 +1010,8 @@ def test_elementwise_bf16_storage(kk):
     close(o16, o32, 1e-5, 1e-5, "rowdot fwd bf16 x")
     dout = dev(torch.randn(B * L, generator=g))
     dw32, dw16, db32, db16 = (torch.zeros(n, device="cuda") for n in (C, C, 1, 1))
-    kk.call("kk_rowdot_bwd", dout, xr, w, None, None, dw32, db32, B * L, C, L, 0, 0)
-    kk.call("kk_rowdot_bwd", dout, xr.bfloat16(), w, None, None, dw16, db16, B * L, C, L, 0, 1)
+    kk.call("kk_rowdot_bwd", dout, xr, w, None, None, dw32, db32, B * L, C, L, 0, 0, None)
+    kk.call("kk_rowdot_bwd", dout, xr.bfloat16(), w, None, None, dw16, db16, B * L, C, L, 0, 1, None)
     close(dw16, dw32, 1e-4, 1e-5, "rowdot dw bf16 x")
     close(db16, db32, 1e-4, 1e-5, "rowdot db bf16 x")
     # column sums of a bf16 matrix; fp32 -> bf16 cast
