@@ -1504,8 +1504,19 @@ __device__ __forceinline__ int kk_xb(int r) { return (((r >> 1) & 1) << 1) | ((r
 // of dma_rows128.  The gradient of the raw projection comes back in the accumulator layout (out), for store_rows_via_lds.
 // (core: the per-column contributions to the gain gradient come back in cr[32], accumulator order, for a caller whose colred buffer
 //  shares LDS with the images and can only be written behind a barrier)
+// the lane's 32 gain values (its columns db * 32 + 8 g + 4 half + e), fetched EARLY by the third-generation epilogues: eight dependent
+// global loads in the middle of the row arithmetic were ~1 us of each head-norm epilogue
+struct HnGain { float4 g4[8]; };
+__device__ __forceinline__ HnGain hn_load_gain(const float *gain, int half) {
+    HnGain r;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) r.g4[db * 4 + g] = ld4(gain + db * 32 + 8 * g + 4 * half);
+    return r;
+}
 __device__ __forceinline__ void hn_bwd_row2_core(const f32x16 (&acc)[2], float mul, bool valid, const char *rawimg, const char *cosimg,
-                                                 const char *sinimg, int row, bool rope, const float *gain, int half, float (&cr)[32],
+                                                 const char *sinimg, int row, bool rope, const HnGain &gn, int half, float (&cr)[32],
                                                  f32x16 (&out)[2]) {
     float dn[32], v[32];
     asm volatile("" : "+v"(row));          // (or the image addresses below are computed in the prologue and spilled across the main loop)
@@ -1545,7 +1556,7 @@ __device__ __forceinline__ void hn_bwd_row2_core(const f32x16 (&acc)[2], float m
     for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 g4 = ld4(gain + db * 32 + 8 * g + 4 * half);
+            const float4 g4 = gn.g4[db * 4 + g];
             const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -1570,11 +1581,61 @@ __device__ __forceinline__ void hn_colred_store(const float (&cr)[32], int half,
 #pragma unroll
             for (int e = 0; e < 4; ++e) colred_row[db * 32 + 8 * g + 4 * half + e] = cr[db * 16 + 4 * g + e];
 }
+// Column sums of cr over the 32 rows a half-wave holds (lane = row), in registers: a transposing butterfly — at the step with xor mask m a
+// lane keeps the half of its live values whose index has bit m like its own lane number and hands the other half to its partner — 31
+// shuffle-adds, after which lane (l31, half) holds the sum over the 32 rows of cr[l31], i.e. of column
+//   d = (l31 >> 4) * 32 + 8 * ((l31 >> 2) & 3) + 4 * half + (l31 & 3).
+// Replaces, per head-norm epilogue, 32 LDS stores per lane into colred[128][65], two workgroup barriers and ONE wave adding up 128 rows.
+template <int N> __device__ __forceinline__ void hn_colsum_step(float (&v)[32], int l31) {      // N live values, xor mask N / 2
+    const bool up = (l31 & (N / 2)) != 0;
+#pragma unroll
+    for (int j = 0; j < N / 2; ++j) {
+        const float keep = up ? v[j + N / 2] : v[j], send = up ? v[j] : v[j + N / 2];
+        v[j] = keep + __shfl_xor(send, N / 2, 64);
+    }
+}
+__device__ __forceinline__ float hn_colsum32(float (&v)[32], int l31) {
+    hn_colsum_step<32>(v, l31);
+    hn_colsum_step<16>(v, l31);
+    hn_colsum_step<8>(v, l31);
+    hn_colsum_step<4>(v, l31);
+    hn_colsum_step<2>(v, l31);
+    return v[0];
+}
+__device__ __forceinline__ int hn_colsum32_col(int l31, int half) { return (l31 >> 4) * 32 + 8 * ((l31 >> 2) & 3) + 4 * half + (l31 & 3); }
+// store_rows_via_lds through a tile of 16 rows (2304 bytes), two halves one after the other: fits the wave's OWN 4 KB of a dead
+// 128-row image, so no workgroup barrier stands between the head-norm arithmetic and the stores.
+__device__ __forceinline__ void store_rows_via_lds16(__bf16 *dst_row0, int64_t ld, int nvalid, const f32x16 (&acc)[2], float mul,
+                                                     char *tile, int lane, int wt) {
+    const int l31 = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if ((l31 >> 4) == h) {
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (__bf16)(acc[db][4 * g + e] * mul);
+                    *reinterpret_cast<bf16x4 *>(tile + (l31 & 15) * 144 + (db * 32 + 8 * g + 4 * half) * 2) = v;
+                }
+        }
+        __builtin_amdgcn_wave_barrier();                       // (one wave: its LDS operations complete in order)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = (lane >> 3) + 8 * j, c = lane & 7;
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(tile + row * 144 + c * 16);
+            if (16 * h + row < nvalid) kk_store16(dst_row0 + (int64_t)(16 * h + row) * ld + c * 8, v, wt);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
 __device__ __forceinline__ void hn_bwd_row2(const f32x16 (&acc)[2], float mul, bool valid, const char *rawimg, const char *cosimg,
                                             const char *sinimg, int row, bool rope, const float *gain, int half, float *colred_row,
                                             f32x16 (&out)[2]) {
     float cr[32];
-    hn_bwd_row2_core(acc, mul, valid, rawimg, cosimg, sinimg, row, rope, gain, half, cr, out);
+    hn_bwd_row2_core(acc, mul, valid, rawimg, cosimg, sinimg, row, rope, hn_load_gain(gain, half), half, cr, out);
     hn_colred_store(cr, half, colred_row);
 }
 // the three epilogue images of a 128-row block (rows row0 .. of a sequence of S rows, position = row): raw | cos | sin
@@ -1977,7 +2038,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dqpass_kernel(AttnArgs a) {
     __syncthreads();
     f32x16 dx[2];
     float cr[32];
-    hn_bwd_row2_core(dq, a.scale, qvalid, smem_raw, smem_raw + 16384, smem_raw + 32768, wave * 32 + l31, a.hn[0].rope != 0, a.hn[0].gain, half, cr, dx);
+    hn_bwd_row2_core(dq, a.scale, qvalid, smem_raw, smem_raw + 16384, smem_raw + 32768, wave * 32 + l31, a.hn[0].rope != 0, hn_load_gain(a.hn[0].gain, half), half, cr, dx);
     __syncthreads();                                           // every wave has read its image rows: colred and the store tiles lie over them
     float *colred = reinterpret_cast<float *>(smem_raw);       // [128 rows][65]
     hn_colred_store(cr, half, colred + (wave * 32 + l31) * 65);
