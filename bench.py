@@ -195,6 +195,11 @@ def kernel_table(records, math_bf16: bool):
                 key, bm_, bn_ = f"{x[2]} (dY.W dgrad + Delta epilogue, 128x128 tiles, loader waves)", x[0], x[1]
             flops, byts = 2.0 * M * N * K, 2.0 * (M * K + N * K + 2 * M * N)
             floor = lds_floor_us(M * N * K, bm_, bn_)
+        elif name == "kk_linear_tail_fwd":              # (ldx, K, y_round, n_bf16, rows, H, S, ...): w_o projection + sub-layer tail, one row-owner launch
+            K, rows_, H_ = int(sc[1]), int(sc[4]), int(sc[5])
+            key = "linear_tail_fwd_kernel (attention output projection + dropout / residual / LayerNorm tail, 32 rows x 512 columns per workgroup)"
+            flops = 2.0 * rows_ * H_ * K
+            byts = 2.0 * rows_ * K + 2.0 * H_ * K + rows_ * H_ * (4.0 + 4.0 + 2.0)      # x, W once; residual in, stream out, LayerNorm out
         elif name in ("kk_attn_bwd", "kk_attn_bwd_kb"):  # (B, h, Sq, Sk, 7 row strides, causal, scale, site, p_drop, math, io_bf16); _kb: + the keep-bit buffer (a tensor)
             B, h, Sq, Sk = (int(x) for x in sc[:4])
             causal = int(sc[-6])
