@@ -259,6 +259,20 @@ __device__ __forceinline__ void phase_qkv(const Ctx &c, const KkEncLayer &L) {
         for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (active) stage_rows<true, HT>(c.smem, L.y1, H, (int64_t)c.b * S + r0, S - r0, 64, H);
         c.substamp();
+        // (the epilogue's table rows are touched HERE, under the panel's DMA: read first in the epilogue they were a dependent L2 round
+        //  trip per phase on the launch's critical chain)
+        const int sub = lane & 15;
+        const float *gain = prt == 0 ? L.g_q : (prt == 1 ? L.g_k : L.g_v);
+        const float4 g = ld4(gain + sub * 4);
+        float tw = 0.f;
+        if (active && prt < 2) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int r = r0 + wave * 16 + it * 4 + (lane >> 4), pos = r < S ? r : S - 1;
+                tw += c.a->cos_t[pos * 64 + sub * 4] + c.a->sin_t[pos * 64 + sub * 4];      // warms the lines kk_headnorm_rope reads below
+            }
+        }
+        asm volatile("" :: "v"(tw));
         dma_wait();
         c.substamp();
         const bool work = active && r0 + wave * 16 < S;
@@ -268,9 +282,6 @@ __device__ __forceinline__ void phase_qkv(const Ctx &c, const KkEncLayer &L) {
         if (work) {
             float *tile = c.tile();
             acc_to_tile<4>(tile, acc, 4);
-            const int sub = lane & 15;
-            const float *gain = prt == 0 ? L.g_q : (prt == 1 ? L.g_k : L.g_v);
-            const float4 g = ld4(gain + sub * 4);
             const bool rope = prt < 2;
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
@@ -464,6 +475,7 @@ __device__ __forceinline__ void phase_wo(const Ctx &c, const KkEncLayer &L) {
         f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
         if (active) stage_rows<true, HT>(c.smem, L.ctx, H, (int64_t)c.b * S + r0, S - r0, 64, H);
         c.substamp();
+        const float4 bv_pre = active ? ld4(L.b_o + c.member * 16 + (lane & 3) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);      // (under the DMA)
         dma_wait();
         c.substamp();
         const bool work = active && r0 + wave * 16 < S;
@@ -476,7 +488,7 @@ __device__ __forceinline__ void phase_wo(const Ctx &c, const KkEncLayer &L) {
             const int rl = lane >> 2, cc = (lane & 3) * 4, r = r0 + wave * 16 + rl, col = c.member * 16 + cc;
             if (r < S) {
                 float4 s = ld4(tile + rl * TPW + cc);
-                const float4 bv = ld4(L.b_o + col);
+                const float4 bv = bv_pre;
                 s.x += bv.x; s.y += bv.y; s.z += bv.z; s.w += bv.w;
                 stf4(Y, (uint32_t)((((int64_t)c.b * S + r) * H + col) * 4), s);
             }
@@ -501,6 +513,13 @@ __device__ __forceinline__ void phase_lin1(const Ctx &c, const KkEncLayer &L) {
         for (int j = 0; j < 6; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (active) stage_rows<true, HT>(c.smem, L.y2, H, (int64_t)c.b * S + r0, S - r0, 64, H);
         c.substamp();
+        float4 ba_pre[3], bb_pre[3];                                 // (under the DMA)
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) {
+            const int col = (first + (jj < cnt ? jj : 0)) * 16 + (lane & 3) * 4;
+            ba_pre[jj] = active ? ld4(L.b1 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bb_pre[jj] = active ? ld4(L.b1 + F + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         dma_wait();
         c.substamp();
         const bool work = active && r0 + wave * 16 < S;
@@ -516,10 +535,12 @@ __device__ __forceinline__ void phase_lin1(const Ctx &c, const KkEncLayer &L) {
             const int rl = lane >> 2, cc = (lane & 3) * 4, r = r0 + wave * 16 + rl;
             if (r < S) {
                 const int64_t row = (int64_t)c.b * S + r;
-                for (int jj = 0; jj < cnt; ++jj) {
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) {
+                    if (jj >= cnt) break;
                     const int col = (first + jj) * 16 + cc;
                     float4 av = ld4(tile + rl * TPW + 16 * jj + cc), bv = ld4(tile + rl * TPW + 16 * (cnt + jj) + cc);
-                    const float4 ba = ld4(L.b1 + col), bb = ld4(L.b1 + F + col);
+                    const float4 ba = ba_pre[jj], bb = bb_pre[jj];
                     av.x += ba.x; av.y += ba.y; av.z += ba.z; av.w += ba.w;
                     bv.x += bb.x; bv.y += bb.y; bv.z += bb.z; bv.w += bb.w;
                     const u32x2 a16 = pack4(av), b16 = pack4(bv);    // what the backward will read
@@ -551,6 +572,7 @@ __device__ __forceinline__ void phase_lin2(const Ctx &c, const KkEncLayer &L) {
         f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
         if (active) stage_rows<true, FT>(c.smem, L.g, F, (int64_t)c.b * S + r0, S - r0, 32, F);
         c.substamp();
+        const float4 b2_pre = active ? ld4(L.b2 + c.member * 16 + (lane & 3) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);      // (under the DMA)
         dma_wait();
         c.substamp();
         const bool work = active && r0 + rbw * 16 < S;
@@ -569,7 +591,7 @@ __device__ __forceinline__ void phase_lin2(const Ctx &c, const KkEncLayer &L) {
             const int rl = lane >> 2, cc = (lane & 3) * 4, r = r0 + rbw * 16 + rl, col = c.member * 16 + cc;
             if (r < S) {
                 float4 s = ld4(tile + rl * TPW + cc);
-                const float4 t = ld4(other + rl * TPW + cc), bv = ld4(L.b2 + col);
+                const float4 t = ld4(other + rl * TPW + cc), bv = b2_pre;
                 s.x += t.x + bv.x; s.y += t.y + bv.y; s.z += t.z + bv.z; s.w += t.w + bv.w;
                 st8(Y, (uint32_t)((((int64_t)c.b * S + r) * H + col) * 2), pack4(s));
             }
