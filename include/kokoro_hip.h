@@ -288,6 +288,14 @@ int kk_bucket_embed_add_fwd(const float *x, const float *pitch, const float *ene
                             const float *ebins, const float *pemb, const float *eemb, const int64_t *lens,
                             float *out, int32_t *pidx, int32_t *eidx, uint8_t *frame_mask, int B, int T,
                             int H, int nbins, int out_bf16, void *stream);
+/* kk_length_regulate_gather + kk_bucket_embed_add_fwd (+ kk_specaug when seed != NULL) in ONE launch, a wave per frame: xf = the
+ * regulated encoder rows (fp32, the predictors' input), out = the cross-attention memory (fp32 / bf16) with the SpecAugment masks of
+ * (seed, site) already applied.  Same bits as the three launches (variance_predictor.py:338-439, model.py:636-639). */
+int kk_regulate_embed_fwd(const float *enc, const int64_t *idx, const float *pitch, const float *energy, const float *pbins,
+                          const float *ebins, const float *pemb, const float *eemb, const int64_t *lens, float *xf, float *out,
+                          int32_t *pidx, int32_t *eidx, uint8_t *frame_mask, int B, int P, int T, int H, int nbins, int out_bf16,
+                          const uint32_t *seed, uint32_t site, int time_mask_max, int feat_mask_max, int n_time, int n_feat,
+                          void *stream);
 int kk_bucket_embed_add_bwd(const float *dout, const int32_t *pidx, const int32_t *eidx,
                             const uint8_t *frame_mask, float *dpemb, float *deemb, int B, int T, int H,
                             int nbins, void *stream);   /* nbins = rows of the two embedding tables */

@@ -449,6 +449,61 @@ __global__ __launch_bounds__(256) void bucket_embed_add_fwd_kernel(
     }
 }
 
+// Length-regulator gather + the bucket-embedding adds + SpecAugment as ONE launch, a wave per frame: the three launches between the
+// encoder's last LayerNorm and the cross-attention K/V GEMM (kk_length_regulate_gather, kk_bucket_embed_add_fwd, kk_specaug) sit on
+// the step's critical chain and were a round trip of the [frames, H] tensor each.  Same expressions, same bits; the SpecAugment decisions
+// are the same functions of (seed, site, sample, mask number) as specaug_kernel's (kk_dropout.hip): its backward is unchanged.
+template <typename TO>
+__global__ __launch_bounds__(256) void regulate_embed_fwd_kernel(
+    const float *__restrict__ enc, const int64_t *__restrict__ idx, const float *__restrict__ pitch, const float *__restrict__ energy,
+    const float *__restrict__ pbins, const float *__restrict__ ebins, const float *__restrict__ pemb, const float *__restrict__ eemb,
+    const int64_t *__restrict__ lens, float *__restrict__ xf, TO *__restrict__ out, int32_t *__restrict__ pidx, int32_t *__restrict__ eidx,
+    uint8_t *__restrict__ fmask, int64_t rows, int P, int T, int H, int nbins, const uint32_t *__restrict__ seedp, uint32_t site, int tmax,
+    int fmax, int nt, int nf) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t seed = seedp ? *seedp : 0u;
+    const int time_limit = max(1, min(tmax, T / 4));
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+        const int b = (int)(r / T), f = (int)(r - (int64_t)b * T);
+        const int64_t j = idx[r];
+        const bool masked = f >= lens[b];
+        const int pi = bucketize_left(pbins, nbins - 1, pitch[r]);
+        const int ei = bucketize_left(ebins, nbins - 1, energy[r]);
+        if (lane == 0) { pidx[r] = pi; eidx[r] = ei; fmask[r] = masked ? 1 : 0; }
+        bool tm = false;
+        if (seedp) {
+            for (int k = 0; k < nt; ++k) {
+                const int len = (int)(kk_hash(seed, site, (uint64_t)b * 64 + 2 * k) % (uint32_t)time_limit);
+                const int t0 = (int)(kk_hash(seed, site, (uint64_t)b * 64 + 2 * k + 1) % (uint32_t)max(1, T - len));
+                tm |= (f >= t0 && f < t0 + len);
+            }
+        }
+        for (int c = lane * 4; c < H; c += 256) {
+            const float4 a = j >= 0 ? ld4(enc + ((int64_t)b * P + j) * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            st4(xf + r * H + c, a);
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!masked) {
+                const float4 p = ld4(pemb + (int64_t)pi * H + c), e = ld4(eemb + (int64_t)ei * H + c);
+                o = make_float4(a.x + p.x + e.x, a.y + p.y + e.y, a.z + p.z + e.z, a.w + p.w + e.w);
+            }
+            if (seedp) {
+                bool fm[4] = {tm, tm, tm, tm};
+                for (int k = 0; k < nf; ++k) {
+                    const int len = (int)(kk_hash(seed, site, (uint64_t)b * 64 + 32 + 2 * k) % (uint32_t)max(1, fmax));
+                    const int f0 = (int)(kk_hash(seed, site, (uint64_t)b * 64 + 32 + 2 * k + 1) % (uint32_t)max(1, H - len));
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; ++e2) fm[e2] |= (c + e2 >= f0 && c + e2 < f0 + len);
+                }
+                if (fm[0]) o.x = 0.f;
+                if (fm[1]) o.y = 0.f;
+                if (fm[2]) o.z = 0.f;
+                if (fm[3]) o.w = 0.f;
+            }
+            stv4<TO>(out + r * H + c, o);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void bucket_embed_add_bwd_kernel(const float *__restrict__ dout, const int32_t *__restrict__ pidx,
                                                                    const int32_t *__restrict__ eidx, const uint8_t *__restrict__ fmask,
                                                                    float *__restrict__ dpemb, float *__restrict__ deemb, int64_t rows, int H) {
@@ -762,6 +817,29 @@ extern "C" int kk_bucket_embed_add_fwd(const float *x, const float *pitch, const
         hipLaunchKernelGGL(bucket_embed_add_fwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, pitch, energy, pbins,
                            ebins, pemb, eemb, lens, out, pidx, eidx, frame_mask, rows, T, H, nbins);
     KK_LAUNCH_CHECK("kk_bucket_embed_add_fwd");
+    return 0;
+}
+extern "C" int kk_regulate_embed_fwd(const float *enc, const int64_t *idx, const float *pitch, const float *energy, const float *pbins,
+                                     const float *ebins, const float *pemb, const float *eemb, const int64_t *lens, float *xf, float *out,
+                                     int32_t *pidx, int32_t *eidx, uint8_t *frame_mask, int B, int P, int T, int H, int nbins, int out_bf16,
+                                     const uint32_t *seed, uint32_t site, int time_mask_max, int feat_mask_max, int n_time, int n_feat,
+                                     void *stream) {
+    KK_REQUIRE(B > 0 && P > 0 && T > 0 && H > 0 && H % 4 == 0 && nbins > 1, "kk_regulate_embed_fwd: bad shape");
+    KK_REQUIRE(enc && idx && pitch && energy && pbins && ebins && pemb && eemb && lens && xf && out && pidx && eidx && frame_mask,
+               "kk_regulate_embed_fwd: null pointer");
+    KK_REQUIRE(n_time >= 0 && n_time <= 16 && n_feat >= 0 && n_feat <= 16, "kk_regulate_embed_fwd: at most 16 masks of each kind");
+    const int64_t rows = (int64_t)B * T;
+    int blocks = kk_cdiv(rows, 4);
+    if (blocks > 4096) blocks = 4096;
+    if (out_bf16)
+        hipLaunchKernelGGL(regulate_embed_fwd_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, enc, idx, pitch, energy, pbins,
+                           ebins, pemb, eemb, lens, xf, reinterpret_cast<__bf16 *>(out), pidx, eidx, frame_mask, rows, P, T, H, nbins, seed,
+                           site, time_mask_max, feat_mask_max, n_time, n_feat);
+    else
+        hipLaunchKernelGGL(regulate_embed_fwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, enc, idx, pitch, energy, pbins,
+                           ebins, pemb, eemb, lens, xf, out, pidx, eidx, frame_mask, rows, P, T, H, nbins, seed, site, time_mask_max,
+                           feat_mask_max, n_time, n_feat);
+    KK_LAUNCH_CHECK("kk_regulate_embed_fwd");
     return 0;
 }
 extern "C" int kk_bucket_embed_add_bwd(const float *dout, const int32_t *pidx, const int32_t *eidx,

@@ -228,6 +228,8 @@ class KokoroEngine:
         # kk_rowdot_bwd (the predictors' / stop head's Linear(C -> 1) backward) leaves its weight-gradient sums as one plain row per
         # workgroup for the backward's single kk_partials_reduce instead of 256 workgroups' atomics on the same C + 1 addresses
         self.rowdot_partials = True
+        # length-regulator gather + pitch / energy embedding adds + SpecAugment of the memory as one launch (kk_regulate_embed_fwd)
+        self.fuse_memory_fwd = True
         # The zero-fill at the start of an accumulation cycle skips what the cycle's first grouped weight-gradient launches
         # overwrite (89 % of the arena at default dims; the fill runs beside the latency-bound encoder launch: 20 us of the step).
         # Which tensors those are is RECORDED from the launches of a step (per precision mode), never assumed, and a step that
@@ -1136,12 +1138,19 @@ class KokoroEngine:
                           self._buf("lr.total", B, dtype=torch.int64))
         kk.call("kk_length_regulate_index", dur, idx, lens, tot, B, Pn, T)
         xf = self._buf("va.xf", Nd, H)
-        kk.call("kk_length_regulate_gather", enc, idx, xf, B, Pn, T, H)       # detached by construction
         memory, fmask = self._buf("va.memory", Nd, H, dtype=ddt), self._buf("va.fmask", B, T, dtype=torch.uint8)
         pidx, eidx = self._buf("va.pidx", B, T, dtype=torch.int32), self._buf("va.eidx", B, T, dtype=torch.int32)
-        kk.call("kk_bucket_embed_add_fwd", xf, batch["pitches"], batch["energies"], P[f"{VA}.pitch_bins"], P[f"{VA}.energy_bins"],
-                P[f"{VA}.pitch_embedding.weight"], P[f"{VA}.energy_embedding.weight"], lens, memory, pidx, eidx, fmask, B, T, H,
-                d.var_bins, _b16(memory))
+        spec_aug = self.train_dropout and hp.use_spec_augment and self.spec_augment_active
+        if self.fuse_memory_fwd:     # gather + embedding adds + SpecAugment: ONE launch between the encoder and the cross-attention K/V GEMM
+            kk.call("kk_regulate_embed_fwd", enc, idx, batch["pitches"], batch["energies"], P[f"{VA}.pitch_bins"], P[f"{VA}.energy_bins"],
+                    P[f"{VA}.pitch_embedding.weight"], P[f"{VA}.energy_embedding.weight"], lens, xf, memory, pidx, eidx, fmask, B, Pn, T, H,
+                    d.var_bins, _b16(memory), self.rng if spec_aug else None, 20, hp.spec_augment_time_mask_max,
+                    hp.spec_augment_freq_mask_max, hp.spec_augment_num_time_masks, hp.spec_augment_num_freq_masks)
+        else:
+            kk.call("kk_length_regulate_gather", enc, idx, xf, B, Pn, T, H)       # detached by construction
+            kk.call("kk_bucket_embed_add_fwd", xf, batch["pitches"], batch["energies"], P[f"{VA}.pitch_bins"], P[f"{VA}.energy_bins"],
+                    P[f"{VA}.pitch_embedding.weight"], P[f"{VA}.energy_embedding.weight"], lens, memory, pidx, eidx, fmask, B, T, H,
+                    d.var_bins, _b16(memory))
         pitch_pred, energy_pred = self._buf("out.pitch", B, Tp), self._buf("out.energy", B, Tp)
         col_f = self._buf("vp.col_frames", Np, 3 * H, dtype=ddt)
         if Tp != T:      # the predictors' own T'-frame view of the expansion; the losses read the first T columns
@@ -1149,8 +1158,7 @@ class KokoroEngine:
             pitch_l, energy_l = self._buf("out.pitch_T", B, T), self._buf("out.energy_T", B, T)
         else:
             xf_p, fmask_p, pitch_l, energy_l = xf, fmask, pitch_pred, energy_pred
-        spec_aug = self.train_dropout and hp.use_spec_augment and self.spec_augment_active
-        if spec_aug:                                      # on the cross-attention memory only (model.py:636-639)
+        if spec_aug and not self.fuse_memory_fwd:         # on the cross-attention memory only (model.py:636-639)
             kk.call("kk_specaug", memory, B, T, H, self.rng, 20, hp.spec_augment_time_mask_max, hp.spec_augment_freq_mask_max,
                     hp.spec_augment_num_time_masks, hp.spec_augment_num_freq_masks, _b16(memory))
 

@@ -592,6 +592,43 @@ def test_side_branch_backward_kernels_model_shapes(kk, B, L, C, chunk, xbf):
     close(de, re, 2e-4, 2e-5, "bucket-embed denergy_emb")
 
 
+@pytest.mark.parametrize("B,T,P,bf,aug", [(8, 512, 64, 1, 1), (8, 1024, 128, 1, 1), (3, 437, 53, 0, 1), (2, 33, 7, 1, 0)])
+def test_regulate_embed_fwd_equals_three_launches(kk, B, T, P, bf, aug):
+    """kk_regulate_embed_fwd == kk_length_regulate_gather + kk_bucket_embed_add_fwd + kk_specaug, bit for bit (ragged lengths, frames
+    past the expansion, boundary pitch values; same seed and site: same SpecAugment masks)."""
+    H, nb = 512, 256
+    g = torch.Generator().manual_seed(B * T + P)
+    enc = dev(torch.randn(B * P, H, generator=g))
+    dur = torch.randint(0, 2 * T // P + 2, (B, P), generator=g)
+    dur[0, :] = 0
+    dur[0, 0] = T // 2                                   # a short sample: half of its frames are padding
+    idx, lens, tot = (torch.full((B, T), -9, dtype=torch.int64, device="cuda"), torch.zeros(B, dtype=torch.int64, device="cuda"),
+                      torch.zeros(B, dtype=torch.int64, device="cuda"))
+    kk.call("kk_length_regulate_index", dev(dur), idx, lens, tot, B, P, T)
+    pitch, energy = dev(torch.rand(B, T, generator=g)), dev(torch.rand(B, T, generator=g))
+    bins = dev(torch.linspace(0, 1, nb - 1))
+    pitch[0, :3] = torch.tensor([0.0, 1.0, float(bins[7])], device="cuda")
+    pemb, eemb = dev(torch.randn(nb, H, generator=g)), dev(torch.randn(nb, H, generator=g))
+    mdt = torch.bfloat16 if bf else torch.float32
+    seed = _seed(5)
+    xa, ma = torch.empty(B * T, H, device="cuda"), torch.empty(B * T, H, device="cuda", dtype=mdt)
+    pa, ea, fa = (torch.empty(B, T, dtype=torch.int32, device="cuda"), torch.empty(B, T, dtype=torch.int32, device="cuda"),
+                  torch.empty(B, T, dtype=torch.uint8, device="cuda"))
+    kk.call("kk_length_regulate_gather", enc, idx, xa, B, P, T, H)
+    kk.call("kk_bucket_embed_add_fwd", xa, pitch, energy, bins, bins, pemb, eemb, lens, ma, pa, ea, fa, B, T, H, nb, bf)
+    if aug:
+        kk.call("kk_specaug", ma, B, T, H, seed, 20, 30, 40, 2, 2, bf)
+    xb, mb = torch.full_like(xa, 3.0), torch.full_like(ma, 3.0)
+    pb, eb, fb = torch.full_like(pa, -1), torch.full_like(ea, -1), torch.full_like(fa, 9)
+    kk.call("kk_regulate_embed_fwd", enc, idx, pitch, energy, bins, bins, pemb, eemb, lens, xb, mb, pb, eb, fb, B, P, T, H, nb, bf,
+            seed if aug else None, 20, 30, 40, 2, 2)
+    torch.cuda.synchronize()
+    assert torch.equal(xb, xa) and torch.equal(mb, ma) and torch.equal(pb, pa) and torch.equal(eb, ea) and torch.equal(fb, fa)
+    if aug:      # the masks really fired: some unmasked frames have zeroed columns / whole zero rows
+        live = (fa.view(-1) == 0)
+        assert float((mb[live].float() == 0).float().mean()) > 0.02
+
+
 def test_small_helpers(kk):
     ids = torch.tensor([[0, 3, 0, 5]])
     m = torch.empty(1, 4, dtype=torch.uint8, device="cuda")
