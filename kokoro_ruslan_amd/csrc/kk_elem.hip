@@ -775,10 +775,12 @@ extern "C" int kk_rowdot_bwd(const float *dout, const float *x, const float *w, 
     const int blocks = kk_rowdot_bwd_blocks(rows);
     const int rpb = kk_cdiv(rows, blocks);
     static const int vec = kk_tune_env("KK_ROWDOT_VEC", 1);
-    KK_REQUIRE(!partials || (vec && C % 4 == 0 && (reinterpret_cast<uintptr_t>(partials) & 15) == 0),
-               "kk_rowdot_bwd: partial rows need C %% 4 == 0 and a 16-byte aligned matrix");
-    if (vec && C % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (!dx || (reinterpret_cast<uintptr_t>(dx) & 15) == 0) &&
-        (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+    const bool rows_form = vec && C % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (!dx || (reinterpret_cast<uintptr_t>(dx) & 15) == 0) &&
+                           (reinterpret_cast<uintptr_t>(w) & 15) == 0;
+    // (only the wave-per-row kernel writes partial rows: a call that asks for them and cannot take it must fail, not drop dw / db)
+    KK_REQUIRE(!partials || (rows_form && (reinterpret_cast<uintptr_t>(partials) & 15) == 0),
+               "kk_rowdot_bwd: partial rows need C %% 4 == 0 and 16-byte aligned x, dx, w and partial matrix");
+    if (rows_form) {
         hipStream_t s = (hipStream_t)stream;
         const __bf16 *xb = reinterpret_cast<const __bf16 *>(x);
         const int nv = kk_cdiv(C, 256);
