@@ -518,7 +518,7 @@ __device__ __forceinline__ void g16x_body(const G16Args &a, const int wg, char *
                     nb = make_float4(nb.x * c1.x + sg * ob_.x * s1.x, nb.y * c1.y + sg * ob_.y * s1.y, nb.z * c1.z + sg * ob_.z * s1.z, nb.w * c1.w + sg * ob_.w * s1.w);
                 }
                 if (row < a.M) {
-                    if (!KK_DBG(a, 64)) kk_store16(raw + (int64_t)row * a.ldc + hc + 8 * u, __builtin_bit_cast(kk_u32x4, r8), a.wt);
+                    if (!KK_DBG(a, 64 | 128)) kk_store16(raw + (int64_t)row * a.ldc + hc + 8 * u, __builtin_bit_cast(kk_u32x4, r8), a.wt);      // (probe 128: the raw projection alone is not stored — the price of writing two tensors)
                     bf16x8 n8;
                     n8[0] = (__bf16)na.x; n8[1] = (__bf16)na.y; n8[2] = (__bf16)na.z; n8[3] = (__bf16)na.w;
                     n8[4] = (__bf16)nb.x; n8[5] = (__bf16)nb.y; n8[6] = (__bf16)nb.z; n8[7] = (__bf16)nb.w;
