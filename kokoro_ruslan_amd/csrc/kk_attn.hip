@@ -1174,9 +1174,13 @@ __device__ __forceinline__ void attn_fwd3_body(const AttnArgs &a) {
         if (pd.thr) {
             const uint32_t xb = pd.row(q, k0 + 4 * half);
             uint64_t mk[16];                                   // the comparisons' lane masks = the unit's ballots
+            uint32_t hprev = 0u;
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const uint32_t hsh = pd.hash(xb + (uint32_t)(frag_row(r, 0) >> 1));
+                // (probe 1024: one hash per FOUR scores — every second hash is a rotation of the one before: wrong masks, the instruction
+                //  count of VERDICT r4 item 2b's 8-bit decisions)
+                const uint32_t hsh = (KK_DBG(a, 1024) && (r & 2)) ? ((hprev >> 8) | (hprev << 24)) : pd.hash(xb + (uint32_t)(frag_row(r, 0) >> 1));
+                hprev = hsh;
                 mk[r] = __builtin_amdgcn_uicmp(hsh & 0xFFFFu, pd.thr, 35);          // >= : keep_lo
                 mk[r + 1] = __builtin_amdgcn_uicmp(hsh >> 16, pd.thr, 35);          //      keep_hi
                 s[r] = __builtin_amdgcn_inverse_ballot_w64(mk[r]) ? s[r] : 0.f;
