@@ -1886,8 +1886,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq3_kernel(AttnArgs a) {
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(AttnArgs a) {
 #include "kk_attn_bwd_dkv3.inc"
 }
+// Dispatch order: the dK/dV half (z = 0) goes out FIRST.  Its workgroups are the long ones (26.5 against 17.5 us at 512 x 512, four
+// matmuls and two head-norm epilogues against three and one); dispatched last they are what a slot delayed by the side branch's
+// workgroups finishes with.  Stand-alone the order makes no difference (32.5 us either way); inside the step it is -0.5 % at 8 x 512
+// and -0.6 % at 8 x 1024 (interleaved, profiles/r05_attn_bwd_dispatch_order_ab.txt).  Probe bit 2048 restores dQ first.
 __global__ __launch_bounds__(256, 2) void attn_bwd_pair3_kernel(AttnArgs a_dq, AttnArgs a_dkv) {
-    if (blockIdx.z == 0) {
+    if ((blockIdx.z == 1) != KK_DBG(a_dq, 2048)) {
 #define a a_dq
 #include "kk_attn_bwd_dq3.inc"
 #undef a
@@ -1902,7 +1906,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pair3_kernel(AttnArgs a_dq, A
 // per 32 x 32 unit less in each half.
 #define KK_KEEP_BITS 1
 __global__ __launch_bounds__(256, 2) void attn_bwd_pair3k_kernel(AttnArgs a_dq, AttnArgs a_dkv) {
-    if (blockIdx.z == 0) {
+    if ((blockIdx.z == 1) != KK_DBG(a_dq, 2048)) {             // (dK/dV first: see attn_bwd_pair3_kernel)
 #define a a_dq
 #include "kk_attn_bwd_dq3.inc"
 #undef a
