@@ -121,8 +121,8 @@ def gemm_symbol(ta, tb, M, N, K, math_bf16, dtypes):
             return f"gemm16_kernel_w8<{b(ta)},{b(tb)},{3 if cd(K, 64) >= 3 else 2}> ({GEMM_ROLE[(ta, tb)]}, 128x64 tiles)", 128, 64
         tiles, ktiles = cd(M, 64) * cd(N, 64), cd(K, 64)
         splits = 1
-        if tiles * 2 <= 384 and not (dtypes & 4):
-            splits = max(1, min(cd(384, tiles), max(ktiles // 2, 1)))
+        if tiles * 2 <= 128 and not (dtypes & 4):                                          # (g16_split_target, kk_gemm16.hip)
+            splits = max(1, min(cd(128, tiles), max(ktiles // 2, 1)))
         ns = 2 if ktiles // splits < 3 else 3
         return f"gemm16_kernel<{b(ta)},{b(tb)},64,64,{ns}> ({GEMM_ROLE[(ta, tb)]})", 64, 64
     tile = 128 if -(-M // 128) * -(-N // 128) >= 512 else 64

@@ -661,7 +661,12 @@ void launch_tile(int ta, int tb, const G16Args &a, dim3 grid, hipStream_t s) {
 // inside the train step (the launches are latency-bound: more, smaller workgroups keep more DMAs in flight); with EIGHT
 // waves the 128x64 tile is level or better from 128 tiles on (the decoder's 4096-row GEMMs), so those take it and the
 // encoder's 512-row GEMMs stay on 64x64.
-int g16_thr128 = 4096, g16_thr12864 = 128, g16_split_target = 384, g16_stages = 3, g16_split_major = 0;
+// Split-K target: a small-tile launch with fewer than target / 2 tiles splits its reduction until it has ~target workgroups.  384 (fill
+// the chip 1.5 x) was chosen stand-alone in round 1; INSIDE the step the launches it applies to are the side branch's (the text
+// encoder's 512-row GEMMs), where more workgroups + a zero-fill launch + fp32 atomics per launch cost the critical chain beside them more
+// than the shorter launch returns: 128 is -0.9 % on the 8 x 512 step (3.722 -> 3.690 ms interleaved), level at 8 x 1024
+// (profiles/r05_splitk_target_ab.txt).
+int g16_thr128 = 4096, g16_thr12864 = 128, g16_split_target = 128, g16_stages = 3, g16_split_major = 0;
 // Optional override of the tile policy, read ONCE when the library is loaded (no mutable policy behind the ABI):
 // KK_GEMM16_TUNE="thr128,thr12864,code" with code = flags*100000 + stages*10000 + split target, as tools/ encode it.
 struct G16EnvInit {
