@@ -629,7 +629,12 @@ __global__ __launch_bounds__(256) void decode_epilogue_kernel(const float *__res
     if (threadIdx.x == 0) *t_dev = t + 1;
 }
 
+// Grid of a grid-stride element-wise launch: at most 1024 workgroups (4 per CU).  4096 was the cap until round 5; most of these launches
+// run on the side branch or beside the persistent encoder launch, and a burst of 2048-4096 short workgroups costs the critical chain beside
+// them more than the launch gains: 1024 is -0.6 % on the 8 x 512 step and -0.9 % at 8 x 1024, interleaved (profiles/r05_elem_grid_cap_ab.txt).
 inline int grid_for(int64_t n, int cap = 4096) {
+    static const int env_cap = kk_tune_env("KK_ELEM_GRID_CAP", 1024);   // (tools: 0 = the callers' own caps)
+    if (env_cap > 0 && cap > env_cap) cap = env_cap;
     int b = kk_cdiv(n, 256);
     return b > cap ? cap : (b < 1 ? 1 : b);
 }

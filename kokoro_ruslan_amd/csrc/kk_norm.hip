@@ -722,7 +722,7 @@ extern "C" int kk_groupnorm_relu_fwd(const float *x, const float *gamma, const f
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(kk_cdiv(total, 64)), dim3(64), 0, s, scratch, stats, L, C, chunk, nch, total);
     const int64_t total4 = (int64_t)B * L * C / 4;
     int blocks = kk_cdiv(total4, 256);
-    if (blocks > 4096) blocks = 4096;
+    { static const int ec = kk_tune_env("KK_ELEM_GRID_CAP", 1024); const int cap_ = ec > 0 ? ec : 4096; if (blocks > cap_) blocks = cap_; }      // (see grid_for, kk_elem.hip)
     hipLaunchKernelGGL(gn_apply_relu_kernel, dim3(blocks), dim3(256), 0, s, x, gamma, beta, stats, y, total4, L, C, chunk, nch,
                        p > 0.f ? seed : nullptr, site, p);
     KK_LAUNCH_CHECK("kk_groupnorm_relu_fwd");
@@ -752,7 +752,7 @@ extern "C" int kk_groupnorm_relu_bwd(const float *dy, const float *x, const floa
                            dbeta, L, C, chunk, nch, slabs, inv_keep);
     const int64_t total4 = (int64_t)B * L * C / 4;
     int blocks = kk_cdiv(total4, 256);
-    if (blocks > 4096) blocks = 4096;
+    { static const int ec = kk_tune_env("KK_ELEM_GRID_CAP", 1024); const int cap_ = ec > 0 ? ec : 4096; if (blocks > cap_) blocks = cap_; }      // (see grid_for, kk_elem.hip)
     if (dx_bf16)
         hipLaunchKernelGGL(gn_bwd_apply_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, dy, x, y, gamma, stats, scratch,
                            reinterpret_cast<__bf16 *>(dx), total4, L, C, chunk, nch, inv_keep);
