@@ -66,10 +66,47 @@ int kk_gemm16_dgrad_glu(int64_t T, int64_t F, int64_t H, const void *dy, int64_t
 
 static inline int kk_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// Cross-lane reductions by DPP (data-parallel primitives: the partner lane's value arrives as an operand modifier of a VALU instruction).
+// __shfl_xor compiles to index arithmetic + ds_bpermute_b32 + s_waitcnt — a round trip through the LDS queue per step, ~150 clocks x 6
+// dependent steps per wave reduction, and the row-per-wave kernels (sub-layer tails, LayerNorms, the encoder launch's tail phases) do
+// two or three of those per row.  Here: quad_perm [1,0,3,2] and [2,3,0,1] (partners 1 and 2 away), row_half_mirror and row_mirror (at
+// that point every lane of a quad / of eight lanes holds the same partial sum, so the mirrored lane is as good as the xor partner), then
+// the four 16-lane rows' sums by v_readlane.  Every lane must be active.  (kk_dpp: v_mov_b32_dpp with bound_ctrl.)
+#ifdef KK_OLD_SHFL      // (A/B flavour: the ds_bpermute forms)
+template <int CTRL> __device__ __forceinline__ float kk_dpp(float v) {
+    return __shfl_xor(v, CTRL == 0xB1 ? 1 : (CTRL == 0x4E ? 2 : (CTRL == 0x141 ? 4 : 8)), 64);
+}
+#else
+template <int CTRL> __device__ __forceinline__ float kk_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+#endif
+__device__ __forceinline__ float kk_row16_sum(float v) {       // sum over the lane's 16-lane row, in every lane of the row
+    v += kk_dpp<0xB1>(v);
+    v += kk_dpp<0x4E>(v);
+    v += kk_dpp<0x141>(v);
+    v += kk_dpp<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ float kk_row16_max(float v) {
+    v = fmaxf(v, kk_dpp<0xB1>(v));
+    v = fmaxf(v, kk_dpp<0x4E>(v));
+    v = fmaxf(v, kk_dpp<0x141>(v));
+    v = fmaxf(v, kk_dpp<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ float kk_readlane_f(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
 __device__ __forceinline__ float wave_sum(float v) {
+#ifdef KK_OLD_SHFL
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+#else
+    v = kk_row16_sum(v);
+    return (kk_readlane_f(v, 0) + kk_readlane_f(v, 16)) + (kk_readlane_f(v, 32) + kk_readlane_f(v, 48));
+#endif
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
@@ -77,9 +114,8 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = kk_row16_max(v);
+    return fmaxf(fmaxf(kk_readlane_f(v, 0), kk_readlane_f(v, 16)), fmaxf(kk_readlane_f(v, 32), kk_readlane_f(v, 48)));
 }
 
 // Block-wide sum for blockDim.x == 256 (4 waves). `red` is >= 4 floats of LDS. Result valid in every thread.
@@ -207,12 +243,9 @@ __device__ __forceinline__ void kk_drop_mul4(uint32_t seed, uint32_t site, uint6
 // per-head RMSNorm(64) (+ RoPE) of one (row, head) vector held by 16 lanes, one float4 each (sub = lane & 15): shared by
 // headnorm_rope_fwd_kernel and the q|k|v GEMM's epilogue so that the two give the same bits.
 // rotate_half(n)[d] = -n[d+32] (d<32), n[d-32] (d>=32)   (positional_encoding.py:152-157)
-__device__ __forceinline__ float kk_sum16(float v) {
-    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-    return v;
-}
-__device__ __forceinline__ float4 kk_shfl8(const float4 &v) {
-    return make_float4(__shfl_xor(v.x, 8, 64), __shfl_xor(v.y, 8, 64), __shfl_xor(v.z, 8, 64), __shfl_xor(v.w, 8, 64));
+__device__ __forceinline__ float kk_sum16(float v) { return kk_row16_sum(v); }      // (same additions as the xor butterfly: same bits)
+__device__ __forceinline__ float4 kk_shfl8(const float4 &v) {       // the lane 8 away in the 16-lane row: row_ror:8
+    return make_float4(kk_dpp<0x128>(v.x), kk_dpp<0x128>(v.y), kk_dpp<0x128>(v.z), kk_dpp<0x128>(v.w));
 }
 __device__ __forceinline__ float4 kk_headnorm_rope(const float4 &v, const float4 &g, bool rope, const float *cos_row,
                                                    const float *sin_row, int sub) {

@@ -352,15 +352,9 @@ __global__ __launch_bounds__(512) void linear_tail_fwd_kernel(RowTailArgs a) {
     const uint32_t seed = *t.d.seed;
     const uint32_t t1 = kk_drop_threshold(t.d.p1), t2 = kk_drop_threshold(t.d.p2);
     const float k1 = t.d.p1 > 0.f ? 1.f / (1.f - t.d.p1) : 1.f, k2 = t.d.p2 > 0.f ? 1.f / (1.f - t.d.p2) : 1.f;
-    auto wave_sum4 = [](float (&x)[4]) {                        // wave_sum of each (same order of additions), interleaved
+    auto wave_sum4 = [](float (&x)[4]) {                        // wave_sum of each: four independent DPP chains
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            float y[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) y[r] = __shfl_xor(x[r], o, 64);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) x[r] += y[r];
-        }
+        for (int r = 0; r < 4; ++r) x[r] = wave_sum(x[r]);
     };
     const int64_t row0 = m0 + 4 * wave;
     float4 v[4][2];

@@ -500,7 +500,7 @@ __device__ __forceinline__ void g16x_body(const G16Args &a, const int wg, char *
                 const float4 va = make_float4((float)r8[0], (float)r8[1], (float)r8[2], (float)r8[3]);
                 const float4 vb = make_float4((float)r8[4], (float)r8[5], (float)r8[6], (float)r8[7]);
                 float ss = (va.x * va.x + va.y * va.y + va.z * va.z + va.w * va.w) + (vb.x * vb.x + vb.y * vb.y + vb.z * vb.z + vb.w * vb.w);
-                ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
+                ss += kk_dpp<0xB1>(ss); ss += kk_dpp<0x4E>(ss); ss += kk_dpp<0x141>(ss);       // (lanes 1, 2, 4 away: DPP, kk_common.h)
                 const float rs = 1.f / sqrtf(ss * (1.f / 64.f) + 1.1920928955078125e-7f);
                 float4 na = make_float4(va.x * rs * g0.x, va.y * rs * g0.y, va.z * rs * g0.z, va.w * rs * g0.w);
                 float4 nb = make_float4(vb.x * rs * g1.x, vb.y * rs * g1.y, vb.z * rs * g1.z, vb.w * rs * g1.w);

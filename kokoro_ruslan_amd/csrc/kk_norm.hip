@@ -301,13 +301,8 @@ struct HeadNormArgs {
     int heads, S, rope_mask;
 };
 
-__device__ __forceinline__ float sum16(float v) {
-    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-    return v;
-}
-__device__ __forceinline__ float4 shfl8(const float4 &v) {
-    return make_float4(__shfl_xor(v.x, 8, 64), __shfl_xor(v.y, 8, 64), __shfl_xor(v.z, 8, 64), __shfl_xor(v.w, 8, 64));
-}
+__device__ __forceinline__ float sum16(float v) { return kk_row16_sum(v); }
+__device__ __forceinline__ float4 shfl8(const float4 &v) { return kk_shfl8(v); }
 
 template <typename T>
 __global__ __launch_bounds__(256) void headnorm_rope_fwd_kernel(HeadNormArgs a) {
