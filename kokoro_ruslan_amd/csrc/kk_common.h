@@ -108,10 +108,29 @@ __device__ __forceinline__ float wave_sum(float v) {
     return (kk_readlane_f(v, 0) + kk_readlane_f(v, 16)) + (kk_readlane_f(v, 32) + kk_readlane_f(v, 48));
 #endif
 }
-__device__ __forceinline__ double wave_sum_d(double v) {
+template <int CTRL> __device__ __forceinline__ double kk_dpp_d(double v) {      // (two 32-bit DPP moves)
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double kk_readlane_d(double v, int lane) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double wave_sum_d(double v) {       // (as wave_sum: the block reductions of the loss / norm kernels do 11 of these)
+#ifdef KK_OLD_SHFL
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+#else
+    v += kk_dpp_d<0xB1>(v);
+    v += kk_dpp_d<0x4E>(v);
+    v += kk_dpp_d<0x141>(v);
+    v += kk_dpp_d<0x140>(v);
+    return (kk_readlane_d(v, 0) + kk_readlane_d(v, 16)) + (kk_readlane_d(v, 32) + kk_readlane_d(v, 48));
+#endif
 }
 __device__ __forceinline__ float wave_max(float v) {
     v = kk_row16_max(v);
