@@ -309,8 +309,13 @@ __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char
         // column sums over the wave's 32 rows: the 16 lanes that share (lane & 3)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-#pragma unroll
-            for (int m = 4; m < 64; m <<= 1) { sa[j] += __shfl_xor(sa[j], m, 64); sb[j] += __shfl_xor(sb[j], m, 64); }
+            {   // lanes 4 and 8 away inside the 16-lane row by DPP rotations (only lanes 0..3 are read below: for them the same additions as
+                // the xor butterfly), the rows 16 and 32 away by ds_bpermute
+                sa[j] += kk_dpp<0x124>(sa[j]); sb[j] += kk_dpp<0x124>(sb[j]);
+                sa[j] += kk_dpp<0x128>(sa[j]); sb[j] += kk_dpp<0x128>(sb[j]);
+                sa[j] += __shfl_xor(sa[j], 16, 64); sb[j] += __shfl_xor(sb[j], 16, 64);
+                sa[j] += __shfl_xor(sa[j], 32, 64); sb[j] += __shfl_xor(sb[j], 32, 64);
+            }
         }
         const int prow = (m0 + wr * 32) / 32;                   // one partial row per 32 rows of dY, kk_gemm_dgrad_glu_blocks(T) of them
         if (lane < 4 && col < F && prow < 2 * ((a.M + 63) / 64)) {

@@ -375,8 +375,13 @@ __device__ __forceinline__ void g16x_body(const G16Args &a, const int wg, char *
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-#pragma unroll
-                for (int m = 4; m < 64; m <<= 1) { sa[e] += __shfl_xor(sa[e], m, 64); sb[e] += __shfl_xor(sb[e], m, 64); }
+                {   // lanes 4 and 8 away inside the 16-lane row by DPP rotations (only lanes 0..3 are read below: for them the same additions as
+                // the xor butterfly), the rows 16 and 32 away by ds_bpermute
+                sa[e] += kk_dpp<0x124>(sa[e]); sb[e] += kk_dpp<0x124>(sb[e]);
+                sa[e] += kk_dpp<0x128>(sa[e]); sb[e] += kk_dpp<0x128>(sb[e]);
+                sa[e] += __shfl_xor(sa[e], 16, 64); sb[e] += __shfl_xor(sb[e], 16, 64);
+                sa[e] += __shfl_xor(sa[e], 32, 64); sb[e] += __shfl_xor(sb[e], 32, 64);
+            }
             }
             const int prow = m0 / 32 + bi;                      // one partial row per 32 rows of dY (kk_gemm_dgrad_glu_blocks)
             if (lane < 4 && col < F && prow < 2 * ((a.M + 63) / 64)) {
