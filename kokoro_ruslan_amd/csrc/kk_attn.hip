@@ -1585,28 +1585,37 @@ __device__ __forceinline__ void hn_colred_store(const float (&cr)[32], int half,
 #pragma unroll
             for (int e = 0; e < 4; ++e) colred_row[db * 32 + 8 * g + 4 * half + e] = cr[db * 16 + 4 * g + e];
 }
-// Column sums of cr over the 32 rows a half-wave holds (lane = row), in registers: a transposing butterfly — at the step with xor mask m a
-// lane keeps the half of its live values whose index has bit m like its own lane number and hands the other half to its partner — 31
-// shuffle-adds, after which lane (l31, half) holds the sum over the 32 rows of cr[l31], i.e. of column
-//   d = (l31 >> 4) * 32 + 8 * ((l31 >> 2) & 3) + 4 * half + (l31 & 3).
+// Column sums of cr over the 32 rows a half-wave holds (lane = row), in registers: a transposing butterfly — at the step with partner
+// mask m a lane keeps the half of its live values whose index bit matches its own lane bit and hands the other half to its partner: 31
+// exchange-adds.  The partner masks are taken in the order 8, 2, 1, 16, 4, so that the three big steps (16 + 8 + 4 exchanges) are DPP
+// operand modifiers (row_ror:8, quad_perm) and only the last 2 + 1 are ds_bpermute round trips.  Afterwards lane l31 holds the sum over
+// the 32 rows of cr[i], i = hn_colsum32_idx(l31): index bit 4 <- lane bit 3, 3 <- 1, 2 <- 0, 1 <- 4, 0 <- 2.
 // Replaces, per head-norm epilogue, 32 LDS stores per lane into colred[128][65], two workgroup barriers and ONE wave adding up 128 rows.
-template <int N> __device__ __forceinline__ void hn_colsum_step(float (&v)[32], int l31) {      // N live values, xor mask N / 2
-    const bool up = (l31 & (N / 2)) != 0;
+template <int N, int MASK> __device__ __forceinline__ void hn_colsum_step(float (&v)[32], int l31) {      // N live values
+    const bool up = (l31 & MASK) != 0;
 #pragma unroll
     for (int j = 0; j < N / 2; ++j) {
         const float keep = up ? v[j + N / 2] : v[j], send = up ? v[j] : v[j + N / 2];
-        v[j] = keep + __shfl_xor(send, N / 2, 64);
+        float got;
+        if constexpr (MASK == 8) got = kk_dpp<0x128>(send);
+        else if constexpr (MASK == 2) got = kk_dpp<0x4E>(send);
+        else if constexpr (MASK == 1) got = kk_dpp<0xB1>(send);
+        else got = __shfl_xor(send, MASK, 64);
+        v[j] = keep + got;
     }
 }
 __device__ __forceinline__ float hn_colsum32(float (&v)[32], int l31) {
-    hn_colsum_step<32>(v, l31);
-    hn_colsum_step<16>(v, l31);
-    hn_colsum_step<8>(v, l31);
-    hn_colsum_step<4>(v, l31);
-    hn_colsum_step<2>(v, l31);
+    hn_colsum_step<32, 8>(v, l31);
+    hn_colsum_step<16, 2>(v, l31);
+    hn_colsum_step<8, 1>(v, l31);
+    hn_colsum_step<4, 16>(v, l31);
+    hn_colsum_step<2, 4>(v, l31);
     return v[0];
 }
-__device__ __forceinline__ int hn_colsum32_col(int l31, int half) { return (l31 >> 4) * 32 + 8 * ((l31 >> 2) & 3) + 4 * half + (l31 & 3); }
+__device__ __forceinline__ int hn_colsum32_col(int l31, int half) {
+    const int i = ((l31 >> 3) & 1) << 4 | ((l31 >> 1) & 1) << 3 | (l31 & 1) << 2 | ((l31 >> 4) & 1) << 1 | ((l31 >> 2) & 1);
+    return (i >> 4) * 32 + 8 * ((i >> 2) & 3) + 4 * half + (i & 3);
+}
 // store_rows_via_lds through a tile of 16 rows (2304 bytes), two halves one after the other: fits the wave's OWN 4 KB of a dead
 // 128-row image, so no workgroup barrier stands between the head-norm arithmetic and the stores.
 __device__ __forceinline__ void store_rows_via_lds16(__bf16 *dst_row0, int64_t ld, int nvalid, const f32x16 (&acc)[2], float mul,
