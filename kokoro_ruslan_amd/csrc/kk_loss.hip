@@ -63,14 +63,28 @@ __global__ __launch_bounds__(256) void losses_fwd_kernel(LossArgs a, double *__r
             if (isfinite(v)) { s[4] += v; n[4] += 1.f; }
         }
     }
+    // the eleven block sums behind ONE barrier (they were eleven block reductions of two barriers each, the larger part of this
+    // latency-bound launch): every wave reduces its eleven values (DPP), the first six threads add the four waves' and issue the atomics
+    __shared__ double red11[11][4];
+    (void)red;
+    const int wv = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-        const double ds = block_sum_256_d((double)s[k], red);
-        const double dn = block_sum_256_d((double)n[k], red);
-        if (threadIdx.x == 0 && dn > 0.0) { atomicAdd(&acc[k], ds); atomicAdd(&acc[5 + k], dn); }
+        const double ds = wave_sum_d((double)s[k]), dn = wave_sum_d((double)n[k]);
+        if ((threadIdx.x & 63) == 0) { red11[k][wv] = ds; red11[5 + k][wv] = dn; }
     }
-    const double db = block_sum_256_d((double)bad, red);
-    if (threadIdx.x == 0 && db > 0.0) atomicAdd(&acc[10], db);
+    const double dbw = wave_sum_d((double)bad);
+    if ((threadIdx.x & 63) == 0) red11[10][wv] = dbw;
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        const int k = threadIdx.x;
+        const double ds = (red11[k][0] + red11[k][1]) + (red11[k][2] + red11[k][3]);
+        const double dn = (red11[5 + k][0] + red11[5 + k][1]) + (red11[5 + k][2] + red11[5 + k][3]);
+        if (dn > 0.0) { atomicAdd(&acc[k], ds); atomicAdd(&acc[5 + k], dn); }
+    } else if (threadIdx.x == 5) {
+        const double db = (red11[10][0] + red11[10][1]) + (red11[10][2] + red11[10][3]);
+        if (db > 0.0) atomicAdd(&acc[10], db);
+    }
 }
 
 // guard (nullable): 2 doubles of the step driver's state — [0] "a micro-batch of the current accumulation cycle had
