@@ -214,7 +214,10 @@ class KokoroEngine:
         # the attention forward stores its dropout keep decisions as packed bits (kk_attn_fwd_kb) and the backward's pair launch reads
         # them (kk_attn_bwd_kb) instead of hashing them again: ~40 % of the backward kernels' vector instructions (round 5)
         self.attn_keep_bits = True
-        self.attn_pair_min_seq = 32                # (one-tile sequences included: the text encoder's 33..64 phonemes; 64 = the round-2 dispatch)
+        # (one-tile sequences — the text encoder's <= 64 phonemes, on the side branch — take the two thinner launches: re-measured INSIDE
+        #  the step in round 5, 3.6215 -> 3.608 ms at 8 x 512 (4 of 4 interleaved rounds); 65..128 phonemes keep the pair launch: two launches
+        #  there are +0.3 % at 8 x 1024.  profiles/r05_encoder_attn_pair_ab.txt)
+        self.attn_pair_min_seq = 64
         self.attn_proj_bf16 = True                 # decoder w_o output stored as bf16 (bf16 mode)
         # the decoder's attention output projection and the sub-layer tail behind it as ONE row-owner launch (kk_linear_tail_fwd) where
         # the library measured it faster (kk_linear_tail_pays: whole rounds of workgroups at >= ~6 K rows); bit-identical results

@@ -631,7 +631,8 @@ def test_bench_config_takes_the_pair_launch_and_it_changes_nothing(eng_mod):
     P = O.init_params(d, 0)
     b = _cuda(synthetic_batch(8, 512, 64, seed=1234))
     e = _engine(eng_mod, d, P, math_mode="bf16", gradient_accumulation_steps=1)
-    assert e.attn_bwd_pair
+    assert e.attn_bwd_pair and e.attn_pair_min_seq == 64               # (round 5: the engine's default is the round-2 dispatch again —
+    e.attn_pair_min_seq = 32                                           #  measured inside the step; the pair launch of one-tile sequences stays tested)
     e.zero_grad()
     kk.profile_start()
     l_pair = e.forward_backward(b)["losses"].clone()
