@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void regulate_embed_fwd_kernel(
     const float *__restrict__ pbins, const float *__restrict__ ebins, const float *__restrict__ pemb, const float *__restrict__ eemb,
     const int64_t *__restrict__ lens, float *__restrict__ xf, TO *__restrict__ out, int32_t *__restrict__ pidx, int32_t *__restrict__ eidx,
     uint8_t *__restrict__ fmask, int64_t rows, int P, int T, int H, int nbins, const uint32_t *__restrict__ seedp, uint32_t site, int tmax,
-    int fmax, int nt, int nf) {
+    int fmax, int nt, int nf, int wt) {
     const int lane = threadIdx.x & 63;
     const uint32_t seed = seedp ? *seedp : 0u;
     const int time_limit = max(1, min(tmax, T / 4));
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256) void regulate_embed_fwd_kernel(
         }
         for (int c = lane * 4; c < H; c += 256) {
             const float4 a = j >= 0 ? ld4(enc + ((int64_t)b * P + j) * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            st4(xf + r * H + c, a);
+            st4_out(xf + r * H + c, a, wt);
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
             if (!masked) {
                 const float4 p = ld4(pemb + (int64_t)pi * H + c), e = ld4(eemb + (int64_t)ei * H + c);
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) void regulate_embed_fwd_kernel(
                 if (fm[2]) o.z = 0.f;
                 if (fm[3]) o.w = 0.f;
             }
-            stv4<TO>(out + r * H + c, o);
+            stv4_out<TO>(out + r * H + c, o, wt);      // (write-through: 12 MB that the cross-attention K/V GEMM reads next)
         }
     }
 }
@@ -841,11 +841,11 @@ extern "C" int kk_regulate_embed_fwd(const float *enc, const int64_t *idx, const
     if (out_bf16)
         hipLaunchKernelGGL(regulate_embed_fwd_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, enc, idx, pitch, energy, pbins,
                            ebins, pemb, eemb, lens, xf, reinterpret_cast<__bf16 *>(out), pidx, eidx, frame_mask, rows, P, T, H, nbins, seed,
-                           site, time_mask_max, feat_mask_max, n_time, n_feat);
+                           site, time_mask_max, feat_mask_max, n_time, n_feat, kk_write_through(rows));
     else
         hipLaunchKernelGGL(regulate_embed_fwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, enc, idx, pitch, energy, pbins,
                            ebins, pemb, eemb, lens, xf, out, pidx, eidx, frame_mask, rows, P, T, H, nbins, seed, site, time_mask_max,
-                           feat_mask_max, n_time, n_feat);
+                           feat_mask_max, n_time, n_feat, kk_write_through(rows));
     KK_LAUNCH_CHECK("kk_regulate_embed_fwd");
     return 0;
 }
