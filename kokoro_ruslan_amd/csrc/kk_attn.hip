@@ -1095,7 +1095,10 @@ __device__ __forceinline__ void attn_fwd3_body(const AttnArgs &a) {
     int kw_unit = -1;                                          // (wave-uniform) key unit whose words are pending in kw_pend
     auto flush_keep = [&]() {
         if (kw_unit >= 0) {
-            if (lane < 32) kbh[kw_unit * 32 + lane] = kw_pend;
+            if (lane < 32) {                                      // (write-through like the launch's other outputs: 2 - 8 MB of bits per launch)
+                if (a.wt) kk_st4_wt(kbh + kw_unit * 32 + lane, kw_pend);
+                else kbh[kw_unit * 32 + lane] = kw_pend;
+            }
             kw_unit = -1;
         }
         asm volatile("" ::: "memory");

@@ -177,6 +177,9 @@ typedef unsigned int kk_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void kk_st16_wt(void *p, kk_u32x4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
+__device__ __forceinline__ void kk_st4_wt(void *p, unsigned v) {
+    asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
 __device__ __forceinline__ void kk_st8_wt(void *p, kk_u32x2 v) {
     asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
