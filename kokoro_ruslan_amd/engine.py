@@ -199,6 +199,12 @@ class KokoroEngine:
         # weight-gradient GEMM 19 %, and moving the duration predictor's forward aside 2 %.
         self._kv = torch.cuda.Stream(device=self.device)
         self.dec_head_aside = True
+        # Where the backward's memory tail (all layers' cross-attention K/V weight gradient, the memory gradient, the two
+        # bucket-embedding gradients: needs only the cross-attention dK / dV) runs.  0: at the end of the main chain; 3: on the side
+        # stream behind the encoder's backward; 4: like 3 with the K/V weight gradient as a member of decoder layer 0's grouped launch;
+        # -1: 4 up to 4096 decoder rows, 3 above (measured: profiles/r05_memory_tail_aside_ab.txt).  1 / 2 (a THIRD branch) serialise
+        # the side branch behind the main chain in the replayed graph (+21 %): kept for the record of that measurement.
+        self.tail_aside = -1
         # Fusion switches: plain attributes (tests and tools/probes set them on the object for A/B runs; nothing reads the
         # environment).  Each fused form is tested against the unfused one it replaces.
         self.fuse_glu_fwd = True
@@ -751,13 +757,15 @@ class KokoroEngine:
         self._proj_headnorm(xkv, self._Wf(f"decoder.layers.{first}.cross_attn.w_k.weight", 2 * (last - first)), raw_all[:, c0:c1],
                             nrm_all[:, c0:c1], Sk, gains, 0, None, None)
 
-    def _cross_kv_bwd_all(self, xkv, Nk, dt, d_xkv):
+    def _cross_kv_bwd_all(self, xkv, Nk, dt, d_xkv, wgrad=True, dgrad=True):
         """Weight gradient of all layers' K/V projections and the memory gradient: two GEMMs over the all-layer buffer."""
         a, H, L = self.arena, self.dims.hidden, self.dims.dec_layers
         draw_all = self._buf("dec.ca.dkv_raw_all", Nk, 2 * H * L, dtype=dt)
-        with self._grouped_wgrads():                    # (a group of one: the 128x64-tile, full-reduction launch)
-            self._wgrad(draw_all, xkv, a.fused(a.g, "decoder.layers.0.cross_attn.w_k.weight", 2 * L))
-        self._dgrad(draw_all, self._Wf("decoder.layers.0.cross_attn.w_k.weight", 2 * L), d_xkv)
+        if wgrad:
+            with self._grouped_wgrads():                # (a group of one — the 128x64-tile, full-reduction launch — or a member of the
+                self._wgrad(draw_all, xkv, a.fused(a.g, "decoder.layers.0.cross_attn.w_k.weight", 2 * L))   # caller's open group)
+        if dgrad:
+            self._dgrad(draw_all, self._Wf("decoder.layers.0.cross_attn.w_k.weight", 2 * L), d_xkv)
 
     def _attn_bwd(self, key, prefix, d_out, xq, xkv, B, Sq, Sk, rope, causal, key_mask, d_xq, d_xkv, d_xkv_beta,
                   site=0, p=0.0, dpr=0.0, layer=0):
@@ -1300,6 +1308,9 @@ class KokoroEngine:
                 kk.call("kk_embed_bwd", ids, stress, dx, G["text_embedding.weight"],
                         G["stress_embedding.weight"] if stress is not None else None, B, Pn, H, float(H ** 0.5), self.rng, 1, pe_drop)
                 self._mark("side: backward done")
+                if tail_mode in (3, 4):                   # the memory tail behind the encoder's backward (no third branch)
+                    torch.cuda.current_stream().wait_event(tail_fork)
+                    memory_tail()
 
         # The decoder backward is the critical path, so it is captured first and the predictors' + encoder's backward
         # after it, forked from the point right after the loss gradients (see _on_stream).
@@ -1314,6 +1325,8 @@ class KokoroEngine:
                     p_dec, self._dpr(i, d.dec_layers), ddt)
         self._tail_bwd("dec.norm", d_dec_out, dec_last, "decoder.norm", dy, False, dhead("ffn", d.dec_layers - 1))
         dmem = self._buf("g.memory", Nd, H)
+        tail_mode = (4 if Nd <= 4096 else 3) if self.tail_aside < 0 else self.tail_aside
+        tail_mode = tail_mode if self.overlap else 0
         dn = self._buf("tmp.dn", Nd, H, dtype=ddt)
         for i in reversed(range(d.dec_layers)):
             pf, key, st = f"decoder.layers.{i}", f"dec{i}", 2000 + 32 * i
@@ -1326,6 +1339,10 @@ class KokoroEngine:
                 self._tail_bwd(key + ".ln3", dn, yc, pf + ".norm3", dy, True, dhead("ca", i))
                 self._attn_bwd(key + ".ca", pf + ".cross_attn", dy, n2, memory, B, T, T, False, False, fmask, dn, dmem,
                                0.0, st + 8, p_dec, dpr, layer=i)
+                if i == 0 and tail_mode in (1, 3, 4):  # every layer's cross-attention dK / dV is written: the memory tail may start
+                    tail_fork = self._fork_point()
+                    if tail_mode == 4:            # (4: the K/V weight gradient as one more member of layer 0's grouped launch)
+                        self._cross_kv_bwd_all(memory, Nd, ddt, dmem, dgrad=False)
                 self._tail_bwd(key + ".ln2", dn, ya, pf + ".norm2", dy, True, dhead("sa", i))
                 self._attn_bwd(key + ".sa", pf + ".self_attn", dy, n1, None, B, T, T, True, True, None, dn, None, 0.0, st, p_dec, dpr)
             self._comm_bucket(f"dec{i}")                    # the layer's weight matrices are final: exchange beside the rest
@@ -1334,23 +1351,40 @@ class KokoroEngine:
             else:
                 self._ln_bwd(key + ".ln1", dn, x_in, pf + ".norm1", dy, accumulate=True)
             self._mark(f"dec{i} bwd done")
-        # decoder input projection (the PE add and the shift are parameter-free; mel is data)
-        if self.train_dropout and (p_din > 0.0 or pe_drop > 0.0):
-            t1, dlin = self._buf("tmp.d_dec_t1", Nd, H), self._buf("tmp.d_dec_lin", Nd, H)
-            kk.call("kk_dropout_bwd", dy, t1, Nd, H, T, self.rng, 31, pe_drop, 0, 0.0, 0, 0.0, 0)
-            kk.call("kk_dropout_bwd", t1, dlin, Nd, H, T, self.rng, 30, p_din, 0, 0.0, 0, 0.0, 0)
-            self._wgrad(dlin, shifted, G["mel_projection_in.weight"], G["mel_projection_in.bias"])
+        def input_projection_bwd():                    # (the PE add and the shift are parameter-free; mel is data)
+            if self.train_dropout and (p_din > 0.0 or pe_drop > 0.0):
+                t1, dlin = self._buf("tmp.d_dec_t1", Nd, H), self._buf("tmp.d_dec_lin", Nd, H)
+                kk.call("kk_dropout_bwd", dy, t1, Nd, H, T, self.rng, 31, pe_drop, 0, 0.0, 0, 0.0, 0)
+                kk.call("kk_dropout_bwd", t1, dlin, Nd, H, T, self.rng, 30, p_din, 0, 0.0, 0, 0.0, 0)
+                self._wgrad(dlin, shifted, G["mel_projection_in.weight"], G["mel_projection_in.bias"])
+            else:
+                self._wgrad(dy, shifted, G["mel_projection_in.weight"], G["mel_projection_in.bias"])
+            self._mark("decoder input projection bwd done")
+
+        def memory_tail():
+            # variance adaptor: memory gradient feeds only the two embedding tables (xf is detached, lengths.py:30)
+            self._cross_kv_bwd_all(memory, Nd, ddt, dmem, wgrad=tail_mode != 4)   # K/V weight gradients and the memory gradient, all layers at once
+            self._mark("cross K/V bwd (all layers) done")
+            if spec_aug:
+                kk.call("kk_specaug", dmem, B, T, H, self.rng, 20, hp.spec_augment_time_mask_max, hp.spec_augment_freq_mask_max,
+                        hp.spec_augment_num_time_masks, hp.spec_augment_num_freq_masks, 0)
+            kk.call("kk_bucket_embed_add_bwd", dmem, pidx, eidx, fmask, G[f"{VA}.pitch_embedding.weight"],
+                    G[f"{VA}.energy_embedding.weight"], B, T, H, d.var_bins)
+
+        if tail_mode:
+            # the memory tail needs the cross-attention dK / dV of all layers and nothing else of the decoder backward: it runs on the
+            # third stream beside layer 0's self-attention backward (1) or beside the input projection's backward (2), or on the side
+            # stream behind the encoder's backward (3)
+            if tail_mode == 2:
+                tail_fork = self._fork_point()
+            input_projection_bwd()
+            if tail_mode not in (3, 4):
+                with self._on_stream(self._kv, "kv.", after=tail_fork):
+                    memory_tail()
+                self._join(self._kv)
         else:
-            self._wgrad(dy, shifted, G["mel_projection_in.weight"], G["mel_projection_in.bias"])
-        # variance adaptor: memory gradient feeds only the two embedding tables (xf is detached, lengths.py:30)
-        self._mark("decoder input projection bwd done")
-        self._cross_kv_bwd_all(memory, Nd, ddt, dmem)     # K/V weight gradients and the memory gradient, all layers at once
-        self._mark("cross K/V bwd (all layers) done")
-        if spec_aug:
-            kk.call("kk_specaug", dmem, B, T, H, self.rng, 20, hp.spec_augment_time_mask_max, hp.spec_augment_freq_mask_max,
-                    hp.spec_augment_num_time_masks, hp.spec_augment_num_freq_masks, 0)
-        kk.call("kk_bucket_embed_add_bwd", dmem, pidx, eidx, fmask, G[f"{VA}.pitch_embedding.weight"],
-                G[f"{VA}.energy_embedding.weight"], B, T, H, d.var_bins)
+            input_projection_bwd()
+            memory_tail()
         self._mark("main: backward tail done")
         side_backward(fork)
         self._join(self._side)

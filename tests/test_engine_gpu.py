@@ -660,6 +660,37 @@ def test_bench_config_takes_the_pair_launch_and_it_changes_nothing(eng_mod):
     assert float((a - r).norm() / r.norm()) < 2e-3 and float(a @ r / (a.norm() * r.norm())) > 0.99999
 
 
+def test_memory_tail_on_the_third_stream_changes_nothing(eng_mod):
+    """tail_aside: the backward's memory tail (cross-attention K/V weight gradients of all layers, the memory gradient, the two
+    bucket-embedding gradients) forked from layer 0's cross-attention backward (1) or from the end of the decoder backward (2) onto
+    the third stream computes what the serial order computes — eager and in a replayed graph (the fork and the join are graph edges)."""
+    from kokoro_ruslan_amd.synthetic import synthetic_batch
+    d = O.ModelDims()
+    P = O.init_params(d, 0)
+    b = _cuda(synthetic_batch(8, 512, 64, seed=77))
+    ref_g = ref_l = None
+    for mode in (0, 1, 2, 3, 4):
+        e = _engine(eng_mod, d, P, math_mode="bf16", gradient_accumulation_steps=1)
+        e.train_dropout = True                                         # the input projection's two dropout sites and SpecAugment are on the tail
+        e.tail_aside = mode
+        e.zero_grad()
+        l = e.forward_backward(b)["losses"].clone()
+        g = e.arena.g.clone()
+        named = {n: e.arena.G[n].double().flatten().clone() for n in
+                 ("decoder.layers.0.cross_attn.w_k.weight", "duration_adaptor.variance_adaptor.pitch_embedding.weight", "mel_projection_in.weight")}
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(g).all())
+        if mode == 0:
+            ref_g, ref_l, ref_named = g.double(), l, named
+            continue
+        assert torch.equal(l, ref_l)
+        # (split-K partial sums land by fp32 atomics: run-to-run order noise only)
+        assert float((g.double() - ref_g).norm() / ref_g.norm()) < 1e-5
+        for n, a in named.items():
+            r = ref_named[n]
+            assert float(r.norm()) > 0 and float((a - r).norm() / r.norm()) < 1e-5, n
+
+
 def test_step_zero_fill_skips_only_what_the_step_overwrites(eng_mod):
     """forward_backward(zero_grads=True) clears the gradient arena minus the tensors the step's grouped weight-gradient launches
     overwrite (recorded from a previous step of the same precision mode).  Poisoned with NaN before a step, every element of the

@@ -20,6 +20,8 @@ T = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 eng = KokoroEngine(ModelDims(), StepHyper(gradient_accumulation_steps=1), math_mode="bf16", total_steps=20000, seed=0)
 eng.train_dropout = True
+for kv in os.environ.get("KK_TIMELINE_SET", "").split():      # tools: attr=int pairs for A/B timelines
+    setattr(eng, kv.split("=")[0], int(kv.split("=")[1]))
 batch = {k: v.cuda() for k, v in synthetic_batch(8, T, P, seed=1).items()}
 for _ in range(12):
     eng.train_step_graphed(batch)
