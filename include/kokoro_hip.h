@@ -464,6 +464,7 @@ typedef struct KkOptCfg {
     /* EMA + weight-norm */
     double ema_decay;
     double max_weight_norm;
+    int64_t ema_update_every;     /* the EMA moves on successful steps 0, N, 2N, ... (trainer.py:1499-1502); <= 1: every step */
 } KkOptCfg;
 /* device-resident optimizer state (doubles): see kk_opt_state_* indices */
 #define KK_OS_SKIPPED 0      /* boundaries skipped for non-finite grads */
@@ -492,7 +493,7 @@ int kk_seg_sumsq(const float *buf, const int32_t *block_seg, int64_t nblocks, do
 int kk_opt_prepare(const double *grad_sumsq, const float *seg_preclip, const float *seg_lr_mult,
                    const float *seg_wd, int nseg, const int64_t *max_dur, const KkOptCfg *cfg,
                    double *opt_state, float *seg_gscale, float *seg_decay, float *seg_stepsize,
-                   float *step_consts /* [4]: skip, sqrt(1-beta2^t), eps, base_lr */,
+                   float *step_consts /* [4]: mode (0 step + EMA, 1 skipped, 2 step without EMA), sqrt(1-beta2^t), eps, base_lr */,
                    double *clear_a, double *clear_b /* nullable: per-segment accumulators [nseg] left zero by this launch — grad_sumsq
                    itself (read before it is cleared) for the next kk_seg_sumsq(zeroed = 1), p_sumsq for the kk_adamw_ema(zeroed = 1)
                    that follows */, void *stream);

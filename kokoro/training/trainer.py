@@ -171,7 +171,7 @@ class KokoroTrainer:
         self.dataset = CachedFeatureDataset(config.feature_cache_dir, tr_idx, config.max_seq_length, config.use_memory_cache, metas)
         self.val_dataset = (CachedFeatureDataset(config.feature_cache_dir, va_idx, config.max_seq_length, config.use_memory_cache, metas)
                             if va_idx else None)
-        for name, honoured in (("ema_update_every", 1), ("use_onecycle_lr", True)):
+        for name, honoured in (("use_onecycle_lr", True),):
             if getattr(config, name, honoured) != honoured:
                 raise ValueError(f"TrainingConfig.{name}={getattr(config, name)!r} is not supported by the MI355X engine "
                                  f"(the device-side step driver implements {name}={honoured!r})")

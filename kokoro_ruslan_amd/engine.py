@@ -1585,7 +1585,7 @@ class KokoroEngine:
                            hp.adam_betas[0], hp.adam_betas[1], hp.adam_eps, hp.max_grad_norm, mel_length,
                            hp.grad_explosion_ema_alpha, hp.grad_explosion_abs_floor, hp.grad_explosion_multiplier,
                            hp.grad_explosion_warmup_floor, hp.grad_explosion_warmup_steps, hp.grad_explosion_min_ema_steps,
-                           hp.ema_decay, hp.dec_ffn_max_weight_norm)
+                           hp.ema_decay, hp.dec_ffn_max_weight_norm, max(1, int(hp.ema_update_every)))
 
     def zero_grad(self) -> None:
         self.arena.g.zero_()

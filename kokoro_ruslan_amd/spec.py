@@ -93,6 +93,7 @@ class StepHyper:
     stop_token_pos_weight: float = 17.0
     use_ema: bool = True
     ema_decay: float = 0.9999
+    ema_update_every: int = 1                  # config.py:87, trainer.py:1499-1502 (counted in successful optimizer steps)
     grad_explosion_ema_alpha: float = 0.95
     grad_explosion_abs_floor: float = 1000.0
     grad_explosion_multiplier: float = 3.0

@@ -86,6 +86,7 @@ class StepHyper:
     energy_huber_delta: float = 0.05
     stop_token_pos_weight: float = 17.0
     ema_decay: float = 0.9999
+    ema_update_every: int = 1
     grad_explosion_ema_alpha: float = 0.95
     grad_explosion_abs_floor: float = 1000.0
     grad_explosion_multiplier: float = 3.0
@@ -963,7 +964,9 @@ def optimizer_step(P: Dict[str, Tensor], G: Dict[str, Tensor], st: OptState, hp:
             st.v[n].mul_(b2).addcmul_(g, g, value=1 - b2)
             denom = (st.v[n].sqrt() / bc2s).add_(hp.adam_eps)
             p.addcdiv_(st.m[n], denom, value=-(lr / bc1))
-        if ema is not None:                                        # S7
+        # S7 (trainer.py:1491-1517): _update_ema runs after every SUCCESSFUL step and counts them in ema_updates; the weights move
+        # when that count is a multiple of ema_update_every (0, N, 2N, ...).  st.step was incremented above: the count is st.step - 1.
+        if ema is not None and (st.step - 1) % max(1, int(hp.ema_update_every)) == 0:
             dcy = hp.ema_decay
             for n, p in P.items():
                 ema[n].mul_(dcy).add_(p, alpha=1 - dcy)

@@ -176,6 +176,48 @@ def test_nonfinite_gradients_skip_the_step(eng_mod, golden_dir):
     assert e.arena.names[int(st["bad_seg"]) - 1] == "mel_projection_out.bias" and st["bad_count"] == 1.0 and st["bad_attempt"] == 0.0
 
 
+def test_ema_update_every_counts_successful_steps(eng_mod, golden_dir):
+    """ema_update_every = N (config.py:87, trainer.py:1499-1502): _update_ema runs after every SUCCESSFUL optimizer step and the EMA
+    weights move when the count of such steps so far is a multiple of N — steps 0, N, 2N, ...; a skipped (non-finite) boundary does
+    not count.  Decided on the device (kk_opt_prepare -> step_consts[0] = 2), so a replayed optimizer graph follows it.  The first
+    move against the oracle's optimizer_step, every move against decay * ema + (1 - decay) * p of that step."""
+    fx, d, batch, P = _load(golden_dir, "tiny_full")
+    names = list(O.param_shapes(d))
+    e = _engine(eng_mod, d, P, gradient_accumulation_steps=1, ema_update_every=3, ema_decay=0.9)
+    b = _cuda(batch)
+    moved = []
+    for attempt in range(6):                                # attempt 2 is poisoned: successful steps are attempts 0, 1, 3, 4, 5
+        e.zero_grad()
+        e.forward_backward(b)
+        if attempt == 2:
+            e.arena.G["mel_projection_out.bias"][0] = float("nan")
+        before = e.arena.ema.clone()
+        e.optimizer_step(40)
+        torch.cuda.synchronize()
+        moved.append(not torch.equal(e.arena.ema, before))
+        if moved[-1]:
+            want = 0.9 * before.double() + 0.1 * e.arena.p.double()
+            assert float((e.arena.ema.double() - want).abs().max()) <= 1e-6 * (1.0 + float(want.abs().max())), attempt
+    assert moved == [True, False, False, False, True, False]          # successful steps 0 and 3 (= attempt 4)
+    st = e.opt_stats()
+    assert st["skipped"] == 1.0 and st["attempt"] == 6.0
+    # the oracle through the same rule: two successful steps, one EMA move
+    hp = O.StepHyper(ema_update_every=3, ema_decay=0.9)
+    Go, _, _ = O.grads_of(P, O.make_buffers(d), batch, d, O.StepHyper())
+    P2, ema2, st2 = {n: P[n].clone() for n in names}, {n: P[n].clone() for n in names}, O.OptState()
+    O.optimizer_step(P2, {n: g.clone() for n, g in Go.items()}, st2, hp, hp.learning_rate, hp.max_grad_norm, ema2, None)
+    after_first = {n: v.clone() for n, v in ema2.items()}
+    O.optimizer_step(P2, {n: g.clone() for n, g in Go.items()}, st2, hp, hp.learning_rate, hp.max_grad_norm, ema2, None)
+    assert all(torch.equal(ema2[n], after_first[n]) for n in names) and any(not torch.equal(after_first[n], P[n]) for n in names)
+    e1 = _engine(eng_mod, d, P, gradient_accumulation_steps=1, ema_update_every=3, ema_decay=0.9)
+    e1.zero_grad()
+    e1.forward_backward(b)
+    e1.optimizer_step(40)
+    esd = e1.state_dict(ema=True)
+    for n in names:
+        assert float((esd[n].cpu() - after_first[n]).abs().max()) <= 2e-6 + 2e-6 * float(after_first[n].abs().max()), ("ema", n)
+
+
 @pytest.mark.parametrize("storage", ["f32", "bf16-dec", "bf16"])
 def test_bf16_math_mode_close_to_fp32(eng_mod, golden_dir, storage):
     """bf16 MFMA arithmetic, with fp32 or bf16 operand storage: losses and gradient directions stay on the reference."""

@@ -1,5 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-o=gpurun_out/r5v; mkdir -p $o
-for d in 0 1 2 3; do echo "DBG=$d"; KK_BE_DBG=$d KK_BE_ROWS=512 python tools/probes/bucket_embed_bench.py 2>&1 | grep KK_BE; done | tee $o/bench_dbg.txt
+o=gpurun_out/r5w; mkdir -p $o
+timeout 900 python -m pytest tests/test_engine_gpu.py tests/test_kernels_gpu.py tests/test_trainer_gpu.py -x -q -m gpu -k "ema or optimizer or nonfinite or trainer or multi_step or device_step" > $o/test.log 2>&1; tail -5 $o/test.log
