@@ -465,6 +465,11 @@ typedef struct KkOptCfg {
     double ema_decay;
     double max_weight_norm;
     int64_t ema_update_every;     /* the EMA moves on successful steps 0, N, 2N, ... (trainer.py:1499-1502); <= 1: every step */
+    /* legacy schedule (use_onecycle_lr = False, trainer.py:789-799): legacy_schedule != 0 replaces warm-up + OneCycle by
+     * lr(segment) = eta_min + (learning_rate * lr_mult - eta_min) * legacy_cos, legacy_cos = the host's (1 + cos(pi T_cur / T_i)) / 2
+     * of the current EPOCH (CosineAnnealingWarmRestarts is stepped once per epoch); a zero-filled struct is the OneCycle schedule */
+    int64_t legacy_schedule;
+    double legacy_cos, eta_min;
 } KkOptCfg;
 /* device-resident optimizer state (doubles): see kk_opt_state_* indices */
 #define KK_OS_SKIPPED 0      /* boundaries skipped for non-finite grads */

@@ -114,6 +114,23 @@ def assemble_checkpoint(*, model_sd: Dict[str, torch.Tensor], ema_sd: Optional[D
         "scheduler_config": {"onecycle_steps": c["onecycle_steps"], "max_lr": c["max_lr"], "pct_start": c["pct_start"],
                              "div_factor": c["div_factor"], "warmup_steps": c["warmup_steps"]},
     }
+    if not getattr(hp, "use_onecycle_lr", True):
+        # legacy schedule (trainer.py:789-799): CosineAnnealingWarmRestarts stepped once per epoch, BEFORE the epoch's checkpoint is
+        # written (trainer.py:2885-2887) — the saved state is the one after epoch + 1 steps, and the groups carry the next epoch's lr
+        t_cur, t_i = epoch + 1, int(hp.lr_T_0)
+        while t_cur >= t_i:
+            t_cur -= t_i
+            t_i *= int(hp.lr_T_mult)
+        f = spec.cosine_restart_factor(epoch + 1, hp.lr_T_0, hp.lr_T_mult)
+        table = spec.group_lr_mult_wd(hp)
+        for gi, g in enumerate(optimizer_sd["param_groups"]):
+            g["initial_lr"] = hp.learning_rate * table[gi][0]
+            g["lr"] = hp.lr_eta_min + (g["initial_lr"] - hp.lr_eta_min) * f
+        ckpt["scheduler_state_dict"] = {"T_0": int(hp.lr_T_0), "T_i": t_i, "T_mult": int(hp.lr_T_mult), "eta_min": float(hp.lr_eta_min),
+                                        "T_cur": t_cur, "base_lrs": [g["initial_lr"] for g in optimizer_sd["param_groups"]],
+                                        "last_epoch": epoch + 1, "_step_count": epoch + 2,
+                                        "_last_lr": [g["lr"] for g in optimizer_sd["param_groups"]]}
+        ckpt["scheduler_config"] = {"onecycle_steps": None, "max_lr": None, "pct_start": None, "div_factor": None, "warmup_steps": 0}   # trainer.py:2016-2022
     if ema_sd is not None:
         ckpt["ema_model_state_dict"] = ema_sd
         ckpt["ema_updates"] = steps_done

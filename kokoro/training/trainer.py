@@ -171,10 +171,6 @@ class KokoroTrainer:
         self.dataset = CachedFeatureDataset(config.feature_cache_dir, tr_idx, config.max_seq_length, config.use_memory_cache, metas)
         self.val_dataset = (CachedFeatureDataset(config.feature_cache_dir, va_idx, config.max_seq_length, config.use_memory_cache, metas)
                             if va_idx else None)
-        for name, honoured in (("use_onecycle_lr", True),):
-            if getattr(config, name, honoured) != honoured:
-                raise ValueError(f"TrainingConfig.{name}={getattr(config, name)!r} is not supported by the MI355X engine "
-                                 f"(the device-side step driver implements {name}={honoured!r})")
         if config.use_dynamic_batching:
             self.sampler = FrameBudgetBatchSampler(self.dataset, config.max_frames_per_batch, config.min_batch_size,
                                                    config.max_batch_size, True, self.rank, self.world, drop_last=True)   # trainer.py:305-312
@@ -227,6 +223,7 @@ class KokoroTrainer:
     def train_epoch(self, epoch: int) -> float:
         cfg, G, e = self.config, max(1, self.config.gradient_accumulation_steps), self.engine
         self.sampler.epoch = epoch
+        self.engine.lr_epoch = epoch                 # legacy schedule (use_onecycle_lr = False): one scheduler step per completed epoch
         batches = self.sampler.batches()
         groups = step_groups(self.sampler.global_batches(), self.world) if self.world > 1 else None
         # model.train() with the configured regularisation (reference trainer.py:2038-2056): dropout, stochastic depth,

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void opt_prepare_kernel(const double *__restri
         st[KK_OS_MICRO_BAD] = 0.0;
         const int64_t k = (int64_t)done;               // index of this step among successful steps
         const double coef = fmin(1.0, clip / (total + 1e-6));
-        const double blr = base_lr_for(c, k);
+        const double blr = c.legacy_schedule ? c.eta_min + (c.learning_rate - c.eta_min) * c.legacy_cos : base_lr_for(c, k);
         sh[0] = coef; sh[1] = blr; sh[2] = 1.0 - pow(c.beta1, (double)(k + 1)); sh[3] = skip ? 1.0 : 0.0;
         // 0: step + EMA, 1: no step (non-finite), 2: step without the EMA update (ema_update_every, trainer.py:1499-1502: the EMA moves
         // on successful steps 0, N, 2N, ...)
@@ -152,7 +152,8 @@ __global__ __launch_bounds__(256) void opt_prepare_kernel(const double *__restri
     __syncthreads();
     const double coef = sh[0], blr = sh[1], bc1 = sh[2];
     for (int i = threadIdx.x; i < nseg; i += 256) {
-        const double lr = blr * (double)seg_lr_mult[i];
+        const double lr = c.legacy_schedule ? c.eta_min + (c.learning_rate * (double)seg_lr_mult[i] - c.eta_min) * c.legacy_cos
+                                              : blr * (double)seg_lr_mult[i];
         seg_gscale[i] = (float)((double)seg_gscale[i] * coef);
         seg_decay[i] = (float)(1.0 - lr * (double)seg_wd[i]);
         seg_stepsize[i] = (float)(lr / bc1);

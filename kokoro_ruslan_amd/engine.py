@@ -205,6 +205,8 @@ class KokoroEngine:
         # -1: 4 up to 4096 decoder rows, 3 above (measured: profiles/r05_memory_tail_aside_ab.txt).  1 / 2 (a THIRD branch) serialise
         # the side branch behind the main chain in the replayed graph (+21 %): kept for the record of that measurement.
         self.tail_aside = -1
+        # legacy schedule (hp.use_onecycle_lr = False): scheduler steps taken so far = epochs completed; the trainer advances it
+        self.lr_epoch = 0
         # Fusion switches: plain attributes (tests and tools/probes set them on the object for A/B runs; nothing reads the
         # environment).  Each fused form is tested against the unfused one it replaces.
         self.fuse_glu_fwd = True
@@ -1585,7 +1587,10 @@ class KokoroEngine:
                            hp.adam_betas[0], hp.adam_betas[1], hp.adam_eps, hp.max_grad_norm, mel_length,
                            hp.grad_explosion_ema_alpha, hp.grad_explosion_abs_floor, hp.grad_explosion_multiplier,
                            hp.grad_explosion_warmup_floor, hp.grad_explosion_warmup_steps, hp.grad_explosion_min_ema_steps,
-                           hp.ema_decay, hp.dec_ffn_max_weight_norm, max(1, int(hp.ema_update_every)))
+                           hp.ema_decay, hp.dec_ffn_max_weight_norm, max(1, int(hp.ema_update_every)),
+                           0 if hp.use_onecycle_lr else 1,
+                           0.0 if hp.use_onecycle_lr else spec.cosine_restart_factor(self.lr_epoch, hp.lr_T_0, hp.lr_T_mult),
+                           hp.lr_eta_min)
 
     def zero_grad(self) -> None:
         self.arena.g.zero_()
@@ -1763,11 +1768,12 @@ class KokoroEngine:
         if grad_sync is not None and is_boundary:
             grad_sync(self.arena.g)
         if is_boundary:
-            opt = ent["opt"].get(mel_length)
+            okey = (mel_length, 0 if self.hp.use_onecycle_lr else self.lr_epoch)    # (KkOptCfg travels by value: the legacy schedule's
+            opt = ent["opt"].get(okey)                                             #  factor changes once per epoch -> one re-capture)
             if opt is None:
                 with self.capture_lock:
                     torch.cuda.synchronize()
-                    opt = ent["opt"][mel_length] = torch.cuda.CUDAGraph()
+                    opt = ent["opt"][okey] = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(opt, capture_error_mode="thread_local"):
                         self.optimizer_step(mel_length)
             opt.replay()

@@ -37,7 +37,8 @@ class KkOptCfg(C.Structure):
                 ("max_grad_norm", C.c_double), ("mel_length", C.c_int64), ("expl_alpha", C.c_double),
                 ("expl_abs_floor", C.c_double), ("expl_multiplier", C.c_double), ("expl_warmup_floor", C.c_double),
                 ("expl_warmup_steps", C.c_int64), ("expl_min_ema_steps", C.c_int64), ("ema_decay", C.c_double),
-                ("max_weight_norm", C.c_double), ("ema_update_every", C.c_int64)]
+                ("max_weight_norm", C.c_double), ("ema_update_every", C.c_int64),
+                ("legacy_schedule", C.c_int64), ("legacy_cos", C.c_double), ("eta_min", C.c_double)]
 
 
 _P, _I, _L, _F, _D, _U = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_uint32

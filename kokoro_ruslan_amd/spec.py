@@ -94,6 +94,10 @@ class StepHyper:
     use_ema: bool = True
     ema_decay: float = 0.9999
     ema_update_every: int = 1                  # config.py:87, trainer.py:1499-1502 (counted in successful optimizer steps)
+    use_onecycle_lr: bool = True               # False: CosineAnnealingWarmRestarts per EPOCH, no warm-up (trainer.py:789-799, 2885-2887)
+    lr_T_0: int = 20
+    lr_T_mult: int = 2
+    lr_eta_min: float = 1e-6
     grad_explosion_ema_alpha: float = 0.95
     grad_explosion_abs_floor: float = 1000.0
     grad_explosion_multiplier: float = 3.0
@@ -314,6 +318,16 @@ def init_params(d: ModelDims, seed: int = 0) -> "OrderedDict[str, torch.Tensor]"
             t = xavier(shape)
         P[name] = t.float()
     return P
+
+
+def cosine_restart_factor(epoch: int, T_0: int, T_mult: int) -> float:
+    """(1 + cos(pi * T_cur / T_i)) / 2 of torch's CosineAnnealingWarmRestarts after `epoch` scheduler steps: the reference's legacy
+    schedule (use_onecycle_lr = False) steps it once per epoch (trainer.py:789-799, 2885-2887)."""
+    t_cur, t_i = int(epoch), int(T_0)
+    while t_cur >= t_i:
+        t_cur -= t_i
+        t_i *= int(T_mult)
+    return (1.0 + math.cos(math.pi * t_cur / t_i)) / 2.0
 
 
 def lr_schedule_consts(hp: StepHyper, total_steps: int) -> Dict[str, float]:

@@ -87,6 +87,10 @@ class StepHyper:
     stop_token_pos_weight: float = 17.0
     ema_decay: float = 0.9999
     ema_update_every: int = 1
+    use_onecycle_lr: bool = True
+    lr_T_0: int = 20
+    lr_T_mult: int = 2
+    lr_eta_min: float = 1e-6
     grad_explosion_ema_alpha: float = 0.95
     grad_explosion_abs_floor: float = 1000.0
     grad_explosion_multiplier: float = 3.0
@@ -819,6 +823,21 @@ def adaptive_loss_scale_and_clip(mel_length: int, max_duration: float, max_grad_
     return scale, clip
 
 
+def cosine_restart_factor(epoch: int, T_0: int, T_mult: int) -> float:
+    """The "legacy" schedule (use_onecycle_lr = False, trainer.py:789-799): torch CosineAnnealingWarmRestarts(T_0, T_mult, eta_min)
+    stepped ONCE PER EPOCH (trainer.py:2885-2887), no warm-up.  After `epoch` scheduler steps every param group runs at
+    eta_min + (its initial lr - eta_min) * factor, factor = (1 + cos(pi * T_cur / T_i)) / 2 with T_cur / T_i from the restarts."""
+    t_cur, t_i = int(epoch), int(T_0)
+    while t_cur >= t_i:
+        t_cur -= t_i
+        t_i *= int(T_mult)
+    return (1.0 + math.cos(math.pi * t_cur / t_i)) / 2.0
+
+
+def legacy_group_lr(hp: "StepHyper", mult: float, epoch: int) -> float:
+    return hp.lr_eta_min + (hp.learning_rate * mult - hp.lr_eta_min) * cosine_restart_factor(epoch, hp.lr_T_0, hp.lr_T_mult)
+
+
 class LRSchedule:
     """Warmup + OneCycleLR exactly as the reference drives them
     (trainer.py:691-772, 1519-1575; torch OneCycleLR cos / three_phase=False).
@@ -918,7 +937,7 @@ class ExplosionTracker:
 def optimizer_step(P: Dict[str, Tensor], G: Dict[str, Tensor], st: OptState, hp: StepHyper,
                    base_lr: float, clip_norm: float, ema: Optional[Dict[str, Tensor]] = None,
                    buffers: Optional[Dict[str, Tensor]] = None,
-                   tracker: Optional[ExplosionTracker] = None) -> Dict[str, float]:
+                   tracker: Optional[ExplosionTracker] = None, lr_of=None) -> Dict[str, float]:
     """One optimizer-step boundary, in the reference's order (trainer.py:2346-2477):
     pre-clip → total norm → [explosion tracker: emergency clip] → [non-finite gradients: skip] → global clip
     (runtime_policies.py:76; clip_grad_norm_) → AdamW → EMA over state_dict floats → FFN weight-norm projection.
@@ -954,7 +973,7 @@ def optimizer_step(P: Dict[str, Tensor], G: Dict[str, Tensor], st: OptState, hp:
         table = group_lr_mult_wd(hp)
         for n, p in P.items():
             mult, wd = table[param_group_of(n)]
-            lr = base_lr * mult
+            lr = base_lr * mult if lr_of is None else lr_of(mult)      # (lr_of: the legacy schedule, whose eta_min is not multiplied)
             g = G[n]
             if n not in st.m:
                 st.m[n] = torch.zeros_like(p)

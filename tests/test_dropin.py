@@ -275,3 +275,49 @@ def test_checkpoint_assembles_from_plain_cpu_state():
     assert [g["group_type"] for g in osd["param_groups"]] == list(spec.GROUP_TYPES)
     assert c["scheduler_state_dict"]["_last_lr"] == [g["lr"] for g in osd["param_groups"]]
     assert c["model_metadata"]["architecture"]["hidden_dim"] == 128
+
+
+def test_legacy_schedule_is_torch_cosine_warm_restarts_per_epoch():
+    """use_onecycle_lr = False (reference trainer.py:789-799, 2885-2887): CosineAnnealingWarmRestarts(T_0, T_mult, eta_min) over the
+    param groups' own initial lr (learning_rate x group multiplier), stepped once per epoch, no warm-up.  The oracle's and the host
+    side's closed form against torch's scheduler itself, across two restarts — and the checkpoint's scheduler / group state loads into
+    a fresh torch scheduler that continues with the same values."""
+    import sys
+    from kokoro.training import checkpoint as ckpt
+    from kokoro_ruslan_amd import spec
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import kokoro_oracle as O
+    hp = spec.StepHyper(use_onecycle_lr=False, lr_T_0=3, lr_T_mult=2, lr_eta_min=1e-6, learning_rate=5e-5)
+    ohp = O.StepHyper(use_onecycle_lr=False, lr_T_0=3, lr_T_mult=2, lr_eta_min=1e-6, learning_rate=5e-5)
+    mults = [m for m, _ in spec.group_lr_mult_wd(hp)]
+    make = lambda: torch.optim.AdamW([{"params": [torch.nn.Parameter(torch.zeros(1))], "lr": hp.learning_rate * m} for m in mults])
+    opt = make()
+    sch = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(opt, T_0=3, T_mult=2, eta_min=1e-6)
+    for epoch in range(25):                                  # restarts after 3 and 9 epochs, the third period runs past the end
+        f = spec.cosine_restart_factor(epoch, 3, 2)
+        assert f == O.cosine_restart_factor(epoch, 3, 2)
+        for g, m in zip(opt.param_groups, mults):
+            want = g["lr"]
+            assert abs(O.legacy_group_lr(ohp, m, epoch) - want) <= 1e-12 * want + 1e-18, (epoch, m)
+            assert abs(hp.lr_eta_min + (hp.learning_rate * m - hp.lr_eta_min) * f - want) <= 1e-12 * want + 1e-18
+        if epoch == 7:                                       # the checkpoint written at the end of epoch 7 (after the scheduler step)
+            dims = spec.ModelDims(hidden=128, heads=2, enc_layers=1, dec_layers=1, enc_ff=96, dec_ff=96, var_filter=32, var_bins=16, mel=20, max_len=300)
+            P = spec.init_params(dims, 1)
+            osd = ckpt.adamw_state_dict(list(P), lambda n: torch.zeros_like(P[n]), lambda n: torch.ones_like(P[n]), 5, hp, 1e-5)
+            c = ckpt.assemble_checkpoint(model_sd={}, ema_sd=None, optimizer_sd=osd, hp=hp, dims=dims, config=TrainingConfig(),
+                                         total_steps=100, epoch=7, loss=1.0, steps_done=5)
+            saved = c
+        opt.step()
+        sch.step()
+    # resume from the epoch-7 checkpoint with torch's own classes, like the reference's load_checkpoint does
+    opt2 = make()
+    sch2 = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(opt2, T_0=3, T_mult=2, eta_min=1e-6)
+    for g, s in zip(opt2.param_groups, saved["optimizer_state_dict"]["param_groups"]):
+        g["lr"], g["initial_lr"] = s["lr"], s["initial_lr"]
+    sch2.load_state_dict(saved["scheduler_state_dict"])
+    for epoch in range(8, 12):
+        for g, m in zip(opt2.param_groups, mults):
+            assert abs(g["lr"] - O.legacy_group_lr(ohp, m, epoch)) <= 1e-12 * g["lr"] + 1e-18, (epoch, m)
+        opt2.step()
+        sch2.step()
+    assert saved["scheduler_config"]["onecycle_steps"] is None

@@ -218,6 +218,34 @@ def test_ema_update_every_counts_successful_steps(eng_mod, golden_dir):
         assert float((esd[n].cpu() - after_first[n]).abs().max()) <= 2e-6 + 2e-6 * float(after_first[n].abs().max()), ("ema", n)
 
 
+@pytest.mark.parametrize("epoch", [0, 2, 3, 7])
+def test_legacy_cosine_restart_schedule(eng_mod, golden_dir, epoch):
+    """use_onecycle_lr = False (trainer.py:789-799): every segment steps at eta_min + (learning_rate x its group multiplier - eta_min) x
+    the epoch's cosine-restart factor (tests/test_dropin.py pins the factor against torch's scheduler) — no warm-up, no OneCycle.  One
+    optimizer step per epoch value against the oracle's optimizer_step under the same rule; T_0 = 3: epoch 3 is a restart."""
+    fx, d, batch, P = _load(golden_dir, "tiny_full")
+    names = list(O.param_shapes(d))
+    kw = dict(use_onecycle_lr=False, lr_T_0=3, lr_T_mult=2, lr_eta_min=1e-6)
+    e = _engine(eng_mod, d, P, gradient_accumulation_steps=1, **kw)
+    e.lr_epoch = epoch
+    e.zero_grad()
+    e.forward_backward(_cuda(batch))
+    e.optimizer_step(40)
+    torch.cuda.synchronize()
+    hp = O.StepHyper(**kw)
+    st = e.opt_stats()
+    assert abs(st["last_base_lr"] - O.legacy_group_lr(hp, 1.0, epoch)) <= 1e-12
+    if epoch in (0, 3):
+        assert abs(st["last_base_lr"] - hp.learning_rate) <= 1e-15          # start of a period: the initial lr
+    Go, _, _ = O.grads_of(P, O.make_buffers(d), batch, d, O.StepHyper())
+    P2 = {n: P[n].clone() for n in names}
+    O.optimizer_step(P2, Go, O.OptState(), hp, hp.learning_rate, hp.max_grad_norm, None, None, lr_of=lambda m: O.legacy_group_lr(hp, m, epoch))
+    sd = e.state_dict()
+    for n in names:
+        dref, dgot = (P2[n] - P[n]).double(), (sd[n].cpu() - P[n]).double()
+        assert float((dgot - dref).norm()) <= 5e-3 * float(dref.norm()) + 1e-9, n
+
+
 @pytest.mark.parametrize("storage", ["f32", "bf16-dec", "bf16"])
 def test_bf16_math_mode_close_to_fp32(eng_mod, golden_dir, storage):
     """bf16 MFMA arithmetic, with fp32 or bf16 operand storage: losses and gradient directions stay on the reference."""
