@@ -257,3 +257,57 @@ def test_kokoro_train_reaches_bench_speed_on_a_fixed_shape(tmp_path):
     print(f"kokoro-train {fps_train:,.0f} frames/s, resident-batch loop {fps_bench:,.0f} frames/s (G = 2)")
     assert fps_train >= 0.85 * fps_bench, (fps_train, fps_bench)
     assert e.opt_stats()["skipped"] == 0
+
+
+def test_trainer_legacy_schedule_and_ema_cadence(tmp_path):
+    """TrainingConfig.use_onecycle_lr = False and ema_update_every = 2 through kokoro-train's trainer (both were refused before round 5):
+    every optimizer step of epoch e runs at the CosineAnnealingWarmRestarts value after e scheduler steps (reference trainer.py:789-799,
+    2885-2887) — also through the replayed optimizer graphs, which are re-captured when the epoch's factor changes — the EMA moves on every
+    second successful step, and the checkpoint carries a scheduler state torch's own class continues from."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from kokoro.training import checkpoint as ckpt
+    from kokoro.training.trainer import KokoroTrainer
+    from kokoro_ruslan_amd import spec
+    corpus = tmp_path / "corpus"
+    _fake_cache(corpus, n=16, tmin=64, tmax=64, pmin=8, pmax=8)          # one batch shape: the second step of it is a graph replay
+    cfg = _config(tmp_path, corpus, "--no-dynamic-batching", "--batch-size", "4", "--epochs", "4", "--val-split", "0.0")
+    cfg.use_onecycle_lr, cfg.lr_T_0, cfg.lr_T_mult, cfg.lr_eta_min = False, 2, 2, 1e-6
+    cfg.ema_update_every, cfg.ema_decay, cfg.gradient_accumulation_steps = 2, 0.9, 1
+    tr = KokoroTrainer(cfg)
+    e = tr.engine
+    assert e.hp.use_onecycle_lr is False and e.hp.ema_update_every == 2
+    lrs, moved = [], []
+    orig = e.train_step_auto
+
+    def spy(*a, **k):
+        before = e.arena.ema.clone()
+        out = orig(*a, **k)
+        torch.cuda.synchronize()
+        lrs.append((e.lr_epoch, e.opt_stats()["last_base_lr"]))
+        moved.append(not torch.equal(e.arena.ema, before))
+        return out
+    e.train_step_auto = spy
+    for epoch in range(3):
+        tr.train_epoch(epoch)
+    assert len(lrs) == 12 and all(ep == i // 4 for i, (ep, _) in enumerate(lrs))
+    for ep, lr in lrs:
+        want = cfg.lr_eta_min + (cfg.learning_rate - cfg.lr_eta_min) * spec.cosine_restart_factor(ep, 2, 2)
+        assert abs(lr - want) <= 1e-12, (ep, lr, want)
+    assert lrs[0][1] == lrs[8][1] and lrs[4][1] < 0.6 * lrs[0][1]      # epoch 2 is a restart (T_0 = 2), epoch 1 the half-way point
+    assert moved == [i % 2 == 0 for i in range(12)]                     # successful steps 0, 2, 4, ...
+    path = ckpt.save_checkpoint(e, cfg, 2, 1.0, str(tmp_path / "out"))
+    c = torch.load(path, map_location="cpu", weights_only=False)
+    mults = [m for m, _ in spec.group_lr_mult_wd(e.hp)]
+    opt = torch.optim.AdamW([{"params": [torch.nn.Parameter(torch.zeros(1))], "lr": cfg.learning_rate * m} for m in mults])
+    sch = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(opt, T_0=2, T_mult=2, eta_min=1e-6)
+    for g, s in zip(opt.param_groups, c["optimizer_state_dict"]["param_groups"]):
+        g["lr"], g["initial_lr"] = s["lr"], s["initial_lr"]
+    sch.load_state_dict(c["scheduler_state_dict"])
+    f3, f4 = spec.cosine_restart_factor(3, 2, 2), spec.cosine_restart_factor(4, 2, 2)
+    for g, m in zip(opt.param_groups, mults):                            # the groups carry the NEXT epoch's lr (the reference steps before it saves)
+        assert abs(g["lr"] - (cfg.lr_eta_min + (cfg.learning_rate * m - cfg.lr_eta_min) * f3)) <= 1e-15 + 1e-12 * g["lr"]
+    opt.step()
+    sch.step()
+    for g, m in zip(opt.param_groups, mults):
+        assert abs(g["lr"] - (cfg.lr_eta_min + (cfg.learning_rate * m - cfg.lr_eta_min) * f4)) <= 1e-15 + 1e-12 * g["lr"]

@@ -2,4 +2,4 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 o=gpurun_out/r5y; mkdir -p $o
-timeout 1500 python -m pytest tests -q -m gpu > $o/test.log 2>&1; grep -n "passed\|failed\|FAILED" $o/test.log | tail -8
+timeout 900 python -m pytest tests/test_trainer_gpu.py -x -q -m gpu -k "legacy" > $o/test2.log 2>&1; tail -30 $o/test2.log
