@@ -299,6 +299,15 @@ int kk_regulate_embed_fwd(const float *enc, const int64_t *idx, const float *pit
 int kk_bucket_embed_add_bwd(const float *dout, const int32_t *pidx, const int32_t *eidx,
                             const uint8_t *frame_mask, float *dpemb, float *deemb, int B, int T, int H,
                             int nbins, void *stream);   /* nbins = rows of the two embedding tables */
+/* The same gradient as a segmented sum (no LDS float atomics).  kk_bucket_sort (forward side, once per batch): order = int32 [2][rows],
+ * the unmasked frames of the pitch (0) and energy (1) table sorted by bin; items = int32 [2][kk_bucket_sort_items(rows, nbins)][4]
+ * (16-byte aligned) = (bin, begin, end, 0) pieces of at most 16 frames of one bin, unused entries empty.  kk_bucket_embed_add_bwd_sorted adds
+ * the rows of every piece into its table row (one workgroup per piece; accumulates like kk_bucket_embed_add_bwd; nbins <= 1024). */
+int kk_bucket_sort_items(int64_t rows, int nbins);
+int kk_bucket_sort(const int32_t *pidx, const int32_t *eidx, const uint8_t *frame_mask, int64_t rows, int nbins, int32_t *order,
+                   int32_t *items, void *stream);
+int kk_bucket_embed_add_bwd_sorted(const float *dout, const int32_t *order, const int32_t *items, float *dpemb, float *deemb,
+                                   int64_t rows, int H, int nbins, void *stream);
 /* text key mask: mask[i] = (ids[i] == 0)  (model.py:586-587). */
 int kk_ids_eq_zero(const int64_t *ids, uint8_t *mask, int64_t n, void *stream);
 /* decoder input shift-right (model.py:519): out[b,0,:]=0, out[b,t,:]=mel[b,t-1,:]. */

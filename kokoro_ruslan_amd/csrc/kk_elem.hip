@@ -565,6 +565,71 @@ __global__ __launch_bounds__(256) void bucket_embed_add_bwd_lds_kernel(const flo
     }
 }
 
+// ---- the same scatter-add as a SEGMENTED sum: the frames of each table sorted by bin in the forward (kk_bucket_sort), the backward
+// one workgroup per piece of at most BS_PIECE frames of ONE bin — row loads of 4 * blockDim contiguous floats, sums in registers, one global
+// atomic per (piece, column).  No LDS float atomics (ds_add_f32 moves about one lane per two clocks per CU: the LDS form above spends
+// half of its time there, profiles/r05_side_branch_kernels.txt).
+constexpr int BS_PIECE = 16, BS_THREADS = 1024, BS_MAXBINS = 1024;
+__global__ __launch_bounds__(BS_THREADS) void bucket_sort_kernel(const int32_t *__restrict__ pidx, const int32_t *__restrict__ eidx,
+                                                                 const uint8_t *__restrict__ fmask, int64_t rows, int nbins, int max_items,
+                                                                 int32_t *__restrict__ order, int32_t *__restrict__ items) {
+    __shared__ int hist[BS_MAXBINS], cur[BS_MAXBINS], istart[BS_MAXBINS + 1];
+    const int32_t *idx = blockIdx.x == 0 ? pidx : eidx;
+    int32_t *ord = order + (int64_t)blockIdx.x * rows;
+    int4 *it = reinterpret_cast<int4 *>(items) + (int64_t)blockIdx.x * max_items;
+    for (int b = threadIdx.x; b < nbins; b += BS_THREADS) hist[b] = 0;
+    __syncthreads();
+    for (int64_t r = threadIdx.x; r < rows; r += BS_THREADS)
+        if (!fmask[r]) atomicAdd(&hist[idx[r]], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int s = 0, n = 0;
+        for (int b = 0; b < nbins; ++b) {
+            cur[b] = s;
+            istart[b] = n;
+            s += hist[b];
+            n += (hist[b] + BS_PIECE - 1) / BS_PIECE;
+        }
+        istart[nbins] = n;
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nbins; b += BS_THREADS) {
+        const int base = cur[b], end = base + hist[b];
+        int k = istart[b];
+        for (int beg = base; beg < end; beg += BS_PIECE, ++k) it[k] = make_int4(b, beg, beg + BS_PIECE < end ? beg + BS_PIECE : end, 0);
+    }
+    for (int k = istart[nbins] + threadIdx.x; k < max_items; k += BS_THREADS) it[k] = make_int4(0, 0, 0, 0);      // empty pieces
+    __syncthreads();
+    for (int64_t r = threadIdx.x; r < rows; r += BS_THREADS)
+        if (!fmask[r]) ord[atomicAdd(&cur[idx[r]], 1)] = (int32_t)r;
+}
+
+__global__ __launch_bounds__(256) void bucket_embed_add_bwd_sorted_kernel(const float *__restrict__ dout, const int32_t *__restrict__ order,
+                                                                          const int32_t *__restrict__ items, float *__restrict__ dpemb,
+                                                                          float *__restrict__ deemb, int64_t rows, int H, int max_items) {
+    const int4 item = reinterpret_cast<const int4 *>(items)[(int64_t)blockIdx.y * max_items + blockIdx.x];
+    const int beg = item.y, n = item.z - item.y;
+    if (n <= 0) return;
+    const int32_t *ord = order + (int64_t)blockIdx.y * rows + beg;
+    float *dst = (blockIdx.y == 0 ? dpemb : deemb) + (int64_t)item.x * H;
+    int rr[BS_PIECE];
+#pragma unroll
+    for (int u = 0; u < BS_PIECE; ++u) rr[u] = ord[u < n ? u : 0];             // (uniform: scalar loads)
+    for (int c = threadIdx.x * 4; c < H; c += blockDim.x * 4) {
+        float4 v[BS_PIECE];
+#pragma unroll
+        for (int u = 0; u < BS_PIECE; ++u) v[u] = ld4(dout + (int64_t)rr[u] * H + c);      // all of the piece's rows in flight
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < BS_PIECE; ++u)
+            if (u < n) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        atomicAdd(dst + c, acc.x);
+        atomicAdd(dst + c + 1, acc.y);
+        atomicAdd(dst + c + 2, acc.z);
+        atomicAdd(dst + c + 3, acc.w);
+    }
+}
+
 __global__ void ids_eq_zero_kernel(const int64_t *__restrict__ ids, uint8_t *__restrict__ mask, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         mask[i] = ids[i] == 0 ? 1 : 0;
@@ -866,6 +931,29 @@ extern "C" int kk_bucket_embed_add_bwd(const float *dout, const int32_t *pidx, c
     hipLaunchKernelGGL(bucket_embed_add_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, pidx, eidx,
                        frame_mask, dpemb, deemb, rows, H);
     KK_LAUNCH_CHECK("kk_bucket_embed_add_bwd");
+    return 0;
+}
+
+extern "C" int kk_bucket_sort_items(int64_t rows, int nbins) { return nbins + (int)((rows + BS_PIECE - 1) / BS_PIECE); }
+extern "C" int kk_bucket_sort(const int32_t *pidx, const int32_t *eidx, const uint8_t *frame_mask, int64_t rows, int nbins,
+                              int32_t *order, int32_t *items, void *stream) {
+    KK_REQUIRE(pidx && eidx && frame_mask && order && items && rows > 0 && rows < (1ll << 30) && nbins > 0 && nbins <= BS_MAXBINS,
+               "kk_bucket_sort: bad args (at most %d bins)", BS_MAXBINS);
+    KK_REQUIRE((reinterpret_cast<uintptr_t>(items) & 15) == 0, "kk_bucket_sort: items must be 16-byte aligned");
+    hipLaunchKernelGGL(bucket_sort_kernel, dim3(2), dim3(BS_THREADS), 0, (hipStream_t)stream, pidx, eidx, frame_mask, rows, nbins,
+                       kk_bucket_sort_items(rows, nbins), order, items);
+    KK_LAUNCH_CHECK("kk_bucket_sort");
+    return 0;
+}
+extern "C" int kk_bucket_embed_add_bwd_sorted(const float *dout, const int32_t *order, const int32_t *items, float *dpemb, float *deemb,
+                                              int64_t rows, int H, int nbins, void *stream) {
+    KK_REQUIRE(dout && order && items && dpemb && deemb && rows > 0 && H > 0 && H % 4 == 0 && nbins > 0 && nbins <= BS_MAXBINS,
+               "kk_bucket_embed_add_bwd_sorted: bad args");
+    const int max_items = kk_bucket_sort_items(rows, nbins);
+    const int threads = H / 4 >= 256 ? 256 : (H / 4 + 63) / 64 * 64;
+    hipLaunchKernelGGL(bucket_embed_add_bwd_sorted_kernel, dim3(max_items, 2), dim3(threads), 0, (hipStream_t)stream, dout, order, items,
+                       dpemb, deemb, rows, H, max_items);
+    KK_LAUNCH_CHECK("kk_bucket_embed_add_bwd_sorted");
     return 0;
 }
 

@@ -205,6 +205,8 @@ class KokoroEngine:
         # -1: 4 up to 4096 decoder rows, 3 above (measured: profiles/r05_memory_tail_aside_ab.txt).  1 / 2 (a THIRD branch) serialise
         # the side branch behind the main chain in the replayed graph (+21 %): kept for the record of that measurement.
         self.tail_aside = -1
+        # bucket-embedding gradients as a segmented sum over frames sorted by bin (kk_bucket_sort beside the predictors' forward)
+        self.embed_bwd_sorted = True
         # legacy schedule (hp.use_onecycle_lr = False): scheduler steps taken so far = epochs completed; the trainer advances it
         self.lr_epoch = 0
         # Fusion switches: plain attributes (tests and tools/probes set them on the object for A/B runs; nothing reads the
@@ -1183,6 +1185,10 @@ class KokoroEngine:
         # with the critical path into the decoder; 2.8 % of the step (729K -> 749K frames/s).
         with self._on_side_stream():                      # joined before the losses
             self._mark("side: predictors fwd start")
+            if backward and self.embed_bwd_sorted and d.var_bins <= 1024:
+                n_items = kk.load().kk_bucket_sort_items(Nd, d.var_bins)
+                be_order, be_items = self._buf("va.be_order", 2, Nd, dtype=torch.int32), self._buf("va.be_items", 2, n_items, 4, dtype=torch.int32)
+                kk.call("kk_bucket_sort", pidx, eidx, fmask, Nd, d.var_bins, be_order, be_items)
             kk.call("kk_im2col3_fwd", enc, col_e, B, Pn, H, CHUNK, _b16(col_e))
             if Tp != T:
                 idx_p, lens_p = self._buf("lr.idx_p", B, Tp, dtype=torch.int64), self._buf("lr.lens_p", B, dtype=torch.int64)
@@ -1370,8 +1376,12 @@ class KokoroEngine:
             if spec_aug:
                 kk.call("kk_specaug", dmem, B, T, H, self.rng, 20, hp.spec_augment_time_mask_max, hp.spec_augment_freq_mask_max,
                         hp.spec_augment_num_time_masks, hp.spec_augment_num_freq_masks, 0)
-            kk.call("kk_bucket_embed_add_bwd", dmem, pidx, eidx, fmask, G[f"{VA}.pitch_embedding.weight"],
-                    G[f"{VA}.energy_embedding.weight"], B, T, H, d.var_bins)
+            if self.embed_bwd_sorted and d.var_bins <= 1024:
+                kk.call("kk_bucket_embed_add_bwd_sorted", dmem, be_order, be_items, G[f"{VA}.pitch_embedding.weight"],
+                        G[f"{VA}.energy_embedding.weight"], Nd, H, d.var_bins)
+            else:
+                kk.call("kk_bucket_embed_add_bwd", dmem, pidx, eidx, fmask, G[f"{VA}.pitch_embedding.weight"],
+                        G[f"{VA}.energy_embedding.weight"], B, T, H, d.var_bins)
 
         if tail_mode:
             # the memory tail needs the cross-attention dK / dV of all layers and nothing else of the decoder backward: it runs on the

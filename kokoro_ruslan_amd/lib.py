@@ -189,6 +189,9 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_bucket_embed_add_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "kk_regulate_embed_fwd": [_P] * 14 + [_I, _I, _I, _I, _I, _I, _P, _U, _I, _I, _I, _I, _P],
     "kk_bucket_embed_add_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "kk_bucket_sort_items": [_L, _I],
+    "kk_bucket_sort": [_P, _P, _P, _L, _I, _P, _P, _P],
+    "kk_bucket_embed_add_bwd_sorted": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
     "kk_dropout_fwd": [_P, _P, _L, _P, _L, _I, _I, _P, _U, _F, _U, _F, _U, _F, _P],
     "kk_sublayer_out_fwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _I, _I, _P, _U, _F, _U, _F, _U, _F, _P],
     "kk_linear_tail_supported": [_L, _I, _I],

@@ -520,6 +520,48 @@ def test_bucket_embed_add(kk):
     close(de, er.grad, 1e-4, 1e-5, "bucket-embed denergy_emb")
 
 
+@pytest.mark.parametrize("B,T,H,nb,heavy", [(8, 512, 512, 256, 0.3), (8, 1024, 512, 256, 0.0), (3, 77, 64, 16, 0.9), (1, 5, 1028, 1024, 0.0),
+                                            (2, 40, 512, 256, 1.0)])
+def test_bucket_embed_bwd_segmented_sum(kk, B, T, H, nb, heavy):
+    """kk_bucket_sort + kk_bucket_embed_add_bwd_sorted against float64 index_add and against the LDS form: the sort's order holds every
+    unmasked frame exactly once, bin by bin; pieces cover each bin's run in order with at most 16 frames each; a bin holding `heavy` of
+    all frames (unvoiced frames share pitch bin 0) is cut into many pieces; an all-masked batch and accumulation onto existing gradients."""
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    rows = B * T
+    pi, ei = torch.randint(0, nb, (rows,), generator=g, dtype=torch.int32), torch.randint(0, nb, (rows,), generator=g, dtype=torch.int32)
+    pi[torch.rand(rows, generator=g) < heavy] = 0
+    fm = (torch.rand(rows, generator=g) < (1.0 if heavy == 1.0 else 0.15)).to(torch.uint8)
+    dout = torch.randn(rows, H, generator=g)
+    keep = fm == 0
+    n_items = kk.load().kk_bucket_sort_items(rows, nb)
+    order = torch.full((2, rows), -1, dtype=torch.int32, device="cuda")
+    items = torch.full((2, n_items, 4), -7, dtype=torch.int32, device="cuda")
+    kk.call("kk_bucket_sort", dev(pi), dev(ei), dev(fm), rows, nb, order, items)
+    for tb, idx in enumerate((pi, ei)):
+        nk = int(keep.sum())
+        o = order[tb, :nk].cpu().long()
+        assert sorted(o.tolist()) == torch.nonzero(keep).flatten().tolist(), "every unmasked frame exactly once"
+        assert bool((idx[o][1:] >= idx[o][:-1]).all()) if nk > 1 else True, "sorted by bin"
+        it = items[tb].cpu()
+        used = it[it[:, 2] > it[:, 1]]
+        assert bool(((used[:, 2] - used[:, 1]) <= 16).all()) and int((used[:, 2] - used[:, 1]).sum()) == nk
+        for b_, beg, end, _ in used.tolist():
+            assert bool((idx[o[beg:end]] == b_).all())
+        assert bool((it[it[:, 2] <= it[:, 1]][:, 1:3] == 0).all()), "unused entries are empty"
+    base_p, base_e = torch.randn(nb, H, generator=g), torch.randn(nb, H, generator=g)
+    ref_p, ref_e = base_p.double().clone(), base_e.double().clone()
+    ref_p.index_add_(0, pi[keep].long(), dout[keep].double())
+    ref_e.index_add_(0, ei[keep].long(), dout[keep].double())
+    dp, de = dev(base_p), dev(base_e)
+    kk.call("kk_bucket_embed_add_bwd_sorted", dev(dout), order, items, dp, de, rows, H, nb)
+    close(dp, ref_p.float(), 1e-5, 2e-5, "segmented dpitch_emb")
+    close(de, ref_e.float(), 1e-5, 2e-5, "segmented denergy_emb")
+    if nb * 16 * 8 <= 64 * 1024:
+        lp, le = dev(base_p), dev(base_e)
+        kk.call("kk_bucket_embed_add_bwd", dev(dout), dev(pi), dev(ei), dev(fm), lp, le, B, T, H, nb)
+        close(dp, lp, 2e-4, 2e-5, "segmented vs LDS form")            # (two fp32 summation orders of up to ~1 K rows against each other)
+
+
 @pytest.mark.parametrize("B,L,C,chunk,xbf", [(8, 512, 256, 0, 0), (8, 512, 256, 0, 1), (8, 64, 256, 0, 0), (3, 437, 256, 128, 0),
                                               (5, 99, 512, 0, 1), (2, 33, 100, 0, 0)])
 def test_side_branch_backward_kernels_model_shapes(kk, B, L, C, chunk, xbf):

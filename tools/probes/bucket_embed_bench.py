@@ -19,7 +19,7 @@ def gtime(fns, reps=20):
     return s.elapsed_time(e) / reps / len(fns) * 1e3
 H, nb = 512, 256
 for B, T, smooth in ((8, 512, 0), (8, 512, 1), (8, 1024, 0), (16, 700, 0)):
-    fns = []
+    fns, sorts, segs = [], [], []
     for i in range(6):
         d = torch.randn(B * T, H, device=dev)
         if smooth:                                     # neighbouring frames in neighbouring bins (speech-like contours)
@@ -30,4 +30,9 @@ for B, T, smooth in ((8, 512, 0), (8, 512, 1), (8, 1024, 0), (16, 700, 0)):
         fm = (torch.rand(B * T, device=dev) < 0.1).to(torch.uint8)
         gp, ge = torch.zeros(nb, H, device=dev), torch.zeros(nb, H, device=dev)
         fns.append(lambda d=d, pi=pi, ei=ei, fm=fm, gp=gp, ge=ge: kk.call("kk_bucket_embed_add_bwd", d, pi, ei, fm, gp, ge, B, T, H, nb))
-    print(f"rows {B*T} smooth {smooth}: {gtime(fns):7.2f} us", flush=True)
+        order = torch.empty(2, B * T, dtype=torch.int32, device=dev)
+        items = torch.empty(2, kk.load().kk_bucket_sort_items(B * T, nb), 4, dtype=torch.int32, device=dev)
+        sorts.append(lambda pi=pi, ei=ei, fm=fm, order=order, items=items: kk.call("kk_bucket_sort", pi, ei, fm, B * T, nb, order, items))
+        sorts[-1]()
+        segs.append(lambda d=d, order=order, items=items, gp=gp, ge=ge: kk.call("kk_bucket_embed_add_bwd_sorted", d, order, items, gp, ge, B * T, H, nb))
+    print(f"rows {B*T} smooth {smooth}: LDS form {gtime(fns):7.2f} us   segmented {gtime(segs):7.2f} us   (+ kk_bucket_sort in the forward {gtime(sorts):7.2f} us)", flush=True)
