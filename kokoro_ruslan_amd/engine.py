@@ -207,6 +207,9 @@ class KokoroEngine:
         self.tail_aside = -1
         # bucket-embedding gradients as a segmented sum over frames sorted by bin (kk_bucket_sort beside the predictors' forward)
         self.embed_bwd_sorted = True
+        # decoder layer 0's grouped weight-gradient launch on the side stream's idle end instead of the main chain: 1 always, 0 never,
+        # -1 where the memory tail is in mode 3 (> 4096 rows: -0.5 ... -1.1 %; at 4096 rows +0.3 ... +1.4 %)
+        self.wgrad0_aside = -1
         # legacy schedule (hp.use_onecycle_lr = False): scheduler steps taken so far = epochs completed; the trainer advances it
         self.lr_epoch = 0
         # Fusion switches: plain attributes (tests and tools/probes set them on the object for A/B runs; nothing reads the
@@ -252,6 +255,7 @@ class KokoroEngine:
         self._ow_seen: Optional[set] = None
         self._ow_expect: Optional[frozenset] = None
         self._wgrad_queue = {}
+        self._defer_wgrads = None                   # a list while a caller collects grouped weight-gradient launches for later
         # The gradient arena was zeroed for THIS micro-batch (first of an accumulation cycle): a layer's grouped weight
         # gradients are each written exactly once per micro-batch, so they overwrite instead of read-modify-write (dW is
         # 31 MB per decoder layer: a sixth of the grouped launch's traffic).  _first_micro: set by train_step around its call.
@@ -556,6 +560,12 @@ class KokoroEngine:
             yield
         finally:
             del self._wgrad_queue[ns]
+        if self._defer_wgrads is not None:               # (the caller issues this group later, elsewhere: _issue_wgrad_group)
+            self._defer_wgrads.append(q)
+            return
+        self._issue_wgrad_group(q)
+
+    def _issue_wgrad_group(self, q) -> None:
         for i in range(0, len(q), 8):
             part = q[i:i + 8]
             sig = ("wg",) + tuple((dy.data_ptr(), x.data_ptr(), dw.data_ptr(), tuple(dy.shape), tuple(x.shape)) for dy, x, dw in part)
@@ -1319,6 +1329,10 @@ class KokoroEngine:
                 if tail_mode in (3, 4):                   # the memory tail behind the encoder's backward (no third branch)
                     torch.cuda.current_stream().wait_event(tail_fork)
                     memory_tail()
+                    if deferred0:
+                        torch.cuda.current_stream().wait_event(wgrad0_fork)
+                        for q in deferred0:
+                            self._issue_wgrad_group(q)
 
         # The decoder backward is the critical path, so it is captured first and the predictors' + encoder's backward
         # after it, forked from the point right after the loss gradients (see _on_stream).
@@ -1335,6 +1349,7 @@ class KokoroEngine:
         dmem = self._buf("g.memory", Nd, H)
         tail_mode = (4 if Nd <= 4096 else 3) if self.tail_aside < 0 else self.tail_aside
         tail_mode = tail_mode if self.overlap else 0
+        deferred0 = []
         dn = self._buf("tmp.dn", Nd, H, dtype=ddt)
         for i in reversed(range(d.dec_layers)):
             pf, key, st = f"decoder.layers.{i}", f"dec{i}", 2000 + 32 * i
@@ -1342,6 +1357,12 @@ class KokoroEngine:
             x_in = self._buf(f"dec{i - 1}.xo", Nd, H) if i > 0 else self._buf("dec.x0", Nd, H)
             ya, yc = self._buf(key + ".xa", Nd, H), self._buf(key + ".xc", Nd, H)
             n1, n2, n3 = (self._buf(f"{key}.ln{j}.y", Nd, H, dtype=ddt) for j in (1, 2, 3))
+            # layer 0's grouped weight gradients: nothing on the main chain overwrites their operands any more (the layer-norm backward and
+            # the input projection below use their own buffers), so the launch can wait for the side stream's idle end (wgrad0_aside)
+            defer0 = i == 0 and tail_mode in (3, 4) and self.group_wgrads and self.dp_comm is None and \
+                (self.wgrad0_aside > 0 or (self.wgrad0_aside < 0 and tail_mode == 3))
+            if defer0:
+                self._defer_wgrads = deferred0 = []
             with self._grouped_wgrads():
                 self._ffn_bwd(key + ".ff", pf + ".ff", dy, n3, dn, d.dec_ff, T, st + 16, p_dec, dpr)
                 self._tail_bwd(key + ".ln3", dn, yc, pf + ".norm3", dy, True, dhead("ca", i))
@@ -1353,6 +1374,9 @@ class KokoroEngine:
                         self._cross_kv_bwd_all(memory, Nd, ddt, dmem, dgrad=False)
                 self._tail_bwd(key + ".ln2", dn, ya, pf + ".norm2", dy, True, dhead("sa", i))
                 self._attn_bwd(key + ".sa", pf + ".self_attn", dy, n1, None, B, T, T, True, True, None, dn, None, 0.0, st, p_dec, dpr)
+            if defer0:
+                self._defer_wgrads = None
+                wgrad0_fork = self._fork_point()
             self._comm_bucket(f"dec{i}")                    # the layer's weight matrices are final: exchange beside the rest
             if i > 0:
                 self._tail_bwd(key + ".ln1", dn, x_in, pf + ".norm1", dy, True, dhead("ffn", i - 1))
