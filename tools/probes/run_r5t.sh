@@ -1,7 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-o=gpurun_out/r5wg; mkdir -p $o
-EXTRA="--workload dyn16384" bash tools/probes/ab.sh $o/abdyn 2 "SET:wgrad0_aside=0" "SET:wgrad0_aside=-1" | tee $o/abdyn.txt
-EXTRA="--frames 768 --phonemes 96" bash tools/probes/ab.sh $o/ab768 2 "SET:wgrad0_aside=0" "SET:wgrad0_aside=-1" | tee $o/ab768.txt
-EXTRA="--batch 16 --frames 512 --phonemes 64" bash tools/probes/ab.sh $o/ab16x512 2 "SET:wgrad0_aside=0" "SET:wgrad0_aside=-1" | tee $o/ab16x512.txt
+o=gpurun_out/r5sk; mkdir -p $o
+bash tools/probes/ab.sh $o/ab512 3 "SET:kv_dgrad_split=0" "SET:kv_dgrad_split=2" "SET:kv_dgrad_split=4" | tee $o/ab512.txt
+EXTRA="--frames 1024 --phonemes 128" bash tools/probes/ab.sh $o/ab1024 2 "SET:kv_dgrad_split=0" "SET:kv_dgrad_split=2" | tee $o/ab1024.txt
