@@ -1,8 +1,7 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-o=gpurun_out/r5w1; mkdir -p $o
-timeout 900 python -m pytest tests/test_engine_gpu.py -x -q -m gpu -k "memory_tail or zero_fill or graphed_accumulation or bench_config or workspace" > $o/test.log 2>&1; tail -5 $o/test.log
-EXTRA="--frames 1024 --phonemes 128" bash tools/probes/ab.sh $o/ab1024 3 "SET:wgrad1_aside=0" "SET:wgrad1_aside=1" | tee $o/ab1024.txt
-EXTRA="--workload dyn16384" bash tools/probes/ab.sh $o/abdyn 2 "SET:wgrad1_aside=0" "SET:wgrad1_aside=1" | tee $o/abdyn.txt
-EXTRA="--frames 768 --phonemes 96" bash tools/probes/ab.sh $o/ab768 2 "SET:wgrad1_aside=0" "SET:wgrad1_aside=1" | tee $o/ab768.txt
+o=gpurun_out/r5soak; mkdir -p $o
+timeout 600 python tools/probes/dyn_stress.py 60 bf16 > $o/dyn_stress.log 2>&1; echo "dyn_stress rc=$?"; tail -3 $o/dyn_stress.log
+for i in 1 2 3 4 5 6; do timeout 600 python -m pytest tests/test_engine_gpu.py -q -m gpu -p no:cacheprovider -k "memory_tail or graphed_accumulation or bench_config or zero_fill or rccl or dynamic" 2>&1 | grep -E " passed| failed|^FAILED"; done | tee $o/soak.txt
+timeout 900 python -m pytest tests/test_trainer_gpu.py -q -m gpu -p no:cacheprovider 2>&1 | grep -E " passed| failed|^FAILED" | tee -a $o/soak.txt
