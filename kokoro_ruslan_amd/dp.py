@@ -173,8 +173,17 @@ class BucketedExchange:
         # on the side branch or by the tail (profiles/r05_dp_exchange_one_gpu_ab.txt; a one-rank fp32 all-reduce enqueues no kernel, which
         # hid this until round 5).  Default: TWO groups of about equal bytes, {dec5..dec0, enc5} and {enc4..enc0, tail} at default dims
         # (KK_DP_GROUPS = a count, or "dec3,enc0" = explicit closing buckets for probes).
-        g = groups if groups is not None else os.environ.get("KK_DP_GROUPS", "2")
-        if isinstance(g, str) and not g.strip().isdigit():      # "dec3,dec0": explicit groups, each closed by the named bucket (probes)
+        # Round 5, late: the default is "2+tail" — the second of the two groups gives up the tail bucket to a third: {enc4..enc0} then
+        # closes with the encoder's backward (260 us before the end of the backward at 8x512) and only the tail (small vectors, the
+        # batched cross K/V projections, embeddings, predictors, heads: ~10 % of the bytes) waits for the last launch.  One-GPU price of
+        # the third group: +0.02 ... +0.04 ms with a kernel on the branch (profiles/r05_dp_exchange_one_gpu_ab.txt); what it saves in
+        # exposed exchange at N > 1 is an estimate until a multi-GPU box measures it.
+        g = groups if groups is not None else os.environ.get("KK_DP_GROUPS", "2+tail")
+        if isinstance(g, str) and g.strip() == "2+tail":
+            self.groups = group_buckets(self.plan, 2)
+            if len(self.groups[-1]) > 1:
+                self.groups = self.groups[:-1] + [self.groups[-1][:-1], self.groups[-1][-1:]]
+        elif isinstance(g, str) and not g.strip().isdigit():    # "dec3,dec0": explicit groups, each closed by the named bucket (probes)
             ends, self.groups = set(g.split(",")), [[]]
             for t in self.plan:
                 self.groups[-1].append(t)

@@ -208,7 +208,8 @@ def _bucket_worker(rank, world, port, q):
     # round 5: the buckets travel in GROUPS (one exchange per group, issued when its last bucket is final) — the engine's arrival
     # order may differ from the plan's (encoder buckets come from the side branch): any order must give the sum of the whole arena
     grouped_ok = True
-    for n_groups, order in ((2, list(ex.plan)), (3, ["enc1", "dec1", "enc0", "dec0", "tail"]), (1, list(ex.plan)[::-1]), (13, list(ex.plan))):
+    for n_groups, order in ((2, list(ex.plan)), (3, ["enc1", "dec1", "enc0", "dec0", "tail"]), (1, list(ex.plan)[::-1]), (13, list(ex.plan)),
+                            ("2+tail", list(ex.plan)), (None, ["enc1", "dec1", "enc0", "dec0", "tail"])):
         g2 = torch.Generator().manual_seed(100 + rank)
         f2 = torch.randn(total, generator=g2)
         ex2 = dp.BucketedExchange(dims, world, backend="dist", groups=n_groups)
@@ -219,7 +220,10 @@ def _bucket_worker(rank, world, port, q):
             if tags is not None:
                 ex2.reduce_tags(f2, tags)
                 calls += 1
-        grouped_ok = grouped_ok and bool(torch.equal(f2, whole)) and calls == min(n_groups, len(ex.plan)) and sorted(ex2.issued) == sorted(ex.plan)
+        want_calls = min(n_groups, len(ex.plan)) if isinstance(n_groups, int) else 3      # (the default: two groups + the tail alone)
+        if not isinstance(n_groups, int):
+            grouped_ok = grouped_ok and ex2.groups[-1] == ["tail"] and len(ex2.groups) == 3 and "tail" not in ex2.groups[1]
+        grouped_ok = grouped_ok and bool(torch.equal(f2, whole)) and calls == want_calls and sorted(ex2.issued) == sorted(ex.plan)
     if rank == 0:
         q.put((bool(torch.equal(flat, whole)) and grouped_ok, list(ex.issued), in_step, diverged_seen))
     dist.destroy_process_group()
