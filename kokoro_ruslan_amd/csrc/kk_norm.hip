@@ -78,10 +78,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TD *__restrict
                                                             const float *__restrict__ rstd, float *__restrict__ dx,
                                                             int dx_acc, float *__restrict__ dgamma, float *__restrict__ dbeta,
                                                             float *__restrict__ partials, int64_t rows, int H) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];   // [2][H]
-    float *sg = sm, *sb = sm + H;
-    for (int c = threadIdx.x; c < 2 * H; c += blockDim.x) sm[c] = 0.f;
-    __syncthreads();
+    // [waves][2][H]: every wave leaves its column sums in a slab of its own (plain 16-byte stores; LDS float atomics move about one
+    // lane per two clocks per CU: 4096 of them were ~3.4 us of this launch), the workgroup adds the four slabs after one barrier
+    extern __shared__ __attribute__((aligned(16))) float sm[];
     const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
     float4 ag[NV], ab[NV], gm[NV];
 #pragma unroll
@@ -143,22 +142,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TD *__restrict
             }
         }
     }
+    float *slab = sm + (size_t)(threadIdx.x >> 6) * 2 * H;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = lane * 4 + 256 * i;
         if (c < H) {
-            atomicAdd(&sg[c], ag[i].x); atomicAdd(&sg[c + 1], ag[i].y); atomicAdd(&sg[c + 2], ag[i].z); atomicAdd(&sg[c + 3], ag[i].w);
-            atomicAdd(&sb[c], ab[i].x); atomicAdd(&sb[c + 1], ab[i].y); atomicAdd(&sb[c + 2], ab[i].z); atomicAdd(&sb[c + 3], ab[i].w);
+            st4(slab + c, ag[i]);
+            st4(slab + H + c, ab[i]);
         }
     }
     __syncthreads();
-    if (partials) {
-        for (int c = threadIdx.x; c < 2 * H; c += blockDim.x) partials[(int64_t)blockIdx.x * 2 * H + c] = sm[c];
-        return;
-    }
-    for (int c = threadIdx.x; c < H; c += blockDim.x) {
-        atomicAdd(&dgamma[c], sg[c]);
-        atomicAdd(&dbeta[c], sb[c]);
+    for (int c = threadIdx.x; c < 2 * H; c += blockDim.x) {
+        float s = sm[c];
+        for (int w = 1; w < wpb; ++w) s += sm[(size_t)w * 2 * H + c];
+        if (partials) partials[(int64_t)blockIdx.x * 2 * H + c] = s;
+        else atomicAdd(c < H ? &dgamma[c] : &dbeta[c - H], s);
     }
 }
 
@@ -615,7 +613,7 @@ extern "C" int kk_layernorm_bwd(const float *dy, const float *x, const float *ga
     KK_CHECK_H("kk_layernorm_bwd");
     const int nv = kk_cdiv(H, 256);
     const int blocks = kk_norm_bwd_blocks(rows, H);            // (rows in flight per wave: 4 / 2 / 1 by register budget)
-    const size_t shm = 2 * H * sizeof(float);
+    const size_t shm = (size_t)4 * 2 * H * sizeof(float);     // one [2][H] slab per wave
     hipStream_t st = (hipStream_t)stream;
 #define KK_LN_BWD(TD, NV, R)                                                                                                  \
     hipLaunchKernelGGL((layernorm_bwd_kernel<TD, NV, R>), dim3(blocks), dim3(256), shm, st, reinterpret_cast<const TD *>(dy), x, gamma, \
