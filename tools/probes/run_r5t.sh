@@ -1,7 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-o=gpurun_out/r5final; mkdir -p $o
-timeout 1500 python -m pytest tests -q -m gpu > $o/test.log 2>&1; grep -n "passed\|failed\|FAILED" $o/test.log | tail -8
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-bash tools/round_artifacts.sh r05 > $o/artifacts.log 2>&1; tail -3 $o/artifacts.log | cut -c1-200
+o=gpurun_out/r5ln; mkdir -p $o
+bash tools/probes/ab.sh $o/ab512 4 "LIBV=lnatom" "LIBV=tuning" | tee $o/ab512.txt
+EXTRA="--frames 1024 --phonemes 128" bash tools/probes/ab.sh $o/ab1024 2 "LIBV=lnatom" "LIBV=tuning" | tee $o/ab1024.txt
