@@ -22,7 +22,9 @@
 extern "C" {
 #endif
 
-#define KK_ABI_VERSION 1
+#define KK_ABI_VERSION 2 /* 2 (round 6): kk_seg_sumsq takes a record workspace instead of `zeroed`; p_sumsq of kk_adamw_ema /
+                          kk_weight_norm_project is an int64 Q34.30 sum; round 5 had already added parameters to kk_losses_fwd,
+                          kk_losses_finalize, kk_opt_prepare, kk_adamw_ema, kk_rowdot_bwd and fields to KkOptCfg under version 1 */
 #define KK_MATH_F32 0
 #define KK_MATH_BF16 1
 #define KK_EINVAL (-22)
@@ -498,9 +500,12 @@ typedef struct KkOptCfg {
 #define KK_OS_MICRO_BAD 14    /* set by kk_losses_*: a micro-batch of the current cycle had non-finite outputs / losses */
 #define KK_OS_MICRO_BAD_TOTAL 15 /* micro-batches flagged so far */
 #define KK_OS_SIZE 16
-/* sumsq[seg] (double) = sum of squares of each arena segment of `buf`.  zeroed == 0: the call zero-fills sumsq first (one more
- * launch); zeroed != 0: the caller guarantees sumsq is zero on entry (kk_opt_prepare, its only reader, can leave it so). */
-int kk_seg_sumsq(const float *buf, const int32_t *block_seg, int64_t nblocks, double *sumsq, int nseg, int zeroed,
+/* sumsq[seg] (double) = sum of squares of each arena segment of `buf`, as a PURE FUNCTION of the buffer: workgroup partials are
+ * merged in arena order by a fixed tree (no atomics), so data-parallel replicas holding the same reduced gradient compute the same
+ * bits (trainer.py:2355-2362 is a host-side sum with the same property).  Every segment is stored exactly once: no zero-fill.
+ * ws: kk_seg_sumsq_ws_bytes(nblocks) bytes of scratch (contents irrelevant on entry). */
+int64_t kk_seg_sumsq_ws_bytes(int64_t nblocks);
+int kk_seg_sumsq(const float *buf, const int32_t *block_seg, int64_t nblocks, double *sumsq, int nseg, void *ws,
                  void *stream);
 /* One-thread-block kernel: per-parameter pre-clip, total norm, non-finite check, explosion tracker,
  * adaptive + global clip, LR schedule -> per-segment gradient scale / lr / step-size constants. */
@@ -509,19 +514,20 @@ int kk_opt_prepare(const double *grad_sumsq, const float *seg_preclip, const flo
                    double *opt_state, float *seg_gscale, float *seg_decay, float *seg_stepsize,
                    float *step_consts /* [4]: mode (0 step + EMA, 1 skipped, 2 step without EMA), sqrt(1-beta2^t), eps, base_lr */,
                    double *clear_a, double *clear_b /* nullable: per-segment accumulators [nseg] left zero by this launch — grad_sumsq
-                   itself (read before it is cleared) for the next kk_seg_sumsq(zeroed = 1), p_sumsq for the kk_adamw_ema(zeroed = 1)
-                   that follows */, void *stream);
+                   itself (kk_seg_sumsq stores every segment, so this is hygiene only), p_sumsq (8-byte words: zero bits are zero in both
+                   types) for the kk_adamw_ema(zeroed = 1) that follows */, void *stream);
 /* Fused single pass: p,g,m,v,(ema) -> p,m,v,(ema).  seg_flags bit0: AdamW-updated, bit1: EMA-tracked,
- * bit2: weight-norm target (its post-step sum of squares is accumulated into p_sumsq; zeroed == 0: zero-filled by the call first,
- * zeroed != 0: zero on entry, e.g. cleared by the kk_opt_prepare in front of it).
+ * bit2: weight-norm target (its post-step sum of squares is accumulated into p_sumsq as a Q34.30 FIXED-POINT integer — integer adds
+ * commute, so the sum and the projection decision taken from it do not depend on the order the blocks arrive in; zeroed == 0:
+ * zero-filled by the call first, zeroed != 0: zero on entry, e.g. cleared by the kk_opt_prepare in front of it).
  * p_bf16 (optional): bf16 shadow of the arena, same element offsets, rewritten wherever p is (the bf16 mode's
  * GEMMs read weights from it). */
 int kk_adamw_ema(float *p, const float *g, float *m, float *v, float *ema, const int32_t *block_seg,
                  int64_t nblocks, const float *seg_gscale, const float *seg_decay, const float *seg_stepsize,
                  const int32_t *seg_flags, const float *step_consts, float beta1, float beta2,
-                 float ema_decay, double *p_sumsq, int nseg, void *p_bf16, int zeroed, void *stream);
+                 float ema_decay, int64_t *p_sumsq, int nseg, void *p_bf16, int zeroed, void *stream);
 /* FFN weight-norm projection: for flagged segments with ||W|| > max: W *= max/||W||. */
-int kk_weight_norm_project(float *p, const int32_t *block_seg, int64_t nblocks, const double *p_sumsq,
+int kk_weight_norm_project(float *p, const int32_t *block_seg, int64_t nblocks, const int64_t *p_sumsq /* Q34.30 */,
                            const int32_t *seg_flags, const float *step_consts, double max_norm, void *p_bf16,
                            void *stream);
 /* dst (bf16) = src (fp32), n % 4 == 0: builds the weight shadow after a checkpoint load. */

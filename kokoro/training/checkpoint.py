@@ -117,10 +117,7 @@ def assemble_checkpoint(*, model_sd: Dict[str, torch.Tensor], ema_sd: Optional[D
     if not getattr(hp, "use_onecycle_lr", True):
         # legacy schedule (trainer.py:789-799): CosineAnnealingWarmRestarts stepped once per epoch, BEFORE the epoch's checkpoint is
         # written (trainer.py:2885-2887) — the saved state is the one after epoch + 1 steps, and the groups carry the next epoch's lr
-        t_cur, t_i = epoch + 1, int(hp.lr_T_0)
-        while t_cur >= t_i:
-            t_cur -= t_i
-            t_i *= int(hp.lr_T_mult)
+        t_cur, t_i = spec.cosine_restart_position(epoch + 1, hp.lr_T_0, hp.lr_T_mult)
         f = spec.cosine_restart_factor(epoch + 1, hp.lr_T_0, hp.lr_T_mult)
         table = spec.group_lr_mult_wd(hp)
         for gi, g in enumerate(optimizer_sd["param_groups"]):

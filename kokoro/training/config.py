@@ -79,6 +79,7 @@ _FIELDS = [
     # ---- new (MI355X engine) -------------------------------------------------------------------------------
     ("mixed_precision_dtype", str, "bfloat16"),   # MFMA arithmetic when use_mixed_precision is on
     ("dp_world_size", int, 1),                     # data-parallel ranks (one process per GPU, RCCL)
+    ("replica_check_every", int, 500),             # data parallel: optimizer steps between parameter-checksum tripwires (0 = only at checkpoints)
 ]
 N_REFERENCE_FIELDS = 133
 

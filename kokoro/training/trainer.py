@@ -212,6 +212,15 @@ class KokoroTrainer:
         # one synchronisation per micro-batch.
         self.strict_nonfinite_guard = os.environ.get("KK_STRICT_NONFINITE", "0") == "1"
         self.prefetch_depth = int(os.environ.get("KK_PREFETCH_DEPTH", "3"))
+        # data parallel: replicas never exchange weights — identical reduced gradients through the identical (order-deterministic)
+        # optimizer pass keep them bit-identical.  The tripwire checks that every `replica_check_every` optimizer steps
+        # and at every epoch end (before validation / checkpoints), and re-broadcasts rank 0's state with a warning on divergence.
+        self.replica_check_every = max(0, int(getattr(config, "replica_check_every", 500)))
+        self.opt_steps = 0
+        self.replica_resyncs = 0
+        if not hp.use_onecycle_lr:
+            from kokoro_ruslan_amd import spec as _spec
+            _spec.cosine_restart_position(0, hp.lr_T_0, hp.lr_T_mult)      # (raises ValueError like torch's scheduler constructor)
         logger.info("engine ready: %d params, %s math, %d train / %d val utterances, %d batches/epoch, world %d",
                     sum(math.prod(s) for s in self.engine.arena.shapes.values()), math_mode, len(self.dataset),
                     len(self.val_dataset) if self.val_dataset else 0, len(self.sampler), self.world)
@@ -265,14 +274,26 @@ class KokoroTrainer:
                     losses += step(batch, div, boundary, self.sync if (self.world > 1 and self.sync is not None) else None, expanded if expanded != T else None)
                 acc = 0 if boundary else acc + 1
                 n += 1
+                if boundary:
+                    self.opt_steps += 1                       # (equal on every rank: the samplers hand out equal step counts)
+                    if self.world > 1 and self.replica_check_every and self.opt_steps % self.replica_check_every == 0:
+                        self._check_replicas(f"optimizer step {self.opt_steps}")
         finally:
             e.train_dropout = False
         avg = (losses / max(n, 1)).cpu().tolist()          # the only host sync of the epoch
         e.check_encoder_stack()                            # (a second word read at the same sync point: raises on a timed-out barrier)
+        if self.world > 1:                                 # every rank, before anything (validation, checkpoint) reads the weights
+            self._check_replicas(f"end of epoch {epoch + 1}")
         if n == 0:
             logger.warning("epoch %d: no training batches", epoch + 1)
         logger.info("epoch %d train: total %.4f mel %.4f dur %.4f stop %.4f pitch %.4f energy %.4f", epoch + 1, *avg)
         return avg[0]
+
+    def _check_replicas(self, where: str) -> bool:
+        ok = dp.check_replicas(self.engine, logger, where)
+        if not ok:
+            self.replica_resyncs += 1
+        return ok
 
     def _val_batches(self):
         """Validation batches like the reference (trainer.py:331-348): same sampler family, no shuffle, nothing dropped;

@@ -14,6 +14,7 @@ The functions take plain tensors so the same code runs under `gloo` on CPU (test
 """
 from __future__ import annotations
 
+import logging
 import os
 from collections import OrderedDict
 from typing import Dict, List, Optional, Tuple
@@ -333,18 +334,58 @@ def all_max(x: torch.Tensor) -> torch.Tensor:
     return x
 
 
+def _arena_checksum(flat: torch.Tensor) -> torch.Tensor:
+    """Two exact int64 checksums of a flat fp32 tensor's BITS (sum of the words, sum of the words weighted by a position pattern):
+    integer arithmetic, so a single flipped mantissa bit anywhere changes them, whatever the magnitudes around it."""
+    w = flat.contiguous().view(torch.int32).to(torch.int64)
+    pos = (torch.arange(w.numel(), device=w.device, dtype=torch.int64) % 8191) + 1
+    return torch.stack([w.sum(), (w * pos).sum()])
+
+
 def replicas_in_step(flat_params: torch.Tensor) -> bool:
     """True when every rank holds bit-identical parameters (data-parallel replicas never exchange weights: identical reduced
-    gradients through the identical optimizer pass keep them equal, so any difference means the exchange went wrong).
-    Two fp64 checksums (sum, sum of squares), MIN- and MAX-reduced; collective — call it on every rank."""
-    x = flat_params.double()
-    chk = torch.stack([x.sum(), (x * x).sum()])
+    gradients through the identical optimizer pass keep them equal, so any difference means the exchange or the pass went wrong).
+    Exact integer checksums of the bits, MIN- and MAX-reduced; non-finite parameters also fail.  Collective — call it on every rank."""
+    finite = bool(torch.isfinite(flat_params.double().sum()))
+    chk = _arena_checksum(flat_params)
     if not (dist.is_initialized() and dist.get_world_size() > 1):
-        return bool(torch.isfinite(chk).all())
+        return finite
+    if dist.get_backend() != "nccl":
+        chk = chk.cpu()
     lo, hi = chk.clone(), chk.clone()
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-    return bool(torch.isfinite(hi).all() and torch.equal(lo, hi))
+    ok = torch.tensor([1.0 if finite else 0.0], device=lo.device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    return bool(float(ok) == 1.0 and torch.equal(lo, hi))
+
+
+def resync_replicas(slabs, src: int = 0) -> None:
+    """Re-broadcast rank `src`'s copy of every tensor in `slabs` (parameters, Adam moments, EMA, bf16 shadow): what the trainer does
+    when replicas_in_step() fails ("verify with a periodic parameter-checksum all-reduce").  Collective."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    for t in slabs:
+        if t is None:
+            continue
+        if dist.get_backend() == "nccl" or not t.is_cuda:
+            dist.broadcast(t, src=src)
+        else:                                             # (gloo with device tensors: through the host)
+            h = t.cpu()
+            dist.broadcast(h, src=src)
+            t.copy_(h)
+
+
+def check_replicas(engine, log=None, where: str = "") -> bool:
+    """The trainer's tripwire: True when the replicas agree; otherwise warns, re-broadcasts rank 0's state (parameters, moments, EMA,
+    bf16 weight shadow) and returns False.  Collective."""
+    a = engine.arena
+    if replicas_in_step(a.p):
+        return True
+    (log or logging.getLogger(__name__)).warning(
+        "data-parallel replicas diverged%s: re-broadcasting rank 0's parameters, Adam moments and EMA", f" ({where})" if where else "")
+    resync_replicas([a.p, a.m, a.v, a.ema, a.p16, engine.opt_state])
+    return False
 
 
 def barrier() -> None:

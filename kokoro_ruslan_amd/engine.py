@@ -160,7 +160,10 @@ class KokoroEngine:
         self.seg_gscale, self.seg_decay, self.seg_stepsize = f32(ns), f32(ns), f32(ns)
         self.step_consts = f32(4)
         self.grad_sumsq = torch.zeros(ns, dtype=torch.float64, device=self.device)
-        self.p_sumsq = torch.zeros(ns, dtype=torch.float64, device=self.device)
+        # (Q34.30 fixed-point sums: integer adds commute, so the weight-norm projection decides the same on every replica)
+        self.p_sumsq = torch.zeros(ns, dtype=torch.int64, device=self.device)
+        # record workspace of kk_seg_sumsq: workgroup partials merged in arena order by a fixed tree (no atomics, no zero-fill)
+        self.sumsq_ws = torch.zeros(kk.load().kk_seg_sumsq_ws_bytes(self.arena.nblocks), dtype=torch.uint8, device=self.device)
         self.max_dur = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.loss_acc = torch.zeros(12, dtype=torch.float64, device=self.device)    # 5 sums, 5 counts, non-finite outputs, spare
         self.losses = f32(6)
@@ -237,7 +240,13 @@ class KokoroEngine:
         self.fuse_linear_tail = True
         # the step's small fp64 accumulators (loss sums, per-segment gradient / parameter norms) are kept zero by their last readers
         # instead of a zero-fill launch in front of every writer (three dependent launches of the critical chain)
-        self.self_cleaning_acc = True
+        # _acc_clean: host-side record of the invariant "the accumulators are zero between steps".  It is dropped while a writer ..
+        # cleaner sequence is in flight and restored only when the sequence has been issued completely (_acc_guard): a step that
+        # aborts in between (a collective or a launch raising), or a flip of the switch on a live engine, costs one zero-fill
+        # instead of silently adding onto stale sums.
+        self._acc_clean = True
+        self._acc_depth = 0
+        self._self_cleaning_acc = True
         # key-padding mask + embedding (+ PE, dropout) + the first encoder layer's pre-LayerNorm as one launch (kk_embed_ln_fwd): the
         # head of the critical path in front of the encoder forward is 3 dependent launches instead of 5
         self.fuse_enc_prologue = True
@@ -284,6 +293,38 @@ class KokoroEngine:
         elif self.arena.ema is not None:
             self.arena.ema.copy_(self.arena.p)
         self.sync_shadow()
+
+    @property
+    def self_cleaning_acc(self) -> bool:
+        return self._self_cleaning_acc
+
+    @self_cleaning_acc.setter
+    def self_cleaning_acc(self, on) -> None:
+        if bool(on) != self._self_cleaning_acc:     # (the other mode's last reader did not leave the sums as this mode expects them)
+            self._acc_clean = False
+        self._self_cleaning_acc = bool(on)
+
+    @contextlib.contextmanager
+    def _acc_guard(self):
+        """Around every sequence that writes and then cleans the handed-round accumulators (loss_acc in _fb; p_sumsq in
+        optimizer_step; a graph capture / replay of either): restores the zero state first when an earlier sequence did not complete."""
+        if self._acc_depth == 0:
+            if not self._acc_clean:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("the step's accumulators are not in their zero state inside a graph capture")
+                self.loss_acc.zero_()
+                self.grad_sumsq.zero_()
+                self.p_sumsq.zero_()
+            self._acc_clean = False
+        self._acc_depth += 1
+        try:
+            yield
+        except BaseException:
+            self._acc_depth -= 1
+            raise
+        self._acc_depth -= 1
+        if self._acc_depth == 0:
+            self._acc_clean = True
 
     # ------------------------------------------------------------------ state
     def load_params(self, params: Dict[str, torch.Tensor], reset_ema: bool = True) -> None:
@@ -1052,6 +1093,15 @@ class KokoroEngine:
 
     def _fb(self, batch, loss_scale, adaptive, backward, zero_grads=False, expanded_len=None):
         """The launch sequence of forward_backward (also what train_step_graphed captures)."""
+        self._defer_wgrads = None                     # (a list only while layer 0's grouped launch is being collected: ADVICE r5)
+        try:
+            with self._acc_guard():
+                return self._fb_launches(batch, loss_scale, adaptive, backward, zero_grads, expanded_len)
+        finally:
+            self._defer_wgrads = None
+            self._wgrad_queue.clear()
+
+    def _fb_launches(self, batch, loss_scale, adaptive, backward, zero_grads=False, expanded_len=None):
         d, a, P, G = self.dims, self.arena, self.arena.P, self.arena.G
         self._grads_fresh = bool(zero_grads) or self._first_micro
         self._ow_seen = set() if (self._grads_fresh and backward) else None
@@ -1362,7 +1412,7 @@ class KokoroEngine:
             defer0 = i == 0 and tail_mode in (3, 4) and self.group_wgrads and self.dp_comm is None and \
                 (self.wgrad0_aside > 0 or (self.wgrad0_aside < 0 and tail_mode == 3))
             if defer0:
-                self._defer_wgrads = deferred0 = []
+                self._defer_wgrads = deferred0 = []           # (reset by _fb whatever happens in between)
             with self._grouped_wgrads():
                 self._ffn_bwd(key + ".ff", pf + ".ff", dy, n3, dn, d.dec_ff, T, st + 16, p_dec, dpr)
                 self._tail_bwd(key + ".ln3", dn, yc, pf + ".norm3", dy, True, dhead("ca", i))
@@ -1664,18 +1714,20 @@ class KokoroEngine:
         a, hp = self.arena, self.hp
         cfg = self._opt_cfg(mel_length)
         self._mark("optimizer start")
-        # grad_sumsq / p_sumsq are private to this sequence: kk_opt_prepare, the one-workgroup launch between their writers, leaves
-        # both zero (grad_sumsq after reading it, for the next step) — two zero-fill launches less on the optimizer's chain
-        sc = 1 if self.self_cleaning_acc else 0
-        kk.call("kk_seg_sumsq", a.g, a.block_seg, a.nblocks, self.grad_sumsq, a.nseg, sc)
-        kk.call("kk_opt_prepare", self.grad_sumsq, a.seg_preclip, a.seg_lr_mult, a.seg_wd, a.nseg, self.max_dur, cfg,
-                self.opt_state, self.seg_gscale, self.seg_decay, self.seg_stepsize, self.step_consts,
-                self.grad_sumsq if sc else None, self.p_sumsq if sc else None)
-        kk.call("kk_adamw_ema", a.p, a.g, a.m, a.v, a.ema, a.block_seg, a.nblocks, self.seg_gscale, self.seg_decay,
-                self.seg_stepsize, a.seg_flags, self.step_consts, hp.adam_betas[0], hp.adam_betas[1], hp.ema_decay,
-                self.p_sumsq, a.nseg, a.p16, sc)
-        kk.call("kk_weight_norm_project", a.p, a.block_seg, a.nblocks, self.p_sumsq, a.seg_flags, self.step_consts,
-                float(hp.dec_ffn_max_weight_norm), a.p16)
+        # grad_sumsq: every segment stored once per call by kk_seg_sumsq (records merged in a fixed order: replicas agree bit for bit).
+        # p_sumsq (fixed-point atomics) is private to this sequence: kk_opt_prepare, the one-workgroup launch in front of its writer,
+        # leaves it zero — no zero-fill launch on the optimizer's chain.
+        with self._acc_guard():
+            sc = 1 if self.self_cleaning_acc else 0
+            kk.call("kk_seg_sumsq", a.g, a.block_seg, a.nblocks, self.grad_sumsq, a.nseg, self.sumsq_ws)
+            kk.call("kk_opt_prepare", self.grad_sumsq, a.seg_preclip, a.seg_lr_mult, a.seg_wd, a.nseg, self.max_dur, cfg,
+                    self.opt_state, self.seg_gscale, self.seg_decay, self.seg_stepsize, self.step_consts,
+                    None, self.p_sumsq if sc else None)
+            kk.call("kk_adamw_ema", a.p, a.g, a.m, a.v, a.ema, a.block_seg, a.nblocks, self.seg_gscale, self.seg_decay,
+                    self.seg_stepsize, a.seg_flags, self.step_consts, hp.adam_betas[0], hp.adam_betas[1], hp.ema_decay,
+                    self.p_sumsq, a.nseg, a.p16, sc)
+            kk.call("kk_weight_norm_project", a.p, a.block_seg, a.nblocks, self.p_sumsq, a.seg_flags, self.step_consts,
+                    float(hp.dec_ffn_max_weight_norm), a.p16)
         self._mark("optimizer done")
 
     def train_step(self, batch: Dict[str, torch.Tensor], accumulation_divisor: Optional[int] = None,
@@ -1791,26 +1843,34 @@ class KokoroEngine:
         # graph captured under one value must not be replayed under another: ADVICE r3; the CANONICAL value, so that a ragged
         # data-parallel run replays one capture per local shape for every global length up to 1400: canonical_mel_length)
         fkey = (div, first, self.train_dropout, self.spec_augment_active, self.math, self.dp_comm is not None and is_boundary,
-                mel_length if self.loss_sync is not None else 0, self.loss_sync is not None)
-        fb = ent["fb"].get(fkey)
-        if fb is None:
-            with self.capture_lock:
-                fb = ent["fb"][fkey] = self._capture_fb(static, scale, first, expanded_len)
-        self._exchange_now = True
-        fb.replay()
+                mel_length if self.loss_sync is not None else 0, self.loss_sync is not None, self.self_cleaning_acc)
+        with self._acc_guard():                        # (a replayed graph assumes the accumulators' zero state like an eager step)
+            fb = ent["fb"].get(fkey)
+            if fb is None:
+                with self.capture_lock:
+                    fb = ent["fb"][fkey] = self._capture_fb(static, scale, first, expanded_len)
+            self._exchange_now = True
+            fb.replay()
         self.micro_in_cycle += 1
         if grad_sync is not None and is_boundary:
             grad_sync(self.arena.g)
         if is_boundary:
-            okey = (mel_length, 0 if self.hp.use_onecycle_lr else self.lr_epoch)    # (KkOptCfg travels by value: the legacy schedule's
-            opt = ent["opt"].get(okey)                                             #  factor changes once per epoch -> one re-capture)
-            if opt is None:
-                with self.capture_lock:
-                    torch.cuda.synchronize()
-                    opt = ent["opt"][okey] = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(opt, capture_error_mode="thread_local"):
-                        self.optimizer_step(mel_length)
-            opt.replay()
+            # (KkOptCfg travels by value: the legacy schedule's factor changes once per epoch -> one re-capture per epoch; the graphs of
+            #  earlier epochs are dropped then — they can never be replayed again and would otherwise pile up, epochs x shapes: ADVICE r5)
+            epoch = 0 if self.hp.use_onecycle_lr else self.lr_epoch
+            okey = (mel_length, epoch, self.self_cleaning_acc)
+            for k in [k for k in ent["opt"] if k[1] != epoch]:
+                torch.cuda.synchronize(self.device)   # (a graph about to be destroyed may still be running)
+                del ent["opt"][k]
+            with self._acc_guard():
+                opt = ent["opt"].get(okey)
+                if opt is None:
+                    with self.capture_lock:
+                        torch.cuda.synchronize()
+                        opt = ent["opt"][okey] = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(opt, capture_error_mode="thread_local"):
+                            self.optimizer_step(mel_length)
+                opt.replay()
             self.micro_in_cycle = 0
         return self.losses
 

@@ -212,7 +212,7 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_losses_fwd": [_P] * 12 + [_I, _I, _I, _I, C.POINTER(KkLossCfg), _P, _P, _P, _P, _P, _I, _P],
     "kk_losses_finalize": [_P, C.POINTER(KkLossCfg), _P, _I, _P, _P, _P, _I, _P],
     "kk_losses_bwd": [_P] * 12 + [_I, _I, _I, _I, C.POINTER(KkLossCfg), _P, _P, _P, _P, _P, _P, _P],
-    "kk_seg_sumsq": [_P, _P, _L, _P, _I, _I, _P],
+    "kk_seg_sumsq": [_P, _P, _L, _P, _I, _P, _P],
     "kk_opt_prepare": [_P, _P, _P, _P, _I, _P, C.POINTER(KkOptCfg), _P, _P, _P, _P, _P, _P, _P, _P],
     "kk_adamw_ema": [_P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _F, _F, _F, _P, _I, _P, _I, _P],
     "kk_weight_norm_project": [_P, _P, _L, _P, _P, _P, _D, _P, _P],
@@ -252,6 +252,9 @@ def profile_stop():
     return [(n, a, s.elapsed_time(e)) for n, a, s, e in rec]
 
 
+ABI_VERSION = 2        # include/kokoro_hip.h: KK_ABI_VERSION
+
+
 def use_library(flavour: str) -> None:
     """Tools only: select the library flavour before the first call — "tuning" = libkokoro_hip_tuning.so (python -m
     kokoro_ruslan_amd.build --tuning: A/B switches and timing probes readable from the environment), "product" = the default."""
@@ -281,8 +284,11 @@ def load() -> C.CDLL:
     lib.kk_attn_bwd_ws_bytes.restype = C.c_int64
     lib.kk_attn_keep_bytes.argtypes = [_I, _I, _I, _I]
     lib.kk_attn_keep_bytes.restype = C.c_int64
-    if lib.kk_abi_version() != 1:
-        raise RuntimeError("libkokoro_hip.so ABI version mismatch")
+    lib.kk_seg_sumsq_ws_bytes.argtypes = [_L]
+    lib.kk_seg_sumsq_ws_bytes.restype = C.c_int64
+    if lib.kk_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH}: ABI version {lib.kk_abi_version()}, this package binds version {ABI_VERSION} "
+                           "(stale library: run `python -m kokoro_ruslan_amd.build --force`)")
     _lib = lib
     return lib
 

@@ -320,13 +320,24 @@ def init_params(d: ModelDims, seed: int = 0) -> "OrderedDict[str, torch.Tensor]"
     return P
 
 
-def cosine_restart_factor(epoch: int, T_0: int, T_mult: int) -> float:
-    """(1 + cos(pi * T_cur / T_i)) / 2 of torch's CosineAnnealingWarmRestarts after `epoch` scheduler steps: the reference's legacy
-    schedule (use_onecycle_lr = False) steps it once per epoch (trainer.py:789-799, 2885-2887)."""
+def cosine_restart_position(epoch: int, T_0: int, T_mult: int) -> Tuple[int, int]:
+    """(T_cur, T_i) of torch's CosineAnnealingWarmRestarts after `epoch` scheduler steps.  Raises ValueError for the values torch's
+    constructor rejects (T_0 <= 0, T_mult < 1) instead of looping forever on them."""
+    if int(T_0) != T_0 or int(T_0) <= 0:
+        raise ValueError(f"Expected positive integer T_0, but got {T_0}")
+    if int(T_mult) != T_mult or int(T_mult) < 1:
+        raise ValueError(f"Expected integer T_mult >= 1, but got {T_mult}")
     t_cur, t_i = int(epoch), int(T_0)
     while t_cur >= t_i:
         t_cur -= t_i
         t_i *= int(T_mult)
+    return t_cur, t_i
+
+
+def cosine_restart_factor(epoch: int, T_0: int, T_mult: int) -> float:
+    """(1 + cos(pi * T_cur / T_i)) / 2 of torch's CosineAnnealingWarmRestarts after `epoch` scheduler steps: the reference's legacy
+    schedule (use_onecycle_lr = False) steps it once per epoch (trainer.py:789-799, 2885-2887)."""
+    t_cur, t_i = cosine_restart_position(epoch, T_0, T_mult)
     return (1.0 + math.cos(math.pi * t_cur / t_i)) / 2.0
 
 

@@ -33,7 +33,8 @@ def test_library_exports_every_declared_symbol(libpath):
     for name in decls:
         assert hasattr(lib, name), f"{name} declared in include/kokoro_hip.h but not exported"
     lib.kk_abi_version.restype = ctypes.c_int
-    assert lib.kk_abi_version() == 1
+    from kokoro_ruslan_amd import lib as kk
+    assert lib.kk_abi_version() == 2 == kk.ABI_VERSION
     lib.kk_last_error.restype = ctypes.c_char_p
     assert isinstance(lib.kk_last_error(), bytes)
 

@@ -365,3 +365,56 @@ def test_encoder_stack_check_is_entered_by_every_rank():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert got == [(0, True, False, 0), (1, True, False, 1)], got
+
+
+# ---- round 6: the trainer's tripwire — a ONE-ULP difference in one parameter on one rank is caught, rank 0's
+# state is re-broadcast, and the next check passes ------------------------------------------------------------------------------------
+def _tripwire_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    import types
+    from kokoro_ruslan_amd import dp
+    dp.init("gloo")
+    g = torch.Generator().manual_seed(5)
+    mk = lambda: torch.randn(70_001, generator=torch.Generator().manual_seed(5))
+    arena = types.SimpleNamespace(p=mk(), m=mk() * 0.1, v=mk().abs(), ema=mk(), p16=None)
+    eng = types.SimpleNamespace(arena=arena, opt_state=torch.zeros(16, dtype=torch.float64))
+    first = dp.check_replicas(eng, where="start")                       # identical replicas: passes, nothing moves
+    before = arena.p.clone()
+    if rank == 1:                                                        # one ulp, one element, one rank (and a stale moment)
+        i = 12_345
+        arena.p[i] = torch.nextafter(arena.p[i], torch.tensor(float("inf")))
+        arena.m[7] += 1.0
+        eng.opt_state[3] = 9.0
+    caught = not dp.check_replicas(eng, where="after the injected ulp")  # warns + re-broadcasts rank 0's slabs
+    healed = dp.check_replicas(eng, where="after the re-broadcast")
+    same = bool(torch.equal(arena.p, before)) and float(arena.m[7]) == float((mk() * 0.1)[7]) and float(eng.opt_state[3]) == 0.0
+    # the float checksum the round-5 guard used cannot see a flipped low bit beside large values; the integer one must
+    big = torch.full((1000,), 3.0e7)
+    big2 = big.clone()
+    if rank == 1:
+        big2[500] = torch.nextafter(big2[500], torch.tensor(float("inf")))
+    bit_seen = not dp.replicas_in_step(big2)
+    nan_seen = not dp.replicas_in_step(torch.tensor([1.0, float("nan")]))
+    out = torch.tensor([float(first), float(caught), float(healed), float(same), float(bit_seen), float(nan_seen)])
+    dist.all_reduce(out, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        q.put(out.tolist())
+    dist.destroy_process_group()
+
+
+def test_replica_tripwire_catches_one_ulp_and_rebroadcasts():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tripwire_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    first, caught, healed, same, bit_seen, nan_seen = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert first == 1.0, "identical replicas must pass the tripwire"
+    assert caught == 1.0, "a one-ulp difference in one parameter on one rank must be caught on EVERY rank"
+    assert healed == 1.0 and same == 1.0, "after the re-broadcast every rank holds rank 0's parameters, moments and optimizer state"
+    assert bit_seen == 1.0 and nan_seen == 1.0

@@ -26,7 +26,7 @@ def test_training_config_field_for_field(surface):
     for f, r in zip(mine, ref):
         assert repr(f.default) == r["default"], f.name
     extra = [f.name for f in mine][len(ref):]
-    assert extra == ["mixed_precision_dtype", "dp_world_size"]                 # new fields come last, with defaults
+    assert extra == ["mixed_precision_dtype", "dp_world_size", "replica_check_every"]                 # new fields come last, with defaults
     c = TrainingConfig(data_dir="/x/corpus", checkpoint_segments=0)
     assert c.feature_cache_dir == "/x/corpus/.feature_cache" and c.checkpoint_segments == 1
     c2 = pickle.loads(pickle.dumps(c))                                         # checkpoints pickle the config object

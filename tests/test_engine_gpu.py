@@ -1056,3 +1056,123 @@ def test_bf16_trajectory_200_steps_tracks_fp32(eng_mod):
     assert rel.max() < 0.06 and rel[-1] < 0.04, (rel.max(), rel[-1], t32[::24].round(4).tolist(), t16[::24].round(4).tolist())
     m32, m16 = sm(c32[:, 1]), sm(c16[:, 1])
     assert (np.abs(m16 - m32) / m32).max() < 0.06, (m32[::24].round(4).tolist(), m16[::24].round(4).tolist())
+
+
+# ---- round 6: an ENGINE-level numeric check at configs[2]-shaped batches, default dims ------------------------
+def _ragged_lengths(B, T, Pn, seed):
+    """Valid lengths as a frame-budget batch has them (data/dataset.py:1007-1127 packs utterances of similar length: the longest defines
+    the padded shape, the others are 55-100 % of it)."""
+    g = torch.Generator().manual_seed(seed)
+    mel = (T * (0.55 + 0.45 * torch.rand(B, generator=g))).long().clamp(min=8)
+    ph = (Pn * (0.55 + 0.45 * torch.rand(B, generator=g))).long().clamp(min=4)
+    mel[0], ph[0] = T, Pn
+    return mel, ph
+
+
+@pytest.mark.parametrize("B,T,Pn", [(12, 1333, 110), (28, 579, 48)])
+def test_dynamic_batching_shapes_at_default_dims(eng_mod, B, T, Pn, monkeypatch):
+    """What dynamic batching (configs[2]: B * T <= 16384, B 4..32) hands the engine: B != 8, ragged valid lengths, T not a multiple of
+    any tile, >= 6 K rows — the routes only such batches take (attn_fwd3_q128 on a ragged sequence, the 256 x 128 large-tile GEMM with a
+    ragged M, the row-owner projection + tail launch, the memory tail on the side stream above 4096 rows, the per-kernel encoder for
+    B > 8).  Every kernel on them is tested alone; this is the step as a whole: (1) the fp32 engine's losses against the CPU oracle,
+    (2) the bf16 engine against the fp32 engine — losses and all 308 gradients by direction and size, as at the bench shapes,
+    (3) the routes ASSERTED from the record of the step's launches."""
+    from kokoro_ruslan_amd import lib as kk
+    from kokoro_ruslan_amd.synthetic import synthetic_batch
+    d = O.ModelDims()
+    P = O.init_params(d, 0)
+    cpu = synthetic_batch(B, T, Pn, seed=77, lengths=_ragged_lengths(B, T, Pn, 9))
+    b = _cuda(cpu)
+    f32 = _engine(eng_mod, d, P, gradient_accumulation_steps=1)
+    f32.zero_grad()
+    l32 = f32.forward_backward(b)["losses"].clone()
+    with torch.no_grad():
+        lo = torch.stack([x.float() for x in O.losses(O.forward(P, O.make_buffers(d), cpu, d), cpu, O.StepHyper())])
+    torch.testing.assert_close(l32.cpu(), lo, rtol=2e-4, atol=2e-4)
+    assert abs(float(l32[1]) - float(lo[1])) < 1e-4, "mel-L1 within 1e-4 of the reference restatement"
+    e = _engine(eng_mod, d, P, math_mode="bf16", gradient_accumulation_steps=1)
+    e.zero_grad()
+    routes = []
+    real_call = kk.call
+
+    def recording_call(name, *args):
+        real_call(name, *args)
+        routes.append((name, kk.last_kernel()))
+    monkeypatch.setattr(kk, "call", recording_call)
+    l16 = e.forward_backward(b)["losses"].clone()
+    monkeypatch.setattr(kk, "call", real_call)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(l16.cpu().numpy(), lo.numpy(), rtol=3e-2, atol=3e-2)
+    cos, rel = [], []
+    for n in O.param_shapes(d):
+        a, r = e.arena.G[n].double().flatten(), f32.arena.G[n].double().flatten()
+        assert bool(torch.isfinite(a).all()), n
+        if float(r.norm()) > 1e-7:
+            cos.append(float(a @ r / (a.norm() * r.norm() + 1e-30)))
+            rel.append(abs(float(a.norm()) / float(r.norm()) - 1.0))
+    assert len(cos) >= 300
+    assert min(cos) > 0.95 and float(np.mean(cos)) > 0.99, (min(cos), float(np.mean(cos)))
+    assert float(np.median(rel)) < 0.02, float(np.median(rel))
+    assert abs(float(e.arena.g.double().norm()) / float(f32.arena.g.double().norm()) - 1.0) < 0.02
+    # (3) routes
+    taken = {k for _, k in routes}
+    names = [n for n, _ in routes]
+    assert B * T > 6000 and B * T <= 16384
+    assert "attn_fwd3_q128" in taken, sorted(taken)
+    assert any(k.startswith("g16x<0,0,256,128,") or k.startswith("g16x<0,1,256,128,") for k in taken), sorted(taken)
+    assert "linear_tail_fwd" in taken and "kk_linear_tail_fwd" in names
+    assert "attn_bwd_pair3k" in taken
+    assert ("kk_encoder_stack_fwd" in names) == (B <= 8)
+    # the memory tail (cross K/V weight gradient + memory gradient + bucket-embedding gradients) ran on the side stream, behind the
+    # text encoder's backward (tail_aside mode 3 above 4096 rows): its launches come after the encoder's embedding backward
+    assert names.index("kk_bucket_embed_add_bwd_sorted") > names.index("kk_embed_bwd")
+    # a second, replayed pass through the same shape computes the same step (eager -> capture -> replay)
+    e.train_dropout = False
+    p0 = e.arena.p.clone()
+    for _ in range(3):
+        e.train_step_graphed(b)
+    torch.cuda.synchronize()
+    assert e.opt_stats()["skipped"] == 0 and bool(torch.isfinite(e.arena.p).all()) and not torch.equal(p0, e.arena.p)
+
+
+def test_accumulators_survive_an_aborted_step(eng_mod, golden_dir):
+    """the handed-round accumulators (loss sums, per-segment norms) rely on their last reader leaving them zero.  A step
+    that dies between writer and cleaner — here: the loss exchange raising after kk_losses_fwd, and a poisoned optimizer accumulator —
+    must cost the next step one zero-fill, not silently wrong losses / clip coefficients.  Also: flipping the switch on a live engine."""
+    fx, d, batch, P = _load(golden_dir, "tiny_full")
+    b = _cuda(batch)
+    ref = _engine(eng_mod, d, P, gradient_accumulation_steps=1)
+    ref.train_step(b)
+    want_l, want_p = ref.losses.clone(), ref.arena.p.clone()
+    ref.train_step(b)
+    want_l2, want_p2 = ref.losses.clone(), ref.arena.p.clone()
+
+    class Boom:
+        capturable = False
+
+        def loss_sync(self, acc, max_dur):
+            raise RuntimeError("collective failed")
+    e = _engine(eng_mod, d, P, gradient_accumulation_steps=1)
+    e.loss_sync = Boom()
+    with pytest.raises(RuntimeError, match="collective failed"):
+        e.train_step(b)                                   # kk_losses_fwd has added its sums; nobody cleared them
+    torch.cuda.synchronize()
+    assert not e._acc_clean and float(e.loss_acc.abs().sum()) > 0
+    e.loss_sync, e.micro_in_cycle = None, 0
+    e.p_sumsq.fill_(123456789)                            # (as if the optimizer had died between kk_adamw_ema and its reader too)
+    e.train_step(b)
+    torch.testing.assert_close(e.losses, want_l, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(e.arena.p, want_p, rtol=0, atol=1e-7)
+    assert e._acc_clean
+    e.self_cleaning_acc = False                           # the A/B switch flipped on a live engine, then back
+    assert not e._acc_clean
+    e.self_cleaning_acc = True
+    e.train_step_graphed(b)
+    e2 = _engine(eng_mod, d, P, gradient_accumulation_steps=1)
+    e2.train_step(b)
+    e2.self_cleaning_acc = False
+    e2.train_step(b)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(e.losses, want_l2, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(e2.losses, want_l2, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(e2.arena.p, want_p2, rtol=0, atol=1e-6)

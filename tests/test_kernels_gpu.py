@@ -730,7 +730,7 @@ def test_losses_fwd_bwd(kk, ragged):
 
 
 def test_optimizer_accumulators_handed_round_zero(kk):
-    """kk_seg_sumsq(zeroed = 1) / kk_opt_prepare(clear_a, clear_b) / kk_adamw_ema(zeroed = 1): the per-segment fp64 accumulators
+    """kk_seg_sumsq (order-deterministic since round 6) / kk_opt_prepare(clear_a, clear_b) / kk_adamw_ema(zeroed = 1): the per-segment accumulators
     kept zero by the one-workgroup launch between their writers give the same numbers as the zero-fill launches they replace."""
     g = torch.Generator().manual_seed(5)
     BLK, nblocks, nseg = 1024, 96, 7
@@ -739,12 +739,39 @@ def test_optimizer_accumulators_handed_round_zero(kk):
     grad = dev(torch.randn(n, generator=g) * 0.01)
     ref = torch.zeros(nseg, dtype=torch.float64, device="cuda")
     ref.index_add_(0, seg_of.long().repeat_interleave(BLK), grad.double() ** 2)
+    ws = torch.empty(kk.load().kk_seg_sumsq_ws_bytes(nblocks), dtype=torch.uint8, device="cuda")
+    ws.fill_(0xAB)                                                        # (the record workspace needs no initial state)
     ss = torch.full((nseg,), 7.0, dtype=torch.float64, device="cuda")
-    kk.call("kk_seg_sumsq", grad, seg_of, nblocks, ss, nseg, 0)              # self-contained form: zero-fills the garbage itself
-    close(ss, ref, 1e-6, 1e-9, "seg_sumsq (zero-fill inside)")
-    ss.zero_()
-    kk.call("kk_seg_sumsq", grad, seg_of, nblocks, ss, nseg, 1)
-    close(ss, ref, 1e-6, 1e-9, "seg_sumsq (zero on entry)")
+    kk.call("kk_seg_sumsq", grad, seg_of, nblocks, ss, nseg, ws)          # every segment is STORED: garbage in the output is harmless
+    close(ss, ref, 1e-6, 1e-9, "seg_sumsq (stores every segment, no zero-fill)")
+    # round 6: a pure function of the buffer — no atomics, the partials merged in arena order by a fixed tree.
+    # A big arena (every workgroup of the launch busy, segments of 1 block up to thousands, boundaries at every position inside a
+    # workgroup's range): 30 calls give the SAME BITS, and they are the fp64 reference's value to rounding.
+    gb = torch.Generator().manual_seed(11)
+    lens = [1, 1, 3, 700, 1, 2, 1500, 1, 1, 64, 5000, 1, 23, 24, 25, 1, 1, 3000, 2, 9000, 1, 1, 1, 777, 48, 1]
+    lens = lens * 3
+    nb2, ns2 = sum(lens), len(lens)
+    seg2 = torch.repeat_interleave(torch.arange(ns2, dtype=torch.int32), torch.tensor(lens)).to("cuda")
+    big = (torch.randn(nb2 * BLK, generator=gb) * torch.rand(nb2 * BLK, generator=gb) * 3.0).to("cuda")
+    ref2 = torch.zeros(ns2, dtype=torch.float64, device="cuda")
+    ref2.index_add_(0, seg2.long().repeat_interleave(BLK), big.double() ** 2)
+    ws2 = torch.empty(kk.load().kk_seg_sumsq_ws_bytes(nb2), dtype=torch.uint8, device="cuda")
+    outs = []
+    for i in range(30):
+        o = torch.full((ns2,), float("nan"), dtype=torch.float64, device="cuda")
+        ws2.random_(0, 255)
+        kk.call("kk_seg_sumsq", big, seg2, nb2, o, ns2, ws2)
+        outs.append(o)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0]), "kk_seg_sumsq must give the same bits on every call (order-deterministic reduction)"
+    close(outs[0], ref2, 1e-12, 1e-12, "seg_sumsq, 78 segments over ~60 K blocks")
+    # an inf / NaN gradient poisons exactly its own segment
+    bad = big.clone()
+    bad[(sum(lens[:6]) + 700) * BLK + 5] = float("inf")
+    o = torch.zeros(ns2, dtype=torch.float64, device="cuda")
+    kk.call("kk_seg_sumsq", bad, seg2, nb2, o, ns2, ws2)
+    fin = torch.isfinite(o)
+    assert int((~fin).sum()) == 1 and not bool(fin[6]) and torch.equal(o[fin], outs[0][fin])
     f = lambda v: torch.full((nseg,), v, device="cuda")
     cfg = kk.KkOptCfg()
     cfg.learning_rate, cfg.max_lr, cfg.warmup_start_lr, cfg.warmup_target_lr, cfg.use_warmup = 1e-3, 1e-3, 1e-4, 1e-3, 0
@@ -754,19 +781,26 @@ def test_optimizer_accumulators_handed_round_zero(kk):
     cfg.expl_warmup_steps, cfg.expl_min_ema_steps, cfg.ema_decay, cfg.max_weight_norm = 0, 5, 0.999, 0.0
     st = torch.zeros(16, dtype=torch.float64, device="cuda")
     gs, dec, stp, consts = f(0.0), f(0.0), f(0.0), torch.zeros(4, device="cuda")
-    psq = torch.full((nseg,), 3.0, dtype=torch.float64, device="cuda")
+    psq = torch.full((nseg,), 3, dtype=torch.int64, device="cuda")         # (Q34.30 fixed point since round 6)
     kk.call("kk_opt_prepare", ss, f(0.0), f(1.0), f(0.01), nseg, None, cfg, st, gs, dec, stp, consts, ss, psq)
-    assert float(ss.abs().sum()) == 0.0 and float(psq.abs().sum()) == 0.0, "kk_opt_prepare leaves both accumulators zero"
+    assert float(ss.abs().sum()) == 0.0 and int(psq.abs().sum()) == 0, "kk_opt_prepare leaves both accumulators zero"
     total = float(ref.sum().sqrt())
     close(torch.tensor(float(st[kk.OS["LAST_GRAD_NORM"]])), torch.tensor(total), 1e-6, 1e-9, "total norm read before the clear")
     p, m, v, ema = dev(torch.randn(n, generator=g)), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
     flags = torch.full((nseg,), 1 | 4, dtype=torch.int32, device="cuda")
     pa, pb = p.clone(), p.clone()
-    psa = torch.full((nseg,), 9.0, dtype=torch.float64, device="cuda")
+    psa = torch.full((nseg,), 9, dtype=torch.int64, device="cuda")
     kk.call("kk_adamw_ema", pa, grad, m.clone(), v.clone(), ema.clone(), seg_of, nblocks, gs, dec, stp, flags, consts, 0.9, 0.999, 0.999, psa, nseg, None, 0)
     kk.call("kk_adamw_ema", pb, grad, m.clone(), v.clone(), ema.clone(), seg_of, nblocks, gs, dec, stp, flags, consts, 0.9, 0.999, 0.999, psq, nseg, None, 1)
     assert torch.equal(pa, pb) and not torch.equal(pa, p)
-    close(psq, psa, 1e-12, 1e-12, "p_sumsq (zero on entry == zero-fill inside)")
+    assert torch.equal(psq, psa), "p_sumsq (zero on entry == zero-fill inside): integer sums, bit for bit"
+    want = torch.zeros(nseg, dtype=torch.float64, device="cuda")
+    want.index_add_(0, seg_of.long().repeat_interleave(BLK), pa.double() ** 2)
+    close(psq.double() / 2.0 ** 30, want, 1e-6, 1e-6, "p_sumsq = Q34.30 sum of the post-step squares")
+    for _ in range(5):                                                     # order-independent: repeated passes agree bit for bit
+        pc, psc = p.clone(), torch.zeros(nseg, dtype=torch.int64, device="cuda")
+        kk.call("kk_adamw_ema", pc, grad, m.clone(), v.clone(), ema.clone(), seg_of, nblocks, gs, dec, stp, flags, consts, 0.9, 0.999, 0.999, psc, nseg, None, 1)
+        assert torch.equal(psc, psq)
 
 
 # ----------------------------------------------------------------------------------------------------------------
