@@ -533,6 +533,19 @@ int kk_weight_norm_project(float *p, const int32_t *block_seg, int64_t nblocks, 
 /* dst (bf16) = src (fp32), n % 4 == 0: builds the weight shadow after a checkpoint load. */
 int kk_cast_f32_bf16(const float *src, void *dst, int64_t n, void *stream);
 
+/* ---- one XCD per batch item: a decoder sub-layer as ONE persistent launch (round 6; csrc/kk_chain.hip) ----
+ * Between kk_chain_begin() and kk_chain_launch() the entry points called on this thread RECORD the launch they would have made
+ * (same dispatch code, same argument blocks) instead of making it; kk_chain_launch runs the recorded kernels' bodies as the phases of
+ * one launch of 256 workgroups — the workgroups of XCD x carry batch item x through all phases, group barriers in between, hand-over
+ * through the XCD's L2 — or returns KK_ENOTSUP and launches NOTHING when it does not carry that sequence (the caller then issues the
+ * launches again, outside a capture).  kind 0 = the decoder's self-attention sub-layer forward (transformers.py:543-560):
+ * kk_gemm_qkv_headnorm, kk_attn_fwd[_kb], kk_gemm (w_o), kk_sublayer_out_fwd at B = 8, 512 or 1024 frames, hidden 512.
+ * sync: 512 zero-initialised uint32 (word 0 != 0: a barrier timed out; word 1: workgroups found on another XCD than their item's).
+ * flags bit 0: agent-scope barrier atomics (placement independent) instead of XCD-local ones.  trace: tools (16 uint64 per workgroup) or NULL. */
+int kk_chain_begin(void *stream);
+int kk_chain_launch(int kind, uint32_t *sync, uint64_t *trace, int flags, void *stream);
+int kk_chain_abort(void *stream);
+
 /* ---- data-parallel gradient exchange over RCCL / xGMI (new functionality: the reference has no distributed code,
  * SURVEY §0 fact 2; contract = "the same maths as one process seeing the global batch", §8e) ----
  * One communicator per process (one process per GPU).  RCCL is bound at run time: the library loads without it, and

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libkokoro_hip.so")
-SOURCES = ["kk_core.hip", "kk_gemm.hip", "kk_gemm16.hip", "kk_gemm16x.hip", "kk_attn.hip", "kk_norm.hip", "kk_elem.hip", "kk_loss.hip", "kk_optim.hip", "kk_dropout.hip", "kk_comm.hip", "kk_encstack.hip"]
+SOURCES = ["kk_core.hip", "kk_gemm.hip", "kk_gemm16.hip", "kk_gemm16x.hip", "kk_attn.hip", "kk_norm.hip", "kk_elem.hip", "kk_loss.hip", "kk_optim.hip", "kk_dropout.hip", "kk_comm.hip", "kk_encstack.hip", "kk_chain.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
 
 
@@ -62,11 +62,12 @@ def build(force: bool = False, verbose: bool = False, tuning: bool = False, vari
             os.remove(stamp)
     headers = [os.path.join(CSRC, "kk_common.h"), os.path.join(os.path.dirname(HERE), "include", "kokoro_hip.h")]
     headers += [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".inc") or (f.endswith(".h") and f != "kk_common.h")]      # kernel bodies included by kk_attn.hip
+    chain_deps = [os.path.join(CSRC, f) for f in ("kk_gemm16x.hip", "kk_gemm16.hip", "kk_attn.hip", "kk_dropout.hip")]      # bodies compiled into kk_chain.hip
 
     def compile_one(src: str) -> str:
         s = os.path.join(CSRC, src)
         o = os.path.join(obj_dir, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + headers):
+        if force or _stale(o, [s] + headers + (chain_deps if src == "kk_chain.hip" else [])):
             cmd = [hipcc] + flags + ["-c", s, "-o", o]
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:

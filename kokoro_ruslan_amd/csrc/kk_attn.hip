@@ -990,8 +990,13 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(AttnArgs a) {
 // software pipelining inside a wave (the other three waves of the SIMD are the overlap), Q fragments re-read from LDS per unit.
 // Same arithmetic per unit as attn_fwd2 (softmax per 32-key unit, same dropout function): the results differ from it only by the
 // order in which the key slots' partial softmaxes are merged.
-template <int QW, int KG, int NS>
-__device__ __forceinline__ void attn_fwd3_body(const AttnArgs &a) {
+#ifndef KK_QKV_AUX
+#define KK_QKV_AUX 0            // cache policy of the Q / K / V DMA loads (kk_chain.hip: sc1 = L1 bypass for tensors written earlier in the launch)
+#endif
+// CHAIN (kk_chain.hip): the body as one phase of a persistent launch — block coordinates from the caller, every wave stays to the end
+// (no early exit in front of a workgroup barrier) and leaves through a barrier that frees the LDS for the next unit.
+template <int QW, int KG, int NS, bool CHAIN = false>
+__device__ __forceinline__ void attn_fwd3_body(const AttnArgs &a, int chain_bx = 0, int chain_by = 0) {
     typedef __bf16 T;
     constexpr int QB = 32 * QW, KT = 32 * KG, KIMG = KT * 128, STAGE = 2 * KIMG, RING = NS * STAGE;
     constexpr int KP = KT / 64, NPT = 2 * KP;                 // 16-byte pieces per thread: per operand, per tile
@@ -1000,7 +1005,8 @@ __device__ __forceinline__ void attn_fwd3_body(const AttnArgs &a) {
     uint64_t *kmb = reinterpret_cast<uint64_t *>(smem_raw + RING);         // [64] one word per 64 keys
     char *qimg = smem_raw + RING + 512;                                    // [QB queries][64] image
     int bx_, by_;
-    attn_block(a, bx_, by_, true);
+    if constexpr (CHAIN) { bx_ = chain_bx; by_ = chain_by; }
+    else attn_block(a, bx_, by_, true);
     const int b = by_ / a.heads, hh = by_ % a.heads;
     const int qblk = bx_ * QB;
     const int lane = threadIdx.x & 63, wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, l31 = lane & 31;
@@ -1021,7 +1027,7 @@ __device__ __forceinline__ void attn_fwd3_body(const AttnArgs &a) {
         for (int j = 0; j < QB * 8 / 512; ++j) {
             const int p = threadIdx.x + 512 * j, row = p >> 3, pc = p & 7;
             const uint32_t vo = (uint32_t)(((int64_t)row * a.ldq + ((pc ^ ((row >> 1) & 7)) * 8)) * 2);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, KK_LDS_PTR(qimg + wave8 * 1024 + j * 8192), 16, vo, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, KK_LDS_PTR(qimg + wave8 * 1024 + j * 8192), 16, vo, 0, 0, KK_QKV_AUX);
         }
     }
     const uint8_t *km = a.key_mask ? a.key_mask + (int64_t)b * a.Sk : nullptr;
@@ -1051,10 +1057,10 @@ __device__ __forceinline__ void attn_fwd3_body(const AttnArgs &a) {
         char *dst = smem_raw + st * STAGE + wave8 * 1024;
 #pragma unroll
         for (int j = 0; j < KP; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, KK_LDS_PTR(dst + j * 8192), 16, kvo[j] + (uint32_t)t * ktile, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, KK_LDS_PTR(dst + j * 8192), 16, kvo[j] + (uint32_t)t * ktile, 0, 0, KK_QKV_AUX);
 #pragma unroll
         for (int j = 0; j < KP; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, KK_LDS_PTR(dst + KIMG + j * 8192), 16, vvo[j] + (uint32_t)t * vtile, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, KK_LDS_PTR(dst + KIMG + j * 8192), 16, vvo[j] + (uint32_t)t * vtile, 0, 0, KK_QKV_AUX);
     };
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t)
@@ -1228,7 +1234,8 @@ __device__ __forceinline__ void attn_fwd3_body(const AttnArgs &a) {
             for (int r = 0; r < 16; ++r) { w[2 + r] = o[0][r]; w[18 + r] = o[1][r]; }
         }
         __syncthreads();
-        if (kg > 0) return;
+        if constexpr (!CHAIN) { if (kg > 0) return; }
+        if (kg == 0) {
 #pragma unroll
         for (int g = 1; g < KG; ++g) {
             const float *w = mb + (((g - 1) * QW + qw) * 64 + lane) * 34;
@@ -1239,15 +1246,22 @@ __device__ __forceinline__ void attn_fwd3_body(const AttnArgs &a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { o[0][r] = o[0][r] * a0 + w[2 + r] * a1; o[1][r] = o[1][r] * a0 + w[18 + r] * a1; }
         }
+        }
     }
     __syncthreads();                                           // (the QW remaining waves: everyone has read the merge area — the store tiles reuse it)
-    const float inv = l > 0.f ? pd.inv_keep / l : 0.f;
     static_assert(RING >= (KG - 1) * QW * 64 * 34 * 4 && RING >= QW * 4608, "merge area / store tiles fit the ring");
-    store_rows_via_lds(static_cast<T *>(a.Out) + ((int64_t)b * a.Sq + qmin) * a.ldout + hh * 64, a.ldout, a.Sq - qmin, o, inv,
-                       smem_raw + qw * 4608, lane, a.wt);
-    if (qvalid && half == 0) a.LSEo[((int64_t)b * a.heads + hh) * a.Sq + q] = l > 0.f ? (m + __builtin_amdgcn_logf(l)) * 0.6931471805599453f : INFINITY;
+    if (kg == 0) {
+        const float inv = l > 0.f ? pd.inv_keep / l : 0.f;
+        store_rows_via_lds(static_cast<T *>(a.Out) + ((int64_t)b * a.Sq + qmin) * a.ldout + hh * 64, a.ldout, a.Sq - qmin, o, inv,
+                           smem_raw + qw * 4608, lane, a.wt);
+        if (qvalid && half == 0) a.LSEo[((int64_t)b * a.heads + hh) * a.Sq + q] = l > 0.f ? (m + __builtin_amdgcn_logf(l)) * 0.6931471805599453f : INFINITY;
+    }
+    if constexpr (CHAIN) __syncthreads();                      // the next unit of this workgroup reuses the ring, the mask words and the Q image
 }
 
+#ifdef KK_BODIES_ONLY
+}  // namespace   (kk_chain.hip includes this file for attn_fwd3_body only)
+#else
 // (plain kernels around the template body: hipcc's host pass did not emit the stub of the kernel TEMPLATE named in kk_attn_fwd, and
 // rejected its explicit instantiation — the same host-pass trouble as g16x_group_kernel in kk_gemm16x.hip)
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd3_q128_kernel(AttnArgs a) { attn_fwd3_body<4, 2, 3>(a); }
@@ -2232,6 +2246,8 @@ static int attn_fwd_impl(const float *Q, const float *K, const float *V, float *
             const bool big = (int64_t)kk_cdiv(Sq, 128) * B * heads >= 2 * g_attn_cus();    // (two workgroups per CU)
             // (a conditional expression: hipcc does not emit the host stub of a kernel template named only inside an if / else chain)
             kk_note_kernel((big || fwd3 == 2) ? "attn_fwd3_q128" : "attn_fwd3_q64");
+            if (kk_capture(kk_last_kernel(), a, (big || fwd3 == 2) ? dim3(kk_cdiv(Sq, 128), B * heads) : dim3(kk_cdiv(Sq, 64), B * heads), 512,
+                           (big || fwd3 == 2) ? (size_t)3 * 16384 + 512 + 16384 : (size_t)2 * 32768 + 512 + 8192)) return 0;
             const int rc3 = (big || fwd3 == 2)
                 ? launch_attn(attn_fwd3_q128_kernel, dim3(kk_cdiv(Sq, 128), B * heads), 2, (size_t)3 * 16384 + 512 + 16384, (hipStream_t)stream, a)
                 : launch_attn(attn_fwd3_q64_kernel, dim3(kk_cdiv(Sq, 64), B * heads), 2, (size_t)2 * 32768 + 512 + 8192, (hipStream_t)stream, a);
@@ -2562,3 +2578,4 @@ extern "C" int kk_attn_bwd_ws(const float *Q, const float *K, const float *V, co
     KK_LAUNCH_CHECK("kk_attn_bwd_ws (dQ pass)");
     return 0;
 }
+#endif  // KK_BODIES_ONLY

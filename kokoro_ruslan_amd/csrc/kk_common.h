@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <type_traits>
 #include "../../include/kokoro_hip.h"
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -13,6 +14,37 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 int kk_fail(int code, const char *fmt, ...);
 void kk_note_kernel(const char *name);         // kk_last_kernel(): `name` must have static storage duration
 void kk_note_kernelf(const char *fmt, ...);    // ... a formatted name (interned)
+
+// ---- launch capture (kk_chain.hip, round 6): between kk_chain_begin() and kk_chain_launch() the entry points of a sub-layer do not
+// launch: their dispatch code runs as always (same tile policy, same argument blocks, same route record) and the launch it would
+// have made — kernel name, grid, the by-value argument block — is RECORDED on the calling thread.  kk_chain_launch then runs the
+// recorded bodies as the phases of ONE persistent launch (one batch item per XCD), or refuses.  Same arguments by construction, so
+// the chained launch stores the bits the separate launches store.
+#include <string.h>
+constexpr int KK_CAPTURE_MAX = 16, KK_CAPTURE_ARG_BYTES = 1024;
+struct KkCapturedLaunch {
+    const char *kernel;                                         // the route record's name (kk_last_kernel form)
+    unsigned grid[3], block;
+    size_t lds, bytes;
+    alignas(16) char args[KK_CAPTURE_ARG_BYTES];
+};
+struct KkLaunchCapture {
+    int n, overflow;
+    KkCapturedLaunch e[KK_CAPTURE_MAX];
+};
+KkLaunchCapture *kk_capture_target();                          // (kk_core.hip) non-null while this thread records
+template <typename A> static inline bool kk_capture(const char *kernel, const A &a, dim3 grid, unsigned block, size_t lds) {
+    static_assert(sizeof(A) <= KK_CAPTURE_ARG_BYTES && std::is_trivially_copyable<A>::value, "argument block too large to record");
+    KkLaunchCapture *c = kk_capture_target();
+    if (c == nullptr) return false;
+    if (c->n >= KK_CAPTURE_MAX) { c->overflow = 1; return true; }
+    KkCapturedLaunch &e = c->e[c->n++];
+    e.kernel = kernel;
+    e.grid[0] = grid.x; e.grid[1] = grid.y; e.grid[2] = grid.z;
+    e.block = block; e.lds = lds; e.bytes = sizeof(A);
+    memcpy(e.args, &a, sizeof(A));
+    return true;
+}
 
 // Tuning switches.  The PRODUCT library reads no environment variable but KK_GEMM16_TUNE (one-time tile policy override, see
 // kk_gemm16.hip): every A/B switch and every result-changing timing probe below exists only in a tools build

@@ -33,6 +33,21 @@ void kk_note_kernelf(const char *fmt, ...) {                       // formatted 
 extern "C" const char *kk_last_kernel(void) { return g_last_kernel; }
 extern "C" int kk_abi_version(void) { return KK_ABI_VERSION; }
 
+// launch capture (kk_common.h): per thread, so a trainer's prefetch thread is never affected
+static thread_local KkLaunchCapture g_capture;
+static thread_local bool g_capturing = false;
+KkLaunchCapture *kk_capture_target() { return g_capturing ? &g_capture : nullptr; }
+KkLaunchCapture *kk_capture_begin() {
+    g_capture.n = 0;
+    g_capture.overflow = 0;
+    g_capturing = true;
+    return &g_capture;
+}
+KkLaunchCapture *kk_capture_end() {
+    g_capturing = false;
+    return &g_capture;
+}
+
 namespace {
 // One wave computes C[32x32] = A[32x16] * B[16x32] with A[i][k] = i + 0.25*k - 3, B[k][j] = 0.5*k - 0.125*j + 1
 // (asymmetric, exactly representable in bf16 products' fp32 sums), through both MFMA flavours, using the

@@ -71,11 +71,10 @@ struct SubOutArgs {
     DropArgs d;
 };
 
+// one row, one wave (every lane active); called by the launch below and by the persistent chain (kk_chain.hip)
 template <typename TY, typename TN, int NV>
-__global__ __launch_bounds__(256) void sublayer_out_fwd_kernel(SubOutArgs a) {
+__device__ __forceinline__ void sublayer_out_row(const SubOutArgs &a, const int64_t row) {
     const int lane = threadIdx.x & 63, H = a.H;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= a.rows) return;
     const uint32_t seed = *a.d.seed;
     const uint32_t t1 = kk_drop_threshold(a.d.p1), t2 = kk_drop_threshold(a.d.p2);
     const float k1 = a.d.p1 > 0.f ? 1.f / (1.f - a.d.p1) : 1.f, k2 = a.d.p2 > 0.f ? 1.f / (1.f - a.d.p2) : 1.f;
@@ -151,10 +150,22 @@ __global__ __launch_bounds__(256) void sublayer_out_fwd_kernel(SubOutArgs a) {
     }
 }
 
+template <typename TY, typename TN, int NV>
+__global__ __launch_bounds__(256) void sublayer_out_fwd_kernel(SubOutArgs a) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    sublayer_out_row<TY, TN, NV>(a, row);
+}
+
+#ifdef KK_BODIES_ONLY
+}  // namespace   (kk_chain.hip includes this file for SubOutArgs / sublayer_out_row only)
+#else
 template <typename TY, typename TN>
 void launch_subout(const SubOutArgs &a, hipStream_t s) {
     const dim3 grid(kk_cdiv(a.rows, 4)), blk(256);
     const int nv = kk_cdiv(a.H, 256);
+    kk_note_kernelf("sublayer_out_fwd<%d,%d,%d>", (int)sizeof(TY), (int)sizeof(TN), nv <= 1 ? 1 : (nv <= 2 ? 2 : (nv <= 4 ? 4 : 8)));
+    if (kk_capture(kk_last_kernel(), a, grid, 256, 0)) return;
     if (nv <= 1) hipLaunchKernelGGL((sublayer_out_fwd_kernel<TY, TN, 1>), grid, blk, 0, s, a);
     else if (nv <= 2) hipLaunchKernelGGL((sublayer_out_fwd_kernel<TY, TN, 2>), grid, blk, 0, s, a);
     else if (nv <= 4) hipLaunchKernelGGL((sublayer_out_fwd_kernel<TY, TN, 4>), grid, blk, 0, s, a);
@@ -797,3 +808,4 @@ extern "C" int kk_specaug(float *x, int B, int T, int H, const uint32_t *seed, u
     KK_LAUNCH_CHECK("kk_specaug");
     return 0;
 }
+#endif  // KK_BODIES_ONLY

@@ -40,6 +40,12 @@ struct G16Args {
 
 constexpr int BK = 64;
 
+// cache policy of the ACTIVATION operand's buffer-load-to-LDS DMA in gemm16_body / g16x_body: 0 in the library's own launches;
+// kk_chain.hip compiles the bodies with sc1 (16: L1 bypass, served by the XCD's L2) for tensors written earlier in the same launch
+#ifndef KK_A_AUX
+#define KK_A_AUX 0
+#endif
+
 // Several independent GEMMs of one operand layout in ONE launch (a layer's weight gradients): descriptor table in the kernel arguments.
 constexpr int GROUP_MAX = 8;
 struct G16Group {

@@ -28,7 +28,7 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 
 // One operand tile of ROWS x 64: DMA issue + fragment reads.
-template <int ROWS, bool KS, int NT = 256> struct Operand {
+template <int ROWS, bool KS, int NT = 256, int AUX = 0> struct Operand {      // AUX: cache policy of the DMA loads (kk_gemm16.h: KK_A_AUX)
     static constexpr int BYTES = ROWS * BK * 2;
     static constexpr int NP = ROWS * 8 / NT;                   // 16-byte pieces per thread per tile (NT threads)
     static constexpr int PITCH = KS ? ROWS * 2 : BK * 2;        // bytes per LDS row
@@ -60,7 +60,7 @@ template <int ROWS, bool KS, int NT = 256> struct Operand {
         const uint32_t so = (uint32_t)kt * kstep;
 #pragma unroll
         for (int j = 0; j < NP; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(dst + (wave * 64 + NT * j) * 16), 16, voff[j], so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(dst + (wave * 64 + NT * j) * 16), 16, voff[j], so, 0, AUX);
     }
 };
 
@@ -140,7 +140,7 @@ __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char
     constexpr int MI = BM / (32 * WR), NI = BN / (32 * WC);     // 32x32 MFMA tiles per wave (wave tile = BM/WR x BN/WC)
     static_assert(EPI == 0 || WAVES == 4 || (WAVES == 8 && BM == 128 && BN == 64),
                   "the epilogue variants are written for four waves and for the eight-wave 128x64 tile");
-    using OA = Operand<BM, TA, 64 * WAVES>;
+    using OA = Operand<BM, TA, 64 * WAVES, KK_A_AUX>;
     using OB = Operand<BN, TB, 64 * WAVES>;
     constexpr int NB = EPI == 2 ? 2 : 1;                        // EPI == 2 multiplies A with TWO 64-row panels of B (see below)
     constexpr int STAGE = OA::BYTES + NB * OB::BYTES;
@@ -551,6 +551,9 @@ __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char
         }
 }
 
+#ifdef KK_BODIES_ONLY
+}  // namespace   (kk_chain.hip includes this file for gemm16_body only)
+#else
 template <bool TA, bool TB, int BM, int BN, int NS, int EPI = 0>
 __global__ __launch_bounds__(256) void gemm16_kernel(G16Args a) {
     __shared__ __attribute__((aligned(16))) char smem[NS * (BM + (EPI == 2 ? 2 : 1) * BN) * BK * 2];
@@ -593,6 +596,7 @@ int g16_w8_glu = kk_tune_env("KK_G16_W8_GLU", 1);      // bit 0: dgrad + GLU bac
 template <int NS>
 void launch_w8(int ta, int tb, const G16Args &a, dim3 grid, hipStream_t s) {
     kk_note_kernelf("gemm16_w8<%d,%d,%d>", ta, tb, NS);
+    if (kk_capture(kk_last_kernel(), a, grid, 512, 0)) return;
     if (!ta && !tb) hipLaunchKernelGGL((gemm16_kernel_w8<false, false, NS>), grid, dim3(512), 0, s, a);
     else if (!ta && tb) hipLaunchKernelGGL((gemm16_kernel_w8<false, true, NS>), grid, dim3(512), 0, s, a);
     else if (ta && !tb) hipLaunchKernelGGL((gemm16_kernel_w8<true, false, NS>), grid, dim3(512), 0, s, a);
@@ -1057,3 +1061,4 @@ int kk_gemm16_qkv_headnorm(int64_t T, int parts, int heads, int64_t K, const voi
     KK_LAUNCH_CHECK("kk_gemm_qkv_headnorm");
     return 0;
 }
+#endif  // KK_BODIES_ONLY

@@ -24,7 +24,7 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 // One operand tile of ROWS x 64.  Rows [0, SPLIT) map to global rows r0.., rows [SPLIT, ROWS) to r1.. (the GLU forward's two
 // panels of W1; SPLIT == ROWS otherwise).
-template <int ROWS, bool KS, int NT, int SPLIT = ROWS> struct OperandX {
+template <int ROWS, bool KS, int NT, int SPLIT = ROWS, int AUX = 0> struct OperandX {      // AUX: cache policy of the DMA loads (kk_gemm16.h: KK_A_AUX)
     static constexpr int BYTES = ROWS * BK * 2;
     static constexpr int NP = ROWS * 8 / NT;                    // 16-byte pieces per thread per tile
     static_assert(ROWS * 8 % NT == 0 && SPLIT % 8 == 0, "whole pieces per thread");
@@ -58,7 +58,7 @@ template <int ROWS, bool KS, int NT, int SPLIT = ROWS> struct OperandX {
         const uint32_t so = (uint32_t)kt * kstep;
 #pragma unroll
         for (int j = 0; j < NP; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(dst + (wave * 64 + NT * j) * 16), 16, voff[j], so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(dst + (wave * 64 + NT * j) * 16), 16, voff[j], so, 0, AUX);
     }
 };
 
@@ -133,7 +133,7 @@ __device__ __forceinline__ void g16x_body(const G16Args &a, const int wg, char *
     constexpr int NW = BNH / WC, NJ = NW / 32;                  // columns / 32-column blocks per wave (per panel)
     constexpr int NI = EPI == 2 ? 2 * NJ : NJ;
     static_assert(BM % (32 * WR) == 0 && BNH % (32 * WC) == 0, "whole 32x32 accumulators per wave");
-    using OA = OperandX<BM, TA, LT>;
+    using OA = OperandX<BM, TA, LT, BM, KK_A_AUX>;
     using OB = OperandX<BN, TB, LT, BNH>;
     constexpr int STAGE = OA::BYTES + OB::BYTES;
     constexpr int NPT = OA::NP + OB::NP;
@@ -667,6 +667,9 @@ __device__ __forceinline__ void g16x_body(const G16Args &a, const int wg, char *
         }
 }
 
+#ifdef KK_BODIES_ONLY
+}  // namespace   (kk_chain.hip includes this file for g16x_body only)
+#else
 template <bool TA, bool TB, int BM, int BN, int NS, int EPI, int WR, int WC, int LW>
 __global__ __launch_bounds__(64 * (WR * WC + LW)) void g16x_kernel(G16Args a) {
     __shared__ __attribute__((aligned(16))) char smem[NS * (BM + BN) * BK * 2 + BN * 4];      // (static: up to 145 KB, one workgroup per CU; the tail: the tile's bias row)
@@ -706,6 +709,7 @@ int launch_x(const G16Args &a0, const char *name, hipStream_t s) {
     const G16Args &a = a0;
 #endif
     kk_note_kernelf("g16x<%d,%d,%d,%d,%d,%d,%d,%d,%d>", (int)TA, (int)TB, BM, BN, NS, EPI, WR, WC, LW);
+    if (kk_capture(kk_last_kernel(), a, dim3(a.tiles_m * a.tiles_n), 64 * (WR * WC + LW), 0)) return 0;
     hipLaunchKernelGGL((g16x_kernel<TA, TB, BM, BN, NS, EPI, WR, WC, LW>), dim3(a.tiles_m * a.tiles_n), dim3(64 * (WR * WC + LW)), 0, s, a);
     KK_LAUNCH_CHECK(name);
     return 0;
@@ -789,3 +793,4 @@ int kk_g16x_group(const G16Group &g, int grid, hipStream_t s) {
     KK_LAUNCH_CHECK("kk_gemm_wgrad_group");
     return 0;
 }
+#endif  // KK_BODIES_ONLY

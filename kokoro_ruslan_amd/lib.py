@@ -212,6 +212,9 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_losses_fwd": [_P] * 12 + [_I, _I, _I, _I, C.POINTER(KkLossCfg), _P, _P, _P, _P, _P, _I, _P],
     "kk_losses_finalize": [_P, C.POINTER(KkLossCfg), _P, _I, _P, _P, _P, _I, _P],
     "kk_losses_bwd": [_P] * 12 + [_I, _I, _I, _I, C.POINTER(KkLossCfg), _P, _P, _P, _P, _P, _P, _P],
+    "kk_chain_begin": [_P],
+    "kk_chain_launch": [_I, _P, _P, _I, _P],
+    "kk_chain_abort": [_P],
     "kk_seg_sumsq": [_P, _P, _L, _P, _I, _P, _P],
     "kk_opt_prepare": [_P, _P, _P, _P, _I, _P, C.POINTER(KkOptCfg), _P, _P, _P, _P, _P, _P, _P, _P],
     "kk_adamw_ema": [_P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _F, _F, _F, _P, _I, _P, _I, _P],

@@ -1121,11 +1121,22 @@ def test_dynamic_batching_shapes_at_default_dims(eng_mod, B, T, Pn, monkeypatch)
     assert "attn_fwd3_q128" in taken, sorted(taken)
     assert any(k.startswith("g16x<0,0,256,128,") or k.startswith("g16x<0,1,256,128,") for k in taken), sorted(taken)
     assert "linear_tail_fwd" in taken and "kk_linear_tail_fwd" in names
-    assert "attn_bwd_pair3k" in taken
+    assert "attn_bwd_pair3" in taken                     # (p = 0 here: the hashing pair launch; the keep-bit one is asserted below)
     assert ("kk_encoder_stack_fwd" in names) == (B <= 8)
     # the memory tail (cross K/V weight gradient + memory gradient + bucket-embedding gradients) ran on the side stream, behind the
     # text encoder's backward (tail_aside mode 3 above 4096 rows): its launches come after the encoder's embedding backward
     assert names.index("kk_bucket_embed_add_bwd_sorted") > names.index("kk_embed_bwd")
+    # the training configuration (all dropout on): the attention forward stores its keep bits for ragged sequences too and the
+    # backward's pair launch reads them
+    e.train_dropout = True
+    e.zero_grad()
+    routes.clear()
+    monkeypatch.setattr(kk, "call", recording_call)
+    ld = e.forward_backward(b)["losses"].clone()
+    monkeypatch.setattr(kk, "call", real_call)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(ld).all()) and bool(torch.isfinite(e.arena.g).all())
+    assert "attn_bwd_pair3k" in {k for _, k in routes} and "kk_attn_fwd_kb" in [n for n, _ in routes]
     # a second, replayed pass through the same shape computes the same step (eager -> capture -> replay)
     e.train_dropout = False
     p0 = e.arena.p.clone()
@@ -1162,7 +1173,8 @@ def test_accumulators_survive_an_aborted_step(eng_mod, golden_dir):
     e.p_sumsq.fill_(123456789)                            # (as if the optimizer had died between kk_adamw_ema and its reader too)
     e.train_step(b)
     torch.testing.assert_close(e.losses, want_l, rtol=1e-6, atol=1e-7)
-    torch.testing.assert_close(e.arena.p, want_p, rtol=0, atol=1e-7)
+    # (the embedding-table gradients are fp32 atomic scatter-adds: two runs differ in their last bits, see the bench-shape test)
+    torch.testing.assert_close(e.arena.p, want_p, rtol=0, atol=3e-6)
     assert e._acc_clean
     e.self_cleaning_acc = False                           # the A/B switch flipped on a live engine, then back
     assert not e._acc_clean
@@ -1175,4 +1187,4 @@ def test_accumulators_survive_an_aborted_step(eng_mod, golden_dir):
     torch.cuda.synchronize()
     torch.testing.assert_close(e.losses, want_l2, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(e2.losses, want_l2, rtol=1e-5, atol=1e-6)
-    torch.testing.assert_close(e2.arena.p, want_p2, rtol=0, atol=1e-6)
+    torch.testing.assert_close(e2.arena.p, want_p2, rtol=0, atol=6e-6)
