@@ -217,8 +217,9 @@ def kernel_table(records, math_bf16: bool):
             key = "attn_bwd_dkv3s_kernel + attn_bwd_dqpass_kernel (dK, dV and the dS tiles, then dQ = dS.K)"
             flops = 4 * 2.0 * B * h * Sq * Sk * 64 * (0.5 if causal else 1.0)        # executes 5: S is the only recomputation left
             byts = 2.0 * B * h * 64 * (4 * Sq + 4 * Sk) + 2 * 2.0 * B * h * Sq * Sk * (0.5 if causal else 1.0)   # + dS written and read once
-        elif name in ("kk_attn_fwd", "kk_attn_fwd_kb", "kk_attn_bwd_dq", "kk_attn_bwd_dkv"):
-            kb_fwd = name == "kk_attn_fwd_kb"                    # (the same kernels, also storing one bit per score)
+        elif name in ("kk_attn_fwd", "kk_attn_fwd_kb", "kk_attn_fwd_rb", "kk_attn_bwd_dq", "kk_attn_bwd_dkv"):
+            kb_fwd = name in ("kk_attn_fwd_kb", "kk_attn_fwd_rb")   # (the same kernels, also storing — or, _rb, reading — one bit per score)
+            rb_fwd = name == "kk_attn_fwd_rb"
             name = "kk_attn_fwd" if kb_fwd else name
             B, h, Sq, Sk = (int(x) for x in sc[:4])
             off = 1 if name == "kk_attn_bwd_dq" else 0       # (..., causal, scale, site, p_drop, math, io_bf16[, ldo])
@@ -230,6 +231,8 @@ def kernel_table(records, math_bf16: bool):
                 fwd_name = ("attn_fwd2_kernel (flash forward, DMA-staged)" if Sk <= 128 else
                             "attn_fwd3_q128_kernel (flash forward, 2 workgroups per CU, 128-query blocks x 2 key slots)" if _cd(Sq, 128) * B * h >= 512 else
                             "attn_fwd3_q64_kernel (flash forward, 2 workgroups per CU, 64-query blocks x 4 key slots)")
+            if rb_fwd:
+                fwd_name = fwd_name.replace("_kernel (flash forward", "r_kernel (flash forward READING the keep bits of kk_attn_keep_gen")
             key = {"kk_attn_fwd": fwd_name,
                    "kk_attn_bwd_dq": "attn_bwd_dq3_kernel (dQ)" if v2 else "attn_bwd_dq_kernel (dQ, first generation)",
                    "kk_attn_bwd_dkv": "attn_bwd_dkv3_kernel (dK, dV)" if v2 else "attn_bwd_dkv_kernel (dK, dV, first generation)"}[name]
@@ -238,7 +241,7 @@ def kernel_table(records, math_bf16: bool):
         keys = [key]
         if name in ("kk_gemm", "kk_gemm_dgrad_delta"):
             keys.append(f"  shape ta={ta} tb={tb} M={M} N={N} K={K}")
-        elif name.startswith("kk_attn_") and name != "kk_attn_delta":
+        elif name.startswith("kk_attn_") and name not in ("kk_attn_delta", "kk_attn_keep_gen"):
             keys.append(f"  shape {name} B={B} h={h} Sq={Sq} Sk={Sk} causal={causal}")
         for kq in keys:
             a = agg.setdefault(kq, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "floor_us": 0.0})

@@ -170,6 +170,23 @@ int kk_attn_bwd_kb(const float *Q, const float *K, const float *V, const float *
                    int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, const uint8_t *key_mask, int causal, float scale,
                    const uint32_t *seed, uint32_t site, float p_drop, int math, int io_bf16, const KkAttnHeadNorm *hn_q,
                    const KkAttnHeadNorm *hn_kv, const void *keep, void *stream);
+/* Keep bits from a launch of their own (round 6).  kk_attn_keep_gen fills the keep-bit arrays of up to 16 attention launches — the
+ * same function of (seed value, site, b, head, q, key), the same layout as kk_attn_fwd_kb stores — in ONE pure-vector launch that needs
+ * no LDS, so it runs beside the persistent encoder forward; kk_attn_fwd_rb is kk_attn_fwd reading those bits instead of hashing (and
+ * storing) them: the same output bits with ~40 % fewer vector instructions per score unit.  kk_attn_bwd_kb reads the same arrays. */
+typedef struct {
+    void *keep;          /* kk_attn_keep_bytes(B, heads, Sq, Sk) bytes */
+    uint32_t site;       /* the site the attention launch is given (engine: sub-layer site + 3) */
+    float p;             /* its dropout probability, in (0, 1) */
+    int B, heads, Sq, Sk, causal;
+} KkKeepSite;
+int kk_attn_keep_gen(const KkKeepSite *sites, int n, const uint32_t *seed, int seed_offset /* the bits of seed value *seed + seed_offset: 1 = the
+                     next micro-batch's, generated a step ahead beside the optimizer pass */,
+                     int max_workgroups /* grid cap (0 = 2048): how many wave slots the launch may take from what runs beside it */, void *stream);
+int kk_attn_fwd_rb(const float *Q, const float *K, const float *V, float *O, float *LSE, int B, int heads,
+                   int Sq, int Sk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, const uint8_t *key_mask,
+                   int causal, float scale, const uint32_t *seed, uint32_t site, float p_drop, int math, int io_bf16,
+                   const void *keep, void *stream);
 /* The same backward in two passes through a caller-owned workspace (same call sites; `ws` of at least kk_attn_bwd_ws_bytes(...)
  * bytes, 16-byte aligned, private to the stream for the duration of the call): the dK/dV kernel also stores dS = P o (dP - Delta)
  * as bf16 tiles (2 bytes per score), and dQ = dS . K is a pass without softmax work (+ the head-norm epilogue) — the pair launch

@@ -54,6 +54,7 @@ struct AttnArgs {
     // (((b * heads + head) * nQU + qu) * nKU + ku) * 128, nQU = ceil(Sq / 32), nKU = ceil(Sk / 32); dword 2 r + h of a unit = bits over
     // the unit's 32 queries (bit = query) for key frag_row(r, h): the forward's ballot of accumulator register r, half h.
     void *keep;
+    int keep_rd;                         // forward: 1 = READ the keep bits (written by kk_attn_keep_gen beside the encoder forward) instead of hashing + storing them
     // backward kernels: the gradient of the per-head RMSNorm (+ RoPE) that produced Q (dQ kernel) / K and V (dK/dV
     // kernel: hn[0], hn[1]) as the epilogue — Out / Out2 then receive the gradient of the RAW projection
     KkAttnHeadNorm hn[2];
@@ -995,7 +996,10 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(AttnArgs a) {
 #endif
 // CHAIN (kk_chain.hip): the body as one phase of a persistent launch — block coordinates from the caller, every wave stays to the end
 // (no early exit in front of a workgroup barrier) and leaves through a barrier that frees the LDS for the next unit.
-template <int QW, int KG, int NS, bool CHAIN = false>
+// KRD (kk_attn_fwd_rb): the dropout keep decisions are READ — the unit's 16 lane masks by two scalar loads from the array that
+// kk_attn_keep_gen filled beside the encoder forward — instead of hashed and stored: -9 vector instructions per two scores and the
+// 32 v_writelane + the store of a unit.  Same bits, same arithmetic: the output equals the hashing launch's bit for bit.
+template <int QW, int KG, int NS, bool CHAIN = false, bool KRD = false>
 __device__ __forceinline__ void attn_fwd3_body(const AttnArgs &a, int chain_bx = 0, int chain_by = 0) {
     typedef __bf16 T;
     constexpr int QB = 32 * QW, KT = 32 * KG, KIMG = KT * 128, STAGE = 2 * KIMG, RING = NS * STAGE;
@@ -1095,8 +1099,11 @@ __device__ __forceinline__ void attn_fwd3_body(const AttnArgs &a, int chain_bx =
     // at the top of the NEXT tile step, BEFORE that step's tile DMAs are issued: the counted vmcnt waits above stay exact — the only
     // operations younger than the tile a step waits for are the DMAs of the tile after it (CDNA4 counts stores in vmcnt too).
     const int nKU = (a.Sk + 31) >> 5;
-    uint32_t *kbh = (a.keep != nullptr && pd.thr != 0u && qmin < a.Sq)         // (a wave whose 32 rows lie beyond Sq has no unit row in the array)
+    uint32_t *kbh = (!KRD && a.keep != nullptr && pd.thr != 0u && qmin < a.Sq)         // (a wave whose 32 rows lie beyond Sq has no unit row in the array)
         ? reinterpret_cast<uint32_t *>(static_cast<char *>(a.keep) + ((int64_t)(b * a.heads + hh) * ((a.Sq + 31) >> 5) + (qmin >> 5)) * nKU * 128) : nullptr;
+    // KRD: this wave's row of units (wave-uniform address: scalar loads); rows beyond Sq read any valid row (their output is not stored)
+    const kk_cu64x8 *keep_row = KRD ? reinterpret_cast<const kk_cu64x8 *>(reinterpret_cast<uintptr_t>(
+        static_cast<const char *>(a.keep) + ((int64_t)(b * a.heads + hh) * ((a.Sq + 31) >> 5) + (qmin < a.Sq ? qmin >> 5 : 0)) * nKU * 128)) : nullptr;
     uint32_t kw_pend = 0u;
     int kw_unit = -1;                                          // (wave-uniform) key unit whose words are pending in kw_pend
     auto flush_keep = [&]() {
@@ -1180,7 +1187,13 @@ __device__ __forceinline__ void attn_fwd3_body(const AttnArgs &a, int chain_bx =
         for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -m)); rs += s[r]; }
         rs = xor32_sum(rs);
         l += rs;
-        if (pd.thr) {
+        if constexpr (KRD) {
+            if (pd.thr) {
+                const kk_u64x8 mk0 = keep_row[(k0 >> 5) * 2], mk1 = keep_row[(k0 >> 5) * 2 + 1];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_inverse_ballot_w64(r < 8 ? mk0[r & 7] : mk1[r & 7]) ? s[r] : 0.f;
+            }
+        } else if (pd.thr) {
             const uint32_t xb = pd.row(q, k0 + 4 * half);
             uint64_t mk[16];                                   // the comparisons' lane masks = the unit's ballots
             uint32_t hprev = 0u;
@@ -1266,6 +1279,59 @@ __device__ __forceinline__ void attn_fwd3_body(const AttnArgs &a, int chain_bx =
 // rejected its explicit instantiation — the same host-pass trouble as g16x_group_kernel in kk_gemm16x.hip)
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd3_q128_kernel(AttnArgs a) { attn_fwd3_body<4, 2, 3>(a); }
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd3_q64_kernel(AttnArgs a) { attn_fwd3_body<2, 4, 2>(a); }
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd3_q128r_kernel(AttnArgs a) { attn_fwd3_body<4, 2, 3, false, true>(a); }
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd3_q64r_kernel(AttnArgs a) { attn_fwd3_body<2, 4, 2, false, true>(a); }
+
+// ------------------------------------------------------------------ keep-bit generator (kk_attn_keep_gen)
+// The dropout keep decisions of up to 16 attention launches as ONE pure-vector launch (no LDS): per 32 x 32 unit the 512 hashes the
+// forward evaluates for it, stored as the same 16 ballots in the same layout (AttnArgs::keep).
+// Issued on the decoder-head stream beside the persistent encoder forward, which is latency-bound and leaves the vector ALUs idle.
+struct KeepGenArgs {
+    KkKeepSite s[16];
+    int64_t start[17];               // first unit of each site in the flattened unit list
+    int n;
+    const uint32_t *seed;
+    uint32_t seed_offset;            // the bits are those of seed value *seed + seed_offset (1: the NEXT micro-batch's, generated beside the optimizer pass)
+};
+// Lane-local on purpose: a lane owns one (unit, key pair) — 16 lanes per unit, four units per wave — walks the unit's 32 queries,
+// and builds the two dwords of that key pair (even key, odd key) bit by bit: the same 512 hashes per unit the forward's 64 lanes
+// evaluate, but no ballots, no v_writelane, nothing wave-wide.  (A first version mirrored the forward — compare masks moved into one
+// register by v_writelane — and wrote stale words whenever it ran beside other kernels: the compares that produce those SGPRs sat
+// right in front of the inline-asm v_writelanes, where the hazard recogniser does not look.)
+__global__ __launch_bounds__(256) void attn_keep_gen_kernel(const KeepGenArgs g) {
+    const int lane = threadIdx.x & 63, j = lane & 15, hbit = j & 1, rr = j >> 1;
+    const int64_t nquads = (int64_t)gridDim.x * 4, total = g.start[g.n];
+    const uint32_t seed = *g.seed + g.seed_offset;
+    const int kp_off = ((rr & 1) + 4 * (rr >> 1));               // frag_row(2 rr, 0) >> 1: the key pair of accumulator registers 2 rr, 2 rr + 1
+    for (int64_t u0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4; u0 < total; u0 += nquads * 4) {
+        const int64_t u = u0 + (lane >> 4);
+        if (u >= total) continue;
+        int i = 0;
+        while (i + 1 < g.n && u >= g.start[i + 1]) ++i;
+        const KkKeepSite &st = g.s[i];
+        const int nQU = (st.Sq + 31) >> 5, nKU = (st.Sk + 31) >> 5;
+        const int64_t v = u - g.start[i];
+        const int ku = (int)(v % nKU), qu = (int)((v / nKU) % nQU), bh = (int)(v / ((int64_t)nKU * nQU));
+        if (st.causal && ku > qu) continue;                    // (the forward never visits a unit above the diagonal)
+        uint32_t thr = (uint32_t)(st.p * 65536.f + 0.5f);
+        thr = thr > 65535u ? 65535u : thr;
+        const uint32_t key = kk_hash(seed, st.site, (uint64_t)bh), sk2 = (uint32_t)(st.Sk + 1) >> 1;
+        // the forward's lane (l31 = query, half) hashes  q * sk2 + ((k0 + 4 half) >> 1) + (frag_row(r, 0) >> 1)  for r = 0, 2, ..., 14
+        uint32_t x0 = (uint32_t)(qu * 32) * sk2 + ((uint32_t)(ku * 32 + 4 * hbit) >> 1) + (uint32_t)kp_off;
+        uint32_t lo = 0u, hi = 0u;
+#pragma unroll 8
+        for (int q = 0; q < 32; ++q) {
+            uint32_t x = x0 ^ key;
+            x ^= x >> 16; x = __umul24(x, 0xb5352du); x ^= x >> 13; x = __umul24(x, 0xca68b5u); x ^= x >> 16;
+            lo |= ((x & 0xFFFFu) >= thr ? 1u : 0u) << q;           // even key: register 2 rr
+            hi |= ((x >> 16) >= thr ? 1u : 0u) << q;               // odd key:  register 2 rr + 1
+            x0 += sk2;
+        }
+        uint32_t *unit = reinterpret_cast<uint32_t *>(static_cast<char *>(st.keep) + (((int64_t)bh * nQU + qu) * nKU + ku) * 128);
+        unit[2 * (2 * rr) + hbit] = lo;                        // dword 2 r + half = the ballot half of register r
+        unit[2 * (2 * rr + 1) + hbit] = hi;
+    }
+}
 
 // ------------------------------------------------------------------ decode: one query per (batch, head)
 // Sq == 1 (the incremental path of transformers.py:237-253: a decoder step against the KV cache / against the memory), no dropout.
@@ -2212,7 +2278,7 @@ extern "C" int64_t kk_attn_keep_bytes(int B, int heads, int Sq, int Sk) {
 static int attn_fwd_impl(const float *Q, const float *K, const float *V, float *O, float *LSE, int B, int heads,
                          int Sq, int Sk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                          const uint8_t *key_mask, int causal, float scale, const uint32_t *seed, uint32_t site,
-                         float p_drop, int math, int io_bf16, void *keep, void *stream) {
+                         float p_drop, int math, int io_bf16, void *keep, void *stream, int keep_rd = 0) {
     KK_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "kk_attn_fwd: dropout probability must be in [0,1)");
     KK_REQUIRE(!io_bf16 || math == KK_MATH_BF16, "kk_attn_fwd: bf16 storage needs KK_MATH_BF16");
     const int64_t lds[4] = {ldq, ldk, ldv, ldo};
@@ -2223,6 +2289,7 @@ static int attn_fwd_impl(const float *Q, const float *K, const float *V, float *
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldout = ldo; a.scale = scale;
     a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(causal); a.dbg = attn_dbg(); a.wt = kk_write_through((int64_t)B * std::max(Sq, Sk));
     a.keep = keep;
+    a.keep_rd = (keep_rd && keep != nullptr && a.seed != nullptr) ? 1 : 0;
 #ifdef KK_TUNING_HOOKS
     if (a.dbg & 256) a.DeltaOut = static_cast<float *>(g_attn_trace);
 #endif
@@ -2245,6 +2312,15 @@ static int attn_fwd_impl(const float *Q, const float *K, const float *V, float *
         if (fwd3 && Sk > 128) {
             const bool big = (int64_t)kk_cdiv(Sq, 128) * B * heads >= 2 * g_attn_cus();    // (two workgroups per CU)
             // (a conditional expression: hipcc does not emit the host stub of a kernel template named only inside an if / else chain)
+            if (a.keep_rd) {
+                kk_note_kernel((big || fwd3 == 2) ? "attn_fwd3_q128r" : "attn_fwd3_q64r");
+                const int rcr = (big || fwd3 == 2)
+                    ? launch_attn(attn_fwd3_q128r_kernel, dim3(kk_cdiv(Sq, 128), B * heads), 2, (size_t)3 * 16384 + 512 + 16384, (hipStream_t)stream, a)
+                    : launch_attn(attn_fwd3_q64r_kernel, dim3(kk_cdiv(Sq, 64), B * heads), 2, (size_t)2 * 32768 + 512 + 8192, (hipStream_t)stream, a);
+                if (rcr) return rcr;
+                KK_LAUNCH_CHECK("kk_attn_fwd_rb");
+                return 0;
+            }
             kk_note_kernel((big || fwd3 == 2) ? "attn_fwd3_q128" : "attn_fwd3_q64");
             if (kk_capture(kk_last_kernel(), a, (big || fwd3 == 2) ? dim3(kk_cdiv(Sq, 128), B * heads) : dim3(kk_cdiv(Sq, 64), B * heads), 512,
                            (big || fwd3 == 2) ? (size_t)3 * 16384 + 512 + 16384 : (size_t)2 * 32768 + 512 + 8192)) return 0;
@@ -2255,7 +2331,7 @@ static int attn_fwd_impl(const float *Q, const float *K, const float *V, float *
             KK_LAUNCH_CHECK("kk_attn_fwd");
             return 0;
         }
-        KK_REQUIRE(keep == nullptr, "kk_attn_fwd_kb: only the third-generation forward stores keep bits (ask kk_attn_keep_bytes)");
+        KK_REQUIRE(keep == nullptr, "kk_attn_fwd_kb / _rb: only the third-generation forward stores or reads keep bits (ask kk_attn_keep_bytes)");
         static const int ns2 = kk_tune_env("KK_ATTN_NS", 3);
         kk_note_kernel("attn_fwd2");
 #ifdef KK_TUNING_HOOKS
@@ -2293,6 +2369,42 @@ extern "C" int kk_attn_fwd_kb(const float *Q, const float *K, const float *V, fl
     KK_REQUIRE(keep == nullptr || (al16(keep) && kk_attn_keep_bytes(B, heads, Sq, Sk) > 0), "kk_attn_fwd_kb: no keep bits for this shape (kk_attn_keep_bytes) or unaligned buffer");
     return attn_fwd_impl(Q, K, V, O, LSE, B, heads, Sq, Sk, ldq, ldk, ldv, ldo, key_mask, causal, scale, seed, site, p_drop, math, io_bf16,
                          keep, stream);
+}
+
+// kk_attn_fwd whose dropout keep decisions are READ from `keep` (filled by kk_attn_keep_gen for the same seed value, site, p and shape):
+// same output bits as kk_attn_fwd / kk_attn_fwd_kb
+extern "C" int kk_attn_fwd_rb(const float *Q, const float *K, const float *V, float *O, float *LSE, int B, int heads,
+                              int Sq, int Sk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                              const uint8_t *key_mask, int causal, float scale, const uint32_t *seed, uint32_t site,
+                              float p_drop, int math, int io_bf16, const void *keep, void *stream) {
+    KK_REQUIRE(keep != nullptr && al16(keep) && kk_attn_keep_bytes(B, heads, Sq, Sk) > 0 && p_drop > 0.f && seed != nullptr && io_bf16,
+               "kk_attn_fwd_rb: needs dropout, bf16 storage and a keep-bit array of a shape that has one (kk_attn_keep_bytes)");
+    return attn_fwd_impl(Q, K, V, O, LSE, B, heads, Sq, Sk, ldq, ldk, ldv, ldo, key_mask, causal, scale, seed, site, p_drop, math, io_bf16,
+                         const_cast<void *>(keep), stream, 1);
+}
+
+// The keep bits of n <= 16 attention launches in one launch (see attn_keep_gen_kernel); sites: HOST array read during the call.
+extern "C" int kk_attn_keep_gen(const KkKeepSite *sites, int n, const uint32_t *seed, int seed_offset, int max_workgroups, void *stream) {
+    KK_REQUIRE(sites != nullptr && seed != nullptr && n > 0 && n <= 16, "kk_attn_keep_gen: 1..16 sites and the seed are required");
+    KeepGenArgs g;
+    g.n = n;
+    g.seed = seed;
+    g.seed_offset = (uint32_t)seed_offset;
+    g.start[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        const KkKeepSite &st = sites[i];
+        KK_REQUIRE(st.keep != nullptr && al16(st.keep) && st.p > 0.f && st.p < 1.f && kk_attn_keep_bytes(st.B, st.heads, st.Sq, st.Sk) > 0,
+                   "kk_attn_keep_gen: site %d has no keep-bit array (kk_attn_keep_bytes) or no dropout", i);
+        g.s[i] = st;
+        g.start[i + 1] = g.start[i] + (int64_t)st.B * st.heads * kk_cdiv(st.Sq, 32) * kk_cdiv(st.Sk, 32);
+    }
+    int64_t wgs = (g.start[n] + 15) / 16;                         // (a wave takes four units at a time)
+    const int cap = max_workgroups > 0 ? max_workgroups : 2048;   // (thin: it runs beside another launch and must leave it its wave slots)
+    if (wgs > cap) wgs = cap;
+    kk_note_kernel("attn_keep_gen");
+    hipLaunchKernelGGL(attn_keep_gen_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, g);
+    KK_LAUNCH_CHECK("kk_attn_keep_gen");
+    return 0;
 }
 
 extern "C" int kk_attn_delta(const float *O, const float *dO, float *Delta, int B, int heads, int Sq, int64_t ldo,

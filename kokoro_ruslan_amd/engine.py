@@ -230,10 +230,11 @@ class KokoroEngine:
         # the attention forward stores its dropout keep decisions as packed bits (kk_attn_fwd_kb) and the backward's pair launch reads
         # them (kk_attn_bwd_kb) instead of hashing them again: ~40 % of the backward kernels' vector instructions (round 5)
         self.attn_keep_bits = True
-        # (one-tile sequences — the text encoder's <= 64 phonemes, on the side branch — take the two thinner launches: re-measured INSIDE
-        #  the step in round 5, 3.6215 -> 3.608 ms at 8 x 512 (4 of 4 interleaved rounds); 65..128 phonemes keep the pair launch: two launches
-        #  there are +0.3 % at 8 x 1024.  profiles/r05_encoder_attn_pair_ab.txt)
-        self.attn_pair_min_seq = 64
+        # ... and, where the persistent encoder launch gives it a place to hide, the bits of ALL the decoder's attention launches come
+        # from ONE pure-vector launch beside the encoder forward (kk_attn_keep_gen, on the decoder-head stream) and the forward READS
+        # them too (kk_attn_fwd_rb): -3 us per forward launch at 512 frames, -6.4 ... -8.6 us at 1024 (round 6; same bits either way)
+        self.attn_keep_gen = True
+        self._keep_ready = set()                    # sub-layer keys whose bits kk_attn_keep_gen has written in this step
         self.attn_proj_bf16 = True                 # decoder w_o output stored as bf16 (bf16 mode)
         # the decoder's attention output projection and the sub-layer tail behind it as ONE row-owner launch (kk_linear_tail_fwd) where
         # the library measured it faster (kk_linear_tail_pays: whole rounds of workgroups at >= ~6 K rows); bit-identical results
@@ -740,7 +741,10 @@ class KokoroEngine:
             k_raw, v_raw, k_n, v_n = kv_raw, kv_raw[:, H:], kv_n, kv_n[:, H:]
         ctx, lse = self._buf(key + ".ctx", Nq, H, dtype=dt), self._buf(key + ".lse", B, h, Sq)
         keep = self._attn_keep(key, B, Sq, Sk, p, i16)
-        if keep is not None:      # the forward also stores the dropout keep decisions (1 bit per score) for the backward's pair launch
+        if keep is not None and key in self._keep_ready:      # the bits are there already (kk_attn_keep_gen): the forward reads them
+            kk.call("kk_attn_fwd_rb", q_n, k_n, v_n, ctx, lse, B, h, Sq, Sk, q_n.stride(0), k_n.stride(0), v_n.stride(0), H, key_mask,
+                    1 if causal else 0, 0.125, self.rng, site + 3, p, self.math, i16, keep)
+        elif keep is not None:    # the forward also stores the dropout keep decisions (1 bit per score) for the backward's pair launch
             kk.call("kk_attn_fwd_kb", q_n, k_n, v_n, ctx, lse, B, h, Sq, Sk, q_n.stride(0), k_n.stride(0), v_n.stride(0), H, key_mask,
                     1 if causal else 0, 0.125, self.rng, site + 3, p, self.math, i16, keep)
         else:
@@ -773,6 +777,22 @@ class KokoroEngine:
             return None
         n = kk.load().kk_attn_keep_bytes(B, self.dims.heads, Sq, Sk)
         return self._buf(key + ".keep", n, dtype=torch.uint8) if n > 0 else None
+
+    def _keep_gen_launch(self, B, T, p_dec, seed_offset=0, mark_ready=True, max_wgs=0) -> bool:
+        """kk_attn_keep_gen for every decoder attention launch of a (B, T) step; False when that shape has no keep-bit arrays."""
+        d, ents = self.dims, []
+        for li in range(d.dec_layers):
+            for sub, off, cz in ((".sa", 0, True), (".ca", 8, False)):
+                kb = self._attn_keep(f"dec{li}{sub}", B, T, T, p_dec, 1)
+                if kb is not None:
+                    ents.append((kb, 2000 + 32 * li + off + 3, p_dec, B, d.heads, T, T, cz))
+                    if mark_ready:
+                        self._keep_ready.add(f"dec{li}{sub}")
+        for c0 in range(0, len(ents), 16):
+            part = ents[c0:c0 + 16]
+            table = self._table(("keepgen",) + tuple((e[0].data_ptr(), e[1], e[2], B, T) for e in part), lambda part=part: kk.keep_sites(part))
+            kk.call("kk_attn_keep_gen", table, len(part), self.rng, seed_offset, max_wgs)
+        return bool(ents)
 
     def _cross_kv(self, layer, Nk, dt, which=""):
         """(raw, normed) K|V of cross-attention layer `layer`: column slices [.., 2H] of the all-layer buffers (row stride
@@ -1151,6 +1171,11 @@ class KokoroEngine:
             if zero_grads and self.zero_late:
                 self._zero_grad_step()
             self._mark("kv: zero_grad done")
+            if gen_keep:
+                # the keep bits of every decoder attention launch of this step, HERE: this stream idles until the persistent encoder
+                # launch (which holds every CU's LDS) has ended, and the generator needs no LDS — it runs beside the encoder
+                self._keep_gen_launch(B, T, p_dec, 0, True)
+                self._mark("kv: keep bits generated")
             ya0, n20 = self_attn(0, y0, n10)
             return y0, ya0, n20
 
@@ -1164,6 +1189,12 @@ class KokoroEngine:
             self.rng.add_(1)                              # fresh masks every micro-batch (captured in the hipGraph)
         pe_drop, p_enc, p_dec, p_var = self._p(hp.encoder_dropout), self._p(hp.encoder_dropout), self._p(hp.decoder_dropout), self._p(hp.variance_dropout)
         self._mark("step.start")
+        stack = self._encoder_stack_ok(B, Pn)
+        self._keep_ready = set()
+        # beside the persistent encoder forward, where that pays (measured: -0.4 % at 8 x 512, +1.6 % at 8 x 1024, where the generator
+        # outlasts the encoder and delays the decoder head; profiles/r06_keep_bits_gen_ab.txt)
+        gen_keep = bool(self.attn_keep_gen and self.attn_keep_bits and self.train_dropout and p_dec > 0.0 and ddt == torch.bfloat16 and
+                        self.overlap and stack and self.dec_head_aside and Nd <= 4096)
         with self._on_stream(self._kv, "kv.", self.dec_head_aside):     # beside the encoder; joined before the first cross-attention
             if zero_grads and not self.zero_late:
                 self._zero_grad_step()
@@ -1179,7 +1210,6 @@ class KokoroEngine:
         else:
             kk.call("kk_embed_fwd", ids, stress, P["text_embedding.weight"], P["stress_embedding.weight"] if stress is not None else None,
                     pe, x, B, Pn, H, float(H ** 0.5), self.rng, 1, pe_drop)
-        stack = self._encoder_stack_ok(B, Pn)
         if stack:                                         # all layers in ONE persistent launch (csrc/kk_encstack.hip)
             if y1 is None:
                 y1 = self._ln_fwd("enc0.ln1", x, "transformer_encoder_layers.0.norm1", edt)
@@ -1843,7 +1873,7 @@ class KokoroEngine:
         # graph captured under one value must not be replayed under another: ADVICE r3; the CANONICAL value, so that a ragged
         # data-parallel run replays one capture per local shape for every global length up to 1400: canonical_mel_length)
         fkey = (div, first, self.train_dropout, self.spec_augment_active, self.math, self.dp_comm is not None and is_boundary,
-                mel_length if self.loss_sync is not None else 0, self.loss_sync is not None, self.self_cleaning_acc)
+                mel_length if self.loss_sync is not None else 0, self.loss_sync is not None, self.self_cleaning_acc, self.attn_keep_gen)
         with self._acc_guard():                        # (a replayed graph assumes the accumulators' zero state like an eager step)
             fb = ent["fb"].get(fkey)
             if fb is None:

@@ -77,6 +77,19 @@ def wgrad_table(entries):
     return arr
 
 
+class KkKeepSite(C.Structure):
+    _fields_ = [("keep", C.c_void_p), ("site", C.c_uint32), ("p", C.c_float), ("B", C.c_int), ("heads", C.c_int), ("Sq", C.c_int),
+                ("Sk", C.c_int), ("causal", C.c_int)]
+
+
+def keep_sites(entries):
+    """Host KkKeepSite array from [(keep buffer, site, p, B, heads, Sq, Sk, causal)] for kk_attn_keep_gen."""
+    arr = (KkKeepSite * len(entries))()
+    for d, (keep, site, p, B, heads, Sq, Sk, causal) in zip(arr, entries):
+        d.keep, d.site, d.p, d.B, d.heads, d.Sq, d.Sk, d.causal = keep.data_ptr(), int(site), float(p), B, heads, Sq, Sk, 1 if causal else 0
+    return arr
+
+
 KK_ENC_MAX_LAYERS = 8
 
 
@@ -149,6 +162,8 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_colsum_acc": [_P, _L, _L, _L, _P, _I, _P],
     "kk_attn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P],
     "kk_attn_fwd_kb": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P, _P],
+    "kk_attn_fwd_rb": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P, _P],
+    "kk_attn_keep_gen": [_P, _I, _P, _I, _I, _P],
     "kk_attn_delta": [_P, _P, _P, _I, _I, _I, _L, _L, _I, _P],
     "kk_attn_bwd_dq": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P, _L, _P, _P],
     "kk_zero_many": [_P, _P, _I, _P],
