@@ -235,6 +235,10 @@ class KokoroEngine:
         # them too (kk_attn_fwd_rb): -3 us per forward launch at 512 frames, -6.4 ... -8.6 us at 1024 (round 6; same bits either way)
         self.attn_keep_gen = True
         self._keep_ready = set()                    # sub-layer keys whose bits kk_attn_keep_gen has written in this step
+        # (one-tile sequences — the text encoder's <= 64 phonemes, on the side branch — take the two thinner launches: re-measured INSIDE
+        #  the step in round 5, 3.6215 -> 3.608 ms at 8 x 512 (4 of 4 interleaved rounds); 65..128 phonemes keep the pair launch: two launches
+        #  there are +0.3 % at 8 x 1024.  profiles/r05_encoder_attn_pair_ab.txt)
+        self.attn_pair_min_seq = 64
         self.attn_proj_bf16 = True                 # decoder w_o output stored as bf16 (bf16 mode)
         # the decoder's attention output projection and the sub-layer tail behind it as ONE row-owner launch (kk_linear_tail_fwd) where
         # the library measured it faster (kk_linear_tail_pays: whole rounds of workgroups at >= ~6 K rows); bit-identical results

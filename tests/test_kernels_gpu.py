@@ -764,7 +764,7 @@ def test_optimizer_accumulators_handed_round_zero(kk):
         outs.append(o)
     for o in outs[1:]:
         assert torch.equal(o, outs[0]), "kk_seg_sumsq must give the same bits on every call (order-deterministic reduction)"
-    assert float(((outs[0] - ref2).abs() / ref2).max()) < 1e-12, "seg_sumsq, 78 segments over ~60 K blocks, against the fp64 reference"
+    assert float(((outs[0] - ref2).abs() / ref2).max()) < 1e-7, "seg_sumsq, 78 segments over ~60 K blocks, against the fp64 reference (squares are fp32 products)"
     # an inf / NaN gradient poisons exactly its own segment
     bad = big.clone()
     bad[(sum(lens[:6]) + 700) * BLK + 5] = float("inf")
