@@ -149,3 +149,50 @@ for parts in (1, 6, 24):
         if it >= 2:
             tot += e0.elapsed_time(e1)
     print(f"main chain as {parts:2d} graph(s) on one stream: {tot * 1000 / (10 * REPS):7.2f} us per sub-layer  ({tot * 100:.1f} us per pass)", flush=True)
+
+# ---- two streams, each chain cut into 6 graphs, launched ALTERNATELY in host order (what a program of per-stream graphs does), with and
+# without events between the launches
+def side_part(i0, i1):
+    def fn():
+        for i in range(i0, i1):
+            a, b = sx[i & 1], sx[(i + 1) & 1]
+            kk.call("kk_gemm", 0, 0, 512, 512, 512, 1.0, a, 512, sw[i % 8], 512, 0.0, b, 512, None, None, 0, 0, 0, kk.KK_MATH_BF16, 1 | 2 | 4)
+    return fn
+
+
+mg = [capture(chain_part(k * 4, (k + 1) * 4), s_main) for k in range(6)]
+sg = [capture(side_part(k * 12, (k + 1) * 12), s_side) for k in range(6)]
+for variant in ("main only", "alternating, no events", "alternating, side waits for a main event each time", "all main then all side"):
+    tm = tw = 0.0
+    for it in range(12):
+        torch.cuda.synchronize()
+        w0, w1, m0, m1 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+        with torch.cuda.stream(s_main):
+            w0.record(s_main)
+            s_side.wait_event(w0)
+            m0.record(s_main)
+            if variant == "all main then all side":
+                for k in range(6):
+                    mg[k].replay()
+                m1.record(s_main)
+                with torch.cuda.stream(s_side):
+                    for k in range(6):
+                        sg[k].replay()
+            else:
+                for k in range(6):
+                    mg[k].replay()
+                    if variant != "main only":
+                        if "event" in variant:
+                            ev = torch.cuda.Event()
+                            ev.record(s_main)
+                            s_side.wait_event(ev)
+                        with torch.cuda.stream(s_side):
+                            sg[k].replay()
+                m1.record(s_main)
+            s_main.wait_stream(s_side)
+            w1.record(s_main)
+        torch.cuda.synchronize()
+        if it >= 2:
+            tm += m0.elapsed_time(m1)
+            tw += w0.elapsed_time(w1)
+    print(f"6 + 6 graphs, {variant:52s} main chain {tm * 1000 / (10 * REPS):7.2f} us per sub-layer   wall {tw * 100:8.1f} us", flush=True)
