@@ -39,7 +39,7 @@ def train_flops(B: int, T: int, P: int, H=512, F=1536, Le=6, Ld=6, M=80, Fv=256)
     return 6.0 * macs
 
 GEMM_ROLE = {(0, 0): "X.W^T fwd", (0, 1): "dY.W dgrad", (1, 1): "dY^T.X wgrad", (1, 0): "X^T.W"}
-PMC_ROUNDS = ("r05", "r04", "r03", "r02h", "r02g")       # profiles/<round>_pmc_hbm_traffic_BxTxP.json, newest first (tools/rocprof_pmc.sh: separate --pmc passes)
+PMC_ROUNDS = ("r06", "r05", "r04", "r03", "r02h", "r02g")       # profiles/<round>_pmc_hbm_traffic_BxTxP.json, newest first (tools/rocprof_pmc.sh: separate --pmc passes)
 
 
 CUS = 256                                  # compute units; set_device_cus() replaces it with the device's count (the library's tile policy reads the same attribute)
