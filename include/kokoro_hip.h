@@ -174,6 +174,10 @@ int kk_attn_bwd_kb(const float *Q, const float *K, const float *V, const float *
  * same function of (seed value, site, b, head, q, key), the same layout as kk_attn_fwd_kb stores — in ONE pure-vector launch that needs
  * no LDS, so it runs beside the persistent encoder forward; kk_attn_fwd_rb is kk_attn_fwd reading those bits instead of hashing (and
  * storing) them: the same output bits with ~40 % fewer vector instructions per score unit.  kk_attn_bwd_kb reads the same arrays. */
+/* Weight warming (round 6): the next kk_attn_fwd / _kb / _rb launch of the calling thread that takes the third-generation kernel also
+ * touches one dword per 128-byte line of up to two read-only device buffers (the weight matrices of the GEMMs behind it) so that
+ * every XCD's L2 holds them when those GEMMs start (an XCD's L2 keeps read-only lines across a kernel boundary).  One-shot. */
+int kk_attn_warm_next(const void *w0, int64_t bytes0, const void *w1, int64_t bytes1);
 typedef struct {
     void *keep;          /* kk_attn_keep_bytes(B, heads, Sq, Sk) bytes */
     uint32_t site;       /* the site the attention launch is given (engine: sub-layer site + 3) */

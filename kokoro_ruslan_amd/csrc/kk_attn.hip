@@ -54,6 +54,12 @@ struct AttnArgs {
     // (((b * heads + head) * nQU + qu) * nKU + ku) * 128, nQU = ceil(Sq / 32), nKU = ceil(Sk / 32); dword 2 r + h of a unit = bits over
     // the unit's 32 queries (bit = query) for key frag_row(r, h): the forward's ballot of accumulator register r, half h.
     void *keep;
+    // weight warming (kk_attn_warm_next): the third-generation forward touches one dword per 128-byte line of up to two matrices the NEXT
+    // launches multiply with — each XCD's workgroups share the lines out — during its last tile step, when its own DMAs are over: the
+    // forward is vector-bound and its CUs' request slots are idle, and an XCD's L2 keeps read-only lines across the kernel boundary
+    // (profiles/r06_l2_retention_probe.txt), so the GEMM behind it finds its weights L2-hot instead of in HBM
+    const void *warm[2];
+    uint32_t warm_bytes[2];
     int keep_rd;                         // forward: 1 = READ the keep bits (written by kk_attn_keep_gen beside the encoder forward) instead of hashing + storing them
     // backward kernels: the gradient of the per-head RMSNorm (+ RoPE) that produced Q (dQ kernel) / K and V (dK/dV
     // kernel: hn[0], hn[1]) as the epilogue — Out / Out2 then receive the gradient of the RAW projection
@@ -1105,6 +1111,7 @@ __device__ __forceinline__ void attn_fwd3_body(const AttnArgs &a, int chain_bx =
     const kk_cu64x8 *keep_row = KRD ? reinterpret_cast<const kk_cu64x8 *>(reinterpret_cast<uintptr_t>(
         static_cast<const char *>(a.keep) + ((int64_t)(b * a.heads + hh) * ((a.Sq + 31) >> 5) + (qmin < a.Sq ? qmin >> 5 : 0)) * nKU * 128)) : nullptr;
     uint32_t kw_pend = 0u;
+    uint32_t warm_sink = 0u;                                   // destination of the weight-warming loads (never read)
     int kw_unit = -1;                                          // (wave-uniform) key unit whose words are pending in kw_pend
     auto flush_keep = [&]() {
         if (kw_unit >= 0) {
@@ -1125,6 +1132,20 @@ __device__ __forceinline__ void attn_fwd3_body(const AttnArgs &a, int chain_bx =
         asm volatile("" ::: "memory");
         flush_keep();
         if (t + NS - 1 < nt) issue_tile(t + NS - 1, (t + NS - 1) % NS);
+        if (t == nt - 1 && a.warm_bytes[0] != 0u) {            // (no DMA is issued after this point: only the final vmcnt(0) waits for these)
+            const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y, ngrp = (gridDim.x * gridDim.y) >> 3, j = lin >> 3;
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                const uint32_t lines = a.warm_bytes[w] >> 7, per = (lines + ngrp - 1) / (ngrp ? ngrp : 1);
+                for (uint32_t i = wave8 * 64 + lane; i < per; i += 512) {
+                    const uint32_t line = j * per + i;
+                    if (line < lines) {
+                        const char *ptr = static_cast<const char *>(a.warm[w]) + ((size_t)line << 7);
+                        asm volatile("global_load_dword %0, %1, off" : "=v"(warm_sink) : "v"(ptr) : "memory");
+                    }
+                }
+            }
+        }
         const int k0 = t * KT + 32 * kg;
         if (k0 >= klim) continue;                             // (causal: nothing of this unit is visible to these queries)
         const uint32_t kimg = sl + (uint32_t)((t % NS) * STAGE + kg * 4096), vimg = kimg + KIMG;
@@ -1237,6 +1258,7 @@ __device__ __forceinline__ void attn_fwd3_body(const AttnArgs &a, int chain_bx =
     }
     flush_keep();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" :: "v"(warm_sink));
     __syncthreads();                                           // the ring is free: the key slots' partial softmaxes meet in it
     {
         float *mb = reinterpret_cast<float *>(smem_raw);       // [(kg - 1) * QW + qw][lane][34]
@@ -2275,6 +2297,17 @@ extern "C" int64_t kk_attn_keep_bytes(int B, int heads, int Sq, int Sk) {
     return per_head < (1ll << 31) ? (int64_t)B * heads * per_head : 0;
 }
 
+static thread_local const void *g_warm_ptr[2] = {nullptr, nullptr};
+static thread_local uint32_t g_warm_bytes[2] = {0u, 0u};
+// The NEXT third-generation forward launch of this thread also warms these (up to two) read-only matrices into every XCD's L2 (see
+// AttnArgs::warm).  One-shot: consumed by that launch, dropped by any other forward launch.
+extern "C" int kk_attn_warm_next(const void *w0, int64_t bytes0, const void *w1, int64_t bytes1) {
+    g_warm_ptr[0] = w0; g_warm_bytes[0] = (w0 && bytes0 > 0 && bytes0 < (1ll << 31)) ? (uint32_t)bytes0 : 0u;
+    g_warm_ptr[1] = w1; g_warm_bytes[1] = (w1 && bytes1 > 0 && bytes1 < (1ll << 31)) ? (uint32_t)bytes1 : 0u;
+    if (g_warm_bytes[0] == 0u) { g_warm_ptr[0] = g_warm_ptr[1]; g_warm_bytes[0] = g_warm_bytes[1]; g_warm_bytes[1] = 0u; }
+    return 0;
+}
+
 static int attn_fwd_impl(const float *Q, const float *K, const float *V, float *O, float *LSE, int B, int heads,
                          int Sq, int Sk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                          const uint8_t *key_mask, int causal, float scale, const uint32_t *seed, uint32_t site,
@@ -2290,6 +2323,9 @@ static int attn_fwd_impl(const float *Q, const float *K, const float *V, float *
     a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(causal); a.dbg = attn_dbg(); a.wt = kk_write_through((int64_t)B * std::max(Sq, Sk));
     a.keep = keep;
     a.keep_rd = (keep_rd && keep != nullptr && a.seed != nullptr) ? 1 : 0;
+    a.warm[0] = g_warm_ptr[0]; a.warm[1] = g_warm_ptr[1];
+    a.warm_bytes[0] = g_warm_bytes[0]; a.warm_bytes[1] = g_warm_bytes[1];
+    g_warm_bytes[0] = g_warm_bytes[1] = 0u;                     // (one-shot)
 #ifdef KK_TUNING_HOOKS
     if (a.dbg & 256) a.DeltaOut = static_cast<float *>(g_attn_trace);
 #endif
@@ -2539,6 +2575,11 @@ static int attn_bwd_impl(const float *Q, const float *K, const float *V, const f
     a.seed = p_drop > 0.f ? seed : nullptr; a.site = site; a.p_drop = p_drop; a.xcd_map = attn_xcd_map(causal); a.dbg = attn_dbg(); a.wt = kk_write_through((int64_t)B * std::max(Sq, Sk));
     if (a.xcd_map && causal) a.xcd_map = 2;                    // (the pair launch: always block-major when causal)
     p.dkv = a;
+    if (attn_gen3() & 1) {                                     // the dQ half of the third-generation pair launch warms the next GEMMs' weights
+        p.dq.warm[0] = g_warm_ptr[0]; p.dq.warm[1] = g_warm_ptr[1];
+        p.dq.warm_bytes[0] = g_warm_bytes[0]; p.dq.warm_bytes[1] = g_warm_bytes[1];
+    }
+    g_warm_bytes[0] = g_warm_bytes[1] = 0u;                     // (one-shot)
     p.dkv.Out = dK; p.dkv.Out2 = dV; p.dkv.ldout = lddk; p.dkv.ldout2 = lddv;
     if (hn_q) {
         if (int rc = check_headnorm("kk_attn_bwd", hn_q, 1)) return rc;

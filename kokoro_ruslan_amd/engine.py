@@ -234,6 +234,14 @@ class KokoroEngine:
         # from ONE pure-vector launch beside the encoder forward (kk_attn_keep_gen, on the decoder-head stream) and the forward READS
         # them too (kk_attn_fwd_rb): -3 us per forward launch at 512 frames, -6.4 ... -8.6 us at 1024 (round 6; same bits either way)
         self.attn_keep_gen = True
+        # Weight warming (kk_attn_warm_next; profiles/r06_l2_retention_probe.txt): an XCD's L2 keeps read-only lines across a kernel
+        # boundary, and the attention launches are vector-bound with idle request slots — so the decoder's attention forward touches
+        # the lines of the output projection behind it (bit 0) and the dQ half of the backward's pair launch, which ends ~9 us before
+        # its dK/dV half, those of the q | k | v (or q) projection whose dgrad follows (bit 2): the GEMMs find their weights L2-hot
+        # instead of in HBM.  Interleaved: -0.2 ... -0.6 % at 8 x 512, -0.4 ... -0.7 % at 8 x 1024, level under dynamic batching; bit 1
+        # (+ the next sub-layer's first matrix, 0.5 - 3 MB, from the forward) and bit 3 (+ the next output projection from the backward)
+        # measured level or worse (profiles/r06_weight_warming_ab.txt).
+        self.attn_warm = 5
         self._keep_ready = set()                    # sub-layer keys whose bits kk_attn_keep_gen has written in this step
         # (one-tile sequences — the text encoder's <= 64 phonemes, on the side branch — take the two thinner launches: re-measured INSIDE
         #  the step in round 5, 3.6215 -> 3.608 ms at 8 x 512 (4 of 4 interleaved rounds); 65..128 phonemes keep the pair launch: two launches
@@ -745,6 +753,14 @@ class KokoroEngine:
             k_raw, v_raw, k_n, v_n = kv_raw, kv_raw[:, H:], kv_n, kv_n[:, H:]
         ctx, lse = self._buf(key + ".ctx", Nq, H, dtype=dt), self._buf(key + ".lse", B, h, Sq)
         keep = self._attn_keep(key, B, Sq, Sk, p, i16)
+        if (self.attn_warm & 3) and i16 and key.startswith("dec") and self.use_shadow:
+            # the forward warms the weights of the GEMMs behind it into every XCD's L2 (kk_attn_warm_next): its own output projection, and
+            # the next sub-layer's first matrix (cross-attention: w_q; feed-forward: linear1)
+            base = prefix.rsplit(".", 1)[0]                # "decoder.layers.<i>"
+            nxt = base + (".cross_attn.w_q.weight" if xkv is None else ".ff.linear1.weight")
+            w0, w1 = self._W(prefix + ".w_o.weight"), self._W(nxt)
+            kk.load().kk_attn_warm_next(w0.data_ptr(), w0.numel() * w0.element_size(), w1.data_ptr() if self.attn_warm & 2 else None,
+                                        w1.numel() * w1.element_size())
         if keep is not None and key in self._keep_ready:      # the bits are there already (kk_attn_keep_gen): the forward reads them
             kk.call("kk_attn_fwd_rb", q_n, k_n, v_n, ctx, lse, B, h, Sq, Sk, q_n.stride(0), k_n.stride(0), v_n.stride(0), H, key_mask,
                     1 if causal else 0, 0.125, self.rng, site + 3, p, self.math, i16, keep)
@@ -901,6 +917,18 @@ class KokoroEngine:
                 self._reduce_lists[self._tmp_ns].append((part[j], dg_, None, nb, 64, 64))
             return table
 
+        def warm_bwd():
+            """the dQ half of the pair launch warms the weights of the dgrad GEMM(s) behind it (kk_attn_warm_next)"""
+            if not (self.attn_warm & 12) or not (i16 and key.startswith("dec") and self.use_shadow):
+                return
+            w0 = self._Wf(prefix + ".w_q.weight", 3) if xkv is None else self._W(prefix + ".w_q.weight")
+            w1 = None
+            if self.attn_warm & 8:       # ... and of the output projection whose dgrad comes after the tail behind that (the self-attention's, from the cross-attention)
+                base = prefix.rsplit(".", 1)[0]
+                w1 = self._W(base + ".self_attn.w_o.weight") if xkv is not None else None
+            kk.load().kk_attn_warm_next(w0.data_ptr(), w0.numel() * w0.element_size(), w1.data_ptr() if w1 is not None else None,
+                                        w1.numel() * w1.element_size() if w1 is not None else 0)
+
         def bwd_one_call(*args):
             """kk_attn_bwd, or — where the library says the shape pays (kk_attn_bwd_two_pass: full attention from 1024 x 1024 scores per
             head up) — kk_attn_bwd_ws with this stream's dS workspace (2 bytes per score; "tmp.": private to the stream)."""
@@ -909,6 +937,7 @@ class KokoroEngine:
                 kk.call("kk_attn_bwd_ws", *args, self._buf("tmp.attn_dS", need, dtype=torch.uint8), need)
                 return
             keep = self._attn_keep(key, B, Sq, Sk, p, i16)          # (the buffer the forward of this sub-layer filled)
+            warm_bwd()
             if keep is not None:
                 kk.call("kk_attn_bwd_kb", *args, keep)
             else:

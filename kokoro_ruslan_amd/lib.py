@@ -302,6 +302,8 @@ def load() -> C.CDLL:
     lib.kk_attn_bwd_ws_bytes.restype = C.c_int64
     lib.kk_attn_keep_bytes.argtypes = [_I, _I, _I, _I]
     lib.kk_attn_keep_bytes.restype = C.c_int64
+    lib.kk_attn_warm_next.argtypes = [_P, _L, _P, _L]
+    lib.kk_attn_warm_next.restype = C.c_int
     lib.kk_seg_sumsq_ws_bytes.argtypes = [_L]
     lib.kk_seg_sumsq_ws_bytes.restype = C.c_int64
     if lib.kk_abi_version() != ABI_VERSION:
