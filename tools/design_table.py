@@ -31,7 +31,10 @@ def short(mangled: str) -> str:
         return f"gemm16_kernel_w8{w8.group(1) or ''}<{','.join(args)}>"
     m = re.search(r"gemm16_(group_)?kernelILb(\d)ELb(\d)E((?:Li\d+E)+)", mangled)
     if m:
-        return f"gemm16_{m.group(1) or ''}kernel<{b(m.group(2))},{b(m.group(3))},{ints(m.group(4))}>"
+        args = INTS.findall(m.group(4))
+        if not m.group(1) and len(args) == 4 and args[3] == "0":      # (the plain epilogue: named without it, like the PMC summary does)
+            args = args[:3]
+        return f"gemm16_{m.group(1) or ''}kernel<{b(m.group(2))},{b(m.group(3))},{','.join(args)}>"
     m = re.search(r"_GLOBAL__N_1\d+([A-Za-z_0-9]+?)(?:I[A-Z]|E[A-Zv]|$)", mangled)
     if m:
         return m.group(1)
