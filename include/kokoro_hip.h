@@ -65,7 +65,12 @@ typedef struct {
 } KkWgradDesc;
 int kk_gemm_wgrad_group(const KkWgradDesc *descs, int n, int split_k /* k-slices per problem, 0 = automatic */,
                         int overwrite /* 1: dw = product (the first micro-batch of an accumulation cycle: dw is not read; no k-slices), 0: dw += */,
-                        void *stream);
+                        void *ss_rec /* nullable; kk_seg_sumsq's record workspace */, const int32_t *ss_seg /* HOST, 2 per problem: arena segment id of dw's row 0, and the rows per
+                        segment when dw spans several ADJACENT segments (the fused q|k|v view; a multiple of 128), else 0 */,
+                        int32_t *ss_count /* HOST in/out: records of ss_rec in use.  When the launch writes every dw element exactly once from
+                        one workgroup (no k-slices, write-through fp32 epilogue) each tile also leaves the sum of squares of what it stored as
+                        a record [*ss_count ..) and *ss_count advances by the launch's tile count — kk_seg_sumsq(seg_skip, extra_records) then
+                        does not read those tensors; otherwise *ss_count is left alone */, void *stream);
 /* Attention projections with the per-head norm as the epilogue: raw[T, parts*heads*64] = x[T,K] . W^T (+bias), saved for
  * the backward, and y = per-head RMSNorm(64)(raw) * gains[part] (+ RoPE on the parts set in rope_mask, position = row % S)
  * from one launch — a 64x64 output tile is exactly 64 (row, head) vectors.  parts <= 12 column groups of heads*64 (q|k|v of
@@ -524,10 +529,15 @@ typedef struct KkOptCfg {
 /* sumsq[seg] (double) = sum of squares of each arena segment of `buf`, as a PURE FUNCTION of the buffer: workgroup partials are
  * merged in arena order by a fixed tree (no atomics), so data-parallel replicas holding the same reduced gradient compute the same
  * bits (trainer.py:2355-2362 is a host-side sum with the same property).  Every segment is stored exactly once: no zero-fill.
- * ws: kk_seg_sumsq_ws_bytes(nblocks) bytes of scratch (contents irrelevant on entry). */
+ * ws: kk_seg_sumsq_ws_bytes(nblocks) bytes of scratch: the arena walk's records first, then room for kk_gemm_wgrad_group's tile
+ * records (kk_seg_sumsq_rec_offset() bytes into ws, kk_seg_sumsq_rec_capacity() records).
+ * seg_skip (nullable, int32[nseg], device): segments NOT read by the walk — their sums come from `extra_records` tile records that
+ * the step's weight-gradient launches left behind the walk's (one GPU only: data parallel norms need the REDUCED gradient). */
 int64_t kk_seg_sumsq_ws_bytes(int64_t nblocks);
+int64_t kk_seg_sumsq_rec_offset(void);
+int kk_seg_sumsq_rec_capacity(void);
 int kk_seg_sumsq(const float *buf, const int32_t *block_seg, int64_t nblocks, double *sumsq, int nseg, void *ws,
-                 void *stream);
+                 const int32_t *seg_skip, int extra_records, void *stream);
 /* One-thread-block kernel: per-parameter pre-clip, total norm, non-finite check, explosion tracker,
  * adaptive + global clip, LR schedule -> per-segment gradient scale / lr / step-size constants. */
 int kk_opt_prepare(const double *grad_sumsq, const float *seg_preclip, const float *seg_lr_mult,

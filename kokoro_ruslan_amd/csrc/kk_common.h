@@ -46,6 +46,10 @@ template <typename A> static inline bool kk_capture(const char *kernel, const A 
     return true;
 }
 
+// A partial per-segment sum of squares (kk_seg_sumsq's records, kk_optim.hip): merged in array order by a fixed tree, so the order the
+// records are WRITTEN in never matters.  The weight-gradient GEMMs write one per tile of a dW they have just finished (G16Args::ss_rec).
+struct KkSegRec { double v; int32_t seg; int32_t pad; };       // seg < 0: empty slot
+
 // Tuning switches.  The PRODUCT library reads no environment variable but KK_GEMM16_TUNE (one-time tile policy override, see
 // kk_gemm16.hip): every A/B switch and every result-changing timing probe below exists only in a tools build
 // (python -m kokoro_ruslan_amd.build --tuning, which defines KK_TUNING_HOOKS); in the product they fold to their defaults.
@@ -75,7 +79,8 @@ int kk_gemm16_launch(int ta, int tb, int64_t M, int64_t N, int64_t K, float alph
                      int64_t ldb, float beta, void *C, int64_t ldc, int c_bf16, const float *bias, const float *residual,
                      int64_t ldr, int64_t res_mod, int split_k, int xcd_swizzle, hipStream_t s);
 void kk_gemm16_tune(int thr128, int thr12864, int split_target);
-int kk_gemm16_wgrad_group(const KkWgradDesc *d, int n, int split_k, int overwrite, int xcd_swizzle, hipStream_t s);
+int kk_gemm16_wgrad_group(const KkWgradDesc *d, int n, int split_k, int overwrite, int xcd_swizzle, hipStream_t s, void *ss_rec = nullptr,
+                          const int32_t *ss_seg = nullptr, int32_t *ss_count = nullptr);
 void kk_gemm16_tune_group(int split);
 int kk_gemm16_qkv_headnorm(int64_t T, int parts, int heads, int64_t K, const void *x, int64_t ldx, const void *W, const float *bias,
                            void *raw, int64_t ldraw, void *y, int64_t ldy, int S, const float *const *gains, int rope_mask,

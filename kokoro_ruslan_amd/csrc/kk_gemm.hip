@@ -480,11 +480,13 @@ extern "C" int kk_gemm_linear_glu(int64_t T, int64_t F, int64_t K, const void *x
 }
 
 // A layer's weight gradients as one grouped launch (bf16 operands, fp32 accumulate into dW).
-extern "C" int kk_gemm_wgrad_group(const KkWgradDesc *descs, int n, int split_k, int overwrite, void *stream) {
+extern "C" int kk_gemm_wgrad_group(const KkWgradDesc *descs, int n, int split_k, int overwrite, void *ss_rec, const int32_t *ss_seg,
+                                   int32_t *ss_count, void *stream) {
     KK_REQUIRE(descs != nullptr, "kk_gemm_wgrad_group: null descriptor table");
     KK_REQUIRE(split_k >= 0 && split_k < 100, "kk_gemm_wgrad_group: split_k out of range");
     KK_REQUIRE(!overwrite || split_k <= 1, "kk_gemm_wgrad_group: overwrite cannot be combined with k-slices (they accumulate with atomics)");
-    return kk_gemm16_wgrad_group(descs, n, split_k, overwrite, g_xcd_swizzle, (hipStream_t)stream);
+    KK_REQUIRE(ss_rec == nullptr || (ss_seg != nullptr && ss_count != nullptr && *ss_count >= 0), "kk_gemm_wgrad_group: ss_rec needs ss_seg and ss_count");
+    return kk_gemm16_wgrad_group(descs, n, split_k, overwrite, g_xcd_swizzle, (hipStream_t)stream, ss_rec, ss_seg, ss_count);
 }
 
 // q / k / v projection with the per-head RMSNorm (+ RoPE) as the epilogue (bf16 operands; see gemm16_kernel, EPI = 3).

@@ -17,6 +17,11 @@ struct G16Args {
     int dbg;                                                    // tools builds only (KK_DBG): timing probes that change results
     int wt;                                                     // write-through stores of C and the epilogues' outputs (kk_common.h: kk_write_through)
     uint32_t a_bytes, b_bytes;
+    // weight gradients written exactly once per element (fp32 C through the LDS transpose, no k-slices): each tile also leaves the sum of
+    // squares of the FINAL values it stored as record `tile index` of ss_rec (segment id ss_seg) — kk_seg_sumsq then skips the tensor
+    KkSegRec *ss_rec;
+    int ss_seg, ss_rows;                                        // segment of dW's row 0; rows per segment when dW spans several ADJACENT segments
+                                                                // (the fused q|k|v / k|v views: a multiple of the tile height), else 0
     // EPI == 1 (GLU backward epilogue): C is not written; see gemm16_kernel
     const __bf16 *glu_h;
     __bf16 *glu_dh;

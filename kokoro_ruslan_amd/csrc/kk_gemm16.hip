@@ -487,6 +487,7 @@ __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char
         float *tile = reinterpret_cast<float *>(smem) + wave * 32 * TP;
         float *C = static_cast<float *>(a.C);
         const int c8 = (lane & 3) * 8;
+        float ssq = 0.f;                                         // (ss_rec: this lane's share of the tile's sum of squares)
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -514,10 +515,23 @@ __device__ __forceinline__ void gemm16_body(const G16Args &a, const int wg, char
                         }
                         kk_st16_wt(dst, __builtin_bit_cast(kk_u32x4, o0));
                         kk_st16_wt(dst + 4, __builtin_bit_cast(kk_u32x4, o1));
+                        ssq += (o0.x * o0.x + o0.y * o0.y) + (o0.z * o0.z + o0.w * o0.w) + (o1.x * o1.x + o1.y * o1.y) + (o1.z * o1.z + o1.w * o1.w);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
             }
+        if (a.ss_rec != nullptr) {                              // (workgroup-uniform; splits == 1 by the caller) wave sums added in wave order
+            double *wsum = reinterpret_cast<double *>(smem + WAVES * 32 * TP * 4);
+            const double wv = wave_sum_d((double)ssq);
+            if (lane == 0) wsum[wave] = wv;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double t = 0.0;
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w) t += wsum[w];
+                a.ss_rec[tid_lin] = KkSegRec{t, a.ss_seg + (a.ss_rows > 0 ? m0 / a.ss_rows : 0), 0};
+            }
+        }
         return;
     }
 #pragma unroll
@@ -932,7 +946,13 @@ int kk_gemm16_linear_glu(int64_t T, int64_t F, int64_t K, const void *x, int64_t
 }
 
 // dW_i[M_i, N_i] += dY_i[T_i, M_i]^T . X_i[T_i, N_i] for i < n, one launch (see gemm16_group_kernel).
-int kk_gemm16_wgrad_group(const KkWgradDesc *d, int n, int split_k, int overwrite, int xcd_swizzle, hipStream_t s) {
+int kk_gemm16_wgrad_group(const KkWgradDesc *d, int n, int split_k, int overwrite, int xcd_swizzle, hipStream_t s, void *ss_rec,
+                          const int32_t *ss_seg, int32_t *ss_count) {
+    // ss_rec / ss_seg: when every problem of the launch is written exactly once per element by one workgroup (no k-slices, the
+    // write-through fp32 epilogue), its tiles leave the sums of squares of what they stored as records [*ss_count ..) of ss_rec and
+    // *ss_count is advanced; otherwise *ss_count stays and the caller's norm pass reads those tensors itself
+    KkSegRec *rec = static_cast<KkSegRec *>(ss_rec);
+    int rec_used = 0;
     auto cd = [](int64_t x, int64_t y) { return (int)((x + y - 1) / y); };
     if (n < 1 || n > GROUP_MAX) return kk_fail(KK_EINVAL, "kk_gemm_wgrad_group: 1..%d problems per launch, got %d", GROUP_MAX, n);
     int total = 0;
@@ -970,6 +990,17 @@ int kk_gemm16_wgrad_group(const KkWgradDesc *d, int n, int split_k, int overwrit
                 a.b_bytes = (uint32_t)(((K - 1) * a.ldb + N) * 2);
                 g.start[i + 1] = g.start[i] + a.tiles_m * a.tiles_n;
             }
+            bool all_wt = rec != nullptr && ss_seg != nullptr && ss_count != nullptr;
+            for (int i = 0; i < n && all_wt; ++i)               // (the conditions of g16x_body's write-through fp32 epilogue; a tile inside ONE segment)
+                all_wt = (ss_seg[2 * i + 1] == 0 || ss_seg[2 * i + 1] % 128 == 0) && g.p[i].wt && (g.p[i].ldc & 3) == 0 && (g.p[i].N & 7) == 0 && (reinterpret_cast<uintptr_t>(g.p[i].C) & 15) == 0;
+            if (all_wt) {
+                for (int i = 0; i < n; ++i) {
+                    g.p[i].ss_rec = rec + *ss_count + g.start[i];
+                    g.p[i].ss_seg = ss_seg[2 * i];
+                    g.p[i].ss_rows = ss_seg[2 * i + 1];
+                }
+                *ss_count += g.start[n];
+            }
             return kk_g16x_group(g, g.start[n], s);
         }
     }
@@ -1000,6 +1031,20 @@ int kk_gemm16_wgrad_group(const KkWgradDesc *d, int n, int split_k, int overwrit
         a.b_bytes = (uint32_t)(((K - 1) * a.ldb + N) * 2);
         g.start[i + 1] = g.start[i] + a.tiles_m * a.tiles_n * sp;
     }
+    {
+        bool all_wt = rec != nullptr && ss_seg != nullptr && ss_count != nullptr && BM == 128 && BN == 64 && g16_group_waves == 8;
+        for (int i = 0; i < n && all_wt; ++i)                   // (the conditions of gemm16_body's write-through fp32 epilogue, one k-slice)
+            all_wt = (ss_seg[2 * i + 1] == 0 || ss_seg[2 * i + 1] % 128 == 0) && g.p[i].splits == 1 && g.p[i].wt && (g.p[i].ldc & 3) == 0 && (g.p[i].N & 7) == 0 && (reinterpret_cast<uintptr_t>(g.p[i].C) & 15) == 0;
+        if (all_wt) {
+            for (int i = 0; i < n; ++i) {
+                g.p[i].ss_rec = rec + *ss_count + g.start[i];
+                g.p[i].ss_seg = ss_seg[2 * i];
+                g.p[i].ss_rows = ss_seg[2 * i + 1];
+            }
+            *ss_count += g.start[n];
+        }
+    }
+    (void)rec_used;
     dim3 grid(g.start[n]);
     kk_note_kernelf("gemm16_group<%d,%d,w%d>", BM, BN, BM == 128 ? g16_group_waves : 4);
     if (BN == 128 && g16_group_waves == 16) hipLaunchKernelGGL((gemm16_group_kernel<true, true, 128, 128, 2, 16, 4>), grid, dim3(1024), 0, s, g);

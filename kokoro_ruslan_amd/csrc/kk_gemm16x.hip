@@ -611,6 +611,7 @@ __device__ __forceinline__ void g16x_body(const G16Args &a, const int wg, char *
                             make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]));
         }
         __syncthreads();
+        float ssq = 0.f;                                         // (ss_rec: this lane's share of the tile's sum of squares)
 #pragma unroll 1
         for (int blk = wave; blk < NBR0 * (BN / 32); blk += WAVES) {
             const int bi = blk / (BN / 32), bj = blk % (BN / 32);
@@ -635,7 +636,22 @@ __device__ __forceinline__ void g16x_body(const G16Args &a, const int wg, char *
                 }
                 kk_st16_wt(dst, __builtin_bit_cast(kk_u32x4, o0));
                 kk_st16_wt(dst + 4, __builtin_bit_cast(kk_u32x4, o1));
+                ssq += (o0.x * o0.x + o0.y * o0.y) + (o0.z * o0.z + o0.w * o0.w) + (o1.x * o1.x + o1.y * o1.y) + (o1.z * o1.z + o1.w * o1.w);
             }
+        }
+        if constexpr (NS * STAGE >= BM * TPF * 4 + 8 * (WR * WC + LW)) {      // (room for the wave sums behind the fp32 tile)
+        if (a.ss_rec != nullptr) {                              // (workgroup-uniform) wave sums in wave order: the same bits whatever the schedule
+            double *wsum = reinterpret_cast<double *>(smem + BM * TPF * 4);
+            const double wv = wave_sum_d((double)ssq);
+            if (lane == 0) wsum[wave] = wv;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double t = 0.0;
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w) t += wsum[w];
+                a.ss_rec[wg] = KkSegRec{t, a.ss_seg + (a.ss_rows > 0 ? m0 / a.ss_rows : 0), 0};
+            }
+        }
         }
         return;
     }

@@ -32,34 +32,51 @@ constexpr double KK_PSUMSQ_ONE = 1073741824.0;                  // 2^30: p_sumsq
 //     (lead, trail); seg_sumsq_finish_kernel (ONE workgroup, launched behind this kernel) merges the records in workgroup order by
 //     a fixed tree (16 records per thread, three levels) and stores every segment once.
 // No atomics, no zero-fill: every segment of the arena is stored exactly once per call.
-struct SegRec { double v; int32_t seg; int32_t pad; };         // seg < 0: empty slot
+typedef KkSegRec SegRec;                                        // (kk_common.h: the weight-gradient GEMMs write them too)
+constexpr int SEG_REC_EXTRA = 4096;                             // tile records of the weight-gradient launches behind the walk's
 constexpr int SEG_SUMSQ_WGS = 2048;
 
 __global__ __launch_bounds__(256) void seg_sumsq_kernel(const float *__restrict__ buf, const int32_t *__restrict__ block_seg,
-                                                        int64_t nblocks, int per_wg, double *__restrict__ sumsq, SegRec *__restrict__ rec) {
+                                                        int64_t nblocks, int per_wg, double *__restrict__ sumsq, SegRec *__restrict__ rec,
+                                                        const int32_t *__restrict__ skip) {
     __shared__ double red[4];
+    __shared__ int32_t segs[256], skips[256];                     // the range's segment ids and skip flags, fetched at once (per_wg <= 256: the
+                                                                  // walk used to pay one dependent L2 round trip per block for them)
     const int64_t beg = (int64_t)blockIdx.x * per_wg;
     const int64_t end = beg + per_wg < nblocks ? beg + per_wg : nblocks;
     SegRec lead = {0.0, -1, 0}, trail = {0.0, -1, 0};
     if (beg < end) {
-        int cur = block_seg[beg];
+        if (threadIdx.x < end - beg) {
+            const int sg = block_seg[beg + threadIdx.x];
+            segs[threadIdx.x] = sg;
+            skips[threadIdx.x] = skip != nullptr ? skip[sg] : 0;
+        }
+        __syncthreads();
+        int cur = segs[0];
         bool first = true;
         double acc = 0.0;
+        bool cur_skip = skips[0] != 0;                          // (a skipped segment: no loads, no record, no store — its sum comes from tile records)
         for (int64_t blk = beg; blk < end; ++blk) {
-            const int seg = block_seg[blk];
+            const int seg = segs[blk - beg];
             if (seg != cur) {
-                const double tot = block_sum_256_d(acc, red);
-                if (first) { lead.v = tot; lead.seg = cur; first = false; }
-                else if (threadIdx.x == 0) sumsq[cur] = tot;      // (a whole segment inside this range)
+                if (!cur_skip) {
+                    const double tot = block_sum_256_d(acc, red);
+                    if (first) { lead.v = tot; lead.seg = cur; first = false; }
+                    else if (threadIdx.x == 0) sumsq[cur] = tot;  // (a whole segment inside this range)
+                }
                 cur = seg;
+                cur_skip = skips[blk - beg] != 0;
                 acc = 0.0;
             }
+            if (cur_skip) continue;
             const float4 v = ld4(buf + blk * BLK + threadIdx.x * 4);
             acc += (double)(v.x * v.x + v.y * v.y) + (double)(v.z * v.z + v.w * v.w);
         }
-        const double tot = block_sum_256_d(acc, red);
-        if (first) { lead.v = tot; lead.seg = cur; }
-        else { trail.v = tot; trail.seg = cur; }
+        if (!cur_skip) {
+            const double tot = block_sum_256_d(acc, red);
+            if (first) { lead.v = tot; lead.seg = cur; }
+            else { trail.v = tot; trail.seg = cur; }
+        }
     }
     if (threadIdx.x == 0) {
         rec[2 * blockIdx.x] = lead;
@@ -95,16 +112,18 @@ __device__ __forceinline__ void seg_merge16(const SegRec *in, int n, SegRec *out
     }
     if (!last) { out[2 * t] = a; out[2 * t + 1] = b; }
 }
-__global__ __launch_bounds__(256) void seg_sumsq_finish_kernel(const SegRec *__restrict__ rec, int nrec, double *__restrict__ sumsq) {
-    __shared__ SegRec l1[512], l2[64], l3[8];
+// rec: [2 * SEG_SUMSQ_WGS walk records | up to SEG_REC_EXTRA tile records]; a segment's records are adjacent in either part and no
+// segment has records in both (the walk skips what the tiles cover)
+__global__ __launch_bounds__(512) void seg_sumsq_finish_kernel(const SegRec *__restrict__ rec, int nrec, double *__restrict__ sumsq) {
+    __shared__ SegRec l1[1024], l2[128], l3[16], l4[2];
     const int t = threadIdx.x;
-    seg_merge16(rec, nrec, l1, sumsq, t, false);                 // 4096 -> 512
+    seg_merge16(rec, nrec, l1, sumsq, t, false);                 // 8192 -> 1024
     __syncthreads();
-    if (t < 32) seg_merge16(l1, 512, l2, sumsq, t, false);       // 512 -> 64
+    if (t < 64) seg_merge16(l1, 1024, l2, sumsq, t, false);      // 1024 -> 128
     __syncthreads();
-    if (t < 4) seg_merge16(l2, 64, l3, sumsq, t, false);         // 64 -> 8
+    if (t < 8) seg_merge16(l2, 128, l3, sumsq, t, false);        // 128 -> 16
     __syncthreads();
-    if (t == 0) seg_merge16(l3, 8, nullptr, sumsq, 0, true);
+    if (t == 0) seg_merge16(l3, 16, l4, sumsq, 0, true);
 }
 
 __device__ double onecycle_lr(const KkOptCfg &c, int64_t step_num) {
@@ -325,19 +344,23 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float *__restrict_
 
 extern "C" int64_t kk_seg_sumsq_ws_bytes(int64_t nblocks) {
     (void)nblocks;
-    return (int64_t)sizeof(SegRec) * 2 * SEG_SUMSQ_WGS;
+    return (int64_t)sizeof(SegRec) * (2 * SEG_SUMSQ_WGS + SEG_REC_EXTRA);
 }
+extern "C" int64_t kk_seg_sumsq_rec_offset(void) { return (int64_t)sizeof(SegRec) * 2 * SEG_SUMSQ_WGS; }
+extern "C" int kk_seg_sumsq_rec_capacity(void) { return SEG_REC_EXTRA; }
 
 extern "C" int kk_seg_sumsq(const float *buf, const int32_t *block_seg, int64_t nblocks, double *sumsq, int nseg, void *ws,
-                            void *stream) {
+                            const int32_t *seg_skip, int extra_records, void *stream) {
     KK_REQUIRE(buf && block_seg && sumsq && ws && nblocks > 0 && nseg > 0, "kk_seg_sumsq: bad args (the record workspace is required)");
+    KK_REQUIRE(extra_records >= 0 && extra_records <= SEG_REC_EXTRA && (extra_records == 0 || seg_skip != nullptr),
+               "kk_seg_sumsq: %d tile records (0..%d, with a skip table)", extra_records, SEG_REC_EXTRA);
     hipStream_t s = (hipStream_t)stream;
-    int wgs = SEG_SUMSQ_WGS;
+    const int wgs = SEG_SUMSQ_WGS;                               // (always: a workgroup without blocks writes its two EMPTY records)
     const int per = kk_cdiv(nblocks, wgs);
-    wgs = kk_cdiv(nblocks, per);
+    KK_REQUIRE(per <= 256, "kk_seg_sumsq: arenas beyond %d blocks are not supported", 256 * SEG_SUMSQ_WGS);
     SegRec *rec = static_cast<SegRec *>(ws);
-    hipLaunchKernelGGL(seg_sumsq_kernel, dim3(wgs), dim3(256), 0, s, buf, block_seg, nblocks, per, sumsq, rec);
-    hipLaunchKernelGGL(seg_sumsq_finish_kernel, dim3(1), dim3(256), 0, s, rec, 2 * wgs, sumsq);
+    hipLaunchKernelGGL(seg_sumsq_kernel, dim3(wgs), dim3(256), 0, s, buf, block_seg, nblocks, per, sumsq, rec, seg_skip);
+    hipLaunchKernelGGL(seg_sumsq_finish_kernel, dim3(1), dim3(512), 0, s, rec, 2 * SEG_SUMSQ_WGS + extra_records, sumsq);
     KK_LAUNCH_CHECK("kk_seg_sumsq");
     return 0;
 }

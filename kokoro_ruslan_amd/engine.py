@@ -234,6 +234,17 @@ class KokoroEngine:
         # from ONE pure-vector launch beside the encoder forward (kk_attn_keep_gen, on the decoder-head stream) and the forward READS
         # them too (kk_attn_fwd_rb): -3 us per forward launch at 512 frames, -6.4 ... -8.6 us at 1024 (round 6; same bits either way)
         self.attn_keep_gen = True
+        # One GPU: the per-segment gradient norms of the weight matrices come from the epilogue of the grouped weight-gradient launches
+        # (a record per tile of the FINAL values it stored) instead of from the optimizer's pass over the 199 MB gradient arena, which then
+        # reads only what no such launch wrote (embeddings, biases, norms, predictors).  Data parallel keeps the full pass: the norm that
+        # clips is the REDUCED gradient's.  _ss_step: the book-keeping of the micro-batch in flight; _ss_ready: what the optimizer boundary
+        # behind it may rely on (consumed by optimizer_step; None = full pass).
+        self.grad_norm_from_wgrads = True
+        self._ss_step = None
+        self._ss_ready = None
+        self._ss_masks: Dict[frozenset, torch.Tensor] = {}
+        self._external_sync = False
+        self._seg_of_ptr = {self.arena.G[n].data_ptr(): i for i, n in enumerate(self.arena.names)}
         # Weight warming (kk_attn_warm_next; profiles/r06_l2_retention_probe.txt): an XCD's L2 keeps read-only lines across a kernel
         # boundary, and the attention launches are vector-bound with idle request slots — so the decoder's attention forward touches
         # the lines of the output projection behind it (bit 0) and the dQ half of the backward's pair launch, which ends ~9 us before
@@ -624,7 +635,34 @@ class KokoroEngine:
             part = q[i:i + 8]
             sig = ("wg",) + tuple((dy.data_ptr(), x.data_ptr(), dw.data_ptr(), tuple(dy.shape), tuple(x.shape)) for dy, x, dw in part)
             table = self._table(sig, lambda: kk.wgrad_table(part))
-            kk.call("kk_gemm_wgrad_group", table, len(part), 0, 1 if self._grads_fresh else 0)
+            st = self._ss_step
+            if st is None:
+                kk.call("kk_gemm_wgrad_group", table, len(part), 0, 1 if self._grads_fresh else 0, None, None, None)
+            else:
+                # (one GPU) the tiles of a launch that writes every element once also leave the sums of squares of what they stored as
+                # records of kk_seg_sumsq's workspace: the optimizer's norm pass then skips those tensors (the library decides per launch
+                # and says so by advancing the count)
+                segs, flat = [], []
+                for _, _, dw in part:
+                    si = self._seg_of_ptr.get(dw.data_ptr())
+                    if si is None:
+                        segs = None
+                        break
+                    rows = self.arena.shapes[self.arena.names[si]][0]
+                    cnt = dw.shape[0] // rows                  # (fused q|k|v / k|v views: `cnt` adjacent segments of `rows` rows each)
+                    if dw.shape[0] % rows or any(self.arena.shapes[self.arena.names[si + c]] != self.arena.shapes[self.arena.names[si]] for c in range(cnt)):
+                        segs = None
+                        break
+                    segs.extend(range(si, si + cnt))
+                    flat.extend((si, rows if cnt > 1 else 0))
+                n0 = st["count"].value
+                if segs is None or n0 + 1024 > st["cap"]:
+                    kk.call("kk_gemm_wgrad_group", table, len(part), 0, 1 if self._grads_fresh else 0, None, None, None)
+                else:
+                    seg_arr = (kk.C.c_int32 * len(flat))(*flat)
+                    kk.call("kk_gemm_wgrad_group", table, len(part), 0, 1 if self._grads_fresh else 0, st["rec"], seg_arr, kk.C.byref(st["count"]))
+                    if st["count"].value != n0:
+                        st["covered"].update(segs)
             if self._grads_fresh and self._ow_seen is not None:
                 self._ow_seen.update((dw.data_ptr(), dw.numel()) for _, _, dw in part)
 
@@ -1147,11 +1185,13 @@ class KokoroEngine:
     def _fb(self, batch, loss_scale, adaptive, backward, zero_grads=False, expanded_len=None):
         """The launch sequence of forward_backward (also what train_step_graphed captures)."""
         self._defer_wgrads = None                     # (a list only while layer 0's grouped launch is being collected: ADVICE r5)
+        self._ss_step = None
         try:
             with self._acc_guard():
                 return self._fb_launches(batch, loss_scale, adaptive, backward, zero_grads, expanded_len)
         finally:
             self._defer_wgrads = None
+            self._ss_step = None
             self._wgrad_queue.clear()
 
     def _fb_launches(self, batch, loss_scale, adaptive, backward, zero_grads=False, expanded_len=None):
@@ -1380,6 +1420,10 @@ class KokoroEngine:
             return out
 
         # =========================== backward ===========================
+        self._ss_ready = None
+        if self.grad_norm_from_wgrads and self.dp_comm is None and not self._external_sync and self.group_wgrads:
+            self._ss_step = dict(rec=kk.C.c_void_p(self.sumsq_ws.data_ptr() + int(kk.load().kk_seg_sumsq_rec_offset())), count=kk.C.c_int32(0),
+                                 cap=int(kk.load().kk_seg_sumsq_rec_capacity()), covered=set())
         for ns in self._reduce_lists:
             self._reduce_lists[ns] = []
         if self.dp_comm is not None and self._exchange_now:
@@ -1541,6 +1585,10 @@ class KokoroEngine:
         self._comm_bucket("tail")                       # everything that was not a layer's weight matrix
         self._comm_join()
         self._mark("backward joined, partials reduced")
+        if self._ss_step is not None:                   # the tile records of this micro-batch: what an optimizer boundary right behind it may use
+            if self._ss_step["covered"]:
+                self._ss_ready = (frozenset(self._ss_step["covered"]), int(self._ss_step["count"].value))
+            self._ss_step = None
         if self._ow_seen is not None:                   # what this cycle's first micro-batch overwrote (see _zero_grad_step)
             seen = frozenset(self._ow_seen)
             if self._ow_expect is not None and seen != self._ow_expect:
@@ -1771,18 +1819,28 @@ class KokoroEngine:
         for dst, nbytes, n in self._table(("zero", a.g.data_ptr(), rec), build):
             kk.call("kk_zero_many", dst, nbytes, n)
 
-    def optimizer_step(self, mel_length: int) -> None:
+    def optimizer_step(self, mel_length: int, tile_norms=None) -> None:
         """Pre-clip → total norm → non-finite skip / explosion tracker / adaptive + global clip → fused AdamW+EMA →
-        FFN weight-norm projection.  All decisions on the device (see csrc/kk_optim.hip)."""
+        FFN weight-norm projection.  All decisions on the device (see csrc/kk_optim.hip).
+        tile_norms = (segments, records) from the micro-batch right in front (train_step passes _ss_ready; see grad_norm_from_wgrads):
+        the norm pass skips those segments — only for callers that have not touched the gradient arena in between."""
         a, hp = self.arena, self.hp
         cfg = self._opt_cfg(mel_length)
         self._mark("optimizer start")
+        skip, extra = None, 0
+        if tile_norms is not None and tile_norms[1] > 0:
+            skip = self._ss_masks.get(tile_norms[0])
+            if skip is None and not torch.cuda.is_current_stream_capturing():
+                m = torch.zeros(a.nseg, dtype=torch.int32)
+                m[sorted(tile_norms[0])] = 1
+                skip = self._ss_masks[tile_norms[0]] = m.to(self.device)
+            extra = tile_norms[1] if skip is not None else 0
         # grad_sumsq: every segment stored once per call by kk_seg_sumsq (records merged in a fixed order: replicas agree bit for bit).
         # p_sumsq (fixed-point atomics) is private to this sequence: kk_opt_prepare, the one-workgroup launch in front of its writer,
         # leaves it zero — no zero-fill launch on the optimizer's chain.
         with self._acc_guard():
             sc = 1 if self.self_cleaning_acc else 0
-            kk.call("kk_seg_sumsq", a.g, a.block_seg, a.nblocks, self.grad_sumsq, a.nseg, self.sumsq_ws)
+            kk.call("kk_seg_sumsq", a.g, a.block_seg, a.nblocks, self.grad_sumsq, a.nseg, self.sumsq_ws, skip, extra)
             kk.call("kk_opt_prepare", self.grad_sumsq, a.seg_preclip, a.seg_lr_mult, a.seg_wd, a.nseg, self.max_dur, cfg,
                     self.opt_state, self.seg_gscale, self.seg_decay, self.seg_stepsize, self.step_consts,
                     None, self.p_sumsq if sc else None)
@@ -1805,16 +1863,20 @@ class KokoroEngine:
         is_boundary = bool(boundary) if boundary is not None else self.micro_in_cycle + 1 >= G
         self._exchange_now = is_boundary                 # (in-step bucket exchange: only the boundary micro-batch communicates)
         self._first_micro = self.micro_in_cycle == 0          # (zeroed just above)
+        self._external_sync = grad_sync is not None
         try:
             out = self.forward_backward(batch, loss_scale=self.dp_loss_scale / div, adaptive=True, expanded_len=expanded_len)
         finally:
             self._first_micro = False
+            self._external_sync = False
         self._exchange_now = True
         self.micro_in_cycle += 1
         if is_boundary:
             if grad_sync is not None:
                 grad_sync(self.arena.g)              # data parallel: SUM over ranks (dp.GradSync)
-            self.optimizer_step(canonical_mel_length(self.global_mel_length, batch["mel_specs"].shape[1]))
+            self.optimizer_step(canonical_mel_length(self.global_mel_length, batch["mel_specs"].shape[1]),
+                                self._ss_ready if grad_sync is None else None)
+            self._ss_ready = None
             self.micro_in_cycle = 0
         return out["losses"]
 
@@ -1875,7 +1937,11 @@ class KokoroEngine:
         self._exchange_now = is_boundary
         if ent is None:                               # first sight of a shape: eager (allocates the workspaces and the
             static = {k: v.clone() for k, v in batch.items()}      # reduction tables — host-to-device copies, illegal in a capture)
-            self._fb(static, scale, True, True, first, expanded_len)
+            self._external_sync = grad_sync is not None
+            try:
+                self._fb(static, scale, True, True, first, expanded_len)
+            finally:
+                self._external_sync = False
             self._exchange_now = True
             # (registered only now: growing a buffer during the eager pass drops every graph entry)
             if len(self._graphs) >= self.max_graphs:
@@ -1886,7 +1952,8 @@ class KokoroEngine:
             if is_boundary:
                 if grad_sync is not None:
                     grad_sync(self.arena.g)
-                self.optimizer_step(mel_length)
+                self.optimizer_step(mel_length, self._ss_ready if grad_sync is None else None)
+                self._ss_ready = None
                 self.micro_in_cycle = 0
             return self.losses
         self._graphs.move_to_end(key)
@@ -1906,14 +1973,21 @@ class KokoroEngine:
         # graph captured under one value must not be replayed under another: ADVICE r3; the CANONICAL value, so that a ragged
         # data-parallel run replays one capture per local shape for every global length up to 1400: canonical_mel_length)
         fkey = (div, first, self.train_dropout, self.spec_augment_active, self.math, self.dp_comm is not None and is_boundary,
-                mel_length if self.loss_sync is not None else 0, self.loss_sync is not None, self.self_cleaning_acc, self.attn_keep_gen)
+                mel_length if self.loss_sync is not None else 0, self.loss_sync is not None, self.self_cleaning_acc, self.attn_keep_gen,
+                self.grad_norm_from_wgrads and grad_sync is None)
         with self._acc_guard():                        # (a replayed graph assumes the accumulators' zero state like an eager step)
-            fb = ent["fb"].get(fkey)
-            if fb is None:
+            fbe = ent["fb"].get(fkey)
+            if fbe is None:
                 with self.capture_lock:
-                    fb = ent["fb"][fkey] = self._capture_fb(static, scale, first, expanded_len)
+                    self._external_sync = grad_sync is not None
+                    try:
+                        g_ = self._capture_fb(static, scale, first, expanded_len)
+                    finally:
+                        self._external_sync = False
+                    fbe = ent["fb"][fkey] = (g_, self._ss_ready)      # (the tile-norm records this launch sequence leaves: the same at every replay)
             self._exchange_now = True
-            fb.replay()
+            fbe[0].replay()
+            self._ss_ready = fbe[1]
         self.micro_in_cycle += 1
         if grad_sync is not None and is_boundary:
             grad_sync(self.arena.g)
@@ -1921,7 +1995,11 @@ class KokoroEngine:
             # (KkOptCfg travels by value: the legacy schedule's factor changes once per epoch -> one re-capture per epoch; the graphs of
             #  earlier epochs are dropped then — they can never be replayed again and would otherwise pile up, epochs x shapes: ADVICE r5)
             epoch = 0 if self.hp.use_onecycle_lr else self.lr_epoch
-            okey = (mel_length, epoch, self.self_cleaning_acc)
+            tn = self._ss_ready if grad_sync is None else None
+            self._ss_ready = None
+            if tn is not None and tn[0] not in self._ss_masks:       # (its skip table is built by an eager boundary only: no copies under capture)
+                tn = None
+            okey = (mel_length, epoch, self.self_cleaning_acc, tn)
             for k in [k for k in ent["opt"] if k[1] != epoch]:
                 torch.cuda.synchronize(self.device)   # (a graph about to be destroyed may still be running)
                 del ent["opt"][k]
@@ -1932,7 +2010,7 @@ class KokoroEngine:
                         torch.cuda.synchronize()
                         opt = ent["opt"][okey] = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(opt, capture_error_mode="thread_local"):
-                            self.optimizer_step(mel_length)
+                            self.optimizer_step(mel_length, tn)
                 opt.replay()
             self.micro_in_cycle = 0
         return self.losses

@@ -158,7 +158,7 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_gemm_linear_glu": [_L, _L, _L, _P, _L, _P, _P, _P, _P, _L, _P, _U, _F, _P],
     "kk_gemm_dgrad_glu": [_L, _L, _L, _P, _L, _P, _P, _P, _P, _P, _U, _F, _P],
     "kk_gemm_dgrad_glu_blocks": [_L],
-    "kk_gemm_wgrad_group": [_P, _I, _I, _I, _P],
+    "kk_gemm_wgrad_group": [_P, _I, _I, _I, _P, _P, _P, _P],
     "kk_colsum_acc": [_P, _L, _L, _L, _P, _I, _P],
     "kk_attn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P],
     "kk_attn_fwd_kb": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _F, _P, _U, _F, _I, _I, _P, _P],
@@ -230,7 +230,7 @@ SIGNATURES: Dict[str, List[Any]] = {
     "kk_chain_begin": [_P],
     "kk_chain_launch": [_I, _P, _P, _I, _P],
     "kk_chain_abort": [_P],
-    "kk_seg_sumsq": [_P, _P, _L, _P, _I, _P, _P],
+    "kk_seg_sumsq": [_P, _P, _L, _P, _I, _P, _P, _I, _P],
     "kk_opt_prepare": [_P, _P, _P, _P, _I, _P, C.POINTER(KkOptCfg), _P, _P, _P, _P, _P, _P, _P, _P],
     "kk_adamw_ema": [_P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _F, _F, _F, _P, _I, _P, _I, _P],
     "kk_weight_norm_project": [_P, _P, _L, _P, _P, _P, _D, _P, _P],
@@ -306,6 +306,10 @@ def load() -> C.CDLL:
     lib.kk_attn_warm_next.restype = C.c_int
     lib.kk_seg_sumsq_ws_bytes.argtypes = [_L]
     lib.kk_seg_sumsq_ws_bytes.restype = C.c_int64
+    lib.kk_seg_sumsq_rec_offset.argtypes = []
+    lib.kk_seg_sumsq_rec_offset.restype = C.c_int64
+    lib.kk_seg_sumsq_rec_capacity.argtypes = []
+    lib.kk_seg_sumsq_rec_capacity.restype = C.c_int
     if lib.kk_abi_version() != ABI_VERSION:
         raise RuntimeError(f"{LIB_PATH}: ABI version {lib.kk_abi_version()}, this package binds version {ABI_VERSION} "
                            "(stale library: run `python -m kokoro_ruslan_amd.build --force`)")

@@ -45,7 +45,10 @@ def test_python_binding_matches_header_arity(libpath):
     for name, args in kk.SIGNATURES.items():
         assert name in decls, f"binding for undeclared function {name}"
         assert len(args) == decls[name], f"{name}: binding has {len(args)} args, header {decls[name]}"
-    missing = set(decls) - set(kk.SIGNATURES) - {"kk_abi_version", "kk_last_error", "kk_last_kernel"}
+    # (entry points without a stream argument are bound by hand in lib.load())
+    missing = set(decls) - set(kk.SIGNATURES) - {"kk_abi_version", "kk_last_error", "kk_last_kernel", "kk_seg_sumsq_rec_capacity", "kk_attn_warm_next"}
+    lib = kk.load()
+    assert lib.kk_seg_sumsq_rec_capacity() >= 2048 and lib.kk_seg_sumsq_rec_offset() > 0
     assert not missing, f"header functions without a Python binding: {missing}"
     kk.load()
 

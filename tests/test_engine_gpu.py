@@ -927,7 +927,7 @@ def test_in_graph_bucket_exchange_over_rccl_one_rank(eng_mod, golden_dir):
         torch.cuda.synchronize()
         assert e.opt_stats()["attempt"] == 4 and e.opt_stats()["skipped"] == 0
         if graphed:
-            assert len(e._graphs) == 1 and any(k[-1] for ent in e._graphs.values() for k in ent["fb"]), "the ragged step must replay from a graph"
+            assert len(e._graphs) == 1 and any(k[7] for ent in e._graphs.values() for k in ent["fb"]), "the ragged step must replay from a graph (key field 7: a loss exchange is captured)"
         return e.arena.p.clone()
     got_e, got_g = run_ragged(False), run_ragged(True)
     assert float((got_e - ref1).abs().max()) <= 2e-5 * float(ref1.abs().max())
@@ -1188,3 +1188,55 @@ def test_accumulators_survive_an_aborted_step(eng_mod, golden_dir):
     torch.testing.assert_close(e.losses, want_l2, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(e2.losses, want_l2, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(e2.arena.p, want_p2, rtol=0, atol=6e-6)
+
+
+def test_gradient_norms_from_the_weight_gradient_epilogues(eng_mod):
+    """Round 6 (one GPU): the per-segment norms of the weight matrices come from the grouped weight-gradient launches' tile records and the
+    optimizer's norm pass skips those tensors.  (1) Every per-segment sum of squares equals the full pass over the arena to fp64 rounding of
+    fp32 partials, and most of the arena is covered; (2) steps with the switch on and off are the same steps; (3) gradient accumulation: the
+    records of the boundary micro-batch describe the ACCUMULATED gradient; (4) a caller that hands its own gradients to optimizer_step gets
+    the full pass."""
+    from kokoro_ruslan_amd import lib as kk
+    from kokoro_ruslan_amd.synthetic import synthetic_batch
+    d = O.ModelDims()
+    P = O.init_params(d, 0)
+    b = _cuda(synthetic_batch(8, 512, 64, seed=5))
+    e = _engine(eng_mod, d, P, math_mode="bf16", gradient_accumulation_steps=1)
+    e.train_dropout = True
+    e.zero_grad()
+    e.forward_backward(b)
+    ready = e._ss_ready
+    assert ready is not None and ready[1] > 0
+    a = e.arena
+    covered_elems = sum(int(np.prod(a.shapes[a.names[s]])) for s in ready[0])
+    assert covered_elems > 0.8 * sum(int(np.prod(a.shapes[n])) for n in a.param_names), "the weight matrices are most of the arena"
+    full = torch.zeros(a.nseg, dtype=torch.float64, device="cuda")
+    kk.call("kk_seg_sumsq", a.g, a.block_seg, a.nblocks, full, a.nseg, torch.empty_like(e.sumsq_ws), None, 0)
+    skip = torch.zeros(a.nseg, dtype=torch.int32)
+    skip[sorted(ready[0])] = 1
+    fused = torch.full((a.nseg,), float("nan"), dtype=torch.float64, device="cuda")
+    kk.call("kk_seg_sumsq", a.g, a.block_seg, a.nblocks, fused, a.nseg, e.sumsq_ws, skip.cuda(), ready[1])
+    torch.cuda.synchronize()
+    rel = ((fused - full).abs() / full.clamp(min=1e-30)).max()
+    assert bool(torch.isfinite(fused).all()) and float(rel) < 1e-6, float(rel)
+    # (2) + (3): trajectories with and without, G = 1 and G = 2
+    for G in (1, 2):
+        outs = []
+        for on in (True, False):
+            e2 = _engine(eng_mod, d, P, math_mode="bf16", gradient_accumulation_steps=G)
+            e2.train_dropout = True
+            e2.grad_norm_from_wgrads = on
+            for it in range(4):
+                e2.train_step_graphed(b)
+            torch.cuda.synchronize()
+            st = e2.opt_stats()
+            assert st["skipped"] == 0
+            outs.append((e2.arena.p.clone(), st["last_grad_norm"], e2.losses.clone()))
+        assert abs(outs[0][1] / outs[1][1] - 1.0) < 1e-5, (G, outs[0][1], outs[1][1])
+        assert float((outs[0][0] - outs[1][0]).abs().max()) <= 5e-5 * float(outs[1][0].abs().max())
+    # (4) gradients from outside: the full pass, whatever records an earlier micro-batch left
+    e.arena.g.mul_(3.0)
+    e.optimizer_step(1400)
+    torch.cuda.synchronize()
+    want = float((e.arena.g.double() ** 2).sum().sqrt())
+    assert abs(e.opt_stats()["last_grad_norm"] / want - 1.0) < 0.05      # (pre-clip shrinks some segments; the records would have been 3x off)

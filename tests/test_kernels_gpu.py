@@ -742,7 +742,7 @@ def test_optimizer_accumulators_handed_round_zero(kk):
     ws = torch.empty(kk.load().kk_seg_sumsq_ws_bytes(nblocks), dtype=torch.uint8, device="cuda")
     ws.fill_(0xAB)                                                        # (the record workspace needs no initial state)
     ss = torch.full((nseg,), 7.0, dtype=torch.float64, device="cuda")
-    kk.call("kk_seg_sumsq", grad, seg_of, nblocks, ss, nseg, ws)          # every segment is STORED: garbage in the output is harmless
+    kk.call("kk_seg_sumsq", grad, seg_of, nblocks, ss, nseg, ws, None, 0)          # every segment is STORED: garbage in the output is harmless
     close(ss, ref, 1e-6, 1e-9, "seg_sumsq (stores every segment, no zero-fill)")
     # round 6: a pure function of the buffer — no atomics, the partials merged in arena order by a fixed tree.
     # A big arena (every workgroup of the launch busy, segments of 1 block up to thousands, boundaries at every position inside a
@@ -760,7 +760,7 @@ def test_optimizer_accumulators_handed_round_zero(kk):
     for i in range(30):
         o = torch.full((ns2,), float("nan"), dtype=torch.float64, device="cuda")
         ws2.random_(0, 255)
-        kk.call("kk_seg_sumsq", big, seg2, nb2, o, ns2, ws2)
+        kk.call("kk_seg_sumsq", big, seg2, nb2, o, ns2, ws2, None, 0)
         outs.append(o)
     for o in outs[1:]:
         assert torch.equal(o, outs[0]), "kk_seg_sumsq must give the same bits on every call (order-deterministic reduction)"
@@ -769,7 +769,7 @@ def test_optimizer_accumulators_handed_round_zero(kk):
     bad = big.clone()
     bad[(sum(lens[:6]) + 700) * BLK + 5] = float("inf")
     o = torch.zeros(ns2, dtype=torch.float64, device="cuda")
-    kk.call("kk_seg_sumsq", bad, seg2, nb2, o, ns2, ws2)
+    kk.call("kk_seg_sumsq", bad, seg2, nb2, o, ns2, ws2, None, 0)
     fin = torch.isfinite(o)
     assert int((~fin).sum()) == 1 and not bool(fin[6]) and torch.equal(o[fin], outs[0][fin])
     f = lambda v: torch.full((nseg,), v, device="cuda")
@@ -1427,7 +1427,7 @@ def test_gemm_wgrad_group(kk, T, shapes, split):
         kk.call("kk_gemm", 1, 1, dy.shape[1], x.shape[1], T, 1.0, dy, dy.stride(0), x, x.stride(0), 1.0, r, x.shape[1], None, None,
                 0, 0, 1, 1, 3)
         ref.append(r)
-    kk.call("kk_gemm_wgrad_group", kk.wgrad_table(probs), len(probs), split, 0)
+    kk.call("kk_gemm_wgrad_group", kk.wgrad_table(probs), len(probs), split, 0, None, None, None)
     torch.cuda.synchronize()
     for (dy, x, dw), r in zip(probs, ref):
         if split == 0 and sum(-(-m // 128) * -(-n // 64) for m, n in shapes) * 2 > 384:      # (no k-slices: the grouped launch's 128x64 tiles fill the chip)
@@ -1435,7 +1435,7 @@ def test_gemm_wgrad_group(kk, T, shapes, split):
         else:
             close(dw, r, 2e-3 * math.sqrt(T / 256), 1e-4, "grouped weight gradient (k-sliced)")
     with pytest.raises(RuntimeError):
-        kk.call("kk_gemm_wgrad_group", kk.wgrad_table(probs * 9), len(probs) * 9, 0, 0)
+        kk.call("kk_gemm_wgrad_group", kk.wgrad_table(probs * 9), len(probs) * 9, 0, 0, None, None, None)
     # overwrite (the first micro-batch of an accumulation cycle): dw = product whatever dw held, never k-sliced
     fresh = []
     for dy, x, dw in probs:
@@ -1444,11 +1444,11 @@ def test_gemm_wgrad_group(kk, T, shapes, split):
                 0, 0, 1, 1, 3)
         fresh.append(r)
         dw.fill_(float("nan"))
-    kk.call("kk_gemm_wgrad_group", kk.wgrad_table(probs), len(probs), 0, 1)
+    kk.call("kk_gemm_wgrad_group", kk.wgrad_table(probs), len(probs), 0, 1, None, None, None)
     for (dy, x, dw), r in zip(probs, fresh):
         close(dw, r, 2e-3 * math.sqrt(T / 256), 1e-4, "grouped weight gradient, overwrite")
     with pytest.raises(RuntimeError):
-        kk.call("kk_gemm_wgrad_group", kk.wgrad_table(probs), len(probs), 2, 1)
+        kk.call("kk_gemm_wgrad_group", kk.wgrad_table(probs), len(probs), 2, 1, None, None, None)
 
 
 @pytest.mark.gpu

@@ -122,7 +122,7 @@ def group(shapes):
         probs = [(rnd(T, M), rnd(T, N), torch.zeros(M, N, device=dev)) for M, N in shapes]
         tab = kk.wgrad_table(probs)
         keep.append((probs, tab))
-        return lambda: kk.call("kk_gemm_wgrad_group", tab, len(probs), 0, 1)
+        return lambda: kk.call("kk_gemm_wgrad_group", tab, len(probs), 0, 1, None, None, None)
     return make
 
 

@@ -59,7 +59,7 @@ for label, shapes in [("enc layer", [(512, 2048), (4096, 512), (512, 512), (1536
         kk.gemm_tune16(1, 4096, 4096, stages * 10000 + 384)
         for split in (1, 2, 101, 102, 201, 202):
             kk.gemm_tune_group(split)
-            t = timeit(lambda: kk.call("kk_gemm_wgrad_group", table, len(probs), 0, 0))
+            t = timeit(lambda: kk.call("kk_gemm_wgrad_group", table, len(probs), 0, 0, None, None, None))
             out.append(f"NS {stages} split {split}: {t:6.1f}us {fl / t / 1e6:4.0f}TF")
     kk.gemm_tune_group(0)
     print("group", label, " | ".join(out))
