@@ -1133,10 +1133,10 @@ __device__ __forceinline__ void attn_fwd3_body(const AttnArgs &a, int chain_bx =
         flush_keep();
         if (t + NS - 1 < nt) issue_tile(t + NS - 1, (t + NS - 1) % NS);
         if (t == nt - 1 && a.warm_bytes[0] != 0u) {            // (no DMA is issued after this point: only the final vmcnt(0) waits for these)
-            const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y, ngrp = (gridDim.x * gridDim.y) >> 3, j = lin >> 3;
+            const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y, ngrp = max((gridDim.x * gridDim.y) >> 3, 1u), j = lin >> 3;    // (a launch of fewer than 8 workgroups: one group)
 #pragma unroll
             for (int w = 0; w < 2; ++w) {
-                const uint32_t lines = a.warm_bytes[w] >> 7, per = (lines + ngrp - 1) / (ngrp ? ngrp : 1);
+                const uint32_t lines = a.warm_bytes[w] >> 7, per = (lines + ngrp - 1) / ngrp;                 // (lines == 0: per == 0, no trip)
                 for (uint32_t i = wave8 * 64 + lane; i < per; i += 512) {
                     const uint32_t line = j * per + i;
                     if (line < lines) {

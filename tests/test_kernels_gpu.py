@@ -1351,6 +1351,33 @@ def test_attention_dq_computes_delta_in_kernel(kk):
     close(dq_new, dq_ref, 1e-3, 1e-3, "dQ with in-kernel delta")
 
 
+@pytest.mark.parametrize("B,h,S", [(1, 2, 48), (1, 1, 200), (2, 4, 256)])
+def test_weight_warming_on_launches_of_a_few_workgroups(kk, B, h, S):
+    """kk_attn_warm_next with ONE matrix (the second slot empty) on launches of fewer than 8 workgroups: the forward and the dQ
+    half terminate and their outputs are those of the launches without warming (the warming loads are never read)."""
+    g = torch.Generator().manual_seed(S)
+    H = h * 64
+    q, k, v, do = (dev(torch.randn(B * S, H, generator=g)).bfloat16() for _ in range(4))
+    W = dev(torch.randn(H, H, generator=g)).bfloat16()
+    lib = kk.load()
+    out = []
+    for warm in (False, True, True):
+        o, lse = torch.empty(B * S, H, device="cuda", dtype=torch.bfloat16), torch.empty(B, h, S, device="cuda")
+        if warm:
+            lib.kk_attn_warm_next(W.data_ptr(), W.numel() * 2, None, 0)
+        kk.call("kk_attn_fwd", q, k, v, o, lse, B, h, S, S, H, H, H, H, None, 1, 0.125, None, 0, 0.0, 1, 1)
+        dl = torch.empty(B, h, S, device="cuda")
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        if warm:
+            lib.kk_attn_warm_next(None, 0, W.data_ptr(), W.numel() * 2)     # (a lone second slot moves to the first)
+        kk.call("kk_attn_delta", o, do, dl, B, h, S, H, H, 1)
+        kk.call("kk_attn_bwd", q, k, v, do, lse, dl, dq, dk, dv, B, h, S, S, H, H, H, H, H, H, H, None, 1, 0.125, None, 0, 0.0, 1, 1, None, None)
+        torch.cuda.synchronize()
+        out.append((o, lse, dq, dk, dv))
+    for t0, t1, t2 in zip(*out):
+        assert torch.equal(t0, t1) and torch.equal(t0, t2)
+
+
 @pytest.mark.parametrize("T,F,H,p", [(200, 96, 128, 0.0), (1000, 1536, 512, 0.2), (77, 192, 64, 0.1), (4096, 1536, 512, 0.2), (4000, 1000, 256, 0.1)])
 def test_gemm_dgrad_glu_epilogue(kk, T, F, H, p):
     """kk_gemm_dgrad_glu == kk_gemm (dgrad) -> kk_glu_bwd -> kk_colsum_acc, up to the bf16 rounding of the intermediate dG
