@@ -986,6 +986,34 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(AttnArgs a) {
     stamp(61);
 }
 
+#ifdef KK_TUNING_HOOKS
+// Probe bit 4096 (tools): every workgroup of a launch leaves (first wave's entry, last wave's exit) in 10 ns ticks of the constant clock
+// and its hardware id at stamp-buffer word 512 + 4 * linear workgroup index — the launch's dispatch ramp, the spread of workgroup
+// durations and its tail, next to the rocprofv3 duration (tools/probes/attn_grid_timeline.py).
+struct KkWgStamp {
+    const AttnArgs &a;
+    __device__ unsigned long long *slot() const {
+        return reinterpret_cast<unsigned long long *>(a.DeltaOut) + 512 + 4 * (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+    }
+    __device__ bool on() const { return KK_DBG(a, 4096) && a.DeltaOut != nullptr && (threadIdx.x & 63) == 0; }
+    __device__ explicit KkWgStamp(const AttnArgs &a_) : a(a_) {
+        if (on()) {
+            atomicMin(slot(), (unsigned long long)__builtin_amdgcn_s_memrealtime());
+            if (threadIdx.x == 0) slot()[2] = (unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32 | __builtin_amdgcn_s_getreg((31 << 11) | 4);   // XCC_ID | HW_ID
+        }
+    }
+    __device__ ~KkWgStamp() {
+        if (on()) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            atomicMax(slot() + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+        }
+    }
+};
+#define KK_WG_STAMP(args) KkWgStamp wg_stamp_(args)
+#else
+#define KK_WG_STAMP(args)
+#endif
+
 // ------------------------------------------------------------------ forward, third generation (bf16 storage): two workgroups per CU
 // What the stamps of attn_fwd2 said (tools/probes/attn_trace.py): the loop is VALU-bound — a wave64 VALU instruction occupies its
 // SIMD for 4 clocks, ~250 of them per 32 x 32 score unit against 8 MFMAs — and its two waves per SIMD, phase-locked by the per-tile
@@ -1299,10 +1327,10 @@ __device__ __forceinline__ void attn_fwd3_body(const AttnArgs &a, int chain_bx =
 #else
 // (plain kernels around the template body: hipcc's host pass did not emit the stub of the kernel TEMPLATE named in kk_attn_fwd, and
 // rejected its explicit instantiation — the same host-pass trouble as g16x_group_kernel in kk_gemm16x.hip)
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd3_q128_kernel(AttnArgs a) { attn_fwd3_body<4, 2, 3>(a); }
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd3_q64_kernel(AttnArgs a) { attn_fwd3_body<2, 4, 2>(a); }
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd3_q128r_kernel(AttnArgs a) { attn_fwd3_body<4, 2, 3, false, true>(a); }
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd3_q64r_kernel(AttnArgs a) { attn_fwd3_body<2, 4, 2, false, true>(a); }
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd3_q128_kernel(AttnArgs a) { KK_WG_STAMP(a); attn_fwd3_body<4, 2, 3>(a); }
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd3_q64_kernel(AttnArgs a) { KK_WG_STAMP(a); attn_fwd3_body<2, 4, 2>(a); }
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd3_q128r_kernel(AttnArgs a) { KK_WG_STAMP(a); attn_fwd3_body<4, 2, 3, false, true>(a); }
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd3_q64r_kernel(AttnArgs a) { KK_WG_STAMP(a); attn_fwd3_body<2, 4, 2, false, true>(a); }
 
 // ------------------------------------------------------------------ keep-bit generator (kk_attn_keep_gen)
 // The dropout keep decisions of up to 16 attention launches as ONE pure-vector launch (no LDS): per 32 x 32 unit the 512 hashes the
@@ -1624,6 +1652,83 @@ __device__ __forceinline__ HnGain hn_load_gain(const float *gain, int half) {
         for (int g = 0; g < 4; ++g) r.g4[db * 4 + g] = ld4(gain + db * 32 + 8 * g + 4 * half);
     return r;
 }
+// (round 6: written on PAIRS — v_pk_mul_f32 / v_pk_fma_f32 on adjacent accumulator elements, one v_cvt_pk_bf16_f32 per two values, the
+//  row mask on the packed word.  The compiler's own version of the scalar source was 737 vector instructions per call, a third of them
+//  v_mov / v_cndmask to marshal pairs it had picked across the two halves of a row; these launches are bound by instruction issue —
+//  profiles/r06_attn_pair_balance.txt — so the epilogues cost what they count.  Sums are taken pairwise: (even elements) + (odd elements).)
+#ifndef KK_HN_CORE_V1
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_ kk_unpack_bf16x2(uint32_t w) { return f32x2_{__uint_as_float(w << 16), __uint_as_float(w & 0xFFFF0000u)}; }
+__device__ __forceinline__ void hn_bwd_row2_core(const f32x16 (&acc)[2], float mul, bool valid, const char *rawimg, const char *cosimg,
+                                                 const char *sinimg, int row, bool rope, const HnGain &gn, int half, float (&cr)[32],
+                                                 f32x16 (&out)[2]) {
+    f32x2_ dn[16], v[16];                  // pair 8 db + 2 g + e2 = elements 4 g + 2 e2, + 1 of accumulator block db
+    asm volatile("" : "+v"(row));          // (or the image addresses below are computed in the prologue and spilled across the main loop)
+    const int swz = (row >> 1) & 7;
+    const uint32_t vm = valid ? 0xFFFFFFFFu : 0u;
+    const f32x2_ mul2 = {mul, mul};
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const kk_u32x2 w = *reinterpret_cast<const kk_u32x2 *>(rawimg + row * 128 + (((4 * db + g) ^ swz) * 16) + half * 8);
+#pragma unroll
+            for (int e2 = 0; e2 < 2; ++e2) {
+                v[db * 8 + 2 * g + e2] = kk_unpack_bf16x2(w[e2]);
+                const f32x2_ a2 = f32x2_{acc[db][4 * g + 2 * e2], acc[db][4 * g + 2 * e2 + 1]} * mul2;
+                const uint32_t pk = __builtin_bit_cast(uint32_t, __builtin_convertvector(a2, bf16x2_)) & vm;      // the bf16 the consumer of this gradient sees
+                dn[db * 8 + 2 * g + e2] = kk_unpack_bf16x2(pk);
+            }
+        }
+    f32x2_ sq2 = v[0] * v[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) sq2 = __builtin_elementwise_fma(v[i], v[i], sq2);
+    const float ssq = xor32_sum(sq2[0] + sq2[1]);
+    const float rs = 1.f / sqrtf(ssq * (1.f / 64.f) + 1.1920928955078125e-7f);
+    if (rope) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4_ c4 = *reinterpret_cast<const f32x4_ *>(cosimg + row * 128 + (((2 * g + half) ^ swz) * 16));
+            const f32x4_ s4 = *reinterpret_cast<const f32x4_ *>(sinimg + row * 128 + (((2 * g + half) ^ swz) * 16));
+#pragma unroll
+            for (int e2 = 0; e2 < 2; ++e2) {
+                const f32x2_ cc = {c4[2 * e2], c4[2 * e2 + 1]}, ss = {s4[2 * e2], s4[2 * e2 + 1]};
+                const f32x2_ lo = dn[2 * g + e2], hi = dn[8 + 2 * g + e2];
+                dn[2 * g + e2] = __builtin_elementwise_fma(lo, cc, hi * ss);
+                dn[8 + 2 * g + e2] = __builtin_elementwise_fma(hi, cc, -(lo * ss));
+            }
+        }
+    }
+    const f32x2_ rs2 = {rs, rs};
+    f32x2_ kd2 = {0.f, 0.f};
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 g4 = gn.g4[db * 4 + g];
+            const f32x2_ gg[2] = {{g4.x, g4.y}, {g4.z, g4.w}};
+#pragma unroll
+            for (int e2 = 0; e2 < 2; ++e2) {
+                const int i = db * 8 + 2 * g + e2;
+                const f32x2_ c2 = (dn[i] * v[i]) * rs2;
+                cr[2 * i] = c2[0];
+                cr[2 * i + 1] = c2[1];
+                dn[i] *= gg[e2];
+                kd2 = __builtin_elementwise_fma(dn[i], v[i], kd2);
+            }
+        }
+    const float kdot = xor32_sum(kd2[0] + kd2[1]);
+    const float k = kdot * (1.f / 64.f) * rs * rs * rs;
+    const f32x2_ k2 = {k, k};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const f32x2_ o2 = __builtin_elementwise_fma(rs2, dn[i], -(v[i] * k2));
+        out[i >> 3][2 * (i & 7)] = o2[0];
+        out[i >> 3][2 * (i & 7) + 1] = o2[1];
+    }
+}
+#else
 __device__ __forceinline__ void hn_bwd_row2_core(const f32x16 (&acc)[2], float mul, bool valid, const char *rawimg, const char *cosimg,
                                                  const char *sinimg, int row, bool rope, const HnGain &gn, int half, float (&cr)[32],
                                                  f32x16 (&out)[2]) {
@@ -1682,6 +1787,7 @@ __device__ __forceinline__ void hn_bwd_row2_core(const f32x16 (&acc)[2], float m
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[db][r] = rs * dn[db * 16 + r] - v[db * 16 + r] * k;
 }
+#endif
 __device__ __forceinline__ void hn_colred_store(const float (&cr)[32], int half, float *colred_row) {
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -2005,6 +2111,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv3_kernel(AttnArgs a) {
 // workgroups finishes with.  Stand-alone the order makes no difference (32.5 us either way); inside the step it is -0.5 % at 8 x 512
 // and -0.6 % at 8 x 1024 (interleaved, profiles/r05_attn_bwd_dispatch_order_ab.txt).  Probe bit 2048 restores dQ first.
 __global__ __launch_bounds__(256, 2) void attn_bwd_pair3_kernel(AttnArgs a_dq, AttnArgs a_dkv) {
+    KK_WG_STAMP(a_dq);
     if ((blockIdx.z == 1) != KK_DBG(a_dq, 2048)) {
 #define a a_dq
 #include "kk_attn_bwd_dq3.inc"
@@ -2020,6 +2127,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_pair3_kernel(AttnArgs a_dq, A
 // per 32 x 32 unit less in each half.
 #define KK_KEEP_BITS 1
 __global__ __launch_bounds__(256, 2) void attn_bwd_pair3k_kernel(AttnArgs a_dq, AttnArgs a_dkv) {
+    KK_WG_STAMP(a_dq);
     if ((blockIdx.z == 1) != KK_DBG(a_dq, 2048)) {             // (dK/dV first: see attn_bwd_pair3_kernel)
 #define a a_dq
 #include "kk_attn_bwd_dq3.inc"
@@ -2327,7 +2435,7 @@ static int attn_fwd_impl(const float *Q, const float *K, const float *V, float *
     a.warm_bytes[0] = g_warm_bytes[0]; a.warm_bytes[1] = g_warm_bytes[1];
     g_warm_bytes[0] = g_warm_bytes[1] = 0u;                     // (one-shot)
 #ifdef KK_TUNING_HOOKS
-    if (a.dbg & 256) a.DeltaOut = static_cast<float *>(g_attn_trace);
+    if (a.dbg & (256 | 4096)) a.DeltaOut = static_cast<float *>(g_attn_trace);
 #endif
     if (Sq == 1 && a.seed == nullptr && !causal && Sk <= 8192 && ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 &&
         (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) == 0) {  // a decoder step of the incremental path: one (batch, head) per workgroup
@@ -2599,7 +2707,7 @@ static int attn_bwd_impl(const float *Q, const float *K, const float *V, const f
         //  order of the second generation is the faster one: 8 x 8 x 1024^2 causal 79 against 96 us)
         p.dkv.short_first = (causal && (attn_gen3() & 2) != 0 && (int64_t)kk_cdiv(Sq, 128) * B * heads <= g_attn_cus()) ? 1 : 0;
 #ifdef KK_TUNING_HOOKS
-        if (a.dbg & 256) { p.dq.DeltaOut = static_cast<float *>(g_attn_trace); p.dkv.DeltaOut = static_cast<float *>(g_attn_trace); }      // (stamp buffer: 8 rows x 64)
+        if (a.dbg & (256 | 4096)) { p.dq.DeltaOut = static_cast<float *>(g_attn_trace); p.dkv.DeltaOut = static_cast<float *>(g_attn_trace); }      // (stamp buffer: 8 rows x 64)
 #endif
         if (keep != nullptr && p_drop > 0.f && Sk > 128 && kk_attn_keep_bytes(B, heads, Sq, Sk) > 0) {      // (exactly the launches whose forward stored the bits)
             static thread_local bool raised3k = false;
