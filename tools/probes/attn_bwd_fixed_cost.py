@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from kokoro_ruslan_amd import lib as kk
 from oracle import kokoro_oracle as O
 causal = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+if os.environ.get("KK_LIBV"):
+    kk.use_library(os.environ["KK_LIBV"])       # a --variant build (A/B of a compile-time switch)
 h, H, P = 8, 512, 0.2
 bf, dev = torch.bfloat16, "cuda"
 res = {}
