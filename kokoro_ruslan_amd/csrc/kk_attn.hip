@@ -2666,6 +2666,7 @@ static int attn_bwd_impl(const float *Q, const float *K, const float *V, const f
                                   (!hn_kv[0].rope || (al16(hn_kv[0].cos_t) && al16(hn_kv[0].sin_t))))) &&
                       (int64_t)Sk * std::max(ldk, ldv) * 2 < (1ll << 31) && (int64_t)Sq * std::max(ldq, lddo) * 2 < (1ll << 31);
     if (!pair) {
+        g_warm_bytes[0] = g_warm_bytes[1] = 0u;                 // (one-shot: a launch that cannot warm drops the request, it never waits for a later one)
         if (int rc = kk_attn_bwd_dq(Q, K, V, dO, LSE, const_cast<float *>(Delta), dQ, B, heads, Sq, Sk, ldq, ldk, ldv, lddo, lddq, key_mask,
                                     causal, scale, seed, site, p_drop, math, io_bf16, nullptr, 0, hn_q, stream))
             return rc;
