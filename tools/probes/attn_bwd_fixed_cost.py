@@ -3,7 +3,7 @@ and without the head-norm epilogues — launch time = a + b * (units per wave). 
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from kokoro_ruslan_amd import lib as kk
-from oracle import kokoro_oracle as O
+from kokoro_ruslan_amd.spec import rope_tables
 causal = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 if os.environ.get("KK_LIBV"):
     kk.use_library(os.environ["KK_LIBV"])       # a --variant build (A/B of a compile-time switch)
@@ -21,7 +21,7 @@ for S, B in ((256, 16), (512, 8), (1024, 4)):
     kk.call("kk_attn_delta", o, do, delta, B, h, S, H, H, 1)
     nb = kk.load().kk_attn_bwd_blocks(B, h, S)
     gains = [torch.ones(64, device=dev) for _ in range(3)]
-    c, s = (t.cuda() for t in O.rope_tables(S, 64))
+    c, s = (t.cuda() for t in rope_tables(S, 64))
     pq, pkv = torch.zeros(1, nb, 64, device=dev), torch.zeros(2, nb, 64, device=dev)
     hq = kk.attn_headnorm([(raw_q, gains[0], pq[0], c, s)])
     hkv = kk.attn_headnorm([(raw_kv, gains[1], pkv[0], c, s), (raw_kv[:, H:], gains[2], pkv[1], None, None)])

@@ -5,7 +5,7 @@ import os, sys, ctypes, torch
 os.environ["KK_ATTN_DBG"] = "4096"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from kokoro_ruslan_amd import lib as kk
-from oracle import kokoro_oracle as O
+from kokoro_ruslan_amd.spec import rope_tables
 kk.use_library("tuning")
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 causal = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -26,7 +26,7 @@ delta = torch.empty(B, h, S, device=dev)
 kk.call("kk_attn_delta", o, do, delta, B, h, S, H, H, 1)
 nb = kk.load().kk_attn_bwd_blocks(B, h, S)
 gains = [torch.ones(64, device=dev) for _ in range(3)]
-c, s = (t.cuda() for t in O.rope_tables(S, 64))
+c, s = (t.cuda() for t in rope_tables(S, 64))
 pq, pkv = torch.zeros(1, nb, 64, device=dev), torch.zeros(2, nb, 64, device=dev)
 hq = kk.attn_headnorm([(raw_q, gains[0], pq[0], c, s)])
 hkv = kk.attn_headnorm([(raw_kv, gains[1], pkv[0], c, s), (raw_kv[:, H:], gains[2], pkv[1], None, None)])
