@@ -234,6 +234,11 @@ class KokoroEngine:
         # from ONE pure-vector launch beside the encoder forward (kk_attn_keep_gen, on the decoder-head stream) and the forward READS
         # them too (kk_attn_fwd_rb): -3 us per forward launch at 512 frames, -6.4 ... -8.6 us at 1024 (round 6; same bits either way)
         self.attn_keep_gen = True
+        # How many decoder layers' bits the generator writes: what fits beside the persistent encoder.  The generator of ALL twelve launches of an
+        # 8 x 1024 step outlasts the encoder and delays the decoder head (+1.3 ... +1.6 %); three layers' worth is the measured optimum there (-0.75 %), all
+        # six at 8 x 512 (-0.4 %) — profiles/r06_keep_bits_gen_ab.txt.  Budget = attn_keep_gen_rate 32 x 32 units per microsecond of encoder time
+        # (~160 + 2 P us for P phonemes); the later layers' forwards hash and store as before (same bits either way).  0 = never generate.
+        self.attn_keep_gen_rate = 730.0
         # One GPU: the per-segment gradient norms of the weight matrices come from the epilogue of the grouped weight-gradient launches
         # (a record per tile of the FINAL values it stored) instead of from the optimizer's pass over the 199 MB gradient arena, which then
         # reads only what no such launch wrote (embeddings, biases, norms, predictors).  Data parallel keeps the full pass: the norm that
@@ -836,10 +841,10 @@ class KokoroEngine:
         n = kk.load().kk_attn_keep_bytes(B, self.dims.heads, Sq, Sk)
         return self._buf(key + ".keep", n, dtype=torch.uint8) if n > 0 else None
 
-    def _keep_gen_launch(self, B, T, p_dec, seed_offset=0, mark_ready=True, max_wgs=0) -> bool:
+    def _keep_gen_launch(self, B, T, p_dec, seed_offset=0, mark_ready=True, max_wgs=0, layers=None) -> bool:
         """kk_attn_keep_gen for every decoder attention launch of a (B, T) step; False when that shape has no keep-bit arrays."""
         d, ents = self.dims, []
-        for li in range(d.dec_layers):
+        for li in range(d.dec_layers if layers is None else min(layers, d.dec_layers)):
             for sub, off, cz in ((".sa", 0, True), (".ca", 8, False)):
                 kb = self._attn_keep(f"dec{li}{sub}", B, T, T, p_dec, 1)
                 if kb is not None:
@@ -1247,7 +1252,7 @@ class KokoroEngine:
             if gen_keep:
                 # the keep bits of every decoder attention launch of this step, HERE: this stream idles until the persistent encoder
                 # launch (which holds every CU's LDS) has ended, and the generator needs no LDS — it runs beside the encoder
-                self._keep_gen_launch(B, T, p_dec, 0, True)
+                self._keep_gen_launch(B, T, p_dec, 0, True, layers=gen_layers)
                 self._mark("kv: keep bits generated")
             ya0, n20 = self_attn(0, y0, n10)
             return y0, ya0, n20
@@ -1267,7 +1272,12 @@ class KokoroEngine:
         # beside the persistent encoder forward, where that pays (measured: -0.4 % at 8 x 512, +1.6 % at 8 x 1024, where the generator
         # outlasts the encoder and delays the decoder head; profiles/r06_keep_bits_gen_ab.txt)
         gen_keep = bool(self.attn_keep_gen and self.attn_keep_bits and self.train_dropout and p_dec > 0.0 and ddt == torch.bfloat16 and
-                        self.overlap and stack and self.dec_head_aside and Nd <= 4096)
+                        self.overlap and stack and self.dec_head_aside)
+        gen_layers = 0
+        if gen_keep:
+            units = B * self.dims.heads * ((T + 31) // 32) ** 2 * 1.5          # a layer: the causal self-attention (half) + the cross-attention
+            gen_layers = min(self.dims.dec_layers, int(self.attn_keep_gen_rate * (160.0 + 2.0 * Pn) / units))
+            gen_keep = gen_layers > 0
         with self._on_stream(self._kv, "kv.", self.dec_head_aside):     # beside the encoder; joined before the first cross-attention
             if zero_grads and not self.zero_late:
                 self._zero_grad_step()
@@ -1973,7 +1983,7 @@ class KokoroEngine:
         # graph captured under one value must not be replayed under another: ADVICE r3; the CANONICAL value, so that a ragged
         # data-parallel run replays one capture per local shape for every global length up to 1400: canonical_mel_length)
         fkey = (div, first, self.train_dropout, self.spec_augment_active, self.math, self.dp_comm is not None and is_boundary,
-                mel_length if self.loss_sync is not None else 0, self.loss_sync is not None, self.self_cleaning_acc, self.attn_keep_gen,
+                mel_length if self.loss_sync is not None else 0, self.loss_sync is not None, self.self_cleaning_acc, (self.attn_keep_gen, self.attn_keep_gen_rate),
                 self.grad_norm_from_wgrads and grad_sync is None)
         with self._acc_guard():                        # (a replayed graph assumes the accumulators' zero state like an eager step)
             fbe = ent["fb"].get(fkey)

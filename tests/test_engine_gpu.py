@@ -1243,3 +1243,51 @@ def test_gradient_norms_from_the_weight_gradient_epilogues(eng_mod):
     torch.cuda.synchronize()
     want = float((e.arena.g.double() ** 2).sum().sqrt())
     assert abs(e.opt_stats()["last_grad_norm"] / want - 1.0) < 0.05      # (pre-clip shrinks some segments; the records would have been 3x off)
+
+
+@pytest.mark.parametrize("B,T,Pn,layers", [(8, 512, 64, 6), (8, 1024, 128, 3)])
+def test_keep_bits_from_their_own_launch_in_the_step(eng_mod, monkeypatch, B, T, Pn, layers):
+    """Round 6: with engine.attn_keep_gen the keep bits of the first `layers` decoder layers (what fits beside the persistent encoder: all six at 8 x 512,
+    three at 8 x 1024) come from kk_attn_keep_gen and those layers' forwards READ them; the later layers hash and store.  Same bits either way: the losses of
+    a dropout-on step are the losses of the step with the generator off, exactly, and the stored arrays are equal byte for byte."""
+    from kokoro_ruslan_amd import lib as kk
+    from kokoro_ruslan_amd.synthetic import synthetic_batch
+    d = O.ModelDims()
+    P = O.init_params(d, 0)
+    b = _cuda(synthetic_batch(B, T, Pn, seed=9))
+    out = []
+    for on in (True, False):
+        e = _engine(eng_mod, d, P, math_mode="bf16", gradient_accumulation_steps=1)
+        e.train_dropout = True
+        e.attn_keep_gen = on
+        e.zero_grad()
+        routes = []
+        real_call = kk.call
+
+        def recording_call(name, *args):
+            real_call(name, *args)
+            routes.append((name, kk.last_kernel()))
+        monkeypatch.setattr(kk, "call", recording_call)
+        losses = e.forward_backward(b)["losses"].clone()
+        monkeypatch.setattr(kk, "call", real_call)
+        torch.cuda.synchronize()
+        keeps = {k: v.clone() for k, v in e._ws.items() if k.endswith(".keep") and k.startswith("dec")}
+        assert len(keeps) == 2 * d.dec_layers
+        out.append((losses, routes, keeps))
+    (l_on, r_on, k_on), (l_off, r_off, k_off) = out
+    assert torch.equal(l_on, l_off), (l_on, l_off)
+    names_on, names_off = [n for n, _ in r_on], [n for n, _ in r_off]
+    assert names_on.count("kk_attn_keep_gen") == 1 and "kk_attn_keep_gen" not in names_off
+    assert names_on.count("kk_attn_fwd_rb") == 2 * layers, names_on.count("kk_attn_fwd_rb")
+    reading = {k for n, k in r_on if n == "kk_attn_fwd_rb"}
+    assert reading <= {"attn_fwd3_q64r", "attn_fwd3_q128r"} and reading, reading
+    assert "kk_attn_fwd_rb" not in names_off
+    nU = (T + 31) // 32
+    n = B * d.heads * nU * nU * 128
+    assert n == kk.load().kk_attn_keep_bytes(B, d.heads, T, T)
+    tril = torch.tril(torch.ones(nU, nU, dtype=torch.bool, device="cuda"))
+    for k in k_on:                                   # (units above the diagonal of a causal launch are visited by nobody: compare what is read)
+        a, c = k_on[k][:n].view(B * d.heads, nU, nU, 128), k_off[k][:n].view(B * d.heads, nU, nU, 128)
+        if k.endswith(".sa.keep"):
+            a, c = a[:, tril], c[:, tril]
+        assert torch.equal(a, c), k
