@@ -41,8 +41,8 @@ def build(force: bool = False, verbose: bool = False, tuning: bool = False, vari
     `bench.py --lib tuning` / kokoro_ruslan_amd.lib.use_library().
     variant="name", defs=["-DX=1", ...]: a tools flavour compiled with extra definitions as libkokoro_hip_<name>.so (compile-time
     A/B of a kernel change on one box: `bench.py --lib <name>`, tools/probes/ab.sh)."""
-    if variant:
-        tuning = True
+    if variant and not os.environ.get("KK_VARIANT_PRODUCT"):       # KK_VARIANT_PRODUCT=1: the PRODUCT flavour + the definitions (an A/B against the product
+        tuning = True                                               # library itself: the tools flavour is ~1 % slower in the step, so never compare across flavours)
     tag = variant or ("tuning" if tuning else "")
     obj_dir = OBJ + (f"_{tag}" if tag else "")
     lib_path = LIB.replace(".so", f"_{tag}.so") if tag else LIB

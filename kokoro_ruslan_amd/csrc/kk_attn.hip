@@ -1369,7 +1369,12 @@ __global__ __launch_bounds__(256) void attn_keep_gen_kernel(const KeepGenArgs g)
         // the forward's lane (l31 = query, half) hashes  q * sk2 + ((k0 + 4 half) >> 1) + (frag_row(r, 0) >> 1)  for r = 0, 2, ..., 14
         uint32_t x0 = (uint32_t)(qu * 32) * sk2 + ((uint32_t)(ku * 32 + 4 * hbit) >> 1) + (uint32_t)kp_off;
         uint32_t lo = 0u, hi = 0u;
-#pragma unroll 8
+// (unrolled by 2: 39 registers, so that TWO waves of this kernel fit a SIMD beside the persistent encoder's two 216-register waves — 432 + 2 x 40 = 512;
+//  unrolled by 8 it held 60 and fit one: -0.2 % of the step at 8 x 512 and -0.7 % at 8 x 1024 for the same bits, profiles/r06_keep_bits_gen_ab.txt)
+#ifndef KK_KEEPGEN_UNROLL
+#define KK_KEEPGEN_UNROLL 2
+#endif
+#pragma unroll KK_KEEPGEN_UNROLL
         for (int q = 0; q < 32; ++q) {
             uint32_t x = x0 ^ key;
             x ^= x >> 16; x = __umul24(x, 0xb5352du); x ^= x >> 13; x = __umul24(x, 0xca68b5u); x ^= x >> 16;

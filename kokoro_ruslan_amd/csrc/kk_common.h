@@ -319,36 +319,7 @@ __device__ __forceinline__ float4 kk_headnorm_rope(const float4 &v, const float4
     return n;
 }
 
-// GELU and its derivative for the bf16 mode (results are rounded to bf16 anyway).  Round 6: Phi(x) = 0.5 + x Q(x^2) on |x| <= 4.3 (argument clamped
-// beyond: Phi(4.3) = 1 - 8.5e-6), Q of degree 8 fitted to the ABSOLUTE error of Phi: |error| <= 1.4e-5, i.e. <= 5.8e-5 on GELU itself, two orders below the
-// bf16 rounding of everything it multiplies.  Eleven packable multiply-adds and no transcendental for the forward value, where Abramowitz-Stegun 7.1.26
-// (rounds 2-5, |error| <= 1.5e-7, kept under KK_GELU_AS for A/B builds) cost one v_rcp_f32 + one v_exp_f32 (a quarter-rate instruction each) + ~15 others:
-// the GLU epilogues of the FFN GEMMs spend 2 x 19 % of their SIMDs' time in the vector ALU (profiles/r06_issue_shares_8x512.txt).  The derivative still needs
-// the Gaussian exp(-x^2 / 2): one v_exp_f32.  The fp32 parity mode keeps the exact forms below.
-#ifndef KK_GELU_AS
-__device__ __forceinline__ float kk_phi_fast(float x) {
-    const float xc = __builtin_amdgcn_fmed3f(x, -4.3f, 4.3f);
-    const float u = xc * xc;
-    float q = 5.161134020e-11f;
-    q = fmaf(q, u, -5.036296269e-09f);
-    q = fmaf(q, u, 2.169277309e-07f);
-    q = fmaf(q, u, -5.492205673e-06f);
-    q = fmaf(q, u, 9.223707457e-05f);
-    q = fmaf(q, u, -1.102715614e-03f);
-    q = fmaf(q, u, 9.800815023e-03f);
-    q = fmaf(q, u, -6.632710248e-02f);
-    q = fmaf(q, u, 3.988966346e-01f);
-    return fmaf(xc, q, 0.5f);
-}
-__device__ __forceinline__ void kk_gelu_pair_fast(float x, float &g, float &dg) {
-    const float phi = kk_phi_fast(x);
-    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);           // exp(-x^2 / 2)
-    g = x * phi;
-    dg = fmaf(x * e, 0.39894228040143267794f, phi);
-}
-__device__ __forceinline__ float kk_gelu_fast(float x) { return x * kk_phi_fast(x); }
-#else
-// (rounds 2-5) erf by Abramowitz-Stegun 7.1.26
+// GELU and its derivative for the bf16 mode (results are rounded to bf16 anyway): erf by Abramowitz-Stegun 7.1.26
 // (|error| <= 1.5e-7), whose exp(-z^2) with z = |x| / sqrt(2) IS the Gaussian exp(-x^2 / 2) the derivative needs — one
 // v_exp_f32, one v_rcp_f32 and ~15 other VALU operations for both values, against ~130 for erff() + expf().  In the GLU
 // epilogues of the GEMMs that arithmetic was a third of the kernel (the backward one: 2081 VALU instructions per wave
@@ -368,7 +339,9 @@ __device__ __forceinline__ float kk_gelu_fast(float x) {
     kk_gelu_pair_fast(x, g, dg);
     return g;
 }
-#endif
+// (Round 6 measured a cheaper form — Phi(x) = 0.5 + x Q(x^2), Q of degree 8, no v_rcp / v_exp in the forward, |error| <= 1.4e-5 — because the GLU epilogues
+//  spend 2 x 19 % of their SIMDs' time in the vector ALU: level in the step against THIS form built the same way (3.513 vs 3.517 ms at 8 x 512, 5.790 vs 5.790
+//  at 8 x 1024, profiles/r06_gelu_poly_ab.txt), so the more accurate form stays.)
 // exact-erf GELU (nn.GELU(), transformers.py:51) and its derivative
 __device__ __forceinline__ float kk_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float kk_gelu_grad(float x) {

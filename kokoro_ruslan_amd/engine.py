@@ -235,10 +235,11 @@ class KokoroEngine:
         # them too (kk_attn_fwd_rb): -3 us per forward launch at 512 frames, -6.4 ... -8.6 us at 1024 (round 6; same bits either way)
         self.attn_keep_gen = True
         # How many decoder layers' bits the generator writes: what fits beside the persistent encoder.  The generator of ALL twelve launches of an
-        # 8 x 1024 step outlasts the encoder and delays the decoder head (+1.3 ... +1.6 %); three layers' worth is the measured optimum there (-0.75 %), all
-        # six at 8 x 512 (-0.4 %) — profiles/r06_keep_bits_gen_ab.txt.  Budget = attn_keep_gen_rate 32 x 32 units per microsecond of encoder time
-        # (~160 + 2 P us for P phonemes); the later layers' forwards hash and store as before (same bits either way).  0 = never generate.
-        self.attn_keep_gen_rate = 730.0
+        # 8 x 1024 step outlasts the encoder and delays the decoder head; four layers' worth is the measured optimum there, all six at 8 x 512
+        # (profiles/r06_keep_bits_gen_ab.txt; the generator holds 40 registers so that TWO of its waves fit a SIMD beside the encoder's two).
+        # Budget = attn_keep_gen_rate 32 x 32 units per microsecond of encoder time (~160 + 2 P us for P phonemes); the later layers' forwards hash and
+        # store as before (same bits either way).  0 = never generate.
+        self.attn_keep_gen_rate = 1100.0
         # One GPU: the per-segment gradient norms of the weight matrices come from the epilogue of the grouped weight-gradient launches
         # (a record per tile of the FINAL values it stored) instead of from the optimizer's pass over the 199 MB gradient arena, which then
         # reads only what no such launch wrote (embeddings, biases, norms, predictors).  Data parallel keeps the full pass: the norm that

@@ -1232,10 +1232,7 @@ def test_gradient_norms_from_the_weight_gradient_epilogues(eng_mod):
             st = e2.opt_stats()
             assert st["skipped"] == 0
             outs.append((e2.arena.p.clone(), st["last_grad_norm"], e2.losses.clone()))
-        # (the two norm paths agree to ~1e-7, which can move the fp32 clip coefficient by an ulp; an ulp in a master weight flips some bf16 roundings
-        #  of the shadow weights, and four steps later the gradient norm differs at the level every bf16 trajectory of this engine is reproducible to —
-        #  the eager-vs-replay test allows 2e-3 on a loss.  1e-5 held in rounds where the coefficients happened to come out bit-identical.)
-        assert abs(outs[0][1] / outs[1][1] - 1.0) < 1e-3, (G, outs[0][1], outs[1][1])
+        assert abs(outs[0][1] / outs[1][1] - 1.0) < 1e-5, (G, outs[0][1], outs[1][1])
         assert float((outs[0][0] - outs[1][0]).abs().max()) <= 5e-5 * float(outs[1][0].abs().max())
     # (4) gradients from outside: the full pass, whatever records an earlier micro-batch left
     e.arena.g.mul_(3.0)
@@ -1245,10 +1242,10 @@ def test_gradient_norms_from_the_weight_gradient_epilogues(eng_mod):
     assert abs(e.opt_stats()["last_grad_norm"] / want - 1.0) < 0.05      # (pre-clip shrinks some segments; the records would have been 3x off)
 
 
-@pytest.mark.parametrize("B,T,Pn,layers", [(8, 512, 64, 6), (8, 1024, 128, 3)])
+@pytest.mark.parametrize("B,T,Pn,layers", [(8, 512, 64, 6), (8, 1024, 128, 4)])
 def test_keep_bits_from_their_own_launch_in_the_step(eng_mod, monkeypatch, B, T, Pn, layers):
     """Round 6: with engine.attn_keep_gen the keep bits of the first `layers` decoder layers (what fits beside the persistent encoder: all six at 8 x 512,
-    three at 8 x 1024) come from kk_attn_keep_gen and those layers' forwards READ them; the later layers hash and store.  Same bits either way: the losses of
+    four at 8 x 1024) come from kk_attn_keep_gen and those layers' forwards READ them; the later layers hash and store.  Same bits either way: the losses of
     a dropout-on step are the losses of the step with the generator off, exactly, and the stored arrays are equal byte for byte."""
     from kokoro_ruslan_amd import lib as kk
     from kokoro_ruslan_amd.synthetic import synthetic_batch

@@ -1091,13 +1091,11 @@ def test_elementwise_bf16_storage(kk):
         g32, g16 = torch.empty(rows, Fd, device="cuda"), torch.empty(rows, Fd, device="cuda", dtype=torch.bfloat16)
         kk.call("kk_glu_fwd", hh, g32, rows, Fd, seed, 5, p, 0)
         kk.call("kk_glu_fwd", hh.bfloat16(), g16, rows, Fd, seed, 5, p, 1)
-        # bf16 storage evaluates GELU by kk_gelu_pair_fast (round 6: a polynomial normal CDF, |error| <= 1.4e-5 before the rounding to bf16 — 1 / 300
-        # of a bf16 half-ulp step relative to the values it multiplies), fp32 storage by the exact erf: the rounded results differ in a last bit in
-        # under 1.5 % of the elements (0.8 % measured; 0.3 % with the Abramowitz-Stegun form of rounds 2-5), never by more than that bit (third
-        # assertion), and the dropout masks are identical
+        # bf16 storage evaluates GELU by kk_gelu_pair_fast (|error| < 5e-7 before the rounding to bf16), fp32 storage by the
+        # exact erf: the rounded results differ in a last bit now and then, and the dropout masks are identical
         def same(a16, a32, what):
             ref = a32.bfloat16()
-            assert float((a16 == ref).float().mean()) > 0.985, what
+            assert float((a16 == ref).float().mean()) > 0.995, what
             assert torch.equal(a16 == 0, ref == 0) or p == 0.0, what + ": mask"
             assert float((a16.float() - a32).abs().max()) <= 2 ** -8 * float(a32.abs().max()) + 1e-6, what
         same(g16, g32, "glu fwd: bf16 storage = rounded fp32 result")
