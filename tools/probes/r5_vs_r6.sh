@@ -1,3 +1,6 @@
+# Round 6 against round 5 on ONE box.  In the container:  git worktree add _r5 28c0d2e && (cd _r5 && python -m kokoro_ruslan_amd.build) ; then
+#   gpurun -- 'rm -rf _r5/.git; bash tools/probes/r5_vs_r6.sh'      (the worktree travels with the snapshot; remove it afterwards: rm -rf _r5; git worktree prune)
+# Each side runs ITS OWN bench.py, engine and product library; three interleaved rounds.  Result: profiles/r06_vs_r05_one_box.txt
 for r in 1 2 3; do
   for w in "r5 _r5" "r6 ."; do
     set -- $w
