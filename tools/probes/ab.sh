@@ -2,6 +2,9 @@
 # Interleaved A/B of environment switches of the TUNING library on one box:  bash tools/probes/ab.sh <out-dir> <reps> "<ENV=a ...>" "<ENV=b ...>" ...
 # SET:attr=value in a variant string sets an engine attribute (bench.py --set).
 # LIBV=<name> in a variant string selects another library flavour (a --variant build).
+# NEVER compare across flavours: the tools flavour (tuning, and every --variant build unless KK_VARIANT_PRODUCT=1 was set when it was built) is ~1.1 % (8 x 512) /
+# 0.7 % (8 x 1024) slower in the step than the product flavour of the same source (profiles/r06_attn_hn_core_ab.txt).  A compile-time change is measured either
+# as two tools-flavour variants (LIBV=tuning against LIBV=<variant>) or as two product-flavour ones (LIBV=product against a KK_VARIANT_PRODUCT=1 variant).
 # Every variant runs bench.py (--lib tuning, headline region only) <reps> times, round-robin, so box and clock drift hit all alike.
 out=$1; reps=$2; shift 2
 mkdir -p $out
